@@ -1,0 +1,70 @@
+"""ctypes binding of libsigman_gsplat.so (the C ABI declared in include/sigman_gsplat.h).
+
+The product path has NO fallback: if the HIP library is missing or a call fails, this module raises.
+PyTorch is used only as the owner of device memory and streams (data_ptr() / current stream).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libsigman_gsplat.so")
+_lib = None
+
+SGR_REC_FLOATS = 12
+SGR_TILE = 16
+
+
+class SgrProblem(C.Structure):
+    _fields_ = [
+        ("P", C.c_int32), ("n_views", C.c_int32), ("views_per_subject", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
+        ("sh_degree", C.c_int32), ("M", C.c_int32),
+        ("tanfovx", C.c_float), ("tanfovy", C.c_float), ("scale_modifier", C.c_float),
+        ("means3D", C.c_void_p), ("opacities", C.c_void_p), ("colors_precomp", C.c_void_p), ("shs", C.c_void_p),
+        ("cov3D_precomp", C.c_void_p), ("scales", C.c_void_p), ("rotations", C.c_void_p),
+        ("viewmatrix", C.c_void_p), ("projmatrix", C.c_void_p), ("campos", C.c_void_p), ("bg", C.c_void_p),
+    ]
+
+
+_SIGNATURES = {
+    "sgr_abi_version": (C.c_int, []),
+    "sgr_last_error": (C.c_char_p, []),
+    "sgr_preprocess_blocks_per_view": (C.c_int32, [C.c_int32]),
+    "sgr_preprocess_forward": (C.c_int, [C.POINTER(SgrProblem)] + [C.c_void_p] * 7),
+    "sgr_bin_workspace_bytes": (C.c_size_t, [C.c_uint64]),
+    "sgr_bin": (C.c_int, [C.POINTER(SgrProblem), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p,
+                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_int32),
+                          C.c_void_p]),
+    "sgr_render_forward": (C.c_int, [C.POINTER(SgrProblem)] + [C.c_void_p] * 9),
+    "sgr_render_backward": (C.c_int, [C.POINTER(SgrProblem)] + [C.c_void_p] * 10),
+    "sgr_preprocess_backward": (C.c_int, [C.POINTER(SgrProblem)] + [C.c_void_p] * 12),
+    "sgr_mark_visible": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+
+def lib():
+    """Load the HIP library; raise loudly (no CPU fallback) if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; "
+                "g.build()'` (or `make -C sigman_release_amd/csrc`). There is no CPU fallback for the rasterizer.")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(L, name)          # AttributeError if a declared symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        if L.sgr_abi_version() != 1:
+            raise RuntimeError(f"ABI version mismatch: library reports {L.sgr_abi_version()}, binding expects 1")
+        _lib = L
+    return _lib
+
+
+def check(status: int, what: str):
+    if status != 0:
+        msg = lib().sgr_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"{what} failed: {msg}")

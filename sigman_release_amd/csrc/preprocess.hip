@@ -1,0 +1,564 @@
+// preprocess.hip -- per-Gaussian stages of the rasterizer for gfx950:
+//   F1  cull / project / 2D covariance / conic / radius / tile rectangle   (sgr_preprocess_forward)
+//   F2  tile-count scan (block partial sums + single-block exclusive scan)
+//   B2+B3  gradient records -> parameter gradients, summed over views in a fixed order (no atomics)
+//   mark_visible
+// Replaces the per-view preprocess of the third-party rasterizer the reference calls at
+// /root/reference/core/gaussians/gs.py:98-106 (and its backward reached from train_vae.py:166).
+//
+// THIS TRANSLATION UNIT IS COMPILED WITH -ffp-contract=off.  Every expression that feeds an integer
+// artefact (depth key bits, radius, tile rectangle) is written in the canonical left-to-right fp32
+// order documented in DESIGN.md, with correctly rounded div/sqrt (hipcc default), so those artefacts
+// are bit-exact against the CPU oracle.  These kernels are HBM-streaming (~76 B read+written per
+// Gaussian per view forward, ~150 B backward); one thread per Gaussian, view index on blockIdx.y so
+// the camera matrices are wave-uniform scalar loads.
+#include "common.h"
+
+namespace {
+
+constexpr int kPreThreads = 256;
+
+
+struct Cov2D {
+    float t[3];
+    float xmul, ymul;
+    float j00, j02, j11, j12;
+    float m0[3], m1[3];
+    float v0[3], v1[3];
+    float a, b, c;
+};
+
+__device__ __forceinline__ void xform4x3(const float *m, const float *p, float *o) {
+    o[0] = ((m[0] * p[0] + m[4] * p[1]) + m[8] * p[2]) + m[12];
+    o[1] = ((m[1] * p[0] + m[5] * p[1]) + m[9] * p[2]) + m[13];
+    o[2] = ((m[2] * p[0] + m[6] * p[1]) + m[10] * p[2]) + m[14];
+}
+__device__ __forceinline__ void xform4x4(const float *m, const float *p, float *o) {
+    o[0] = ((m[0] * p[0] + m[4] * p[1]) + m[8] * p[2]) + m[12];
+    o[1] = ((m[1] * p[0] + m[5] * p[1]) + m[9] * p[2]) + m[13];
+    o[2] = ((m[2] * p[0] + m[6] * p[1]) + m[10] * p[2]) + m[14];
+    o[3] = ((m[3] * p[0] + m[7] * p[1]) + m[11] * p[2]) + m[15];
+}
+__device__ __forceinline__ float ndc2pix(float v, int S) { return (float)((((double)v + 1.0) * (double)S - 1.0) * 0.5); }
+
+__device__ __forceinline__ void quat_to_rot(const float *q, float R[3][3]) {
+    const float r = q[0], x = q[1], y = q[2], z = q[3];
+    R[0][0] = 1.f - 2.f * (y * y + z * z); R[0][1] = 2.f * (x * y - r * z); R[0][2] = 2.f * (x * z + r * y);
+    R[1][0] = 2.f * (x * y + r * z); R[1][1] = 1.f - 2.f * (x * x + z * z); R[1][2] = 2.f * (y * z - r * x);
+    R[2][0] = 2.f * (x * z - r * y); R[2][1] = 2.f * (y * z + r * x); R[2][2] = 1.f - 2.f * (x * x + y * y);
+}
+
+// Sigma = R diag(mod*s)^2 R^T, packed xx,xy,xz,yy,yz,zz
+__device__ __forceinline__ void cov3d_from_scale_rot(const float *s, float mod, const float *q, float *cov) {
+    float R[3][3];
+    quat_to_rot(q, R);
+    const float sv[3] = {mod * s[0], mod * s[1], mod * s[2]};
+    float Mx[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int k = 0; k < 3; k++) Mx[i][k] = R[i][k] * sv[k];
+    float S[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) S[i][j] = (Mx[i][0] * Mx[j][0] + Mx[i][1] * Mx[j][1]) + Mx[i][2] * Mx[j][2];
+    cov[0] = S[0][0]; cov[1] = S[0][1]; cov[2] = S[0][2];
+    cov[3] = S[1][1]; cov[4] = S[1][2]; cov[5] = S[2][2];
+}
+
+__device__ __forceinline__ void load_cov3d(const SgrProblem &pb, size_t sp /* s*P+i */, float *c6) {
+    if (pb.cov3D_precomp) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) c6[k] = pb.cov3D_precomp[sp * 6 + k];   // scale_modifier NOT applied (as upstream)
+    } else {
+        float s[3], q[4];
+#pragma unroll
+        for (int k = 0; k < 3; k++) s[k] = pb.scales[sp * 3 + k];
+#pragma unroll
+        for (int k = 0; k < 4; k++) q[k] = pb.rotations[sp * 4 + k];
+        cov3d_from_scale_rot(s, pb.scale_modifier, q, c6);
+    }
+}
+
+__device__ __forceinline__ void cov2d_eval(const float *pview, const float *V, const float *cov6, float fx, float fy,
+                                           float tanfovx, float tanfovy, Cov2D &o) {
+    const float limx = 1.3f * tanfovx, limy = 1.3f * tanfovy;
+    const float tz = pview[2];
+    const float txtz = pview[0] / tz, tytz = pview[1] / tz;
+    o.xmul = (txtz < -limx || txtz > limx) ? 0.f : 1.f;
+    o.ymul = (tytz < -limy || tytz > limy) ? 0.f : 1.f;
+    const float tx = fminf(limx, fmaxf(-limx, txtz)) * tz;
+    const float ty = fminf(limy, fmaxf(-limy, tytz)) * tz;
+    o.t[0] = tx; o.t[1] = ty; o.t[2] = tz;
+    o.j00 = fx / tz; o.j02 = -(fx * tx) / (tz * tz);
+    o.j11 = fy / tz; o.j12 = -(fy * ty) / (tz * tz);
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const float r0 = V[4 * k + 0], r1 = V[4 * k + 1], r2 = V[4 * k + 2];
+        o.m0[k] = o.j00 * r0 + o.j02 * r2;
+        o.m1[k] = o.j11 * r1 + o.j12 * r2;
+    }
+    const float S[3][3] = {{cov6[0], cov6[1], cov6[2]}, {cov6[1], cov6[3], cov6[4]}, {cov6[2], cov6[4], cov6[5]}};
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        o.v0[i] = (S[i][0] * o.m0[0] + S[i][1] * o.m0[1]) + S[i][2] * o.m0[2];
+        o.v1[i] = (S[i][0] * o.m1[0] + S[i][1] * o.m1[1]) + S[i][2] * o.m1[2];
+    }
+    o.a = ((o.m0[0] * o.v0[0] + o.m0[1] * o.v0[1]) + o.m0[2] * o.v0[2]) + 0.3f;
+    o.b = (o.m0[0] * o.v1[0] + o.m0[1] * o.v1[1]) + o.m0[2] * o.v1[2];
+    o.c = ((o.m1[0] * o.v1[0] + o.m1[1] * o.v1[1]) + o.m1[2] * o.v1[2]) + 0.3f;
+}
+
+// real SH basis (degree <= 3) and its gradient w.r.t. the unit direction
+__device__ __forceinline__ int sh_basis(int deg, const float *d, float *B) {
+    const float C0 = 0.28209479177387814f, C1 = 0.4886025119029199f;
+    const float C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f, -1.0925484305920792f, 0.5462742152960396f};
+    const float C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f, 0.3731763325901154f,
+                         -0.4570457994644658f, 1.445305721320277f, -0.5900435899266435f};
+    const float x = d[0], y = d[1], z = d[2];
+    B[0] = C0;
+    if (deg < 1) return 1;
+    B[1] = -C1 * y; B[2] = C1 * z; B[3] = -C1 * x;
+    if (deg < 2) return 4;
+    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+    B[4] = C2[0] * xy; B[5] = C2[1] * yz; B[6] = C2[2] * (2.f * zz - xx - yy);
+    B[7] = C2[3] * xz; B[8] = C2[4] * (xx - yy);
+    if (deg < 3) return 9;
+    B[9] = C3[0] * y * (3.f * xx - yy); B[10] = C3[1] * xy * z;
+    B[11] = C3[2] * y * (4.f * zz - xx - yy); B[12] = C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy);
+    B[13] = C3[4] * x * (4.f * zz - xx - yy); B[14] = C3[5] * z * (xx - yy);
+    B[15] = C3[6] * x * (xx - 3.f * yy);
+    return 16;
+}
+__device__ __forceinline__ void sh_basis_grad(int deg, const float *d, float G[16][3]) {
+    const float C1 = 0.4886025119029199f;
+    const float C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f, -1.0925484305920792f, 0.5462742152960396f};
+    const float C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f, 0.3731763325901154f,
+                         -0.4570457994644658f, 1.445305721320277f, -0.5900435899266435f};
+    const float x = d[0], y = d[1], z = d[2];
+#pragma unroll
+    for (int k = 0; k < 16; k++) G[k][0] = G[k][1] = G[k][2] = 0.f;
+    if (deg < 1) return;
+    G[1][1] = -C1; G[2][2] = C1; G[3][0] = -C1;
+    if (deg < 2) return;
+    const float xx = x * x, yy = y * y, zz = z * z;
+    G[4][0] = C2[0] * y; G[4][1] = C2[0] * x;
+    G[5][1] = C2[1] * z; G[5][2] = C2[1] * y;
+    G[6][0] = C2[2] * (-2.f * x); G[6][1] = C2[2] * (-2.f * y); G[6][2] = C2[2] * (4.f * z);
+    G[7][0] = C2[3] * z; G[7][2] = C2[3] * x;
+    G[8][0] = C2[4] * (2.f * x); G[8][1] = C2[4] * (-2.f * y);
+    if (deg < 3) return;
+    G[9][0] = C3[0] * (6.f * x * y); G[9][1] = C3[0] * (3.f * xx - 3.f * yy);
+    G[10][0] = C3[1] * y * z; G[10][1] = C3[1] * x * z; G[10][2] = C3[1] * x * y;
+    G[11][0] = C3[2] * (-2.f * x * y); G[11][1] = C3[2] * (4.f * zz - xx - 3.f * yy); G[11][2] = C3[2] * (8.f * y * z);
+    G[12][0] = C3[3] * (-6.f * x * z); G[12][1] = C3[3] * (-6.f * y * z); G[12][2] = C3[3] * (6.f * zz - 3.f * xx - 3.f * yy);
+    G[13][0] = C3[4] * (4.f * zz - 3.f * xx - yy); G[13][1] = C3[4] * (-2.f * x * y); G[13][2] = C3[4] * (8.f * x * z);
+    G[14][0] = C3[5] * (2.f * x * z); G[14][1] = C3[5] * (-2.f * y * z); G[14][2] = C3[5] * (xx - yy);
+    G[15][0] = C3[6] * (3.f * xx - 3.f * yy); G[15][1] = C3[6] * (-6.f * x * y);
+}
+
+// block-wide sum of one u32 per thread (256 threads = 4 waves); result valid in thread 0
+__device__ __forceinline__ uint32_t block_sum_u32(uint32_t v, uint32_t *lds4) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) lds4[wave] = v;
+    __syncthreads();
+    return lds4[0] + lds4[1] + lds4[2] + lds4[3];
+}
+
+// -------------------------------------------------------------------------------------------------
+// F1
+// -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kPreThreads) void preprocess_fwd_kernel(SgrProblem pb, float4 *__restrict__ rec,
+                                                                     int32_t *__restrict__ radii,
+                                                                     uint2 *__restrict__ rect,
+                                                                     uint8_t *__restrict__ clamped,
+                                                                     uint32_t *__restrict__ block_sums) {
+    __shared__ uint32_t red[4];
+    const int view = blockIdx.y;
+    const int i = blockIdx.x * kPreThreads + threadIdx.x;
+    const int subj = view / pb.views_per_subject;
+    const int W = pb.W, H = pb.H;
+    const int Tx = (W + SGR_TILE - 1) / SGR_TILE, Ty = (H + SGR_TILE - 1) / SGR_TILE;
+    const float *V = pb.viewmatrix + 16 * (size_t)view;
+    const float *M = pb.projmatrix + 16 * (size_t)view;
+    uint32_t tiles = 0;
+    if (i < pb.P) {
+        const size_t q = (size_t)view * pb.P + i, sp = (size_t)subj * pb.P + i;
+        float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = make_float4(0.f, 0.f, -1.f, -1.f);
+        int32_t rad_out = 0;
+        uint2 rect_out = make_uint2(0u, 0u);
+        uint8_t clamp_bits = 0;
+        const float p[3] = {pb.means3D[sp * 3 + 0], pb.means3D[sp * 3 + 1], pb.means3D[sp * 3 + 2]};
+        float pv[3];
+        xform4x3(V, p, pv);
+        if (pv[2] > 0.2f) {                                  // near cull; the lateral test is disabled upstream
+            float ph[4];
+            xform4x4(M, p, ph);
+            const float pw = 1.0f / (ph[3] + 0.0000001f);
+            const float projx = ph[0] * pw, projy = ph[1] * pw;
+            float c6[6];
+            load_cov3d(pb, sp, c6);
+            const float fx = (float)W / (2.0f * pb.tanfovx), fy = (float)H / (2.0f * pb.tanfovy);
+            Cov2D cq;
+            cov2d_eval(pv, V, c6, fx, fy, pb.tanfovx, pb.tanfovy, cq);
+            const float det = cq.a * cq.c - cq.b * cq.b;
+            if (det != 0.0f) {
+                const float det_inv = 1.f / det;
+                const float cx = cq.c * det_inv, cy = -cq.b * det_inv, cz = cq.a * det_inv;
+                const float mid = 0.5f * (cq.a + cq.c);
+                const float disc = sqrtf(fmaxf(0.1f, mid * mid - det));
+                const float lam1 = mid + disc, lam2 = mid - disc;
+                const float my_radius = ceilf(3.f * sqrtf(fmaxf(lam1, lam2)));
+                const float px = ndc2pix(projx, W), py = ndc2pix(projy, H);
+                const int rad = (int)my_radius;
+                int minx = (int)((px - (float)rad) / (float)SGR_TILE); minx = min(Tx, max(0, minx));
+                int miny = (int)((py - (float)rad) / (float)SGR_TILE); miny = min(Ty, max(0, miny));
+                int maxx = (int)((px + (float)rad + (float)(SGR_TILE - 1)) / (float)SGR_TILE); maxx = min(Tx, max(0, maxx));
+                int maxy = (int)((py + (float)rad + (float)(SGR_TILE - 1)) / (float)SGR_TILE); maxy = min(Ty, max(0, maxy));
+                const int area = (maxx - minx) * (maxy - miny);
+                if (area != 0) {
+                    float rgb[3];
+                    if (pb.colors_precomp) {
+#pragma unroll
+                        for (int k = 0; k < 3; k++) rgb[k] = pb.colors_precomp[sp * 3 + k];   // untouched, no clamp
+                    } else {
+                        const float *cp = pb.campos + 3 * (size_t)view;
+                        float d[3] = {p[0] - cp[0], p[1] - cp[1], p[2] - cp[2]};
+                        const float len = sqrtf((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]);
+                        d[0] /= len; d[1] /= len; d[2] /= len;
+                        float B[16];
+                        const int nb = sh_basis(pb.sh_degree, d, B);
+                        const float *sh = pb.shs + sp * (size_t)pb.M * 3;
+#pragma unroll
+                        for (int ch = 0; ch < 3; ch++) {
+                            float r = 0.f;
+                            for (int k = 0; k < nb; k++) r += B[k] * sh[3 * k + ch];
+                            r += 0.5f;
+                            if (r < 0.f) clamp_bits |= (uint8_t)(1u << ch);
+                            rgb[ch] = fmaxf(r, 0.f);
+                        }
+                    }
+                    const float op = pb.opacities[sp];
+                    // exact sub-tile cull bound: alpha = op*exp(power) >= 1/255  <=>  d^T Q d <= 2 ln(255 op);
+                    // the bounding box of that ellipse has half extents sqrt(tau*cov_xx), sqrt(tau*cov_yy).
+                    // Inflated by 1e-3 relative + 0.02 px so fp32 rounding can never cull a contributing pixel.
+                    float hx = -1.f, hy = -1.f;
+                    if (!(det > 0.f) || !(cq.a > 0.f) || !(cq.c > 0.f)) {
+                        hx = hy = 3.0e38f;                      // not an ellipse: never cull
+                    } else if (op * 255.f > 1.f) {
+                        const float tau = 2.f * logf(op * 255.f) * 1.001f + 1e-3f;
+                        hx = sqrtf(tau * cq.a) * 1.001f + 0.02f;
+                        hy = sqrtf(tau * cq.c) * 1.001f + 0.02f;
+                    } else if (!(op * 255.f <= 1.f)) {
+                        hx = hy = 3.0e38f;                      // NaN opacity: keep upstream behaviour
+                    }
+                    r0 = make_float4(px, py, cx, cy);
+                    r1 = make_float4(cz, op, pv[2], rgb[0]);
+                    r2 = make_float4(rgb[1], rgb[2], hx, hy);
+                    rad_out = rad;
+                    rect_out = make_uint2((uint32_t)minx | ((uint32_t)miny << 16), (uint32_t)maxx | ((uint32_t)maxy << 16));
+                    tiles = (uint32_t)area;
+                }
+            }
+        }
+        rec[q * 3 + 0] = r0; rec[q * 3 + 1] = r1; rec[q * 3 + 2] = r2;
+        radii[q] = rad_out;
+        rect[q] = rect_out;
+        if (clamped) clamped[q] = clamp_bits;
+    }
+    const uint32_t tot = block_sum_u32(tiles, red);
+    if (threadIdx.x == 0) block_sums[(size_t)view * gridDim.x + blockIdx.x] = tot;
+}
+
+// -------------------------------------------------------------------------------------------------
+// F2: exclusive scan of the per-block tile counts (n is small: n_views * ceil(P/256)), one workgroup.
+// out[0..n) = exclusive prefix, out[n] = total (also stored as u64 in *num_rendered).
+// -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void scan_block_sums_kernel(const uint32_t *__restrict__ in, uint32_t *__restrict__ out,
+                                                               uint32_t n, uint64_t *__restrict__ num_rendered,
+                                                               uint32_t *__restrict__ overflow) {
+    __shared__ unsigned long long part[1024];
+    const uint32_t t = threadIdx.x;
+    const uint32_t chunk = (n + 1023u) / 1024u;
+    const uint32_t lo = min(n, t * chunk), hi = min(n, lo + chunk);
+    unsigned long long s = 0;
+    for (uint32_t k = lo; k < hi; k++) s += in[k];
+    part[t] = s;
+    __syncthreads();
+    for (uint32_t off = 1; off < 1024; off <<= 1) {            // Hillis-Steele inclusive scan in LDS
+        unsigned long long v = (t >= off) ? part[t - off] : 0ull;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    unsigned long long run = part[t] - s;
+    for (uint32_t k = lo; k < hi; k++) { const uint32_t v = in[k]; out[k] = (uint32_t)run; run += v; }
+    if (t == 1023) {
+        const unsigned long long total = part[1023];
+        out[n] = (uint32_t)total;
+        *num_rendered = total;
+        *overflow = total > 0xFFFFFFF0ull ? 1u : 0u;
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// B2 + B3: one thread per (subject, Gaussian); loops over the subject's views in order.
+// -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kPreThreads) void preprocess_bwd_kernel(SgrProblem pb, const int32_t *__restrict__ radii,
+                                                                     const uint8_t *__restrict__ clamped,
+                                                                     const float4 *__restrict__ grec,
+                                                                     float *__restrict__ dL_dmeans3D,
+                                                                     float *__restrict__ dL_dmeans2D,
+                                                                     float *__restrict__ dL_dopacity,
+                                                                     float *__restrict__ dL_dcolors,
+                                                                     float *__restrict__ dL_dsh,
+                                                                     float *__restrict__ dL_dcov3D,
+                                                                     float *__restrict__ dL_dscales,
+                                                                     float *__restrict__ dL_drot) {
+    const int subj = blockIdx.y;
+    const int i = blockIdx.x * kPreThreads + threadIdx.x;
+    if (i >= pb.P) return;
+    const size_t sp = (size_t)subj * pb.P + i;
+    const int W = pb.W, H = pb.H;
+    const float fx = (float)W / (2.0f * pb.tanfovx), fy = (float)H / (2.0f * pb.tanfovy);
+    const float p[3] = {pb.means3D[sp * 3 + 0], pb.means3D[sp * 3 + 1], pb.means3D[sp * 3 + 2]};
+    float c6[6];
+    load_cov3d(pb, sp, c6);
+    float gmean[3] = {0.f, 0.f, 0.f}, gcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, gop = 0.f, gcol[3] = {0.f, 0.f, 0.f};
+    const int nsh = pb.shs ? pb.M : 0;
+    // SH gradients are accumulated straight into global memory across the view loop (same thread, fixed order)
+    if (pb.shs) {
+        float *gsh = dL_dsh + sp * (size_t)pb.M * 3;
+        for (int k = 0; k < nsh * 3; k++) gsh[k] = 0.f;
+    }
+    const int v0 = subj * pb.views_per_subject;
+    for (int vv = 0; vv < pb.views_per_subject; vv++) {
+        const int view = v0 + vv;
+        const size_t q = (size_t)view * pb.P + i;
+        float *g2out = dL_dmeans2D + q * 3;
+        if (!(radii[q] > 0)) { g2out[0] = g2out[1] = g2out[2] = 0.f; continue; }
+        const float4 g0 = grec[q * 3 + 0], g1 = grec[q * 3 + 1], g2 = grec[q * 3 + 2];
+        const float *V = pb.viewmatrix + 16 * (size_t)view;
+        const float *M = pb.projmatrix + 16 * (size_t)view;
+        float pv[3];
+        xform4x3(V, p, pv);
+        Cov2D cq;
+        cov2d_eval(pv, V, c6, fx, fy, pb.tanfovx, pb.tanfovy, cq);
+        // ---- B2: conic -> (a,b,c) -> Sigma, projection Jacobian
+        const float a = cq.a, b = cq.b, c = cq.c;
+        const float gx = g0.z, gy = g0.w, gz = g1.x;
+        const float denom = a * c - b * b;
+        const float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
+        float dL_da = 0.f, dL_db = 0.f, dL_dc = 0.f;
+        if (denom2inv != 0.f) {
+            dL_da = denom2inv * (-c * c * gx + 2.f * b * c * gy + (denom - a * c) * gz);
+            dL_dc = denom2inv * (-a * a * gz + 2.f * a * b * gy + (denom - a * c) * gx);
+            dL_db = denom2inv * 2.f * (b * c * gx - (denom + 2.f * b * b) * gy + a * b * gz);
+            const float *m0 = cq.m0, *m1 = cq.m1;
+            gcov[0] += m0[0] * m0[0] * dL_da + m0[0] * m1[0] * dL_db + m1[0] * m1[0] * dL_dc;
+            gcov[3] += m0[1] * m0[1] * dL_da + m0[1] * m1[1] * dL_db + m1[1] * m1[1] * dL_dc;
+            gcov[5] += m0[2] * m0[2] * dL_da + m0[2] * m1[2] * dL_db + m1[2] * m1[2] * dL_dc;
+            gcov[1] += 2.f * m0[0] * m0[1] * dL_da + (m0[0] * m1[1] + m0[1] * m1[0]) * dL_db + 2.f * m1[0] * m1[1] * dL_dc;
+            gcov[2] += 2.f * m0[0] * m0[2] * dL_da + (m0[0] * m1[2] + m0[2] * m1[0]) * dL_db + 2.f * m1[0] * m1[2] * dL_dc;
+            gcov[4] += 2.f * m0[2] * m0[1] * dL_da + (m0[1] * m1[2] + m0[2] * m1[1]) * dL_db + 2.f * m1[1] * m1[2] * dL_dc;
+        }
+        float gm0[3], gm1[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            gm0[k] = 2.f * cq.v0[k] * dL_da + cq.v1[k] * dL_db;
+            gm1[k] = 2.f * cq.v1[k] * dL_dc + cq.v0[k] * dL_db;
+        }
+        float dJ00 = 0.f, dJ02 = 0.f, dJ11 = 0.f, dJ12 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            dJ00 += V[4 * k + 0] * gm0[k]; dJ02 += V[4 * k + 2] * gm0[k];
+            dJ11 += V[4 * k + 1] * gm1[k]; dJ12 += V[4 * k + 2] * gm1[k];
+        }
+        const float tz = 1.f / cq.t[2], tz2 = tz * tz, tz3 = tz2 * tz;
+        const float dtx = cq.xmul * -fx * tz2 * dJ02;
+        const float dty = cq.ymul * -fy * tz2 * dJ12;
+        const float dtz = -fx * tz2 * dJ00 - fy * tz2 * dJ11 + (2.f * fx * cq.t[0]) * tz3 * dJ02 + (2.f * fy * cq.t[1]) * tz3 * dJ12;
+        float gm[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) gm[k] = (V[4 * k + 0] * dtx + V[4 * k + 1] * dty) + V[4 * k + 2] * dtz;
+        // ---- B3: NDC mean -> 3D mean through the full projection
+        float ph[4];
+        xform4x4(M, p, ph);
+        const float mw = 1.0f / (ph[3] + 0.0000001f);
+        const float mul1 = ph[0] * mw * mw, mul2 = ph[1] * mw * mw;
+        const float g2x = g0.x, g2y = g0.y;
+        gm[0] += (M[0] * mw - M[3] * mul1) * g2x + (M[1] * mw - M[3] * mul2) * g2y;
+        gm[1] += (M[4] * mw - M[7] * mul1) * g2x + (M[5] * mw - M[7] * mul2) * g2y;
+        gm[2] += (M[8] * mw - M[11] * mul1) * g2x + (M[9] * mw - M[11] * mul2) * g2y;
+        const float gdep = g1.z;
+        gm[0] += V[2] * gdep; gm[1] += V[6] * gdep; gm[2] += V[10] * gdep;
+        const float gc3[3] = {g1.w, g2.x, g2.y};
+        if (pb.shs) {
+            const float *cp = pb.campos + 3 * (size_t)view;
+            const float d[3] = {p[0] - cp[0], p[1] - cp[1], p[2] - cp[2]};
+            const float len = sqrtf((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]);
+            const float u[3] = {d[0] / len, d[1] / len, d[2] / len};
+            float B[16], Gb[16][3];
+            const int nb = sh_basis(pb.sh_degree, u, B);
+            sh_basis_grad(pb.sh_degree, u, Gb);
+            const float *sh = pb.shs + sp * (size_t)pb.M * 3;
+            float *gsh = dL_dsh + sp * (size_t)pb.M * 3;
+            const uint8_t cb = clamped[q];
+            float gdir[3] = {0.f, 0.f, 0.f};
+            for (int ch = 0; ch < 3; ch++) {
+                const float gcl = ((cb >> ch) & 1) ? 0.f : gc3[ch];
+                for (int k = 0; k < nb; k++) {
+                    gsh[3 * k + ch] += B[k] * gcl;
+                    const float sg = sh[3 * k + ch] * gcl;
+                    gdir[0] += Gb[k][0] * sg; gdir[1] += Gb[k][1] * sg; gdir[2] += Gb[k][2] * sg;
+                }
+            }
+            const float udot = (u[0] * gdir[0] + u[1] * gdir[1]) + u[2] * gdir[2];
+#pragma unroll
+            for (int k = 0; k < 3; k++) gm[k] += (gdir[k] - u[k] * udot) / len;
+        } else {
+            gcol[0] += gc3[0]; gcol[1] += gc3[1]; gcol[2] += gc3[2];
+        }
+        gop += g1.y;
+        gmean[0] += gm[0]; gmean[1] += gm[1]; gmean[2] += gm[2];
+        g2out[0] = g2x; g2out[1] = g2y; g2out[2] = 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) dL_dmeans3D[sp * 3 + k] = gmean[k];
+#pragma unroll
+    for (int k = 0; k < 6; k++) dL_dcov3D[sp * 6 + k] = gcov[k];
+    dL_dopacity[sp] = gop;
+    if (!pb.shs) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) dL_dcolors[sp * 3 + k] = gcol[k];
+    }
+    if (pb.scales) {
+        float s[3], qv[4], Rm[3][3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) s[k] = pb.scales[sp * 3 + k];
+#pragma unroll
+        for (int k = 0; k < 4; k++) qv[k] = pb.rotations[sp * 4 + k];
+        quat_to_rot(qv, Rm);
+        const float r = qv[0], x = qv[1], y = qv[2], z = qv[3];
+        const float mod = pb.scale_modifier;
+        const float sv[3] = {mod * s[0], mod * s[1], mod * s[2]};
+        const float Gs[3][3] = {{gcov[0], 0.5f * gcov[1], 0.5f * gcov[2]},
+                                {0.5f * gcov[1], gcov[3], 0.5f * gcov[4]},
+                                {0.5f * gcov[2], 0.5f * gcov[4], gcov[5]}};
+        float dMx[3][3], dR[3][3];
+#pragma unroll
+        for (int a3 = 0; a3 < 3; a3++)
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                float acc = 0.f;
+#pragma unroll
+                for (int j = 0; j < 3; j++) acc += Gs[a3][j] * (Rm[j][k] * sv[k]);
+                dMx[a3][k] = 2.f * acc;
+            }
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            float acc = 0.f;
+#pragma unroll
+            for (int a3 = 0; a3 < 3; a3++) { acc += dMx[a3][k] * Rm[a3][k]; dR[a3][k] = dMx[a3][k] * sv[k]; }
+            dL_dscales[sp * 3 + k] = mod * acc;
+        }
+        float *gq = dL_drot + sp * 4;
+        gq[0] = 2.f * (z * (dR[1][0] - dR[0][1]) + y * (dR[0][2] - dR[2][0]) + x * (dR[2][1] - dR[1][2]));
+        gq[1] = 2.f * (y * (dR[0][1] + dR[1][0]) + z * (dR[0][2] + dR[2][0]) + r * (dR[2][1] - dR[1][2])) - 4.f * x * (dR[1][1] + dR[2][2]);
+        gq[2] = 2.f * (x * (dR[0][1] + dR[1][0]) + r * (dR[0][2] - dR[2][0]) + z * (dR[1][2] + dR[2][1])) - 4.f * y * (dR[0][0] + dR[2][2]);
+        gq[3] = 2.f * (r * (dR[1][0] - dR[0][1]) + x * (dR[0][2] + dR[2][0]) + y * (dR[1][2] + dR[2][1])) - 4.f * z * (dR[0][0] + dR[1][1]);
+    }
+}
+
+__global__ __launch_bounds__(kPreThreads) void mark_visible_kernel(int P, const float *__restrict__ means3D,
+                                                                   const float *__restrict__ V, uint8_t *__restrict__ present) {
+    const int i = blockIdx.x * kPreThreads + threadIdx.x;
+    if (i >= P) return;
+    const float p[3] = {means3D[3 * (size_t)i], means3D[3 * (size_t)i + 1], means3D[3 * (size_t)i + 2]};
+    float pv[3];
+    xform4x3(V, p, pv);
+    present[i] = pv[2] > 0.2f ? 1 : 0;
+}
+
+int validate_problem(const SgrProblem *pb) {
+    if (!pb) { sgr_set_error("null SgrProblem"); return 1; }
+    if (pb->P < 0 || pb->n_views <= 0 || pb->views_per_subject <= 0 || pb->n_views % pb->views_per_subject != 0) {
+        sgr_set_error("bad batch shape: P=%d n_views=%d views_per_subject=%d", pb->P, pb->n_views, pb->views_per_subject);
+        return 1;
+    }
+    if (pb->H <= 0 || pb->W <= 0 || pb->H > 65535 * SGR_TILE || pb->W > 65535 * SGR_TILE) {
+        sgr_set_error("bad image size %dx%d", pb->H, pb->W);
+        return 1;
+    }
+    if (pb->P > 0 && (!pb->means3D || !pb->opacities)) { sgr_set_error("means3D / opacities must not be NULL"); return 1; }
+    if ((pb->colors_precomp != nullptr) == (pb->shs != nullptr) && pb->P > 0) {
+        sgr_set_error("Please provide excatly one of either SHs or precomputed colors!");
+        return 1;
+    }
+    const bool sr = pb->scales != nullptr && pb->rotations != nullptr;
+    if (((pb->scales != nullptr) != (pb->rotations != nullptr)) || (sr == (pb->cov3D_precomp != nullptr) && pb->P > 0)) {
+        sgr_set_error("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!");
+        return 1;
+    }
+    if (pb->shs && (pb->sh_degree < 0 || pb->sh_degree > 3 || pb->M < (pb->sh_degree + 1) * (pb->sh_degree + 1))) {
+        sgr_set_error("sh_degree %d needs M >= %d coefficients (got %d)", pb->sh_degree, (pb->sh_degree + 1) * (pb->sh_degree + 1), pb->M);
+        return 1;
+    }
+    if (!pb->viewmatrix || !pb->projmatrix || !pb->bg || (pb->shs && !pb->campos)) { sgr_set_error("camera pointers must not be NULL"); return 1; }
+    return 0;
+}
+
+}  // namespace
+
+int sgr_validate_problem(const SgrProblem *pb) { return validate_problem(pb); }
+
+extern "C" int32_t sgr_preprocess_blocks_per_view(int32_t P) { return P <= 0 ? 1 : (P + kPreThreads - 1) / kPreThreads; }
+
+extern "C" int sgr_preprocess_forward(const SgrProblem *pb, float *rec, int32_t *radii, uint32_t *rect, uint8_t *clamped,
+                                      uint32_t *block_offsets, uint64_t *num_rendered, void *stream_) {
+    if (validate_problem(pb)) return 1;
+    hipStream_t stream = (hipStream_t)stream_;
+    const int nbx = sgr_preprocess_blocks_per_view(pb->P);
+    const uint32_t n = (uint32_t)nbx * (uint32_t)pb->n_views;
+    // the un-scanned block sums live in the upper half of a caller buffer? no: scan in place is unsafe with
+    // chunked reads, so the sums are staged right behind the offsets (caller allocates 2*(n+1) entries).
+    uint32_t *sums = block_offsets + (n + 1);
+    dim3 grid(nbx, pb->n_views);
+    hipLaunchKernelGGL(preprocess_fwd_kernel, grid, dim3(kPreThreads), 0, stream, *pb, (float4 *)rec, radii, (uint2 *)rect,
+                       clamped, sums);
+    SGR_CHECK_LAUNCH("preprocess_fwd_kernel");
+    hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(1024), 0, stream, sums, block_offsets, n, num_rendered,
+                       (uint32_t *)(num_rendered + 1));
+    SGR_CHECK_LAUNCH("scan_block_sums_kernel");
+    return 0;
+}
+
+extern "C" int sgr_preprocess_backward(const SgrProblem *pb, const int32_t *radii, const uint8_t *clamped, const float *grec,
+                                       float *dL_dmeans3D, float *dL_dmeans2D, float *dL_dopacity, float *dL_dcolors,
+                                       float *dL_dsh, float *dL_dcov3D, float *dL_dscales, float *dL_drotations,
+                                       void *stream_) {
+    if (validate_problem(pb)) return 1;
+    if (pb->P == 0) return 0;
+    if (pb->shs && (!dL_dsh || !clamped)) { sgr_set_error("dL_dsh / clamped required on the SH path"); return 1; }
+    if (!pb->shs && !dL_dcolors) { sgr_set_error("dL_dcolors required on the colors_precomp path"); return 1; }
+    if (pb->scales && (!dL_dscales || !dL_drotations)) { sgr_set_error("dL_dscales / dL_drotations required"); return 1; }
+    hipStream_t stream = (hipStream_t)stream_;
+    const int nbx = sgr_preprocess_blocks_per_view(pb->P);
+    dim3 grid(nbx, pb->n_views / pb->views_per_subject);
+    hipLaunchKernelGGL(preprocess_bwd_kernel, grid, dim3(kPreThreads), 0, stream, *pb, radii, clamped, (const float4 *)grec,
+                       dL_dmeans3D, dL_dmeans2D, dL_dopacity, dL_dcolors, dL_dsh, dL_dcov3D, dL_dscales, dL_drotations);
+    SGR_CHECK_LAUNCH("preprocess_bwd_kernel");
+    return 0;
+}
+
+extern "C" int sgr_mark_visible(int32_t P, const float *means3D, const float *viewmatrix, uint8_t *present, void *stream_) {
+    if (P <= 0) return 0;
+    if (!means3D || !viewmatrix || !present) { sgr_set_error("sgr_mark_visible: NULL pointer"); return 1; }
+    hipLaunchKernelGGL(mark_visible_kernel, dim3((P + kPreThreads - 1) / kPreThreads), dim3(kPreThreads), 0, (hipStream_t)stream_,
+                       P, means3D, viewmatrix, present);
+    SGR_CHECK_LAUNCH("mark_visible_kernel");
+    return 0;
+}

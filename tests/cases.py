@@ -1,0 +1,96 @@
+"""Seeded input cases shared by the CPU and GPU parity tests (numpy, float32)."""
+from __future__ import annotations
+
+import numpy as np
+
+from sigman_release_amd import cameras, synthetic
+
+BG_WHITE = np.array([1.0, 1.0, 1.0], np.float32)
+
+
+def _cams(view_ids):
+    cv, cvp, cp = cameras.make_cameras(view_ids)
+    return cv, cvp, cp
+
+
+def _settings(view_ids, H, W, bg=BG_WHITE, **kw):
+    cv, cvp, cp = _cams(view_ids)
+    d = dict(viewmatrix=cv, projmatrix=cvp, campos=cp, bg=np.asarray(bg, np.float32), tanfovx=cameras.TAN_HALF_FOV,
+             tanfovy=cameras.TAN_HALF_FOV, image_height=H, image_width=W, scale_modifier=1.0, sh_degree=0)
+    d.update(kw)
+    return d
+
+
+def cloud_precomp(P=300, H=64, W=80, seed=0, views=(30,), scale_mul=4.0, bg=BG_WHITE):
+    g = synthetic.random_cloud(P, seed)
+    g["world_scale"] = (g["world_scale"] * scale_mul).astype(np.float32)
+    inp = dict(means3D=g["position"], opacities=g["opacity"].reshape(P), colors_precomp=g["rgb"],
+               cov3D_precomp=synthetic.covariance_from_gaussians(g))
+    return inp, _settings(views, H, W, bg=bg)
+
+
+def cloud_sh(P=300, H=64, W=80, seed=0, views=(30,), deg=3, scale_mul=4.0, scale_modifier=0.9):
+    rng = np.random.default_rng(seed + 77)
+    g = synthetic.random_cloud(P, seed)
+    q = rng.normal(size=(P, 4)).astype(np.float32)
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    inp = dict(means3D=g["position"], opacities=g["opacity"].reshape(P),
+               shs=(rng.normal(size=(P, (deg + 1) ** 2, 3)) * 0.3).astype(np.float32),
+               scales=(g["world_scale"] * scale_mul).astype(np.float32), rotations=q)
+    return inp, _settings(views, H, W, sh_degree=deg, scale_modifier=scale_modifier)
+
+
+def cull_and_clamp(P=400, H=96, W=96, seed=3):
+    """Camera INSIDE the cloud: exercises the z<=0.2 cull and the 1.3*tanfov clamp (x_grad_mul = 0)."""
+    g = synthetic.random_cloud(P, seed)
+    g["position"] = (g["position"] * 3.5).astype(np.float32)          # cloud of +-2.8 m around a camera at 2.5 m
+    g["world_scale"] = (g["world_scale"] * 6).astype(np.float32)
+    inp = dict(means3D=g["position"], opacities=g["opacity"].reshape(P), colors_precomp=g["rgb"],
+               cov3D_precomp=synthetic.covariance_from_gaussians(g))
+    return inp, _settings((30,), H, W, bg=np.array([0.2, 0.5, 0.9], np.float32))
+
+
+def opaque_stack(P=600, H=48, W=48, seed=5):
+    """Many large, nearly opaque Gaussians: exercises the 0.99 alpha cap and the T<1e-4 stop rule."""
+    rng = np.random.default_rng(seed)
+    g = synthetic.random_cloud(P, seed)
+    g["position"] = (g["position"] * np.array([0.3, 0.3, 1.0])).astype(np.float32)
+    g["world_scale"] = np.full((P, 3), 0.08, np.float32)
+    op = np.where(rng.random(P) < 0.7, 1.0, rng.random(P)).astype(np.float32)
+    inp = dict(means3D=g["position"], opacities=op, colors_precomp=g["rgb"],
+               cov3D_precomp=synthetic.covariance_from_gaussians(g))
+    return inp, _settings((30,), H, W)
+
+
+def humanoid(P=20000, H=256, W=256, seed=1, views=(30,)):
+    g = synthetic.humanoid(P, seed)
+    inp = dict(means3D=g["position"], opacities=g["opacity"].reshape(P), colors_precomp=g["rgb"],
+               cov3D_precomp=synthetic.covariance_from_gaussians(g))
+    return inp, _settings(views, H, W)
+
+
+CASES = {
+    "cloud_precomp": lambda: cloud_precomp(),
+    "cloud_precomp_ragged": lambda: cloud_precomp(P=257, H=50, W=70, seed=11, bg=np.array([0.1, 0.7, 0.3], np.float32)),
+    "cloud_sh3": lambda: cloud_sh(),
+    "cloud_sh1": lambda: cloud_sh(seed=2, deg=1),
+    "cull_and_clamp": lambda: cull_and_clamp(),
+    "opaque_stack": lambda: opaque_stack(),
+    "single_gaussian": lambda: cloud_precomp(P=1, H=33, W=17, seed=4, scale_mul=20.0),
+    "c1_10k_256": lambda: cloud_precomp(P=10000, H=256, W=256, seed=0, scale_mul=1.0),
+    "humanoid_20k_256": lambda: humanoid(),
+}
+
+
+def grads_for(H, W, seed=99):
+    rng = np.random.default_rng(seed)
+    gC = (rng.normal(size=(3, H, W)) / (H * W) * 100).astype(np.float32)
+    gD = (rng.normal(size=(1, H, W)) / (H * W) * 100).astype(np.float32)
+    gA = (rng.normal(size=(1, H, W)) / (H * W) * 100).astype(np.float32)
+    return gC, gD, gA
+
+
+def single_view(settings, v=0):
+    s = dict(settings)
+    s["viewmatrix"], s["projmatrix"], s["campos"] = settings["viewmatrix"][v], settings["projmatrix"][v], settings["campos"][v]
+    return s

@@ -1,0 +1,195 @@
+"""-m gpu: HIP path (through the C ABI) against the CPU oracle on identical seeded inputs.
+
+Bars: integer artefacts (radii, tile rects, sorted keys, point lists, tile ranges) BIT-EXACT; images within
+1e-4 abs (north_star tolerance; observed ~1e-6); n_contrib equal except on ulp-borderline alpha tests;
+gradients within 1e-4 * max|g| per tensor (float atomics make the summation order free).
+"""
+import numpy as np
+import pytest
+import torch
+
+import cases
+
+pytestmark = pytest.mark.gpu
+
+IMG_TOL = 1e-4
+GRAD_TOL = 1e-4
+
+
+def _dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+def _to_dev(inp, dev):
+    return {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in inp.items()}
+
+
+def _batched_settings(st, dev, vps):
+    from sigman_release_amd.rasterizer import BatchedRasterizationSettings
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    return BatchedRasterizationSettings(st["image_height"], st["image_width"], st["tanfovx"], st["tanfovy"], t(st["bg"]),
+                                        st["scale_modifier"], t(st["viewmatrix"]), t(st["projmatrix"]), st["sh_degree"],
+                                        t(st["campos"]), vps)
+
+
+@pytest.mark.parametrize("name", list(cases.CASES))
+def test_forward_artefacts_and_images(name, oracle):
+    from sigman_release_amd import rasterizer as R
+    dev = _dev()
+    inp, st = cases.CASES[name]()
+    ref = oracle.forward(**inp, **cases.single_view(st))
+    d = _to_dev(inp, dev)
+    out = R.forward_debug(d["means3D"][None], d["opacities"][None], colors_precomp=d.get("colors_precomp", None) if "colors_precomp" not in d else d["colors_precomp"][None],
+                          shs=d["shs"][None] if "shs" in d else None,
+                          cov3D_precomp=d["cov3D_precomp"][None] if "cov3D_precomp" in d else None,
+                          scales=d["scales"][None] if "scales" in d else None,
+                          rotations=d["rotations"][None] if "rotations" in d else None,
+                          settings=_batched_settings(st, dev, 1))
+    torch.cuda.synchronize()
+    P = ref.P
+    # ---- integer artefacts: bit exact
+    assert out["num_rendered"] == ref.R
+    np.testing.assert_array_equal(out["radii"][0].cpu().numpy(), ref.radii)
+    rect = out["rect"][0].cpu().numpy().astype(np.uint32)
+    rect4 = np.stack([rect[:, 0] & 0xFFFF, rect[:, 0] >> 16, rect[:, 1] & 0xFFFF, rect[:, 1] >> 16], 1).astype(np.int32)
+    np.testing.assert_array_equal(rect4, ref.rect)
+    np.testing.assert_array_equal(out["keys"].cpu().numpy().view(np.uint64), ref.keys)
+    np.testing.assert_array_equal(out["point_list"].cpu().numpy().astype(np.uint32), ref.point_list)
+    np.testing.assert_array_equal(out["ranges"][0].cpu().numpy().astype(np.uint32), ref.ranges)
+    rec = out["rec"][0].cpu().numpy()
+    vis = ref.radii > 0
+    np.testing.assert_array_equal(rec[vis, 6].view(np.uint32), ref.depths[vis].view(np.uint32))       # depth bits
+    np.testing.assert_array_equal(rec[vis, 0:2].view(np.uint32), ref.xy[vis].view(np.uint32))         # pixel centre bits
+    np.testing.assert_allclose(rec[vis][:, [2, 3, 4]], ref.conic_opacity[vis][:, :3], rtol=1e-6, atol=0)
+    # ---- images
+    for k, r in (("color", ref.color), ("depth", ref.depth), ("alpha", ref.alpha)):
+        err = np.abs(out[k][0].cpu().numpy() - r).max() if r.size else 0.0
+        assert err <= IMG_TOL, f"{name}: {k} max abs err {err}"
+    nc = out["n_contrib"][0].cpu().numpy().astype(np.uint32)
+    frac_bad = float((nc != ref.n_contrib).mean())
+    assert frac_bad <= 1e-3, f"{name}: n_contrib differs on {frac_bad:.2%} of pixels"
+    assert np.abs(out["final_T"][0].cpu().numpy() - ref.final_T).max() <= IMG_TOL
+
+
+@pytest.mark.parametrize("name", list(cases.CASES))
+def test_backward_gradients(name, oracle):
+    from sigman_release_amd import rasterizer as R
+    dev = _dev()
+    inp, st = cases.CASES[name]()
+    H, W = st["image_height"], st["image_width"]
+    gC, gD, gA = cases.grads_for(H, W)
+    ref = oracle.forward(**inp, **cases.single_view(st))
+    gref = oracle.backward(ref, gC, gD, gA)
+    d = {k: v.clone().requires_grad_(True) for k, v in _to_dev(inp, dev).items()}
+    P = ref.P
+    means2D = torch.zeros(P, 3, device=dev, requires_grad=True)
+    sv = cases.single_view(st)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    rs = R.GaussianRasterizationSettings(H, W, st["tanfovx"], st["tanfovy"], t(st["bg"]), st["scale_modifier"],
+                                         t(sv["viewmatrix"]), t(sv["projmatrix"]), st["sh_degree"], t(sv["campos"]), False, False)
+    rast = R.GaussianRasterizer(rs)
+    color, radii, depth, alpha = rast(means3D=d["means3D"], means2D=means2D, opacities=d["opacities"].reshape(P, 1),
+                                      shs=d.get("shs"), colors_precomp=d.get("colors_precomp"), scales=d.get("scales"),
+                                      rotations=d.get("rotations"), cov3D_precomp=d.get("cov3D_precomp"))
+    loss = (color * t(gC)).sum() + (depth * t(gD)).sum() + (alpha * t(gA)).sum()
+    loss.backward()
+    torch.cuda.synchronize()
+    pairs = [("means3D", d["means3D"].grad, gref["means3D"]), ("means2D", means2D.grad, gref["means2D"]),
+             ("opacities", d["opacities"].grad.reshape(P, 1), gref["opacities"])]
+    if "colors_precomp" in d:
+        pairs.append(("colors_precomp", d["colors_precomp"].grad, gref["colors_precomp"]))
+    else:
+        pairs.append(("shs", d["shs"].grad, gref["sh"]))
+    if "cov3D_precomp" in d:
+        pairs.append(("cov3D_precomp", d["cov3D_precomp"].grad, gref["cov3D_precomp"]))
+    else:
+        pairs += [("scales", d["scales"].grad, gref["scales"]), ("rotations", d["rotations"].grad, gref["rotations"])]
+    for nm, got, want in pairs:
+        got = got.detach().cpu().numpy()
+        scale = max(float(np.abs(want).max()), 1e-20)
+        err = float(np.abs(got - want).max()) / scale
+        assert np.isfinite(got).all(), f"{name}: {nm} has non-finite gradients"
+        assert err <= GRAD_TOL, f"{name}: grad {nm} rel-to-max err {err:.3e} (max|g| {scale:.3e})"
+
+
+def test_empty_and_degenerate():
+    """P = 0 and an identity camera (everything culled) must give the pure background, not crash."""
+    from sigman_release_amd import rasterizer as R
+    dev = _dev()
+    bg = torch.tensor([0.25, 0.5, 0.75], device=dev)
+    eye = torch.eye(4, device=dev)
+    rs = R.GaussianRasterizationSettings(40, 56, 0.5, 0.5, bg, 1.0, eye, eye, 0, torch.zeros(3, device=dev), False, False)
+    rast = R.GaussianRasterizer(rs)
+    for P in (0, 5):
+        m = torch.zeros(P, 3, device=dev, requires_grad=True)          # z = 0 <= 0.2: culled
+        color, radii, depth, alpha = rast(means3D=m, means2D=torch.zeros_like(m), opacities=torch.ones(P, 1, device=dev),
+                                          colors_precomp=torch.ones(P, 3, device=dev),
+                                          cov3D_precomp=torch.ones(P, 6, device=dev) * 0.01)
+        assert torch.equal(color, bg[:, None, None].expand(3, 40, 56))
+        assert float(alpha.abs().max()) == 0.0 and float(depth.abs().max()) == 0.0
+        assert radii.shape == (P,) and int(radii.sum()) == 0
+        color.sum().backward()
+        assert m.grad is not None and float(m.grad.abs().sum()) == 0.0
+
+
+def test_argument_errors():
+    from sigman_release_amd import rasterizer as R
+    dev = _dev()
+    eye = torch.eye(4, device=dev)
+    rs = R.GaussianRasterizationSettings(16, 16, 0.5, 0.5, torch.ones(3, device=dev), 1.0, eye, eye, 0,
+                                         torch.zeros(3, device=dev), False, False)
+    rast = R.GaussianRasterizer(rs)
+    m = torch.zeros(4, 3, device=dev)
+    with pytest.raises(Exception, match="excatly one of either SHs"):
+        rast(means3D=m, means2D=m, opacities=torch.ones(4, 1, device=dev), cov3D_precomp=torch.ones(4, 6, device=dev))
+    with pytest.raises(Exception, match="scale/rotation pair"):
+        rast(means3D=m, means2D=m, opacities=torch.ones(4, 1, device=dev), colors_precomp=torch.ones(4, 3, device=dev))
+
+
+def test_batched_equals_per_view(oracle):
+    """One batched launch chain over S=2 subjects x V=3 views == the per-view oracle, grads summed over views."""
+    from sigman_release_amd import rasterizer as R
+    dev = _dev()
+    views = (30, 37, 65)
+    H = W = 128
+    subj = [cases.humanoid(P=3000, H=H, W=W, seed=s, views=views) for s in (7, 8)]
+    st = subj[0][1]
+    S, V, P = 2, 3, 3000
+    stack = lambda k: torch.from_numpy(np.stack([s[0][k] for s in subj])).to(dev).requires_grad_(True)
+    means3D, op, col, cov = stack("means3D"), stack("opacities"), stack("colors_precomp"), stack("cov3D_precomp")
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    bst = R.BatchedRasterizationSettings(H, W, st["tanfovx"], st["tanfovy"], t(st["bg"]), 1.0,
+                                         t(np.concatenate([st["viewmatrix"]] * S)), t(np.concatenate([st["projmatrix"]] * S)),
+                                         0, t(np.concatenate([st["campos"]] * S)), V)
+    means2D = torch.zeros(S * V, P, 3, device=dev, requires_grad=True)
+    color, radii, depth, alpha = R.rasterize_gaussians_batched(means3D, means2D, None, col, op.unsqueeze(-1), None, None, cov, bst)
+    gs = [cases.grads_for(H, W, seed=200 + i) for i in range(S * V)]
+    gC = t(np.stack([g[0] for g in gs])); gD = t(np.stack([g[1] for g in gs])); gA = t(np.stack([g[2] for g in gs]))
+    ((color * gC).sum() + (depth * gD).sum() + (alpha * gA).sum()).backward()
+    torch.cuda.synchronize()
+    for s in range(S):
+        acc = None
+        for v in range(V):
+            ref = oracle.forward(**subj[s][0], **cases.single_view(st, v))
+            i = s * V + v
+            assert np.abs(color[i].detach().cpu().numpy() - ref.color).max() <= IMG_TOL
+            np.testing.assert_array_equal(radii[i].cpu().numpy(), ref.radii)
+            g = oracle.backward(ref, *gs[i])
+            np.testing.assert_allclose(means2D.grad[i].cpu().numpy(), g["means2D"], atol=GRAD_TOL * np.abs(g["means2D"]).max())
+            acc = g if acc is None else {k: acc[k] + g[k] for k in acc}
+        for nm, got, want in (("means3D", means3D.grad[s], acc["means3D"]), ("opacities", op.grad[s], acc["opacities"][:, 0]),
+                              ("colors", col.grad[s], acc["colors_precomp"]), ("cov3D", cov.grad[s], acc["cov3D_precomp"])):
+            err = np.abs(got.cpu().numpy() - want).max() / max(np.abs(want).max(), 1e-20)
+            assert err <= GRAD_TOL, f"subject {s}: {nm} err {err:.3e}"
+
+
+def test_mark_visible(oracle):
+    from sigman_release_amd import rasterizer as R
+    dev = _dev()
+    inp, st = cases.cull_and_clamp()
+    sv = cases.single_view(st)
+    got = R.mark_visible(torch.from_numpy(inp["means3D"]).to(dev), torch.from_numpy(sv["viewmatrix"]).to(dev)).cpu().numpy()
+    want = oracle.mark_visible(inp["means3D"], sv["viewmatrix"])
+    np.testing.assert_array_equal(got, want)
+    assert 0 < want.sum() < want.size
