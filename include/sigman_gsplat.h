@@ -89,7 +89,8 @@ int32_t sgr_preprocess_blocks_per_view(int32_t P);
  * F1 + F2: cull/project/cov2D/conic/radius/rect per (view,Gaussian), block-wise tile counts and their
  * exclusive scan.  Outputs: rec [n_views*P*12], radii i32 [n_views*P], rect u32 [n_views*P*2]
  * (minx | miny<<16, maxx | maxy<<16), clamped u8 [n_views*P] (SH clamp bits, may be NULL without shs),
- * block_offsets u32 [n_views*blocks_per_view + 1] (last entry = R), num_rendered u64 [1] (= R).
+ * block_offsets u32 [2*(n_views*blocks_per_view + 1)] (first half: exclusive offsets, entry n = R; second half:
+ * scratch for the un-scanned sums), num_rendered u64 [2] ([0] = R, [1] = 1 if R overflows the 32-bit instance index).
  */
 int sgr_preprocess_forward(const SgrProblem *pb, float *rec, int32_t *radii, uint32_t *rect, uint8_t *clamped,
                            uint32_t *block_offsets, uint64_t *num_rendered, void *stream);
@@ -135,6 +136,17 @@ int sgr_preprocess_backward(const SgrProblem *pb, const int32_t *radii, const ui
                             float *dL_dmeans3D, float *dL_dmeans2D, float *dL_dopacity, float *dL_dcolors,
                             float *dL_dsh, float *dL_dcov3D, float *dL_dscales, float *dL_drotations,
                             void *stream);
+
+/* ---- optional per-kernel profiler (HIP events on the launch stream; used by bench.py) -------- */
+enum {
+    SGR_K_PREPROCESS_FWD = 0, SGR_K_SCAN = 1, SGR_K_DUPLICATE = 2, SGR_K_SORT = 3, SGR_K_RANGES = 4,
+    SGR_K_RENDER_FWD = 5, SGR_K_RENDER_BWD = 6, SGR_K_PREPROCESS_BWD = 7, SGR_K_KNN = 8, SGR_K_COV3D = 9,
+    SGR_K_LOSS = 10, SGR_K_COUNT = 16
+};
+/* bit k of kernel_mask enables event pairs around kernel id k; 0 disables (default) */
+int sgr_prof_configure(uint32_t kernel_mask);
+/* after a device/stream synchronise: per-kernel-id summed milliseconds and launch counts; clears the log */
+int sgr_prof_collect(double *total_ms /*[SGR_K_COUNT]*/, uint32_t *counts /*[SGR_K_COUNT]*/);
 
 /* upstream `mark_visible`: present[i] = (view-space z > 0.2) */
 int sgr_mark_visible(int32_t P, const float *means3D, const float *viewmatrix, uint8_t *present, void *stream);

@@ -1,6 +1,9 @@
-// api.hip -- C-ABI plumbing shared by every entry point of libsigman_gsplat.so (error string, version).
+// api.hip -- C-ABI plumbing shared by every entry point of libsigman_gsplat.so: error string, version,
+// and the optional per-kernel HIP-event profiler bench.py uses for its roofline numbers.
 #include <stdarg.h>
 #include <stdio.h>
+
+#include <vector>
 
 #include "common.h"
 
@@ -15,3 +18,51 @@ void sgr_set_error(const char *fmt, ...) {
 
 extern "C" const char *sgr_last_error(void) { return g_err; }
 extern "C" int sgr_abi_version(void) { return SGR_ABI_VERSION; }
+
+// ---------------------------------------------------------------------------------------------
+// profiler: hipEventRecord pairs on the launch stream around selected kernels (off by default; when off the
+// cost is one predictable branch per launch).  Single-threaded use only (bench.py).
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct Slot { hipEvent_t a, b; int kid; };
+uint32_t g_mask = 0;
+std::vector<Slot> g_slots;
+size_t g_used = 0;
+}  // namespace
+
+int sgr_prof_begin(int kid, hipStream_t s) {
+    if (!((g_mask >> kid) & 1u)) return -1;
+    if (g_used == g_slots.size()) {
+        Slot sl;
+        if (hipEventCreate(&sl.a) != hipSuccess || hipEventCreate(&sl.b) != hipSuccess) return -1;
+        g_slots.push_back(sl);
+    }
+    Slot &sl = g_slots[g_used];
+    sl.kid = kid;
+    (void)hipEventRecord(sl.a, s);
+    return (int)g_used++;
+}
+void sgr_prof_end(int slot, hipStream_t s) {
+    if (slot >= 0) (void)hipEventRecord(g_slots[slot].b, s);
+}
+
+extern "C" int sgr_prof_configure(uint32_t kernel_mask) {
+    g_mask = kernel_mask;
+    g_used = 0;
+    return 0;
+}
+
+// Sums the recorded durations per kernel id (SGR_K_*), clears the recordings.  Caller must have synchronised.
+extern "C" int sgr_prof_collect(double *total_ms /*[SGR_K_COUNT]*/, uint32_t *counts /*[SGR_K_COUNT]*/) {
+    for (int k = 0; k < SGR_K_COUNT; k++) { total_ms[k] = 0.0; counts[k] = 0; }
+    for (size_t i = 0; i < g_used; i++) {
+        float ms = 0.f;
+        hipError_t e = hipEventSynchronize(g_slots[i].b);
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, g_slots[i].a, g_slots[i].b);
+        if (e != hipSuccess) { sgr_set_error("sgr_prof_collect: %s", hipGetErrorString(e)); return 1; }
+        total_ms[g_slots[i].kid] += ms;
+        counts[g_slots[i].kid] += 1;
+    }
+    g_used = 0;
+    return 0;
+}

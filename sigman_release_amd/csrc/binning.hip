@@ -221,15 +221,18 @@ extern "C" int sgr_bin(const SgrProblem *pb, const float *rec, const int32_t *ra
     if (workspace_bytes < sgr_bin_workspace_bytes(R)) { sgr_set_error("sgr_bin: workspace too small"); return 1; }
     const uint32_t n = (uint32_t)R;
     const int nbx = sgr_preprocess_blocks_per_view(pb->P);
+    { SgrProfScope _p(SGR_K_DUPLICATE, stream);
     hipLaunchKernelGGL(duplicate_keys_kernel, dim3(nbx, pb->n_views), dim3(kThreads), 0, stream, pb->P, Tx, Tx * Ty,
                        (const float4 *)rec, radii, (const uint2 *)rect, block_offsets, keys_a, vals_a);
     SGR_CHECK_LAUNCH("duplicate_keys_kernel");
+    }
     const uint32_t nblocks = (n + kTileKeys - 1) / kTileKeys;
     uint32_t *hist = (uint32_t *)workspace;
     const int total_bits = 32 + bits_for(tiles_total);
     const int passes = (total_bits + kRadixBits - 1) / kRadixBits;
     uint64_t *kin = keys_a, *kout = keys_b;
     uint32_t *vin = vals_a, *vout = vals_b;
+    { SgrProfScope _ps(SGR_K_SORT, stream);
     for (int p = 0; p < passes; p++) {
         const int shift = p * kRadixBits;
         hipLaunchKernelGGL(radix_upsweep_kernel, dim3(nblocks), dim3(kThreads), 0, stream, kin, n, shift, nblocks, hist);
@@ -242,9 +245,12 @@ extern "C" int sgr_bin(const SgrProblem *pb, const float *rec, const int32_t *ra
         uint64_t *tk = kin; kin = kout; kout = tk;
         uint32_t *tv = vin; vin = vout; vout = tv;
     }
+    }
     if (result_in_b_host) *result_in_b_host = (kin == keys_b) ? 1 : 0;
+    { SgrProfScope _p(SGR_K_RANGES, stream);
     hipLaunchKernelGGL(tile_ranges_kernel, dim3((n + kThreads - 1) / kThreads), dim3(kThreads), 0, stream, kin, n,
                        (uint2 *)ranges);
     SGR_CHECK_LAUNCH("tile_ranges_kernel");
+    }
     return 0;
 }

@@ -29,6 +29,15 @@ void sgr_set_error(const char *fmt, ...);
         }                                                                                        \
     } while (0)
 
+// profiler hooks (api.hip): slot = sgr_prof_begin(kernel id, stream); launch...; sgr_prof_end(slot, stream)
+int sgr_prof_begin(int kid, hipStream_t s);
+void sgr_prof_end(int slot, hipStream_t s);
+struct SgrProfScope {
+    int slot; hipStream_t s;
+    SgrProfScope(int kid, hipStream_t st) : slot(sgr_prof_begin(kid, st)), s(st) {}
+    ~SgrProfScope() { sgr_prof_end(slot, s); }
+};
+
 // ---------------------------------------------------------------------------------------------
 // device helpers
 // ---------------------------------------------------------------------------------------------

@@ -527,12 +527,16 @@ extern "C" int sgr_preprocess_forward(const SgrProblem *pb, float *rec, int32_t 
     // chunked reads, so the sums are staged right behind the offsets (caller allocates 2*(n+1) entries).
     uint32_t *sums = block_offsets + (n + 1);
     dim3 grid(nbx, pb->n_views);
+    { SgrProfScope _p(SGR_K_PREPROCESS_FWD, stream);
     hipLaunchKernelGGL(preprocess_fwd_kernel, grid, dim3(kPreThreads), 0, stream, *pb, (float4 *)rec, radii, (uint2 *)rect,
                        clamped, sums);
     SGR_CHECK_LAUNCH("preprocess_fwd_kernel");
+    }
+    { SgrProfScope _p(SGR_K_SCAN, stream);
     hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(1024), 0, stream, sums, block_offsets, n, num_rendered,
                        (uint32_t *)(num_rendered + 1));
     SGR_CHECK_LAUNCH("scan_block_sums_kernel");
+    }
     return 0;
 }
 
@@ -548,9 +552,11 @@ extern "C" int sgr_preprocess_backward(const SgrProblem *pb, const int32_t *radi
     hipStream_t stream = (hipStream_t)stream_;
     const int nbx = sgr_preprocess_blocks_per_view(pb->P);
     dim3 grid(nbx, pb->n_views / pb->views_per_subject);
+    { SgrProfScope _p(SGR_K_PREPROCESS_BWD, stream);
     hipLaunchKernelGGL(preprocess_bwd_kernel, grid, dim3(kPreThreads), 0, stream, *pb, radii, clamped, (const float4 *)grec,
                        dL_dmeans3D, dL_dmeans2D, dL_dopacity, dL_dcolors, dL_dsh, dL_dcov3D, dL_dscales, dL_drotations);
     SGR_CHECK_LAUNCH("preprocess_bwd_kernel");
+    }
     return 0;
 }
 

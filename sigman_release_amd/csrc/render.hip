@@ -269,7 +269,9 @@ extern "C" int sgr_render_forward(const SgrProblem *pb, const uint32_t *ranges, 
     if (sgr_validate_problem(pb)) return 1;
     const int Tx = (pb->W + SGR_TILE - 1) / SGR_TILE, Ty = (pb->H + SGR_TILE - 1) / SGR_TILE;
     const uint32_t tiles = (uint32_t)Tx * Ty;
-    hipLaunchKernelGGL(render_fwd_kernel, dim3(tiles * pb->n_views), dim3(kBlock), 0, (hipStream_t)stream_, pb->W, pb->H, Tx, tiles,
+    hipStream_t stream = (hipStream_t)stream_;
+    SgrProfScope _p(SGR_K_RENDER_FWD, stream);
+    hipLaunchKernelGGL(render_fwd_kernel, dim3(tiles * pb->n_views), dim3(kBlock), 0, stream, pb->W, pb->H, Tx, tiles,
                        (const uint2 *)ranges, point_list, (const float4 *)rec, pb->bg, out_color, out_depth, out_alpha, final_T,
                        n_contrib);
     SGR_CHECK_LAUNCH("render_fwd_kernel");
@@ -285,6 +287,7 @@ extern "C" int sgr_render_backward(const SgrProblem *pb, const uint32_t *ranges,
     const uint32_t tiles = (uint32_t)Tx * Ty;
     if (pb->P > 0)
         SGR_CHECK_HIP(hipMemsetAsync(grec, 0, (size_t)pb->n_views * pb->P * SGR_REC_FLOATS * sizeof(float), stream));
+    SgrProfScope _p(SGR_K_RENDER_BWD, stream);
     hipLaunchKernelGGL(render_bwd_kernel, dim3(tiles * pb->n_views), dim3(kBlock), 0, stream, pb->W, pb->H, Tx, tiles,
                        (const uint2 *)ranges, point_list, (const float4 *)rec, pb->bg, final_T, n_contrib, grad_color, grad_depth,
                        grad_alpha, grec);

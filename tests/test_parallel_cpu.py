@@ -1,0 +1,84 @@
+"""CPU tests of the view-parallel path: world_size-2 gloo processes, render function injected (the CPU oracle stands in
+for the HIP rasterizer here -- test infrastructure only).  Checks that sharded loss/gradients equal the single-process ones."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import cases
+from sigman_release_amd import parallel
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+VIEWS = [30, 37, 65]
+
+
+class _OracleRender(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, cov3D, opacity, rgb, sv, H, W):
+        from oracle import ref
+        r = ref.forward(means3D.numpy(), opacity.numpy().reshape(-1), colors_precomp=rgb.numpy(), cov3D_precomp=cov3D.numpy(), **sv)
+        ctx.r = r
+        return torch.from_numpy(r.color.copy())
+
+    @staticmethod
+    def backward(ctx, g):
+        from oracle import ref
+        gr = ref.backward(ctx.r, g.numpy())
+        t = torch.from_numpy
+        return t(gr["means3D"]), t(gr["cov3D_precomp"]), t(gr["opacities"]), t(gr["colors_precomp"]), None, None, None
+
+
+def _render_loss_factory(st, H, W):
+    def render_loss(means3D, cov3D, opacity, rgb, my_views):
+        total = 0.0
+        for v in my_views:
+            sv = cases.single_view(st, VIEWS.index(v))
+            img = _OracleRender.apply(means3D, cov3D, opacity, rgb, sv, H, W)
+            total = total + (img.clamp(0, 1) - 0.5).abs().sum() / (3 * H * W * len(VIEWS))
+        return total
+    return render_loss
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    H = W = 48
+    inp, st = cases.humanoid(P=800, H=H, W=W, seed=5, views=tuple(VIEWS))
+    t = torch.from_numpy
+    packed = parallel.pack_attributes(t(inp["means3D"]), t(inp["cov3D_precomp"]), t(inp["opacities"]), t(inp["colors_precomp"]))
+    if rank != 0:
+        packed = torch.zeros_like(packed)               # only the producer rank holds the attributes
+    loss, grad = parallel.view_parallel_step(packed, VIEWS, _render_loss_factory(st, H, W), src=0)
+    q.put((rank, float(loss), grad.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_view_parallel_gloo_matches_single_process():
+    H = W = 48
+    inp, st = cases.humanoid(P=800, H=H, W=W, seed=5, views=tuple(VIEWS))
+    t = torch.from_numpy
+    packed = parallel.pack_attributes(t(inp["means3D"]), t(inp["cov3D_precomp"]), t(inp["opacities"]), t(inp["colors_precomp"]))
+    loss1, grad1 = parallel.view_parallel_step(packed.clone(), VIEWS, _render_loss_factory(st, H, W))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    res = [q.get(timeout=300) for _ in range(2)]
+    [p.join(timeout=60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    for rank, loss, grad in res:
+        assert abs(loss - float(loss1)) <= 1e-6 * max(1.0, abs(float(loss1)))
+        np.testing.assert_allclose(grad, grad1.numpy(), atol=1e-6 * np.abs(grad1.numpy()).max())
+
+
+def test_shard_views():
+    assert parallel.shard_views(8, 3, 8) == [3]
+    assert parallel.shard_views(90, 0, 8) == list(range(0, 90, 8))
+    assert sorted(sum((parallel.shard_views(90, r, 8) for r in range(8)), [])) == list(range(90))
+    assert parallel.shard_views(2, 5, 8) == []
