@@ -137,6 +137,26 @@ int sgr_preprocess_backward(const SgrProblem *pb, const int32_t *radii, const ui
                             float *dL_dsh, float *dL_dcov3D, float *dL_dscales, float *dL_drotations,
                             void *stream);
 
+/* ---- callers on either side of the rasterizer --------------------------------- */
+
+/*
+ * simple_knn.distCUDA2 replacement (gs.py:70): out_dist2[i] = mean of the squared distances from point i to its 3
+ * nearest OTHER points (exact).  points [P,3].  workspace: sgr_knn_workspace_bytes(P, max_cells) bytes;
+ * max_cells bounds the uniform grid (e.g. 1<<21).
+ */
+size_t sgr_knn_workspace_bytes(int32_t P, int32_t max_cells);
+int sgr_knn_dist2(int32_t P, const float *points, float *out_dist2, void *workspace, size_t workspace_bytes,
+                  int32_t max_cells, void *stream);
+
+/*
+ * Fused covariance build (gs.py:71-73 + get_covariance/strip_lowerdiag, gs.py:17-38), n = total Gaussians:
+ *   scale = (scale_raw + 1) * sqrt(max(dist2, 1e-7));  Sigma = R diag(scale^2) R^T;  cov6 = xx,xy,xz,yy,yz,zz
+ * scale_raw [n,3], rotation [n,3,3] (any 3x3 matrix, as the reference passes R_def), dist2 [n] (no gradient).
+ */
+int sgr_cov3d_forward(int32_t n, const float *scale_raw, const float *rotation, const float *dist2, float *cov6, void *stream);
+int sgr_cov3d_backward(int32_t n, const float *scale_raw, const float *rotation, const float *dist2, const float *grad_cov6,
+                       float *grad_scale_raw, float *grad_rotation, void *stream);
+
 /* ---- optional per-kernel profiler (HIP events on the launch stream; used by bench.py) -------- */
 enum {
     SGR_K_PREPROCESS_FWD = 0, SGR_K_SCAN = 1, SGR_K_DUPLICATE = 2, SGR_K_SORT = 3, SGR_K_RANGES = 4,

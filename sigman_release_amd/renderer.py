@@ -1,0 +1,88 @@
+"""`GaussianRenderer` with the interface of /root/reference/core/gaussians/gs.py:41-117, on the batched HIP path.
+
+    GaussianRenderer(opt).render(gaussians, cam_view, cam_view_proj, cam_pos, bg_color=None, scale_modifier=0.5)
+        gaussians: dict  position [B,P,3], opacity [B,P,1], scale [B,P,3] in (-1,1), cov3d [B,P,3,3], rgb [B,P,3]
+        cam_view / cam_view_proj [B,V,4,4], cam_pos [B,V,3]
+        -> {"image": [B,V,3,H,W] (clamped to [0,1], gs.py:107), "alpha": [B,V,1,H,W]}
+
+What changes underneath (same numbers out):
+  * simple_knn.distCUDA2 (gs.py:70)            -> `dist_cuda2` (HIP grid-hash exact 3-NN, sgr_knn_dist2), detached
+  * get_covariance/strip_lowerdiag (gs.py:71-73) -> `covariance_from_scale_rotation` (one fused HIP kernel + backward)
+  * the B x V Python loop (gs.py:62,75)         -> ONE batched launch chain over all B*V views
+`scale_modifier` is accepted and ignored exactly like upstream ignores it on the cov3D_precomp path.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import _cabi
+from .rasterizer import BatchedRasterizationSettings, _f32c, _ptr, _stream, rasterize_gaussians_batched
+
+_KNN_MAX_CELLS = 1 << 21
+
+
+def dist_cuda2(points: torch.Tensor) -> torch.Tensor:
+    """Drop-in for simple_knn._C.distCUDA2: [P,3] -> [P] mean squared distance to the 3 nearest other points."""
+    L = _cabi.lib()
+    if points.device.type != "cuda":
+        raise RuntimeError("dist_cuda2 needs a ROCm device tensor (there is no CPU fallback)")
+    pts = _f32c(points.detach())
+    P = pts.shape[0]
+    out = torch.empty(P, dtype=torch.float32, device=pts.device)
+    nbytes = L.sgr_knn_workspace_bytes(P, _KNN_MAX_CELLS)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=pts.device)
+    _cabi.check(L.sgr_knn_dist2(P, _ptr(pts), _ptr(out), _ptr(ws), nbytes, _KNN_MAX_CELLS, _stream()), "sgr_knn_dist2")
+    return out
+
+
+class _Cov3D(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, scale_raw, rotation, dist2):
+        L = _cabi.lib()
+        scale_raw, rotation, dist2 = _f32c(scale_raw), _f32c(rotation), _f32c(dist2)
+        n = dist2.numel()
+        cov = torch.empty(*dist2.shape, 6, dtype=torch.float32, device=dist2.device)
+        _cabi.check(L.sgr_cov3d_forward(n, _ptr(scale_raw), _ptr(rotation), _ptr(dist2), _ptr(cov), _stream()), "sgr_cov3d_forward")
+        ctx.save_for_backward(scale_raw, rotation, dist2)
+        return cov
+
+    @staticmethod
+    def backward(ctx, g):
+        L = _cabi.lib()
+        scale_raw, rotation, dist2 = ctx.saved_tensors
+        g = _f32c(g)
+        gs, gr = torch.empty_like(scale_raw), torch.empty_like(rotation)
+        _cabi.check(L.sgr_cov3d_backward(dist2.numel(), _ptr(scale_raw), _ptr(rotation), _ptr(dist2), _ptr(g), _ptr(gs), _ptr(gr),
+                                         _stream()), "sgr_cov3d_backward")
+        return gs, gr, None
+
+
+def covariance_from_scale_rotation(scale_raw, rotation, dist2):
+    """[...,3], [...,3,3], [...] -> [...,6]: strip_lowerdiag(R diag(((s+1)*sqrt(max(dist2,1e-7)))^2) R^T)."""
+    if scale_raw.device.type != "cuda":
+        raise RuntimeError("covariance_from_scale_rotation needs ROCm device tensors (there is no CPU fallback)")
+    return _Cov3D.apply(scale_raw, rotation, dist2)
+
+
+class GaussianRenderer:
+    def __init__(self, opt, device="cuda"):
+        self.opt = opt
+        self.bg_color = torch.tensor([1, 1, 1], dtype=torch.float32, device=device)
+        self.tan_half_fov = float(np.tan(0.5 * self.opt.FoVy))
+
+    def render(self, gaussians, cam_view, cam_view_proj, cam_pos, bg_color=None, scale_modifier=0.5):
+        B, V = cam_view.shape[:2]
+        H, W = self.opt.output_size_h, self.opt.output_size_w
+        position = gaussians["position"].float()
+        P = position.shape[1]
+        with torch.no_grad():
+            dist2 = torch.stack([dist_cuda2(position[b]) for b in range(B)], 0)          # [B,P], detached (gs.py:71)
+        cov3D = covariance_from_scale_rotation(gaussians["scale"].float(), gaussians["cov3d"].float(), dist2)   # [B,P,6]
+        st = BatchedRasterizationSettings(H, W, self.tan_half_fov, self.tan_half_fov,
+                                          self.bg_color if bg_color is None else bg_color, scale_modifier,
+                                          cam_view.reshape(B * V, 4, 4), cam_view_proj.reshape(B * V, 4, 4), 0,
+                                          cam_pos.reshape(B * V, 3), V)
+        color, radii, depth, alpha = rasterize_gaussians_batched(position, None, None, gaussians["rgb"].float(),
+                                                                 gaussians["opacity"].float(), None, None, cov3D, st)
+        return {"image": color.clamp(0, 1).view(B, V, 3, H, W), "alpha": alpha.view(B, V, 1, H, W)}
