@@ -109,21 +109,33 @@ int sgr_bin(const SgrProblem *pb, const float *rec, const int32_t *radii, const 
             uint32_t *vals_b, void *workspace, size_t workspace_bytes, uint32_t *ranges,
             int32_t *result_in_b_host, void *stream);
 
+/* number of bucket slots per quadrant for the auxiliary forward outputs: (R >> 6) + tiles_total + 1 */
+uint64_t sgr_bucket_slots(uint64_t R, uint64_t tiles_total);
+
 /*
  * F6: per-tile front-to-back compositing.  out_color [n_views,3,H,W], out_depth [n_views,1,H,W],
  * out_alpha [n_views,1,H,W], final_T f32 [n_views,H,W], n_contrib u32 [n_views,H,W].
+ * Optional auxiliary outputs for the bucket-parallel backward (pass all four or none; NS = sgr_bucket_slots(R, n_views*tiles)):
+ *   aux_compact  u32 [4][R][2]   per (tile, 8x8 quadrant) culled list: (record id, index in the tile list)
+ *   aux_ckpt_tc  f32 [4*NS][64][4], aux_ckpt_da f32 [4*NS][64][2]   per-pixel (T,C) / (D,A) at the start of each 64-Gaussian bucket
+ *   aux_desc     u32 [4*NS][2]   bucket descriptors (zeroed by this call)
  */
 int sgr_render_forward(const SgrProblem *pb, const uint32_t *ranges, const uint32_t *point_list, const float *rec,
                        float *out_color, float *out_depth, float *out_alpha, float *final_T, uint32_t *n_contrib,
-                       void *stream);
+                       uint64_t R, void *aux_compact, void *aux_ckpt_tc, void *aux_ckpt_da, void *aux_desc, void *stream);
 
 /*
- * B1: per-pixel reverse walk.  grad_depth / grad_alpha may be NULL (treated as zero).
- * grec [n_views*P*12] is ZEROED by this call and then accumulated with float atomics.
+ * B1: gradient records from the image gradients.  grad_depth / grad_alpha may be NULL (treated as zero).
+ * grec [n_views*P*12] is ZEROED by this call and then accumulated with hardware float atomics.
+ * With the forward's aux buffers (and the forward's output images) the bucket-parallel kernel runs: one wave per
+ * 64-Gaussian bucket, lanes own Gaussians, pixel states rotate through the wave (no reductions, no LDS).
+ * Without them (NULL) the pixel-parallel reverse walk runs (needs final_T).
  */
 int sgr_render_backward(const SgrProblem *pb, const uint32_t *ranges, const uint32_t *point_list, const float *rec,
-                        const float *final_T, const uint32_t *n_contrib, const float *grad_color,
-                        const float *grad_depth, const float *grad_alpha, float *grec, void *stream);
+                        const float *final_T, const uint32_t *n_contrib, const float *out_color, const float *out_depth,
+                        const float *out_alpha, const float *grad_color, const float *grad_depth, const float *grad_alpha,
+                        uint64_t R, const void *aux_compact, const void *aux_ckpt_tc, const void *aux_ckpt_da,
+                        const void *aux_desc, float *grec, void *stream);
 
 /*
  * B2 + B3: per-(view,Gaussian) gradient records -> per-subject parameter gradients, summed over the

@@ -36,8 +36,9 @@ _SIGNATURES = {
     "sgr_bin": (C.c_int, [C.POINTER(SgrProblem), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p,
                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_int32),
                           C.c_void_p]),
-    "sgr_render_forward": (C.c_int, [C.POINTER(SgrProblem)] + [C.c_void_p] * 9),
-    "sgr_render_backward": (C.c_int, [C.POINTER(SgrProblem)] + [C.c_void_p] * 10),
+    "sgr_bucket_slots": (C.c_uint64, [C.c_uint64, C.c_uint64]),
+    "sgr_render_forward": (C.c_int, [C.POINTER(SgrProblem)] + [C.c_void_p] * 8 + [C.c_uint64] + [C.c_void_p] * 5),
+    "sgr_render_backward": (C.c_int, [C.POINTER(SgrProblem)] + [C.c_void_p] * 11 + [C.c_uint64] + [C.c_void_p] * 6),
     "sgr_preprocess_backward": (C.c_int, [C.POINTER(SgrProblem)] + [C.c_void_p] * 12),
     "sgr_mark_visible": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sgr_knn_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),

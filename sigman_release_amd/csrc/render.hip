@@ -38,18 +38,31 @@ __device__ __forceinline__ uint32_t cull_mask(const float4 &a, const float4 &c, 
     return (uint32_t)(xl && yt) | ((uint32_t)(xr && yt) << 1) | ((uint32_t)(xl && yb) << 2) | ((uint32_t)(xr && yb) << 3);
 }
 
+// auxiliary forward outputs that feed the bucket-parallel backward (all optional; see sgr_render_forward)
+struct FwdAux {
+    uint2 *compact;       // [4][R]  per (tile, quadrant) culled list in order: (record id, 0-based index in the tile list)
+    float4 *ckpt_tc;      // [4*NS][64]  per bucket, per pixel: T, C0, C1, C2 at the START of the bucket
+    float2 *ckpt_da;      // [4*NS][64]  D, A
+    uint2 *desc;          // [4*NS]  (global tile id, (bucket << 7) | count); count == 0 -> slot unused
+    uint32_t R, NS;
+};
+
 // -------------------------------------------------------------------------------------------------
-// F6
+// F6.  AUX=true additionally records what the bucket-parallel backward needs: the per-quadrant culled
+// lists, a per-pixel state checkpoint every 64 surviving Gaussians, and one descriptor per bucket.
 // -------------------------------------------------------------------------------------------------
+template <bool AUX>
 __global__ __launch_bounds__(kBlock) void render_fwd_kernel(int W, int H, int Tx, uint32_t tiles_per_view,
                                                             const uint2 *__restrict__ ranges,
                                                             const uint32_t *__restrict__ point_list,
                                                             const float4 *__restrict__ rec, const float *__restrict__ bg,
                                                             float *__restrict__ out_color, float *__restrict__ out_depth,
                                                             float *__restrict__ out_alpha, float *__restrict__ final_T,
-                                                            uint32_t *__restrict__ n_contrib) {
-    __shared__ float4 sA[kBlock], sB[kBlock], sC[kBlock];
+                                                            uint32_t *__restrict__ n_contrib, FwdAux aux) {
+    __shared__ float4 sA[kBlock + 1], sB[kBlock + 1], sC[kBlock + 1];   // entry 256 = null Gaussian (opacity 0)
     __shared__ uint32_t sMask[kBlock];
+    __shared__ uint32_t sId[kBlock];
+    __shared__ __attribute__((aligned(8))) uint16_t sList[4][kBlock + 8];
     const uint32_t bid = sgr_xcd_remap(blockIdx.x, gridDim.x);
     const uint32_t view = bid / tiles_per_view, tile = bid - view * tiles_per_view;
     const uint32_t tx = tile % Tx, ty = tile / Tx;
@@ -60,51 +73,88 @@ __global__ __launch_bounds__(kBlock) void render_fwd_kernel(int W, int H, int Tx
     const bool inside = px < W && py < H;
     const float pxf = (float)px, pyf = (float)py;
     const float x0 = (float)(tx * 16), y0 = (float)(ty * 16);
+    const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     bool done = !inside;
     float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f, D = 0.f, A = 0.f;
-    uint32_t last = 0;
+    uint32_t last = 0, lastk = 0;
+    uint32_t kbase = 0;                                  // survivors of this wave's quadrant in earlier batches
     const int n = (int)(range.y - range.x);
     const int rounds = (n + kBlock - 1) / kBlock;
+    const size_t slot0 = (size_t)wave * aux.NS + (range.x >> 6) + bid;     // first bucket slot of (tile, quadrant)
+    if (t == 0) { sA[kBlock] = make_float4(0.f, 0.f, 0.f, 0.f); sB[kBlock] = sA[kBlock]; sC[kBlock] = sA[kBlock]; }
     for (int r = 0; r < rounds; r++) {
         if (__syncthreads_count(done) == kBlock) break;      // also the barrier that protects LDS reuse
         const int idx = r * kBlock + t;
         uint32_t m = 0;
         if (idx < n) {
-            const size_t id = point_list[range.x + idx];
-            const float4 a = rec[id * 3 + 0], b = rec[id * 3 + 1], c = rec[id * 3 + 2];
+            const uint32_t id = point_list[range.x + idx];
+            const float4 a = rec[(size_t)id * 3 + 0], b = rec[(size_t)id * 3 + 1], c = rec[(size_t)id * 3 + 2];
             sA[t] = a; sB[t] = b; sC[t] = c;
+            sId[t] = id;
             m = cull_mask(a, c, x0, y0);
         }
         sMask[t] = m;
         __syncthreads();
+        // ---- wave-private culled list of this batch (ballot + prefix popcount), padded with the null entry
+        uint32_t cnt = 0;
+#pragma unroll
+        for (int ch = 0; ch < 4; ch++) {
+            const bool bit = (sMask[ch * 64 + lane] >> wave) & 1u;
+            const uint64_t bal = __ballot(bit);
+            if (bit) sList[wave][cnt + (uint32_t)__popcll(bal & lt_mask)] = (uint16_t)(ch * 64 + lane);
+            cnt += (uint32_t)__popcll(bal);
+        }
+        if (lane < 4) sList[wave][cnt + lane] = (uint16_t)kBlock;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         uint64_t active = __ballot(!done);
-        for (int ch = 0; ch < 4 && active; ch++) {
-            uint64_t bal = __ballot((sMask[ch * 64 + lane] >> wave) & 1u);
-            while (bal && active) {
-                const int bit = __builtin_ctzll(bal);
-                bal &= bal - 1;
-                const int j = ch * 64 + bit;
-                const float4 a = sA[j], b = sB[j];
-                const float4 c = sC[j];
-                const float dx = a.x - pxf, dy = a.y - pyf;
-                const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
-                const float alpha = fminf(0.99f, b.y * __expf(power));
-                if (!done && power <= 0.f && alpha >= (1.0f / 255.0f)) {
-                    const float test_T = T * (1.f - alpha);
+        if (AUX && active) {
+            uint2 *dst = aux.compact + (size_t)wave * aux.R + range.x + kbase;
+            for (uint32_t g = lane; g < cnt; g += 64) {
+                const uint32_t j = sList[wave][g];
+                dst[g] = make_uint2(sId[j], (uint32_t)(r * kBlock) + j);
+            }
+        }
+        for (uint32_t g = 0; g < cnt && active; g += 4) {
+            const ushort4 jj = *reinterpret_cast<const ushort4 *>(&sList[wave][g]);
+            const int js[4] = {jj.x, jj.y, jj.z, jj.w};
+            float4 a[4], b[4], c[4];
+            float alpha[4], power[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) { a[u] = sA[js[u]]; b[u] = sB[js[u]]; c[u] = sC[js[u]]; }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const float dx = a[u].x - pxf, dy = a[u].y - pyf;
+                power[u] = -0.5f * (a[u].z * dx * dx + b[u].x * dy * dy) - a[u].w * dx * dy;
+                alpha[u] = fminf(0.99f, b[u].y * __expf(power[u]));
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t ord = kbase + g + u;                       // ordinal of this survivor in the quadrant list
+                if (AUX && (ord & 63u) == 0u && ord != 0u && g + u < cnt) {
+                    const size_t s = (slot0 + (ord >> 6)) * 64 + lane;
+                    aux.ckpt_tc[s] = make_float4(T, C0, C1, C2);
+                    aux.ckpt_da[s] = make_float2(D, A);
+                }
+                if (!done && power[u] <= 0.f && alpha[u] >= (1.0f / 255.0f)) {
+                    const float test_T = T * (1.f - alpha[u]);
                     if (test_T < 0.0001f) {
                         done = true;                          // the crossing Gaussian is NOT composited
                     } else {
-                        const float w = alpha * T;
-                        C0 += b.w * w; C1 += c.x * w; C2 += c.y * w;
-                        D += b.z * w;
+                        const float w = alpha[u] * T;
+                        C0 += b[u].w * w; C1 += c[u].x * w; C2 += c[u].y * w;
+                        D += b[u].z * w;
                         A += w;
                         T = test_T;
-                        last = (uint32_t)(r * kBlock + j + 1);
+                        last = (uint32_t)(r * kBlock + js[u] + 1);
+                        lastk = ord + 1;
                     }
                 }
-                active = __ballot(!done);
             }
+            active = __ballot(!done);
         }
+        kbase += cnt;
     }
     if (inside) {
         const size_t hw = (size_t)H * W;
@@ -117,6 +167,14 @@ __global__ __launch_bounds__(kBlock) void render_fwd_kernel(int W, int H, int Tx
         out_color[(vb * 3) + 2 * hw + pix] = C2 + T * bg[2];
         out_depth[vb + pix] = D;
         out_alpha[vb + pix] = A;
+    }
+    if (AUX) {
+        uint32_t kmax = lastk;                                 // survivors up to the last one that blended anywhere in the quadrant
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, off, 64));
+        const uint32_t nb = (kmax + 63u) >> 6;
+        for (uint32_t bk = lane; bk < nb; bk += 64)
+            aux.desc[slot0 + bk] = make_uint2(bid, (bk << 7) | min(64u, kmax - (bk << 6)));
     }
 }
 
@@ -259,35 +317,201 @@ __global__ __launch_bounds__(kBlock) void render_bwd_kernel(int W, int H, int Tx
     }
 }
 
+
+// -------------------------------------------------------------------------------------------------
+// B1 (v2): bucket-parallel "systolic" backward.  One wave = one bucket of <= 64 consecutive surviving
+// Gaussians of one (tile, quadrant) against that quadrant's 64 pixels.  LANES OWN GAUSSIANS: each lane keeps
+// its Gaussian's record and its 10 gradient accumulators in registers for the whole kernel, so there is
+// no cross-lane reduction and no LDS at all.  The 64 pixel states (position, n_contrib, upstream grads, and
+// the running transmittance / composited-so-far dot product) travel through the lanes by a full-wave DPP
+// rotate (wave_ror:1, available on the gfx9 family) -- pixel p enters lane 0 at step p and reaches lane i at
+// step p+i, i.e. in front-to-back order, starting from the forward pass's checkpoint for this bucket.
+// All buckets of a frame run concurrently (thousands of independent waves instead of one serial walk per tile),
+// and each (tile-quadrant, Gaussian) pair costs ONE set of hardware float atomics.
+//
+// Math (front-to-back form of the published reverse walk), per pixel with g = upstream gradient vector over
+// (r,g,b,depth,alpha), f_j = (r_j,g_j,b_j,depth_j,1), q_j = f_j . g, w_j = alpha_j T_j:
+//   dL/dalpha_j = T_j q_j - (O - Pre_j - w_j q_j) / (1 - alpha_j),   O = out . g (includes the T_final*bg term),
+//   Pre_j = sum_{k<j} w_k q_k  (running), T_{j+1} = T_j (1 - alpha_j)  (bit-identical to the forward's T sequence).
+// -------------------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ float rot(float v) { return sgr_dpp<CTRL>(v); }
+
+template <bool HAS_DA>
+__global__ __launch_bounds__(kBlock) void render_bwd_bucket_kernel(int W, int H, int Tx, uint32_t tiles_per_view,
+                                                                   const uint2 *__restrict__ ranges,
+                                                                   const float4 *__restrict__ rec,
+                                                                   const uint32_t *__restrict__ n_contrib,
+                                                                   const float *__restrict__ out_color,
+                                                                   const float *__restrict__ out_depth,
+                                                                   const float *__restrict__ out_alpha,
+                                                                   const float *__restrict__ gC, const float *__restrict__ gD,
+                                                                   const float *__restrict__ gA, FwdAux aux,
+                                                                   float *__restrict__ grec) {
+    const int lane = threadIdx.x & 63;
+    const size_t slot = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (slot >= (size_t)4 * aux.NS) return;
+    const uint2 desc = aux.desc[slot];
+    const uint32_t count = desc.y & 127u;
+    if (count == 0) return;                                   // wave-uniform: unused bucket slot
+    const uint32_t bucket = desc.y >> 7, bid = desc.x;
+    const uint32_t q = (uint32_t)(slot / aux.NS);
+    const uint32_t view = bid / tiles_per_view, tile = bid - view * tiles_per_view;
+    const uint32_t tx = tile % Tx, ty = tile / Tx;
+    const uint32_t rx = ranges[bid].x;
+    // ---- my Gaussian
+    const bool has_g = (uint32_t)lane < count;
+    uint2 e = make_uint2(0u, 0xFFFFFFFFu);
+    if (has_g) e = aux.compact[(size_t)q * aux.R + rx + (bucket << 6) + lane];
+    const uint32_t gidx = e.y;
+    float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra, rc = ra;
+    if (has_g) { ra = rec[(size_t)e.x * 3 + 0]; rb = rec[(size_t)e.x * 3 + 1]; rc = rec[(size_t)e.x * 3 + 2]; }
+    const float gx = ra.x, gy = ra.y, cxx = ra.z, cxy = ra.w, cyy = rb.x, op = rb.y, gdep = rb.z, cr = rb.w, cg = rc.x, cb = rc.y;
+    // ---- the pixel that starts in my lane: p = (64 - lane) mod 64, so that wave_ror:1 brings pixel p to lane 0 at step p
+    const int p = (64 - lane) & 63;
+    const int px = (int)tx * 16 + (int)(q & 1u) * 8 + (p & 7);
+    const int py = (int)ty * 16 + (int)(q >> 1) * 8 + (p >> 3);
+    const bool inside = px < W && py < H;
+    const size_t hw = (size_t)H * W;
+    const size_t pix = (size_t)py * W + px;
+    const size_t vb = (size_t)view * hw;
+    float pxf = (float)px, pyf = (float)py;
+    float g0 = 0.f, g1 = 0.f, g2 = 0.f, gd = 0.f, ga = 0.f, O = 0.f, T = 1.f, Pre = 0.f;
+    uint32_t last = 0;
+    if (inside) {
+        last = n_contrib[vb + pix];
+        g0 = gC[vb * 3 + pix]; g1 = gC[vb * 3 + hw + pix]; g2 = gC[vb * 3 + 2 * hw + pix];
+        O = out_color[vb * 3 + pix] * g0 + out_color[vb * 3 + hw + pix] * g1 + out_color[vb * 3 + 2 * hw + pix] * g2;
+        if (HAS_DA) {
+            if (gD) gd = gD[vb + pix];
+            if (gA) ga = gA[vb + pix];
+            O += out_depth[vb + pix] * gd + out_alpha[vb + pix] * ga;
+        }
+        if (bucket) {
+            const float4 tc = aux.ckpt_tc[slot * 64 + p];
+            T = tc.x;
+            Pre = tc.y * g0 + tc.z * g1 + tc.w * g2;
+            if (HAS_DA) { const float2 da = aux.ckpt_da[slot * 64 + p]; Pre += da.x * gd + da.y * ga; }
+        }
+    }
+    float lastf = __uint_as_float(last);
+    const float ddelx_dx = 0.5f * (float)W, ddely_dy = 0.5f * (float)H;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f, a5 = 0.f, a6 = 0.f, a7 = 0.f, a8 = 0.f, a9 = 0.f;
+    const int nsteps = 63 + (int)count;
+    for (int s = 0; s < nsteps; s++) {
+        const uint32_t dlt = (uint32_t)(s - lane);              // pixel (s - lane) is in my lane iff 0 <= s - lane < 64
+        const float dx = gx - pxf, dy = gy - pyf;
+        const float power = -0.5f * (cxx * dx * dx + cyy * dy * dy) - cxy * dx * dy;
+        const float G = __expf(power);
+        const float alpha = fminf(0.99f, op * G);
+        const bool valid = has_g && dlt < 64u && gidx < __float_as_uint(lastf) && power <= 0.f && alpha >= (1.0f / 255.0f);
+        if (valid) {
+            const float w = alpha * T;
+            float qj = cr * g0 + cg * g1 + cb * g2;
+            if (HAS_DA) qj += gdep * gd + ga;
+            const float wq = w * qj;
+            const float inv = 1.f / (1.f - alpha);
+            const float dL_dalpha = T * qj - (O - Pre - wq) * inv;
+            Pre += wq;
+            T = T * (1.f - alpha);
+            const float dL_dG = op * dL_dalpha;               // differentiates through op*G even when capped (as upstream)
+            const float gdx = G * dx, gdy = G * dy;
+            a0 += dL_dG * (-gdx * cxx - gdy * cxy) * ddelx_dx;
+            a1 += dL_dG * (-gdy * cyy - gdx * cxy) * ddely_dy;
+            a2 += -0.5f * gdx * dx * dL_dG;
+            a3 += -0.5f * gdx * dy * dL_dG;
+            a4 += -0.5f * gdy * dy * dL_dG;
+            a5 += G * dL_dalpha;
+            if (HAS_DA) a6 += w * gd;
+            a7 += w * g0; a8 += w * g1; a9 += w * g2;
+        }
+        // ---- systolic shift: every pixel state moves one lane up (lane 63 wraps to lane 0, masked out by `dlt`)
+        pxf = rot<SGR_DPP_WAVE_ROR1>(pxf); pyf = rot<SGR_DPP_WAVE_ROR1>(pyf); lastf = rot<SGR_DPP_WAVE_ROR1>(lastf);
+        g0 = rot<SGR_DPP_WAVE_ROR1>(g0); g1 = rot<SGR_DPP_WAVE_ROR1>(g1); g2 = rot<SGR_DPP_WAVE_ROR1>(g2);
+        O = rot<SGR_DPP_WAVE_ROR1>(O); T = rot<SGR_DPP_WAVE_ROR1>(T); Pre = rot<SGR_DPP_WAVE_ROR1>(Pre);
+        if (HAS_DA) { gd = rot<SGR_DPP_WAVE_ROR1>(gd); ga = rot<SGR_DPP_WAVE_ROR1>(ga); }
+    }
+    if (has_g) {
+        float *g = grec + (size_t)e.x * SGR_REC_FLOATS;
+        if (a0 != 0.f) sgr_atomic_add(g + 0, a0);
+        if (a1 != 0.f) sgr_atomic_add(g + 1, a1);
+        if (a2 != 0.f) sgr_atomic_add(g + 2, a2);
+        if (a3 != 0.f) sgr_atomic_add(g + 3, a3);
+        if (a4 != 0.f) sgr_atomic_add(g + 4, a4);
+        if (a5 != 0.f) sgr_atomic_add(g + 5, a5);
+        if (HAS_DA && a6 != 0.f) sgr_atomic_add(g + 6, a6);
+        if (a7 != 0.f) sgr_atomic_add(g + 7, a7);
+        if (a8 != 0.f) sgr_atomic_add(g + 8, a8);
+        if (a9 != 0.f) sgr_atomic_add(g + 9, a9);
+    }
+}
+
 }  // namespace
 
 int sgr_validate_problem(const SgrProblem *pb);
 
+extern "C" uint64_t sgr_bucket_slots(uint64_t R, uint64_t tiles_total) { return (R >> 6) + tiles_total + 1; }
+
+static FwdAux make_aux(void *compact, void *ckpt_tc, void *ckpt_da, void *desc, uint64_t R, uint64_t tiles_total) {
+    FwdAux a;
+    a.compact = (uint2 *)compact; a.ckpt_tc = (float4 *)ckpt_tc; a.ckpt_da = (float2 *)ckpt_da; a.desc = (uint2 *)desc;
+    a.R = (uint32_t)R; a.NS = (uint32_t)sgr_bucket_slots(R, tiles_total);
+    return a;
+}
+
 extern "C" int sgr_render_forward(const SgrProblem *pb, const uint32_t *ranges, const uint32_t *point_list, const float *rec,
                                   float *out_color, float *out_depth, float *out_alpha, float *final_T, uint32_t *n_contrib,
+                                  uint64_t R, void *aux_compact, void *aux_ckpt_tc, void *aux_ckpt_da, void *aux_desc,
                                   void *stream_) {
     if (sgr_validate_problem(pb)) return 1;
     const int Tx = (pb->W + SGR_TILE - 1) / SGR_TILE, Ty = (pb->H + SGR_TILE - 1) / SGR_TILE;
     const uint32_t tiles = (uint32_t)Tx * Ty;
     hipStream_t stream = (hipStream_t)stream_;
+    const bool use_aux = aux_compact && aux_ckpt_tc && aux_ckpt_da && aux_desc;
+    FwdAux aux = make_aux(aux_compact, aux_ckpt_tc, aux_ckpt_da, aux_desc, R, (uint64_t)tiles * pb->n_views);
+    if (use_aux) SGR_CHECK_HIP(hipMemsetAsync(aux_desc, 0, (size_t)4 * aux.NS * sizeof(uint2), stream));
     SgrProfScope _p(SGR_K_RENDER_FWD, stream);
-    hipLaunchKernelGGL(render_fwd_kernel, dim3(tiles * pb->n_views), dim3(kBlock), 0, stream, pb->W, pb->H, Tx, tiles,
-                       (const uint2 *)ranges, point_list, (const float4 *)rec, pb->bg, out_color, out_depth, out_alpha, final_T,
-                       n_contrib);
+    if (use_aux)
+        hipLaunchKernelGGL(render_fwd_kernel<true>, dim3(tiles * pb->n_views), dim3(kBlock), 0, stream, pb->W, pb->H, Tx, tiles,
+                           (const uint2 *)ranges, point_list, (const float4 *)rec, pb->bg, out_color, out_depth, out_alpha,
+                           final_T, n_contrib, aux);
+    else
+        hipLaunchKernelGGL(render_fwd_kernel<false>, dim3(tiles * pb->n_views), dim3(kBlock), 0, stream, pb->W, pb->H, Tx, tiles,
+                           (const uint2 *)ranges, point_list, (const float4 *)rec, pb->bg, out_color, out_depth, out_alpha,
+                           final_T, n_contrib, aux);
     SGR_CHECK_LAUNCH("render_fwd_kernel");
     return 0;
 }
 
 extern "C" int sgr_render_backward(const SgrProblem *pb, const uint32_t *ranges, const uint32_t *point_list, const float *rec,
-                                   const float *final_T, const uint32_t *n_contrib, const float *grad_color,
-                                   const float *grad_depth, const float *grad_alpha, float *grec, void *stream_) {
+                                   const float *final_T, const uint32_t *n_contrib, const float *out_color,
+                                   const float *out_depth, const float *out_alpha, const float *grad_color,
+                                   const float *grad_depth, const float *grad_alpha, uint64_t R, const void *aux_compact,
+                                   const void *aux_ckpt_tc, const void *aux_ckpt_da, const void *aux_desc, float *grec,
+                                   void *stream_) {
     if (sgr_validate_problem(pb)) return 1;
     hipStream_t stream = (hipStream_t)stream_;
     const int Tx = (pb->W + SGR_TILE - 1) / SGR_TILE, Ty = (pb->H + SGR_TILE - 1) / SGR_TILE;
     const uint32_t tiles = (uint32_t)Tx * Ty;
     if (pb->P > 0)
         SGR_CHECK_HIP(hipMemsetAsync(grec, 0, (size_t)pb->n_views * pb->P * SGR_REC_FLOATS * sizeof(float), stream));
+    const bool use_aux = aux_compact && aux_ckpt_tc && aux_ckpt_da && aux_desc && out_color && out_depth && out_alpha;
     SgrProfScope _p(SGR_K_RENDER_BWD, stream);
+    if (use_aux) {
+        FwdAux aux = make_aux((void *)aux_compact, (void *)aux_ckpt_tc, (void *)aux_ckpt_da, (void *)aux_desc, R,
+                              (uint64_t)tiles * pb->n_views);
+        const uint32_t nblocks = aux.NS;                        // 4*NS waves, 4 waves per workgroup
+        if (grad_depth || grad_alpha)
+            hipLaunchKernelGGL(render_bwd_bucket_kernel<true>, dim3(nblocks), dim3(kBlock), 0, stream, pb->W, pb->H, Tx, tiles,
+                               (const uint2 *)ranges, (const float4 *)rec, n_contrib, out_color, out_depth, out_alpha, grad_color,
+                               grad_depth, grad_alpha, aux, grec);
+        else
+            hipLaunchKernelGGL(render_bwd_bucket_kernel<false>, dim3(nblocks), dim3(kBlock), 0, stream, pb->W, pb->H, Tx, tiles,
+                               (const uint2 *)ranges, (const float4 *)rec, n_contrib, out_color, out_depth, out_alpha, grad_color,
+                               grad_depth, grad_alpha, aux, grec);
+        SGR_CHECK_LAUNCH("render_bwd_bucket_kernel");
+        return 0;
+    }
     hipLaunchKernelGGL(render_bwd_kernel, dim3(tiles * pb->n_views), dim3(kBlock), 0, stream, pb->W, pb->H, Tx, tiles,
                        (const uint2 *)ranges, point_list, (const float4 *)rec, pb->bg, final_T, n_contrib, grad_color, grad_depth,
                        grad_alpha, grec);

@@ -14,6 +14,7 @@ The batched entry point `rasterize_gaussians_batched` renders all B*V views of a
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import NamedTuple, Optional
 
 import torch
@@ -52,6 +53,10 @@ class BatchedRasterizationSettings(NamedTuple):
     debug: bool = False
 
 
+# SIGMAN_BWD_V1=1 selects the pixel-parallel backward (no auxiliary forward outputs) for A/B comparisons
+_USE_BWD_V1 = os.environ.get("SIGMAN_BWD_V1", "0") == "1"
+
+
 def _ptr(t: Optional[torch.Tensor]):
     return None if t is None or t.numel() == 0 else t.data_ptr()
 
@@ -69,7 +74,7 @@ def _f32c(t: torch.Tensor) -> torch.Tensor:
 class _Ctx:
     """Plain holder for the forward's device buffers (== upstream geomBuffer / binningBuffer / imgBuffer)."""
     __slots__ = ("pb", "keep", "rec", "radii", "rect", "clamped", "point_list", "keys", "ranges", "final_T", "n_contrib",
-                 "num_rendered", "dims")
+                 "num_rendered", "dims", "aux", "images")
 
 
 def _make_problem(means3D, opacities, colors_precomp, shs, cov3D_precomp, scales, rotations, st: BatchedRasterizationSettings):
@@ -132,8 +137,15 @@ def _forward_impl(means3D, opacities, colors_precomp, shs, cov3D_precomp, scales
                           _ptr(vals_a), _ptr(vals_b), _ptr(ws), ws_bytes, _ptr(ranges), C.byref(in_b), stream), "sgr_bin")
     point_list = vals_b if in_b.value else vals_a
     keys = keys_b if in_b.value else keys_a
+    aux = None
+    if need_ctx and not keep_keys and R > 0 and not _USE_BWD_V1:
+        NS = L.sgr_bucket_slots(R, nv * tiles)
+        aux = (torch.empty(4 * R * 2, dtype=i32, device=dev), torch.empty(4 * NS * 64 * 4, dtype=f32, device=dev),
+               torch.empty(4 * NS * 64 * 2, dtype=f32, device=dev), torch.empty(4 * NS * 2, dtype=i32, device=dev))
+    ax = aux if aux is not None else (None, None, None, None)
     _cabi.check(L.sgr_render_forward(C.byref(pb), _ptr(ranges), _ptr(point_list), _ptr(rec), _ptr(color), _ptr(depth),
-                                     _ptr(alpha), _ptr(final_T), _ptr(n_contrib), stream), "sgr_render_forward")
+                                     _ptr(alpha), _ptr(final_T), _ptr(n_contrib), R, _ptr(ax[0]), _ptr(ax[1]), _ptr(ax[2]),
+                                     _ptr(ax[3]), stream), "sgr_render_forward")
     radii_out = radii[: nv * P].view(nv, P)
     ctx = None
     if need_ctx:
@@ -145,6 +157,8 @@ def _forward_impl(means3D, opacities, colors_precomp, shs, cov3D_precomp, scales
         ctx.num_rendered = R
         ctx.dims = (S, P, nv, H, W)
         ctx.keep = (st.viewmatrix, st.projmatrix, st.campos, st.bg)
+        ctx.aux = aux
+        ctx.images = (color, depth, alpha)
     return color, radii_out, depth, alpha, ctx
 
 
@@ -160,8 +174,11 @@ def _backward_impl(ctx: _Ctx, means3D, opacities, colors_precomp, shs, cov3D_pre
     gC = _f32c(grad_color)
     gD = None if grad_depth is None else _f32c(grad_depth)
     gA = None if grad_alpha is None else _f32c(grad_alpha)
+    ax = ctx.aux if ctx.aux is not None else (None, None, None, None)
+    img = ctx.images
     _cabi.check(L.sgr_render_backward(C.byref(pb), _ptr(ctx.ranges), _ptr(ctx.point_list), _ptr(ctx.rec), _ptr(ctx.final_T),
-                                      _ptr(ctx.n_contrib), _ptr(gC), _ptr(gD), _ptr(gA), _ptr(grec), stream),
+                                      _ptr(ctx.n_contrib), _ptr(img[0]), _ptr(img[1]), _ptr(img[2]), _ptr(gC), _ptr(gD), _ptr(gA),
+                                      ctx.num_rendered, _ptr(ax[0]), _ptr(ax[1]), _ptr(ax[2]), _ptr(ax[3]), _ptr(grec), stream),
                 "sgr_render_backward")
     d_means3D = torch.empty(S, P, 3, dtype=f32, device=dev)
     d_means2D = torch.empty(nv, P, 3, dtype=f32, device=dev)
