@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libsigman_gsplat.so")
+LIB_PATH = os.environ.get("SIGMAN_GSPLAT_LIB") or os.path.join(_HERE, "lib", "libsigman_gsplat.so")   # env override: dev A/B builds only
 _lib = None
 
 SGR_REC_FLOATS = 12

@@ -21,8 +21,9 @@ namespace {
 constexpr int kThreads = 256;
 constexpr int kRadixBits = 8;
 constexpr int kRadix = 1 << kRadixBits;
-constexpr int kItems = 16;                       // keys per thread per block
-constexpr int kTileKeys = kThreads * kItems;     // 4096 keys per workgroup
+// keys per thread per workgroup: small inputs (one 512^2 view: R ~ 2e5) want many small workgroups to fill 256 CUs,
+// large batches want fewer, longer ones (less histogram traffic)
+constexpr int kItemsSmall = 4, kItemsLarge = 16;
 
 // ---- F3 -----------------------------------------------------------------------------------------
 // Same grid as preprocess (blockIdx.y = view).  The block re-scans its 256 tile counts in LDS and adds
@@ -77,14 +78,15 @@ __global__ __launch_bounds__(kThreads) void duplicate_keys_kernel(int P, int Tx,
 // upsweep: per-block digit histogram, stored digit-major hist[d * nblocks + b] so that one linear
 // exclusive scan yields, for every (digit, block), the global output offset of that block's first key
 // with that digit.
+template <int ITEMS>
 __global__ __launch_bounds__(kThreads) void radix_upsweep_kernel(const uint64_t *__restrict__ keys, uint32_t n, int shift,
                                                                  uint32_t nblocks, uint32_t *__restrict__ hist) {
     __shared__ uint32_t h[kRadix];
     h[threadIdx.x] = 0;
     __syncthreads();
-    const uint32_t base = blockIdx.x * kTileKeys;
+    const uint32_t base = blockIdx.x * (kThreads * ITEMS);
 #pragma unroll 4
-    for (int it = 0; it < kItems; it++) {
+    for (int it = 0; it < ITEMS; it++) {
         const uint32_t k = base + it * kThreads + threadIdx.x;
         if (k < n) atomicAdd(&h[(uint32_t)(keys[k] >> shift) & (kRadix - 1)], 1u);
     }
@@ -92,24 +94,20 @@ __global__ __launch_bounds__(kThreads) void radix_upsweep_kernel(const uint64_t 
     hist[(size_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
 }
 
-// exclusive scan of `n` u32 in place, one workgroup of 1024 threads, coalesced tiles of 1024*4 entries
-__global__ __launch_bounds__(1024) void radix_scan_kernel(uint32_t *__restrict__ data, uint32_t n) {
-    __shared__ uint32_t wave_tot[16];
+// per-digit row scan: workgroup d turns hist[d][0..nblocks) into its exclusive prefix (in place) and writes the digit total.
+// 256 workgroups run in parallel; the 256 digit totals are scanned by every downsweep workgroup itself (in LDS).
+__global__ __launch_bounds__(kThreads) void radix_rowscan_kernel(uint32_t *__restrict__ hist, uint32_t nblocks,
+                                                                 uint32_t *__restrict__ totals) {
+    __shared__ uint32_t wave_tot[4];
     __shared__ uint32_t carry_s;
+    uint32_t *row = hist + (size_t)blockIdx.x * nblocks;
     const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
     if (t == 0) carry_s = 0;
     __syncthreads();
-    for (uint32_t base = 0; base < n; base += 4096) {
-        const uint32_t idx = base + t * 4;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (idx + 3 < n) v = *reinterpret_cast<const uint4 *>(data + idx);
-        else {
-            if (idx < n) v.x = data[idx];
-            if (idx + 1 < n) v.y = data[idx + 1];
-            if (idx + 2 < n) v.z = data[idx + 2];
-        }
-        const uint32_t s = v.x + v.y + v.z + v.w;
-        uint32_t inc = s;
+    for (uint32_t base = 0; base < nblocks; base += kThreads) {
+        const uint32_t idx = base + t;
+        const uint32_t v = idx < nblocks ? row[idx] : 0u;
+        uint32_t inc = v;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
             const uint32_t nb = __shfl_up(inc, off, 64);
@@ -119,36 +117,45 @@ __global__ __launch_bounds__(1024) void radix_scan_kernel(uint32_t *__restrict__
         __syncthreads();
         uint32_t pre = carry_s;
         for (uint32_t w = 0; w < wave; w++) pre += wave_tot[w];
-        uint32_t e = pre + inc - s;
-        uint4 o;
-        o.x = e; o.y = e + v.x; o.z = o.y + v.y; o.w = o.z + v.z;
-        if (idx + 3 < n) *reinterpret_cast<uint4 *>(data + idx) = o;
-        else {
-            if (idx < n) data[idx] = o.x;
-            if (idx + 1 < n) data[idx + 1] = o.y;
-            if (idx + 2 < n) data[idx + 2] = o.z;
-        }
+        if (idx < nblocks) row[idx] = pre + inc - v;
         __syncthreads();
-        if (t == 1023) carry_s = pre + inc;
+        if (t == kThreads - 1) carry_s = pre + inc;
         __syncthreads();
     }
+    if (t == 0) totals[blockIdx.x] = carry_s;
 }
 
 // downsweep: stable scatter.  Keys are consumed in rounds of 256 in memory order; inside a round the rank
 // of a key among equal digits is (keys of earlier waves) + (earlier lanes of its own wave), the latter
 // from a wave64 "match-any" built out of 8 ballots.
+template <int ITEMS>
 __global__ __launch_bounds__(kThreads) void radix_downsweep_kernel(const uint64_t *__restrict__ keys_in,
                                                                    const uint32_t *__restrict__ vals_in,
                                                                    uint64_t *__restrict__ keys_out,
                                                                    uint32_t *__restrict__ vals_out, uint32_t n, int shift,
-                                                                   uint32_t nblocks, const uint32_t *__restrict__ hist) {
+                                                                   uint32_t nblocks, const uint32_t *__restrict__ hist,
+                                                                   const uint32_t *__restrict__ totals) {
     __shared__ uint32_t digit_base[kRadix];
     __shared__ uint32_t wave_cnt[4][kRadix];
+    __shared__ uint32_t wtot[4];
     const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    digit_base[t] = hist[(size_t)t * nblocks + blockIdx.x];
-    const uint32_t base = blockIdx.x * kTileKeys;
+    {   // exclusive scan of the 256 digit totals (one per thread) + this block's offset inside its digit
+        const uint32_t v = totals[t];
+        uint32_t inc = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t nb = __shfl_up(inc, off, 64);
+            if (lane >= (uint32_t)off) inc += nb;
+        }
+        if (lane == 63) wtot[wave] = inc;
+        __syncthreads();
+        uint32_t pre = 0;
+        for (uint32_t w = 0; w < wave; w++) pre += wtot[w];
+        digit_base[t] = pre + inc - v + hist[(size_t)t * nblocks + blockIdx.x];
+    }
+    const uint32_t base = blockIdx.x * (kThreads * ITEMS);
     const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    for (int it = 0; it < kItems; it++) {
+    for (int it = 0; it < ITEMS; it++) {
         const uint32_t k = base + it * kThreads + t;
         const bool valid = k < n;
         uint64_t key = 0;
@@ -201,8 +208,8 @@ inline int bits_for(uint64_t v) { int b = 0; while ((1ull << b) < v) b++; return
 int sgr_validate_problem(const SgrProblem *pb);
 
 extern "C" size_t sgr_bin_workspace_bytes(uint64_t R) {
-    const uint64_t nblocks = (R + kTileKeys - 1) / kTileKeys;
-    return (size_t)((nblocks > 0 ? nblocks : 1) * kRadix * sizeof(uint32_t) + 256);
+    const uint64_t nblocks = (R + kThreads * kItemsSmall - 1) / (kThreads * kItemsSmall);
+    return (size_t)(((nblocks > 0 ? nblocks : 1) + 1) * kRadix * sizeof(uint32_t) + 256);
 }
 
 extern "C" int sgr_bin(const SgrProblem *pb, const float *rec, const int32_t *radii, const uint32_t *rect,
@@ -226,8 +233,11 @@ extern "C" int sgr_bin(const SgrProblem *pb, const float *rec, const int32_t *ra
                        (const float4 *)rec, radii, (const uint2 *)rect, block_offsets, keys_a, vals_a);
     SGR_CHECK_LAUNCH("duplicate_keys_kernel");
     }
-    const uint32_t nblocks = (n + kTileKeys - 1) / kTileKeys;
+    const bool small = n <= (1u << 19);
+    const uint32_t tile_keys = kThreads * (small ? kItemsSmall : kItemsLarge);
+    const uint32_t nblocks = (n + tile_keys - 1) / tile_keys;
     uint32_t *hist = (uint32_t *)workspace;
+    uint32_t *totals = hist + (size_t)nblocks * kRadix;
     const int total_bits = 32 + bits_for(tiles_total);
     const int passes = (total_bits + kRadixBits - 1) / kRadixBits;
     uint64_t *kin = keys_a, *kout = keys_b;
@@ -235,12 +245,13 @@ extern "C" int sgr_bin(const SgrProblem *pb, const float *rec, const int32_t *ra
     { SgrProfScope _ps(SGR_K_SORT, stream);
     for (int p = 0; p < passes; p++) {
         const int shift = p * kRadixBits;
-        hipLaunchKernelGGL(radix_upsweep_kernel, dim3(nblocks), dim3(kThreads), 0, stream, kin, n, shift, nblocks, hist);
+        if (small) hipLaunchKernelGGL(radix_upsweep_kernel<kItemsSmall>, dim3(nblocks), dim3(kThreads), 0, stream, kin, n, shift, nblocks, hist);
+        else hipLaunchKernelGGL(radix_upsweep_kernel<kItemsLarge>, dim3(nblocks), dim3(kThreads), 0, stream, kin, n, shift, nblocks, hist);
         SGR_CHECK_LAUNCH("radix_upsweep_kernel");
-        hipLaunchKernelGGL(radix_scan_kernel, dim3(1), dim3(1024), 0, stream, hist, nblocks * kRadix);
-        SGR_CHECK_LAUNCH("radix_scan_kernel");
-        hipLaunchKernelGGL(radix_downsweep_kernel, dim3(nblocks), dim3(kThreads), 0, stream, kin, vin, kout, vout, n, shift,
-                           nblocks, hist);
+        hipLaunchKernelGGL(radix_rowscan_kernel, dim3(kRadix), dim3(kThreads), 0, stream, hist, nblocks, totals);
+        SGR_CHECK_LAUNCH("radix_rowscan_kernel");
+        if (small) hipLaunchKernelGGL(radix_downsweep_kernel<kItemsSmall>, dim3(nblocks), dim3(kThreads), 0, stream, kin, vin, kout, vout, n, shift, nblocks, hist, totals);
+        else hipLaunchKernelGGL(radix_downsweep_kernel<kItemsLarge>, dim3(nblocks), dim3(kThreads), 0, stream, kin, vin, kout, vout, n, shift, nblocks, hist, totals);
         SGR_CHECK_LAUNCH("radix_downsweep_kernel");
         uint64_t *tk = kin; kin = kout; kout = tk;
         uint32_t *tv = vin; vin = vout; vout = tv;

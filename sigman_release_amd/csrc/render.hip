@@ -116,19 +116,30 @@ __global__ __launch_bounds__(kBlock) void render_fwd_kernel(int W, int H, int Tx
                 dst[g] = make_uint2(sId[j], (uint32_t)(r * kBlock) + j);
             }
         }
+#ifdef SGR_DBG_NOCOMPUTE
+        if (cnt > 100000)
+#endif
         for (uint32_t g = 0; g < cnt && active; g += 4) {
             const ushort4 jj = *reinterpret_cast<const ushort4 *>(&sList[wave][g]);
             const int js[4] = {jj.x, jj.y, jj.z, jj.w};
             float4 a[4], b[4], c[4];
-            float alpha[4], power[4];
+            float al[4];
+            bool valid[4];
 #pragma unroll
+#ifdef SGR_DBG_NOLDS
+            for (int u = 0; u < 4; u++) { const float f = (float)js[u]; a[u] = make_float4(x0 + f * 0.06f, y0 + f * 0.05f, 0.1f, 0.01f); b[u] = make_float4(0.12f, 0.5f, 2.f + f, 0.3f); c[u] = make_float4(0.2f, 0.4f, 1.f, 1.f); }
+#else
             for (int u = 0; u < 4; u++) { a[u] = sA[js[u]]; b[u] = sB[js[u]]; c[u] = sC[js[u]]; }
+#endif
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 const float dx = a[u].x - pxf, dy = a[u].y - pyf;
-                power[u] = -0.5f * (a[u].z * dx * dx + b[u].x * dy * dy) - a[u].w * dx * dy;
-                alpha[u] = fminf(0.99f, b[u].y * __expf(power[u]));
+                const float power = -0.5f * (a[u].z * dx * dx + b[u].x * dy * dy) - a[u].w * dx * dy;
+                const float alpha = fminf(0.99f, b[u].y * __expf(power));
+                valid[u] = (power <= 0.f) & (alpha >= (1.0f / 255.0f));
+                al[u] = valid[u] ? alpha : 0.f;
             }
+            // sequential part, branch-free: the only loop-carried chain is T -> test_T -> (stop) -> T
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 const uint32_t ord = kbase + g + u;                       // ordinal of this survivor in the quadrant list
@@ -137,20 +148,16 @@ __global__ __launch_bounds__(kBlock) void render_fwd_kernel(int W, int H, int Tx
                     aux.ckpt_tc[s] = make_float4(T, C0, C1, C2);
                     aux.ckpt_da[s] = make_float2(D, A);
                 }
-                if (!done && power[u] <= 0.f && alpha[u] >= (1.0f / 255.0f)) {
-                    const float test_T = T * (1.f - alpha[u]);
-                    if (test_T < 0.0001f) {
-                        done = true;                          // the crossing Gaussian is NOT composited
-                    } else {
-                        const float w = alpha[u] * T;
-                        C0 += b[u].w * w; C1 += c[u].x * w; C2 += c[u].y * w;
-                        D += b[u].z * w;
-                        A += w;
-                        T = test_T;
-                        last = (uint32_t)(r * kBlock + js[u] + 1);
-                        lastk = ord + 1;
-                    }
-                }
+                const float test_T = T * (1.f - al[u]);
+                done = done | (valid[u] & (test_T < 0.0001f));            // the crossing Gaussian is NOT composited
+                const bool contrib = valid[u] & !done;
+                const float w = contrib ? al[u] * T : 0.f;
+                C0 = fmaf(b[u].w, w, C0); C1 = fmaf(c[u].x, w, C1); C2 = fmaf(c[u].y, w, C2);
+                D = fmaf(b[u].z, w, D);
+                A += w;
+                T = contrib ? test_T : T;
+                last = contrib ? (uint32_t)(r * kBlock + js[u] + 1) : last;
+                if (AUX) lastk = contrib ? ord + 1 : lastk;
             }
             active = __ballot(!done);
         }
