@@ -36,6 +36,7 @@ sys.path.insert(0, ROOT)
 
 from sigman_release_amd import _cabi, cameras, parallel, synthetic  # noqa: E402
 from sigman_release_amd import rasterizer as R  # noqa: E402
+from sigman_release_amd.losses import clamped_l1_loss  # noqa: E402
 
 VIEWS = (30, 37, 45, 53, 65, 85, 0, 8)
 KERNELS = {0: "preprocess_fwd", 1: "scan_block_sums", 2: "duplicate_keys", 3: "radix_sort(all passes)", 4: "tile_ranges",
@@ -76,7 +77,7 @@ def main():
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        dist.init_process_group(os.environ.get("SIGMAN_BENCH_BACKEND", "nccl"), **({"device_id": dev} if os.environ.get("SIGMAN_BENCH_BACKEND", "nccl") == "nccl" else {}))
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     P, H, W = args.gaussians, args.size, args.size
@@ -103,7 +104,7 @@ def main():
     def render_loss(means3D, cov3D, opacity, rgb, _views=None):
         color, radii, depth, alpha = R.rasterize_gaussians_batched(means3D[None], None, None, rgb[None], opacity[None], None,
                                                                    None, cov3D[None], st)
-        return (color.clamp(0, 1) - gt).abs().sum() * norm       # gs.py:107 clamp + L1
+        return clamped_l1_loss(color, gt, None, norm)               # gs.py:107 clamp + whole_loss.py:126-131 L1, fused HIP epilogue
 
     leaves = {k: v.clone().requires_grad_(True) for k, v in subj.items()}
     packed = parallel.pack_attributes(subj["means3D"], subj["cov3D"], subj["opacity"], subj["rgb"])
@@ -190,7 +191,7 @@ def main():
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
                      "algorithmic_bytes_per_launch": abytes, "avg_launch_ms": round(dom_avg_ms, 5), "launches": dom_n},
         "kernel_ms_per_step": breakdown,
-        "loss": float(loss),
+        "loss": float(loss.detach()),
     }
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -213,6 +214,7 @@ def cpu_baseline(g_host, cov_host, view, H, W, gt, norm):
         t0 = time.perf_counter()
         st = ref.forward(g_host["position"], g_host["opacity"].reshape(P), colors_precomp=g_host["rgb"], cov3D_precomp=cov_host, **kw)
         img = np.clip(st.color, 0, 1)
+        loss_cpu = float(np.abs(img - gt).sum() * norm)   # noqa: F841  (same clamp + L1 epilogue as the GPU step)
         gC = (np.sign(img - gt) * ((st.color > 0) & (st.color < 1)) * norm).astype(np.float32)
         ref.backward(st, gC)
         times.append(time.perf_counter() - t0)

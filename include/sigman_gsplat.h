@@ -169,6 +169,15 @@ int sgr_cov3d_forward(int32_t n, const float *scale_raw, const float *rotation, 
 int sgr_cov3d_backward(int32_t n, const float *scale_raw, const float *rotation, const float *dist2, const float *grad_cov6,
                        float *grad_scale_raw, float *grad_rotation, void *stream);
 
+/*
+ * Fused image-space loss epilogue (gs.py:107 clamp + whole_loss.py:126-131 masked L1), one pass:
+ *   loss_per_view[v] = weight * sum_{c,p} mask * |clamp(color,0,1) - target|      (zeroed by the call)
+ *   grad_color       = weight * mask * sign(clamp(color) - target) * 1[0 < color < 1]
+ * color/target/grad_color [n_views,3,H,W]; mask [n_views,1,H,W] or NULL.
+ */
+int sgr_clamped_l1_loss(int32_t n_views, int32_t H, int32_t W, const float *color, const float *target, const float *mask,
+                        float weight, float *grad_color, float *loss_per_view, void *stream);
+
 /* ---- optional per-kernel profiler (HIP events on the launch stream; used by bench.py) -------- */
 enum {
     SGR_K_PREPROCESS_FWD = 0, SGR_K_SCAN = 1, SGR_K_DUPLICATE = 2, SGR_K_SORT = 3, SGR_K_RANGES = 4,

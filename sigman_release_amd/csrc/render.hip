@@ -341,8 +341,14 @@ __global__ __launch_bounds__(kBlock) void render_bwd_kernel(int W, int H, int Tx
 //   dL/dalpha_j = T_j q_j - (O - Pre_j - w_j q_j) / (1 - alpha_j),   O = out . g (includes the T_final*bg term),
 //   Pre_j = sum_{k<j} w_k q_k  (running), T_{j+1} = T_j (1 - alpha_j)  (bit-identical to the forward's T sequence).
 // -------------------------------------------------------------------------------------------------
-template <int CTRL>
-__device__ __forceinline__ float rot(float v) { return sgr_dpp<CTRL>(v); }
+// in-place full-wave rotate: lane i+1 <- lane i, lane 0 <- lane 63 (old == src, so no zero-init / copy is generated)
+__device__ __forceinline__ float rot1(float v) {
+#ifdef SGR_DBG_NOROT
+    return v * 1.0000001f;
+#endif
+    const int i = __builtin_bit_cast(int, v);
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(i, i, SGR_DPP_WAVE_ROR1, 0xF, 0xF, false));
+}
 
 template <bool HAS_DA>
 __global__ __launch_bounds__(kBlock) void render_bwd_bucket_kernel(int W, int H, int Tx, uint32_t tiles_per_view,
@@ -358,10 +364,13 @@ __global__ __launch_bounds__(kBlock) void render_bwd_bucket_kernel(int W, int H,
     const int lane = threadIdx.x & 63;
     const size_t slot = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (slot >= (size_t)4 * aux.NS) return;
-    const uint2 desc = aux.desc[slot];
-    const uint32_t count = desc.y & 127u;
-    if (count == 0) return;                                   // wave-uniform: unused bucket slot
-    const uint32_t bucket = desc.y >> 7, bid = desc.x;
+    const uint2 desc_v = aux.desc[slot];
+    // the descriptor is wave-uniform: move it to SGPRs so the step loop below is a scalar loop
+    const uint32_t desc_y = (uint32_t)__builtin_amdgcn_readfirstlane((int)desc_v.y);
+    const uint32_t bid = (uint32_t)__builtin_amdgcn_readfirstlane((int)desc_v.x);
+    const uint32_t count = desc_y & 127u;
+    if (count == 0) return;                                   // unused bucket slot
+    const uint32_t bucket = desc_y >> 7;
     const uint32_t q = (uint32_t)(slot / aux.NS);
     const uint32_t view = bid / tiles_per_view, tile = bid - view * tiles_per_view;
     const uint32_t tx = tile % Tx, ty = tile / Tx;
@@ -370,10 +379,14 @@ __global__ __launch_bounds__(kBlock) void render_bwd_bucket_kernel(int W, int H,
     const bool has_g = (uint32_t)lane < count;
     uint2 e = make_uint2(0u, 0xFFFFFFFFu);
     if (has_g) e = aux.compact[(size_t)q * aux.R + rx + (bucket << 6) + lane];
+    // a lane without a Gaussian gets list index 0xFFFFFFFF, which no pixel's n_contrib exceeds -> never valid
     const uint32_t gidx = e.y;
     float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra, rc = ra;
     if (has_g) { ra = rec[(size_t)e.x * 3 + 0]; rb = rec[(size_t)e.x * 3 + 1]; rc = rec[(size_t)e.x * 3 + 2]; }
     const float gx = ra.x, gy = ra.y, cxx = ra.z, cxy = ra.w, cyy = rb.x, op = rb.y, gdep = rb.z, cr = rb.w, cg = rc.x, cb = rc.y;
+    // conic pre-scaled into the exp2 domain: G = exp(power) = exp2(kxx dx^2 + kyy dy^2 + kxy dx dy)
+    const float kLog2e = 1.4426950408889634f;
+    const float kxx = -0.5f * kLog2e * cxx, kyy = -0.5f * kLog2e * cyy, kxy = -kLog2e * cxy;
     // ---- the pixel that starts in my lane: p = (64 - lane) mod 64, so that wave_ror:1 brings pixel p to lane 0 at step p
     const int p = (64 - lane) & 63;
     const int px = (int)tx * 16 + (int)(q & 1u) * 8 + (p & 7);
@@ -383,70 +396,77 @@ __global__ __launch_bounds__(kBlock) void render_bwd_bucket_kernel(int W, int H,
     const size_t pix = (size_t)py * W + px;
     const size_t vb = (size_t)view * hw;
     float pxf = (float)px, pyf = (float)py;
-    float g0 = 0.f, g1 = 0.f, g2 = 0.f, gd = 0.f, ga = 0.f, O = 0.f, T = 1.f, Pre = 0.f;
+    float g0 = 0.f, g1 = 0.f, g2 = 0.f, gd = 0.f, ga = 0.f, Rem = 0.f, T = 1.f;
     uint32_t last = 0;
     if (inside) {
         last = n_contrib[vb + pix];
         g0 = gC[vb * 3 + pix]; g1 = gC[vb * 3 + hw + pix]; g2 = gC[vb * 3 + 2 * hw + pix];
-        O = out_color[vb * 3 + pix] * g0 + out_color[vb * 3 + hw + pix] * g1 + out_color[vb * 3 + 2 * hw + pix] * g2;
+        // Rem = O - Pre: what is still to be composited behind the current position, dotted with the upstream gradient
+        Rem = out_color[vb * 3 + pix] * g0 + out_color[vb * 3 + hw + pix] * g1 + out_color[vb * 3 + 2 * hw + pix] * g2;
         if (HAS_DA) {
             if (gD) gd = gD[vb + pix];
             if (gA) ga = gA[vb + pix];
-            O += out_depth[vb + pix] * gd + out_alpha[vb + pix] * ga;
+            Rem += out_depth[vb + pix] * gd + out_alpha[vb + pix] * ga;
         }
         if (bucket) {
             const float4 tc = aux.ckpt_tc[slot * 64 + p];
             T = tc.x;
-            Pre = tc.y * g0 + tc.z * g1 + tc.w * g2;
-            if (HAS_DA) { const float2 da = aux.ckpt_da[slot * 64 + p]; Pre += da.x * gd + da.y * ga; }
+            Rem -= tc.y * g0 + tc.z * g1 + tc.w * g2;
+            if (HAS_DA) { const float2 da = aux.ckpt_da[slot * 64 + p]; Rem -= da.x * gd + da.y * ga; }
         }
     }
     float lastf = __uint_as_float(last);
-    const float ddelx_dx = 0.5f * (float)W, ddely_dy = 0.5f * (float)H;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f, a5 = 0.f, a6 = 0.f, a7 = 0.f, a8 = 0.f, a9 = 0.f;
+    // per-Gaussian moment accumulators of v = G * dL/dalpha over the pixels (constant factors applied once at the end)
+    float S1 = 0.f, Sx = 0.f, Sy = 0.f, Sxx = 0.f, Sxy = 0.f, Syy = 0.f, aD = 0.f, a7 = 0.f, a8 = 0.f, a9 = 0.f;
+#ifdef SGR_DBG_NOSTEPS
+    const int nsteps = 1;
+#else
     const int nsteps = 63 + (int)count;
+#endif
     for (int s = 0; s < nsteps; s++) {
         const uint32_t dlt = (uint32_t)(s - lane);              // pixel (s - lane) is in my lane iff 0 <= s - lane < 64
         const float dx = gx - pxf, dy = gy - pyf;
-        const float power = -0.5f * (cxx * dx * dx + cyy * dy * dy) - cxy * dx * dy;
-        const float G = __expf(power);
+        const float p2 = (kxx * dx) * dx + ((kyy * dy) * dy + (kxy * dx) * dy);
+        const float G = __builtin_amdgcn_exp2f(p2);
         const float alpha = fminf(0.99f, op * G);
-        const bool valid = has_g && dlt < 64u && gidx < __float_as_uint(lastf) && power <= 0.f && alpha >= (1.0f / 255.0f);
+        const bool valid = dlt < 64u && gidx < __float_as_uint(lastf) && p2 <= 0.f && alpha >= (1.0f / 255.0f);
         if (valid) {
             const float w = alpha * T;
             float qj = cr * g0 + cg * g1 + cb * g2;
             if (HAS_DA) qj += gdep * gd + ga;
-            const float wq = w * qj;
-            const float inv = 1.f / (1.f - alpha);
-            const float dL_dalpha = T * qj - (O - Pre - wq) * inv;
-            Pre += wq;
-            T = T * (1.f - alpha);
-            const float dL_dG = op * dL_dalpha;               // differentiates through op*G even when capped (as upstream)
-            const float gdx = G * dx, gdy = G * dy;
-            a0 += dL_dG * (-gdx * cxx - gdy * cxy) * ddelx_dx;
-            a1 += dL_dG * (-gdy * cyy - gdx * cxy) * ddely_dy;
-            a2 += -0.5f * gdx * dx * dL_dG;
-            a3 += -0.5f * gdx * dy * dL_dG;
-            a4 += -0.5f * gdy * dy * dL_dG;
-            a5 += G * dL_dalpha;
-            if (HAS_DA) a6 += w * gd;
-            a7 += w * g0; a8 += w * g1; a9 += w * g2;
+            const float oma = 1.f - alpha;
+            Rem -= w * qj;
+            const float dL_dalpha = T * qj - Rem * __builtin_amdgcn_rcpf(oma);
+            T *= oma;
+            const float v = G * dL_dalpha;                    // upstream differentiates through op*G even when alpha is capped
+            const float vx = v * dx, vy = v * dy;
+            S1 += v; Sx += vx; Sy += vy;
+            Sxx = fmaf(vx, dx, Sxx); Sxy = fmaf(vx, dy, Sxy); Syy = fmaf(vy, dy, Syy);
+            if (HAS_DA) aD = fmaf(w, gd, aD);
+            a7 = fmaf(w, g0, a7); a8 = fmaf(w, g1, a8); a9 = fmaf(w, g2, a9);
         }
         // ---- systolic shift: every pixel state moves one lane up (lane 63 wraps to lane 0, masked out by `dlt`)
-        pxf = rot<SGR_DPP_WAVE_ROR1>(pxf); pyf = rot<SGR_DPP_WAVE_ROR1>(pyf); lastf = rot<SGR_DPP_WAVE_ROR1>(lastf);
-        g0 = rot<SGR_DPP_WAVE_ROR1>(g0); g1 = rot<SGR_DPP_WAVE_ROR1>(g1); g2 = rot<SGR_DPP_WAVE_ROR1>(g2);
-        O = rot<SGR_DPP_WAVE_ROR1>(O); T = rot<SGR_DPP_WAVE_ROR1>(T); Pre = rot<SGR_DPP_WAVE_ROR1>(Pre);
-        if (HAS_DA) { gd = rot<SGR_DPP_WAVE_ROR1>(gd); ga = rot<SGR_DPP_WAVE_ROR1>(ga); }
+        pxf = rot1(pxf); pyf = rot1(pyf); lastf = rot1(lastf);
+        g0 = rot1(g0); g1 = rot1(g1); g2 = rot1(g2);
+        Rem = rot1(Rem); T = rot1(T);
+        if (HAS_DA) { gd = rot1(gd); ga = rot1(ga); }
     }
+#ifdef SGR_DBG_NOATOMIC
+    if (has_g && S1 == 123.456f) {
+#else
     if (has_g) {
+#endif
         float *g = grec + (size_t)e.x * SGR_REC_FLOATS;
+        const float a0 = -0.5f * (float)W * op * (cxx * Sx + cxy * Sy);       // dL/dNDC x (includes 0.5*W like upstream)
+        const float a1 = -0.5f * (float)H * op * (cyy * Sy + cxy * Sx);
+        const float a2 = -0.5f * op * Sxx, a3 = -0.5f * op * Sxy, a4 = -0.5f * op * Syy;
         if (a0 != 0.f) sgr_atomic_add(g + 0, a0);
         if (a1 != 0.f) sgr_atomic_add(g + 1, a1);
         if (a2 != 0.f) sgr_atomic_add(g + 2, a2);
         if (a3 != 0.f) sgr_atomic_add(g + 3, a3);
         if (a4 != 0.f) sgr_atomic_add(g + 4, a4);
-        if (a5 != 0.f) sgr_atomic_add(g + 5, a5);
-        if (HAS_DA && a6 != 0.f) sgr_atomic_add(g + 6, a6);
+        if (S1 != 0.f) sgr_atomic_add(g + 5, S1);
+        if (HAS_DA && aD != 0.f) sgr_atomic_add(g + 6, aD);
         if (a7 != 0.f) sgr_atomic_add(g + 7, a7);
         if (a8 != 0.f) sgr_atomic_add(g + 8, a8);
         if (a9 != 0.f) sgr_atomic_add(g + 9, a9);

@@ -116,3 +116,23 @@ def test_import_shims_resolve_to_hip():
     from simple_knn._C import distCUDA2
     from sigman_release_amd import rasterizer, renderer
     assert dgr.GaussianRasterizer is rasterizer.GaussianRasterizer and distCUDA2 is renderer.dist_cuda2
+
+
+@pytest.mark.parametrize("H,W,use_mask", [(64, 64, False), (50, 70, True), (33, 17, True)])
+def test_fused_clamped_l1_loss(H, W, use_mask):
+    """sgr_clamped_l1_loss == the reference's clamp (gs.py:107) + masked L1 (whole_loss.py:126-131) under autograd."""
+    from sigman_release_amd.losses import clamped_l1_loss
+    dev = _dev()
+    g = torch.Generator(device="cpu").manual_seed(3)
+    color = (torch.rand(3, 3, H, W, generator=g) * 1.4 - 0.2).to(dev).requires_grad_(True)     # some values outside [0,1]
+    target = torch.rand(3, 3, H, W, generator=g).to(dev)
+    mask = (torch.rand(3, 1, H, W, generator=g) > 0.3).float().to(dev) if use_mask else None
+    w = 0.37
+    loss = clamped_l1_loss(color, target, mask, w)
+    (loss * 2.0).backward()
+    c2 = color.detach().double().requires_grad_(True)
+    m2 = 1.0 if mask is None else mask.double()
+    ref = w * ((c2.clamp(0, 1) - target.double()) * m2).abs().sum()
+    (ref * 2.0).backward()
+    assert abs(float(loss) - float(ref)) <= 1e-5 * abs(float(ref))
+    assert torch.allclose(color.grad.double(), c2.grad, atol=1e-7)
