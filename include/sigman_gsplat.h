@@ -109,8 +109,12 @@ int sgr_bin(const SgrProblem *pb, const float *rec, const int32_t *radii, const 
             uint32_t *vals_b, void *workspace, size_t workspace_bytes, uint32_t *ranges,
             int32_t *result_in_b_host, void *stream);
 
-/* number of bucket slots per quadrant for the auxiliary forward outputs: (R >> 6) + tiles_total + 1 */
+/* number of bucket slots per quadrant for the auxiliary forward outputs: (R >> 6) + 8*tiles_total + 1 */
 uint64_t sgr_bucket_slots(uint64_t R, uint64_t tiles_total);
+
+/* forward compositing kernel choice: 0 = automatic (segment-parallel for launches of <= 2048 tiles, serial per-tile
+ * otherwise), 1 = serial, 2 = segment-parallel.  Both produce the same outputs. */
+int sgr_set_forward_mode(int mode);
 
 /*
  * F6: per-tile front-to-back compositing.  out_color [n_views,3,H,W], out_depth [n_views,1,H,W],

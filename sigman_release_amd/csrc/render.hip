@@ -43,7 +43,8 @@ struct FwdAux {
     uint2 *compact;       // [4][R]  per (tile, quadrant) culled list in order: (record id, 0-based index in the tile list)
     float4 *ckpt_tc;      // [4*NS][64]  per bucket, per pixel: T, C0, C1, C2 at the START of the bucket
     float2 *ckpt_da;      // [4*NS][64]  D, A
-    uint2 *desc;          // [4*NS]  (global tile id, (bucket << 7) | count); count == 0 -> slot unused
+    uint2 *desc;          // [4*NS]  (global tile id, (start << 7) | count): `count` (<= 64) survivors starting at ordinal `start` of the
+                          //          (tile, quadrant) list; count == 0 -> slot unused
     uint32_t R, NS;
 };
 
@@ -80,7 +81,7 @@ __global__ __launch_bounds__(kBlock) void render_fwd_kernel(int W, int H, int Tx
     uint32_t kbase = 0;                                  // survivors of this wave's quadrant in earlier batches
     const int n = (int)(range.y - range.x);
     const int rounds = (n + kBlock - 1) / kBlock;
-    const size_t slot0 = (size_t)wave * aux.NS + (range.x >> 6) + bid;     // first bucket slot of (tile, quadrant)
+    const size_t slot0 = (size_t)wave * aux.NS + (range.x >> 6) + (size_t)bid * 8;     // first bucket slot of (tile, quadrant)
     if (t == 0) { sA[kBlock] = make_float4(0.f, 0.f, 0.f, 0.f); sB[kBlock] = sA[kBlock]; sC[kBlock] = sA[kBlock]; }
     for (int r = 0; r < rounds; r++) {
         if (__syncthreads_count(done) == kBlock) break;      // also the barrier that protects LDS reuse
@@ -181,7 +182,208 @@ __global__ __launch_bounds__(kBlock) void render_fwd_kernel(int W, int H, int Tx
         for (int off = 32; off > 0; off >>= 1) kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, off, 64));
         const uint32_t nb = (kmax + 63u) >> 6;
         for (uint32_t bk = lane; bk < nb; bk += 64)
-            aux.desc[slot0 + bk] = make_uint2(bid, (bk << 7) | min(64u, kmax - (bk << 6)));
+            aux.desc[slot0 + bk] = make_uint2(bid, (bk << 13) | min(64u, kmax - (bk << 6)));
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// F6, segment-parallel variant for launches that cannot fill the chip (one 512^2 view has ~200 occupied tiles
+// for 256 CUs, and the serial walk of the longest tile list -- ~2900 entries at C2 -- is the whole critical path).
+// One workgroup = one (tile, quadrant), 8 waves.  Each 512-entry chunk of the tile list is culled and
+// compacted for this quadrant into LDS, the survivors are split into 8 contiguous segments (one per wave), and
+//   phase 1  every wave computes its segment's transmittance product per pixel (alpha only),
+//   prefix   T_in(segment) = T_carry * prod(earlier segments)       (same association in every wave),
+//   phase 2  every wave composites its segment with the published sequential rule starting from T_in.
+// Contributions are absolute (already multiplied by T), so the 8 partial sums simply add up at the end.
+// A pixel that stopped in an earlier segment has T_in < 1e-4 (T is monotone), so later segments skip it.
+// ~1.5x the arithmetic of the serial kernel, 8x shorter dependency chain.  Each segment doubles as one bucket
+// (<= 64 survivors) of the bucket-parallel backward, with its checkpoint (T_in, composited-so-far).
+// -------------------------------------------------------------------------------------------------
+constexpr int kSegThreads = 512, kSegWaves = 8;
+
+__device__ __forceinline__ bool cull_quadrant(const float4 &a, const float4 &c, float qx0, float qy0) {
+    const float hx = c.z, hy = c.w;
+    if (hx < 0.f) return false;
+    return (a.x + hx >= qx0) && (a.x - hx <= qx0 + 7.f) && (a.y + hy >= qy0) && (a.y - hy <= qy0 + 7.f);
+}
+
+template <bool AUX>
+__global__ __launch_bounds__(kSegThreads, 4) void render_fwd_seg_kernel(int W, int H, int Tx, uint32_t tiles_per_view,
+                                                                     const uint2 *__restrict__ ranges,
+                                                                     const uint32_t *__restrict__ point_list,
+                                                                     const float4 *__restrict__ rec, const float *__restrict__ bg,
+                                                                     float *__restrict__ out_color, float *__restrict__ out_depth,
+                                                                     float *__restrict__ out_alpha, float *__restrict__ final_T,
+                                                                     uint32_t *__restrict__ n_contrib, FwdAux aux) {
+    __shared__ float4 sA[kSegThreads], sB[kSegThreads], sC[kSegThreads];
+    __shared__ uint32_t sId[kSegThreads], sIdx[kSegThreads];
+    __shared__ float sT[kSegWaves][64];
+    __shared__ float sAcc[kSegWaves][5][64];
+    __shared__ float sTstop[64];
+    __shared__ uint32_t sLast[kSegWaves][64];
+    __shared__ uint32_t sWaveCnt[kSegWaves];
+    const uint32_t bid = blockIdx.x >> 2, q = blockIdx.x & 3u;
+    const uint32_t view = bid / tiles_per_view, tile = bid - view * tiles_per_view;
+    const uint32_t tx = tile % Tx, ty = tile / Tx;
+    const uint2 range = ranges[bid];
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    const int px = (int)tx * 16 + (int)(q & 1u) * 8 + (lane & 7);
+    const int py = (int)ty * 16 + (int)(q >> 1) * 8 + (lane >> 3);
+    const bool inside = px < W && py < H;
+    const float pxf = (float)px, pyf = (float)py;
+    const float qx0 = (float)(tx * 16 + (q & 1u) * 8), qy0 = (float)(ty * 16 + (q >> 1) * 8);
+    const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const int n = (int)(range.y - range.x);
+    float C0 = 0.f, C1 = 0.f, C2 = 0.f, D = 0.f, A = 0.f;      // this wave's share of the pixel sums
+    float Tcarry = 1.f;                                         // identical in all 8 waves
+    float cc0 = 0.f, cc1 = 0.f, cc2 = 0.f, ccD = 0.f, ccA = 0.f;   // composited-so-far (all waves), AUX only
+    float Tstop = -1.f;
+    uint32_t last = 0;
+    uint32_t kbase = 0;
+    size_t slot_next = (size_t)q * aux.NS + (range.x >> 6) + (size_t)bid * 8;
+    if (t < 64) sTstop[t] = -1.f;
+    bool pix_done = !inside;
+    for (int chunk = 0; chunk * kSegThreads < n; chunk++) {
+        if (__syncthreads_count(pix_done) == kSegThreads) break;
+        // ---- stage + cull + block-wide compaction of this chunk
+        const int idx = chunk * kSegThreads + t;
+        bool bit = false;
+        float4 a, b, c;
+        uint32_t id = 0;
+        if (idx < n) {
+            id = point_list[range.x + idx];
+            a = rec[(size_t)id * 3 + 0]; b = rec[(size_t)id * 3 + 1]; c = rec[(size_t)id * 3 + 2];
+            bit = cull_quadrant(a, c, qx0, qy0);
+        }
+        const uint64_t bal = __ballot(bit);
+        if (lane == 0) sWaveCnt[wave] = (uint32_t)__popcll(bal);
+        __syncthreads();
+        uint32_t woff = 0, m = 0;
+#pragma unroll
+        for (int w = 0; w < kSegWaves; w++) { const uint32_t cw = sWaveCnt[w]; if (w < wave) woff += cw; m += cw; }
+        if (bit) {
+            const uint32_t s = woff + (uint32_t)__popcll(bal & lt_mask);
+            sA[s] = a; sB[s] = b; sC[s] = c; sId[s] = id; sIdx[s] = (uint32_t)idx;
+        }
+        __syncthreads();
+        if (m == 0) continue;
+        if (AUX) {
+            uint2 *dst = aux.compact + (size_t)q * aux.R + range.x + kbase;
+            if ((uint32_t)t < m) dst[t] = make_uint2(sId[t], sIdx[t]);
+        }
+        const uint32_t per = (m + kSegWaves - 1) / kSegWaves;          // <= 64 survivors per wave
+        const uint32_t s0 = min(m, (uint32_t)wave * per), s1 = min(m, s0 + per);
+        // ---- phase 1: transmittance product of my segment
+        float Tseg = 1.f;
+        for (uint32_t s = s0; s < s1; s += 4) {
+            float om[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t su = min(s + u, s1 - 1);
+                const float4 ga = sA[su], gb = sB[su];
+                const float dx = ga.x - pxf, dy = ga.y - pyf;
+                const float power = -0.5f * (ga.z * dx * dx + gb.x * dy * dy) - ga.w * dx * dy;
+                const float alpha = fminf(0.99f, gb.y * __expf(power));
+                const bool valid = (power <= 0.f) & (alpha >= (1.0f / 255.0f)) & (s + u < s1);
+                om[u] = valid ? 1.f - alpha : 1.f;
+            }
+            Tseg = (((Tseg * om[0]) * om[1]) * om[2]) * om[3];
+        }
+        sT[wave][lane] = Tseg;
+        __syncthreads();
+        float Tin = Tcarry, Tall = Tcarry;
+#pragma unroll
+        for (int w = 0; w < kSegWaves; w++) { const float tw = sT[w][lane]; if (w < wave) Tin *= tw; Tall *= tw; }
+        // ---- phase 2: composite my segment from T_in with the published sequential rule
+        float T = Tin;
+        bool done = !inside | (Tin < 0.0001f);
+        const bool done_at_start = done;
+        float d0 = 0.f, d1 = 0.f, d2 = 0.f, dD = 0.f, dA = 0.f;
+        uint32_t contributed = 0;
+        for (uint32_t s = s0; s < s1; s += 4) {
+            float al[4];
+            float4 gb4[4], gc4[4];
+            uint32_t li[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t su = min(s + u, s1 - 1);
+                const float4 ga = sA[su];
+                gb4[u] = sB[su]; gc4[u] = sC[su]; li[u] = sIdx[su] + 1u;
+                const float dx = ga.x - pxf, dy = ga.y - pyf;
+                const float power = -0.5f * (ga.z * dx * dx + gb4[u].x * dy * dy) - ga.w * dx * dy;
+                const float alpha = fminf(0.99f, gb4[u].y * __expf(power));
+                const bool valid = (power <= 0.f) & (alpha >= (1.0f / 255.0f)) & (s + u < s1);
+                al[u] = valid ? alpha : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const float test_T = T * (1.f - al[u]);
+                done = done | (test_T < 0.0001f);                 // the crossing Gaussian is NOT composited
+                const bool contrib = (al[u] > 0.f) & !done;
+                const float w = contrib ? al[u] * T : 0.f;
+                d0 = fmaf(gb4[u].w, w, d0); d1 = fmaf(gc4[u].x, w, d1); d2 = fmaf(gc4[u].y, w, d2);
+                dD = fmaf(gb4[u].z, w, dD);
+                dA += w;
+                T = contrib ? test_T : T;
+                last = contrib ? li[u] : last;
+                contributed |= contrib ? 1u : 0u;
+            }
+        }
+        if (done && !done_at_start) Tstop = T;                   // I am the segment in which this pixel stopped
+        C0 += d0; C1 += d1; C2 += d2; D += dD; A += dA;
+        if (AUX) {
+            sAcc[wave][0][lane] = d0; sAcc[wave][1][lane] = d1; sAcc[wave][2][lane] = d2; sAcc[wave][3][lane] = dD; sAcc[wave][4][lane] = dA;
+            __syncthreads();
+            float p0 = cc0, p1 = cc1, p2 = cc2, pD = ccD, pA = ccA;
+#pragma unroll
+            for (int w = 0; w < kSegWaves; w++) {
+                const float e0 = sAcc[w][0][lane], e1 = sAcc[w][1][lane], e2 = sAcc[w][2][lane], e3 = sAcc[w][3][lane], e4 = sAcc[w][4][lane];
+                if (w < wave) { p0 += e0; p1 += e1; p2 += e2; pD += e3; pA += e4; }
+                cc0 += e0; cc1 += e1; cc2 += e2; ccD += e3; ccA += e4;
+            }
+            const uint32_t nseg = (m + per - 1) / per;
+            if ((uint32_t)wave < nseg) {
+                const size_t slot = slot_next + wave;
+                if (kbase + s0 != 0u) {
+                    aux.ckpt_tc[slot * 64 + lane] = make_float4(Tin, p0, p1, p2);
+                    aux.ckpt_da[slot * 64 + lane] = make_float2(pD, pA);
+                }
+                // only buckets in which some pixel of the quadrant composited something can receive gradient
+                if (__ballot(contributed != 0u) && lane == 0)
+                    aux.desc[slot] = make_uint2(bid, ((kbase + s0) << 7) | (s1 - s0));
+            }
+            slot_next += nseg;
+        }
+        kbase += m;
+        Tcarry = Tall;
+        pix_done = !inside | (Tcarry < 0.0001f);
+    }
+    // ---- combine the 8 partial sums
+    __syncthreads();
+    if (Tstop >= 0.f) sTstop[lane] = Tstop;
+    sAcc[wave][0][lane] = C0; sAcc[wave][1][lane] = C1; sAcc[wave][2][lane] = C2; sAcc[wave][3][lane] = D; sAcc[wave][4][lane] = A;
+    sLast[wave][lane] = last;
+    __syncthreads();
+    if (wave == 0 && inside) {
+        float r0 = 0.f, r1 = 0.f, r2 = 0.f, rD = 0.f, rA = 0.f;
+        uint32_t lmax = 0;
+#pragma unroll
+        for (int w = 0; w < kSegWaves; w++) {
+            r0 += sAcc[w][0][lane]; r1 += sAcc[w][1][lane]; r2 += sAcc[w][2][lane]; rD += sAcc[w][3][lane]; rA += sAcc[w][4][lane];
+            lmax = max(lmax, sLast[w][lane]);
+        }
+        const float ts = sTstop[lane];
+        const float Tf = ts >= 0.f ? ts : Tcarry;
+        const size_t hw = (size_t)H * W;
+        const size_t pix = (size_t)py * W + px;
+        const size_t vb = (size_t)view * hw;
+        final_T[vb + pix] = Tf;
+        n_contrib[vb + pix] = lmax;
+        out_color[(vb * 3) + pix] = r0 + Tf * bg[0];
+        out_color[(vb * 3) + hw + pix] = r1 + Tf * bg[1];
+        out_color[(vb * 3) + 2 * hw + pix] = r2 + Tf * bg[2];
+        out_depth[vb + pix] = rD;
+        out_alpha[vb + pix] = rA;
     }
 }
 
@@ -370,7 +572,7 @@ __global__ __launch_bounds__(kBlock) void render_bwd_bucket_kernel(int W, int H,
     const uint32_t bid = (uint32_t)__builtin_amdgcn_readfirstlane((int)desc_v.x);
     const uint32_t count = desc_y & 127u;
     if (count == 0) return;                                   // unused bucket slot
-    const uint32_t bucket = desc_y >> 7;
+    const uint32_t start = desc_y >> 7;                        // ordinal of this bucket's first survivor in the quadrant list
     const uint32_t q = (uint32_t)(slot / aux.NS);
     const uint32_t view = bid / tiles_per_view, tile = bid - view * tiles_per_view;
     const uint32_t tx = tile % Tx, ty = tile / Tx;
@@ -378,7 +580,7 @@ __global__ __launch_bounds__(kBlock) void render_bwd_bucket_kernel(int W, int H,
     // ---- my Gaussian
     const bool has_g = (uint32_t)lane < count;
     uint2 e = make_uint2(0u, 0xFFFFFFFFu);
-    if (has_g) e = aux.compact[(size_t)q * aux.R + rx + (bucket << 6) + lane];
+    if (has_g) e = aux.compact[(size_t)q * aux.R + rx + start + lane];
     // a lane without a Gaussian gets list index 0xFFFFFFFF, which no pixel's n_contrib exceeds -> never valid
     const uint32_t gidx = e.y;
     float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra, rc = ra;
@@ -408,7 +610,7 @@ __global__ __launch_bounds__(kBlock) void render_bwd_bucket_kernel(int W, int H,
             if (gA) ga = gA[vb + pix];
             Rem += out_depth[vb + pix] * gd + out_alpha[vb + pix] * ga;
         }
-        if (bucket) {
+        if (start) {
             const float4 tc = aux.ckpt_tc[slot * 64 + p];
             T = tc.x;
             Rem -= tc.y * g0 + tc.z * g1 + tc.w * g2;
@@ -477,7 +679,11 @@ __global__ __launch_bounds__(kBlock) void render_bwd_bucket_kernel(int W, int H,
 
 int sgr_validate_problem(const SgrProblem *pb);
 
-extern "C" uint64_t sgr_bucket_slots(uint64_t R, uint64_t tiles_total) { return (R >> 6) + tiles_total + 1; }
+// 0 = automatic, 1 = serial per-tile kernel, 2 = segment-parallel kernel (dev/test override: sgr_set_forward_mode)
+static int sgr_fwd_mode = 0;
+extern "C" int sgr_set_forward_mode(int mode) { sgr_fwd_mode = mode; return 0; }
+
+extern "C" uint64_t sgr_bucket_slots(uint64_t R, uint64_t tiles_total) { return (R >> 6) + 8 * tiles_total + 1; }
 
 static FwdAux make_aux(void *compact, void *ckpt_tc, void *ckpt_da, void *desc, uint64_t R, uint64_t tiles_total) {
     FwdAux a;
@@ -498,6 +704,20 @@ extern "C" int sgr_render_forward(const SgrProblem *pb, const uint32_t *ranges, 
     FwdAux aux = make_aux(aux_compact, aux_ckpt_tc, aux_ckpt_da, aux_desc, R, (uint64_t)tiles * pb->n_views);
     if (use_aux) SGR_CHECK_HIP(hipMemsetAsync(aux_desc, 0, (size_t)4 * aux.NS * sizeof(uint2), stream));
     SgrProfScope _p(SGR_K_RENDER_FWD, stream);
+    // few workgroups (one or two 512^2 views): trade 1.5x arithmetic for an 8x shorter dependency chain
+    const bool seg = sgr_fwd_mode == 2 || (sgr_fwd_mode == 0 && (uint64_t)tiles * pb->n_views <= 2048);
+    if (seg) {
+        if (use_aux)
+            hipLaunchKernelGGL(render_fwd_seg_kernel<true>, dim3(tiles * pb->n_views * 4), dim3(kSegThreads), 0, stream, pb->W, pb->H,
+                               Tx, tiles, (const uint2 *)ranges, point_list, (const float4 *)rec, pb->bg, out_color, out_depth,
+                               out_alpha, final_T, n_contrib, aux);
+        else
+            hipLaunchKernelGGL(render_fwd_seg_kernel<false>, dim3(tiles * pb->n_views * 4), dim3(kSegThreads), 0, stream, pb->W, pb->H,
+                               Tx, tiles, (const uint2 *)ranges, point_list, (const float4 *)rec, pb->bg, out_color, out_depth,
+                               out_alpha, final_T, n_contrib, aux);
+        SGR_CHECK_LAUNCH("render_fwd_seg_kernel");
+        return 0;
+    }
     if (use_aux)
         hipLaunchKernelGGL(render_fwd_kernel<true>, dim3(tiles * pb->n_views), dim3(kBlock), 0, stream, pb->W, pb->H, Tx, tiles,
                            (const uint2 *)ranges, point_list, (const float4 *)rec, pb->bg, out_color, out_depth, out_alpha,

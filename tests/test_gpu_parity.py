@@ -21,6 +21,15 @@ def _dev():
     return torch.device("cuda:0")
 
 
+@pytest.fixture(params=[1, 2], ids=["fwd_serial", "fwd_segment_parallel"])
+def fwd_mode(request):
+    """Run the test once per forward compositing kernel (serial per-tile / segment-parallel); both must match the oracle."""
+    from sigman_release_amd import _cabi
+    _cabi.lib().sgr_set_forward_mode(request.param)
+    yield request.param
+    _cabi.lib().sgr_set_forward_mode(0)
+
+
 def _to_dev(inp, dev):
     return {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in inp.items()}
 
@@ -34,7 +43,7 @@ def _batched_settings(st, dev, vps):
 
 
 @pytest.mark.parametrize("name", list(cases.CASES))
-def test_forward_artefacts_and_images(name, oracle):
+def test_forward_artefacts_and_images(name, oracle, fwd_mode):
     from sigman_release_amd import rasterizer as R
     dev = _dev()
     inp, st = cases.CASES[name]()
@@ -73,7 +82,7 @@ def test_forward_artefacts_and_images(name, oracle):
 
 
 @pytest.mark.parametrize("name", list(cases.CASES))
-def test_backward_gradients(name, oracle):
+def test_backward_gradients(name, oracle, fwd_mode):
     from sigman_release_amd import rasterizer as R
     dev = _dev()
     inp, st = cases.CASES[name]()
@@ -147,7 +156,7 @@ def test_argument_errors():
         rast(means3D=m, means2D=m, opacities=torch.ones(4, 1, device=dev), colors_precomp=torch.ones(4, 3, device=dev))
 
 
-def test_batched_equals_per_view(oracle):
+def test_batched_equals_per_view(oracle, fwd_mode):
     """One batched launch chain over S=2 subjects x V=3 views == the per-view oracle, grads summed over views."""
     from sigman_release_amd import rasterizer as R
     dev = _dev()
