@@ -67,6 +67,7 @@ def main():
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--views-per-step", type=int, default=1, help="views per GPU per step (C2 = 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--exact-sync", action="store_true", help="read num_rendered back every step (upstream behaviour) instead of the sync-free capacity mode")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -90,6 +91,13 @@ def main():
     cv, cvp, cp = cameras.make_cameras(my_views)
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     st = R.BatchedRasterizationSettings(H, W, cameras.TAN_HALF_FOV, cameras.TAN_HALF_FOV, bg, 0.5, t(cv), t(cvp), 0, t(cp), len(my_views))
+    if not args.exact_sync:
+        # sync-free mode: size the binning buffers from one exact (untimed) forward, +25 % head-room; an overflow would raise
+        with torch.no_grad():
+            probe = R.forward_debug(subj["means3D"][None], subj["opacity"][None], colors_precomp=subj["rgb"][None],
+                                    cov3D_precomp=subj["cov3D"][None], settings=st)
+        st = st._replace(max_rendered=int(probe["num_rendered"] * 1.25) + 4096)
+        del probe
     n_total_views = len(all_views)
     norm = 1.0 / (n_total_views * 3 * H * W)
 
@@ -166,7 +174,7 @@ def main():
     # ---- workload counters (from the run's own buffers)
     with torch.no_grad():
         dbg = R.forward_debug(subj["means3D"][None], subj["opacity"][None], colors_precomp=subj["rgb"][None],
-                              cov3D_precomp=subj["cov3D"][None], settings=st)
+                              cov3D_precomp=subj["cov3D"][None], settings=st._replace(max_rendered=0))
         Rn = int(dbg["num_rendered"])
         S_visits = int(dbg["n_contrib"].to(torch.int64).sum().item())
     ms_per_step = elapsed / args.steps * 1e3
@@ -185,7 +193,8 @@ def main():
         "config": {"workload": f"C2: procedural humanoid (SMPL-X stand-in), {P} Gaussians, {len(my_views)} view(s)/GPU/step "
                                f"{H}x{W}, fwd+bwd, colors_precomp+cov3D_precomp, clamp+L1 loss",
                    "views_per_step_total": n_total_views, "parallelism": f"view-parallel x{world}" if world > 1 else "single GPU",
-                   "num_rendered_per_gpu": Rn, "gaussian_pixel_visits_per_gpu": S_visits},
+                   "num_rendered_per_gpu": Rn, "gaussian_pixel_visits_per_gpu": S_visits,
+                   "binning_buffers": "exact (D2H read of num_rendered per step)" if args.exact_sync else f"pre-sized, max_rendered={st.max_rendered} (sync-free)"},
         "gaussian_pixel_ops_per_s_per_gpu": round(S_visits / (ms_per_step * 1e-3), 1),
         "tile_instances_per_s_per_gpu": round(Rn / (ms_per_step * 1e-3), 1),
         "roofline": {"bound": "hbm", "kernel": KERNELS.get(dominant, str(dominant)), "achieved": round(achieved, 2),

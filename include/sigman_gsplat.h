@@ -80,6 +80,50 @@ typedef struct SgrProblem {
 int sgr_abi_version(void);
 const char *sgr_last_error(void);
 
+/* ---- one-call API (upstream-shaped: allocator callbacks, all views of a batch) --------------- */
+
+/*
+ * Allocator callback, the C-ABI form of upstream's `std::function<char*(size_t)>` resize functors: must return a DEVICE
+ * pointer to at least `bytes` bytes (256-byte aligned) that stays valid until the matching backward has run.
+ * which: 0 = geometry blob, 1 = binning blob, 2 = image blob, 3 = backward scratch.
+ */
+typedef char *(*sgr_alloc_fn)(void *user, int32_t which, size_t bytes);
+
+/* Filled by sgr_rasterize_forward; the caller keeps it (and the blobs) alive for sgr_rasterize_backward. */
+typedef struct SgrForwardState {
+    uint64_t R_alloc;            /* size of the binning buffers in tile instances: exact num_rendered, or the capacity */
+    uint64_t true_rendered;      /* exact mode: num_rendered; sync-free mode: ~0 (read nr_pinned_host after nr_event) */
+    uint64_t NS;                 /* bucket slots per quadrant */
+    int32_t with_aux, result_in_b;
+    void *geom, *binning, *image;
+    uint64_t geom_bytes, binning_bytes, image_bytes;
+    uint64_t off_rec, off_rect, off_clamped, off_block_offsets, off_num_rendered;               /* in geom   */
+    uint64_t off_keys_a, off_keys_b, off_vals_a, off_vals_b, off_sort_ws;                        /* in binning */
+    uint64_t off_ranges, off_final_T, off_n_contrib, off_compact, off_ckpt_tc, off_ckpt_da, off_desc;   /* in image */
+} SgrForwardState;
+
+/*
+ * == upstream _C.rasterize_gaussians (gs.py:98-106), for all n_views view slots at once.
+ * capacity = 0: exact mode, ONE blocking read of num_rendered per call (upstream: one per view).
+ * capacity > 0: sync-free mode; binning buffers sized for `capacity` instances; the true count is copied asynchronously to
+ *               nr_pinned_host[0] (and [1] = overflow flag) and `nr_event` (a hipEvent_t, may be NULL) is recorded right after.
+ * with_aux != 0 also records what the bucket-parallel backward needs.
+ * Outputs: out_color [n_views,3,H,W], out_depth/out_alpha [n_views,1,H,W], out_radii i32 [n_views,P].
+ */
+int sgr_rasterize_forward(const SgrProblem *pb, uint64_t capacity, int32_t with_aux, sgr_alloc_fn alloc, void *user,
+                          float *out_color, float *out_depth, float *out_alpha, int32_t *out_radii, uint64_t *nr_pinned_host,
+                          void *nr_event, SgrForwardState *state, void *stream);
+
+/*
+ * == upstream _C.rasterize_gaussians_backward (reached from train_vae.py:166).  Gradient outputs as in
+ * sgr_preprocess_backward.  out_color/out_depth/out_alpha are the forward's outputs.
+ */
+int sgr_rasterize_backward(const SgrProblem *pb, const SgrForwardState *state, const int32_t *radii, const float *out_color,
+                           const float *out_depth, const float *out_alpha, const float *grad_color, const float *grad_depth,
+                           const float *grad_alpha, sgr_alloc_fn alloc, void *user, float *dL_dmeans3D, float *dL_dmeans2D,
+                           float *dL_dopacity, float *dL_dcolors, float *dL_dsh, float *dL_dcov3D, float *dL_dscales,
+                           float *dL_drotations, void *stream);
+
 /* ---- staged, batched API -------------------------------------------------------------------- */
 
 /* number of preprocess thread blocks per view (block_offsets needs n_views*that + 1 entries) */
@@ -90,10 +134,12 @@ int32_t sgr_preprocess_blocks_per_view(int32_t P);
  * exclusive scan.  Outputs: rec [n_views*P*12], radii i32 [n_views*P], rect u32 [n_views*P*2]
  * (minx | miny<<16, maxx | maxy<<16), clamped u8 [n_views*P] (SH clamp bits, may be NULL without shs),
  * block_offsets u32 [2*(n_views*blocks_per_view + 1)] (first half: exclusive offsets, entry n = R; second half:
- * scratch for the un-scanned sums), num_rendered u64 [2] ([0] = R, [1] = 1 if R overflows the 32-bit instance index).
+ * scratch for the un-scanned sums), num_rendered u64 [2] ([0] = R, [1] = 1 if R overflows the 32-bit instance index or
+ * `capacity`).  capacity = 0: none (the caller reads R back and sizes the binning buffers exactly, like upstream);
+ * capacity > 0: the caller pre-sized its binning buffers for `capacity` instances and never reads R on the critical path.
  */
 int sgr_preprocess_forward(const SgrProblem *pb, float *rec, int32_t *radii, uint32_t *rect, uint8_t *clamped,
-                           uint32_t *block_offsets, uint64_t *num_rendered, void *stream);
+                           uint32_t *block_offsets, uint64_t *num_rendered, uint64_t capacity, void *stream);
 
 /* bytes of scratch sgr_bin needs for R tile instances */
 size_t sgr_bin_workspace_bytes(uint64_t R);
@@ -101,12 +147,14 @@ size_t sgr_bin_workspace_bytes(uint64_t R);
 /*
  * F3 + F4 + F5: emit (key,value) per touched tile, stable LSD radix sort on the significant key bits,
  * per-tile ranges.  key = ((view*tiles + tile) << 32) | float_bits(depth); value = v*P + i.
+ * R = exact instance count (num_rendered_dev = NULL), or the buffer CAPACITY with num_rendered_dev pointing at the device
+ * counter written by sgr_preprocess_forward (sync-free mode: grids are sized by the capacity, kernels read the true count).
  * keys/vals: two buffers of R entries each (ping-pong).  On return *result_in_b_host tells which
  * buffer holds the sorted list.  ranges u32 [n_views*tiles*2] (start,end) into the sorted list.
  */
 int sgr_bin(const SgrProblem *pb, const float *rec, const int32_t *radii, const uint32_t *rect,
-            const uint32_t *block_offsets, uint64_t R, uint64_t *keys_a, uint64_t *keys_b, uint32_t *vals_a,
-            uint32_t *vals_b, void *workspace, size_t workspace_bytes, uint32_t *ranges,
+            const uint32_t *block_offsets, uint64_t R, const uint64_t *num_rendered_dev, uint64_t *keys_a, uint64_t *keys_b,
+            uint32_t *vals_a, uint32_t *vals_b, void *workspace, size_t workspace_bytes, uint32_t *ranges,
             int32_t *result_in_b_host, void *stream);
 
 /* number of bucket slots per quadrant for the auxiliary forward outputs: (R >> 6) + 8*tiles_total + 1 */

@@ -33,7 +33,7 @@ __global__ __launch_bounds__(kThreads) void duplicate_keys_kernel(int P, int Tx,
                                                                   const float4 *__restrict__ rec,
                                                                   const int32_t *__restrict__ radii,
                                                                   const uint2 *__restrict__ rect,
-                                                                  const uint32_t *__restrict__ block_offsets,
+                                                                  const uint32_t *__restrict__ block_offsets, uint32_t cap,
                                                                   uint64_t *__restrict__ keys, uint32_t *__restrict__ vals) {
     __shared__ uint32_t wave_tot[4];
     const int view = blockIdx.y;
@@ -67,8 +67,10 @@ __global__ __launch_bounds__(kThreads) void duplicate_keys_kernel(int P, int Tx,
         const uint32_t tbase = (uint32_t)view * (uint32_t)tiles_per_view;
         for (int y = miny; y < maxy; y++)
             for (int x = minx; x < maxx; x++) {
-                keys[off] = ((uint64_t)(tbase + (uint32_t)(y * Tx + x)) << 32) | dbits;
-                vals[off] = (uint32_t)q;
+                if (off < cap) {                                   // capacity mode: never write past the caller's buffers
+                    keys[off] = ((uint64_t)(tbase + (uint32_t)(y * Tx + x)) << 32) | dbits;
+                    vals[off] = (uint32_t)q;
+                }
                 off++;
             }
     }
@@ -79,9 +81,10 @@ __global__ __launch_bounds__(kThreads) void duplicate_keys_kernel(int P, int Tx,
 // exclusive scan yields, for every (digit, block), the global output offset of that block's first key
 // with that digit.
 template <int ITEMS>
-__global__ __launch_bounds__(kThreads) void radix_upsweep_kernel(const uint64_t *__restrict__ keys, uint32_t n, int shift,
-                                                                 uint32_t nblocks, uint32_t *__restrict__ hist) {
+__global__ __launch_bounds__(kThreads) void radix_upsweep_kernel(const uint64_t *__restrict__ keys, uint32_t n_host, const uint64_t *__restrict__ n_dev,
+                                                                 int shift, uint32_t nblocks, uint32_t *__restrict__ hist) {
     __shared__ uint32_t h[kRadix];
+    const uint32_t n = n_dev ? (uint32_t)min((uint64_t)n_host, *n_dev) : n_host;
     h[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t base = blockIdx.x * (kThreads * ITEMS);
@@ -132,9 +135,11 @@ template <int ITEMS>
 __global__ __launch_bounds__(kThreads) void radix_downsweep_kernel(const uint64_t *__restrict__ keys_in,
                                                                    const uint32_t *__restrict__ vals_in,
                                                                    uint64_t *__restrict__ keys_out,
-                                                                   uint32_t *__restrict__ vals_out, uint32_t n, int shift,
+                                                                   uint32_t *__restrict__ vals_out, uint32_t n_host,
+                                                                   const uint64_t *__restrict__ n_dev, int shift,
                                                                    uint32_t nblocks, const uint32_t *__restrict__ hist,
                                                                    const uint32_t *__restrict__ totals) {
+    const uint32_t n = n_dev ? (uint32_t)min((uint64_t)n_host, *n_dev) : n_host;
     __shared__ uint32_t digit_base[kRadix];
     __shared__ uint32_t wave_cnt[4][kRadix];
     __shared__ uint32_t wtot[4];
@@ -188,8 +193,9 @@ __global__ __launch_bounds__(kThreads) void radix_downsweep_kernel(const uint64_
 }
 
 // ---- F5 -------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kThreads) void tile_ranges_kernel(const uint64_t *__restrict__ keys, uint32_t n,
-                                                               uint2 *__restrict__ ranges) {
+__global__ __launch_bounds__(kThreads) void tile_ranges_kernel(const uint64_t *__restrict__ keys, uint32_t n_host,
+                                                               const uint64_t *__restrict__ n_dev, uint2 *__restrict__ ranges) {
+    const uint32_t n = n_dev ? (uint32_t)min((uint64_t)n_host, *n_dev) : n_host;
     const uint32_t r = blockIdx.x * kThreads + threadIdx.x;
     if (r >= n) return;
     const uint32_t tile = (uint32_t)(keys[r] >> 32);
@@ -213,9 +219,9 @@ extern "C" size_t sgr_bin_workspace_bytes(uint64_t R) {
 }
 
 extern "C" int sgr_bin(const SgrProblem *pb, const float *rec, const int32_t *radii, const uint32_t *rect,
-                       const uint32_t *block_offsets, uint64_t R, uint64_t *keys_a, uint64_t *keys_b, uint32_t *vals_a,
-                       uint32_t *vals_b, void *workspace, size_t workspace_bytes, uint32_t *ranges,
-                       int32_t *result_in_b_host, void *stream_) {
+                       const uint32_t *block_offsets, uint64_t R, const uint64_t *num_rendered_dev, uint64_t *keys_a,
+                       uint64_t *keys_b, uint32_t *vals_a, uint32_t *vals_b, void *workspace, size_t workspace_bytes,
+                       uint32_t *ranges, int32_t *result_in_b_host, void *stream_) {
     if (sgr_validate_problem(pb)) return 1;
     hipStream_t stream = (hipStream_t)stream_;
     const int Tx = (pb->W + SGR_TILE - 1) / SGR_TILE, Ty = (pb->H + SGR_TILE - 1) / SGR_TILE;
@@ -230,7 +236,7 @@ extern "C" int sgr_bin(const SgrProblem *pb, const float *rec, const int32_t *ra
     const int nbx = sgr_preprocess_blocks_per_view(pb->P);
     { SgrProfScope _p(SGR_K_DUPLICATE, stream);
     hipLaunchKernelGGL(duplicate_keys_kernel, dim3(nbx, pb->n_views), dim3(kThreads), 0, stream, pb->P, Tx, Tx * Ty,
-                       (const float4 *)rec, radii, (const uint2 *)rect, block_offsets, keys_a, vals_a);
+                       (const float4 *)rec, radii, (const uint2 *)rect, block_offsets, n, keys_a, vals_a);
     SGR_CHECK_LAUNCH("duplicate_keys_kernel");
     }
     const bool small = n <= (1u << 19);
@@ -245,13 +251,13 @@ extern "C" int sgr_bin(const SgrProblem *pb, const float *rec, const int32_t *ra
     { SgrProfScope _ps(SGR_K_SORT, stream);
     for (int p = 0; p < passes; p++) {
         const int shift = p * kRadixBits;
-        if (small) hipLaunchKernelGGL(radix_upsweep_kernel<kItemsSmall>, dim3(nblocks), dim3(kThreads), 0, stream, kin, n, shift, nblocks, hist);
-        else hipLaunchKernelGGL(radix_upsweep_kernel<kItemsLarge>, dim3(nblocks), dim3(kThreads), 0, stream, kin, n, shift, nblocks, hist);
+        if (small) hipLaunchKernelGGL(radix_upsweep_kernel<kItemsSmall>, dim3(nblocks), dim3(kThreads), 0, stream, kin, n, num_rendered_dev, shift, nblocks, hist);
+        else hipLaunchKernelGGL(radix_upsweep_kernel<kItemsLarge>, dim3(nblocks), dim3(kThreads), 0, stream, kin, n, num_rendered_dev, shift, nblocks, hist);
         SGR_CHECK_LAUNCH("radix_upsweep_kernel");
         hipLaunchKernelGGL(radix_rowscan_kernel, dim3(kRadix), dim3(kThreads), 0, stream, hist, nblocks, totals);
         SGR_CHECK_LAUNCH("radix_rowscan_kernel");
-        if (small) hipLaunchKernelGGL(radix_downsweep_kernel<kItemsSmall>, dim3(nblocks), dim3(kThreads), 0, stream, kin, vin, kout, vout, n, shift, nblocks, hist, totals);
-        else hipLaunchKernelGGL(radix_downsweep_kernel<kItemsLarge>, dim3(nblocks), dim3(kThreads), 0, stream, kin, vin, kout, vout, n, shift, nblocks, hist, totals);
+        if (small) hipLaunchKernelGGL(radix_downsweep_kernel<kItemsSmall>, dim3(nblocks), dim3(kThreads), 0, stream, kin, vin, kout, vout, n, num_rendered_dev, shift, nblocks, hist, totals);
+        else hipLaunchKernelGGL(radix_downsweep_kernel<kItemsLarge>, dim3(nblocks), dim3(kThreads), 0, stream, kin, vin, kout, vout, n, num_rendered_dev, shift, nblocks, hist, totals);
         SGR_CHECK_LAUNCH("radix_downsweep_kernel");
         uint64_t *tk = kin; kin = kout; kout = tk;
         uint32_t *tv = vin; vin = vout; vout = tv;
@@ -260,7 +266,7 @@ extern "C" int sgr_bin(const SgrProblem *pb, const float *rec, const int32_t *ra
     if (result_in_b_host) *result_in_b_host = (kin == keys_b) ? 1 : 0;
     { SgrProfScope _p(SGR_K_RANGES, stream);
     hipLaunchKernelGGL(tile_ranges_kernel, dim3((n + kThreads - 1) / kThreads), dim3(kThreads), 0, stream, kin, n,
-                       (uint2 *)ranges);
+                       num_rendered_dev, (uint2 *)ranges);
     SGR_CHECK_LAUNCH("tile_ranges_kernel");
     }
     return 0;

@@ -279,7 +279,7 @@ __global__ __launch_bounds__(kPreThreads) void preprocess_fwd_kernel(SgrProblem 
 // -------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void scan_block_sums_kernel(const uint32_t *__restrict__ in, uint32_t *__restrict__ out,
                                                                uint32_t n, uint64_t *__restrict__ num_rendered,
-                                                               uint32_t *__restrict__ overflow) {
+                                                               unsigned long long capacity) {
     __shared__ unsigned long long part[1024];
     const uint32_t t = threadIdx.x;
     const uint32_t chunk = (n + 1023u) / 1024u;
@@ -299,8 +299,8 @@ __global__ __launch_bounds__(1024) void scan_block_sums_kernel(const uint32_t *_
     if (t == 1023) {
         const unsigned long long total = part[1023];
         out[n] = (uint32_t)total;
-        *num_rendered = total;
-        *overflow = total > 0xFFFFFFF0ull ? 1u : 0u;
+        num_rendered[0] = total;
+        num_rendered[1] = (total > 0xFFFFFFF0ull || total > capacity) ? 1ull : 0ull;
     }
 }
 
@@ -518,8 +518,9 @@ int sgr_validate_problem(const SgrProblem *pb) { return validate_problem(pb); }
 extern "C" int32_t sgr_preprocess_blocks_per_view(int32_t P) { return P <= 0 ? 1 : (P + kPreThreads - 1) / kPreThreads; }
 
 extern "C" int sgr_preprocess_forward(const SgrProblem *pb, float *rec, int32_t *radii, uint32_t *rect, uint8_t *clamped,
-                                      uint32_t *block_offsets, uint64_t *num_rendered, void *stream_) {
+                                      uint32_t *block_offsets, uint64_t *num_rendered, uint64_t capacity, void *stream_) {
     if (validate_problem(pb)) return 1;
+    if (capacity == 0) capacity = ~0ull;
     hipStream_t stream = (hipStream_t)stream_;
     const int nbx = sgr_preprocess_blocks_per_view(pb->P);
     const uint32_t n = (uint32_t)nbx * (uint32_t)pb->n_views;
@@ -534,7 +535,7 @@ extern "C" int sgr_preprocess_forward(const SgrProblem *pb, float *rec, int32_t 
     }
     { SgrProfScope _p(SGR_K_SCAN, stream);
     hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(1024), 0, stream, sums, block_offsets, n, num_rendered,
-                       (uint32_t *)(num_rendered + 1));
+                       (unsigned long long)capacity);
     SGR_CHECK_LAUNCH("scan_block_sums_kernel");
     }
     return 0;

@@ -51,6 +51,10 @@ class BatchedRasterizationSettings(NamedTuple):
     campos: torch.Tensor        # [n_views,3]
     views_per_subject: int
     debug: bool = False
+    # 0: exact mode (one device->host read of num_rendered per batched forward, like upstream does per view).
+    # >0: sync-free mode: binning buffers are pre-sized for this many tile instances; an overflow raises at backward /
+    #     at the next call (checked through an async copy + event, never on the critical path).
+    max_rendered: int = 0
 
 
 # SIGMAN_BWD_V1=1 selects the pixel-parallel backward (no auxiliary forward outputs) for A/B comparisons
@@ -71,10 +75,59 @@ def _f32c(t: torch.Tensor) -> torch.Tensor:
     return t.contiguous()
 
 
+class _PinnedRing:
+    """Small ring of pinned host slots + events for the asynchronous num_rendered read-back (allocating pinned memory or
+    events per call would cost more than the sync it replaces)."""
+
+    def __init__(self, n=32):
+        self.n, self.i, self.buf, self.ev = n, 0, None, None
+
+    def next(self):
+        if self.buf is None:
+            self.buf = torch.zeros(self.n, 2, dtype=torch.int64).pin_memory()
+            self.ev = [torch.cuda.Event() for _ in range(self.n)]
+            for e in self.ev:
+                e.record()                     # materialises the underlying hipEvent_t so its handle can cross the C ABI
+        k = self.i
+        self.i = (self.i + 1) % self.n
+        return self.buf[k], self.ev[k]
+
+
+_ring = _PinnedRing()
+
+# one persistent allocator callback for the C ABI (creating a ctypes callback per call costs ~10 us); it serves the call
+# that is currently in flight on this thread: PyTorch allocates, the library only receives the pointer.
+_alloc_target = {"dev": None, "blobs": None}
+
+
+def _alloc_cb(_user, which, nbytes):
+    t = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=_alloc_target["dev"])
+    _alloc_target["blobs"][which] = t
+    return t.data_ptr()
+
+
+_ALLOC = _cabi.ALLOC_FN(_alloc_cb)
+
+
 class _Ctx:
-    """Plain holder for the forward's device buffers (== upstream geomBuffer / binningBuffer / imgBuffer)."""
-    __slots__ = ("pb", "keep", "rec", "radii", "rect", "clamped", "point_list", "keys", "ranges", "final_T", "n_contrib",
-                 "num_rendered", "dims", "aux", "images")
+    """What the forward leaves behind for the backward (== upstream geomBuffer / binningBuffer / imgBuffer + num_rendered)."""
+    __slots__ = ("state", "blobs", "radii", "images", "dims", "nr_host", "nr_event", "capacity", "true_rendered", "keep")
+
+    def check_overflow(self):
+        """Sync-free mode: raise if the forward needed more tile instances than `max_rendered` (cheap: the copy finished long ago)."""
+        if self.nr_event is not None:
+            self.nr_event.synchronize()
+            nr = self.nr_host.tolist()
+            self.nr_event = None
+            self.true_rendered = int(nr[0])
+            if nr[1] != 0:
+                raise RuntimeError(f"num_rendered {nr[0]} exceeds max_rendered {self.capacity}: results of this forward are truncated; "
+                                   "raise BatchedRasterizationSettings.max_rendered (or use 0 = exact mode)")
+
+    def view(self, which, off, count, dtype):
+        """Typed tensor view into one of the three blobs (debug / parity tests)."""
+        esz = torch.empty(0, dtype=dtype).element_size()
+        return self.blobs[which][off: off + count * esz].view(dtype)
 
 
 def _make_problem(means3D, opacities, colors_precomp, shs, cov3D_precomp, scales, rotations, st: BatchedRasterizationSettings):
@@ -91,7 +144,7 @@ def _make_problem(means3D, opacities, colors_precomp, shs, cov3D_precomp, scales
 
 
 def _forward_impl(means3D, opacities, colors_precomp, shs, cov3D_precomp, scales, rotations, st: BatchedRasterizationSettings,
-                  need_ctx: bool, keep_keys: bool = False):
+                  need_ctx: bool, with_aux: bool = True):
     L = _cabi.lib()
     dev = means3D.device
     if dev.type != "cuda":
@@ -100,66 +153,30 @@ def _forward_impl(means3D, opacities, colors_precomp, shs, cov3D_precomp, scales
     H, W = int(st.image_height), int(st.image_width)
     nv = st.viewmatrix.shape[0]
     pb = _make_problem(means3D, opacities, colors_precomp, shs, cov3D_precomp, scales, rotations, st)
-    stream = _stream()
-    Tx, Ty = (W + 15) // 16, (H + 15) // 16
-    tiles = Tx * Ty
-    i32, u8, f32 = torch.int32, torch.uint8, torch.float32
-    nq = max(nv * P, 1)
-    rec = torch.empty(nq * 12, dtype=f32, device=dev)
-    radii = torch.empty(nq, dtype=i32, device=dev)
-    rect = torch.empty(nq * 2, dtype=i32, device=dev)
-    clamped = torch.empty(nq, dtype=u8, device=dev) if shs is not None else None
-    nbx = L.sgr_preprocess_blocks_per_view(P)
-    block_offsets = torch.empty(2 * (nbx * nv + 1), dtype=i32, device=dev)
-    num_rendered = torch.zeros(2, dtype=torch.int64, device=dev)
+    f32 = torch.float32
     color = torch.empty(nv, 3, H, W, dtype=f32, device=dev)
     depth = torch.empty(nv, 1, H, W, dtype=f32, device=dev)
     alpha = torch.empty(nv, 1, H, W, dtype=f32, device=dev)
-    final_T = torch.empty(nv, H, W, dtype=f32, device=dev)
-    n_contrib = torch.empty(nv, H, W, dtype=i32, device=dev)
-    ranges = torch.empty(nv * tiles * 2, dtype=i32, device=dev)
-    R = 0
-    if P > 0:
-        _cabi.check(L.sgr_preprocess_forward(C.byref(pb), _ptr(rec), _ptr(radii), _ptr(rect), _ptr(clamped),
-                                             _ptr(block_offsets), _ptr(num_rendered), stream), "sgr_preprocess_forward")
-        nr = num_rendered.tolist()              # the ONE device->host sync of a batched forward (upstream: one per view)
-        R = int(nr[0])
-        if nr[1] != 0:
-            raise RuntimeError(f"num_rendered {R} exceeds the 32-bit instance index")
-    keys_a = torch.empty(max(R, 1), dtype=torch.int64, device=dev)
-    keys_b = torch.empty(max(R, 1), dtype=torch.int64, device=dev)
-    vals_a = torch.empty(max(R, 1), dtype=i32, device=dev)
-    vals_b = torch.empty(max(R, 1), dtype=i32, device=dev)
-    ws_bytes = L.sgr_bin_workspace_bytes(R)
-    ws = torch.empty(ws_bytes, dtype=u8, device=dev)
-    in_b = C.c_int32(0)
-    _cabi.check(L.sgr_bin(C.byref(pb), _ptr(rec), _ptr(radii), _ptr(rect), _ptr(block_offsets), R, _ptr(keys_a), _ptr(keys_b),
-                          _ptr(vals_a), _ptr(vals_b), _ptr(ws), ws_bytes, _ptr(ranges), C.byref(in_b), stream), "sgr_bin")
-    point_list = vals_b if in_b.value else vals_a
-    keys = keys_b if in_b.value else keys_a
-    aux = None
-    if need_ctx and not keep_keys and R > 0 and not _USE_BWD_V1:
-        NS = L.sgr_bucket_slots(R, nv * tiles)
-        aux = (torch.empty(4 * R * 2, dtype=i32, device=dev), torch.empty(4 * NS * 64 * 4, dtype=f32, device=dev),
-               torch.empty(4 * NS * 64 * 2, dtype=f32, device=dev), torch.empty(4 * NS * 2, dtype=i32, device=dev))
-    ax = aux if aux is not None else (None, None, None, None)
-    _cabi.check(L.sgr_render_forward(C.byref(pb), _ptr(ranges), _ptr(point_list), _ptr(rec), _ptr(color), _ptr(depth),
-                                     _ptr(alpha), _ptr(final_T), _ptr(n_contrib), R, _ptr(ax[0]), _ptr(ax[1]), _ptr(ax[2]),
-                                     _ptr(ax[3]), stream), "sgr_render_forward")
-    radii_out = radii[: nv * P].view(nv, P)
+    radii = torch.empty(nv, P, dtype=torch.int32, device=dev)
+    capacity = int(getattr(st, "max_rendered", 0) or 0)
+    nr_host, nr_event = _ring.next()
+    state = _cabi.SgrForwardState()
+    blobs = [None, None, None, None]
+    _alloc_target["dev"], _alloc_target["blobs"] = dev, blobs
+    use_aux = 1 if (need_ctx and with_aux and not _USE_BWD_V1) else 0
+    _cabi.check(L.sgr_rasterize_forward(C.byref(pb), capacity, use_aux, _ALLOC, None, color.data_ptr(), depth.data_ptr(),
+                                        alpha.data_ptr(), radii.data_ptr(), nr_host.data_ptr(),
+                                        nr_event.cuda_event if capacity > 0 else None, C.byref(state), _stream()),
+                "sgr_rasterize_forward")
     ctx = None
     if need_ctx:
         ctx = _Ctx()
-        ctx.pb = pb
-        ctx.rec, ctx.radii, ctx.rect, ctx.clamped = rec, radii, rect, clamped
-        ctx.point_list, ctx.ranges, ctx.final_T, ctx.n_contrib = point_list, ranges, final_T, n_contrib
-        ctx.keys = keys if keep_keys else None
-        ctx.num_rendered = R
+        ctx.state, ctx.blobs, ctx.radii, ctx.images = state, blobs, radii, (color, depth, alpha)
         ctx.dims = (S, P, nv, H, W)
+        ctx.nr_host, ctx.nr_event, ctx.capacity = nr_host, (nr_event if capacity > 0 and P > 0 else None), capacity
+        ctx.true_rendered = int(state.true_rendered) if capacity == 0 else None
         ctx.keep = (st.viewmatrix, st.projmatrix, st.campos, st.bg)
-        ctx.aux = aux
-        ctx.images = (color, depth, alpha)
-    return color, radii_out, depth, alpha, ctx
+    return color, radii, depth, alpha, ctx
 
 
 def _backward_impl(ctx: _Ctx, means3D, opacities, colors_precomp, shs, cov3D_precomp, scales, rotations,
@@ -168,18 +185,11 @@ def _backward_impl(ctx: _Ctx, means3D, opacities, colors_precomp, shs, cov3D_pre
     S, P, nv, H, W = ctx.dims
     dev = means3D.device
     f32 = torch.float32
+    ctx.check_overflow()
     pb = _make_problem(means3D, opacities, colors_precomp, shs, cov3D_precomp, scales, rotations, st)
-    stream = _stream()
-    grec = torch.empty(max(nv * P, 1) * 12, dtype=f32, device=dev)
     gC = _f32c(grad_color)
     gD = None if grad_depth is None else _f32c(grad_depth)
     gA = None if grad_alpha is None else _f32c(grad_alpha)
-    ax = ctx.aux if ctx.aux is not None else (None, None, None, None)
-    img = ctx.images
-    _cabi.check(L.sgr_render_backward(C.byref(pb), _ptr(ctx.ranges), _ptr(ctx.point_list), _ptr(ctx.rec), _ptr(ctx.final_T),
-                                      _ptr(ctx.n_contrib), _ptr(img[0]), _ptr(img[1]), _ptr(img[2]), _ptr(gC), _ptr(gD), _ptr(gA),
-                                      ctx.num_rendered, _ptr(ax[0]), _ptr(ax[1]), _ptr(ax[2]), _ptr(ax[3]), _ptr(grec), stream),
-                "sgr_render_backward")
     d_means3D = torch.empty(S, P, 3, dtype=f32, device=dev)
     d_means2D = torch.empty(nv, P, 3, dtype=f32, device=dev)
     d_op = torch.empty(S, P, dtype=f32, device=dev)
@@ -188,9 +198,14 @@ def _backward_impl(ctx: _Ctx, means3D, opacities, colors_precomp, shs, cov3D_pre
     d_sh = torch.empty_like(shs) if shs is not None else None
     d_sc = torch.empty(S, P, 3, dtype=f32, device=dev) if scales is not None else None
     d_rot = torch.empty(S, P, 4, dtype=f32, device=dev) if scales is not None else None
-    _cabi.check(L.sgr_preprocess_backward(C.byref(pb), _ptr(ctx.radii), _ptr(ctx.clamped), _ptr(grec), _ptr(d_means3D),
-                                          _ptr(d_means2D), _ptr(d_op), _ptr(d_col), _ptr(d_sh), _ptr(d_cov), _ptr(d_sc),
-                                          _ptr(d_rot), stream), "sgr_preprocess_backward")
+    blobs = ctx.blobs
+    _alloc_target["dev"], _alloc_target["blobs"] = dev, blobs
+    img = ctx.images
+    _cabi.check(L.sgr_rasterize_backward(C.byref(pb), C.byref(ctx.state), _ptr(ctx.radii), _ptr(img[0]), _ptr(img[1]), _ptr(img[2]),
+                                         _ptr(gC), _ptr(gD), _ptr(gA), _ALLOC, None, _ptr(d_means3D), _ptr(d_means2D), _ptr(d_op),
+                                         _ptr(d_col), _ptr(d_sh), _ptr(d_cov), _ptr(d_sc), _ptr(d_rot), _stream()),
+                "sgr_rasterize_backward")
+    grec = blobs[3]
     return d_means3D, d_means2D, d_sh, d_col, d_op, d_sc, d_rot, d_cov, grec
 
 
@@ -324,10 +339,22 @@ def forward_debug(means3D, opacities, *, colors_precomp=None, shs=None, cov3D_pr
         opt = lambda t: None if t is None else _f32c(t)
         color, radii, depth, alpha, c = _forward_impl(_f32c(means3D), _f32c(opacities).reshape(S, P), opt(colors_precomp),
                                                       opt(shs), opt(cov3D_precomp), opt(scales), opt(rotations), st,
-                                                      need_ctx=True, keep_keys=True)
+                                                      need_ctx=True, with_aux=False)
         nv = st.viewmatrix.shape[0]
-        R = c.num_rendered
-        return dict(color=color, radii=radii, depth=depth, alpha=alpha, rec=c.rec[: nv * P * 12].view(nv, P, 12),
-                    rect=c.rect[: nv * P * 2].view(nv, P, 2), clamped=c.clamped, point_list=c.point_list[:R],
-                    keys=c.keys[:R], ranges=c.ranges.view(nv, -1, 2), final_T=c.final_T, n_contrib=c.n_contrib,
+        H, W = int(st.image_height), int(st.image_width)
+        tiles = ((W + 15) // 16) * ((H + 15) // 16)
+        c.check_overflow()
+        R = c.true_rendered
+        s_ = c.state
+        i32, i64, f32, u8 = torch.int32, torch.int64, torch.float32, torch.uint8
+        in_b = bool(s_.result_in_b)
+        return dict(color=color, radii=radii, depth=depth, alpha=alpha,
+                    rec=c.view(0, s_.off_rec, nv * P * 12, f32).view(nv, P, 12),
+                    rect=c.view(0, s_.off_rect, nv * P * 2, i32).view(nv, P, 2),
+                    clamped=c.view(0, s_.off_clamped, nv * P, u8) if shs is not None else None,
+                    point_list=c.view(1, s_.off_vals_b if in_b else s_.off_vals_a, R, i32),
+                    keys=c.view(1, s_.off_keys_b if in_b else s_.off_keys_a, R, i64),
+                    ranges=c.view(2, s_.off_ranges, nv * tiles * 2, i32).view(nv, tiles, 2),
+                    final_T=c.view(2, s_.off_final_T, nv * H * W, f32).view(nv, H, W),
+                    n_contrib=c.view(2, s_.off_n_contrib, nv * H * W, i32).view(nv, H, W),
                     num_rendered=R, ctx=c, settings=st)

@@ -242,3 +242,31 @@ def test_against_committed_golden_vectors(name):
     for nm, got, want in chk:
         err = np.abs(got.cpu().numpy() - want).max() / max(np.abs(want).max(), 1e-20)
         assert err <= GRAD_TOL, f"{name}: {nm} {err:.3e}"
+
+
+def test_sync_free_capacity_mode(oracle):
+    """max_rendered > 0: no D2H read on the critical path; same results; an overflow raises instead of corrupting memory."""
+    from sigman_release_amd import rasterizer as R
+    dev = _dev()
+    inp, st = cases.humanoid(P=5000, H=128, W=128, seed=12)
+    ref = oracle.forward(**inp, **cases.single_view(st))
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    base = _batched_settings(st, dev, 1)
+    gC, gD, gA = cases.grads_for(128, 128)
+    outs = []
+    for cap in (0, ref.R + 1000, ref.R):                      # exact, roomy capacity, capacity == R exactly
+        d = {k: t(v)[None].requires_grad_(True) for k, v in inp.items()}
+        color, radii, depth, alpha = R.rasterize_gaussians_batched(d["means3D"], None, None, d["colors_precomp"], d["opacities"][..., None],
+                                                                   None, None, d["cov3D_precomp"], base._replace(max_rendered=cap))
+        ((color[0] * t(gC)).sum() + (depth[0] * t(gD)).sum() + (alpha[0] * t(gA)).sum()).backward()
+        torch.cuda.synchronize()
+        assert np.abs(color[0].detach().cpu().numpy() - ref.color).max() <= IMG_TOL
+        outs.append(d["means3D"].grad.clone())
+    for g in outs[1:]:
+        assert (g - outs[0]).abs().max() <= GRAD_TOL * outs[0].abs().max()
+    d = {k: t(v)[None].requires_grad_(True) for k, v in inp.items()}
+    color, _, _, _ = R.rasterize_gaussians_batched(d["means3D"], None, None, d["colors_precomp"], d["opacities"][..., None], None, None,
+                                                   d["cov3D_precomp"], base._replace(max_rendered=ref.R // 2))
+    with pytest.raises(RuntimeError, match="exceeds max_rendered"):
+        color.sum().backward()
+    torch.cuda.synchronize()

@@ -1,0 +1,30 @@
+"""Dev tool: where does the HOST time of one fwd+bwd step go? (cProfile over N steps, sync-free mode)"""
+import cProfile, pstats, os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from sigman_release_amd import cameras, synthetic
+from sigman_release_amd import rasterizer as R
+from sigman_release_amd.losses import clamped_l1_loss
+dev = torch.device("cuda:0")
+P, H = 100000, 512
+g = synthetic.humanoid(P, 1); cov = synthetic.covariance_from_gaussians(g)
+t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+cv, cvp, cp = cameras.make_cameras([30])
+st = R.BatchedRasterizationSettings(H, H, cameras.TAN_HALF_FOV, cameras.TAN_HALF_FOV, torch.ones(3, device=dev), 1.0, t(cv), t(cvp), 0, t(cp), 1, False, int(os.environ.get("CAP", "260000")))
+m, c, o, rgb = [t(x)[None].requires_grad_(True) for x in (g["position"], cov, g["opacity"], g["rgb"])]
+gt = torch.rand(1, 3, H, H, device=dev)
+def step():
+    for v in (m, c, o, rgb): v.grad = None
+    color, radii, depth, alpha = R.rasterize_gaussians_batched(m, None, None, rgb, o, None, None, c, st)
+    clamped_l1_loss(color, gt, None, 1e-6).backward()
+for _ in range(20): step()
+torch.cuda.synchronize()
+N = 300
+t0 = time.perf_counter()
+for _ in range(N): step()
+t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
+print(f"host-side {1e6*(t1-t0)/N:.0f} us/step issue time; {1e6*(t2-t0)/N:.0f} us/step incl. drain")
+pr = cProfile.Profile(); pr.enable()
+for _ in range(N): step()
+pr.disable(); torch.cuda.synchronize()
+pstats.Stats(pr).sort_stats("cumulative").print_stats(28)
