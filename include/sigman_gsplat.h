@@ -38,7 +38,8 @@ extern "C" {
 
 #define SGR_ABI_VERSION 1
 #define SGR_TILE 16                 /* 16x16 pixel tiles, as the published algorithm */
-#define SGR_REC_FLOATS 12           /* per-(view,Gaussian) packed record, see below */
+#define SGR_REC_FLOATS 12           /* floats of a gradient record (grec / partial records) */
+#define SGR_REC_STRIDE 16           /* floats of the packed per-(view,Gaussian) record `rec` (64 B, one cache line) */
 
 /* Problem description shared by every staged call. */
 typedef struct SgrProblem {
@@ -67,10 +68,11 @@ typedef struct SgrProblem {
 
 /*
  * Packed per-(view,Gaussian) record written by sgr_preprocess_forward and gathered by the render
- * kernels (3 x float4, 48 B, one 16-B-aligned gather per float4):
- *   rec[0..3]  = pixel x, pixel y, conic.xx, conic.xy
- *   rec[4..7]  = conic.yy, opacity, view depth, r
- *   rec[8..11] = g, b, hx, hy      (hx,hy: half extents of the exact alpha >= 1/255 bound; <0 = never visible)
+ * kernels (4 x float4 = 64 B = one cache line per tile instance):
+ *   rec[0..3]   = pixel x, pixel y, conic.xx, conic.xy
+ *   rec[4..7]   = conic.yy, opacity, view depth, r
+ *   rec[8..11]  = g, b, hx, hy      (hx,hy: half extents of the exact alpha >= 1/255 bound; <0 = never visible)
+ *   rec[12..15] = bits: first tile-instance index of this Gaussian (written by sgr_bin), rect min, rect max, 0
  * The gradient record written by sgr_render_backward has the same shape:
  *   grec[0..3] = dL/dNDCx, dL/dNDCy, dL/dconic.xx, dL/dconic.xy
  *   grec[4..7] = dL/dconic.yy, dL/dopacity, dL/ddepth, dL/dr
@@ -131,7 +133,7 @@ int32_t sgr_preprocess_blocks_per_view(int32_t P);
 
 /*
  * F1 + F2: cull/project/cov2D/conic/radius/rect per (view,Gaussian), block-wise tile counts and their
- * exclusive scan.  Outputs: rec [n_views*P*12], radii i32 [n_views*P], rect u32 [n_views*P*2]
+ * exclusive scan.  Outputs: rec [n_views*P*16], radii i32 [n_views*P], rect u32 [n_views*P*2]
  * (minx | miny<<16, maxx | maxy<<16), clamped u8 [n_views*P] (SH clamp bits, may be NULL without shs),
  * block_offsets u32 [2*(n_views*blocks_per_view + 1)] (first half: exclusive offsets, entry n = R; second half:
  * scratch for the un-scanned sums), num_rendered u64 [2] ([0] = R, [1] = 1 if R overflows the 32-bit instance index or
@@ -152,7 +154,7 @@ size_t sgr_bin_workspace_bytes(uint64_t R);
  * keys/vals: two buffers of R entries each (ping-pong).  On return *result_in_b_host tells which
  * buffer holds the sorted list.  ranges u32 [n_views*tiles*2] (start,end) into the sorted list.
  */
-int sgr_bin(const SgrProblem *pb, const float *rec, const int32_t *radii, const uint32_t *rect,
+int sgr_bin(const SgrProblem *pb, float *rec, const int32_t *radii, const uint32_t *rect,
             const uint32_t *block_offsets, uint64_t R, const uint64_t *num_rendered_dev, uint64_t *keys_a, uint64_t *keys_b,
             uint32_t *vals_a, uint32_t *vals_b, void *workspace, size_t workspace_bytes, uint32_t *ranges,
             int32_t *result_in_b_host, void *stream);
@@ -178,26 +180,30 @@ int sgr_render_forward(const SgrProblem *pb, const uint32_t *ranges, const uint3
 
 /*
  * B1: gradient records from the image gradients.  grad_depth / grad_alpha may be NULL (treated as zero).
- * grec [n_views*P*12] is ZEROED by this call and then accumulated with hardware float atomics.
  * With the forward's aux buffers (and the forward's output images) the bucket-parallel kernel runs: one wave per
- * 64-Gaussian bucket, lanes own Gaussians, pixel states rotate through the wave (no reductions, no LDS).
- * Without them (NULL) the pixel-parallel reverse walk runs (needs final_T).
+ * <=64-Gaussian bucket, lanes own Gaussians, pixel states rotate through the wave (no reductions, no LDS, NO ATOMICS):
+ * each lane writes one partial record part[(4*instance + quadrant)*12 .. +10] and sets flags byte [4*instance + quadrant]
+ * (part f32 [4*R*12], flags u32 [R], flags zeroed by this call); sgr_preprocess_backward gathers them in a fixed order,
+ * so gradients are bitwise reproducible.  grec may be NULL on this path.
+ * Without the aux buffers (NULL) the pixel-parallel reverse walk runs: needs final_T and grec [n_views*P*12], which is
+ * zeroed by this call and accumulated with hardware float atomics (one set per tile and Gaussian).
  */
 int sgr_render_backward(const SgrProblem *pb, const uint32_t *ranges, const uint32_t *point_list, const float *rec,
                         const float *final_T, const uint32_t *n_contrib, const float *out_color, const float *out_depth,
                         const float *out_alpha, const float *grad_color, const float *grad_depth, const float *grad_alpha,
                         uint64_t R, const void *aux_compact, const void *aux_ckpt_tc, const void *aux_ckpt_da,
-                        const void *aux_desc, float *grec, void *stream);
+                        const void *aux_desc, float *grec, float *part, uint32_t *flags, void *stream);
 
 /*
- * B2 + B3: per-(view,Gaussian) gradient records -> per-subject parameter gradients, summed over the
+ * B2 + B3: per-(view,Gaussian) gradient records (either `grec`, or `rec` + `part` + `flags` from the bucket-parallel
+ * sgr_render_backward) -> per-subject parameter gradients, summed over the
  * subject's views in a fixed order (no atomics).  Outputs are fully written (no pre-zeroing needed):
  *   dL_dmeans3D [S,P,3], dL_dmeans2D [n_views,P,3] (NDC units like upstream, z = 0),
  *   dL_dopacity [S,P], dL_dcolors [S,P,3] (or dL_dsh [S,P,M,3] when shs), dL_dcov3D [S,P,6],
  *   dL_dscales [S,P,3] / dL_drotations [S,P,4] (only when scales given; else may be NULL)
  */
 int sgr_preprocess_backward(const SgrProblem *pb, const int32_t *radii, const uint8_t *clamped, const float *grec,
-                            float *dL_dmeans3D, float *dL_dmeans2D, float *dL_dopacity, float *dL_dcolors,
+                            const float *rec, const float *part, const uint32_t *flags, float *dL_dmeans3D, float *dL_dmeans2D, float *dL_dopacity, float *dL_dcolors,
                             float *dL_dsh, float *dL_dcov3D, float *dL_dscales, float *dL_drotations,
                             void *stream);
 

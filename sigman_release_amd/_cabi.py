@@ -54,8 +54,8 @@ _SIGNATURES = {
     "sgr_bucket_slots": (C.c_uint64, [C.c_uint64, C.c_uint64]),
     "sgr_set_forward_mode": (C.c_int, [C.c_int]),
     "sgr_render_forward": (C.c_int, [C.POINTER(SgrProblem)] + [C.c_void_p] * 8 + [C.c_uint64] + [C.c_void_p] * 5),
-    "sgr_render_backward": (C.c_int, [C.POINTER(SgrProblem)] + [C.c_void_p] * 11 + [C.c_uint64] + [C.c_void_p] * 6),
-    "sgr_preprocess_backward": (C.c_int, [C.POINTER(SgrProblem)] + [C.c_void_p] * 12),
+    "sgr_render_backward": (C.c_int, [C.POINTER(SgrProblem)] + [C.c_void_p] * 11 + [C.c_uint64] + [C.c_void_p] * 8),
+    "sgr_preprocess_backward": (C.c_int, [C.POINTER(SgrProblem)] + [C.c_void_p] * 15),
     "sgr_mark_visible": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sgr_knn_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
     "sgr_knn_dist2": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int32, C.c_void_p]),

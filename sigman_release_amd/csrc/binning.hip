@@ -30,7 +30,7 @@ constexpr int kItemsSmall = 4, kItemsLarge = 16;
 // the block offset from F2, so the per-Gaussian offsets array of the published algorithm is never
 // materialised in HBM.
 __global__ __launch_bounds__(kThreads) void duplicate_keys_kernel(int P, int Tx, int tiles_per_view,
-                                                                  const float4 *__restrict__ rec,
+                                                                  float4 *__restrict__ rec,
                                                                   const int32_t *__restrict__ radii,
                                                                   const uint2 *__restrict__ rect,
                                                                   const uint32_t *__restrict__ block_offsets, uint32_t cap,
@@ -63,7 +63,8 @@ __global__ __launch_bounds__(kThreads) void duplicate_keys_kernel(int P, int Tx,
     for (int w = 0; w < wave; w++) base += wave_tot[w];
     uint32_t off = base + inc - cnt;
     if (cnt) {
-        const uint32_t dbits = __float_as_uint(rec[q * 3 + 1].z);
+        const uint32_t dbits = __float_as_uint(rec[q * 4 + 1].z);
+        rec[q * 4 + 3].x = __uint_as_float(off);           // first tile-instance index of this Gaussian (backward gather)
         const uint32_t tbase = (uint32_t)view * (uint32_t)tiles_per_view;
         for (int y = miny; y < maxy; y++)
             for (int x = minx; x < maxx; x++) {
@@ -218,7 +219,7 @@ extern "C" size_t sgr_bin_workspace_bytes(uint64_t R) {
     return (size_t)(((nblocks > 0 ? nblocks : 1) + 1) * kRadix * sizeof(uint32_t) + 256);
 }
 
-extern "C" int sgr_bin(const SgrProblem *pb, const float *rec, const int32_t *radii, const uint32_t *rect,
+extern "C" int sgr_bin(const SgrProblem *pb, float *rec, const int32_t *radii, const uint32_t *rect,
                        const uint32_t *block_offsets, uint64_t R, const uint64_t *num_rendered_dev, uint64_t *keys_a,
                        uint64_t *keys_b, uint32_t *vals_a, uint32_t *vals_b, void *workspace, size_t workspace_bytes,
                        uint32_t *ranges, int32_t *result_in_b_host, void *stream_) {
@@ -236,7 +237,7 @@ extern "C" int sgr_bin(const SgrProblem *pb, const float *rec, const int32_t *ra
     const int nbx = sgr_preprocess_blocks_per_view(pb->P);
     { SgrProfScope _p(SGR_K_DUPLICATE, stream);
     hipLaunchKernelGGL(duplicate_keys_kernel, dim3(nbx, pb->n_views), dim3(kThreads), 0, stream, pb->P, Tx, Tx * Ty,
-                       (const float4 *)rec, radii, (const uint2 *)rect, block_offsets, n, keys_a, vals_a);
+                       (float4 *)rec, radii, (const uint2 *)rect, block_offsets, n, keys_a, vals_a);
     SGR_CHECK_LAUNCH("duplicate_keys_kernel");
     }
     const bool small = n <= (1u << 19);

@@ -264,7 +264,8 @@ __global__ __launch_bounds__(kPreThreads) void preprocess_fwd_kernel(SgrProblem 
                 }
             }
         }
-        rec[q * 3 + 0] = r0; rec[q * 3 + 1] = r1; rec[q * 3 + 2] = r2;
+        rec[q * 4 + 0] = r0; rec[q * 4 + 1] = r1; rec[q * 4 + 2] = r2;
+        rec[q * 4 + 3] = make_float4(0.f, __uint_as_float(rect_out.x), __uint_as_float(rect_out.y), 0.f);   // .x = first instance index (sgr_bin)
         radii[q] = rad_out;
         rect[q] = rect_out;
         if (clamped) clamped[q] = clamp_bits;
@@ -310,6 +311,9 @@ __global__ __launch_bounds__(1024) void scan_block_sums_kernel(const uint32_t *_
 __global__ __launch_bounds__(kPreThreads) void preprocess_bwd_kernel(SgrProblem pb, const int32_t *__restrict__ radii,
                                                                      const uint8_t *__restrict__ clamped,
                                                                      const float4 *__restrict__ grec,
+                                                                     const float4 *__restrict__ rec,
+                                                                     const float4 *__restrict__ part,
+                                                                     const uint32_t *__restrict__ flags,
                                                                      float *__restrict__ dL_dmeans3D,
                                                                      float *__restrict__ dL_dmeans2D,
                                                                      float *__restrict__ dL_dopacity,
@@ -340,7 +344,30 @@ __global__ __launch_bounds__(kPreThreads) void preprocess_bwd_kernel(SgrProblem 
         const size_t q = (size_t)view * pb.P + i;
         float *g2out = dL_dmeans2D + q * 3;
         if (!(radii[q] > 0)) { g2out[0] = g2out[1] = g2out[2] = 0.f; continue; }
-        const float4 g0 = grec[q * 3 + 0], g1 = grec[q * 3 + 1], g2 = grec[q * 3 + 2];
+        float4 g0, g1, g2;
+        if (part) {
+            // deterministic gather of the bucket-parallel backward's partial records: one per (tile instance, quadrant),
+            // summed in tile order then quadrant order -- no atomics anywhere in the backward
+            const float4 r3 = rec[q * 4 + 3];
+            const uint32_t off = __float_as_uint(r3.x), rmin = __float_as_uint(r3.y), rmax = __float_as_uint(r3.z);
+            const uint32_t ntile = ((rmax & 0xFFFFu) - (rmin & 0xFFFFu)) * ((rmax >> 16) - (rmin >> 16));
+            g0 = make_float4(0.f, 0.f, 0.f, 0.f); g1 = g0; g2 = g0;
+            for (uint32_t k = 0; k < ntile; k++) {
+                const uint32_t f = flags[off + k];
+                if (!f) continue;
+#pragma unroll
+                for (uint32_t qd = 0; qd < 4; qd++) {
+                    if (!((f >> (8 * qd)) & 0xFFu)) continue;
+                    const float4 *pp = part + ((size_t)(off + k) * 4 + qd) * 3;
+                    const float4 p0 = pp[0], p1 = pp[1], p2 = pp[2];
+                    g0.x += p0.x; g0.y += p0.y; g0.z += p0.z; g0.w += p0.w;
+                    g1.x += p1.x; g1.y += p1.y; g1.z += p1.z; g1.w += p1.w;
+                    g2.x += p2.x; g2.y += p2.y;
+                }
+            }
+        } else {
+            g0 = grec[q * 3 + 0]; g1 = grec[q * 3 + 1]; g2 = grec[q * 3 + 2];
+        }
         const float *V = pb.viewmatrix + 16 * (size_t)view;
         const float *M = pb.projmatrix + 16 * (size_t)view;
         float pv[3];
@@ -542,11 +569,12 @@ extern "C" int sgr_preprocess_forward(const SgrProblem *pb, float *rec, int32_t 
 }
 
 extern "C" int sgr_preprocess_backward(const SgrProblem *pb, const int32_t *radii, const uint8_t *clamped, const float *grec,
-                                       float *dL_dmeans3D, float *dL_dmeans2D, float *dL_dopacity, float *dL_dcolors,
+                                       const float *rec, const float *part, const uint32_t *flags, float *dL_dmeans3D, float *dL_dmeans2D, float *dL_dopacity, float *dL_dcolors,
                                        float *dL_dsh, float *dL_dcov3D, float *dL_dscales, float *dL_drotations,
                                        void *stream_) {
     if (validate_problem(pb)) return 1;
     if (pb->P == 0) return 0;
+    if (!grec && !(part && flags && rec)) { sgr_set_error("sgr_preprocess_backward: need grec, or rec + part + flags"); return 1; }
     if (pb->shs && (!dL_dsh || !clamped)) { sgr_set_error("dL_dsh / clamped required on the SH path"); return 1; }
     if (!pb->shs && !dL_dcolors) { sgr_set_error("dL_dcolors required on the colors_precomp path"); return 1; }
     if (pb->scales && (!dL_dscales || !dL_drotations)) { sgr_set_error("dL_dscales / dL_drotations required"); return 1; }
@@ -555,7 +583,7 @@ extern "C" int sgr_preprocess_backward(const SgrProblem *pb, const int32_t *radi
     dim3 grid(nbx, pb->n_views / pb->views_per_subject);
     { SgrProfScope _p(SGR_K_PREPROCESS_BWD, stream);
     hipLaunchKernelGGL(preprocess_bwd_kernel, grid, dim3(kPreThreads), 0, stream, *pb, radii, clamped, (const float4 *)grec,
-                       dL_dmeans3D, dL_dmeans2D, dL_dopacity, dL_dcolors, dL_dsh, dL_dcov3D, dL_dscales, dL_drotations);
+                       (const float4 *)rec, (const float4 *)part, flags, dL_dmeans3D, dL_dmeans2D, dL_dopacity, dL_dcolors, dL_dsh, dL_dcov3D, dL_dscales, dL_drotations);
     SGR_CHECK_LAUNCH("preprocess_bwd_kernel");
     }
     return 0;

@@ -27,7 +27,7 @@ extern "C" int sgr_rasterize_forward(const SgrProblem *pb, uint64_t capacity, in
     memset(st, 0, sizeof(*st));
     // ---- geometry blob
     uint64_t o = 0;
-    st->off_rec = o; o = align_up(o + (nq ? nq : 1) * SGR_REC_FLOATS * 4);
+    st->off_rec = o; o = align_up(o + (nq ? nq : 1) * SGR_REC_STRIDE * 4);
     st->off_rect = o; o = align_up(o + (nq ? nq : 1) * 8);
     st->off_clamped = o; o = align_up(o + (pb->shs ? (nq ? nq : 1) : 0));
     st->off_block_offsets = o; o = align_up(o + 2 * nbo * 4);
@@ -114,18 +114,24 @@ extern "C" int sgr_rasterize_backward(const SgrProblem *pb, const SgrForwardStat
     if (!pb || !st || !alloc) { sgr_set_error("sgr_rasterize_backward: NULL argument"); return 1; }
     if (pb->P <= 0) return 0;
     const uint64_t nq = (uint64_t)pb->n_views * (uint64_t)pb->P;
-    char *scratch = alloc(user, 3, (size_t)(nq * SGR_REC_FLOATS * 4));
+    const bool aux_on = st->with_aux != 0;
+    // scratch: bucket-parallel path = partial records [4*R][12] f32 + flags [R] u32; pixel-parallel path = grec [nq][12] f32
+    const uint64_t part_bytes = align_up(st->R_alloc * 4 * SGR_REC_FLOATS * 4);
+    const uint64_t scratch_bytes = aux_on ? part_bytes + align_up(st->R_alloc * 4) : nq * SGR_REC_FLOATS * 4;
+    char *scratch = alloc(user, 3, (size_t)scratch_bytes);
     if (!scratch) { sgr_set_error("scratch allocator returned NULL"); return 1; }
+    float *part = aux_on ? (float *)scratch : nullptr;
+    uint32_t *flags = aux_on ? (uint32_t *)(scratch + part_bytes) : nullptr;
+    float *grec = aux_on ? nullptr : (float *)scratch;
     const char *geom = (const char *)st->geom, *binning = (const char *)st->binning, *image = (const char *)st->image;
     const float *rec = (const float *)(geom + st->off_rec);
     const uint32_t *point_list = (const uint32_t *)(binning + (st->result_in_b ? st->off_vals_b : st->off_vals_a));
-    const bool aux_on = st->with_aux != 0;
     if (sgr_render_backward(pb, (const uint32_t *)(image + st->off_ranges), point_list, rec, (const float *)(image + st->off_final_T),
                             (const uint32_t *)(image + st->off_n_contrib), out_color, out_depth, out_alpha, grad_color, grad_depth,
                             grad_alpha, st->R_alloc, aux_on ? image + st->off_compact : nullptr, aux_on ? image + st->off_ckpt_tc : nullptr,
-                            aux_on ? image + st->off_ckpt_da : nullptr, aux_on ? image + st->off_desc : nullptr, (float *)scratch, stream_))
+                            aux_on ? image + st->off_ckpt_da : nullptr, aux_on ? image + st->off_desc : nullptr, grec, part, flags, stream_))
         return 1;
-    return sgr_preprocess_backward(pb, radii, pb->shs ? (const uint8_t *)(geom + st->off_clamped) : nullptr, (const float *)scratch,
+    return sgr_preprocess_backward(pb, radii, pb->shs ? (const uint8_t *)(geom + st->off_clamped) : nullptr, grec, rec, part, flags,
                                    dL_dmeans3D, dL_dmeans2D, dL_dopacity, dL_dcolors, dL_dsh, dL_dcov3D, dL_dscales, dL_drotations,
                                    stream_);
 }

@@ -89,7 +89,7 @@ __global__ __launch_bounds__(kBlock) void render_fwd_kernel(int W, int H, int Tx
         uint32_t m = 0;
         if (idx < n) {
             const uint32_t id = point_list[range.x + idx];
-            const float4 a = rec[(size_t)id * 3 + 0], b = rec[(size_t)id * 3 + 1], c = rec[(size_t)id * 3 + 2];
+            const float4 a = rec[(size_t)id * 4 + 0], b = rec[(size_t)id * 4 + 1], c = rec[(size_t)id * 4 + 2];
             sA[t] = a; sB[t] = b; sC[t] = c;
             sId[t] = id;
             m = cull_mask(a, c, x0, y0);
@@ -252,7 +252,7 @@ __global__ __launch_bounds__(kSegThreads, 4) void render_fwd_seg_kernel(int W, i
         uint32_t id = 0;
         if (idx < n) {
             id = point_list[range.x + idx];
-            a = rec[(size_t)id * 3 + 0]; b = rec[(size_t)id * 3 + 1]; c = rec[(size_t)id * 3 + 2];
+            a = rec[(size_t)id * 4 + 0]; b = rec[(size_t)id * 4 + 1]; c = rec[(size_t)id * 4 + 2];
             bit = cull_quadrant(a, c, qx0, qy0);
         }
         const uint64_t bal = __ballot(bit);
@@ -446,7 +446,7 @@ __global__ __launch_bounds__(kBlock) void render_bwd_kernel(int W, int H, int Tx
         uint32_t m = 0;
         if (idx < n) {
             const uint32_t id = point_list[range.x + idx];
-            const float4 a = rec[(size_t)id * 3 + 0], b = rec[(size_t)id * 3 + 1], c = rec[(size_t)id * 3 + 2];
+            const float4 a = rec[(size_t)id * 4 + 0], b = rec[(size_t)id * 4 + 1], c = rec[(size_t)id * 4 + 2];
             sA[t] = a; sB[t] = b; sC[t] = c;
             sId[t] = id;
             m = cull_mask(a, c, x0, y0);
@@ -562,7 +562,7 @@ __global__ __launch_bounds__(kBlock) void render_bwd_bucket_kernel(int W, int H,
                                                                    const float *__restrict__ out_alpha,
                                                                    const float *__restrict__ gC, const float *__restrict__ gD,
                                                                    const float *__restrict__ gA, FwdAux aux,
-                                                                   float *__restrict__ grec) {
+                                                                   float4 *__restrict__ part, uint8_t *__restrict__ flags) {
     const int lane = threadIdx.x & 63;
     const size_t slot = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (slot >= (size_t)4 * aux.NS) return;
@@ -584,7 +584,8 @@ __global__ __launch_bounds__(kBlock) void render_bwd_bucket_kernel(int W, int H,
     // a lane without a Gaussian gets list index 0xFFFFFFFF, which no pixel's n_contrib exceeds -> never valid
     const uint32_t gidx = e.y;
     float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra, rc = ra;
-    if (has_g) { ra = rec[(size_t)e.x * 3 + 0]; rb = rec[(size_t)e.x * 3 + 1]; rc = rec[(size_t)e.x * 3 + 2]; }
+    float4 rd = ra;
+    if (has_g) { ra = rec[(size_t)e.x * 4 + 0]; rb = rec[(size_t)e.x * 4 + 1]; rc = rec[(size_t)e.x * 4 + 2]; rd = rec[(size_t)e.x * 4 + 3]; }
     const float gx = ra.x, gy = ra.y, cxx = ra.z, cxy = ra.w, cyy = rb.x, op = rb.y, gdep = rb.z, cr = rb.w, cg = rc.x, cb = rc.y;
     // conic pre-scaled into the exp2 domain: G = exp(power) = exp2(kxx dx^2 + kyy dy^2 + kxy dx dy)
     const float kLog2e = 1.4426950408889634f;
@@ -653,25 +654,17 @@ __global__ __launch_bounds__(kBlock) void render_bwd_bucket_kernel(int W, int H,
         Rem = rot1(Rem); T = rot1(T);
         if (HAS_DA) { gd = rot1(gd); ga = rot1(ga); }
     }
-#ifdef SGR_DBG_NOATOMIC
-    if (has_g && S1 == 123.456f) {
-#else
     if (has_g) {
-#endif
-        float *g = grec + (size_t)e.x * SGR_REC_FLOATS;
+        // one NON-atomic 40-byte partial record per (tile instance, quadrant); preprocess_bwd gathers them in a fixed order
+        const uint32_t off = __float_as_uint(rd.x), rmin = __float_as_uint(rd.y), rmax = __float_as_uint(rd.z);
+        const uint32_t inst = off + (ty - (rmin >> 16)) * ((rmax & 0xFFFFu) - (rmin & 0xFFFFu)) + (tx - (rmin & 0xFFFFu));
         const float a0 = -0.5f * (float)W * op * (cxx * Sx + cxy * Sy);       // dL/dNDC x (includes 0.5*W like upstream)
         const float a1 = -0.5f * (float)H * op * (cyy * Sy + cxy * Sx);
-        const float a2 = -0.5f * op * Sxx, a3 = -0.5f * op * Sxy, a4 = -0.5f * op * Syy;
-        if (a0 != 0.f) sgr_atomic_add(g + 0, a0);
-        if (a1 != 0.f) sgr_atomic_add(g + 1, a1);
-        if (a2 != 0.f) sgr_atomic_add(g + 2, a2);
-        if (a3 != 0.f) sgr_atomic_add(g + 3, a3);
-        if (a4 != 0.f) sgr_atomic_add(g + 4, a4);
-        if (S1 != 0.f) sgr_atomic_add(g + 5, S1);
-        if (HAS_DA && aD != 0.f) sgr_atomic_add(g + 6, aD);
-        if (a7 != 0.f) sgr_atomic_add(g + 7, a7);
-        if (a8 != 0.f) sgr_atomic_add(g + 8, a8);
-        if (a9 != 0.f) sgr_atomic_add(g + 9, a9);
+        float4 *pp = part + ((size_t)inst * 4 + q) * 3;
+        pp[0] = make_float4(a0, a1, -0.5f * op * Sxx, -0.5f * op * Sxy);
+        pp[1] = make_float4(-0.5f * op * Syy, S1, aD, a7);
+        pp[2] = make_float4(a8, a9, 0.f, 0.f);
+        flags[(size_t)inst * 4 + q] = 1;
     }
 }
 
@@ -735,14 +728,18 @@ extern "C" int sgr_render_backward(const SgrProblem *pb, const uint32_t *ranges,
                                    const float *out_depth, const float *out_alpha, const float *grad_color,
                                    const float *grad_depth, const float *grad_alpha, uint64_t R, const void *aux_compact,
                                    const void *aux_ckpt_tc, const void *aux_ckpt_da, const void *aux_desc, float *grec,
-                                   void *stream_) {
+                                   float *part, uint32_t *flags, void *stream_) {
     if (sgr_validate_problem(pb)) return 1;
     hipStream_t stream = (hipStream_t)stream_;
     const int Tx = (pb->W + SGR_TILE - 1) / SGR_TILE, Ty = (pb->H + SGR_TILE - 1) / SGR_TILE;
     const uint32_t tiles = (uint32_t)Tx * Ty;
-    if (pb->P > 0)
-        SGR_CHECK_HIP(hipMemsetAsync(grec, 0, (size_t)pb->n_views * pb->P * SGR_REC_FLOATS * sizeof(float), stream));
-    const bool use_aux = aux_compact && aux_ckpt_tc && aux_ckpt_da && aux_desc && out_color && out_depth && out_alpha;
+    const bool use_aux = aux_compact && aux_ckpt_tc && aux_ckpt_da && aux_desc && out_color && out_depth && out_alpha && part && flags;
+    if (use_aux) {
+        if (R > 0) SGR_CHECK_HIP(hipMemsetAsync(flags, 0, (size_t)R * 4, stream));
+    } else {
+        if (!grec) { sgr_set_error("sgr_render_backward: grec required for the pixel-parallel kernel"); return 1; }
+        if (pb->P > 0) SGR_CHECK_HIP(hipMemsetAsync(grec, 0, (size_t)pb->n_views * pb->P * SGR_REC_FLOATS * sizeof(float), stream));
+    }
     SgrProfScope _p(SGR_K_RENDER_BWD, stream);
     if (use_aux) {
         FwdAux aux = make_aux((void *)aux_compact, (void *)aux_ckpt_tc, (void *)aux_ckpt_da, (void *)aux_desc, R,
@@ -751,11 +748,11 @@ extern "C" int sgr_render_backward(const SgrProblem *pb, const uint32_t *ranges,
         if (grad_depth || grad_alpha)
             hipLaunchKernelGGL(render_bwd_bucket_kernel<true>, dim3(nblocks), dim3(kBlock), 0, stream, pb->W, pb->H, Tx, tiles,
                                (const uint2 *)ranges, (const float4 *)rec, n_contrib, out_color, out_depth, out_alpha, grad_color,
-                               grad_depth, grad_alpha, aux, grec);
+                               grad_depth, grad_alpha, aux, (float4 *)part, (uint8_t *)flags);
         else
             hipLaunchKernelGGL(render_bwd_bucket_kernel<false>, dim3(nblocks), dim3(kBlock), 0, stream, pb->W, pb->H, Tx, tiles,
                                (const uint2 *)ranges, (const float4 *)rec, n_contrib, out_color, out_depth, out_alpha, grad_color,
-                               grad_depth, grad_alpha, aux, grec);
+                               grad_depth, grad_alpha, aux, (float4 *)part, (uint8_t *)flags);
         SGR_CHECK_LAUNCH("render_bwd_bucket_kernel");
         return 0;
     }

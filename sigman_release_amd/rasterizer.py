@@ -349,7 +349,7 @@ def forward_debug(means3D, opacities, *, colors_precomp=None, shs=None, cov3D_pr
         i32, i64, f32, u8 = torch.int32, torch.int64, torch.float32, torch.uint8
         in_b = bool(s_.result_in_b)
         return dict(color=color, radii=radii, depth=depth, alpha=alpha,
-                    rec=c.view(0, s_.off_rec, nv * P * 12, f32).view(nv, P, 12),
+                    rec=c.view(0, s_.off_rec, nv * P * 16, f32).view(nv, P, 16),
                     rect=c.view(0, s_.off_rect, nv * P * 2, i32).view(nv, P, 2),
                     clamped=c.view(0, s_.off_clamped, nv * P, u8) if shs is not None else None,
                     point_list=c.view(1, s_.off_vals_b if in_b else s_.off_vals_a, R, i32),
