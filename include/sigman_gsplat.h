@@ -126,6 +126,13 @@ int sgr_rasterize_backward(const SgrProblem *pb, const SgrForwardState *state, c
                            float *dL_dopacity, float *dL_dcolors, float *dL_dsh, float *dL_dcov3D, float *dL_dscales,
                            float *dL_drotations, void *stream);
 
+/*
+ * hipGraph replay of the forward launch chain (sync-free mode only): 1 = enabled (default), 0 = plain launches.
+ * The chain is captured once per distinct argument set (problem + pointers) and replayed with one hipGraphLaunch.
+ */
+int sgr_set_graphs(int enable);
+int sgr_graph_stats(uint64_t *hits, uint64_t *misses);
+
 /* ---- staged, batched API -------------------------------------------------------------------- */
 
 /* number of preprocess thread blocks per view (block_offsets needs n_views*that + 1 entries) */

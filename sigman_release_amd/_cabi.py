@@ -53,6 +53,8 @@ _SIGNATURES = {
                           C.c_void_p]),
     "sgr_bucket_slots": (C.c_uint64, [C.c_uint64, C.c_uint64]),
     "sgr_set_forward_mode": (C.c_int, [C.c_int]),
+    "sgr_set_graphs": (C.c_int, [C.c_int]),
+    "sgr_graph_stats": (C.c_int, [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "sgr_render_forward": (C.c_int, [C.POINTER(SgrProblem)] + [C.c_void_p] * 8 + [C.c_uint64] + [C.c_void_p] * 5),
     "sgr_render_backward": (C.c_int, [C.POINTER(SgrProblem)] + [C.c_void_p] * 11 + [C.c_uint64] + [C.c_void_p] * 8),
     "sgr_preprocess_backward": (C.c_int, [C.POINTER(SgrProblem)] + [C.c_void_p] * 15),

@@ -46,6 +46,8 @@ void sgr_prof_end(int slot, hipStream_t s) {
     if (slot >= 0) (void)hipEventRecord(g_slots[slot].b, s);
 }
 
+int sgr_prof_active() { return g_mask != 0; }
+
 extern "C" int sgr_prof_configure(uint32_t kernel_mask) {
     g_mask = kernel_mask;
     g_used = 0;

@@ -14,6 +14,60 @@ namespace {
 inline uint64_t align_up(uint64_t v, uint64_t a = 256) { return (v + a - 1) / a * a; }
 }
 
+// ---------------------------------------------------------------------------------------------
+// hipGraph cache (sync-free mode only).  With every buffer size known up front, the whole forward chain is a
+// static sequence of ~27 launches whose arguments are the problem description and a handful of pointers.  A
+// training loop presents the SAME pointers step after step (PyTorch's caching allocator replays its
+// allocation sequence), so the chain is captured once per distinct argument set and replayed with a single
+// hipGraphLaunch: one host call instead of ~27, and back-to-back kernel dispatch on the GPU.  Any capture
+// failure, a profiling request, or too many distinct argument sets falls back to plain launches.
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct FwdKey {
+    SgrProblem pb;
+    uint64_t capacity;
+    int32_t with_aux, fwd_mode;
+    void *color, *depth, *alpha, *radii, *nr_host, *geom, *binning, *image, *stream;
+};
+struct FwdEntry { FwdKey key; hipGraphExec_t exec; SgrForwardState st; uint64_t stamp; };
+constexpr int kGraphSlots = 16;
+FwdEntry g_fwd[kGraphSlots];
+int g_fwd_n = 0;
+uint64_t g_stamp = 0, g_graph_misses = 0, g_graph_hits = 0;
+int g_graphs_enabled = 1;
+}  // namespace
+
+int sgr_prof_active();
+int sgr_get_forward_mode();
+
+extern "C" int sgr_set_graphs(int enable) { g_graphs_enabled = enable; return 0; }
+extern "C" int sgr_graph_stats(uint64_t *hits, uint64_t *misses) { if (hits) *hits = g_graph_hits; if (misses) *misses = g_graph_misses; return 0; }
+
+static int forward_launches(const SgrProblem *pb, uint64_t capacity, uint64_t R, SgrForwardState *st, float *out_color, float *out_depth,
+                            float *out_alpha, int32_t *out_radii, uint64_t *nr_pinned_host, bool preprocess_done, hipStream_t stream) {
+    char *geom = (char *)st->geom, *binning = (char *)st->binning, *image = (char *)st->image;
+    float *rec = (float *)(geom + st->off_rec);
+    uint32_t *rect = (uint32_t *)(geom + st->off_rect);
+    uint8_t *clamped = pb->shs ? (uint8_t *)(geom + st->off_clamped) : nullptr;
+    uint32_t *block_offsets = (uint32_t *)(geom + st->off_block_offsets);
+    uint64_t *num_rendered = (uint64_t *)(geom + st->off_num_rendered);
+    if (!preprocess_done) {
+        if (sgr_preprocess_forward(pb, rec, out_radii, rect, clamped, block_offsets, num_rendered, capacity, stream)) return 1;
+        if (nr_pinned_host) SGR_CHECK_HIP(hipMemcpyAsync(nr_pinned_host, num_rendered, 16, hipMemcpyDeviceToHost, stream));
+    }
+    int32_t in_b = 0;
+    if (sgr_bin(pb, rec, out_radii, rect, block_offsets, R, capacity > 0 ? num_rendered : nullptr, (uint64_t *)(binning + st->off_keys_a),
+                (uint64_t *)(binning + st->off_keys_b), (uint32_t *)(binning + st->off_vals_a), (uint32_t *)(binning + st->off_vals_b),
+                binning + st->off_sort_ws, (size_t)sgr_bin_workspace_bytes(R), (uint32_t *)(image + st->off_ranges), &in_b, stream)) return 1;
+    st->result_in_b = in_b;
+    const uint32_t *point_list = (const uint32_t *)(binning + (in_b ? st->off_vals_b : st->off_vals_a));
+    const bool aux_on = st->with_aux != 0;
+    return sgr_render_forward(pb, (const uint32_t *)(image + st->off_ranges), point_list, rec, out_color, out_depth, out_alpha,
+                              (float *)(image + st->off_final_T), (uint32_t *)(image + st->off_n_contrib), R,
+                              aux_on ? image + st->off_compact : nullptr, aux_on ? image + st->off_ckpt_tc : nullptr,
+                              aux_on ? image + st->off_ckpt_da : nullptr, aux_on ? image + st->off_desc : nullptr, stream);
+}
+
 extern "C" int sgr_rasterize_forward(const SgrProblem *pb, uint64_t capacity, int32_t with_aux, sgr_alloc_fn alloc, void *user,
                                      float *out_color, float *out_depth, float *out_alpha, int32_t *out_radii,
                                      uint64_t *nr_pinned_host, void *nr_event, SgrForwardState *st, void *stream_) {
@@ -36,30 +90,26 @@ extern "C" int sgr_rasterize_forward(const SgrProblem *pb, uint64_t capacity, in
     char *geom = alloc(user, 0, (size_t)o);
     if (!geom) { sgr_set_error("geometry allocator returned NULL"); return 1; }
     st->geom = geom;
-    float *rec = (float *)(geom + st->off_rec);
-    uint32_t *rect = (uint32_t *)(geom + st->off_rect);
-    uint8_t *clamped = pb->shs ? (uint8_t *)(geom + st->off_clamped) : nullptr;
-    uint32_t *block_offsets = (uint32_t *)(geom + st->off_block_offsets);
     uint64_t *num_rendered = (uint64_t *)(geom + st->off_num_rendered);
     uint64_t R = 0;
-    if (pb->P > 0) {
-        if (sgr_preprocess_forward(pb, rec, out_radii, rect, clamped, block_offsets, num_rendered, capacity, stream)) return 1;
-        if (capacity > 0) {
-            R = capacity;                         // sync-free: buffers pre-sized, the true count goes to the host asynchronously
-            if (nr_pinned_host) {
-                SGR_CHECK_HIP(hipMemcpyAsync(nr_pinned_host, num_rendered, 16, hipMemcpyDeviceToHost, stream));
-                if (nr_event) SGR_CHECK_HIP(hipEventRecord((hipEvent_t)nr_event, stream));
-            }
-        } else {
-            uint64_t host2[2] = {0, 0};           // exact mode: the one blocking read per batched forward (upstream: one per VIEW)
-            SGR_CHECK_HIP(hipMemcpyAsync(nr_pinned_host ? nr_pinned_host : host2, num_rendered, 16, hipMemcpyDeviceToHost, stream));
-            SGR_CHECK_HIP(hipStreamSynchronize(stream));
-            const uint64_t *h = nr_pinned_host ? nr_pinned_host : host2;
-            if (h[1]) { sgr_set_error("num_rendered %llu exceeds the 32-bit instance index", (unsigned long long)h[0]); return 1; }
-            R = h[0];
-        }
+    bool preprocess_done = false;
+    if (pb->P > 0 && capacity == 0) {
+        // exact mode: preprocess first, then the one blocking read of num_rendered per batched forward (upstream: one per VIEW)
+        if (sgr_preprocess_forward(pb, (float *)(geom + st->off_rec), out_radii, (uint32_t *)(geom + st->off_rect),
+                                   pb->shs ? (uint8_t *)(geom + st->off_clamped) : nullptr, (uint32_t *)(geom + st->off_block_offsets),
+                                   num_rendered, 0, stream)) return 1;
+        uint64_t host2[2] = {0, 0};
+        SGR_CHECK_HIP(hipMemcpyAsync(nr_pinned_host ? nr_pinned_host : host2, num_rendered, 16, hipMemcpyDeviceToHost, stream));
+        SGR_CHECK_HIP(hipStreamSynchronize(stream));
+        const uint64_t *h = nr_pinned_host ? nr_pinned_host : host2;
+        if (h[1]) { sgr_set_error("num_rendered %llu exceeds the 32-bit instance index", (unsigned long long)h[0]); return 1; }
+        R = h[0];
+        preprocess_done = true;
+    } else if (pb->P > 0) {
+        R = capacity;                             // sync-free: buffers pre-sized, the true count goes to the host asynchronously
     } else {
         SGR_CHECK_HIP(hipMemsetAsync(num_rendered, 0, 16, stream));
+        preprocess_done = true;
     }
     st->R_alloc = R;
     st->true_rendered = capacity > 0 ? ~0ull : R;
@@ -70,8 +120,7 @@ extern "C" int sgr_rasterize_forward(const SgrProblem *pb, uint64_t capacity, in
     st->off_keys_b = o; o = align_up(o + Rn * 8);
     st->off_vals_a = o; o = align_up(o + Rn * 4);
     st->off_vals_b = o; o = align_up(o + Rn * 4);
-    const uint64_t sort_ws = sgr_bin_workspace_bytes(R);
-    st->off_sort_ws = o; o = align_up(o + sort_ws);
+    st->off_sort_ws = o; o = align_up(o + sgr_bin_workspace_bytes(R));
     st->binning_bytes = o;
     char *binning = alloc(user, 1, (size_t)o);
     if (!binning) { sgr_set_error("binning allocator returned NULL"); return 1; }
@@ -94,16 +143,57 @@ extern "C" int sgr_rasterize_forward(const SgrProblem *pb, uint64_t capacity, in
     char *image = alloc(user, 2, (size_t)o);
     if (!image) { sgr_set_error("image allocator returned NULL"); return 1; }
     st->image = image;
-    int32_t in_b = 0;
-    if (sgr_bin(pb, rec, out_radii, rect, block_offsets, R, capacity > 0 ? num_rendered : nullptr, (uint64_t *)(binning + st->off_keys_a),
-                (uint64_t *)(binning + st->off_keys_b), (uint32_t *)(binning + st->off_vals_a), (uint32_t *)(binning + st->off_vals_b),
-                binning + st->off_sort_ws, (size_t)sort_ws, (uint32_t *)(image + st->off_ranges), &in_b, stream)) return 1;
-    st->result_in_b = in_b;
-    const uint32_t *point_list = (const uint32_t *)(binning + (in_b ? st->off_vals_b : st->off_vals_a));
-    return sgr_render_forward(pb, (const uint32_t *)(image + st->off_ranges), point_list, rec, out_color, out_depth, out_alpha,
-                              (float *)(image + st->off_final_T), (uint32_t *)(image + st->off_n_contrib), R,
-                              aux_on ? image + st->off_compact : nullptr, aux_on ? image + st->off_ckpt_tc : nullptr,
-                              aux_on ? image + st->off_ckpt_da : nullptr, aux_on ? image + st->off_desc : nullptr, stream);
+
+    const bool try_graph = g_graphs_enabled && capacity > 0 && pb->P > 0 && !sgr_prof_active();
+    if (try_graph) {
+        FwdKey key;
+        memset(&key, 0, sizeof(key));
+        key.pb = *pb; key.capacity = capacity; key.with_aux = with_aux; key.fwd_mode = sgr_get_forward_mode();
+        key.color = out_color; key.depth = out_depth; key.alpha = out_alpha; key.radii = out_radii; key.nr_host = nullptr;
+        key.geom = geom; key.binning = binning; key.image = image; key.stream = nullptr;
+        for (int i = 0; i < g_fwd_n; i++) {
+            if (memcmp(&g_fwd[i].key, &key, sizeof(key)) == 0) {
+                g_fwd[i].stamp = ++g_stamp; g_graph_hits++;
+                *st = g_fwd[i].st;
+                SGR_CHECK_HIP(hipGraphLaunch(g_fwd[i].exec, stream));
+                if (nr_pinned_host) SGR_CHECK_HIP(hipMemcpyAsync(nr_pinned_host, num_rendered, 16, hipMemcpyDeviceToHost, stream));
+                if (nr_event) SGR_CHECK_HIP(hipEventRecord((hipEvent_t)nr_event, stream));
+                return 0;
+            }
+        }
+        g_graph_misses++;
+        if (g_graph_misses > 64 && g_graph_hits < g_graph_misses) g_graphs_enabled = 0;   // pointers are not stable here: stop trying
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+        // capture on a library-owned stream (the caller's stream may be the legacy default stream, which cannot be captured);
+        // the instantiated graph is then launched into the caller's stream
+        static hipStream_t cap_stream = nullptr;
+        if (!cap_stream && hipStreamCreateWithFlags(&cap_stream, hipStreamNonBlocking) != hipSuccess) { cap_stream = nullptr; g_graphs_enabled = 0; }
+        if (g_graphs_enabled && hipStreamBeginCapture(cap_stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+            const int rc = forward_launches(pb, capacity, R, st, out_color, out_depth, out_alpha, out_radii, nullptr, false, cap_stream);
+            const hipError_t e1 = hipStreamEndCapture(cap_stream, &graph);
+            if (rc == 0 && e1 == hipSuccess && graph && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess) {
+                (void)hipGraphDestroy(graph);
+                int slot = g_fwd_n < kGraphSlots ? g_fwd_n++ : 0;
+                if (slot == 0 && g_fwd_n == kGraphSlots) {       // evict the least recently used entry
+                    for (int i = 1; i < kGraphSlots; i++) if (g_fwd[i].stamp < g_fwd[slot].stamp) slot = i;
+                    (void)hipGraphExecDestroy(g_fwd[slot].exec);
+                }
+                g_fwd[slot].key = key; g_fwd[slot].exec = exec; g_fwd[slot].st = *st; g_fwd[slot].stamp = ++g_stamp;
+                SGR_CHECK_HIP(hipGraphLaunch(exec, stream));
+                if (nr_pinned_host) SGR_CHECK_HIP(hipMemcpyAsync(nr_pinned_host, num_rendered, 16, hipMemcpyDeviceToHost, stream));
+                if (nr_event) SGR_CHECK_HIP(hipEventRecord((hipEvent_t)nr_event, stream));
+                return 0;
+            }
+            if (graph) (void)hipGraphDestroy(graph);
+            (void)hipGetLastError();
+            g_graphs_enabled = 0;                                  // capture is not usable in this process: plain launches from now on
+        }
+    }
+    if (forward_launches(pb, capacity, R, st, out_color, out_depth, out_alpha, out_radii, capacity > 0 ? nr_pinned_host : nullptr,
+                         preprocess_done, stream)) return 1;
+    if (capacity > 0 && nr_event) SGR_CHECK_HIP(hipEventRecord((hipEvent_t)nr_event, stream));
+    return 0;
 }
 
 extern "C" int sgr_rasterize_backward(const SgrProblem *pb, const SgrForwardState *st, const int32_t *radii, const float *out_color,

@@ -675,6 +675,7 @@ int sgr_validate_problem(const SgrProblem *pb);
 // 0 = automatic, 1 = serial per-tile kernel, 2 = segment-parallel kernel (dev/test override: sgr_set_forward_mode)
 static int sgr_fwd_mode = 0;
 extern "C" int sgr_set_forward_mode(int mode) { sgr_fwd_mode = mode; return 0; }
+int sgr_get_forward_mode() { return sgr_fwd_mode; }
 
 extern "C" uint64_t sgr_bucket_slots(uint64_t R, uint64_t tiles_total) { return (R >> 6) + 8 * tiles_total + 1; }
 

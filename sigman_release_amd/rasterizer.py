@@ -111,7 +111,7 @@ _ALLOC = _cabi.ALLOC_FN(_alloc_cb)
 
 class _Ctx:
     """What the forward leaves behind for the backward (== upstream geomBuffer / binningBuffer / imgBuffer + num_rendered)."""
-    __slots__ = ("state", "blobs", "radii", "images", "dims", "nr_host", "nr_event", "capacity", "true_rendered", "keep")
+    __slots__ = ("state", "blobs", "radii", "dims", "nr_host", "nr_event", "capacity", "true_rendered", "keep")
 
     def check_overflow(self):
         """Sync-free mode: raise if the forward needed more tile instances than `max_rendered` (cheap: the copy finished long ago)."""
@@ -171,7 +171,7 @@ def _forward_impl(means3D, opacities, colors_precomp, shs, cov3D_precomp, scales
     ctx = None
     if need_ctx:
         ctx = _Ctx()
-        ctx.state, ctx.blobs, ctx.radii, ctx.images = state, blobs, radii, (color, depth, alpha)
+        ctx.state, ctx.blobs, ctx.radii = state, blobs, radii
         ctx.dims = (S, P, nv, H, W)
         ctx.nr_host, ctx.nr_event, ctx.capacity = nr_host, (nr_event if capacity > 0 and P > 0 else None), capacity
         ctx.true_rendered = int(state.true_rendered) if capacity == 0 else None
@@ -180,12 +180,11 @@ def _forward_impl(means3D, opacities, colors_precomp, shs, cov3D_precomp, scales
 
 
 def _backward_impl(ctx: _Ctx, means3D, opacities, colors_precomp, shs, cov3D_precomp, scales, rotations,
-                   st: BatchedRasterizationSettings, grad_color, grad_depth, grad_alpha):
+                   st: BatchedRasterizationSettings, grad_color, grad_depth, grad_alpha, img):
     L = _cabi.lib()
     S, P, nv, H, W = ctx.dims
     dev = means3D.device
     f32 = torch.float32
-    ctx.check_overflow()
     pb = _make_problem(means3D, opacities, colors_precomp, shs, cov3D_precomp, scales, rotations, st)
     gC = _f32c(grad_color)
     gD = None if grad_depth is None else _f32c(grad_depth)
@@ -200,12 +199,12 @@ def _backward_impl(ctx: _Ctx, means3D, opacities, colors_precomp, shs, cov3D_pre
     d_rot = torch.empty(S, P, 4, dtype=f32, device=dev) if scales is not None else None
     blobs = ctx.blobs
     _alloc_target["dev"], _alloc_target["blobs"] = dev, blobs
-    img = ctx.images
     _cabi.check(L.sgr_rasterize_backward(C.byref(pb), C.byref(ctx.state), _ptr(ctx.radii), _ptr(img[0]), _ptr(img[1]), _ptr(img[2]),
                                          _ptr(gC), _ptr(gD), _ptr(gA), _ALLOC, None, _ptr(d_means3D), _ptr(d_means2D), _ptr(d_op),
                                          _ptr(d_col), _ptr(d_sh), _ptr(d_cov), _ptr(d_sc), _ptr(d_rot), _stream()),
                 "sgr_rasterize_backward")
     grec = blobs[3]
+    ctx.check_overflow()        # after the backward is queued: the host never idles the GPU while it waits for the forward's counter
     return d_means3D, d_means2D, d_sh, d_col, d_op, d_sc, d_rot, d_cov, grec
 
 
@@ -221,15 +220,17 @@ def _fwd_common(ctx, means3D, sh, colors_precomp, opacities, scales, rotations, 
     ctx.sgr = c
     ctx.st = st
     ctx.has = (sh is not None, colors_precomp is not None, scales is not None, cov3Ds_precomp is not None)
-    ctx.save_for_backward(means3D, opacities, colors_precomp, sh, cov3Ds_precomp, scales, rotations)
+    # the outputs go through save_for_backward (a plain attribute would create a ctx -> output -> grad_fn -> ctx cycle and keep
+    # every step's buffers alive until the garbage collector runs)
+    ctx.save_for_backward(means3D, opacities, colors_precomp, sh, cov3Ds_precomp, scales, rotations, color, depth, alpha)
     return color, radii, depth, alpha
 
 
 def _bwd_common(ctx, grad_color, grad_depth, grad_alpha):
-    means3D, opacities, colors_precomp, sh, cov3Ds_precomp, scales, rotations = ctx.saved_tensors
+    means3D, opacities, colors_precomp, sh, cov3Ds_precomp, scales, rotations, color, depth, alpha = ctx.saved_tensors
     d_means3D, d_means2D, d_sh, d_col, d_op, d_sc, d_rot, d_cov, _ = _backward_impl(
         ctx.sgr, means3D, opacities, colors_precomp, sh, cov3Ds_precomp, scales, rotations, ctx.st, grad_color, grad_depth,
-        grad_alpha)
+        grad_alpha, (color, depth, alpha))
     has_sh, has_col, has_sr, has_cov = ctx.has
     return (d_means3D, d_means2D if ctx.has_means2D else None, d_sh if has_sh else None, d_col if has_col else None, d_op.unsqueeze(-1),
             d_sc if has_sr else None, d_rot if has_sr else None, d_cov if has_cov else None)

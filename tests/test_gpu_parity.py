@@ -290,3 +290,29 @@ def test_backward_is_bitwise_deterministic():
         res.append([d[k].grad.clone() for k in ("means3D", "colors_precomp", "opacities", "cov3D_precomp")])
     for a, b in zip(*res):
         assert torch.equal(a, b)
+
+
+def test_no_buffer_leak_across_steps():
+    """Forward buffers must be released by reference counting (no ctx <-> output cycle): device memory stays flat over steps."""
+    import gc
+    from sigman_release_amd import rasterizer as R
+    dev = _dev()
+    inp, st = cases.humanoid(P=20000, H=256, W=256, seed=1)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    base = _batched_settings(st, dev, 1)
+    d = {k: t(v)[None].requires_grad_(True) for k, v in inp.items()}
+    gc.disable()
+    try:
+        mem = []
+        for i in range(12):
+            for v in d.values():
+                v.grad = None
+            color, radii, depth, alpha = R.rasterize_gaussians_batched(d["means3D"], None, None, d["colors_precomp"],
+                                                                       d["opacities"][..., None], None, None, d["cov3D_precomp"], base)
+            color.sum().backward()
+            del color, radii, depth, alpha
+            torch.cuda.synchronize()
+            mem.append(torch.cuda.memory_allocated())
+        assert mem[-1] == mem[3], f"device memory grows across steps: {mem}"
+    finally:
+        gc.enable()

@@ -28,3 +28,7 @@ pr = cProfile.Profile(); pr.enable()
 for _ in range(N): step()
 pr.disable(); torch.cuda.synchronize()
 pstats.Stats(pr).sort_stats("cumulative").print_stats(28)
+import ctypes as C
+from sigman_release_amd import _cabi
+h, m = C.c_uint64(0), C.c_uint64(0)
+_cabi.lib().sgr_graph_stats(C.byref(h), C.byref(m)); print("graph hits", h.value, "misses", m.value)
