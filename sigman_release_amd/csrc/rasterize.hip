@@ -151,43 +151,51 @@ extern "C" int sgr_rasterize_forward(const SgrProblem *pb, uint64_t capacity, in
         key.pb = *pb; key.capacity = capacity; key.with_aux = with_aux; key.fwd_mode = sgr_get_forward_mode();
         key.color = out_color; key.depth = out_depth; key.alpha = out_alpha; key.radii = out_radii; key.nr_host = nullptr;
         key.geom = geom; key.binning = binning; key.image = image; key.stream = nullptr;
-        for (int i = 0; i < g_fwd_n; i++) {
-            if (memcmp(&g_fwd[i].key, &key, sizeof(key)) == 0) {
-                g_fwd[i].stamp = ++g_stamp; g_graph_hits++;
-                *st = g_fwd[i].st;
-                SGR_CHECK_HIP(hipGraphLaunch(g_fwd[i].exec, stream));
-                if (nr_pinned_host) SGR_CHECK_HIP(hipMemcpyAsync(nr_pinned_host, num_rendered, 16, hipMemcpyDeviceToHost, stream));
-                if (nr_event) SGR_CHECK_HIP(hipEventRecord((hipEvent_t)nr_event, stream));
-                return 0;
-            }
+        int found = -1;
+        for (int i = 0; i < g_fwd_n; i++)
+            if (memcmp(&g_fwd[i].key, &key, sizeof(key)) == 0) { found = i; break; }
+        if (found >= 0 && g_fwd[found].exec) {
+            g_fwd[found].stamp = ++g_stamp; g_graph_hits++;
+            *st = g_fwd[found].st;
+            SGR_CHECK_HIP(hipGraphLaunch(g_fwd[found].exec, stream));
+            if (nr_pinned_host) SGR_CHECK_HIP(hipMemcpyAsync(nr_pinned_host, num_rendered, 16, hipMemcpyDeviceToHost, stream));
+            if (nr_event) SGR_CHECK_HIP(hipEventRecord((hipEvent_t)nr_event, stream));
+            return 0;
         }
         g_graph_misses++;
         if (g_graph_misses > 64 && g_graph_hits < g_graph_misses) g_graphs_enabled = 0;   // pointers are not stable here: stop trying
-        hipGraph_t graph = nullptr;
-        hipGraphExec_t exec = nullptr;
-        // capture on a library-owned stream (the caller's stream may be the legacy default stream, which cannot be captured);
-        // the instantiated graph is then launched into the caller's stream
-        static hipStream_t cap_stream = nullptr;
-        if (!cap_stream && hipStreamCreateWithFlags(&cap_stream, hipStreamNonBlocking) != hipSuccess) { cap_stream = nullptr; g_graphs_enabled = 0; }
-        if (g_graphs_enabled && hipStreamBeginCapture(cap_stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-            const int rc = forward_launches(pb, capacity, R, st, out_color, out_depth, out_alpha, out_radii, nullptr, false, cap_stream);
-            const hipError_t e1 = hipStreamEndCapture(cap_stream, &graph);
-            if (rc == 0 && e1 == hipSuccess && graph && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess) {
-                (void)hipGraphDestroy(graph);
-                int slot = g_fwd_n < kGraphSlots ? g_fwd_n++ : 0;
-                if (slot == 0 && g_fwd_n == kGraphSlots) {       // evict the least recently used entry
-                    for (int i = 1; i < kGraphSlots; i++) if (g_fwd[i].stamp < g_fwd[slot].stamp) slot = i;
-                    (void)hipGraphExecDestroy(g_fwd[slot].exec);
-                }
-                g_fwd[slot].key = key; g_fwd[slot].exec = exec; g_fwd[slot].st = *st; g_fwd[slot].stamp = ++g_stamp;
-                SGR_CHECK_HIP(hipGraphLaunch(exec, stream));
-                if (nr_pinned_host) SGR_CHECK_HIP(hipMemcpyAsync(nr_pinned_host, num_rendered, 16, hipMemcpyDeviceToHost, stream));
-                if (nr_event) SGR_CHECK_HIP(hipEventRecord((hipEvent_t)nr_event, stream));
-                return 0;
+        if (found < 0) {
+            // first sighting of this argument set: run it with plain launches (this also makes sure every kernel's code object is
+            // loaded before anything is captured) and only remember the key; it is captured when it shows up again
+            int slot = g_fwd_n < kGraphSlots ? g_fwd_n++ : -1;
+            if (slot < 0) {                                            // evict the least recently used entry
+                slot = 0;
+                for (int i = 1; i < kGraphSlots; i++) if (g_fwd[i].stamp < g_fwd[slot].stamp) slot = i;
+                if (g_fwd[slot].exec) { (void)hipDeviceSynchronize(); (void)hipGraphExecDestroy(g_fwd[slot].exec); }
             }
-            if (graph) (void)hipGraphDestroy(graph);
-            (void)hipGetLastError();
-            g_graphs_enabled = 0;                                  // capture is not usable in this process: plain launches from now on
+            g_fwd[slot].key = key; g_fwd[slot].exec = nullptr; g_fwd[slot].stamp = ++g_stamp;
+        } else if (g_graphs_enabled) {
+            // capture on a library-owned stream (the caller's stream may be the legacy default stream, which cannot be captured);
+            // the instantiated graph is then launched into the caller's stream
+            static hipStream_t cap_stream = nullptr;
+            if (!cap_stream && hipStreamCreateWithFlags(&cap_stream, hipStreamNonBlocking) != hipSuccess) { cap_stream = nullptr; g_graphs_enabled = 0; }
+            hipGraph_t graph = nullptr;
+            hipGraphExec_t exec = nullptr;
+            if (g_graphs_enabled && hipStreamBeginCapture(cap_stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+                const int rc = forward_launches(pb, capacity, R, st, out_color, out_depth, out_alpha, out_radii, nullptr, false, cap_stream);
+                const hipError_t e1 = hipStreamEndCapture(cap_stream, &graph);
+                if (rc == 0 && e1 == hipSuccess && graph && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess) {
+                    (void)hipGraphDestroy(graph);
+                    g_fwd[found].exec = exec; g_fwd[found].st = *st; g_fwd[found].stamp = ++g_stamp;
+                    SGR_CHECK_HIP(hipGraphLaunch(exec, stream));
+                    if (nr_pinned_host) SGR_CHECK_HIP(hipMemcpyAsync(nr_pinned_host, num_rendered, 16, hipMemcpyDeviceToHost, stream));
+                    if (nr_event) SGR_CHECK_HIP(hipEventRecord((hipEvent_t)nr_event, stream));
+                    return 0;
+                }
+                if (graph) (void)hipGraphDestroy(graph);
+                (void)hipGetLastError();
+                g_graphs_enabled = 0;                              // capture is not usable in this process: plain launches from now on
+            }
         }
     }
     if (forward_launches(pb, capacity, R, st, out_color, out_depth, out_alpha, out_radii, capacity > 0 ? nr_pinned_host : nullptr,

@@ -13,6 +13,8 @@ cv, cvp, cp = cameras.make_cameras([30])
 st = R.BatchedRasterizationSettings(H, H, cameras.TAN_HALF_FOV, cameras.TAN_HALF_FOV, torch.ones(3, device=dev), 1.0, t(cv), t(cvp), 0, t(cp), 1, False, int(os.environ.get("CAP", "260000")))
 m, c, o, rgb = [t(x)[None].requires_grad_(True) for x in (g["position"], cov, g["opacity"], g["rgb"])]
 gt = torch.rand(1, 3, H, H, device=dev)
+from sigman_release_amd import _cabi as _c
+_c.lib().sgr_set_graphs(int(os.environ.get("GRAPHS", "1")))
 def step():
     for v in (m, c, o, rgb): v.grad = None
     color, radii, depth, alpha = R.rasterize_gaussians_batched(m, None, None, rgb, o, None, None, c, st)
@@ -24,6 +26,10 @@ t0 = time.perf_counter()
 for _ in range(N): step()
 t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
 print(f"host-side {1e6*(t1-t0)/N:.0f} us/step issue time; {1e6*(t2-t0)/N:.0f} us/step incl. drain")
+import ctypes as C
+h, m_ = C.c_uint64(0), C.c_uint64(0)
+_c.lib().sgr_graph_stats(C.byref(h), C.byref(m_)); print("graph hits", h.value, "misses", m_.value, flush=True)
+if os.environ.get("NOPROF"): sys.exit(0)
 pr = cProfile.Profile(); pr.enable()
 for _ in range(N): step()
 pr.disable(); torch.cuda.synchronize()
