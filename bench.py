@@ -192,6 +192,16 @@ def main():
     abytes = algorithmic_bytes(dominant, P * len(my_views), Rn, H * W * len(my_views), tiles * len(my_views), len(my_views))
     achieved = abytes / (dom_avg_ms * 1e-3) / 1e9 if dom_avg_ms > 0 else 0.0
 
+    # HBM traffic of the dominant kernel from the committed rocprofv3 PMC summary of this same command (separate --pmc passes,
+    # gfx950 FETCH_SIZE correction applied as MI355X_MICROARCH.md prescribes); null when no summary matches this workload
+    traffic = None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_c2.json")))
+        if P == 100_000 and H == 512 and len(my_views) == 1:
+            traffic = pmc["kernels"].get(KERNELS.get(dominant, ""), {}).get("hbm_bytes_corrected")
+    except Exception:
+        traffic = None
+
     out = {
         "metric": f"rendered views/sec (fwd+bwd) at {H}x{W}, {P} Gaussians/view",
         "value": round(views_per_s, 3), "unit": "views/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -205,7 +215,7 @@ def main():
         "gaussian_pixel_ops_per_s_per_gpu": round(S_visits / (ms_per_step * 1e-3), 1),
         "tile_instances_per_s_per_gpu": round(Rn / (ms_per_step * 1e-3), 1),
         "roofline": {"bound": "hbm", "kernel": KERNELS.get(dominant, str(dominant)), "achieved": round(achieved, 2),
-                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                      "algorithmic_bytes_per_launch": abytes, "avg_launch_ms": round(dom_avg_ms, 5), "launches": dom_n},
         "kernel_ms_per_step": breakdown,
         "loss": float(loss.detach()),

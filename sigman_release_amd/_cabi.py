@@ -87,6 +87,8 @@ def lib():
             fn.argtypes = args
         if L.sgr_abi_version() != 1:
             raise RuntimeError(f"ABI version mismatch: library reports {L.sgr_abi_version()}, binding expects 1")
+        if os.environ.get("SIGMAN_GRAPHS", "1") == "0":      # e.g. for counter collection with rocprofv3 --pmc
+            L.sgr_set_graphs(0)
         _lib = L
     return _lib
 
