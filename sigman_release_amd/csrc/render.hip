@@ -20,6 +20,8 @@
 namespace {
 
 constexpr int kBlock = 256;
+constexpr float kLog2e = -1.4426950408889634f;          // conic.xy is pre-multiplied by -log2(e)
+constexpr float kHalfLog2e = -0.7213475204444817f;      // conic.xx / conic.yy by -0.5*log2(e)
 
 struct Quad {
     uint32_t view, tile, tx, ty;
@@ -90,7 +92,10 @@ __global__ __launch_bounds__(kBlock) void render_fwd_kernel(int W, int H, int Tx
         if (idx < n) {
             const uint32_t id = point_list[range.x + idx];
             const float4 a = rec[(size_t)id * 4 + 0], b = rec[(size_t)id * 4 + 1], c = rec[(size_t)id * 4 + 2];
-            sA[t] = a; sB[t] = b; sC[t] = c;
+            // conic pre-scaled into the exp2 domain: exp(power) = exp2(kxx dx^2 + kyy dy^2 + kxy dx dy)
+            sA[t] = make_float4(a.x, a.y, kHalfLog2e * a.z, kLog2e * a.w);
+            sB[t] = make_float4(kHalfLog2e * b.x, b.y, b.z, b.w);
+            sC[t] = c;
             sId[t] = id;
             m = cull_mask(a, c, x0, y0);
         }
@@ -135,8 +140,8 @@ __global__ __launch_bounds__(kBlock) void render_fwd_kernel(int W, int H, int Tx
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 const float dx = a[u].x - pxf, dy = a[u].y - pyf;
-                const float power = -0.5f * (a[u].z * dx * dx + b[u].x * dy * dy) - a[u].w * dx * dy;
-                const float alpha = fminf(0.99f, b[u].y * __expf(power));
+                const float power = (a[u].z * dx) * dx + ((b[u].x * dy) * dy + (a[u].w * dx) * dy);
+                const float alpha = fminf(0.99f, b[u].y * __builtin_amdgcn_exp2f(power));
                 valid[u] = (power <= 0.f) & (alpha >= (1.0f / 255.0f));
                 al[u] = valid[u] ? alpha : 0.f;
             }
@@ -263,7 +268,9 @@ __global__ __launch_bounds__(kSegThreads, 4) void render_fwd_seg_kernel(int W, i
         for (int w = 0; w < kSegWaves; w++) { const uint32_t cw = sWaveCnt[w]; if (w < wave) woff += cw; m += cw; }
         if (bit) {
             const uint32_t s = woff + (uint32_t)__popcll(bal & lt_mask);
-            sA[s] = a; sB[s] = b; sC[s] = c; sId[s] = id; sIdx[s] = (uint32_t)idx;
+            sA[s] = make_float4(a.x, a.y, kHalfLog2e * a.z, kLog2e * a.w);
+            sB[s] = make_float4(kHalfLog2e * b.x, b.y, b.z, b.w);
+            sC[s] = c; sId[s] = id; sIdx[s] = (uint32_t)idx;
         }
         __syncthreads();
         if (m == 0) continue;
@@ -282,8 +289,8 @@ __global__ __launch_bounds__(kSegThreads, 4) void render_fwd_seg_kernel(int W, i
                 const uint32_t su = min(s + u, s1 - 1);
                 const float4 ga = sA[su], gb = sB[su];
                 const float dx = ga.x - pxf, dy = ga.y - pyf;
-                const float power = -0.5f * (ga.z * dx * dx + gb.x * dy * dy) - ga.w * dx * dy;
-                const float alpha = fminf(0.99f, gb.y * __expf(power));
+                const float power = (ga.z * dx) * dx + ((gb.x * dy) * dy + (ga.w * dx) * dy);
+                const float alpha = fminf(0.99f, gb.y * __builtin_amdgcn_exp2f(power));
                 const bool valid = (power <= 0.f) & (alpha >= (1.0f / 255.0f)) & (s + u < s1);
                 om[u] = valid ? 1.f - alpha : 1.f;
             }
@@ -310,8 +317,8 @@ __global__ __launch_bounds__(kSegThreads, 4) void render_fwd_seg_kernel(int W, i
                 const float4 ga = sA[su];
                 gb4[u] = sB[su]; gc4[u] = sC[su]; li[u] = sIdx[su] + 1u;
                 const float dx = ga.x - pxf, dy = ga.y - pyf;
-                const float power = -0.5f * (ga.z * dx * dx + gb4[u].x * dy * dy) - ga.w * dx * dy;
-                const float alpha = fminf(0.99f, gb4[u].y * __expf(power));
+                const float power = (ga.z * dx) * dx + ((gb4[u].x * dy) * dy + (ga.w * dx) * dy);
+                const float alpha = fminf(0.99f, gb4[u].y * __builtin_amdgcn_exp2f(power));
                 const bool valid = (power <= 0.f) & (alpha >= (1.0f / 255.0f)) & (s + u < s1);
                 al[u] = valid ? alpha : 0.f;
             }
@@ -344,13 +351,14 @@ __global__ __launch_bounds__(kSegThreads, 4) void render_fwd_seg_kernel(int W, i
             const uint32_t nseg = (m + per - 1) / per;
             if ((uint32_t)wave < nseg) {
                 const size_t slot = slot_next + wave;
-                if (kbase + s0 != 0u) {
-                    aux.ckpt_tc[slot * 64 + lane] = make_float4(Tin, p0, p1, p2);
-                    aux.ckpt_da[slot * 64 + lane] = make_float2(pD, pA);
-                }
                 // only buckets in which some pixel of the quadrant composited something can receive gradient
-                if (__ballot(contributed != 0u) && lane == 0)
-                    aux.desc[slot] = make_uint2(bid, ((kbase + s0) << 7) | (s1 - s0));
+                if (__ballot(contributed != 0u)) {
+                    if (kbase + s0 != 0u) {
+                        aux.ckpt_tc[slot * 64 + lane] = make_float4(Tin, p0, p1, p2);
+                        aux.ckpt_da[slot * 64 + lane] = make_float2(pD, pA);
+                    }
+                    if (lane == 0) aux.desc[slot] = make_uint2(bid, ((kbase + s0) << 7) | (s1 - s0));
+                }
             }
             slot_next += nseg;
         }
