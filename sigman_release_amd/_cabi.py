@@ -47,13 +47,14 @@ _SIGNATURES = {
     "sgr_rasterize_backward": (C.c_int, [C.POINTER(SgrProblem), C.POINTER(SgrForwardState)] + [C.c_void_p] * 7 + [ALLOC_FN, C.c_void_p]
                                + [C.c_void_p] * 9),
     "sgr_preprocess_forward": (C.c_int, [C.POINTER(SgrProblem)] + [C.c_void_p] * 6 + [C.c_uint64, C.c_void_p]),
-    "sgr_bin_workspace_bytes": (C.c_size_t, [C.c_uint64]),
+    "sgr_bin_workspace_bytes": (C.c_size_t, [C.c_uint64, C.c_uint64]),
     "sgr_bin": (C.c_int, [C.POINTER(SgrProblem), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_int32),
                           C.c_void_p]),
     "sgr_bucket_slots": (C.c_uint64, [C.c_uint64, C.c_uint64]),
     "sgr_set_forward_mode": (C.c_int, [C.c_int]),
     "sgr_set_graphs": (C.c_int, [C.c_int]),
+    "sgr_set_sort_mode": (C.c_int, [C.c_int]),
     "sgr_graph_stats": (C.c_int, [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "sgr_render_forward": (C.c_int, [C.POINTER(SgrProblem)] + [C.c_void_p] * 8 + [C.c_uint64] + [C.c_void_p] * 5),
     "sgr_render_backward": (C.c_int, [C.POINTER(SgrProblem)] + [C.c_void_p] * 11 + [C.c_uint64] + [C.c_void_p] * 8),

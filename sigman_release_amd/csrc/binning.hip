@@ -193,10 +193,270 @@ __global__ __launch_bounds__(kThreads) void radix_downsweep_kernel(const uint64_
     }
 }
 
+// ---- F4, onesweep variant: ONE kernel per digit instead of three --------------------------------------
+// (a) radix_hist_all_kernel reads the keys once and builds the global histograms of every pass (the multiset of keys
+//     does not change between passes, so all digit histograms can be taken up front);
+// (b) per pass, radix_onesweep_kernel's workgroups draw tile ids from an atomic ticket (so every lower-numbered tile is
+//     owned by a workgroup that is already running), publish their per-digit counts in a status word
+//     (2 flag bits | 30-bit value) and resolve their exclusive prefix by decoupled look-back over the earlier tiles.
+// The status word carries its own payload and only moves 0 -> AGGREGATE -> INCLUSIVE, so a stale read is merely an
+// older valid state: relaxed agent-scope atomics suffice, no fences, no placement assumptions (guide G16).  Spins are
+// bounded: if a status never shows up the kernel raises an error flag and returns instead of hanging.
+constexpr uint32_t kFlagAgg = 1u << 30, kFlagInc = 2u << 30, kValMask = (1u << 30) - 1u;
+constexpr int kMaxPasses = 8;
+
+__global__ __launch_bounds__(kThreads) void radix_hist_all_kernel(const uint64_t *__restrict__ keys, uint32_t n_host,
+                                                                  const uint64_t *__restrict__ n_dev, int passes,
+                                                                  uint32_t *__restrict__ ghist /*[passes][256]*/) {
+    __shared__ uint32_t h[kMaxPasses][kRadix];
+    const uint32_t n = n_dev ? (uint32_t)min((uint64_t)n_host, *n_dev) : n_host;
+    for (int p = 0; p < passes; p++) h[p][threadIdx.x] = 0;
+    __syncthreads();
+    for (uint32_t k = blockIdx.x * kThreads + threadIdx.x; k < n; k += gridDim.x * kThreads) {
+        const uint64_t key = keys[k];
+        for (int p = 0; p < passes; p++) atomicAdd(&h[p][(uint32_t)(key >> (p * kRadixBits)) & (kRadix - 1)], 1u);
+    }
+    __syncthreads();
+    for (int p = 0; p < passes; p++) {
+        const uint32_t c = h[p][threadIdx.x];
+        if (c) atomicAdd(&ghist[p * kRadix + threadIdx.x], c);
+    }
+}
+
+template <int ITEMS>
+__global__ __launch_bounds__(kThreads) void radix_onesweep_kernel(const uint64_t *__restrict__ keys_in,
+                                                                  const uint32_t *__restrict__ vals_in,
+                                                                  uint64_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out,
+                                                                  uint32_t n_host, const uint64_t *__restrict__ n_dev, int shift,
+                                                                  const uint32_t *__restrict__ ghist /*[256] of this pass*/,
+                                                                  uint32_t *__restrict__ status /*[tiles][256] of this pass*/,
+                                                                  uint32_t *__restrict__ ticket, uint32_t *__restrict__ err) {
+    __shared__ uint32_t digit_base[kRadix];
+    __shared__ uint32_t hist[kRadix];
+    __shared__ uint32_t wave_cnt[4][kRadix];
+    __shared__ uint32_t wtot[4];
+    __shared__ uint32_t s_tile;
+    const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const uint32_t n = n_dev ? (uint32_t)min((uint64_t)n_host, *n_dev) : n_host;
+    if (t == 0) s_tile = atomicAdd(ticket, 1u);
+    hist[t] = 0;
+    __syncthreads();
+    const uint32_t tile = s_tile;
+    const uint32_t base = tile * (kThreads * ITEMS);
+    if (base >= n) return;                                     // workgroup-uniform
+    uint64_t key[ITEMS];
+    uint32_t val[ITEMS];
+#pragma unroll
+    for (int it = 0; it < ITEMS; it++) {
+        const uint32_t k = base + it * kThreads + t;
+        key[it] = 0; val[it] = 0;
+        if (k < n) { key[it] = keys_in[k]; val[it] = vals_in[k]; atomicAdd(&hist[(uint32_t)(key[it] >> shift) & (kRadix - 1)], 1u); }
+    }
+    __syncthreads();
+    {   // thread t owns digit t: global start of the digit (scan of the pass histogram) + tiles before mine (look-back)
+        const uint32_t g = ghist[t];
+        uint32_t inc = g;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t nb = __shfl_up(inc, off, 64);
+            if (lane >= (uint32_t)off) inc += nb;
+        }
+        if (lane == 63) wtot[wave] = inc;
+        __syncthreads();
+        uint32_t gstart = inc - g;
+        for (uint32_t w = 0; w < wave; w++) gstart += wtot[w];
+        const uint32_t cnt = hist[t];
+        uint32_t excl = 0;
+        uint32_t *mine = status + (size_t)tile * kRadix + t;
+        if (tile == 0) {
+            __hip_atomic_store(mine, cnt | kFlagInc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            __hip_atomic_store(mine, cnt | kFlagAgg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int tt = (int)tile - 1; tt >= 0; --tt) {
+                const uint32_t *p = status + (size_t)tt * kRadix + t;
+                uint32_t v = 0;
+                uint32_t spins = 0;
+                do {
+                    v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } while ((v >> 30) == 0u && ++spins < (1u << 22));
+                if ((v >> 30) == 0u) { atomicOr(err, 1u); break; }          // bounded spin: report instead of hanging
+                excl += v & kValMask;
+                if ((v >> 30) == 2u) break;
+            }
+            __hip_atomic_store(mine, ((excl + cnt) & kValMask) | kFlagInc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        digit_base[t] = gstart + excl;
+    }
+    const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+    for (int it = 0; it < ITEMS; it++) {
+        const uint32_t k = base + it * kThreads + t;
+        const bool valid = k < n;
+        const uint32_t d = (uint32_t)(key[it] >> shift) & (kRadix - 1);
+#pragma unroll
+        for (int w = 0; w < 4; w++) wave_cnt[w][t] = 0;
+        __syncthreads();
+        uint64_t peers = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < kRadixBits; b++) {
+            const bool bit = (d >> b) & 1;
+            const uint64_t m = __ballot(bit);
+            peers &= bit ? m : ~m;
+        }
+        const uint32_t rank = (uint32_t)__popcll(peers & lt_mask);
+        if (valid && rank == 0) wave_cnt[wave][d] = (uint32_t)__popcll(peers);
+        __syncthreads();
+        if (valid) {
+            uint32_t pos = digit_base[d] + rank;
+            for (uint32_t w = 0; w < wave; w++) pos += wave_cnt[w][d];
+            keys_out[pos] = key[it];
+            vals_out[pos] = val[it];
+        }
+        __syncthreads();
+        digit_base[t] += wave_cnt[0][t] + wave_cnt[1][t] + wave_cnt[2][t] + wave_cnt[3][t];
+        __syncthreads();
+    }
+}
+
+// ---- F4, segmented variant: the key is (tile, depth), so sort the TILE bits globally and the DEPTH bits per tile ----
+// Global LSD passes are run over the tile-id bits only (2 passes for up to 65536 tiles instead of 6-7 over the
+// whole key); they are stable, so afterwards every tile owns a contiguous segment whose entries are still in
+// emission order (ascending Gaussian index).  tile_ranges then finds the segments and tile_sort_kernel sorts each
+// one by its 32 depth bits with a stable LSD radix sort that lives entirely in LDS (160 KB/CU on MI355X: a 4096-entry
+// segment needs 64 KB for two key/value ping-pong pairs).  Digits on which a whole segment agrees are skipped -- the
+// exponent byte of the depths inside one tile almost always is.  Segments longer than the LDS capacity are sorted by
+// the same code through the global ping-pong buffers.  The result is bit-identical to one stable sort of the full key.
+constexpr int kSegCapSmall = 1024, kSegCapLarge = 4096;
+
+template <int NT, bool IN_LDS>
+__device__ __forceinline__ void seg_sort_passes(uint32_t n, uint32_t *ka, uint32_t *va, uint32_t *kb, uint32_t *vb,
+                                                uint64_t *gka, uint32_t *gva, uint64_t *gkb, uint32_t *gvb, bool &in_b,
+                                                uint32_t *hist, uint32_t *digit_base, uint32_t (*wave_cnt)[kRadix], uint32_t *wtot) {
+    constexpr int NW = NT / 64;
+    const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    for (int shift = 0; shift < 32; shift += kRadixBits) {
+        // ---- histogram of this digit over the segment
+        if (t < kRadix) hist[t] = 0;
+        __syncthreads();
+        for (uint32_t k = t; k < n; k += NT) {
+            const uint32_t key = IN_LDS ? (in_b ? kb[k] : ka[k]) : (uint32_t)(in_b ? gkb[k] : gka[k]);
+            atomicAdd(&hist[(key >> shift) & (kRadix - 1)], 1u);
+        }
+        __syncthreads();
+        const uint32_t cnt = t < kRadix ? hist[t] : 0u;
+        if (__syncthreads_or(cnt == n)) continue;                 // every key has the same digit: nothing to do
+        // ---- exclusive scan of the 256 bins (threads 0..255 own one bin each)
+        uint32_t inc = cnt;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t nb = __shfl_up(inc, off, 64);
+            if (lane >= (uint32_t)off) inc += nb;
+        }
+        if (lane == 63 && wave < 4) wtot[wave] = inc;
+        __syncthreads();
+        if (t < kRadix) {
+            uint32_t pre = inc - cnt;
+            for (uint32_t w = 0; w < wave; w++) pre += wtot[w];
+            digit_base[t] = pre;
+        }
+        // ---- stable scatter, NT keys per round in segment order
+        for (uint32_t r0 = 0; r0 < n; r0 += NT) {
+            const uint32_t k = r0 + t;
+            const bool valid = k < n;
+            uint32_t key = 0, val = 0;
+            uint64_t key64 = 0;
+            if (valid) {
+                if (IN_LDS) { key = in_b ? kb[k] : ka[k]; val = in_b ? vb[k] : va[k]; }
+                else { key64 = in_b ? gkb[k] : gka[k]; key = (uint32_t)key64; val = in_b ? gvb[k] : gva[k]; }
+            }
+            const uint32_t d = (key >> shift) & (kRadix - 1);
+            if (t < kRadix) {
+#pragma unroll
+                for (int w = 0; w < NW; w++) wave_cnt[w][t] = 0;
+            }
+            __syncthreads();
+            uint64_t peers = __ballot(valid);
+#pragma unroll
+            for (int b = 0; b < kRadixBits; b++) {
+                const bool bit = (d >> b) & 1;
+                const uint64_t m = __ballot(bit);
+                peers &= bit ? m : ~m;
+            }
+            const uint32_t rank = (uint32_t)__popcll(peers & lt_mask);
+            if (valid && rank == 0) wave_cnt[wave][d] = (uint32_t)__popcll(peers);
+            __syncthreads();
+            if (valid) {
+                uint32_t pos = digit_base[d] + rank;
+                for (uint32_t w = 0; w < wave; w++) pos += wave_cnt[w][d];
+                if (IN_LDS) { (in_b ? ka : kb)[pos] = key; (in_b ? va : vb)[pos] = val; }
+                else { (in_b ? gka : gkb)[pos] = key64; (in_b ? gva : gvb)[pos] = val; }
+            }
+            __syncthreads();
+            if (t < kRadix) {
+                uint32_t add = 0;
+#pragma unroll
+                for (int w = 0; w < NW; w++) add += wave_cnt[w][t];
+                digit_base[t] += add;
+            }
+            __syncthreads();
+        }
+        in_b = !in_b;
+        if (!IN_LDS) { __threadfence_block(); __syncthreads(); }
+    }
+}
+
+// src = buffers holding the tile-bucketed data, dst = the other pair; the sorted segment always ends up in dst.
+// Two size classes share the code: CAP=1024 / 256 threads (16 KB of LDS: full occupancy for the many short lists) handles
+// segments of <= 1024 entries, CAP=4096 / 1024 threads handles the rest (and oversize segments through global memory).
+// (launching a 1024-thread / 80-KB-LDS workgroup per tile just to have it exit costs ~10 us per CU slot, so the small-class
+// launch, one workgroup per tile, appends the long tiles to a worklist that a fixed-size large-class grid then drains)
+template <int NT, int CAP, bool SMALL_CLASS>
+__global__ __launch_bounds__(NT) void tile_sort_kernel(const uint2 *__restrict__ ranges, uint64_t *__restrict__ src_keys,
+                                                       uint32_t *__restrict__ src_vals, uint64_t *__restrict__ dst_keys,
+                                                       uint32_t *__restrict__ dst_vals, uint32_t *__restrict__ worklist /*[0]=count, [1..]=tiles*/) {
+    __shared__ uint32_t ka[CAP], va[CAP], kb[CAP], vb[CAP];
+    __shared__ uint32_t hist[kRadix], digit_base[kRadix], wave_cnt[NT / 64][kRadix], wtot[4];
+    const uint32_t t = threadIdx.x;
+    const uint32_t nwork = SMALL_CLASS ? 1u : worklist[0];
+    for (uint32_t wi = SMALL_CLASS ? 0u : blockIdx.x; wi < nwork; wi += gridDim.x) {
+    const uint32_t tile_id = SMALL_CLASS ? blockIdx.x : worklist[1 + wi];
+    const uint2 range = ranges[tile_id];
+    const uint32_t n = range.y - range.x;
+    if (n == 0) return;
+    if (SMALL_CLASS && n > (uint32_t)kSegCapSmall) {
+        if (t == 0) worklist[1 + atomicAdd(&worklist[0], 1u)] = tile_id;
+        return;
+    }
+    __syncthreads();                                               // (large class: LDS reuse between worklist items)
+    uint64_t *gsrc_k = src_keys + range.x, *gdst_k = dst_keys + range.x;
+    uint32_t *gsrc_v = src_vals + range.x, *gdst_v = dst_vals + range.x;
+    bool in_b = false;
+    if (n <= (uint32_t)CAP) {
+        const uint32_t hi = (uint32_t)(gsrc_k[0] >> 32);                      // tile id, identical for the whole segment
+        for (uint32_t k = t; k < n; k += NT) { ka[k] = (uint32_t)gsrc_k[k]; va[k] = gsrc_v[k]; }
+        __syncthreads();
+        if (n > 1) seg_sort_passes<NT, true>(n, ka, va, kb, vb, nullptr, nullptr, nullptr, nullptr, in_b, hist, digit_base, wave_cnt, wtot);
+        __syncthreads();
+        const uint32_t *fk = in_b ? kb : ka, *fv = in_b ? vb : va;
+        for (uint32_t k = t; k < n; k += NT) { gdst_k[k] = ((uint64_t)hi << 32) | fk[k]; gdst_v[k] = fv[k]; }
+    } else {
+        // oversize segment: same algorithm through the global ping-pong pair (a = src, b = dst)
+        seg_sort_passes<NT, false>(n, nullptr, nullptr, nullptr, nullptr, gsrc_k, gsrc_v, gdst_k, gdst_v, in_b, hist, digit_base, wave_cnt, wtot);
+        __threadfence_block();
+        __syncthreads();
+        if (!in_b)                                               // result sits in src: move it to dst
+            for (uint32_t k = t; k < n; k += NT) { gdst_k[k] = gsrc_k[k]; gdst_v[k] = gsrc_v[k]; }
+    }
+    }
+}
+
 // ---- F5 -------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kThreads) void tile_ranges_kernel(const uint64_t *__restrict__ keys, uint32_t n_host,
-                                                               const uint64_t *__restrict__ n_dev, uint2 *__restrict__ ranges) {
+                                                               const uint64_t *__restrict__ n_dev, uint2 *__restrict__ ranges,
+                                                               uint32_t *__restrict__ worklist_count) {
     const uint32_t n = n_dev ? (uint32_t)min((uint64_t)n_host, *n_dev) : n_host;
+    if (worklist_count && blockIdx.x == 0 && threadIdx.x == 0) *worklist_count = 0;
     const uint32_t r = blockIdx.x * kThreads + threadIdx.x;
     if (r >= n) return;
     const uint32_t tile = (uint32_t)(keys[r] >> 32);
@@ -208,15 +468,23 @@ __global__ __launch_bounds__(kThreads) void tile_ranges_kernel(const uint64_t *_
     if (r == n - 1) ranges[tile].y = n;
 }
 
+// 3 = automatic (default, by instance count: measured crossovers on MI355X), 2 = segmented (tile bits globally, depth bits per tile in LDS),
+// 0 = onesweep, 1 = three kernels per pass
+int sgr_sort_mode = 3;
+
 inline int bits_for(uint64_t v) { int b = 0; while ((1ull << b) < v) b++; return b; }   // smallest b with 2^b >= v
 
 }  // namespace
 
 int sgr_validate_problem(const SgrProblem *pb);
 
-extern "C" size_t sgr_bin_workspace_bytes(uint64_t R) {
+extern "C" int sgr_set_sort_mode(int mode) { sgr_sort_mode = mode; return 0; }
+
+extern "C" size_t sgr_bin_workspace_bytes(uint64_t R, uint64_t tiles_total) {
     const uint64_t nblocks = (R + kThreads * kItemsSmall - 1) / (kThreads * kItemsSmall);
-    return (size_t)(((nblocks > 0 ? nblocks : 1) + 1) * kRadix * sizeof(uint32_t) + 256);
+    // onesweep: [ghist 8x256][tickets 8][err][pad] + status [8 passes][tiles][256]; three-kernel path: [hist tiles x 256][totals 256]
+    return (size_t)((kMaxPasses * (nblocks > 0 ? nblocks : 1) + kMaxPasses + 2) * kRadix * sizeof(uint32_t) + 1024 +
+                    (tiles_total ? (tiles_total + 64) * sizeof(uint32_t) : 0));
 }
 
 extern "C" int sgr_bin(const SgrProblem *pb, float *rec, const int32_t *radii, const uint32_t *rect,
@@ -232,7 +500,7 @@ extern "C" int sgr_bin(const SgrProblem *pb, float *rec, const int32_t *radii, c
     SGR_CHECK_HIP(hipMemsetAsync(ranges, 0, tiles_total * 2 * sizeof(uint32_t), stream));
     if (result_in_b_host) *result_in_b_host = 0;
     if (R == 0 || pb->P == 0) return 0;
-    if (workspace_bytes < sgr_bin_workspace_bytes(R)) { sgr_set_error("sgr_bin: workspace too small"); return 1; }
+    if (workspace_bytes < sgr_bin_workspace_bytes(R, tiles_total)) { sgr_set_error("sgr_bin: workspace too small"); return 1; }
     const uint32_t n = (uint32_t)R;
     const int nbx = sgr_preprocess_blocks_per_view(pb->P);
     { SgrProfScope _p(SGR_K_DUPLICATE, stream);
@@ -249,7 +517,65 @@ extern "C" int sgr_bin(const SgrProblem *pb, float *rec, const int32_t *radii, c
     const int passes = (total_bits + kRadixBits - 1) / kRadixBits;
     uint64_t *kin = keys_a, *kout = keys_b;
     uint32_t *vin = vals_a, *vout = vals_b;
+    // sort flavour: 2 (default) = tile bits globally + depth bits per tile in LDS; 0 = onesweep over the whole key; 1 = three kernels
+    // automatic: segmented up to 2^19 instances (one 512^2 view: 74 vs 82 vs 100 us), three-kernel up to 2^23 (16 views: 285 vs
+    // 323 vs 360 us), onesweep beyond (64 views: 1041 vs 1176 vs 1186 us; 90 views at 1024^2: 3.57 vs 3.82 vs 3.87 ms)
+    const int mode = sgr_sort_mode != 3 ? sgr_sort_mode : (R <= (1ull << 19) ? 2 : (R <= (1ull << 23) ? 1 : 0));
+    const bool segmented = mode == 2;
+    if (segmented) {
+        uint32_t *worklist = (uint32_t *)((char *)workspace + sgr_bin_workspace_bytes(R, 0));   // [1 + tiles_total] behind the radix scratch
+        const int tile_bits = bits_for(tiles_total);
+        const int tpasses = (tile_bits + kRadixBits - 1) / kRadixBits;
+        { SgrProfScope _ps(SGR_K_SORT, stream);
+        for (int p = 0; p < tpasses; p++) {
+            const int shift = 32 + p * kRadixBits;
+            if (small) hipLaunchKernelGGL(radix_upsweep_kernel<kItemsSmall>, dim3(nblocks), dim3(kThreads), 0, stream, kin, n, num_rendered_dev, shift, nblocks, hist);
+            else hipLaunchKernelGGL(radix_upsweep_kernel<kItemsLarge>, dim3(nblocks), dim3(kThreads), 0, stream, kin, n, num_rendered_dev, shift, nblocks, hist);
+            hipLaunchKernelGGL(radix_rowscan_kernel, dim3(kRadix), dim3(kThreads), 0, stream, hist, nblocks, totals);
+            if (small) hipLaunchKernelGGL(radix_downsweep_kernel<kItemsSmall>, dim3(nblocks), dim3(kThreads), 0, stream, kin, vin, kout, vout, n, num_rendered_dev, shift, nblocks, hist, totals);
+            else hipLaunchKernelGGL(radix_downsweep_kernel<kItemsLarge>, dim3(nblocks), dim3(kThreads), 0, stream, kin, vin, kout, vout, n, num_rendered_dev, shift, nblocks, hist, totals);
+            SGR_CHECK_LAUNCH("radix tile-bit pass");
+            uint64_t *tk = kin; kin = kout; kout = tk;
+            uint32_t *tv = vin; vin = vout; vout = tv;
+        }
+        }
+        { SgrProfScope _pr(SGR_K_RANGES, stream);
+        hipLaunchKernelGGL(tile_ranges_kernel, dim3((n + kThreads - 1) / kThreads), dim3(kThreads), 0, stream, kin, n, num_rendered_dev, (uint2 *)ranges, worklist);
+        SGR_CHECK_LAUNCH("tile_ranges_kernel");
+        }
+        { SgrProfScope _ps(SGR_K_SORT, stream);
+        hipLaunchKernelGGL((tile_sort_kernel<256, kSegCapSmall, true>), dim3((uint32_t)tiles_total), dim3(256), 0, stream,
+                           (const uint2 *)ranges, kin, vin, kout, vout, worklist);
+        const uint32_t big_grid = (uint32_t)(tiles_total < 512 ? tiles_total : 512);
+        hipLaunchKernelGGL((tile_sort_kernel<1024, kSegCapLarge, false>), dim3(big_grid), dim3(1024), 0, stream,
+                           (const uint2 *)ranges, kin, vin, kout, vout, worklist);
+        SGR_CHECK_LAUNCH("tile_sort_kernel");
+        }
+        if (result_in_b_host) *result_in_b_host = (kout == keys_b) ? 1 : 0;
+        return 0;
+    }
+    const bool onesweep = mode == 0 && passes <= kMaxPasses && R < (1ull << 30);
     { SgrProfScope _ps(SGR_K_SORT, stream);
+    if (onesweep) {
+        uint32_t *ws32 = (uint32_t *)workspace;
+        uint32_t *ghist = ws32;                                   // [kMaxPasses][256]
+        uint32_t *tickets = ghist + kMaxPasses * kRadix;          // [kMaxPasses]
+        uint32_t *err = tickets + kMaxPasses;                     // [1] (+ padding to 256 entries)
+        uint32_t *status = tickets + kRadix;                      // [passes][nblocks][256]
+        SGR_CHECK_HIP(hipMemsetAsync(ws32, 0, ((size_t)(kMaxPasses + 1) * kRadix + (size_t)passes * nblocks * kRadix) * sizeof(uint32_t), stream));
+        const uint32_t hist_blocks = nblocks < 1024u ? (nblocks ? nblocks : 1u) : 1024u;
+        hipLaunchKernelGGL(radix_hist_all_kernel, dim3(hist_blocks), dim3(kThreads), 0, stream, kin, n, num_rendered_dev, passes, ghist);
+        SGR_CHECK_LAUNCH("radix_hist_all_kernel");
+        for (int p = 0; p < passes; p++) {
+            const int shift = p * kRadixBits;
+            uint32_t *st_p = status + (size_t)p * nblocks * kRadix;
+            if (small) hipLaunchKernelGGL(radix_onesweep_kernel<kItemsSmall>, dim3(nblocks), dim3(kThreads), 0, stream, kin, vin, kout, vout, n, num_rendered_dev, shift, ghist + p * kRadix, st_p, tickets + p, err);
+            else hipLaunchKernelGGL(radix_onesweep_kernel<kItemsLarge>, dim3(nblocks), dim3(kThreads), 0, stream, kin, vin, kout, vout, n, num_rendered_dev, shift, ghist + p * kRadix, st_p, tickets + p, err);
+            SGR_CHECK_LAUNCH("radix_onesweep_kernel");
+            uint64_t *tk = kin; kin = kout; kout = tk;
+            uint32_t *tv = vin; vin = vout; vout = tv;
+        }
+    } else
     for (int p = 0; p < passes; p++) {
         const int shift = p * kRadixBits;
         if (small) hipLaunchKernelGGL(radix_upsweep_kernel<kItemsSmall>, dim3(nblocks), dim3(kThreads), 0, stream, kin, n, num_rendered_dev, shift, nblocks, hist);
@@ -267,7 +593,7 @@ extern "C" int sgr_bin(const SgrProblem *pb, float *rec, const int32_t *radii, c
     if (result_in_b_host) *result_in_b_host = (kin == keys_b) ? 1 : 0;
     { SgrProfScope _p(SGR_K_RANGES, stream);
     hipLaunchKernelGGL(tile_ranges_kernel, dim3((n + kThreads - 1) / kThreads), dim3(kThreads), 0, stream, kin, n,
-                       num_rendered_dev, (uint2 *)ranges);
+                       num_rendered_dev, (uint2 *)ranges, (uint32_t *)nullptr);
     SGR_CHECK_LAUNCH("tile_ranges_kernel");
     }
     return 0;

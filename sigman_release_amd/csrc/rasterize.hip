@@ -58,7 +58,8 @@ static int forward_launches(const SgrProblem *pb, uint64_t capacity, uint64_t R,
     int32_t in_b = 0;
     if (sgr_bin(pb, rec, out_radii, rect, block_offsets, R, capacity > 0 ? num_rendered : nullptr, (uint64_t *)(binning + st->off_keys_a),
                 (uint64_t *)(binning + st->off_keys_b), (uint32_t *)(binning + st->off_vals_a), (uint32_t *)(binning + st->off_vals_b),
-                binning + st->off_sort_ws, (size_t)sgr_bin_workspace_bytes(R), (uint32_t *)(image + st->off_ranges), &in_b, stream)) return 1;
+                binning + st->off_sort_ws, (size_t)sgr_bin_workspace_bytes(R, (uint64_t)((pb->W + SGR_TILE - 1) / SGR_TILE) * ((pb->H + SGR_TILE - 1) / SGR_TILE) * pb->n_views),
+                (uint32_t *)(image + st->off_ranges), &in_b, stream)) return 1;
     st->result_in_b = in_b;
     const uint32_t *point_list = (const uint32_t *)(binning + (in_b ? st->off_vals_b : st->off_vals_a));
     const bool aux_on = st->with_aux != 0;
@@ -120,7 +121,7 @@ extern "C" int sgr_rasterize_forward(const SgrProblem *pb, uint64_t capacity, in
     st->off_keys_b = o; o = align_up(o + Rn * 8);
     st->off_vals_a = o; o = align_up(o + Rn * 4);
     st->off_vals_b = o; o = align_up(o + Rn * 4);
-    st->off_sort_ws = o; o = align_up(o + sgr_bin_workspace_bytes(R));
+    st->off_sort_ws = o; o = align_up(o + sgr_bin_workspace_bytes(R, tiles_total));
     st->binning_bytes = o;
     char *binning = alloc(user, 1, (size_t)o);
     if (!binning) { sgr_set_error("binning allocator returned NULL"); return 1; }

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, n), f"{n} declared in include/sigman_gsplat.h but not exported"
     assert _cabi.lib().sgr_abi_version() == 1
     assert _cabi.lib().sgr_preprocess_blocks_per_view(1000) == 4
-    assert _cabi.lib().sgr_bin_workspace_bytes(10_000) >= 3 * 256 * 4
+    assert _cabi.lib().sgr_bin_workspace_bytes(10_000, 1024) >= 3 * 256 * 4
 
 
 def test_binding_covers_the_header():

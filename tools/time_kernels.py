@@ -9,7 +9,7 @@ from sigman_release_amd import rasterizer as R
 ap = argparse.ArgumentParser()
 ap.add_argument("--views", type=int, default=1); ap.add_argument("--iters", type=int, default=30)
 ap.add_argument("--bwd", action="store_true"); ap.add_argument("--P", type=int, default=100000); ap.add_argument("--size", type=int, default=512)
-ap.add_argument("--layers", type=int, default=0); ap.add_argument("--fwd-mode", type=int, default=0)
+ap.add_argument("--layers", type=int, default=0); ap.add_argument("--fwd-mode", type=int, default=0); ap.add_argument("--sort-mode", type=int, default=-1)
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 g = synthetic.humanoid(a.P, 1) if not a.layers else synthetic.humanoid_layers(a.P, 4, a.layers)
@@ -21,6 +21,7 @@ st = R.BatchedRasterizationSettings(a.size, a.size, cameras.TAN_HALF_FOV, camera
 m, c, o, rgb = [t(x)[None].requires_grad_(a.bwd) for x in (g["position"], cov, g["opacity"], g["rgb"])]
 L = _cabi.lib()
 L.sgr_set_forward_mode(a.fwd_mode)
+if a.sort_mode >= 0: L.sgr_set_sort_mode(a.sort_mode)
 names = {0: "pre_fwd", 1: "scan", 2: "dup", 3: "sort", 4: "ranges", 5: "render_fwd", 6: "render_bwd", 7: "pre_bwd"}
 gc = torch.randn(len(V), 3, a.size, a.size, device=dev) / (a.size * a.size)
 def step():
