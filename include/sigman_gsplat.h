@@ -183,7 +183,8 @@ int sgr_set_forward_mode(int mode);
  * out_alpha [n_views,1,H,W], final_T f32 [n_views,H,W], n_contrib u32 [n_views,H,W].
  * Optional auxiliary outputs for the bucket-parallel backward (pass all four or none; NS = sgr_bucket_slots(R, n_views*tiles)):
  *   aux_compact  u32 [4][R][2]   per (tile, 8x8 quadrant) culled list: (record id, index in the tile list)
- *   aux_ckpt_tc  f32 [4*NS][64][4], aux_ckpt_da f32 [4*NS][64][2]   per-pixel (T,C) / (D,A) at the start of each 64-Gaussian bucket
+ *   aux_ckpt_tc  f32 [4*NS][4][64][4], aux_ckpt_da f32 [4*NS][4][64][2]   per-pixel (T,C) / (D,A) at the start of each <=64-survivor
+ *                bucket (row 0, absolute) and after its 16th/32nd/48th survivor (rows 1-3, relative to row 0)
  *   aux_desc     u32 [4*NS][2]   bucket descriptors (zeroed by this call)
  */
 int sgr_render_forward(const SgrProblem *pb, const uint32_t *ranges, const uint32_t *point_list, const float *rec,

@@ -136,8 +136,8 @@ extern "C" int sgr_rasterize_forward(const SgrProblem *pb, uint64_t capacity, in
     st->off_n_contrib = o; o = align_up(o + hw * 4);
     if (aux_on) {
         st->off_compact = o; o = align_up(o + 4 * R * 8);
-        st->off_ckpt_tc = o; o = align_up(o + 4 * NS * 64 * 16);
-        st->off_ckpt_da = o; o = align_up(o + 4 * NS * 64 * 8);
+        st->off_ckpt_tc = o; o = align_up(o + 4 * NS * 4 * 64 * 16);
+        st->off_ckpt_da = o; o = align_up(o + 4 * NS * 4 * 64 * 8);
         st->off_desc = o; o = align_up(o + 4 * NS * 8);
     }
     st->image_bytes = o;

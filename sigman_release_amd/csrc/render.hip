@@ -43,8 +43,9 @@ __device__ __forceinline__ uint32_t cull_mask(const float4 &a, const float4 &c, 
 // auxiliary forward outputs that feed the bucket-parallel backward (all optional; see sgr_render_forward)
 struct FwdAux {
     uint2 *compact;       // [4][R]  per (tile, quadrant) culled list in order: (record id, 0-based index in the tile list)
-    float4 *ckpt_tc;      // [4*NS][64]  per bucket, per pixel: T, C0, C1, C2 at the START of the bucket
-    float2 *ckpt_da;      // [4*NS][64]  D, A
+    float4 *ckpt_tc;      // [4*NS][4][64]  per bucket, per 16-survivor row, per pixel: row 0 = (T, C0, C1, C2) at the START of the bucket;
+                          //                rows 1-3 = (T, C - C_row0) at survivor 16, 32, 48 of the bucket
+    float2 *ckpt_da;      // [4*NS][4][64]  same for (D, A)
     uint2 *desc;          // [4*NS]  (global tile id, (start << 7) | count): `count` (<= 64) survivors starting at ordinal `start` of the
                           //          (tile, quadrant) list; count == 0 -> slot unused
     uint32_t R, NS;
@@ -79,6 +80,7 @@ __global__ __launch_bounds__(kBlock) void render_fwd_kernel(int W, int H, int Tx
     const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     bool done = !inside;
     float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f, D = 0.f, A = 0.f;
+    float B0 = 0.f, B1 = 0.f, B2 = 0.f, BD = 0.f, BA = 0.f;   // composited sums at the start of the current 64-survivor bucket (AUX)
     uint32_t last = 0, lastk = 0;
     uint32_t kbase = 0;                                  // survivors of this wave's quadrant in earlier batches
     const int n = (int)(range.y - range.x);
@@ -149,10 +151,12 @@ __global__ __launch_bounds__(kBlock) void render_fwd_kernel(int W, int H, int Tx
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 const uint32_t ord = kbase + g + u;                       // ordinal of this survivor in the quadrant list
-                if (AUX && (ord & 63u) == 0u && ord != 0u && g + u < cnt) {
-                    const size_t s = (slot0 + (ord >> 6)) * 64 + lane;
-                    aux.ckpt_tc[s] = make_float4(T, C0, C1, C2);
-                    aux.ckpt_da[s] = make_float2(D, A);
+                if (AUX && (ord & 15u) == 0u && ord != 0u && g + u < cnt) {
+                    const uint32_t row = (ord >> 4) & 3u;
+                    const size_t s = ((slot0 + (ord >> 6)) * 4 + row) * 64 + lane;
+                    if (row == 0u) { B0 = C0; B1 = C1; B2 = C2; BD = D; BA = A; }       // bucket start: absolute state
+                    aux.ckpt_tc[s] = row ? make_float4(T, C0 - B0, C1 - B1, C2 - B2) : make_float4(T, C0, C1, C2);
+                    aux.ckpt_da[s] = row ? make_float2(D - BD, A - BA) : make_float2(D, A);
                 }
                 const float test_T = T * (1.f - al[u]);
                 done = done | (valid[u] & (test_T < 0.0001f));            // the crossing Gaussian is NOT composited
@@ -308,6 +312,13 @@ __global__ __launch_bounds__(kSegThreads, 4) void render_fwd_seg_kernel(int W, i
         float d0 = 0.f, d1 = 0.f, d2 = 0.f, dD = 0.f, dA = 0.f;
         uint32_t contributed = 0;
         for (uint32_t s = s0; s < s1; s += 4) {
+            if (AUX && s != s0 && ((s - s0) & 15u) == 0u) {
+                // state at survivor 16 / 32 / 48 of my bucket, relative to the bucket start (the start's absolute sums are only
+                // known after the cross-wave prefix below; the backward adds the two)
+                const size_t sl = ((slot_next + wave) * 4 + ((s - s0) >> 4)) * 64 + lane;
+                aux.ckpt_tc[sl] = make_float4(T, d0, d1, d2);
+                aux.ckpt_da[sl] = make_float2(dD, dA);
+            }
             float al[4];
             float4 gb4[4], gc4[4];
             uint32_t li[4];
@@ -354,8 +365,8 @@ __global__ __launch_bounds__(kSegThreads, 4) void render_fwd_seg_kernel(int W, i
                 // only buckets in which some pixel of the quadrant composited something can receive gradient
                 if (__ballot(contributed != 0u)) {
                     if (kbase + s0 != 0u) {
-                        aux.ckpt_tc[slot * 64 + lane] = make_float4(Tin, p0, p1, p2);
-                        aux.ckpt_da[slot * 64 + lane] = make_float2(pD, pA);
+                        aux.ckpt_tc[slot * 256 + lane] = make_float4(Tin, p0, p1, p2);
+                        aux.ckpt_da[slot * 256 + lane] = make_float2(pD, pA);
                     }
                     if (lane == 0) aux.desc[slot] = make_uint2(bid, ((kbase + s0) << 7) | (s1 - s0));
                 }
@@ -551,15 +562,17 @@ __global__ __launch_bounds__(kBlock) void render_bwd_kernel(int W, int H, int Tx
 //   dL/dalpha_j = T_j q_j - (O - Pre_j - w_j q_j) / (1 - alpha_j),   O = out . g (includes the T_final*bg term),
 //   Pre_j = sum_{k<j} w_k q_k  (running), T_{j+1} = T_j (1 - alpha_j)  (bit-identical to the forward's T sequence).
 // -------------------------------------------------------------------------------------------------
-// in-place full-wave rotate: lane i+1 <- lane i, lane 0 <- lane 63 (old == src, so no zero-init / copy is generated)
-__device__ __forceinline__ float rot1(float v) {
-#ifdef SGR_DBG_NOROT
-    return v * 1.0000001f;
-#endif
-    const int i = __builtin_bit_cast(int, v);
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(i, i, SGR_DPP_WAVE_ROR1, 0xF, 0xF, false));
+// shift one lane up inside each 16-lane row; lane 0 of every row takes `feed` (DPP row_shr:1 keeps `old` where there is no source)
+__device__ __forceinline__ float row_shift_in(float v, float feed) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, feed), __builtin_bit_cast(int, v),
+                                                                 SGR_DPP_ROW_SHR(1), 0xF, 0xF, false));
 }
 
+// One wave = one bucket of <= 64 consecutive surviving Gaussians of a (tile, quadrant), run as FOUR independent 16-lane
+// pipelines: row r owns survivors 16r..16r+15 and starts from the forward's checkpoint for that row.  The quadrant's 64
+// pixel states are fed into lane 0 of every row from LDS, one per step, and move one lane up per step (DPP row_shr:1), so
+// pixel p meets the row's Gaussians in front-to-back order.  79 steps per bucket instead of the 127 a single 64-lane
+// pipeline needs (fill/drain is 15 steps instead of 63).
 template <bool HAS_DA>
 __global__ __launch_bounds__(kBlock) void render_bwd_bucket_kernel(int W, int H, int Tx, uint32_t tiles_per_view,
                                                                    const uint2 *__restrict__ ranges,
@@ -571,24 +584,29 @@ __global__ __launch_bounds__(kBlock) void render_bwd_bucket_kernel(int W, int H,
                                                                    const float *__restrict__ gC, const float *__restrict__ gD,
                                                                    const float *__restrict__ gA, FwdAux aux,
                                                                    float4 *__restrict__ part, uint8_t *__restrict__ flags) {
-    const int lane = threadIdx.x & 63;
-    const size_t slot = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    __shared__ float4 sPixA[4][64];           // per wave: (x, y, n_contrib bits, g0) of pixel p
+    __shared__ float4 sPixB[4][64];           //           (g1, g2, gD, gA)
+    __shared__ float2 sDyn[4][4][64];         // per wave, per row: (T, Rem) of pixel p at the start of the row
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const size_t slot = (size_t)blockIdx.x * 4 + wv;
     if (slot >= (size_t)4 * aux.NS) return;
     const uint2 desc_v = aux.desc[slot];
     // the descriptor is wave-uniform: move it to SGPRs so the step loop below is a scalar loop
     const uint32_t desc_y = (uint32_t)__builtin_amdgcn_readfirstlane((int)desc_v.y);
     const uint32_t bid = (uint32_t)__builtin_amdgcn_readfirstlane((int)desc_v.x);
     const uint32_t count = desc_y & 127u;
-    if (count == 0) return;                                   // unused bucket slot
+    if (count == 0) return;                                   // unused bucket slot (no block-level barrier is used below)
     const uint32_t start = desc_y >> 7;                        // ordinal of this bucket's first survivor in the quadrant list
     const uint32_t q = (uint32_t)(slot / aux.NS);
     const uint32_t view = bid / tiles_per_view, tile = bid - view * tiles_per_view;
     const uint32_t tx = tile % Tx, ty = tile / Tx;
     const uint32_t rx = ranges[bid].x;
-    // ---- my Gaussian
-    const bool has_g = (uint32_t)lane < count;
+    // ---- my Gaussian: survivor 16*row + l of the bucket
+    const int row = lane >> 4;
+    const uint32_t gi = (uint32_t)lane;                        // == 16*row + (lane & 15)
+    const bool has_g = gi < count;
     uint2 e = make_uint2(0u, 0xFFFFFFFFu);
-    if (has_g) e = aux.compact[(size_t)q * aux.R + rx + start + lane];
+    if (has_g) e = aux.compact[(size_t)q * aux.R + rx + start + gi];
     // a lane without a Gaussian gets list index 0xFFFFFFFF, which no pixel's n_contrib exceeds -> never valid
     const uint32_t gidx = e.y;
     float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra, rc = ra;
@@ -596,51 +614,76 @@ __global__ __launch_bounds__(kBlock) void render_bwd_bucket_kernel(int W, int H,
     if (has_g) { ra = rec[(size_t)e.x * 4 + 0]; rb = rec[(size_t)e.x * 4 + 1]; rc = rec[(size_t)e.x * 4 + 2]; rd = rec[(size_t)e.x * 4 + 3]; }
     const float gx = ra.x, gy = ra.y, cxx = ra.z, cxy = ra.w, cyy = rb.x, op = rb.y, gdep = rb.z, cr = rb.w, cg = rc.x, cb = rc.y;
     // conic pre-scaled into the exp2 domain: G = exp(power) = exp2(kxx dx^2 + kyy dy^2 + kxy dx dy)
-    const float kLog2e = 1.4426950408889634f;
-    const float kxx = -0.5f * kLog2e * cxx, kyy = -0.5f * kLog2e * cyy, kxy = -kLog2e * cxy;
-    // ---- the pixel that starts in my lane: p = (64 - lane) mod 64, so that wave_ror:1 brings pixel p to lane 0 at step p
-    const int p = (64 - lane) & 63;
-    const int px = (int)tx * 16 + (int)(q & 1u) * 8 + (p & 7);
-    const int py = (int)ty * 16 + (int)(q >> 1) * 8 + (p >> 3);
-    const bool inside = px < W && py < H;
-    const size_t hw = (size_t)H * W;
-    const size_t pix = (size_t)py * W + px;
-    const size_t vb = (size_t)view * hw;
-    float pxf = (float)px, pyf = (float)py;
-    float g0 = 0.f, g1 = 0.f, g2 = 0.f, gd = 0.f, ga = 0.f, Rem = 0.f, T = 1.f;
-    uint32_t last = 0;
-    if (inside) {
-        last = n_contrib[vb + pix];
-        g0 = gC[vb * 3 + pix]; g1 = gC[vb * 3 + hw + pix]; g2 = gC[vb * 3 + 2 * hw + pix];
-        // Rem = O - Pre: what is still to be composited behind the current position, dotted with the upstream gradient
-        Rem = out_color[vb * 3 + pix] * g0 + out_color[vb * 3 + hw + pix] * g1 + out_color[vb * 3 + 2 * hw + pix] * g2;
-        if (HAS_DA) {
-            if (gD) gd = gD[vb + pix];
-            if (gA) ga = gA[vb + pix];
-            Rem += out_depth[vb + pix] * gd + out_alpha[vb + pix] * ga;
+    const float kL2e = 1.4426950408889634f;
+    const float kxx = -0.5f * kL2e * cxx, kyy = -0.5f * kL2e * cyy, kxy = -kL2e * cxy;
+    // ---- pixel p = lane: static data and the four row start states go to LDS (the per-step feeders)
+    {
+        const int p = lane;
+        const int px = (int)tx * 16 + (int)(q & 1u) * 8 + (p & 7);
+        const int py = (int)ty * 16 + (int)(q >> 1) * 8 + (p >> 3);
+        const bool inside = px < W && py < H;
+        const size_t hw = (size_t)H * W;
+        const size_t pix = (size_t)py * W + px;
+        const size_t vb = (size_t)view * hw;
+        float g0 = 0.f, g1 = 0.f, g2 = 0.f, gd = 0.f, ga = 0.f, O = 0.f;
+        uint32_t last = 0;
+        if (inside) {
+            last = n_contrib[vb + pix];
+            g0 = gC[vb * 3 + pix]; g1 = gC[vb * 3 + hw + pix]; g2 = gC[vb * 3 + 2 * hw + pix];
+            // O = out . g: everything the pixel composited (incl. the T_final*bg term), dotted with the upstream gradient
+            O = out_color[vb * 3 + pix] * g0 + out_color[vb * 3 + hw + pix] * g1 + out_color[vb * 3 + 2 * hw + pix] * g2;
+            if (HAS_DA) {
+                if (gD) gd = gD[vb + pix];
+                if (gA) ga = gA[vb + pix];
+                O += out_depth[vb + pix] * gd + out_alpha[vb + pix] * ga;
+            }
         }
-        if (start) {
-            const float4 tc = aux.ckpt_tc[slot * 64 + p];
-            T = tc.x;
-            Rem -= tc.y * g0 + tc.z * g1 + tc.w * g2;
-            if (HAS_DA) { const float2 da = aux.ckpt_da[slot * 64 + p]; Rem -= da.x * gd + da.y * ga; }
+        sPixA[wv][p] = make_float4((float)px, (float)py, __uint_as_float(last), g0);
+        sPixB[wv][p] = make_float4(g1, g2, gd, ga);
+        float T0 = 1.f, Pre0 = 0.f;
+        if (inside && start) {
+            const float4 tc = aux.ckpt_tc[slot * 256 + p];
+            T0 = tc.x;
+            Pre0 = tc.y * g0 + tc.z * g1 + tc.w * g2;
+            if (HAS_DA) { const float2 da = aux.ckpt_da[slot * 256 + p]; Pre0 += da.x * gd + da.y * ga; }
+        }
+        sDyn[wv][0][p] = make_float2(T0, O - Pre0);
+#pragma unroll
+        for (int r = 1; r < 4; r++) {
+            float Tr = 1.f, Prer = Pre0;
+            if (inside && (uint32_t)(16 * r) < count) {
+                const float4 tc = aux.ckpt_tc[(slot * 4 + r) * 64 + p];
+                Tr = tc.x;
+                Prer += tc.y * g0 + tc.z * g1 + tc.w * g2;
+                if (HAS_DA) { const float2 da = aux.ckpt_da[(slot * 4 + r) * 64 + p]; Prer += da.x * gd + da.y * ga; }
+            }
+            sDyn[wv][r][p] = make_float2(Tr, O - Prer);
         }
     }
-    float lastf = __uint_as_float(last);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // ---- per-lane state of the pixel currently in this lane (n_contrib = 0 marks "no pixel here")
+    float pxf = 0.f, pyf = 0.f, lastf = 0.f, g0 = 0.f, g1 = 0.f, g2 = 0.f, gd = 0.f, ga = 0.f, Rem = 0.f, T = 1.f;
     // per-Gaussian moment accumulators of v = G * dL/dalpha over the pixels (constant factors applied once at the end)
     float S1 = 0.f, Sx = 0.f, Sy = 0.f, Sxx = 0.f, Sxy = 0.f, Syy = 0.f, aD = 0.f, a7 = 0.f, a8 = 0.f, a9 = 0.f;
-#ifdef SGR_DBG_NOSTEPS
-    const int nsteps = 1;
-#else
-    const int nsteps = 63 + (int)count;
-#endif
+    const int nsteps = 64 + (int)min(count, 16u) - 1;
     for (int s = 0; s < nsteps; s++) {
-        const uint32_t dlt = (uint32_t)(s - lane);              // pixel (s - lane) is in my lane iff 0 <= s - lane < 64
+        // ---- feed pixel s into lane 0 of every row, everything else moves one lane up
+        const int sp = min(s, 63);
+        float4 fa = sPixA[wv][sp];
+        const float4 fb = sPixB[wv][sp];
+        const float2 fd = sDyn[wv][row][sp];
+        if (s >= 64) fa.z = 0.f;                               // drain: n_contrib = 0 -> never valid
+        pxf = row_shift_in(pxf, fa.x); pyf = row_shift_in(pyf, fa.y); lastf = row_shift_in(lastf, fa.z);
+        g0 = row_shift_in(g0, fa.w); g1 = row_shift_in(g1, fb.x); g2 = row_shift_in(g2, fb.y);
+        if (HAS_DA) { gd = row_shift_in(gd, fb.z); ga = row_shift_in(ga, fb.w); }
+        T = row_shift_in(T, fd.x); Rem = row_shift_in(Rem, fd.y);
         const float dx = gx - pxf, dy = gy - pyf;
         const float p2 = (kxx * dx) * dx + ((kyy * dy) * dy + (kxy * dx) * dy);
         const float G = __builtin_amdgcn_exp2f(p2);
         const float alpha = fminf(0.99f, op * G);
-        const bool valid = dlt < 64u && gidx < __float_as_uint(lastf) && p2 <= 0.f && alpha >= (1.0f / 255.0f);
+        const bool valid = gidx < __float_as_uint(lastf) && p2 <= 0.f && alpha >= (1.0f / 255.0f);
         if (valid) {
             const float w = alpha * T;
             float qj = cr * g0 + cg * g1 + cb * g2;
@@ -656,11 +699,6 @@ __global__ __launch_bounds__(kBlock) void render_bwd_bucket_kernel(int W, int H,
             if (HAS_DA) aD = fmaf(w, gd, aD);
             a7 = fmaf(w, g0, a7); a8 = fmaf(w, g1, a8); a9 = fmaf(w, g2, a9);
         }
-        // ---- systolic shift: every pixel state moves one lane up (lane 63 wraps to lane 0, masked out by `dlt`)
-        pxf = rot1(pxf); pyf = rot1(pyf); lastf = rot1(lastf);
-        g0 = rot1(g0); g1 = rot1(g1); g2 = rot1(g2);
-        Rem = rot1(Rem); T = rot1(T);
-        if (HAS_DA) { gd = rot1(gd); ga = rot1(ga); }
     }
     if (has_g) {
         // one NON-atomic 40-byte partial record per (tile instance, quadrant); preprocess_bwd gathers them in a fixed order
