@@ -308,6 +308,8 @@ __global__ __launch_bounds__(1024) void scan_block_sums_kernel(const uint32_t *_
 // -------------------------------------------------------------------------------------------------
 // B2 + B3: one thread per (subject, Gaussian); loops over the subject's views in order.
 // -------------------------------------------------------------------------------------------------
+// SH=false (the reference's colors_precomp path) compiles without the spherical-harmonics tables: no scratch, half the VGPRs
+template <bool SH>
 __global__ __launch_bounds__(kPreThreads) void preprocess_bwd_kernel(SgrProblem pb, const int32_t *__restrict__ radii,
                                                                      const uint8_t *__restrict__ clamped,
                                                                      const float4 *__restrict__ grec,
@@ -332,9 +334,9 @@ __global__ __launch_bounds__(kPreThreads) void preprocess_bwd_kernel(SgrProblem 
     float c6[6];
     load_cov3d(pb, sp, c6);
     float gmean[3] = {0.f, 0.f, 0.f}, gcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, gop = 0.f, gcol[3] = {0.f, 0.f, 0.f};
-    const int nsh = pb.shs ? pb.M : 0;
+    const int nsh = SH ? pb.M : 0;
     // SH gradients are accumulated straight into global memory across the view loop (same thread, fixed order)
-    if (pb.shs) {
+    if (SH) {
         float *gsh = dL_dsh + sp * (size_t)pb.M * 3;
         for (int k = 0; k < nsh * 3; k++) gsh[k] = 0.f;
     }
@@ -423,7 +425,7 @@ __global__ __launch_bounds__(kPreThreads) void preprocess_bwd_kernel(SgrProblem 
         const float gdep = g1.z;
         gm[0] += V[2] * gdep; gm[1] += V[6] * gdep; gm[2] += V[10] * gdep;
         const float gc3[3] = {g1.w, g2.x, g2.y};
-        if (pb.shs) {
+        if constexpr (SH) {
             const float *cp = pb.campos + 3 * (size_t)view;
             const float d[3] = {p[0] - cp[0], p[1] - cp[1], p[2] - cp[2]};
             const float len = sqrtf((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]);
@@ -458,7 +460,7 @@ __global__ __launch_bounds__(kPreThreads) void preprocess_bwd_kernel(SgrProblem 
 #pragma unroll
     for (int k = 0; k < 6; k++) dL_dcov3D[sp * 6 + k] = gcov[k];
     dL_dopacity[sp] = gop;
-    if (!pb.shs) {
+    if (!SH) {
 #pragma unroll
         for (int k = 0; k < 3; k++) dL_dcolors[sp * 3 + k] = gcol[k];
     }
@@ -582,8 +584,12 @@ extern "C" int sgr_preprocess_backward(const SgrProblem *pb, const int32_t *radi
     const int nbx = sgr_preprocess_blocks_per_view(pb->P);
     dim3 grid(nbx, pb->n_views / pb->views_per_subject);
     { SgrProfScope _p(SGR_K_PREPROCESS_BWD, stream);
-    hipLaunchKernelGGL(preprocess_bwd_kernel, grid, dim3(kPreThreads), 0, stream, *pb, radii, clamped, (const float4 *)grec,
-                       (const float4 *)rec, (const float4 *)part, flags, dL_dmeans3D, dL_dmeans2D, dL_dopacity, dL_dcolors, dL_dsh, dL_dcov3D, dL_dscales, dL_drotations);
+    if (pb->shs)
+        hipLaunchKernelGGL(preprocess_bwd_kernel<true>, grid, dim3(kPreThreads), 0, stream, *pb, radii, clamped, (const float4 *)grec,
+                           (const float4 *)rec, (const float4 *)part, flags, dL_dmeans3D, dL_dmeans2D, dL_dopacity, dL_dcolors, dL_dsh, dL_dcov3D, dL_dscales, dL_drotations);
+    else
+        hipLaunchKernelGGL(preprocess_bwd_kernel<false>, grid, dim3(kPreThreads), 0, stream, *pb, radii, clamped, (const float4 *)grec,
+                           (const float4 *)rec, (const float4 *)part, flags, dL_dmeans3D, dL_dmeans2D, dL_dopacity, dL_dcolors, dL_dsh, dL_dcov3D, dL_dscales, dL_drotations);
     SGR_CHECK_LAUNCH("preprocess_bwd_kernel");
     }
     return 0;

@@ -3,9 +3,9 @@
 The reference is subject-parallel DDP only (configs/training.yaml): every rank renders its own
 B*V views serially (gs.py:62,75).  Views are independent units, so this module shards the V views of
 a subject one-view-per-GPU and adds exactly the exchange steps that sharding needs:
-  1. broadcast of the packed Gaussian attributes [P,13] (mean 3 | cov3D 6 | opacity 1 | rgb 3) from the producer rank
+  1. broadcast of the packed Gaussian attributes, one flat [13*P] buffer (means | cov3D | opacity | rgb), from the producer rank
   2. all-reduce(sum) of the image-space loss scalar(s)       (the collective BASELINE.json's north_star names)
-  3. all-reduce(sum) of the packed attribute gradients [P,13] (needed for training parity: only then is the
+  3. all-reduce(sum) of the packed attribute gradients [13*P] (needed for training parity: only then is the
      gradient, not just the loss value, global)
 xGMI is point-to-point (7 links x ~153 GB/s); 5.2 MB at P=1e5 is latency-bound (~60 us ring time), so the payload is
 kept as ONE contiguous tensor = one collective each way.
@@ -28,36 +28,39 @@ def shard_views(n_views: int, rank: int, world: int) -> list[int]:
 
 
 def pack_attributes(means3D, cov3D, opacity, rgb) -> torch.Tensor:
+    """One flat buffer [13*P] in struct-of-arrays order (means | cov3D | opacity | rgb): ONE collective moves everything and
+    every attribute is a contiguous view of it (no unpack copies on the receiving ranks)."""
     P = means3D.shape[0]
-    return torch.cat([means3D.reshape(P, 3), cov3D.reshape(P, 6), opacity.reshape(P, 1), rgb.reshape(P, 3)], 1).contiguous()
+    return torch.cat([means3D.reshape(P * 3), cov3D.reshape(P * 6), opacity.reshape(P), rgb.reshape(P * 3)]).contiguous()
 
 
 def unpack_attributes(packed: torch.Tensor):
-    return packed[:, 0:3], packed[:, 3:9], packed[:, 9:10], packed[:, 10:13]
+    P = packed.numel() // ATTR
+    return (packed[: 3 * P].view(P, 3), packed[3 * P: 9 * P].view(P, 6), packed[9 * P: 10 * P].view(P, 1),
+            packed[10 * P:].view(P, 3))
 
 
 def view_parallel_step(packed: torch.Tensor, view_ids: Sequence[int], render_loss: Callable, *, src: int = 0, group=None,
                        broadcast: bool = True):
     """One fwd+bwd step of a subject whose views are sharded over the ranks of `group`.
 
-    packed      [P,13] attributes; only rank `src` needs valid contents when broadcast=True
+    packed      flat [13*P] attributes (pack_attributes); only rank `src` needs valid contents when broadcast=True
     view_ids    all views of the subject (same list on every rank)
     render_loss (means3D, cov3D, opacity, rgb, my_view_ids) -> scalar loss SUM over my views (differentiable)
-    returns     (global loss = sum over all views, global gradient [P,13])
+    returns     (global loss = sum over all views, global gradient, flat [13*P] in the same layout)
     """
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     if world > 1 and broadcast:
         dist.broadcast(packed, src=src, group=group)
-    P = packed.shape[0]
-    # separate contiguous leaves (slicing one packed leaf would make autograd materialise 4 zero-padded [P,13] tensors)
-    leaves = [x.detach().contiguous().clone().requires_grad_(True) for x in unpack_attributes(packed)]
+    # the four attributes are contiguous views of the flat buffer: separate autograd leaves without any copy
+    leaves = [x.detach().requires_grad_(True) for x in unpack_attributes(packed)]
     mine = [view_ids[i] for i in shard_views(len(view_ids), rank, world)]
     if mine:
         loss = render_loss(*leaves, mine)
         loss.backward()
         loss_val = loss.detach().reshape(1).clone()
-        grad = torch.cat([l.grad.reshape(P, -1) if l.grad is not None else torch.zeros_like(l).reshape(P, -1) for l in leaves], 1)
+        grad = torch.cat([(l.grad if l.grad is not None else torch.zeros_like(l)).reshape(-1) for l in leaves])
     else:
         loss_val = torch.zeros(1, device=packed.device, dtype=packed.dtype)
         grad = torch.zeros_like(packed)

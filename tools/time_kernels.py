@@ -9,16 +9,16 @@ from sigman_release_amd import rasterizer as R
 ap = argparse.ArgumentParser()
 ap.add_argument("--views", type=int, default=1); ap.add_argument("--iters", type=int, default=30)
 ap.add_argument("--bwd", action="store_true"); ap.add_argument("--P", type=int, default=100000); ap.add_argument("--size", type=int, default=512)
-ap.add_argument("--layers", type=int, default=0); ap.add_argument("--fwd-mode", type=int, default=0); ap.add_argument("--sort-mode", type=int, default=-1)
+ap.add_argument("--layers", type=int, default=0); ap.add_argument("--subjects", type=int, default=1); ap.add_argument("--fwd-mode", type=int, default=0); ap.add_argument("--sort-mode", type=int, default=-1)
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 g = synthetic.humanoid(a.P, 1) if not a.layers else synthetic.humanoid_layers(a.P, 4, a.layers)
 cov = synthetic.covariance_from_gaussians(g)
 t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
-V = [(30, 37, 45, 53, 65, 85, 0, 8)[i % 8] for i in range(a.views)]
+V = [(30, 37, 45, 53, 65, 85, 0, 8)[i % 8] for i in range(a.views)] * a.subjects
 cv, cvp, cp = cameras.make_cameras(V)
-st = R.BatchedRasterizationSettings(a.size, a.size, cameras.TAN_HALF_FOV, cameras.TAN_HALF_FOV, torch.ones(3, device=dev), 1.0, t(cv), t(cvp), 0, t(cp), len(V))
-m, c, o, rgb = [t(x)[None].requires_grad_(a.bwd) for x in (g["position"], cov, g["opacity"], g["rgb"])]
+st = R.BatchedRasterizationSettings(a.size, a.size, cameras.TAN_HALF_FOV, cameras.TAN_HALF_FOV, torch.ones(3, device=dev), 1.0, t(cv), t(cvp), 0, t(cp), a.views)
+m, c, o, rgb = [t(x)[None].repeat(a.subjects, *([1] * x.ndim)).contiguous().requires_grad_(a.bwd) for x in (g["position"], cov, g["opacity"], g["rgb"])]
 L = _cabi.lib()
 L.sgr_set_forward_mode(a.fwd_mode)
 if a.sort_mode >= 0: L.sgr_set_sort_mode(a.sort_mode)
