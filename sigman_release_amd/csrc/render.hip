@@ -663,43 +663,55 @@ __global__ __launch_bounds__(kBlock) void render_bwd_bucket_kernel(int W, int H,
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // ---- per-lane state of the pixel currently in this lane (n_contrib = 0 marks "no pixel here")
-    float pxf = 0.f, pyf = 0.f, lastf = 0.f, g0 = 0.f, g1 = 0.f, g2 = 0.f, gd = 0.f, ga = 0.f, Rem = 0.f, T = 1.f;
+    // ---- per-lane state of the pixel currently in this lane (n_contrib = 0 marks "no pixel here"), kept in TWO register sets
+    // that alternate roles every step: a DPP shift-in writes its result over the freshly loaded feed, so with a single set the
+    // compiler has to copy every state register once per step.
+    struct PixState { float px, py, last, g0, g1, g2, gd, ga, T, Rem; };
+    PixState A = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 1.f, 0.f}, B = A;
     // per-Gaussian moment accumulators of v = G * dL/dalpha over the pixels (constant factors applied once at the end)
     float S1 = 0.f, Sx = 0.f, Sy = 0.f, Sxx = 0.f, Sxy = 0.f, Syy = 0.f, aD = 0.f, a7 = 0.f, a8 = 0.f, a9 = 0.f;
     const int nsteps = 64 + (int)min(count, 16u) - 1;
-    for (int s = 0; s < nsteps; s++) {
-        // ---- feed pixel s into lane 0 of every row, everything else moves one lane up
-        const int sp = min(s, 63);
-        float4 fa = sPixA[wv][sp];
-        const float4 fb = sPixB[wv][sp];
-        const float2 fd = sDyn[wv][row][sp];
-        if (s >= 64) fa.z = 0.f;                               // drain: n_contrib = 0 -> never valid
-        pxf = row_shift_in(pxf, fa.x); pyf = row_shift_in(pyf, fa.y); lastf = row_shift_in(lastf, fa.z);
-        g0 = row_shift_in(g0, fa.w); g1 = row_shift_in(g1, fb.x); g2 = row_shift_in(g2, fb.y);
-        if (HAS_DA) { gd = row_shift_in(gd, fb.z); ga = row_shift_in(ga, fb.w); }
-        T = row_shift_in(T, fd.x); Rem = row_shift_in(Rem, fd.y);
-        const float dx = gx - pxf, dy = gy - pyf;
-        const float p2 = (kxx * dx) * dx + ((kyy * dy) * dy + (kxy * dx) * dy);
-        const float G = __builtin_amdgcn_exp2f(p2);
-        const float alpha = fminf(0.99f, op * G);
-        const bool valid = gidx < __float_as_uint(lastf) && p2 <= 0.f && alpha >= (1.0f / 255.0f);
-        if (valid) {
-            const float w = alpha * T;
-            float qj = cr * g0 + cg * g1 + cb * g2;
-            if (HAS_DA) qj += gdep * gd + ga;
-            const float oma = 1.f - alpha;
-            Rem -= w * qj;
-            const float dL_dalpha = T * qj - Rem * __builtin_amdgcn_rcpf(oma);
-            T *= oma;
-            const float v = G * dL_dalpha;                    // upstream differentiates through op*G even when alpha is capped
-            const float vx = v * dx, vy = v * dy;
-            S1 += v; Sx += vx; Sy += vy;
-            Sxx = fmaf(vx, dx, Sxx); Sxy = fmaf(vx, dy, Sxy); Syy = fmaf(vy, dy, Syy);
-            if (HAS_DA) aD = fmaf(w, gd, aD);
-            a7 = fmaf(w, g0, a7); a8 = fmaf(w, g1, a8); a9 = fmaf(w, g2, a9);
-        }
+    const float4 *pa = &sPixA[wv][0], *pb = &sPixB[wv][0];
+    const float2 *pd = &sDyn[wv][row][0];
+#define SGR_BWD_STEP(IN, OUT, S)                                                                                        \
+    {                                                                                                                   \
+        const int sp = min((S), 63);                                                                                    \
+        float4 fa = pa[sp];                                                                                             \
+        const float4 fb = pb[sp];                                                                                       \
+        const float2 fd = pd[sp];                                                                                       \
+        if ((S) >= 64) fa.z = 0.f; /* drain: n_contrib = 0 -> never valid */                                           \
+        OUT.px = row_shift_in(IN.px, fa.x); OUT.py = row_shift_in(IN.py, fa.y); OUT.last = row_shift_in(IN.last, fa.z); \
+        OUT.g0 = row_shift_in(IN.g0, fa.w); OUT.g1 = row_shift_in(IN.g1, fb.x); OUT.g2 = row_shift_in(IN.g2, fb.y);     \
+        if (HAS_DA) { OUT.gd = row_shift_in(IN.gd, fb.z); OUT.ga = row_shift_in(IN.ga, fb.w); }                         \
+        OUT.T = row_shift_in(IN.T, fd.x); OUT.Rem = row_shift_in(IN.Rem, fd.y);                                         \
+        const float dx = gx - OUT.px, dy = gy - OUT.py;                                                                 \
+        const float p2 = (kxx * dx) * dx + ((kyy * dy) * dy + (kxy * dx) * dy);                                         \
+        const float G = __builtin_amdgcn_exp2f(p2);                                                                     \
+        const float alpha = fminf(0.99f, op * G);                                                                       \
+        const bool valid = gidx < __float_as_uint(OUT.last) && p2 <= 0.f && alpha >= (1.0f / 255.0f);                   \
+        if (valid) {                                                                                                    \
+            const float w = alpha * OUT.T;                                                                              \
+            float qj = cr * OUT.g0 + cg * OUT.g1 + cb * OUT.g2;                                                         \
+            if (HAS_DA) qj += gdep * OUT.gd + OUT.ga;                                                                   \
+            const float oma = 1.f - alpha;                                                                              \
+            OUT.Rem -= w * qj;                                                                                          \
+            const float dL_dalpha = OUT.T * qj - OUT.Rem * __builtin_amdgcn_rcpf(oma);                                  \
+            OUT.T *= oma;                                                                                               \
+            const float v = G * dL_dalpha; /* upstream differentiates through op*G even when alpha is capped */         \
+            const float vx = v * dx, vy = v * dy;                                                                       \
+            S1 += v; Sx += vx; Sy += vy;                                                                                \
+            Sxx = fmaf(vx, dx, Sxx); Sxy = fmaf(vx, dy, Sxy); Syy = fmaf(vy, dy, Syy);                                  \
+            if (HAS_DA) aD = fmaf(w, OUT.gd, aD);                                                                       \
+            a7 = fmaf(w, OUT.g0, a7); a8 = fmaf(w, OUT.g1, a8); a9 = fmaf(w, OUT.g2, a9);                               \
+        }                                                                                                               \
     }
+    int s = 0;
+    for (; s + 1 < nsteps; s += 2) {
+        SGR_BWD_STEP(A, B, s)
+        SGR_BWD_STEP(B, A, s + 1)
+    }
+    if (s < nsteps) SGR_BWD_STEP(A, B, s)
+#undef SGR_BWD_STEP
     if (has_g) {
         // one NON-atomic 40-byte partial record per (tile instance, quadrant); preprocess_bwd gathers them in a fixed order
         const uint32_t off = __float_as_uint(rd.x), rmin = __float_as_uint(rd.y), rmax = __float_as_uint(rd.z);
