@@ -186,6 +186,8 @@ def _backward_impl(ctx: _Ctx, means3D, opacities, colors_precomp, shs, cov3D_pre
     dev = means3D.device
     f32 = torch.float32
     pb = _make_problem(means3D, opacities, colors_precomp, shs, cov3D_precomp, scales, rotations, st)
+    if grad_color is None:
+        grad_color = torch.zeros(nv, 3, H, W, dtype=f32, device=dev)
     gC = _f32c(grad_color)
     gD = None if grad_depth is None else _f32c(grad_depth)
     gA = None if grad_alpha is None else _f32c(grad_alpha)
@@ -219,6 +221,9 @@ def _fwd_common(ctx, means3D, sh, colors_precomp, opacities, scales, rotations, 
                                                   st, need_ctx=True)
     ctx.sgr = c
     ctx.st = st
+    # unused outputs (depth / alpha on the reference path, gs.py:99,107-109) then arrive as None in backward instead of as
+    # materialised zero tensors: no fill kernels, and the backward kernel variant without the depth/alpha channels runs
+    ctx.set_materialize_grads(False)
     ctx.has = (sh is not None, colors_precomp is not None, scales is not None, cov3Ds_precomp is not None)
     # the outputs go through save_for_backward (a plain attribute would create a ctx -> output -> grad_fn -> ctx cycle and keep
     # every step's buffers alive until the garbage collector runs)
@@ -284,7 +289,7 @@ class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_color, grad_radii, grad_depth, grad_alpha):
         ub = lambda t: None if t is None else t.unsqueeze(0)
-        g = _bwd_common(ctx, grad_color.unsqueeze(0), ub(grad_depth), ub(grad_alpha))
+        g = _bwd_common(ctx, ub(grad_color), ub(grad_depth), ub(grad_alpha))
         return tuple(None if x is None else x[0] for x in g) + (None,)
 
 
