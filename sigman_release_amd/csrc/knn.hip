@@ -34,6 +34,7 @@ __device__ __forceinline__ int f2ord(float f) { int i = __float_as_int(f); retur
 __device__ __forceinline__ float ord2f(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7FFFFFFF); }
 
 __global__ __launch_bounds__(kT) void bbox_kernel(int P, const float *__restrict__ pts, int *__restrict__ bb /*[6] min xyz, max xyz (ordered ints)*/) {
+    __shared__ float red[4][6];
     float mn[3] = {3.0e38f, 3.0e38f, 3.0e38f}, mx[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
     for (int i = blockIdx.x * kT + threadIdx.x; i < P; i += gridDim.x * kT)
 #pragma unroll
@@ -43,9 +44,17 @@ __global__ __launch_bounds__(kT) void bbox_kernel(int P, const float *__restrict
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) { mn[k] = fminf(mn[k], __shfl_xor(mn[k], off, 64)); mx[k] = fmaxf(mx[k], __shfl_xor(mx[k], off, 64)); }
     }
+    const int wave = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) {
 #pragma unroll
-        for (int k = 0; k < 3; k++) { atomicMin(&bb[k], f2ord(mn[k])); atomicMax(&bb[3 + k], f2ord(mx[k])); }
+        for (int k = 0; k < 3; k++) { red[wave][k] = mn[k]; red[wave][3 + k] = mx[k]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {                                   // one atomic per block and component (the grid is at most 64 blocks)
+        const int k = threadIdx.x;
+        const float a = red[0][k], b = red[1][k], c = red[2][k], d = red[3][k];
+        if (k < 3) atomicMin(&bb[k], f2ord(fminf(fminf(a, b), fminf(c, d))));
+        else atomicMax(&bb[k], f2ord(fmaxf(fmaxf(a, b), fmaxf(c, d))));
     }
 }
 
@@ -55,9 +64,11 @@ __global__ void grid_setup_kernel(int P, const int *__restrict__ bb, int max_cel
     if (threadIdx.x || blockIdx.x) return;
     float mn[3], ex[3];
     for (int k = 0; k < 3; k++) { mn[k] = ord2f(bb[k]); ex[k] = fmaxf(ord2f(bb[3 + k]) - mn[k], 1e-6f); }
-    // surface-like clouds leave most cells empty; aim at ~2 points per cell of the bounding volume
+    // ~2 points per cell if the cloud fills its bounding volume, ~8 per occupied cell if it is a surface (the reference's
+    // inputs are points on the SMPL-X surface): take the finer of the two estimates
     float vol = ex[0] * ex[1] * ex[2];
-    float cell = cbrtf(vol * 2.0f / (float)max(P, 1));
+    const float area = 2.f * (ex[0] * ex[1] + ex[1] * ex[2] + ex[0] * ex[2]);
+    float cell = fminf(cbrtf(vol * 2.0f / (float)max(P, 1)), sqrtf(area * 2.0f / (float)max(P, 1)));
     const float longest = fmaxf(ex[0], fmaxf(ex[1], ex[2]));
     cell = fmaxf(cell, longest / 1024.f);
     for (int it = 0; it < 64; it++) {
@@ -82,34 +93,65 @@ __global__ __launch_bounds__(kT) void cell_count_kernel(int P, const float *__re
     atomicAdd(&cell_cnt[c], 1u);
 }
 
-// exclusive scan over the cells (single workgroup, coalesced 4096-entry tiles); cell_start[ncell] = P
-__global__ __launch_bounds__(1024) void cell_scan_kernel(const Grid *__restrict__ gp, uint32_t *__restrict__ data) {
-    __shared__ uint32_t wave_tot[16];
-    __shared__ uint32_t carry_s;
+// exclusive scan over the cells in three parallel steps (a fine grid has ~1e6 cells: one workgroup walking them serially
+// was the single most expensive kernel of the 3-NN): per-4096-cell block sums, scan of the <= 512 sums, local rescan + offset.
+// After it cell_start[c] = first slot of cell c and cell_start[ncell] = P.
+constexpr int kScanTile = 4096;
+
+__global__ __launch_bounds__(kT) void cell_blocksum_kernel(const Grid *__restrict__ gp, const uint32_t *__restrict__ data,
+                                                           uint32_t *__restrict__ bsum) {
+    __shared__ uint32_t red[4];
     const uint32_t n = (uint32_t)(gp->gx * gp->gy * gp->gz) + 1u;
-    const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    if (t == 0) carry_s = 0;
+    const uint32_t base = blockIdx.x * kScanTile;
+    if (base >= n) return;
+    uint32_t s = 0;
+#pragma unroll
+    for (int k = 0; k < kScanTile / kT; k++) { const uint32_t i = base + k * kT + threadIdx.x; if (i < n) s += data[i]; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    for (uint32_t base = 0; base < n; base += 4096) {
-        const uint32_t idx = base + t * 4;
-        uint32_t v[4];
+    if (threadIdx.x == 0) bsum[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(1024) void cell_scan_sums_kernel(const Grid *__restrict__ gp, uint32_t *__restrict__ bsum) {
+    __shared__ uint32_t wave_tot[16];
+    const uint32_t n = (uint32_t)(gp->gx * gp->gy * gp->gz) + 1u;
+    const uint32_t nb = (n + kScanTile - 1) / kScanTile;          // <= 1024 by construction (max_cells <= 2^22)
+    const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const uint32_t v = t < nb ? bsum[t] : 0u;
+    uint32_t inc = v;
 #pragma unroll
-        for (int k = 0; k < 4; k++) v[k] = (idx + k < n) ? data[idx + k] : 0u;
-        const uint32_t s = v[0] + v[1] + v[2] + v[3];
-        uint32_t inc = s;
+    for (int off = 1; off < 64; off <<= 1) { const uint32_t x = __shfl_up(inc, off, 64); if (lane >= (uint32_t)off) inc += x; }
+    if (lane == 63) wave_tot[wave] = inc;
+    __syncthreads();
+    uint32_t pre = inc - v;
+    for (uint32_t w = 0; w < wave; w++) pre += wave_tot[w];
+    if (t < nb) bsum[t] = pre;
+}
+
+__global__ __launch_bounds__(kT) void cell_scan_kernel(const Grid *__restrict__ gp, uint32_t *__restrict__ data,
+                                                       const uint32_t *__restrict__ bsum) {
+    __shared__ uint32_t wave_tot[4];
+    const uint32_t n = (uint32_t)(gp->gx * gp->gy * gp->gz) + 1u;
+    const uint32_t base = blockIdx.x * kScanTile;
+    if (base >= n) return;
+    const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    constexpr int PER = kScanTile / kT;                           // 16 consecutive cells per thread
+    const uint32_t i0 = base + t * PER;
+    uint32_t v[PER];
+    uint32_t s = 0;
 #pragma unroll
-        for (int off = 1; off < 64; off <<= 1) { const uint32_t nb = __shfl_up(inc, off, 64); if (lane >= (uint32_t)off) inc += nb; }
-        if (lane == 63) wave_tot[wave] = inc;
-        __syncthreads();
-        uint32_t pre = carry_s;
-        for (uint32_t w = 0; w < wave; w++) pre += wave_tot[w];
-        uint32_t e = pre + inc - s;
+    for (int k = 0; k < PER; k++) { v[k] = (i0 + k < n) ? data[i0 + k] : 0u; s += v[k]; }
+    uint32_t inc = s;
 #pragma unroll
-        for (int k = 0; k < 4; k++) { if (idx + k < n) data[idx + k] = e; e += v[k]; }
-        __syncthreads();
-        if (t == 1023) carry_s = pre + inc;
-        __syncthreads();
-    }
+    for (int off = 1; off < 64; off <<= 1) { const uint32_t x = __shfl_up(inc, off, 64); if (lane >= (uint32_t)off) inc += x; }
+    if (lane == 63) wave_tot[wave] = inc;
+    __syncthreads();
+    uint32_t e = bsum[blockIdx.x] + inc - s;
+    for (uint32_t w = 0; w < wave; w++) e += wave_tot[w];
+#pragma unroll
+    for (int k = 0; k < PER; k++) { if (i0 + k < n) data[i0 + k] = e; e += v[k]; }
 }
 
 __global__ __launch_bounds__(kT) void cell_scatter_kernel(int P, const float *__restrict__ pts, const uint32_t *__restrict__ pt_cell,
@@ -139,29 +181,40 @@ __global__ __launch_bounds__(kT) void knn3_kernel(int P, const Grid *__restrict_
     cell_of(g, me.x, me.y, me.z, cx, cy, cz);
     float b0 = 3.0e38f, b1 = 3.0e38f, b2 = 3.0e38f;
     const int rmax = max(g.gx, max(g.gy, g.gz));
-    for (int r = 0; r <= rmax; r++) {
-        // shell of Chebyshev radius r around (cx,cy,cz)
+    // Growing cubes of Chebyshev radius r = 1, 2, ... around the point's cell.  Cells are stored x-fastest, so a whole x-row of
+    // the cube is ONE contiguous run of `sorted` (2 boundary loads, then a streaming loop); rows that were already covered by
+    // the previous cube only contribute their two new end cells.
+    for (int r = 1; r <= rmax; r++) {
         const int z0 = max(0, cz - r), z1 = min(g.gz - 1, cz + r);
         const int y0 = max(0, cy - r), y1 = min(g.gy - 1, cy + r);
-        const int x0 = max(0, cx - r), x1 = min(g.gx - 1, cx + r);
+        const int xa = max(0, cx - r), xb = min(g.gx - 1, cx + r);
         for (int z = z0; z <= z1; z++)
             for (int y = y0; y <= y1; y++) {
-                const bool face = (abs(z - cz) == r) || (abs(y - cy) == r);
-                // face rows of the shell: every x; interior rows: only the two x end caps (if inside the grid)
-                const int xa = face ? x0 : cx - r, xb = face ? x1 : cx + r, xs = face ? 1 : max(1, 2 * r);
-                for (int x = xa; x <= xb; x += xs) {
-                    if (x < 0 || x >= g.gx) continue;
-                    const int c = (z * g.gy + y) * g.gx + x;
-                    const uint32_t lo = cell_start[c], hi = cell_start[c + 1];
+                const int row = (z * g.gy + y) * g.gx;
+                const bool inner = r > 1 && abs(y - cy) < r && abs(z - cz) < r;
+                if (!inner) {
+                    const uint32_t lo = cell_start[row + xa], hi = cell_start[row + xb + 1];
                     for (uint32_t k = lo; k < hi; k++) {
                         if ((int)k == s) continue;
                         const float4 o = sorted[k];
                         const float dx = o.x - me.x, dy = o.y - me.y, dz = o.z - me.z;
                         push3(dx * dx + dy * dy + dz * dz, b0, b1, b2);
                     }
+                } else {
+#pragma unroll
+                    for (int side = 0; side < 2; side++) {
+                        const int x = side ? cx + r : cx - r;
+                        if (x < 0 || x >= g.gx) continue;
+                        const uint32_t lo = cell_start[row + x], hi = cell_start[row + x + 1];
+                        for (uint32_t k = lo; k < hi; k++) {
+                            const float4 o = sorted[k];
+                            const float dx = o.x - me.x, dy = o.y - me.y, dz = o.z - me.z;
+                            push3(dx * dx + dy * dy + dz * dz, b0, b1, b2);
+                        }
+                    }
                 }
             }
-        const float safe = (float)r * g.cell * 0.9999f;                      // every unsearched point is at least this far away
+        const float safe = (float)r * g.cell * 0.9999f;            // every unsearched point is at least this far away
         if (b2 <= safe * safe) break;
     }
     // fewer than 4 points in total: missing neighbours count as distance 0 (upstream initialises its best[] to FLT_MAX
@@ -232,7 +285,7 @@ __global__ __launch_bounds__(kT) void cov3d_bwd_kernel(int n, const float *__res
 
 extern "C" size_t sgr_knn_workspace_bytes(int32_t P, int32_t max_cells) {
     // [bbox 8 u32][Grid 16 u32][cell_cnt/start max_cells+1][cell_fill max_cells][pt_cell P][sorted P float4]
-    return (size_t)(8 + 16 + (size_t)max_cells + 1 + (size_t)max_cells + (size_t)P) * 4 + (size_t)P * 16 + 64;
+    return (size_t)(8 + 16 + 1024 + (size_t)max_cells + 1 + (size_t)max_cells + (size_t)P) * 4 + (size_t)P * 16 + 64;
 }
 
 extern "C" int sgr_knn_dist2(int32_t P, const float *points, float *out_dist2, void *workspace, size_t workspace_bytes,
@@ -240,12 +293,14 @@ extern "C" int sgr_knn_dist2(int32_t P, const float *points, float *out_dist2, v
     if (P <= 0) return 0;
     if (!points || !out_dist2 || !workspace) { sgr_set_error("sgr_knn_dist2: NULL pointer"); return 1; }
     if (max_cells < 1) max_cells = 1;
+    if (max_cells > (1 << 22) - 1) max_cells = (1 << 22) - 1;        // the block-sum scan handles up to 1024 tiles of 4096 cells
     if (workspace_bytes < sgr_knn_workspace_bytes(P, max_cells)) { sgr_set_error("sgr_knn_dist2: workspace too small"); return 1; }
     hipStream_t stream = (hipStream_t)stream_;
     uint32_t *w = (uint32_t *)workspace;
     int *bb = (int *)w;
     Grid *grid = (Grid *)(w + 8);
-    uint32_t *cell_start = w + 24;
+    uint32_t *bsum = w + 24;
+    uint32_t *cell_start = w + 24 + 1024;
     uint32_t *cell_fill = cell_start + (size_t)max_cells + 1;
     uint32_t *pt_cell = cell_fill + max_cells;
     float4 *sorted = (float4 *)(((uintptr_t)(pt_cell + P) + 15) & ~(uintptr_t)15);
@@ -255,10 +310,13 @@ extern "C" int sgr_knn_dist2(int32_t P, const float *points, float *out_dist2, v
     SGR_CHECK_HIP(hipMemcpyAsync(bb, init, sizeof(init), hipMemcpyHostToDevice, stream));
     SGR_CHECK_HIP(hipMemsetAsync(cell_start, 0, ((size_t)2 * max_cells + 1) * sizeof(uint32_t), stream));
     const int nb = (P + kT - 1) / kT;
-    hipLaunchKernelGGL(bbox_kernel, dim3(min(nb, 1024)), dim3(kT), 0, stream, P, points, bb);
+    hipLaunchKernelGGL(bbox_kernel, dim3(min(nb, 64)), dim3(kT), 0, stream, P, points, bb);
     hipLaunchKernelGGL(grid_setup_kernel, dim3(1), dim3(64), 0, stream, P, bb, max_cells, grid);
     hipLaunchKernelGGL(cell_count_kernel, dim3(nb), dim3(kT), 0, stream, P, points, grid, cell_start, pt_cell);
-    hipLaunchKernelGGL(cell_scan_kernel, dim3(1), dim3(1024), 0, stream, grid, cell_start);
+    const int scan_blocks = (max_cells + 1 + kScanTile - 1) / kScanTile;
+    hipLaunchKernelGGL(cell_blocksum_kernel, dim3(scan_blocks), dim3(kT), 0, stream, grid, cell_start, bsum);
+    hipLaunchKernelGGL(cell_scan_sums_kernel, dim3(1), dim3(1024), 0, stream, grid, bsum);
+    hipLaunchKernelGGL(cell_scan_kernel, dim3(scan_blocks), dim3(kT), 0, stream, grid, cell_start, bsum);
     hipLaunchKernelGGL(cell_scatter_kernel, dim3(nb), dim3(kT), 0, stream, P, points, pt_cell, cell_start, cell_fill, sorted);
     hipLaunchKernelGGL(knn3_kernel, dim3(nb), dim3(kT), 0, stream, P, grid, cell_start, sorted, out_dist2);
     SGR_CHECK_LAUNCH("knn kernels");
