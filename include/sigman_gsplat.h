@@ -230,6 +230,10 @@ int sgr_preprocess_backward(const SgrProblem *pb, const int32_t *radii, const ui
 size_t sgr_knn_workspace_bytes(int32_t P, int32_t max_cells);
 int sgr_knn_dist2(int32_t P, const float *points, float *out_dist2, void *workspace, size_t workspace_bytes,
                   int32_t max_cells, void *stream);
+/* the same for n_sets point sets [n_sets,P,3] -> [n_sets,P] in one launch sequence (the B subjects of a step, gs.py:62);
+ * workspace: n_sets * round_up(sgr_knn_workspace_bytes(P, max_cells), 256) bytes */
+int sgr_knn_dist2_batched(int32_t n_sets, int32_t P, const float *points, float *out_dist2, void *workspace,
+                          size_t workspace_bytes, int32_t max_cells, void *stream);
 
 /*
  * Fused covariance build (gs.py:71-73 + get_covariance/strip_lowerdiag, gs.py:17-38), n = total Gaussians:

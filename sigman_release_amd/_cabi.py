@@ -62,6 +62,7 @@ _SIGNATURES = {
     "sgr_mark_visible": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sgr_knn_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
     "sgr_knn_dist2": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int32, C.c_void_p]),
+    "sgr_knn_dist2_batched": (C.c_int, [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int32, C.c_void_p]),
     "sgr_cov3d_forward": (C.c_int, [C.c_int32] + [C.c_void_p] * 5),
     "sgr_cov3d_backward": (C.c_int, [C.c_int32] + [C.c_void_p] * 7),
     "sgr_clamped_l1_loss": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p,

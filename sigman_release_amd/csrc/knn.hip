@@ -29,11 +29,34 @@ __device__ __forceinline__ int cell_of(const Grid &g, float x, float y, float z,
     return (cz * g.gy + cy) * g.gx + cx;
 }
 
+// All kernels of the 3-NN run over a BATCH of point sets (blockIdx.y = set): the reference calls distCUDA2 once per subject of
+// the batch (gs.py:62,70); one launch sequence for all subjects keeps 256 CUs busy where a single 100k-point set cannot.
+struct KnnBatch {
+    int P, max_cells;
+    const float *points;      // [n_sets, P, 3]
+    float *out;               // [n_sets, P]
+    char *ws;                 // n_sets workspaces of ws_stride bytes
+    size_t ws_stride;
+};
+struct KnnSet { const float *pts; float *out; int *bb; Grid *grid; uint32_t *bsum, *cell_start, *cell_fill, *pt_cell; float4 *sorted; };
+__device__ __forceinline__ KnnSet knn_set(const KnnBatch &kb, int set) {
+    KnnSet k;
+    k.pts = kb.points + (size_t)set * kb.P * 3;
+    k.out = kb.out + (size_t)set * kb.P;
+    uint32_t *w = (uint32_t *)(kb.ws + (size_t)set * kb.ws_stride);
+    k.bb = (int *)w; k.grid = (Grid *)(w + 8); k.bsum = w + 24; k.cell_start = w + 24 + 1024;
+    k.cell_fill = k.cell_start + (size_t)kb.max_cells + 1; k.pt_cell = k.cell_fill + kb.max_cells;
+    k.sorted = (float4 *)(((uintptr_t)(k.pt_cell + kb.P) + 15) & ~(uintptr_t)15);
+    return k;
+}
+
 // bbox: per-block min/max -> atomics on ordered-int encodings
 __device__ __forceinline__ int f2ord(float f) { int i = __float_as_int(f); return i >= 0 ? i : i ^ 0x7FFFFFFF; }
 __device__ __forceinline__ float ord2f(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7FFFFFFF); }
 
-__global__ __launch_bounds__(kT) void bbox_kernel(int P, const float *__restrict__ pts, int *__restrict__ bb /*[6] min xyz, max xyz (ordered ints)*/) {
+__global__ __launch_bounds__(kT) void bbox_kernel(KnnBatch kb) {
+    const KnnSet ks = knn_set(kb, blockIdx.y);
+    const int P = kb.P; const float *pts = ks.pts; int *bb = ks.bb;
     __shared__ float red[4][6];
     float mn[3] = {3.0e38f, 3.0e38f, 3.0e38f}, mx[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
     for (int i = blockIdx.x * kT + threadIdx.x; i < P; i += gridDim.x * kT)
@@ -60,8 +83,10 @@ __global__ __launch_bounds__(kT) void bbox_kernel(int P, const float *__restrict
 
 // derive the grid from the bbox on device (no host round trip): cell = cbrt(volume * 2 / P), clamped so the
 // grid has at most max_cells cells; degenerate extents are padded.
-__global__ void grid_setup_kernel(int P, const int *__restrict__ bb, int max_cells, Grid *__restrict__ g) {
+__global__ void grid_setup_kernel(KnnBatch kb) {
     if (threadIdx.x || blockIdx.x) return;
+    const KnnSet ks = knn_set(kb, blockIdx.y);
+    const int P = kb.P, max_cells = kb.max_cells; const int *bb = ks.bb; Grid *g = ks.grid;
     float mn[3], ex[3];
     for (int k = 0; k < 3; k++) { mn[k] = ord2f(bb[k]); ex[k] = fmaxf(ord2f(bb[3 + k]) - mn[k], 1e-6f); }
     // ~2 points per cell if the cloud fills its bounding volume, ~8 per occupied cell if it is a surface (the reference's
@@ -82,8 +107,9 @@ __global__ void grid_setup_kernel(int P, const int *__restrict__ bb, int max_cel
     g->gz = max(1, (int)ceilf(ex[2] / cell + 1e-3f));
 }
 
-__global__ __launch_bounds__(kT) void cell_count_kernel(int P, const float *__restrict__ pts, const Grid *__restrict__ gp,
-                                                        uint32_t *__restrict__ cell_cnt, uint32_t *__restrict__ pt_cell) {
+__global__ __launch_bounds__(kT) void cell_count_kernel(KnnBatch kb) {
+    const KnnSet ks = knn_set(kb, blockIdx.y);
+    const int P = kb.P; const float *pts = ks.pts; const Grid *gp = ks.grid; uint32_t *cell_cnt = ks.cell_start, *pt_cell = ks.pt_cell;
     const int i = blockIdx.x * kT + threadIdx.x;
     if (i >= P) return;
     const Grid g = *gp;
@@ -98,8 +124,9 @@ __global__ __launch_bounds__(kT) void cell_count_kernel(int P, const float *__re
 // After it cell_start[c] = first slot of cell c and cell_start[ncell] = P.
 constexpr int kScanTile = 4096;
 
-__global__ __launch_bounds__(kT) void cell_blocksum_kernel(const Grid *__restrict__ gp, const uint32_t *__restrict__ data,
-                                                           uint32_t *__restrict__ bsum) {
+__global__ __launch_bounds__(kT) void cell_blocksum_kernel(KnnBatch kb) {
+    const KnnSet ks = knn_set(kb, blockIdx.y);
+    const Grid *gp = ks.grid; const uint32_t *data = ks.cell_start; uint32_t *bsum = ks.bsum;
     __shared__ uint32_t red[4];
     const uint32_t n = (uint32_t)(gp->gx * gp->gy * gp->gz) + 1u;
     const uint32_t base = blockIdx.x * kScanTile;
@@ -114,7 +141,9 @@ __global__ __launch_bounds__(kT) void cell_blocksum_kernel(const Grid *__restric
     if (threadIdx.x == 0) bsum[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 
-__global__ __launch_bounds__(1024) void cell_scan_sums_kernel(const Grid *__restrict__ gp, uint32_t *__restrict__ bsum) {
+__global__ __launch_bounds__(1024) void cell_scan_sums_kernel(KnnBatch kb) {
+    const KnnSet ks = knn_set(kb, blockIdx.y);
+    const Grid *gp = ks.grid; uint32_t *bsum = ks.bsum;
     __shared__ uint32_t wave_tot[16];
     const uint32_t n = (uint32_t)(gp->gx * gp->gy * gp->gz) + 1u;
     const uint32_t nb = (n + kScanTile - 1) / kScanTile;          // <= 1024 by construction (max_cells <= 2^22)
@@ -130,8 +159,9 @@ __global__ __launch_bounds__(1024) void cell_scan_sums_kernel(const Grid *__rest
     if (t < nb) bsum[t] = pre;
 }
 
-__global__ __launch_bounds__(kT) void cell_scan_kernel(const Grid *__restrict__ gp, uint32_t *__restrict__ data,
-                                                       const uint32_t *__restrict__ bsum) {
+__global__ __launch_bounds__(kT) void cell_scan_kernel(KnnBatch kb) {
+    const KnnSet ks = knn_set(kb, blockIdx.y);
+    const Grid *gp = ks.grid; uint32_t *data = ks.cell_start; const uint32_t *bsum = ks.bsum;
     __shared__ uint32_t wave_tot[4];
     const uint32_t n = (uint32_t)(gp->gx * gp->gy * gp->gz) + 1u;
     const uint32_t base = blockIdx.x * kScanTile;
@@ -154,9 +184,10 @@ __global__ __launch_bounds__(kT) void cell_scan_kernel(const Grid *__restrict__ 
     for (int k = 0; k < PER; k++) { if (i0 + k < n) data[i0 + k] = e; e += v[k]; }
 }
 
-__global__ __launch_bounds__(kT) void cell_scatter_kernel(int P, const float *__restrict__ pts, const uint32_t *__restrict__ pt_cell,
-                                                          const uint32_t *__restrict__ cell_start, uint32_t *__restrict__ cell_fill,
-                                                          float4 *__restrict__ sorted /* xyz + bitcast original index */) {
+__global__ __launch_bounds__(kT) void cell_scatter_kernel(KnnBatch kb) {
+    const KnnSet ks = knn_set(kb, blockIdx.y);
+    const int P = kb.P; const float *pts = ks.pts; const uint32_t *pt_cell = ks.pt_cell, *cell_start = ks.cell_start;
+    uint32_t *cell_fill = ks.cell_fill; float4 *sorted = ks.sorted;      // xyz + bitcast original index
     const int i = blockIdx.x * kT + threadIdx.x;
     if (i >= P) return;
     const uint32_t c = pt_cell[i];
@@ -171,8 +202,9 @@ __device__ __forceinline__ void push3(float d, float &b0, float &b1, float &b2) 
     }
 }
 
-__global__ __launch_bounds__(kT) void knn3_kernel(int P, const Grid *__restrict__ gp, const uint32_t *__restrict__ cell_start,
-                                                  const float4 *__restrict__ sorted, float *__restrict__ out) {
+__global__ __launch_bounds__(kT) void knn3_kernel(KnnBatch kb) {
+    const KnnSet ks = knn_set(kb, blockIdx.y);
+    const int P = kb.P; const Grid *gp = ks.grid; const uint32_t *cell_start = ks.cell_start; const float4 *sorted = ks.sorted; float *out = ks.out;
     const int s = blockIdx.x * kT + threadIdx.x;      // walk points in CELL order: neighbouring threads search the same cells
     if (s >= P) return;
     const Grid g = *gp;
@@ -288,39 +320,42 @@ extern "C" size_t sgr_knn_workspace_bytes(int32_t P, int32_t max_cells) {
     return (size_t)(8 + 16 + 1024 + (size_t)max_cells + 1 + (size_t)max_cells + (size_t)P) * 4 + (size_t)P * 16 + 64;
 }
 
-extern "C" int sgr_knn_dist2(int32_t P, const float *points, float *out_dist2, void *workspace, size_t workspace_bytes,
-                             int32_t max_cells, void *stream_) {
-    if (P <= 0) return 0;
+extern "C" int sgr_knn_dist2_batched(int32_t n_sets, int32_t P, const float *points, float *out_dist2, void *workspace,
+                                     size_t workspace_bytes, int32_t max_cells, void *stream_) {
+    if (P <= 0 || n_sets <= 0) return 0;
     if (!points || !out_dist2 || !workspace) { sgr_set_error("sgr_knn_dist2: NULL pointer"); return 1; }
     if (max_cells < 1) max_cells = 1;
     if (max_cells > (1 << 22) - 1) max_cells = (1 << 22) - 1;        // the block-sum scan handles up to 1024 tiles of 4096 cells
-    if (workspace_bytes < sgr_knn_workspace_bytes(P, max_cells)) { sgr_set_error("sgr_knn_dist2: workspace too small"); return 1; }
+    const size_t stride = (sgr_knn_workspace_bytes(P, max_cells) + 255) & ~(size_t)255;
+    if (workspace_bytes < stride * (size_t)n_sets) { sgr_set_error("sgr_knn_dist2: workspace too small"); return 1; }
     hipStream_t stream = (hipStream_t)stream_;
-    uint32_t *w = (uint32_t *)workspace;
-    int *bb = (int *)w;
-    Grid *grid = (Grid *)(w + 8);
-    uint32_t *bsum = w + 24;
-    uint32_t *cell_start = w + 24 + 1024;
-    uint32_t *cell_fill = cell_start + (size_t)max_cells + 1;
-    uint32_t *pt_cell = cell_fill + max_cells;
-    float4 *sorted = (float4 *)(((uintptr_t)(pt_cell + P) + 15) & ~(uintptr_t)15);
+    KnnBatch kb;
+    kb.P = P; kb.max_cells = max_cells; kb.points = points; kb.out = out_dist2; kb.ws = (char *)workspace; kb.ws_stride = stride;
     SgrProfScope _p(SGR_K_KNN, stream);
-    // bbox init: min = +max ordered, max = -max ordered
+    // per set: bbox init (min = +max ordered, max = -max ordered) and zeroed cell counters / fill cursors
     const int init[8] = {0x7F7FFFFF, 0x7F7FFFFF, 0x7F7FFFFF, (int)0x80800000, (int)0x80800000, (int)0x80800000, 0, 0};
-    SGR_CHECK_HIP(hipMemcpyAsync(bb, init, sizeof(init), hipMemcpyHostToDevice, stream));
-    SGR_CHECK_HIP(hipMemsetAsync(cell_start, 0, ((size_t)2 * max_cells + 1) * sizeof(uint32_t), stream));
+    for (int s = 0; s < n_sets; s++) {
+        char *w = (char *)workspace + (size_t)s * stride;
+        SGR_CHECK_HIP(hipMemcpyAsync(w, init, sizeof(init), hipMemcpyHostToDevice, stream));
+        SGR_CHECK_HIP(hipMemsetAsync(w + (24 + 1024) * 4, 0, ((size_t)2 * max_cells + 1) * sizeof(uint32_t), stream));
+    }
     const int nb = (P + kT - 1) / kT;
-    hipLaunchKernelGGL(bbox_kernel, dim3(min(nb, 64)), dim3(kT), 0, stream, P, points, bb);
-    hipLaunchKernelGGL(grid_setup_kernel, dim3(1), dim3(64), 0, stream, P, bb, max_cells, grid);
-    hipLaunchKernelGGL(cell_count_kernel, dim3(nb), dim3(kT), 0, stream, P, points, grid, cell_start, pt_cell);
     const int scan_blocks = (max_cells + 1 + kScanTile - 1) / kScanTile;
-    hipLaunchKernelGGL(cell_blocksum_kernel, dim3(scan_blocks), dim3(kT), 0, stream, grid, cell_start, bsum);
-    hipLaunchKernelGGL(cell_scan_sums_kernel, dim3(1), dim3(1024), 0, stream, grid, bsum);
-    hipLaunchKernelGGL(cell_scan_kernel, dim3(scan_blocks), dim3(kT), 0, stream, grid, cell_start, bsum);
-    hipLaunchKernelGGL(cell_scatter_kernel, dim3(nb), dim3(kT), 0, stream, P, points, pt_cell, cell_start, cell_fill, sorted);
-    hipLaunchKernelGGL(knn3_kernel, dim3(nb), dim3(kT), 0, stream, P, grid, cell_start, sorted, out_dist2);
+    hipLaunchKernelGGL(bbox_kernel, dim3(min(nb, 64), n_sets), dim3(kT), 0, stream, kb);
+    hipLaunchKernelGGL(grid_setup_kernel, dim3(1, n_sets), dim3(64), 0, stream, kb);
+    hipLaunchKernelGGL(cell_count_kernel, dim3(nb, n_sets), dim3(kT), 0, stream, kb);
+    hipLaunchKernelGGL(cell_blocksum_kernel, dim3(scan_blocks, n_sets), dim3(kT), 0, stream, kb);
+    hipLaunchKernelGGL(cell_scan_sums_kernel, dim3(1, n_sets), dim3(1024), 0, stream, kb);
+    hipLaunchKernelGGL(cell_scan_kernel, dim3(scan_blocks, n_sets), dim3(kT), 0, stream, kb);
+    hipLaunchKernelGGL(cell_scatter_kernel, dim3(nb, n_sets), dim3(kT), 0, stream, kb);
+    hipLaunchKernelGGL(knn3_kernel, dim3(nb, n_sets), dim3(kT), 0, stream, kb);
     SGR_CHECK_LAUNCH("knn kernels");
     return 0;
+}
+
+extern "C" int sgr_knn_dist2(int32_t P, const float *points, float *out_dist2, void *workspace, size_t workspace_bytes,
+                             int32_t max_cells, void *stream_) {
+    return sgr_knn_dist2_batched(1, P, points, out_dist2, workspace, workspace_bytes, max_cells, stream_);
 }
 
 extern "C" int sgr_cov3d_forward(int32_t n, const float *scale_raw, const float *rotation, const float *dist2, float *cov6,

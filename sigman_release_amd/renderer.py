@@ -23,17 +23,19 @@ _KNN_MAX_CELLS = 1 << 21
 
 
 def dist_cuda2(points: torch.Tensor) -> torch.Tensor:
-    """Drop-in for simple_knn._C.distCUDA2: [P,3] -> [P] mean squared distance to the 3 nearest other points."""
+    """Drop-in for simple_knn._C.distCUDA2: [P,3] -> [P] mean squared distance to the 3 nearest other points.
+    Also accepts a batch [B,P,3] -> [B,P] (all point sets in one launch sequence)."""
     L = _cabi.lib()
     if points.device.type != "cuda":
         raise RuntimeError("dist_cuda2 needs a ROCm device tensor (there is no CPU fallback)")
     pts = _f32c(points.detach())
-    P = pts.shape[0]
-    out = torch.empty(P, dtype=torch.float32, device=pts.device)
-    nbytes = L.sgr_knn_workspace_bytes(P, _KNN_MAX_CELLS)
-    ws = torch.empty(nbytes, dtype=torch.uint8, device=pts.device)
-    _cabi.check(L.sgr_knn_dist2(P, _ptr(pts), _ptr(out), _ptr(ws), nbytes, _KNN_MAX_CELLS, _stream()), "sgr_knn_dist2")
-    return out
+    batched = pts.ndim == 3
+    B, P = (pts.shape[0], pts.shape[1]) if batched else (1, pts.shape[0])
+    out = torch.empty(B, P, dtype=torch.float32, device=pts.device)
+    stride = (L.sgr_knn_workspace_bytes(P, _KNN_MAX_CELLS) + 255) // 256 * 256
+    ws = torch.empty(stride * B, dtype=torch.uint8, device=pts.device)
+    _cabi.check(L.sgr_knn_dist2_batched(B, P, _ptr(pts), _ptr(out), _ptr(ws), stride * B, _KNN_MAX_CELLS, _stream()), "sgr_knn_dist2")
+    return out if batched else out[0]
 
 
 class _Cov3D(torch.autograd.Function):
@@ -77,7 +79,7 @@ class GaussianRenderer:
         position = gaussians["position"].float()
         P = position.shape[1]
         with torch.no_grad():
-            dist2 = torch.stack([dist_cuda2(position[b]) for b in range(B)], 0)          # [B,P], detached (gs.py:71)
+            dist2 = dist_cuda2(position)                                               # [B,P], detached (gs.py:70-71), one batched launch
         cov3D = covariance_from_scale_rotation(gaussians["scale"].float(), gaussians["cov3d"].float(), dist2)   # [B,P,6]
         st = BatchedRasterizationSettings(H, W, self.tan_half_fov, self.tan_half_fov,
                                           self.bg_color if bg_color is None else bg_color, scale_modifier,

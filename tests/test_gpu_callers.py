@@ -37,6 +37,20 @@ def test_dist_cuda2_exact_knn(kind, P):
     np.testing.assert_allclose(got, want, rtol=2e-5, atol=1e-12)
 
 
+def test_dist_cuda2_batched_equals_per_set():
+    """[B,P,3] in one launch sequence == B single-set calls, bit for bit (sets with very different extents)."""
+    from sigman_release_amd.renderer import dist_cuda2
+    rng = np.random.default_rng(9)
+    P = 20_000
+    sets = [synthetic.humanoid(P, 5)["position"], rng.uniform(-3, 3, size=(P, 3)).astype(np.float32),
+            (rng.normal(size=(P, 3)) * 0.01).astype(np.float32)]
+    pts = torch.from_numpy(np.stack(sets)).to(_dev())
+    got = dist_cuda2(pts)
+    assert got.shape == (3, P)
+    for b in range(3):
+        assert torch.equal(got[b], dist_cuda2(pts[b]))
+
+
 def test_covariance_build_forward_backward():
     from sigman_release_amd.renderer import covariance_from_scale_rotation
     dev = _dev()
