@@ -27,6 +27,8 @@ import os
 import sys
 import time
 
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")   # before torch/HIP initialise: see sigman_release_amd/__init__.py
+
 import numpy as np
 import torch
 import torch.distributed as dist

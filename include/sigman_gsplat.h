@@ -127,8 +127,13 @@ int sgr_rasterize_backward(const SgrProblem *pb, const SgrForwardState *state, c
                            float *dL_drotations, void *stream);
 
 /*
- * hipGraph replay of the forward launch chain (sync-free mode only): 1 = enabled (default), 0 = plain launches.
- * The chain is captured once per distinct argument set (problem + pointers) and replayed with one hipGraphLaunch.
+ * hipGraph replay of the forward launch chain (sync-free mode only).  The chain is captured once per distinct argument
+ * set (problem + pointers) and replayed with one hipGraphLaunch.
+ *   1 = auto (default): replay only if DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 is in the process environment -- ROCm 7.2's
+ *       pre-recorded graph packets fault after large host<->device copies in the same process, so that runtime feature
+ *       has to be off (set the variable before the HIP runtime initialises; the Python package does so when it is imported
+ *       before torch, bench.py and tests/conftest.py always do);
+ *   0 = plain launches;   2 = force replay (caller guarantees the runtime is safe).
  */
 int sgr_set_graphs(int enable);
 int sgr_graph_stats(uint64_t *hits, uint64_t *misses);

@@ -89,8 +89,8 @@ def lib():
             fn.argtypes = args
         if L.sgr_abi_version() != 1:
             raise RuntimeError(f"ABI version mismatch: library reports {L.sgr_abi_version()}, binding expects 1")
-        if os.environ.get("SIGMAN_GRAPHS", "1") == "0":      # e.g. for counter collection with rocprofv3 --pmc
-            L.sgr_set_graphs(0)
+        if os.environ.get("SIGMAN_GRAPHS", "1") in ("0", "2"):    # 0: plain launches (e.g. rocprofv3 --pmc runs); 2: force replay
+            L.sgr_set_graphs(int(os.environ["SIGMAN_GRAPHS"]))
         _lib = L
     return _lib
 

@@ -8,6 +8,7 @@
 // GPU needs ~0.35 ms for a 512^2 view fwd+bwd, which a Python-driven launch sequence cannot feed.
 #include <string.h>
 
+#include <cstdlib>
 #include "common.h"
 
 namespace {
@@ -34,13 +35,26 @@ constexpr int kGraphSlots = 16;
 FwdEntry g_fwd[kGraphSlots];
 int g_fwd_n = 0;
 uint64_t g_stamp = 0, g_graph_misses = 0, g_graph_hits = 0;
-int g_graphs_enabled = 1;
+int g_graphs_enabled = -1;       // -1 = not decided yet (see graphs_allowed)
 }  // namespace
 
 int sgr_prof_active();
 int sgr_get_forward_mode();
 
-extern "C" int sgr_set_graphs(int enable) { g_graphs_enabled = enable; return 0; }
+// ROCm 7.2's hipGraph "packet capture" (pre-recorded AQL packets, on by default) is not safe next to large host<->device
+// copies issued by the same process: a few replays after e.g. a 5 MB pageable D2H copy the command processor faults
+// ("write access to a read-only page", no wave involved; reproduced with tests/test_gpu_parity.py::test_graph_replay_survives_
+// host_copies).  With DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 in the environment BEFORE the HIP runtime initialises, replay is
+// stable.  So: graph replay is used only when that variable is visibly "0" (the Python package and bench.py set it before
+// importing torch), or when the caller forces it with sgr_set_graphs(2).
+static bool graphs_allowed() {
+    if (g_graphs_enabled < 0) {
+        const char *e = getenv("DEBUG_CLR_GRAPH_PACKET_CAPTURE");
+        g_graphs_enabled = (e && e[0] == '0' && e[1] == 0) ? 1 : 0;
+    }
+    return g_graphs_enabled > 0;
+}
+extern "C" int sgr_set_graphs(int enable) { g_graphs_enabled = enable == 1 ? -1 : enable; return 0; }   // 0 off, 1 auto, 2 force
 extern "C" int sgr_graph_stats(uint64_t *hits, uint64_t *misses) { if (hits) *hits = g_graph_hits; if (misses) *misses = g_graph_misses; return 0; }
 
 static int forward_launches(const SgrProblem *pb, uint64_t capacity, uint64_t R, SgrForwardState *st, float *out_color, float *out_depth,
@@ -145,7 +159,7 @@ extern "C" int sgr_rasterize_forward(const SgrProblem *pb, uint64_t capacity, in
     if (!image) { sgr_set_error("image allocator returned NULL"); return 1; }
     st->image = image;
 
-    const bool try_graph = g_graphs_enabled && capacity > 0 && pb->P > 0 && !sgr_prof_active();
+    const bool try_graph = graphs_allowed() && capacity > 0 && pb->P > 0 && !sgr_prof_active();
     if (try_graph) {
         FwdKey key;
         memset(&key, 0, sizeof(key));
@@ -175,14 +189,14 @@ extern "C" int sgr_rasterize_forward(const SgrProblem *pb, uint64_t capacity, in
                 if (g_fwd[slot].exec) { (void)hipDeviceSynchronize(); (void)hipGraphExecDestroy(g_fwd[slot].exec); }
             }
             g_fwd[slot].key = key; g_fwd[slot].exec = nullptr; g_fwd[slot].stamp = ++g_stamp;
-        } else if (g_graphs_enabled) {
+        } else if (g_graphs_enabled > 0) {
             // capture on a library-owned stream (the caller's stream may be the legacy default stream, which cannot be captured);
             // the instantiated graph is then launched into the caller's stream
             static hipStream_t cap_stream = nullptr;
             if (!cap_stream && hipStreamCreateWithFlags(&cap_stream, hipStreamNonBlocking) != hipSuccess) { cap_stream = nullptr; g_graphs_enabled = 0; }
             hipGraph_t graph = nullptr;
             hipGraphExec_t exec = nullptr;
-            if (g_graphs_enabled && hipStreamBeginCapture(cap_stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+            if (g_graphs_enabled > 0 && hipStreamBeginCapture(cap_stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
                 const int rc = forward_launches(pb, capacity, R, st, out_color, out_depth, out_alpha, out_radii, nullptr, false, cap_stream);
                 const hipError_t e1 = hipStreamEndCapture(cap_stream, &graph);
                 if (rc == 0 && e1 == hipSuccess && graph && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess) {

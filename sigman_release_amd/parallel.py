@@ -8,7 +8,8 @@ a subject one-view-per-GPU and adds exactly the exchange steps that sharding nee
   3. all-reduce(sum) of the packed attribute gradients [13*P] (needed for training parity: only then is the
      gradient, not just the loss value, global)
 xGMI is point-to-point (7 links x ~153 GB/s); 5.2 MB at P=1e5 is latency-bound (~60 us ring time), so the payload is
-kept as ONE contiguous tensor = one collective each way.
+kept as ONE contiguous tensor = one collective each way: the loss scalar rides in the last element of the gradient
+buffer ([13*P + 1]), so 2 and 3 are a single all-reduce.
 
 The render function is injected, so the sharding/collective logic is testable on CPU with gloo (tests/test_parallel.py).
 """
@@ -59,12 +60,10 @@ def view_parallel_step(packed: torch.Tensor, view_ids: Sequence[int], render_los
     if mine:
         loss = render_loss(*leaves, mine)
         loss.backward()
-        loss_val = loss.detach().reshape(1).clone()
-        grad = torch.cat([(l.grad if l.grad is not None else torch.zeros_like(l)).reshape(-1) for l in leaves])
+        buf = torch.cat([(l.grad if l.grad is not None else torch.zeros_like(l)).reshape(-1) for l in leaves]
+                        + [loss.detach().reshape(1).to(packed.dtype)])
     else:
-        loss_val = torch.zeros(1, device=packed.device, dtype=packed.dtype)
-        grad = torch.zeros_like(packed)
+        buf = torch.zeros(packed.numel() + 1, device=packed.device, dtype=packed.dtype)
     if world > 1:
-        dist.all_reduce(loss_val, op=dist.ReduceOp.SUM, group=group)
-        dist.all_reduce(grad, op=dist.ReduceOp.SUM, group=group)
-    return loss_val[0], grad
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)     # gradients [13*P] + loss scalar: one collective
+    return buf[-1], buf[:-1]

@@ -1,6 +1,8 @@
 import os
 import sys
 
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")   # before torch/HIP initialise (hipGraph replay gate, csrc/rasterize.hip)
+
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -4,6 +4,8 @@ Bars: integer artefacts (radii, tile rects, sorted keys, point lists, tile range
 1e-4 abs (north_star tolerance; observed ~1e-6); n_contrib equal except on ulp-borderline alpha tests;
 gradients within 1e-4 * max|g| per tensor (float atomics make the summation order free).
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -460,3 +462,65 @@ def test_side_stream_and_graph_replay(oracle):
     h1, m1 = C.c_uint64(0), C.c_uint64(0)
     _cabi.lib().sgr_graph_stats(C.byref(h1), C.byref(m1))
     assert h1.value > h0.value, "the launch graph was never replayed"
+
+
+_HOST_COPY_SCRIPT = r"""
+import os, sys
+os.environ["DEBUG_CLR_GRAPH_PACKET_CAPTURE"] = "0"          # what sigman_release_amd/__init__.py / bench.py / conftest.py arrange
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import ctypes as C
+import numpy as np, torch
+import cases
+from sigman_release_amd import _cabi, cameras
+from sigman_release_amd import rasterizer as R
+dev = torch.device("cuda", 0)
+inp, st = cases.humanoid(P=20000, H=256, W=256, seed=3)
+t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+d = {k: t(v)[None].requires_grad_(True) for k, v in inp.items()}
+bst = R.BatchedRasterizationSettings(st["image_height"], st["image_width"], st["tanfovx"], st["tanfovy"], t(st["bg"]), 1.0,
+                                     t(st["viewmatrix"]), t(st["projmatrix"]), 0, t(st["campos"]), 1, max_rendered=400000)
+big = torch.zeros(2_000_000, device=dev)                     # 8 MB: pageable D2H / H2D copies of this size triggered the runtime fault
+first = None
+for it in range(40):
+    for v in d.values():
+        v.grad = None
+    color, radii, depth, alpha = R.rasterize_gaussians_batched(d["means3D"], None, None, d["colors_precomp"], d["opacities"][..., None],
+                                                               None, None, d["cov3D_precomp"], bst)
+    (color * color).sum().backward()
+    g = d["means3D"].grad.clone()
+    first = g if first is None else first
+    assert torch.equal(g, first)
+    del color, radii, depth, alpha
+    if it % 5 == 4:
+        h = big.cpu(); big.copy_(h)
+    torch.cuda.synchronize()
+hits, misses = C.c_uint64(0), C.c_uint64(0)
+_cabi.lib().sgr_graph_stats(C.byref(hits), C.byref(misses))
+assert hits.value >= 15, (hits.value, misses.value)
+print("HOSTCOPY_OK", hits.value)
+"""
+
+
+def test_graph_replay_survives_host_copies():
+    """Regression: hipGraph replay next to large pageable host copies (a training loop's batch uploads / image logging).
+    With ROCm 7.2's graph packet capture left on this faulted the GPU a few replays after the copy; the library therefore
+    only replays when DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 (csrc/rasterize.hip graphs_allowed).  Runs in a subprocess so that a
+    runtime fault cannot take the test session down."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _HOST_COPY_SCRIPT, root], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "HOSTCOPY_OK" in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-1500:])
+
+
+def test_graphs_off_without_the_runtime_flag():
+    """Without DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 in the environment the library must not replay graphs (plain launches only)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = _HOST_COPY_SCRIPT.replace('os.environ["DEBUG_CLR_GRAPH_PACKET_CAPTURE"] = "0"', 'os.environ.pop("DEBUG_CLR_GRAPH_PACKET_CAPTURE", None)') \
+                              .replace("assert hits.value >= 15, (hits.value, misses.value)", "assert hits.value == 0, hits.value") \
+                              .replace("import ctypes as C\nimport numpy as np, torch", "import ctypes as C\nimport torch, numpy as np")
+    env = {k: v for k, v in os.environ.items() if k != "DEBUG_CLR_GRAPH_PACKET_CAPTURE"}
+    r = subprocess.run([sys.executable, "-c", script, root], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0 and "HOSTCOPY_OK 0" in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-1500:])
