@@ -253,10 +253,11 @@ int sgr_cov3d_backward(int32_t n, const float *scale_raw, const float *rotation,
  * Fused image-space loss epilogue (gs.py:107 clamp + whole_loss.py:126-131 masked L1), one pass:
  *   loss_per_view[v] = weight * sum_{c,p} mask * |clamp(color,0,1) - target|      (zeroed by the call)
  *   grad_color       = weight * mask * sign(clamp(color) - target) * 1[0 < color < 1]
+ *   loss_total       = sum_v loss_per_view[v]   (optional, may be NULL; zeroed by the call; saves the caller a reduction launch)
  * color/target/grad_color [n_views,3,H,W]; mask [n_views,1,H,W] or NULL.
  */
 int sgr_clamped_l1_loss(int32_t n_views, int32_t H, int32_t W, const float *color, const float *target, const float *mask,
-                        float weight, float *grad_color, float *loss_per_view, void *stream);
+                        float weight, float *grad_color, float *loss_per_view, float *loss_total, void *stream);
 
 /* ---- optional per-kernel profiler (HIP events on the launch stream; used by bench.py) -------- */
 enum {

@@ -13,7 +13,7 @@ constexpr int kT = 256;
 // grad[v,c,p] = w * mask * sign(clamp(color) - target) * 1[0 < color < 1]      (clamp kills the gradient where saturated)
 __global__ __launch_bounds__(kT) void clamped_l1_kernel(const float *__restrict__ color, const float *__restrict__ target,
                                                         const float *__restrict__ mask, float weight, int hw, int vec,
-                                                        float *__restrict__ grad, float *__restrict__ loss_view) {
+                                                        float *__restrict__ grad, float *__restrict__ loss_view, float *__restrict__ loss_total) {
     __shared__ float red[4];
     const int v = blockIdx.y;
     const size_t base = (size_t)v * 3 * hw;
@@ -57,24 +57,31 @@ __global__ __launch_bounds__(kT) void clamped_l1_kernel(const float *__restrict_
     acc = sgr_wave_sum(acc);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) sgr_atomic_add(&loss_view[v], weight * ((red[0] + red[1]) + (red[2] + red[3])));
+    if (threadIdx.x == 0) {
+        const float part = weight * ((red[0] + red[1]) + (red[2] + red[3]));
+        sgr_atomic_add(&loss_view[v], part);
+        if (loss_total) sgr_atomic_add(loss_total, part);
+    }
 }
 }  // namespace
 
 extern "C" int sgr_clamped_l1_loss(int32_t n_views, int32_t H, int32_t W, const float *color, const float *target,
-                                   const float *mask, float weight, float *grad_color, float *loss_per_view, void *stream_) {
+                                   const float *mask, float weight, float *grad_color, float *loss_per_view, float *loss_total,
+                                   void *stream_) {
     if (n_views <= 0 || H <= 0 || W <= 0) return 0;
     if (!color || !target || !grad_color || !loss_per_view) { sgr_set_error("sgr_clamped_l1_loss: NULL pointer"); return 1; }
     const int hw = H * W;
     const bool vec_ok = !((((uintptr_t)color | (uintptr_t)target | (uintptr_t)grad_color | (uintptr_t)mask) & 15) || (hw & 3));
     hipStream_t stream = (hipStream_t)stream_;
-    SGR_CHECK_HIP(hipMemsetAsync(loss_per_view, 0, sizeof(float) * n_views, stream));
+    const bool adjacent = loss_total == loss_per_view + n_views;            // the usual layout: [n_views | total], one memset
+    SGR_CHECK_HIP(hipMemsetAsync(loss_per_view, 0, sizeof(float) * (n_views + (adjacent ? 1 : 0)), stream));
+    if (loss_total && !adjacent) SGR_CHECK_HIP(hipMemsetAsync(loss_total, 0, sizeof(float), stream));
     SgrProfScope _p(SGR_K_LOSS, stream);
     const int n4 = hw >> 2;
     int bx = (n4 + kT - 1) / kT;
     bx = bx < 1 ? 1 : (bx > 256 ? 256 : bx);
     hipLaunchKernelGGL(clamped_l1_kernel, dim3(vec_ok ? bx : 1, n_views), dim3(kT), 0, stream, color, target, mask, weight, hw,
-                       vec_ok ? 1 : 0, grad_color, loss_per_view);
+                       vec_ok ? 1 : 0, grad_color, loss_per_view, loss_total);
     SGR_CHECK_LAUNCH("clamped_l1_kernel");
     return 0;
 }

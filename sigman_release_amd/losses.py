@@ -22,12 +22,13 @@ class _ClampedL1(torch.autograd.Function):
         mask = None if mask is None else _f32c(mask)
         nv, _, H, W = color.shape
         grad = torch.empty_like(color)
-        per_view = torch.empty(nv, dtype=torch.float32, device=color.device)
+        sums = torch.empty(nv + 1, dtype=torch.float32, device=color.device)      # [per-view partial sums | total]
+        p = sums.data_ptr()
         _cabi.check(L.sgr_clamped_l1_loss(nv, H, W, _ptr(color), _ptr(target), _ptr(mask), float(weight), _ptr(grad),
-                                          _ptr(per_view), _stream()), "sgr_clamped_l1_loss")
+                                          p, p + 4 * nv, _stream(color.device)), "sgr_clamped_l1_loss")
         ctx.save_for_backward(grad)
-        ctx.per_view = per_view
-        return per_view.sum()
+        ctx.per_view = sums[:nv]
+        return sums[nv]
 
     @staticmethod
     def backward(ctx, g):

@@ -65,11 +65,21 @@ def _ptr(t: Optional[torch.Tensor]):
     return None if t is None or t.numel() == 0 else t.data_ptr()
 
 
-def _stream():
-    return torch.cuda.current_stream().cuda_stream
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
+def _stream(dev: Optional[torch.device] = None):
+    """hipStream_t of PyTorch's current stream (torch.cuda.current_stream() costs ~20 us per call on the bench host; the raw
+    query costs well under 1 us)."""
+    if _raw_stream is not None:
+        idx = dev.index if dev is not None and dev.index is not None else torch.cuda.current_device()
+        return _raw_stream(idx)
+    return torch.cuda.current_stream(dev).cuda_stream
 
 
 def _f32c(t: torch.Tensor) -> torch.Tensor:
+    if t.dtype is torch.float32 and t.is_contiguous():
+        return t
     if t.dtype != torch.float32:
         t = t.float()
     return t.contiguous()
@@ -88,9 +98,12 @@ class _PinnedRing:
             self.ev = [torch.cuda.Event() for _ in range(self.n)]
             for e in self.ev:
                 e.record()                     # materialises the underlying hipEvent_t so its handle can cross the C ABI
+            self.slots = [self.buf[k] for k in range(self.n)]
+            self.ptrs = [x.data_ptr() for x in self.slots]
+            self.handles = [e.cuda_event for e in self.ev]
         k = self.i
         self.i = (self.i + 1) % self.n
-        return self.buf[k], self.ev[k]
+        return self.slots[k], self.ev[k], self.ptrs[k], self.handles[k]
 
 
 _ring = _PinnedRing()
@@ -111,7 +124,7 @@ _ALLOC = _cabi.ALLOC_FN(_alloc_cb)
 
 class _Ctx:
     """What the forward leaves behind for the backward (== upstream geomBuffer / binningBuffer / imgBuffer + num_rendered)."""
-    __slots__ = ("state", "blobs", "radii", "dims", "nr_host", "nr_event", "capacity", "true_rendered", "keep")
+    __slots__ = ("state", "blobs", "radii", "dims", "nr_host", "nr_event", "capacity", "true_rendered", "keep", "pb")
 
     def check_overflow(self):
         """Sync-free mode: raise if the forward needed more tile instances than `max_rendered` (cheap: the copy finished long ago)."""
@@ -159,14 +172,14 @@ def _forward_impl(means3D, opacities, colors_precomp, shs, cov3D_precomp, scales
     alpha = torch.empty(nv, 1, H, W, dtype=f32, device=dev)
     radii = torch.empty(nv, P, dtype=torch.int32, device=dev)
     capacity = int(getattr(st, "max_rendered", 0) or 0)
-    nr_host, nr_event = _ring.next()
+    nr_host, nr_event, nr_ptr, nr_handle = _ring.next()
     state = _cabi.SgrForwardState()
     blobs = [None, None, None, None]
     _alloc_target["dev"], _alloc_target["blobs"] = dev, blobs
     use_aux = 1 if (need_ctx and with_aux and not _USE_BWD_V1) else 0
     _cabi.check(L.sgr_rasterize_forward(C.byref(pb), capacity, use_aux, _ALLOC, None, color.data_ptr(), depth.data_ptr(),
-                                        alpha.data_ptr(), radii.data_ptr(), nr_host.data_ptr(),
-                                        nr_event.cuda_event if capacity > 0 else None, C.byref(state), _stream()),
+                                        alpha.data_ptr(), radii.data_ptr(), nr_ptr,
+                                        nr_handle if capacity > 0 else None, C.byref(state), _stream(dev)),
                 "sgr_rasterize_forward")
     ctx = None
     if need_ctx:
@@ -176,6 +189,7 @@ def _forward_impl(means3D, opacities, colors_precomp, shs, cov3D_precomp, scales
         ctx.nr_host, ctx.nr_event, ctx.capacity = nr_host, (nr_event if capacity > 0 and P > 0 else None), capacity
         ctx.true_rendered = int(state.true_rendered) if capacity == 0 else None
         ctx.keep = (st.viewmatrix, st.projmatrix, st.campos, st.bg)
+        ctx.pb = pb            # the backward sees the same tensors (saved_tensors share their storage), so the struct is reused
     return color, radii, depth, alpha, ctx
 
 
@@ -185,7 +199,9 @@ def _backward_impl(ctx: _Ctx, means3D, opacities, colors_precomp, shs, cov3D_pre
     S, P, nv, H, W = ctx.dims
     dev = means3D.device
     f32 = torch.float32
-    pb = _make_problem(means3D, opacities, colors_precomp, shs, cov3D_precomp, scales, rotations, st)
+    pb = ctx.pb
+    if pb.means3D != _ptr(means3D):      # (cannot happen through autograd; guards direct callers that pass other tensors)
+        pb = _make_problem(means3D, opacities, colors_precomp, shs, cov3D_precomp, scales, rotations, st)
     if grad_color is None:
         grad_color = torch.zeros(nv, 3, H, W, dtype=f32, device=dev)
     gC = _f32c(grad_color)
@@ -203,7 +219,7 @@ def _backward_impl(ctx: _Ctx, means3D, opacities, colors_precomp, shs, cov3D_pre
     _alloc_target["dev"], _alloc_target["blobs"] = dev, blobs
     _cabi.check(L.sgr_rasterize_backward(C.byref(pb), C.byref(ctx.state), _ptr(ctx.radii), _ptr(img[0]), _ptr(img[1]), _ptr(img[2]),
                                          _ptr(gC), _ptr(gD), _ptr(gA), _ALLOC, None, _ptr(d_means3D), _ptr(d_means2D), _ptr(d_op),
-                                         _ptr(d_col), _ptr(d_sh), _ptr(d_cov), _ptr(d_sc), _ptr(d_rot), _stream()),
+                                         _ptr(d_col), _ptr(d_sh), _ptr(d_cov), _ptr(d_sc), _ptr(d_rot), _stream(dev)),
                 "sgr_rasterize_backward")
     grec = blobs[3]
     ctx.check_overflow()        # after the backward is queued: the host never idles the GPU while it waits for the forward's counter
@@ -216,7 +232,10 @@ def _fwd_common(ctx, means3D, sh, colors_precomp, opacities, scales, rotations, 
     means3D = _f32c(means3D)
     opacities = _f32c(opacities).reshape(means3D.shape[0], means3D.shape[1])
     sh, colors_precomp, scales, rotations, cov3Ds_precomp = map(opt, (sh, colors_precomp, scales, rotations, cov3Ds_precomp))
-    st = st._replace(viewmatrix=_f32c(st.viewmatrix), projmatrix=_f32c(st.projmatrix), campos=_f32c(st.campos), bg=_f32c(st.bg))
+    f32 = torch.float32
+    if not (st.viewmatrix.dtype is f32 and st.projmatrix.dtype is f32 and st.campos.dtype is f32 and st.bg.dtype is f32
+            and st.viewmatrix.is_contiguous() and st.projmatrix.is_contiguous() and st.campos.is_contiguous() and st.bg.is_contiguous()):
+        st = st._replace(viewmatrix=_f32c(st.viewmatrix), projmatrix=_f32c(st.projmatrix), campos=_f32c(st.campos), bg=_f32c(st.bg))
     color, radii, depth, alpha, c = _forward_impl(means3D, opacities, colors_precomp, sh, cov3Ds_precomp, scales, rotations,
                                                   st, need_ctx=True)
     ctx.sgr = c
@@ -303,7 +322,7 @@ def mark_visible(positions: torch.Tensor, viewmatrix: torch.Tensor) -> torch.Ten
     positions = _f32c(positions)
     out = torch.zeros(positions.shape[0], dtype=torch.uint8, device=positions.device)
     vm = _f32c(viewmatrix)
-    _cabi.check(L.sgr_mark_visible(positions.shape[0], _ptr(positions), _ptr(vm), _ptr(out), _stream()), "sgr_mark_visible")
+    _cabi.check(L.sgr_mark_visible(positions.shape[0], _ptr(positions), _ptr(vm), _ptr(out), _stream(positions.device)), "sgr_mark_visible")
     return out.bool()
 
 

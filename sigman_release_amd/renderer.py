@@ -34,7 +34,7 @@ def dist_cuda2(points: torch.Tensor) -> torch.Tensor:
     out = torch.empty(B, P, dtype=torch.float32, device=pts.device)
     stride = (L.sgr_knn_workspace_bytes(P, _KNN_MAX_CELLS) + 255) // 256 * 256
     ws = torch.empty(stride * B, dtype=torch.uint8, device=pts.device)
-    _cabi.check(L.sgr_knn_dist2_batched(B, P, _ptr(pts), _ptr(out), _ptr(ws), stride * B, _KNN_MAX_CELLS, _stream()), "sgr_knn_dist2")
+    _cabi.check(L.sgr_knn_dist2_batched(B, P, _ptr(pts), _ptr(out), _ptr(ws), stride * B, _KNN_MAX_CELLS, _stream(pts.device)), "sgr_knn_dist2")
     return out if batched else out[0]
 
 
@@ -45,7 +45,7 @@ class _Cov3D(torch.autograd.Function):
         scale_raw, rotation, dist2 = _f32c(scale_raw), _f32c(rotation), _f32c(dist2)
         n = dist2.numel()
         cov = torch.empty(*dist2.shape, 6, dtype=torch.float32, device=dist2.device)
-        _cabi.check(L.sgr_cov3d_forward(n, _ptr(scale_raw), _ptr(rotation), _ptr(dist2), _ptr(cov), _stream()), "sgr_cov3d_forward")
+        _cabi.check(L.sgr_cov3d_forward(n, _ptr(scale_raw), _ptr(rotation), _ptr(dist2), _ptr(cov), _stream(cov.device)), "sgr_cov3d_forward")
         ctx.save_for_backward(scale_raw, rotation, dist2)
         return cov
 
@@ -56,7 +56,7 @@ class _Cov3D(torch.autograd.Function):
         g = _f32c(g)
         gs, gr = torch.empty_like(scale_raw), torch.empty_like(rotation)
         _cabi.check(L.sgr_cov3d_backward(dist2.numel(), _ptr(scale_raw), _ptr(rotation), _ptr(dist2), _ptr(g), _ptr(gs), _ptr(gr),
-                                         _stream()), "sgr_cov3d_backward")
+                                         _stream(g.device)), "sgr_cov3d_backward")
         return gs, gr, None
 
 

@@ -1,5 +1,6 @@
 """Dev tool: where does the HOST time of one fwd+bwd step go? (cProfile over N steps, sync-free mode)"""
 import cProfile, pstats, os, sys, time
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from sigman_release_amd import cameras, synthetic
