@@ -101,7 +101,7 @@ typedef struct SgrForwardState {
     uint64_t geom_bytes, binning_bytes, image_bytes;
     uint64_t off_rec, off_rect, off_clamped, off_block_offsets, off_num_rendered;               /* in geom   */
     uint64_t off_keys_a, off_keys_b, off_vals_a, off_vals_b, off_sort_ws;                        /* in binning */
-    uint64_t off_ranges, off_final_T, off_n_contrib, off_compact, off_ckpt_tc, off_ckpt_da, off_desc;   /* in image */
+    uint64_t off_ranges, off_final_T, off_n_contrib, off_compact, off_ckpt_tc, off_ckpt_da, off_desc, off_order;   /* in image */
 } SgrForwardState;
 
 /*
@@ -176,7 +176,7 @@ int sgr_bin(const SgrProblem *pb, float *rec, const int32_t *radii, const uint32
             uint32_t *vals_a, uint32_t *vals_b, void *workspace, size_t workspace_bytes, uint32_t *ranges,
             int32_t *result_in_b_host, void *stream);
 
-/* number of bucket slots per quadrant for the auxiliary forward outputs: (R >> 6) + 8*tiles_total + 1 */
+/* number of bucket slots per quadrant for the auxiliary forward outputs: (R >> 6) + tiles_total + 1 */
 uint64_t sgr_bucket_slots(uint64_t R, uint64_t tiles_total);
 
 /* forward compositing kernel choice: 0 = automatic (segment-parallel for launches of <= 2048 tiles, serial per-tile
@@ -188,13 +188,16 @@ int sgr_set_forward_mode(int mode);
  * out_alpha [n_views,1,H,W], final_T f32 [n_views,H,W], n_contrib u32 [n_views,H,W].
  * Optional auxiliary outputs for the bucket-parallel backward (pass all four or none; NS = sgr_bucket_slots(R, n_views*tiles)):
  *   aux_compact  u32 [4][R][2]   per (tile, 8x8 quadrant) culled list: (record id, index in the tile list)
- *   aux_ckpt_tc  f32 [4*NS][4][64][4], aux_ckpt_da f32 [4*NS][4][64][2]   per-pixel (T,C) / (D,A) at the start of each <=64-survivor
- *                bucket (row 0, absolute) and after its 16th/32nd/48th survivor (rows 1-3, relative to row 0)
- *   aux_desc     u32 [4*NS][2]   bucket descriptors (zeroed by this call)
+ *   aux_ckpt_tc  f32 [4*NS][4][64][4], aux_ckpt_da f32 [4*NS][4][64][2]   per-pixel (T,C) / (D,A) before each 16-survivor row of each
+ *                <=64-survivor bucket: T absolute; sums absolute on rows that start a forward segment, else relative to that row
+ *   aux_desc     u32 [4*NS][2]   bucket descriptors (tile | (rows per segment - 1) << 30, (start << 7) | count); zeroed by this call
+ * aux_order (optional, u32 [1 + n_views*tiles]) receives the work order of the segment-parallel kernel (longest tile lists
+ * first, empty tiles last); NULL = tiles in index order.
  */
 int sgr_render_forward(const SgrProblem *pb, const uint32_t *ranges, const uint32_t *point_list, const float *rec,
                        float *out_color, float *out_depth, float *out_alpha, float *final_T, uint32_t *n_contrib,
-                       uint64_t R, void *aux_compact, void *aux_ckpt_tc, void *aux_ckpt_da, void *aux_desc, void *stream);
+                       uint64_t R, void *aux_compact, void *aux_ckpt_tc, void *aux_ckpt_da, void *aux_desc, uint32_t *aux_order,
+                       void *stream);
 
 /*
  * B1: gradient records from the image gradients.  grad_depth / grad_alpha may be NULL (treated as zero).

@@ -33,7 +33,7 @@ class SgrForwardState(C.Structure):
                 ("geom_bytes", C.c_uint64), ("binning_bytes", C.c_uint64), ("image_bytes", C.c_uint64)] + \
                [(n, C.c_uint64) for n in ("off_rec", "off_rect", "off_clamped", "off_block_offsets", "off_num_rendered", "off_keys_a",
                                           "off_keys_b", "off_vals_a", "off_vals_b", "off_sort_ws", "off_ranges", "off_final_T",
-                                          "off_n_contrib", "off_compact", "off_ckpt_tc", "off_ckpt_da", "off_desc")]
+                                          "off_n_contrib", "off_compact", "off_ckpt_tc", "off_ckpt_da", "off_desc", "off_order")]
 
 
 ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_int32, C.c_size_t)
@@ -56,7 +56,7 @@ _SIGNATURES = {
     "sgr_set_graphs": (C.c_int, [C.c_int]),
     "sgr_set_sort_mode": (C.c_int, [C.c_int]),
     "sgr_graph_stats": (C.c_int, [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
-    "sgr_render_forward": (C.c_int, [C.POINTER(SgrProblem)] + [C.c_void_p] * 8 + [C.c_uint64] + [C.c_void_p] * 5),
+    "sgr_render_forward": (C.c_int, [C.POINTER(SgrProblem)] + [C.c_void_p] * 8 + [C.c_uint64] + [C.c_void_p] * 6),
     "sgr_render_backward": (C.c_int, [C.POINTER(SgrProblem)] + [C.c_void_p] * 11 + [C.c_uint64] + [C.c_void_p] * 8),
     "sgr_preprocess_backward": (C.c_int, [C.POINTER(SgrProblem)] + [C.c_void_p] * 15),
     "sgr_mark_visible": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -80,7 +80,8 @@ static int forward_launches(const SgrProblem *pb, uint64_t capacity, uint64_t R,
     return sgr_render_forward(pb, (const uint32_t *)(image + st->off_ranges), point_list, rec, out_color, out_depth, out_alpha,
                               (float *)(image + st->off_final_T), (uint32_t *)(image + st->off_n_contrib), R,
                               aux_on ? image + st->off_compact : nullptr, aux_on ? image + st->off_ckpt_tc : nullptr,
-                              aux_on ? image + st->off_ckpt_da : nullptr, aux_on ? image + st->off_desc : nullptr, stream);
+                              aux_on ? image + st->off_ckpt_da : nullptr, aux_on ? image + st->off_desc : nullptr,
+                              (uint32_t *)(image + st->off_order), stream);
 }
 
 extern "C" int sgr_rasterize_forward(const SgrProblem *pb, uint64_t capacity, int32_t with_aux, sgr_alloc_fn alloc, void *user,
@@ -148,6 +149,7 @@ extern "C" int sgr_rasterize_forward(const SgrProblem *pb, uint64_t capacity, in
     st->off_ranges = o; o = align_up(o + tiles_total * 8);
     st->off_final_T = o; o = align_up(o + hw * 4);
     st->off_n_contrib = o; o = align_up(o + hw * 4);
+    st->off_order = o; o = align_up(o + (tiles_total + 1) * 4);
     if (aux_on) {
         st->off_compact = o; o = align_up(o + 4 * R * 8);
         st->off_ckpt_tc = o; o = align_up(o + 4 * NS * 4 * 64 * 16);

@@ -46,11 +46,14 @@ __device__ __forceinline__ uint32_t cull_mask(const float4 &a, const float4 &c, 
 // auxiliary forward outputs that feed the bucket-parallel backward (all optional; see sgr_render_forward)
 struct FwdAux {
     uint2 *compact;       // [4][R]  per (tile, quadrant) culled list in order: (record id, 0-based index in the tile list)
-    float4 *ckpt_tc;      // [4*NS][4][64]  per bucket, per 16-survivor row, per pixel: row 0 = (T, C0, C1, C2) at the START of the bucket;
-                          //                rows 1-3 = (T, C - C_row0) at survivor 16, 32, 48 of the bucket
+    float4 *ckpt_tc;      // [4*NS][4][64]  per bucket, per 16-survivor row, per pixel: (T, C0, C1, C2) before the row's first survivor.
+                          //                T is absolute.  With rps = rows per forward segment (1..4, in the descriptor): rows with
+                          //                r % rps == 0 start a segment and hold ABSOLUTE composited sums, the others hold the sums
+                          //                accumulated since their segment's start (row r - r % rps).  The row at ordinal 0 of a list
+                          //                is not stored (T = 1, sums = 0).
     float2 *ckpt_da;      // [4*NS][4][64]  same for (D, A)
-    uint2 *desc;          // [4*NS]  (global tile id, (start << 7) | count): `count` (<= 64) survivors starting at ordinal `start` of the
-                          //          (tile, quadrant) list; count == 0 -> slot unused
+    uint2 *desc;          // [4*NS]  (global tile id | (rps - 1) << 30, (start << 7) | count): `count` (<= 64) survivors starting at
+                          //          ordinal `start` (a multiple of 64) of the (tile, quadrant) list; count == 0 -> slot unused
     uint32_t R, NS;
 };
 
@@ -88,7 +91,7 @@ __global__ __launch_bounds__(kBlock) void render_fwd_kernel(int W, int H, int Tx
     uint32_t kbase = 0;                                  // survivors of this wave's quadrant in earlier batches
     const int n = (int)(range.y - range.x);
     const int rounds = (n + kBlock - 1) / kBlock;
-    const size_t slot0 = (size_t)wave * aux.NS + (range.x >> 6) + (size_t)bid * 8;     // first bucket slot of (tile, quadrant)
+    const size_t slot0 = (size_t)wave * aux.NS + (range.x >> 6) + (size_t)bid;         // first bucket slot of (tile, quadrant)
     if (t == 0) { sA[kBlock] = make_float4(0.f, 0.f, 0.f, 0.f); sB[kBlock] = sA[kBlock]; sC[kBlock] = sA[kBlock]; }
     for (int r = 0; r < rounds; r++) {
         if (__syncthreads_count(done) == kBlock) break;      // also the barrier that protects LDS reuse
@@ -195,24 +198,30 @@ __global__ __launch_bounds__(kBlock) void render_fwd_kernel(int W, int H, int Tx
         for (int off = 32; off > 0; off >>= 1) kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, off, 64));
         const uint32_t nb = (kmax + 63u) >> 6;
         for (uint32_t bk = lane; bk < nb; bk += 64)
-            aux.desc[slot0 + bk] = make_uint2(bid, (bk << 13) | min(64u, kmax - (bk << 6)));
+            aux.desc[slot0 + bk] = make_uint2(bid | (3u << 30), (bk << 13) | min(64u, kmax - (bk << 6)));   // rps = 4: rows 1-3 relative to row 0
     }
 }
 
 // -------------------------------------------------------------------------------------------------
-// F6, segment-parallel variant for launches that cannot fill the chip (one 512^2 view has ~200 occupied tiles
-// for 256 CUs, and the serial walk of the longest tile list -- ~2900 entries at C2 -- is the whole critical path).
-// One workgroup = one (tile, quadrant), 8 waves.  Each 512-entry chunk of the tile list is culled and
-// compacted for this quadrant into LDS, the survivors are split into 8 contiguous segments (one per wave), and
+// F6, segment-parallel variant for launches that cannot fill the chip (one 512^2 humanoid view has ~200 occupied
+// tiles for 256 CUs, and the serial walk of the longest tile list -- ~2900 entries at C2 -- is the whole critical path).
+// One workgroup = one (tile, quadrant), 8 waves.  The tile list is streamed in 512-entry sub-chunks (software
+// pipelined: ids two sub-chunks ahead, records one ahead, both held in registers), culled for this quadrant and
+// appended to an LDS ring.  Whenever the ring holds >= 512 survivors (or the list is exhausted) one ROUND composites
+// up to 512 of them as 8 contiguous segments of 64 (one per wave):
 //   phase 1  every wave computes its segment's transmittance product per pixel (alpha only),
 //   prefix   T_in(segment) = T_carry * prod(earlier segments)       (same association in every wave),
 //   phase 2  every wave composites its segment with the published sequential rule starting from T_in.
 // Contributions are absolute (already multiplied by T), so the 8 partial sums simply add up at the end.
 // A pixel that stopped in an earlier segment has T_in < 1e-4 (T is monotone), so later segments skip it.
-// ~1.5x the arithmetic of the serial kernel, 8x shorter dependency chain.  Each segment doubles as one bucket
-// (<= 64 survivors) of the bucket-parallel backward, with its checkpoint (T_in, composited-so-far).
+// ~1.5x the arithmetic of the serial kernel, 8x shorter dependency chain.  Each segment doubles as one bucket of
+// the bucket-parallel backward with its checkpoint (T_in, composited-so-far); cutting segments at exactly 64
+// survivors (only the last one of a list is shorter) keeps all four 16-lane rows of the backward's waves busy.
 // -------------------------------------------------------------------------------------------------
-constexpr int kSegThreads = 512, kSegWaves = 8;
+constexpr int kSegThreads = 512, kSegWaves = 8, kSegRing = 1024, kSegPer = 64;
+#ifdef SGR_DBG_TIMING
+__device__ uint32_t g_dbg_timing[4 * 16384];      // per block: start, end (100 MHz ticks), list length, rounds
+#endif
 
 __device__ __forceinline__ bool cull_quadrant(const float4 &a, const float4 &c, float qx0, float qy0) {
     const float hx = c.z, hy = c.w;
@@ -227,15 +236,21 @@ __global__ __launch_bounds__(kSegThreads, 4) void render_fwd_seg_kernel(int W, i
                                                                      const float4 *__restrict__ rec, const float *__restrict__ bg,
                                                                      float *__restrict__ out_color, float *__restrict__ out_depth,
                                                                      float *__restrict__ out_alpha, float *__restrict__ final_T,
-                                                                     uint32_t *__restrict__ n_contrib, FwdAux aux) {
-    __shared__ float4 sA[kSegThreads], sB[kSegThreads], sC[kSegThreads];
-    __shared__ uint32_t sId[kSegThreads], sIdx[kSegThreads];
+                                                                     uint32_t *__restrict__ n_contrib, FwdAux aux,
+                                                                     const uint32_t *__restrict__ order) {
+    __shared__ float4 sA[kSegRing], sB[kSegRing];               // (x, y, kxx, kxy), (kyy, opacity, depth, r)
+    __shared__ float2 sC[kSegRing];                             // (g, b)
+    __shared__ uint32_t sIdx[kSegRing];                         // index in the tile list
     __shared__ float sT[kSegWaves][64];
     __shared__ float sAcc[kSegWaves][5][64];
     __shared__ float sTstop[64];
     __shared__ uint32_t sLast[kSegWaves][64];
     __shared__ uint32_t sWaveCnt[kSegWaves];
-    const uint32_t bid = blockIdx.x >> 2, q = blockIdx.x & 3u;
+    __shared__ uint32_t sContrib[kSegWaves];
+    // work order: longest lists first (fwd_prepare_kernel); the tail of the grid are the empty tiles, which only write the background
+    uint32_t bid = blockIdx.x >> 2;
+    const uint32_t q = blockIdx.x & 3u;
+    if (order) bid = order[1 + bid];
     const uint32_t view = bid / tiles_per_view, tile = bid - view * tiles_per_view;
     const uint32_t tx = tile % Tx, ty = tile / Tx;
     const uint2 range = ranges[bid];
@@ -252,49 +267,71 @@ __global__ __launch_bounds__(kSegThreads, 4) void render_fwd_seg_kernel(int W, i
     float cc0 = 0.f, cc1 = 0.f, cc2 = 0.f, ccD = 0.f, ccA = 0.f;   // composited-so-far (all waves), AUX only
     float Tstop = -1.f;
     uint32_t last = 0;
-    uint32_t kbase = 0;
-    size_t slot_next = (size_t)q * aux.NS + (range.x >> 6) + (size_t)bid * 8;
+    uint32_t kbase = 0;                                         // survivors composited in earlier rounds
+    uint32_t qhead = 0, qcount = 0;                             // LDS ring of survivors waiting to be composited
+    size_t slot_next = (size_t)q * aux.NS + (range.x >> 6) + (size_t)bid;
     if (t < 64) sTstop[t] = -1.f;
     bool pix_done = !inside;
-    for (int chunk = 0; chunk * kSegThreads < n; chunk++) {
-        if (__syncthreads_count(pix_done) == kSegThreads) break;
-        // ---- stage + cull + block-wide compaction of this chunk
-        const int idx = chunk * kSegThreads + t;
-        bool bit = false;
-        float4 a, b, c;
-        uint32_t id = 0;
-        if (idx < n) {
-            id = point_list[range.x + idx];
-            a = rec[(size_t)id * 4 + 0]; b = rec[(size_t)id * 4 + 1]; c = rec[(size_t)id * 4 + 2];
-            bit = cull_quadrant(a, c, qx0, qy0);
-        }
-        const uint64_t bal = __ballot(bit);
-        if (lane == 0) sWaveCnt[wave] = (uint32_t)__popcll(bal);
-        __syncthreads();
-        uint32_t woff = 0, m = 0;
+#ifdef SGR_DBG_TIMING
+    const uint64_t dbg_t0 = wall_clock64();
+    uint32_t dbg_rounds = 0;
+#endif
+    // ---- software pipeline of the list: records of sub-chunk `commit` and ids of sub-chunk `commit + 1` live in registers
+    int commit = 0;                                             // first list entry of the sub-chunk held in (ra, rb, rc, rid)
+    float4 ra, rb, rc;
+    uint32_t rid = 0, id_nx = 0;
+    ra = rb = rc = make_float4(0.f, 0.f, 0.f, -1.f);
+    if (t < n) {
+        rid = point_list[range.x + t];
+        ra = rec[(size_t)rid * 4 + 0]; rb = rec[(size_t)rid * 4 + 1]; rc = rec[(size_t)rid * 4 + 2];
+    }
+    if (t + kSegThreads < n) id_nx = point_list[range.x + t + kSegThreads];
+    for (;;) {
+        if (__syncthreads_count(pix_done) == kSegThreads) break;     // also: every wave is done reading the previous round's ring entries
+        // ---- fill: cull + append sub-chunks until a full round is available
+        while (qcount < (uint32_t)(kSegWaves * kSegPer) && commit < n) {
+            const int idx = commit + t;
+            const bool bit = (idx < n) && cull_quadrant(ra, rc, qx0, qy0);
+            const uint64_t bal = __ballot(bit);
+            if (lane == 0) sWaveCnt[wave] = (uint32_t)__popcll(bal);
+            __syncthreads();
+            uint32_t woff = 0, m = 0;
 #pragma unroll
-        for (int w = 0; w < kSegWaves; w++) { const uint32_t cw = sWaveCnt[w]; if (w < wave) woff += cw; m += cw; }
-        if (bit) {
-            const uint32_t s = woff + (uint32_t)__popcll(bal & lt_mask);
-            sA[s] = make_float4(a.x, a.y, kHalfLog2e * a.z, kLog2e * a.w);
-            sB[s] = make_float4(kHalfLog2e * b.x, b.y, b.z, b.w);
-            sC[s] = c; sId[s] = id; sIdx[s] = (uint32_t)idx;
+            for (int w = 0; w < kSegWaves; w++) { const uint32_t cw = sWaveCnt[w]; if (w < wave) woff += cw; m += cw; }
+            if (bit) {
+                const uint32_t ord = qcount + woff + (uint32_t)__popcll(bal & lt_mask);     // position behind the ring head
+                const uint32_t s = (qhead + ord) & (kSegRing - 1);
+                sA[s] = make_float4(ra.x, ra.y, kHalfLog2e * ra.z, kLog2e * ra.w);
+                sB[s] = make_float4(kHalfLog2e * rb.x, rb.y, rb.z, rb.w);
+                sC[s] = make_float2(rc.x, rc.y); sIdx[s] = (uint32_t)idx;
+                if (AUX) aux.compact[(size_t)q * aux.R + range.x + kbase + ord] = make_uint2(rid, (uint32_t)idx);
+            }
+            qcount += m;
+            commit += kSegThreads;
+            // advance the pipeline: records of the next sub-chunk (its ids arrived a stage ago), ids of the one after
+            const int nidx = commit + t;
+            if (nidx < n) {
+                rid = id_nx;
+                ra = rec[(size_t)rid * 4 + 0]; rb = rec[(size_t)rid * 4 + 1]; rc = rec[(size_t)rid * 4 + 2];
+            }
+            if (nidx + kSegThreads < n) id_nx = point_list[range.x + nidx + kSegThreads];
+            __syncthreads();                                     // ring entries visible; sWaveCnt reusable
         }
-        __syncthreads();
-        if (m == 0) continue;
-        if (AUX) {
-            uint2 *dst = aux.compact + (size_t)q * aux.R + range.x + kbase;
-            if ((uint32_t)t < m) dst[t] = make_uint2(sId[t], sIdx[t]);
-        }
-        const uint32_t per = (m + kSegWaves - 1) / kSegWaves;          // <= 64 survivors per wave
+        if (qcount == 0) break;
+        // one round: m survivors in up to 8 segments of 16, 32 or 64 (1, 2 or 4 backward rows; segments never straddle a
+        // 64-survivor bucket).  Only the last round of a list is shorter than 512, and then spreads over all waves.
+        const uint32_t m = min(qcount, (uint32_t)(kSegWaves * kSegPer));
+        const uint32_t per = m <= 128u ? 16u : (m <= 256u ? 32u : 64u);
         const uint32_t s0 = min(m, (uint32_t)wave * per), s1 = min(m, s0 + per);
+        const uint32_t brow0 = (s0 & 63u) >> 4;                     // my segment's first row inside its 64-survivor bucket
+#define SGR_RING(S) ((qhead + (S)) & (kSegRing - 1))
         // ---- phase 1: transmittance product of my segment
         float Tseg = 1.f;
         for (uint32_t s = s0; s < s1; s += 4) {
             float om[4];
 #pragma unroll
             for (int u = 0; u < 4; u++) {
-                const uint32_t su = min(s + u, s1 - 1);
+                const uint32_t su = SGR_RING(min(s + u, s1 - 1));
                 const float4 ga = sA[su], gb = sB[su];
                 const float dx = ga.x - pxf, dy = ga.y - pyf;
                 const float power = (ga.z * dx) * dx + ((gb.x * dy) * dy + (ga.w * dx) * dy);
@@ -317,20 +354,21 @@ __global__ __launch_bounds__(kSegThreads, 4) void render_fwd_seg_kernel(int W, i
         uint32_t contributed = 0;
         for (uint32_t s = s0; s < s1; s += 4) {
             if (AUX && s != s0 && ((s - s0) & 15u) == 0u) {
-                // state at survivor 16 / 32 / 48 of my bucket, relative to the bucket start (the start's absolute sums are only
+                // state at survivor 16 / 32 / 48 of my segment, relative to the segment start (the start's absolute sums are only
                 // known after the cross-wave prefix below; the backward adds the two)
-                const size_t sl = ((slot_next + wave) * 4 + ((s - s0) >> 4)) * 64 + lane;
+                const size_t sl = ((slot_next + (s0 >> 6)) * 4 + brow0 + ((s - s0) >> 4)) * 64 + lane;
                 aux.ckpt_tc[sl] = make_float4(T, d0, d1, d2);
                 aux.ckpt_da[sl] = make_float2(dD, dA);
             }
             float al[4];
-            float4 gb4[4], gc4[4];
+            float4 gb4[4];
+            float2 gc2[4];
             uint32_t li[4];
 #pragma unroll
             for (int u = 0; u < 4; u++) {
-                const uint32_t su = min(s + u, s1 - 1);
+                const uint32_t su = SGR_RING(min(s + u, s1 - 1));
                 const float4 ga = sA[su];
-                gb4[u] = sB[su]; gc4[u] = sC[su]; li[u] = sIdx[su] + 1u;
+                gb4[u] = sB[su]; gc2[u] = sC[su]; li[u] = sIdx[su] + 1u;
                 const float dx = ga.x - pxf, dy = ga.y - pyf;
                 const float power = (ga.z * dx) * dx + ((gb4[u].x * dy) * dy + (ga.w * dx) * dy);
                 const float alpha = fminf(0.99f, gb4[u].y * __builtin_amdgcn_exp2f(power));
@@ -343,7 +381,7 @@ __global__ __launch_bounds__(kSegThreads, 4) void render_fwd_seg_kernel(int W, i
                 done = done | (test_T < 0.0001f);                 // the crossing Gaussian is NOT composited
                 const bool contrib = (al[u] > 0.f) & !done;
                 const float w = contrib ? al[u] * T : 0.f;
-                d0 = fmaf(gb4[u].w, w, d0); d1 = fmaf(gc4[u].x, w, d1); d2 = fmaf(gc4[u].y, w, d2);
+                d0 = fmaf(gb4[u].w, w, d0); d1 = fmaf(gc2[u].x, w, d1); d2 = fmaf(gc2[u].y, w, d2);
                 dD = fmaf(gb4[u].z, w, dD);
                 dA += w;
                 T = contrib ? test_T : T;
@@ -351,10 +389,13 @@ __global__ __launch_bounds__(kSegThreads, 4) void render_fwd_seg_kernel(int W, i
                 contributed |= contrib ? 1u : 0u;
             }
         }
+#undef SGR_RING
         if (done && !done_at_start) Tstop = T;                   // I am the segment in which this pixel stopped
         C0 += d0; C1 += d1; C2 += d2; D += dD; A += dA;
         if (AUX) {
             sAcc[wave][0][lane] = d0; sAcc[wave][1][lane] = d1; sAcc[wave][2][lane] = d2; sAcc[wave][3][lane] = dD; sAcc[wave][4][lane] = dA;
+            const uint64_t any_contrib = __ballot(contributed != 0u);
+            if (lane == 0) sContrib[wave] = any_contrib ? 1u : 0u;
             __syncthreads();
             float p0 = cc0, p1 = cc1, p2 = cc2, pD = ccD, pA = ccA;
 #pragma unroll
@@ -363,21 +404,29 @@ __global__ __launch_bounds__(kSegThreads, 4) void render_fwd_seg_kernel(int W, i
                 if (w < wave) { p0 += e0; p1 += e1; p2 += e2; pD += e3; pA += e4; }
                 cc0 += e0; cc1 += e1; cc2 += e2; ccD += e3; ccA += e4;
             }
-            const uint32_t nseg = (m + per - 1) / per;
-            if ((uint32_t)wave < nseg) {
-                const size_t slot = slot_next + wave;
+            if (s0 < m) {
                 // only buckets in which some pixel of the quadrant composited something can receive gradient
-                if (__ballot(contributed != 0u)) {
+                uint32_t live = 0;                                    // any segment of my bucket (1, 2 or 4 waves share one)
+#pragma unroll
+                for (int w = 0; w < kSegWaves; w++) if ((((uint32_t)w * per) >> 6) == (s0 >> 6)) live |= sContrib[w];
+                if (live) {
+                    const size_t slot = slot_next + (s0 >> 6);
                     if (kbase + s0 != 0u) {
-                        aux.ckpt_tc[slot * 256 + lane] = make_float4(Tin, p0, p1, p2);
-                        aux.ckpt_da[slot * 256 + lane] = make_float2(pD, pA);
+                        aux.ckpt_tc[(slot * 4 + brow0) * 64 + lane] = make_float4(Tin, p0, p1, p2);
+                        aux.ckpt_da[(slot * 4 + brow0) * 64 + lane] = make_float2(pD, pA);
                     }
-                    if (lane == 0) aux.desc[slot] = make_uint2(bid, ((kbase + s0) << 7) | (s1 - s0));
+                    if (lane == 0 && (s0 & 63u) == 0u)
+                        aux.desc[slot] = make_uint2(bid | (((per >> 4) - 1u) << 30), ((kbase + s0) << 7) | min(64u, m - s0));
                 }
             }
-            slot_next += nseg;
+            slot_next += (m + 63u) >> 6;
         }
+#ifdef SGR_DBG_TIMING
+        dbg_rounds++;
+#endif
         kbase += m;
+        qhead = (qhead + m) & (kSegRing - 1);
+        qcount -= m;
         Tcarry = Tall;
         pix_done = !inside | (Tcarry < 0.0001f);
     }
@@ -407,6 +456,45 @@ __global__ __launch_bounds__(kSegThreads, 4) void render_fwd_seg_kernel(int W, i
         out_color[(vb * 3) + 2 * hw + pix] = r2 + Tf * bg[2];
         out_depth[vb + pix] = rD;
         out_alpha[vb + pix] = rA;
+    }
+#ifdef SGR_DBG_TIMING
+    if (t == 0 && blockIdx.x < 16384) {
+        g_dbg_timing[4 * blockIdx.x + 0] = (uint32_t)dbg_t0; g_dbg_timing[4 * blockIdx.x + 1] = (uint32_t)wall_clock64();
+        g_dbg_timing[4 * blockIdx.x + 2] = (uint32_t)n; g_dbg_timing[4 * blockIdx.x + 3] = dbg_rounds | (kbase << 8);
+    }
+#endif
+}
+
+// -------------------------------------------------------------------------------------------------
+// Work order for the segment-parallel forward (one workgroup): occupied tiles, longest lists first, so that the tiles on the
+// critical path start at t = 0 and the tail of the launch is made of short ones (the unordered launch started the heaviest
+// C2 tiles 35 us late behind 3000 empty workgroups).  32 length classes (n >> 7), order inside a class is arbitrary -- it only
+// affects scheduling, never results.  Also clears the bucket descriptors (replaces a memset launch).
+// order[0] = number of tiles, order[1..] = tile ids, longest list first, empty tiles last.
+// -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void fwd_prepare_kernel(const uint2 *__restrict__ ranges, uint32_t tiles_total, uint2 *__restrict__ desc,
+                                                           size_t n_desc, uint32_t *__restrict__ order) {
+    __shared__ uint32_t sHist[33], sCur[33];
+    const uint32_t t = threadIdx.x;
+    if (desc) for (size_t i = t; i < n_desc; i += 1024) desc[i] = make_uint2(0u, 0u);
+    if (!order) return;
+    if (t < 33) sHist[t] = 0;
+    __syncthreads();
+    // class 0 = longest lists ... class 31 = 1..127 entries, class 32 = empty tiles (they still have to write the background)
+    for (uint32_t tile = t; tile < tiles_total; tile += 1024) {
+        const uint2 r = ranges[tile];
+        atomicAdd(&sHist[r.y > r.x ? 31u - min(31u, (r.y - r.x) >> 7) : 32u], 1u);
+    }
+    __syncthreads();
+    if (t == 0) {
+        uint32_t run = 0;
+        for (int c = 0; c < 33; c++) { sCur[c] = run; run += sHist[c]; }
+        order[0] = run;                                          // == tiles_total
+    }
+    __syncthreads();
+    for (uint32_t tile = t; tile < tiles_total; tile += 1024) {
+        const uint2 r = ranges[tile];
+        order[1u + atomicAdd(&sCur[r.y > r.x ? 31u - min(31u, (r.y - r.x) >> 7) : 32u], 1u)] = tile;
     }
 }
 
@@ -597,7 +685,9 @@ __global__ __launch_bounds__(kBlock) void render_bwd_bucket_kernel(int W, int H,
     const uint2 desc_v = aux.desc[slot];
     // the descriptor is wave-uniform: move it to SGPRs so the step loop below is a scalar loop
     const uint32_t desc_y = (uint32_t)__builtin_amdgcn_readfirstlane((int)desc_v.y);
-    const uint32_t bid = (uint32_t)__builtin_amdgcn_readfirstlane((int)desc_v.x);
+    const uint32_t desc_x = (uint32_t)__builtin_amdgcn_readfirstlane((int)desc_v.x);
+    const uint32_t bid = desc_x & 0x3FFFFFFFu;
+    const uint32_t rps = (desc_x >> 30) + 1u;                  // rows per forward segment: rows with r % rps == 0 hold absolute sums
     const uint32_t count = desc_y & 127u;
     if (count == 0) return;                                   // unused bucket slot (no block-level barrier is used below)
     const uint32_t start = desc_y >> 7;                        // ordinal of this bucket's first survivor in the quadrant list
@@ -652,14 +742,17 @@ __global__ __launch_bounds__(kBlock) void render_bwd_bucket_kernel(int W, int H,
             if (HAS_DA) { const float2 da = aux.ckpt_da[slot * 256 + p]; Pre0 += da.x * gd + da.y * ga; }
         }
         sDyn[wv][0][p] = make_float2(T0, O - Pre0);
+        float PreSeg = Pre0;                                   // composited-so-far at the start of the forward segment the row is in
 #pragma unroll
         for (int r = 1; r < 4; r++) {
             float Tr = 1.f, Prer = Pre0;
             if (inside && (uint32_t)(16 * r) < count) {
                 const float4 tc = aux.ckpt_tc[(slot * 4 + r) * 64 + p];
                 Tr = tc.x;
-                Prer += tc.y * g0 + tc.z * g1 + tc.w * g2;
-                if (HAS_DA) { const float2 da = aux.ckpt_da[(slot * 4 + r) * 64 + p]; Prer += da.x * gd + da.y * ga; }
+                float dotv = tc.y * g0 + tc.z * g1 + tc.w * g2;
+                if (HAS_DA) { const float2 da = aux.ckpt_da[(slot * 4 + r) * 64 + p]; dotv += da.x * gd + da.y * ga; }
+                if (((uint32_t)r & (rps - 1u)) == 0u) PreSeg = dotv;      // rps is 1, 2 or 4
+                Prer = (((uint32_t)r & (rps - 1u)) == 0u) ? dotv : PreSeg + dotv;
             }
             sDyn[wv][r][p] = make_float2(Tr, O - Prer);
         }
@@ -736,10 +829,15 @@ int sgr_validate_problem(const SgrProblem *pb);
 
 // 0 = automatic, 1 = serial per-tile kernel, 2 = segment-parallel kernel (dev/test override: sgr_set_forward_mode)
 static int sgr_fwd_mode = 0;
+#ifdef SGR_DBG_TIMING
+extern "C" int sgr_dbg_timing_read(uint32_t *host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_dbg_timing), sizeof(uint32_t) * 4 * 16384); }
+#endif
 extern "C" int sgr_set_forward_mode(int mode) { sgr_fwd_mode = mode; return 0; }
 int sgr_get_forward_mode() { return sgr_fwd_mode; }
 
-extern "C" uint64_t sgr_bucket_slots(uint64_t R, uint64_t tiles_total) { return (R >> 6) + 8 * tiles_total + 1; }
+// a (tile, quadrant) list of n entries has <= n survivors in <= floor(n / 64) + 1 buckets, and floor(a/64) + floor(n/64) <= floor((a+n)/64):
+// slot base (range.x >> 6) + tile id leaves exactly that room
+extern "C" uint64_t sgr_bucket_slots(uint64_t R, uint64_t tiles_total) { return (R >> 6) + tiles_total + 1; }
 
 static FwdAux make_aux(void *compact, void *ckpt_tc, void *ckpt_da, void *desc, uint64_t R, uint64_t tiles_total) {
     FwdAux a;
@@ -751,26 +849,35 @@ static FwdAux make_aux(void *compact, void *ckpt_tc, void *ckpt_da, void *desc, 
 extern "C" int sgr_render_forward(const SgrProblem *pb, const uint32_t *ranges, const uint32_t *point_list, const float *rec,
                                   float *out_color, float *out_depth, float *out_alpha, float *final_T, uint32_t *n_contrib,
                                   uint64_t R, void *aux_compact, void *aux_ckpt_tc, void *aux_ckpt_da, void *aux_desc,
-                                  void *stream_) {
+                                  uint32_t *aux_order, void *stream_) {
     if (sgr_validate_problem(pb)) return 1;
     const int Tx = (pb->W + SGR_TILE - 1) / SGR_TILE, Ty = (pb->H + SGR_TILE - 1) / SGR_TILE;
     const uint32_t tiles = (uint32_t)Tx * Ty;
     hipStream_t stream = (hipStream_t)stream_;
     const bool use_aux = aux_compact && aux_ckpt_tc && aux_ckpt_da && aux_desc;
     FwdAux aux = make_aux(aux_compact, aux_ckpt_tc, aux_ckpt_da, aux_desc, R, (uint64_t)tiles * pb->n_views);
-    if (use_aux) SGR_CHECK_HIP(hipMemsetAsync(aux_desc, 0, (size_t)4 * aux.NS * sizeof(uint2), stream));
-    SgrProfScope _p(SGR_K_RENDER_FWD, stream);
+    const uint64_t tiles_total = (uint64_t)tiles * pb->n_views;
+    if (use_aux && tiles_total >= (1ull << 30)) { sgr_set_error("too many tiles (%llu) for the bucket descriptors", (unsigned long long)tiles_total); return 1; }
     // few workgroups (one or two 512^2 views): trade 1.5x arithmetic for an 8x shorter dependency chain
-    const bool seg = sgr_fwd_mode == 2 || (sgr_fwd_mode == 0 && (uint64_t)tiles * pb->n_views <= 2048);
+    const bool seg = sgr_fwd_mode == 2 || (sgr_fwd_mode == 0 && tiles_total <= 2048);
+    const size_t n_desc = use_aux ? (size_t)4 * aux.NS : 0;
+    const bool prep = seg && (aux_order || (use_aux && n_desc <= (1u << 17)));     // one workgroup orders the tiles and clears the descriptors
+    if (use_aux && !(prep && n_desc <= (1u << 17))) SGR_CHECK_HIP(hipMemsetAsync(aux_desc, 0, n_desc * sizeof(uint2), stream));
+    SgrProfScope _p(SGR_K_RENDER_FWD, stream);
+    if (prep) {
+        hipLaunchKernelGGL(fwd_prepare_kernel, dim3(1), dim3(1024), 0, stream, (const uint2 *)ranges, (uint32_t)tiles_total,
+                           (use_aux && n_desc <= (1u << 17)) ? (uint2 *)aux_desc : (uint2 *)nullptr, n_desc, aux_order);
+        SGR_CHECK_LAUNCH("fwd_prepare_kernel");
+    }
     if (seg) {
         if (use_aux)
             hipLaunchKernelGGL(render_fwd_seg_kernel<true>, dim3(tiles * pb->n_views * 4), dim3(kSegThreads), 0, stream, pb->W, pb->H,
                                Tx, tiles, (const uint2 *)ranges, point_list, (const float4 *)rec, pb->bg, out_color, out_depth,
-                               out_alpha, final_T, n_contrib, aux);
+                               out_alpha, final_T, n_contrib, aux, (const uint32_t *)aux_order);
         else
             hipLaunchKernelGGL(render_fwd_seg_kernel<false>, dim3(tiles * pb->n_views * 4), dim3(kSegThreads), 0, stream, pb->W, pb->H,
                                Tx, tiles, (const uint2 *)ranges, point_list, (const float4 *)rec, pb->bg, out_color, out_depth,
-                               out_alpha, final_T, n_contrib, aux);
+                               out_alpha, final_T, n_contrib, aux, (const uint32_t *)aux_order);
         SGR_CHECK_LAUNCH("render_fwd_seg_kernel");
         return 0;
     }
