@@ -25,6 +25,16 @@ constexpr int kRadix = 1 << kRadixBits;
 // large batches want fewer, longer ones (less histogram traffic)
 constexpr int kItemsSmall = 4, kItemsLarge = 16;
 
+struct DupExtra {
+    const uint32_t *self_sums;          // un-scanned per-workgroup tile counts (NULL: block_offsets already holds the scan)
+    uint64_t *num_rendered;             // [2] device counter + overflow flag (self-scan mode)
+    uint64_t *nr_host;                  // optional pinned host copy of the same
+    unsigned long long capacity;
+    uint32_t *zero_ptr;                 // optional buffer to clear
+    uint32_t zero_words;
+    uint32_t *zero_one;                 // optional single word to clear (the tile-sort worklist counter)
+};
+
 // ---- F3 -----------------------------------------------------------------------------------------
 // Same grid as preprocess (blockIdx.y = view).  The block re-scans its 256 tile counts in LDS and adds
 // the block offset from F2, so the per-Gaussian offsets array of the published algorithm is never
@@ -34,9 +44,15 @@ __global__ __launch_bounds__(kThreads) void duplicate_keys_kernel(int P, int Tx,
                                                                   const int32_t *__restrict__ radii,
                                                                   const uint2 *__restrict__ rect,
                                                                   const uint32_t *__restrict__ block_offsets, uint32_t cap,
-                                                                  uint64_t *__restrict__ keys, uint32_t *__restrict__ vals) {
+                                                                  uint64_t *__restrict__ keys, uint32_t *__restrict__ vals,
+                                                                  DupExtra ex) {
     __shared__ uint32_t wave_tot[4];
+    __shared__ unsigned long long red64[4];
     const int view = blockIdx.y;
+    // piggy-backed clear of a small buffer the later kernels expect zeroed (the tile ranges): replaces a memset launch
+    for (uint32_t z = (blockIdx.y * gridDim.x + blockIdx.x) * kThreads + threadIdx.x; z < ex.zero_words; z += gridDim.x * gridDim.y * kThreads)
+        ex.zero_ptr[z] = 0u;
+    if (ex.zero_one && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *ex.zero_one = 0u;
     const int i = blockIdx.x * kThreads + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t cnt = 0;
@@ -59,7 +75,29 @@ __global__ __launch_bounds__(kThreads) void duplicate_keys_kernel(int P, int Tx,
     }
     if (lane == 63) wave_tot[wave] = inc;
     __syncthreads();
-    uint32_t base = block_offsets[(size_t)view * gridDim.x + blockIdx.x];
+    uint32_t base;
+    if (ex.self_sums) {
+        // F2 folded in (small launches, sync-free mode): every workgroup sums the un-scanned counts of the workgroups before it
+        // (at most a few thousand values) instead of waiting for a separate one-workgroup scan kernel; workgroup 0 also
+        // publishes the total (device counter, overflow flag and -- if given -- the caller's pinned host slot)
+        const uint32_t b = blockIdx.y * gridDim.x + blockIdx.x, nb = gridDim.x * gridDim.y;
+        const uint32_t upto = b == 0 ? nb : b;
+        unsigned long long acc = 0;
+        for (uint32_t k = threadIdx.x; k < upto; k += kThreads) acc += ex.self_sums[k];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+        if (lane == 0) red64[wave] = acc;
+        __syncthreads();
+        const unsigned long long tot = (red64[0] + red64[1]) + (red64[2] + red64[3]);
+        base = b == 0 ? 0u : (uint32_t)tot;
+        if (b == 0 && threadIdx.x == 0) {
+            const unsigned long long ovf = (tot > 0xFFFFFFF0ull || tot > ex.capacity) ? 1ull : 0ull;
+            ex.num_rendered[0] = tot; ex.num_rendered[1] = ovf;
+            if (ex.nr_host) { ex.nr_host[0] = tot; ex.nr_host[1] = ovf; __threadfence_system(); }
+        }
+    } else {
+        base = block_offsets[(size_t)view * gridDim.x + blockIdx.x];
+    }
     for (int w = 0; w < wave; w++) base += wave_tot[w];
     uint32_t off = base + inc - cnt;
     if (cnt) {
@@ -421,6 +459,8 @@ __device__ __forceinline__ void seg_sort_passes(uint32_t n, uint32_t *ka, uint32
 // segments of <= 1024 entries, CAP=4096 / 1024 threads handles the rest (and oversize segments through global memory).
 // (launching a 1024-thread / 80-KB-LDS workgroup per tile just to have it exit costs ~10 us per CU slot, so the small-class
 // launch, one workgroup per tile, appends the long tiles to a worklist that a fixed-size large-class grid then drains)
+// (a launch with few tiles -- one 512^2 view -- skips the small class: tile_ranges_kernel puts every occupied tile on the worklist
+// and the large-class workgroups take one each, all resident at once, so the two classes no longer run back to back)
 template <int NT, int CAP, bool SMALL_CLASS>
 __global__ __launch_bounds__(NT) void tile_sort_kernel(const uint2 *__restrict__ ranges, uint64_t *__restrict__ src_keys,
                                                        uint32_t *__restrict__ src_vals, uint64_t *__restrict__ dst_keys,
@@ -464,18 +504,22 @@ __global__ __launch_bounds__(NT) void tile_sort_kernel(const uint2 *__restrict__
 // ---- F5 -------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kThreads) void tile_ranges_kernel(const uint64_t *__restrict__ keys, uint32_t n_host,
                                                                const uint64_t *__restrict__ n_dev, uint2 *__restrict__ ranges,
-                                                               uint32_t *__restrict__ worklist_count) {
+                                                               uint32_t *__restrict__ worklist, int append_all) {
+    // worklist[0] = counter: append_all == 0 -> reset here for the small-class tile sort that fills it afterwards;
+    // append_all != 0 -> (already cleared by the duplicate kernel) every occupied tile is appended by the thread at its segment start
     const uint32_t n = n_dev ? (uint32_t)min((uint64_t)n_host, *n_dev) : n_host;
-    if (worklist_count && blockIdx.x == 0 && threadIdx.x == 0) *worklist_count = 0;
+    if (worklist && !append_all && blockIdx.x == 0 && threadIdx.x == 0) worklist[0] = 0;
     const uint32_t r = blockIdx.x * kThreads + threadIdx.x;
     if (r >= n) return;
     const uint32_t tile = (uint32_t)(keys[r] >> 32);
+    bool first = r == 0;
     if (r == 0) ranges[tile].x = 0;
     else {
         const uint32_t prev = (uint32_t)(keys[r - 1] >> 32);
-        if (tile != prev) { ranges[prev].y = r; ranges[tile].x = r; }
+        if (tile != prev) { ranges[prev].y = r; ranges[tile].x = r; first = true; }
     }
     if (r == n - 1) ranges[tile].y = n;
+    if (append_all && first) worklist[1 + atomicAdd(&worklist[0], 1u)] = tile;
 }
 
 // 3 = automatic (default, by instance count: measured crossovers on MI355X), 2 = segmented (tile bits globally, depth bits per tile in LDS),
@@ -497,25 +541,38 @@ extern "C" size_t sgr_bin_workspace_bytes(uint64_t R, uint64_t tiles_total) {
                     (tiles_total ? (tiles_total + 64) * sizeof(uint32_t) : 0));
 }
 
-extern "C" int sgr_bin(const SgrProblem *pb, float *rec, const int32_t *radii, const uint32_t *rect,
-                       const uint32_t *block_offsets, uint64_t R, const uint64_t *num_rendered_dev, uint64_t *keys_a,
-                       uint64_t *keys_b, uint32_t *vals_a, uint32_t *vals_b, void *workspace, size_t workspace_bytes,
-                       uint32_t *ranges, int32_t *result_in_b_host, void *stream_) {
+// self_scan: the caller skipped the F2 scan kernel (sgr_preprocess_forward_ex) and block_offsets + n + 1 holds the un-scanned
+// counts; num_rendered_dev is then WRITTEN by the duplicate kernel (capacity mode only).  nr_host: optional pinned host slot.
+int sgr_bin_ex(const SgrProblem *pb, float *rec, const int32_t *radii, const uint32_t *rect,
+               const uint32_t *block_offsets, uint64_t R, const uint64_t *num_rendered_dev, uint64_t *keys_a,
+               uint64_t *keys_b, uint32_t *vals_a, uint32_t *vals_b, void *workspace, size_t workspace_bytes,
+               uint32_t *ranges, int32_t *result_in_b_host, bool self_scan, uint64_t *nr_host, void *stream_) {
     if (sgr_validate_problem(pb)) return 1;
     hipStream_t stream = (hipStream_t)stream_;
     const int Tx = (pb->W + SGR_TILE - 1) / SGR_TILE, Ty = (pb->H + SGR_TILE - 1) / SGR_TILE;
     const uint64_t tiles_total = (uint64_t)Tx * Ty * pb->n_views;
     if (tiles_total >= (1ull << 32)) { sgr_set_error("too many tiles (%llu)", (unsigned long long)tiles_total); return 1; }
     if (R > 0xFFFFFFF0ull) { sgr_set_error("num_rendered %llu exceeds the 32-bit instance index", (unsigned long long)R); return 1; }
-    SGR_CHECK_HIP(hipMemsetAsync(ranges, 0, tiles_total * 2 * sizeof(uint32_t), stream));
     if (result_in_b_host) *result_in_b_host = 0;
+    const bool fold_clear = R > 0 && pb->P > 0 && tiles_total * 2 <= (1u << 20);     // small: cleared by the duplicate kernel
+    if (!fold_clear) SGR_CHECK_HIP(hipMemsetAsync(ranges, 0, tiles_total * 2 * sizeof(uint32_t), stream));
     if (R == 0 || pb->P == 0) return 0;
     if (workspace_bytes < sgr_bin_workspace_bytes(R, tiles_total)) { sgr_set_error("sgr_bin: workspace too small"); return 1; }
     const uint32_t n = (uint32_t)R;
     const int nbx = sgr_preprocess_blocks_per_view(pb->P);
+    // few tiles + segmented sort: every occupied tile goes on the large-class worklist (counter cleared by the duplicate kernel,
+    // filled by tile_ranges)
+    const bool all_large = tiles_total <= 2048;
     { SgrProfScope _p(SGR_K_DUPLICATE, stream);
+    DupExtra ex;
+    const uint32_t nblk = (uint32_t)nbx * (uint32_t)pb->n_views;
+    ex.self_sums = self_scan ? block_offsets + (nblk + 1) : nullptr;
+    ex.num_rendered = const_cast<uint64_t *>(num_rendered_dev); ex.nr_host = self_scan ? nr_host : nullptr; ex.capacity = R;
+    ex.zero_ptr = fold_clear ? ranges : nullptr; ex.zero_words = fold_clear ? (uint32_t)(tiles_total * 2) : 0u;
+    ex.zero_one = all_large ? (uint32_t *)((char *)workspace + sgr_bin_workspace_bytes(R, 0)) : nullptr;
+    if (self_scan && !num_rendered_dev) { sgr_set_error("sgr_bin: self-scan needs the device counter"); return 1; }
     hipLaunchKernelGGL(duplicate_keys_kernel, dim3(nbx, pb->n_views), dim3(kThreads), 0, stream, pb->P, Tx, Tx * Ty,
-                       (float4 *)rec, radii, (const uint2 *)rect, block_offsets, n, keys_a, vals_a);
+                       (float4 *)rec, radii, (const uint2 *)rect, block_offsets, n, keys_a, vals_a, ex);
     SGR_CHECK_LAUNCH("duplicate_keys_kernel");
     }
     const bool small = n <= (1u << 19);
@@ -550,13 +607,14 @@ extern "C" int sgr_bin(const SgrProblem *pb, float *rec, const int32_t *radii, c
         }
         }
         { SgrProfScope _pr(SGR_K_RANGES, stream);
-        hipLaunchKernelGGL(tile_ranges_kernel, dim3((n + kThreads - 1) / kThreads), dim3(kThreads), 0, stream, kin, n, num_rendered_dev, (uint2 *)ranges, worklist);
+        hipLaunchKernelGGL(tile_ranges_kernel, dim3((n + kThreads - 1) / kThreads), dim3(kThreads), 0, stream, kin, n, num_rendered_dev, (uint2 *)ranges, worklist, all_large ? 1 : 0);
         SGR_CHECK_LAUNCH("tile_ranges_kernel");
         }
         { SgrProfScope _ps(SGR_K_SORT, stream);
-        hipLaunchKernelGGL((tile_sort_kernel<256, kSegCapSmall, true>), dim3((uint32_t)tiles_total), dim3(256), 0, stream,
-                           (const uint2 *)ranges, kin, vin, kout, vout, worklist);
         const uint32_t big_grid = (uint32_t)(tiles_total < 512 ? tiles_total : 512);
+        if (!all_large)
+            hipLaunchKernelGGL((tile_sort_kernel<256, kSegCapSmall, true>), dim3((uint32_t)tiles_total), dim3(256), 0, stream,
+                               (const uint2 *)ranges, kin, vin, kout, vout, worklist);
         hipLaunchKernelGGL((tile_sort_kernel<1024, kSegCapLarge, false>), dim3(big_grid), dim3(1024), 0, stream,
                            (const uint2 *)ranges, kin, vin, kout, vout, worklist);
         SGR_CHECK_LAUNCH("tile_sort_kernel");
@@ -603,8 +661,16 @@ extern "C" int sgr_bin(const SgrProblem *pb, float *rec, const int32_t *radii, c
     if (result_in_b_host) *result_in_b_host = (kin == keys_b) ? 1 : 0;
     { SgrProfScope _p(SGR_K_RANGES, stream);
     hipLaunchKernelGGL(tile_ranges_kernel, dim3((n + kThreads - 1) / kThreads), dim3(kThreads), 0, stream, kin, n,
-                       num_rendered_dev, (uint2 *)ranges, (uint32_t *)nullptr);
+                       num_rendered_dev, (uint2 *)ranges, (uint32_t *)nullptr, 0);
     SGR_CHECK_LAUNCH("tile_ranges_kernel");
     }
     return 0;
+}
+
+extern "C" int sgr_bin(const SgrProblem *pb, float *rec, const int32_t *radii, const uint32_t *rect,
+                       const uint32_t *block_offsets, uint64_t R, const uint64_t *num_rendered_dev, uint64_t *keys_a,
+                       uint64_t *keys_b, uint32_t *vals_a, uint32_t *vals_b, void *workspace, size_t workspace_bytes,
+                       uint32_t *ranges, int32_t *result_in_b_host, void *stream_) {
+    return sgr_bin_ex(pb, rec, radii, rect, block_offsets, R, num_rendered_dev, keys_a, keys_b, vals_a, vals_b, workspace,
+                      workspace_bytes, ranges, result_in_b_host, false, nullptr, stream_);
 }

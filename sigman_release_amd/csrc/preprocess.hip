@@ -546,8 +546,9 @@ int sgr_validate_problem(const SgrProblem *pb) { return validate_problem(pb); }
 
 extern "C" int32_t sgr_preprocess_blocks_per_view(int32_t P) { return P <= 0 ? 1 : (P + kPreThreads - 1) / kPreThreads; }
 
-extern "C" int sgr_preprocess_forward(const SgrProblem *pb, float *rec, int32_t *radii, uint32_t *rect, uint8_t *clamped,
-                                      uint32_t *block_offsets, uint64_t *num_rendered, uint64_t capacity, void *stream_) {
+// skip_scan: leave the per-workgroup counts un-scanned behind block_offsets; sgr_bin_ex(self_scan = true) folds F2 into F3
+int sgr_preprocess_forward_ex(const SgrProblem *pb, float *rec, int32_t *radii, uint32_t *rect, uint8_t *clamped,
+                              uint32_t *block_offsets, uint64_t *num_rendered, uint64_t capacity, bool skip_scan, void *stream_) {
     if (validate_problem(pb)) return 1;
     if (capacity == 0) capacity = ~0ull;
     hipStream_t stream = (hipStream_t)stream_;
@@ -562,12 +563,18 @@ extern "C" int sgr_preprocess_forward(const SgrProblem *pb, float *rec, int32_t 
                        clamped, sums);
     SGR_CHECK_LAUNCH("preprocess_fwd_kernel");
     }
+    if (skip_scan) return 0;
     { SgrProfScope _p(SGR_K_SCAN, stream);
     hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(1024), 0, stream, sums, block_offsets, n, num_rendered,
                        (unsigned long long)capacity);
     SGR_CHECK_LAUNCH("scan_block_sums_kernel");
     }
     return 0;
+}
+
+extern "C" int sgr_preprocess_forward(const SgrProblem *pb, float *rec, int32_t *radii, uint32_t *rect, uint8_t *clamped,
+                                      uint32_t *block_offsets, uint64_t *num_rendered, uint64_t capacity, void *stream_) {
+    return sgr_preprocess_forward_ex(pb, rec, radii, rect, clamped, block_offsets, num_rendered, capacity, false, stream_);
 }
 
 extern "C" int sgr_preprocess_backward(const SgrProblem *pb, const int32_t *radii, const uint8_t *clamped, const float *grec,

@@ -39,6 +39,11 @@ int g_graphs_enabled = -1;       // -1 = not decided yet (see graphs_allowed)
 }  // namespace
 
 int sgr_prof_active();
+int sgr_preprocess_forward_ex(const SgrProblem *pb, float *rec, int32_t *radii, uint32_t *rect, uint8_t *clamped, uint32_t *block_offsets,
+                              uint64_t *num_rendered, uint64_t capacity, bool skip_scan, void *stream_);
+int sgr_bin_ex(const SgrProblem *pb, float *rec, const int32_t *radii, const uint32_t *rect, const uint32_t *block_offsets, uint64_t R,
+               const uint64_t *num_rendered_dev, uint64_t *keys_a, uint64_t *keys_b, uint32_t *vals_a, uint32_t *vals_b, void *workspace,
+               size_t workspace_bytes, uint32_t *ranges, int32_t *result_in_b_host, bool self_scan, uint64_t *nr_host, void *stream_);
 int sgr_get_forward_mode();
 
 // ROCm 7.2's hipGraph "packet capture" (pre-recorded AQL packets, on by default) is not safe next to large host<->device
@@ -65,15 +70,19 @@ static int forward_launches(const SgrProblem *pb, uint64_t capacity, uint64_t R,
     uint8_t *clamped = pb->shs ? (uint8_t *)(geom + st->off_clamped) : nullptr;
     uint32_t *block_offsets = (uint32_t *)(geom + st->off_block_offsets);
     uint64_t *num_rendered = (uint64_t *)(geom + st->off_num_rendered);
+    // small sync-free launches: the block-sum scan (F2), the clear of the tile ranges and the copy of the instance count to the
+    // caller's pinned slot are folded into the duplicate kernel (three launches fewer)
+    const uint64_t nblk = (uint64_t)sgr_preprocess_blocks_per_view(pb->P) * pb->n_views;
+    const bool self_scan = !preprocess_done && capacity > 0 && nblk <= 2048;
     if (!preprocess_done) {
-        if (sgr_preprocess_forward(pb, rec, out_radii, rect, clamped, block_offsets, num_rendered, capacity, stream)) return 1;
-        if (nr_pinned_host) SGR_CHECK_HIP(hipMemcpyAsync(nr_pinned_host, num_rendered, 16, hipMemcpyDeviceToHost, stream));
+        if (sgr_preprocess_forward_ex(pb, rec, out_radii, rect, clamped, block_offsets, num_rendered, capacity, self_scan, stream)) return 1;
+        if (nr_pinned_host && !self_scan) SGR_CHECK_HIP(hipMemcpyAsync(nr_pinned_host, num_rendered, 16, hipMemcpyDeviceToHost, stream));
     }
     int32_t in_b = 0;
-    if (sgr_bin(pb, rec, out_radii, rect, block_offsets, R, capacity > 0 ? num_rendered : nullptr, (uint64_t *)(binning + st->off_keys_a),
-                (uint64_t *)(binning + st->off_keys_b), (uint32_t *)(binning + st->off_vals_a), (uint32_t *)(binning + st->off_vals_b),
-                binning + st->off_sort_ws, (size_t)sgr_bin_workspace_bytes(R, (uint64_t)((pb->W + SGR_TILE - 1) / SGR_TILE) * ((pb->H + SGR_TILE - 1) / SGR_TILE) * pb->n_views),
-                (uint32_t *)(image + st->off_ranges), &in_b, stream)) return 1;
+    if (sgr_bin_ex(pb, rec, out_radii, rect, block_offsets, R, capacity > 0 ? num_rendered : nullptr, (uint64_t *)(binning + st->off_keys_a),
+                   (uint64_t *)(binning + st->off_keys_b), (uint32_t *)(binning + st->off_vals_a), (uint32_t *)(binning + st->off_vals_b),
+                   binning + st->off_sort_ws, (size_t)sgr_bin_workspace_bytes(R, (uint64_t)((pb->W + SGR_TILE - 1) / SGR_TILE) * ((pb->H + SGR_TILE - 1) / SGR_TILE) * pb->n_views),
+                   (uint32_t *)(image + st->off_ranges), &in_b, self_scan, self_scan ? nr_pinned_host : nullptr, stream)) return 1;
     st->result_in_b = in_b;
     const uint32_t *point_list = (const uint32_t *)(binning + (in_b ? st->off_vals_b : st->off_vals_a));
     const bool aux_on = st->with_aux != 0;
