@@ -241,6 +241,125 @@ __global__ __launch_bounds__(kThreads) void radix_downsweep_kernel(const uint64_
     }
 }
 
+// ---- F4, wide-digit variant for the tile bits of small launches ---------------------------------------
+// With <= 2048 tiles (one 512^2 view = 1024) the whole tile id fits ONE 11-bit digit: a single stable pass (three
+// kernels) instead of two 8-bit passes (six).  Same structure as above; the per-round bookkeeping only touches the
+// digits that occur in the round (leaders of each wave's match-any groups), never the whole 2048-entry tables.
+constexpr int kWideBits = 11, kWide = 1 << kWideBits;
+
+template <int ITEMS>
+__global__ __launch_bounds__(kThreads) void wide_upsweep_kernel(const uint64_t *__restrict__ keys, uint32_t n_host, const uint64_t *__restrict__ n_dev,
+                                                                int shift, uint32_t nblocks, uint32_t *__restrict__ hist) {
+    __shared__ uint32_t h[kWide];
+    const uint32_t n = n_dev ? (uint32_t)min((uint64_t)n_host, *n_dev) : n_host;
+    for (int d = threadIdx.x; d < kWide; d += kThreads) h[d] = 0;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * (kThreads * ITEMS);
+#pragma unroll
+    for (int it = 0; it < ITEMS; it++) {
+        const uint32_t k = base + it * kThreads + threadIdx.x;
+        if (k < n) atomicAdd(&h[(uint32_t)(keys[k] >> shift) & (kWide - 1)], 1u);
+    }
+    __syncthreads();
+    for (int d = threadIdx.x; d < kWide; d += kThreads) hist[(size_t)d * nblocks + blockIdx.x] = h[d];
+}
+
+// one wave per digit row (rows are ~200 entries at C2): 4 rows per workgroup, exclusive prefix in place + digit total
+__global__ __launch_bounds__(kThreads) void wide_rowscan_kernel(uint32_t *__restrict__ hist, uint32_t nblocks, uint32_t *__restrict__ totals) {
+    const uint32_t lane = threadIdx.x & 63, d = blockIdx.x * 4 + (threadIdx.x >> 6);
+    uint32_t *row = hist + (size_t)d * nblocks;
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < nblocks; base += 64) {
+        const uint32_t idx = base + lane;
+        const uint32_t v = idx < nblocks ? row[idx] : 0u;
+        uint32_t inc = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t nb = __shfl_up(inc, off, 64);
+            if (lane >= (uint32_t)off) inc += nb;
+        }
+        if (idx < nblocks) row[idx] = carry + inc - v;
+        carry += __shfl(inc, 63, 64);
+    }
+    if (lane == 0) totals[d] = carry;
+}
+
+template <int ITEMS>
+__global__ __launch_bounds__(kThreads) void wide_downsweep_kernel(const uint64_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
+                                                                  uint64_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, uint32_t n_host,
+                                                                  const uint64_t *__restrict__ n_dev, int shift, uint32_t nblocks,
+                                                                  const uint32_t *__restrict__ hist, const uint32_t *__restrict__ totals) {
+    const uint32_t n = n_dev ? (uint32_t)min((uint64_t)n_host, *n_dev) : n_host;
+    __shared__ uint32_t digit_base[kWide];
+    __shared__ uint32_t wave_cnt[4][kWide];
+    __shared__ uint32_t wtot[4];
+    const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    constexpr int PER = kWide / kThreads;                        // 8 consecutive digits per thread
+    {   // exclusive scan of the 2048 digit totals + this workgroup's offset inside each digit; wave_cnt starts zeroed
+        uint32_t v[PER], sum = 0;
+#pragma unroll
+        for (int j = 0; j < PER; j++) { v[j] = totals[t * PER + j]; sum += v[j]; }
+        uint32_t inc = sum;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t nb = __shfl_up(inc, off, 64);
+            if (lane >= (uint32_t)off) inc += nb;
+        }
+        if (lane == 63) wtot[wave] = inc;
+        __syncthreads();
+        uint32_t run = inc - sum;
+        for (uint32_t w = 0; w < wave; w++) run += wtot[w];
+#pragma unroll
+        for (int j = 0; j < PER; j++) {
+            const uint32_t d = t * PER + j;
+            digit_base[d] = run + hist[(size_t)d * nblocks + blockIdx.x];
+            run += v[j];
+#pragma unroll
+            for (int w = 0; w < 4; w++) wave_cnt[w][d] = 0;
+        }
+    }
+    const uint32_t base = blockIdx.x * (kThreads * ITEMS);
+    const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    uint64_t keys_r[ITEMS];
+    uint32_t vals_r[ITEMS];
+#pragma unroll
+    for (int it = 0; it < ITEMS; it++) {
+        const uint32_t k = base + it * kThreads + t;
+        keys_r[it] = 0; vals_r[it] = 0;
+        if (k < n) { keys_r[it] = keys_in[k]; vals_r[it] = vals_in[k]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < ITEMS; it++) {
+        const uint32_t k = base + it * kThreads + t;
+        const bool valid = k < n;
+        const uint64_t key = keys_r[it];
+        const uint32_t val = vals_r[it];
+        const uint32_t d = (uint32_t)(key >> shift) & (kWide - 1);
+        uint64_t peers = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < kWideBits; b++) {
+            const bool bit = (d >> b) & 1;
+            const uint64_t m = __ballot(bit);
+            peers &= bit ? m : ~m;
+        }
+        const uint32_t rank = (uint32_t)__popcll(peers & lt_mask);
+        const uint32_t grp = (uint32_t)__popcll(peers);
+        const bool leader = valid && rank == 0;
+        if (leader) wave_cnt[wave][d] = grp;
+        __syncthreads();
+        if (valid) {
+            uint32_t pos = digit_base[d] + rank;
+            for (uint32_t w = 0; w < wave; w++) pos += wave_cnt[w][d];
+            keys_out[pos] = key;
+            vals_out[pos] = val;
+        }
+        __syncthreads();
+        if (leader) { atomicAdd(&digit_base[d], grp); wave_cnt[wave][d] = 0; }
+        __syncthreads();
+    }
+}
+
 // ---- F4, onesweep variant: ONE kernel per digit instead of three --------------------------------------
 // (a) radix_hist_all_kernel reads the keys once and builds the global histograms of every pass (the multiset of keys
 //     does not change between passes, so all digit histograms can be taken up front);
@@ -593,7 +712,16 @@ int sgr_bin_ex(const SgrProblem *pb, float *rec, const int32_t *radii, const uin
         uint32_t *worklist = (uint32_t *)((char *)workspace + sgr_bin_workspace_bytes(R, 0));   // [1 + tiles_total] behind the radix scratch
         const int tile_bits = bits_for(tiles_total);
         const int tpasses = (tile_bits + kRadixBits - 1) / kRadixBits;
+        const bool wide = small && tile_bits > kRadixBits && tile_bits <= kWideBits;      // one 11-bit pass instead of two 8-bit passes
         { SgrProfScope _ps(SGR_K_SORT, stream);
+        if (wide) {
+            hipLaunchKernelGGL(wide_upsweep_kernel<kItemsSmall>, dim3(nblocks), dim3(kThreads), 0, stream, kin, n, num_rendered_dev, 32, nblocks, hist);
+            hipLaunchKernelGGL(wide_rowscan_kernel, dim3(kWide / 4), dim3(kThreads), 0, stream, hist, nblocks, hist + (size_t)nblocks * kWide);
+            hipLaunchKernelGGL(wide_downsweep_kernel<kItemsSmall>, dim3(nblocks), dim3(kThreads), 0, stream, kin, vin, kout, vout, n, num_rendered_dev, 32, nblocks, hist, hist + (size_t)nblocks * kWide);
+            SGR_CHECK_LAUNCH("wide tile-bit pass");
+            uint64_t *tk = kin; kin = kout; kout = tk;
+            uint32_t *tv = vin; vin = vout; vout = tv;
+        } else
         for (int p = 0; p < tpasses; p++) {
             const int shift = 32 + p * kRadixBits;
             if (small) hipLaunchKernelGGL(radix_upsweep_kernel<kItemsSmall>, dim3(nblocks), dim3(kThreads), 0, stream, kin, n, num_rendered_dev, shift, nblocks, hist);
