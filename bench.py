@@ -63,8 +63,8 @@ def build_subject(P: int, seed: int, dev):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--gaussians", type=int, default=100_000)
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--views-per-step", type=int, default=1, help="views per GPU per step (C2 = 1)")

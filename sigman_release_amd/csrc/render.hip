@@ -238,9 +238,8 @@ __global__ __launch_bounds__(kSegThreads, 4) void render_fwd_seg_kernel(int W, i
                                                                      float *__restrict__ out_alpha, float *__restrict__ final_T,
                                                                      uint32_t *__restrict__ n_contrib, FwdAux aux,
                                                                      const uint32_t *__restrict__ order) {
-    __shared__ float4 sA[kSegRing], sB[kSegRing];               // (x, y, kxx, kxy), (kyy, opacity, depth, r)
-    __shared__ float2 sC[kSegRing];                             // (g, b)
-    __shared__ uint32_t sIdx[kSegRing];                         // index in the tile list
+    // survivor ring, one float4 per field group at the same index (one address computation serves all three reads):
+    __shared__ float4 sA[kSegRing], sB[kSegRing], sC[kSegRing];   // (x, y, kxx, kxy), (kyy, opacity, depth, r), (g, b, list index + 1, -)
     __shared__ float sT[kSegWaves][64];
     __shared__ float sAcc[kSegWaves][5][64];
     __shared__ float sTstop[64];
@@ -303,7 +302,7 @@ __global__ __launch_bounds__(kSegThreads, 4) void render_fwd_seg_kernel(int W, i
                 const uint32_t s = (qhead + ord) & (kSegRing - 1);
                 sA[s] = make_float4(ra.x, ra.y, kHalfLog2e * ra.z, kLog2e * ra.w);
                 sB[s] = make_float4(kHalfLog2e * rb.x, rb.y, rb.z, rb.w);
-                sC[s] = make_float2(rc.x, rc.y); sIdx[s] = (uint32_t)idx;
+                sC[s] = make_float4(rc.x, rc.y, __uint_as_float((uint32_t)idx + 1u), 0.f);
                 if (AUX) aux.compact[(size_t)q * aux.R + range.x + kbase + ord] = make_uint2(rid, (uint32_t)idx);
             }
             qcount += m;
@@ -324,19 +323,26 @@ __global__ __launch_bounds__(kSegThreads, 4) void render_fwd_seg_kernel(int W, i
         const uint32_t per = m <= 128u ? 16u : (m <= 256u ? 32u : 64u);
         const uint32_t s0 = min(m, (uint32_t)wave * per), s1 = min(m, s0 + per);
         const uint32_t brow0 = (s0 & 63u) >> 4;                     // my segment's first row inside its 64-survivor bucket
+        // the loops below take survivors four at a time without bounds checks: pad the (last) round with null entries (opacity 0).
+        // qhead and every segment start are multiples of 4, so a group of four never wraps around the ring.
+        if ((m & 3u) && (uint32_t)t < 4u - (m & 3u)) {
+            const uint32_t s = (qhead + m + (uint32_t)t) & (kSegRing - 1);
+            sA[s] = make_float4(0.f, 0.f, 0.f, 0.f); sB[s] = sA[s]; sC[s] = sA[s];
+        }
+        if (m & 3u) __syncthreads();
 #define SGR_RING(S) ((qhead + (S)) & (kSegRing - 1))
         // ---- phase 1: transmittance product of my segment
         float Tseg = 1.f;
         for (uint32_t s = s0; s < s1; s += 4) {
             float om[4];
+            const uint32_t sb = SGR_RING(s);
 #pragma unroll
             for (int u = 0; u < 4; u++) {
-                const uint32_t su = SGR_RING(min(s + u, s1 - 1));
-                const float4 ga = sA[su], gb = sB[su];
+                const float4 ga = sA[sb + u], gb = sB[sb + u];
                 const float dx = ga.x - pxf, dy = ga.y - pyf;
                 const float power = (ga.z * dx) * dx + ((gb.x * dy) * dy + (ga.w * dx) * dy);
                 const float alpha = fminf(0.99f, gb.y * __builtin_amdgcn_exp2f(power));
-                const bool valid = (power <= 0.f) & (alpha >= (1.0f / 255.0f)) & (s + u < s1);
+                const bool valid = (power <= 0.f) & (alpha >= (1.0f / 255.0f));
                 om[u] = valid ? 1.f - alpha : 1.f;
             }
             Tseg = (((Tseg * om[0]) * om[1]) * om[2]) * om[3];
@@ -361,18 +367,16 @@ __global__ __launch_bounds__(kSegThreads, 4) void render_fwd_seg_kernel(int W, i
                 aux.ckpt_da[sl] = make_float2(dD, dA);
             }
             float al[4];
-            float4 gb4[4];
-            float2 gc2[4];
-            uint32_t li[4];
+            float4 gb4[4], gc2[4];
+            const uint32_t sb = SGR_RING(s);
 #pragma unroll
             for (int u = 0; u < 4; u++) {
-                const uint32_t su = SGR_RING(min(s + u, s1 - 1));
-                const float4 ga = sA[su];
-                gb4[u] = sB[su]; gc2[u] = sC[su]; li[u] = sIdx[su] + 1u;
+                const float4 ga = sA[sb + u];
+                gb4[u] = sB[sb + u]; gc2[u] = sC[sb + u];
                 const float dx = ga.x - pxf, dy = ga.y - pyf;
                 const float power = (ga.z * dx) * dx + ((gb4[u].x * dy) * dy + (ga.w * dx) * dy);
                 const float alpha = fminf(0.99f, gb4[u].y * __builtin_amdgcn_exp2f(power));
-                const bool valid = (power <= 0.f) & (alpha >= (1.0f / 255.0f)) & (s + u < s1);
+                const bool valid = (power <= 0.f) & (alpha >= (1.0f / 255.0f));
                 al[u] = valid ? alpha : 0.f;
             }
 #pragma unroll
@@ -385,7 +389,7 @@ __global__ __launch_bounds__(kSegThreads, 4) void render_fwd_seg_kernel(int W, i
                 dD = fmaf(gb4[u].z, w, dD);
                 dA += w;
                 T = contrib ? test_T : T;
-                last = contrib ? li[u] : last;
+                last = contrib ? __float_as_uint(gc2[u].z) : last;
                 contributed |= contrib ? 1u : 0u;
             }
         }
