@@ -29,6 +29,30 @@ import time
 
 os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")   # before torch/HIP initialise: see sigman_release_amd/__init__.py
 
+
+def _pin_host_threads():
+    """One process per GPU, pinned to 4 neighbouring cores (before torch creates its threads): the C2 step is ~0.2 ms of
+    GPU work driven by two host threads (Python + autograd engine); left to the scheduler of a 2-socket / 256-thread host they
+    wander across CCXs and NUMA nodes and the step time varies 0.21-0.34 ms run to run; pinned it is 0.21 ms every time.
+    Rank r of n local ranks gets cores [r * (physical / n), +4) -- ranks spread evenly over both sockets like the GPUs.
+    SIGMAN_NO_PIN=1 disables it.  Returns the original affinity (the cpu_baseline leg needs all cores back)."""
+    if os.environ.get("SIGMAN_NO_PIN") == "1" or not hasattr(os, "sched_setaffinity"):
+        return None
+    try:
+        orig = os.sched_getaffinity(0)
+        lr, lw = int(os.environ.get("LOCAL_RANK", "0")), max(int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1"))), 1)
+        phys = max((os.cpu_count() or 2) // 2, 1)               # SMT siblings are numbered in the upper half
+        start = (lr % lw) * (phys // lw)
+        want = {c for c in range(start, start + 4) if c in orig}
+        if len(want) >= 2:
+            os.sched_setaffinity(0, want)
+        return orig
+    except OSError:
+        return None
+
+
+_ORIG_AFFINITY = _pin_host_threads()
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -113,9 +137,9 @@ def main():
         gt = gt.clamp(0, 1)
 
     def render_loss(means3D, cov3D, opacity, rgb, _views=None):
-        color, radii, depth, alpha = R.rasterize_gaussians_batched(means3D[None], None, None, rgb[None], opacity[None], None,
-                                                                   None, cov3D[None], st)
-        return clamped_l1_loss(color, gt, None, norm)               # gs.py:107 clamp + whole_loss.py:126-131 L1, fused HIP epilogue
+        # gs.py:98-107 rasterize + clamp, whole_loss.py:126-131 L1: one autograd node, loss kernel right behind the compositing kernel
+        return R.rasterize_l1_loss_batched(means3D[None], None, None, rgb[None], opacity[None], None, None, cov3D[None], st, gt,
+                                           None, norm)[0]
 
     leaves = {k: v.clone().requires_grad_(True) for k, v in subj.items()}
     packed = parallel.pack_attributes(subj["means3D"], subj["cov3D"], subj["opacity"], subj["rgb"])
@@ -223,7 +247,10 @@ def main():
         "loss": float(loss.detach()),
     }
 
+    out["config"]["host_threads"] = ("pinned to cores %s" % sorted(os.sched_getaffinity(0))) if _ORIG_AFFINITY is not None else "not pinned"
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        if _ORIG_AFFINITY is not None:
+            os.sched_setaffinity(0, _ORIG_AFFINITY)      # the OpenMP oracle gets every host core
         out["cpu_baseline"] = cpu_baseline(g_host, cov_host, my_views[0], H, W, gt[0].cpu().numpy(), norm)
     if rank == 0:
         print(json.dumps(out))

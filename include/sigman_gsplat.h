@@ -118,11 +118,12 @@ int sgr_rasterize_forward(const SgrProblem *pb, uint64_t capacity, int32_t with_
 
 /*
  * == upstream _C.rasterize_gaussians_backward (reached from train_vae.py:166).  Gradient outputs as in
- * sgr_preprocess_backward.  out_color/out_depth/out_alpha are the forward's outputs.
+ * sgr_preprocess_backward.  out_color/out_depth/out_alpha are the forward's outputs.  grad_color_scale: optional DEVICE scalar
+ * multiplied onto grad_color (the upstream gradient of a fused image loss; saves the caller an elementwise kernel), or NULL.
  */
 int sgr_rasterize_backward(const SgrProblem *pb, const SgrForwardState *state, const int32_t *radii, const float *out_color,
                            const float *out_depth, const float *out_alpha, const float *grad_color, const float *grad_depth,
-                           const float *grad_alpha, sgr_alloc_fn alloc, void *user, float *dL_dmeans3D, float *dL_dmeans2D,
+                           const float *grad_alpha, const float *grad_color_scale, sgr_alloc_fn alloc, void *user, float *dL_dmeans3D, float *dL_dmeans2D,
                            float *dL_dopacity, float *dL_dcolors, float *dL_dsh, float *dL_dcov3D, float *dL_dscales,
                            float *dL_drotations, void *stream);
 
@@ -212,6 +213,7 @@ int sgr_render_forward(const SgrProblem *pb, const uint32_t *ranges, const uint3
 int sgr_render_backward(const SgrProblem *pb, const uint32_t *ranges, const uint32_t *point_list, const float *rec,
                         const float *final_T, const uint32_t *n_contrib, const float *out_color, const float *out_depth,
                         const float *out_alpha, const float *grad_color, const float *grad_depth, const float *grad_alpha,
+                        const float *grad_color_scale /* optional device scalar on grad_color, or NULL */,
                         uint64_t R, const void *aux_compact, const void *aux_ckpt_tc, const void *aux_ckpt_da,
                         const void *aux_desc, float *grec, float *part, uint32_t *flags, void *stream);
 

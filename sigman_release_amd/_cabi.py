@@ -44,7 +44,7 @@ _SIGNATURES = {
     "sgr_preprocess_blocks_per_view": (C.c_int32, [C.c_int32]),
     "sgr_rasterize_forward": (C.c_int, [C.POINTER(SgrProblem), C.c_uint64, C.c_int32, ALLOC_FN, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(SgrForwardState), C.c_void_p]),
-    "sgr_rasterize_backward": (C.c_int, [C.POINTER(SgrProblem), C.POINTER(SgrForwardState)] + [C.c_void_p] * 7 + [ALLOC_FN, C.c_void_p]
+    "sgr_rasterize_backward": (C.c_int, [C.POINTER(SgrProblem), C.POINTER(SgrForwardState)] + [C.c_void_p] * 8 + [ALLOC_FN, C.c_void_p]
                                + [C.c_void_p] * 9),
     "sgr_preprocess_forward": (C.c_int, [C.POINTER(SgrProblem)] + [C.c_void_p] * 6 + [C.c_uint64, C.c_void_p]),
     "sgr_bin_workspace_bytes": (C.c_size_t, [C.c_uint64, C.c_uint64]),
@@ -57,7 +57,7 @@ _SIGNATURES = {
     "sgr_set_sort_mode": (C.c_int, [C.c_int]),
     "sgr_graph_stats": (C.c_int, [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "sgr_render_forward": (C.c_int, [C.POINTER(SgrProblem)] + [C.c_void_p] * 8 + [C.c_uint64] + [C.c_void_p] * 6),
-    "sgr_render_backward": (C.c_int, [C.POINTER(SgrProblem)] + [C.c_void_p] * 11 + [C.c_uint64] + [C.c_void_p] * 8),
+    "sgr_render_backward": (C.c_int, [C.POINTER(SgrProblem)] + [C.c_void_p] * 12 + [C.c_uint64] + [C.c_void_p] * 8),
     "sgr_preprocess_backward": (C.c_int, [C.POINTER(SgrProblem)] + [C.c_void_p] * 15),
     "sgr_mark_visible": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sgr_knn_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),

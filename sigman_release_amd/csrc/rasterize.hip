@@ -232,7 +232,8 @@ extern "C" int sgr_rasterize_forward(const SgrProblem *pb, uint64_t capacity, in
 
 extern "C" int sgr_rasterize_backward(const SgrProblem *pb, const SgrForwardState *st, const int32_t *radii, const float *out_color,
                                       const float *out_depth, const float *out_alpha, const float *grad_color,
-                                      const float *grad_depth, const float *grad_alpha, sgr_alloc_fn alloc, void *user,
+                                      const float *grad_depth, const float *grad_alpha, const float *grad_color_scale,
+                                      sgr_alloc_fn alloc, void *user,
                                       float *dL_dmeans3D, float *dL_dmeans2D, float *dL_dopacity, float *dL_dcolors, float *dL_dsh,
                                       float *dL_dcov3D, float *dL_dscales, float *dL_drotations, void *stream_) {
     if (!pb || !st || !alloc) { sgr_set_error("sgr_rasterize_backward: NULL argument"); return 1; }
@@ -252,7 +253,7 @@ extern "C" int sgr_rasterize_backward(const SgrProblem *pb, const SgrForwardStat
     const uint32_t *point_list = (const uint32_t *)(binning + (st->result_in_b ? st->off_vals_b : st->off_vals_a));
     if (sgr_render_backward(pb, (const uint32_t *)(image + st->off_ranges), point_list, rec, (const float *)(image + st->off_final_T),
                             (const uint32_t *)(image + st->off_n_contrib), out_color, out_depth, out_alpha, grad_color, grad_depth,
-                            grad_alpha, st->R_alloc, aux_on ? image + st->off_compact : nullptr, aux_on ? image + st->off_ckpt_tc : nullptr,
+                            grad_alpha, grad_color_scale, st->R_alloc, aux_on ? image + st->off_compact : nullptr, aux_on ? image + st->off_ckpt_tc : nullptr,
                             aux_on ? image + st->off_ckpt_da : nullptr, aux_on ? image + st->off_desc : nullptr, grec, part, flags, stream_))
         return 1;
     return sgr_preprocess_backward(pb, radii, pb->shs ? (const uint8_t *)(geom + st->off_clamped) : nullptr, grec, rec, part, flags,

@@ -514,7 +514,8 @@ __global__ __launch_bounds__(kBlock) void render_bwd_kernel(int W, int H, int Tx
                                                             const float *__restrict__ final_T,
                                                             const uint32_t *__restrict__ n_contrib,
                                                             const float *__restrict__ gC, const float *__restrict__ gD,
-                                                            const float *__restrict__ gA, float *__restrict__ grec) {
+                                                            const float *__restrict__ gA, const float *__restrict__ gscale,
+                                                            float *__restrict__ grec) {
     __shared__ float4 sA[kBlock], sB[kBlock], sC[kBlock];
     __shared__ uint32_t sMask[kBlock];
     __shared__ uint32_t sId[kBlock];
@@ -537,7 +538,8 @@ __global__ __launch_bounds__(kBlock) void render_bwd_kernel(int W, int H, int Tx
     const uint32_t last = inside ? n_contrib[vb + pix] : 0u;
     float g0 = 0.f, g1 = 0.f, g2 = 0.f, gd = 0.f, ga = 0.f;
     if (inside) {
-        g0 = gC[vb * 3 + pix]; g1 = gC[vb * 3 + hw + pix]; g2 = gC[vb * 3 + 2 * hw + pix];
+        const float gs = gscale ? *gscale : 1.f;              // optional device scalar on dL/dcolor (a loss weight / upstream scalar)
+        g0 = gs * gC[vb * 3 + pix]; g1 = gs * gC[vb * 3 + hw + pix]; g2 = gs * gC[vb * 3 + 2 * hw + pix];
         if (gD) gd = gD[vb + pix];
         if (gA) ga = gA[vb + pix];
     }
@@ -678,8 +680,8 @@ __global__ __launch_bounds__(kBlock) void render_bwd_bucket_kernel(int W, int H,
                                                                    const float *__restrict__ out_depth,
                                                                    const float *__restrict__ out_alpha,
                                                                    const float *__restrict__ gC, const float *__restrict__ gD,
-                                                                   const float *__restrict__ gA, FwdAux aux,
-                                                                   float4 *__restrict__ part, uint8_t *__restrict__ flags) {
+                                                                   const float *__restrict__ gA, const float *__restrict__ gscale,
+                                                                   FwdAux aux, float4 *__restrict__ part, uint8_t *__restrict__ flags) {
     __shared__ float4 sPixA[4][64];           // per wave: (x, y, n_contrib bits, g0) of pixel p
     __shared__ float4 sPixB[4][64];           //           (g1, g2, gD, gA)
     __shared__ float2 sDyn[4][4][64];         // per wave, per row: (T, Rem) of pixel p at the start of the row
@@ -727,7 +729,8 @@ __global__ __launch_bounds__(kBlock) void render_bwd_bucket_kernel(int W, int H,
         uint32_t last = 0;
         if (inside) {
             last = n_contrib[vb + pix];
-            g0 = gC[vb * 3 + pix]; g1 = gC[vb * 3 + hw + pix]; g2 = gC[vb * 3 + 2 * hw + pix];
+            const float gs = gscale ? *gscale : 1.f;          // optional device scalar on dL/dcolor
+            g0 = gs * gC[vb * 3 + pix]; g1 = gs * gC[vb * 3 + hw + pix]; g2 = gs * gC[vb * 3 + 2 * hw + pix];
             // O = out . g: everything the pixel composited (incl. the T_final*bg term), dotted with the upstream gradient
             O = out_color[vb * 3 + pix] * g0 + out_color[vb * 3 + hw + pix] * g1 + out_color[vb * 3 + 2 * hw + pix] * g2;
             if (HAS_DA) {
@@ -900,9 +903,9 @@ extern "C" int sgr_render_forward(const SgrProblem *pb, const uint32_t *ranges, 
 extern "C" int sgr_render_backward(const SgrProblem *pb, const uint32_t *ranges, const uint32_t *point_list, const float *rec,
                                    const float *final_T, const uint32_t *n_contrib, const float *out_color,
                                    const float *out_depth, const float *out_alpha, const float *grad_color,
-                                   const float *grad_depth, const float *grad_alpha, uint64_t R, const void *aux_compact,
-                                   const void *aux_ckpt_tc, const void *aux_ckpt_da, const void *aux_desc, float *grec,
-                                   float *part, uint32_t *flags, void *stream_) {
+                                   const float *grad_depth, const float *grad_alpha, const float *grad_color_scale, uint64_t R,
+                                   const void *aux_compact, const void *aux_ckpt_tc, const void *aux_ckpt_da, const void *aux_desc,
+                                   float *grec, float *part, uint32_t *flags, void *stream_) {
     if (sgr_validate_problem(pb)) return 1;
     hipStream_t stream = (hipStream_t)stream_;
     const int Tx = (pb->W + SGR_TILE - 1) / SGR_TILE, Ty = (pb->H + SGR_TILE - 1) / SGR_TILE;
@@ -922,17 +925,17 @@ extern "C" int sgr_render_backward(const SgrProblem *pb, const uint32_t *ranges,
         if (grad_depth || grad_alpha)
             hipLaunchKernelGGL(render_bwd_bucket_kernel<true>, dim3(nblocks), dim3(kBlock), 0, stream, pb->W, pb->H, Tx, tiles,
                                (const uint2 *)ranges, (const float4 *)rec, n_contrib, out_color, out_depth, out_alpha, grad_color,
-                               grad_depth, grad_alpha, aux, (float4 *)part, (uint8_t *)flags);
+                               grad_depth, grad_alpha, grad_color_scale, aux, (float4 *)part, (uint8_t *)flags);
         else
             hipLaunchKernelGGL(render_bwd_bucket_kernel<false>, dim3(nblocks), dim3(kBlock), 0, stream, pb->W, pb->H, Tx, tiles,
                                (const uint2 *)ranges, (const float4 *)rec, n_contrib, out_color, out_depth, out_alpha, grad_color,
-                               grad_depth, grad_alpha, aux, (float4 *)part, (uint8_t *)flags);
+                               grad_depth, grad_alpha, grad_color_scale, aux, (float4 *)part, (uint8_t *)flags);
         SGR_CHECK_LAUNCH("render_bwd_bucket_kernel");
         return 0;
     }
     hipLaunchKernelGGL(render_bwd_kernel, dim3(tiles * pb->n_views), dim3(kBlock), 0, stream, pb->W, pb->H, Tx, tiles,
                        (const uint2 *)ranges, point_list, (const float4 *)rec, pb->bg, final_T, n_contrib, grad_color, grad_depth,
-                       grad_alpha, grec);
+                       grad_alpha, grad_color_scale, grec);
     SGR_CHECK_LAUNCH("render_bwd_kernel");
     return 0;
 }

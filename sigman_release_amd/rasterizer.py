@@ -194,7 +194,7 @@ def _forward_impl(means3D, opacities, colors_precomp, shs, cov3D_precomp, scales
 
 
 def _backward_impl(ctx: _Ctx, means3D, opacities, colors_precomp, shs, cov3D_precomp, scales, rotations,
-                   st: BatchedRasterizationSettings, grad_color, grad_depth, grad_alpha, img):
+                   st: BatchedRasterizationSettings, grad_color, grad_depth, grad_alpha, img, grad_color_scale=None):
     L = _cabi.lib()
     S, P, nv, H, W = ctx.dims
     dev = means3D.device
@@ -218,7 +218,7 @@ def _backward_impl(ctx: _Ctx, means3D, opacities, colors_precomp, shs, cov3D_pre
     blobs = ctx.blobs
     _alloc_target["dev"], _alloc_target["blobs"] = dev, blobs
     _cabi.check(L.sgr_rasterize_backward(C.byref(pb), C.byref(ctx.state), _ptr(ctx.radii), _ptr(img[0]), _ptr(img[1]), _ptr(img[2]),
-                                         _ptr(gC), _ptr(gD), _ptr(gA), _ALLOC, None, _ptr(d_means3D), _ptr(d_means2D), _ptr(d_op),
+                                         _ptr(gC), _ptr(gD), _ptr(gA), _ptr(grad_color_scale), _ALLOC, None, _ptr(d_means3D), _ptr(d_means2D), _ptr(d_op),
                                          _ptr(d_col), _ptr(d_sh), _ptr(d_cov), _ptr(d_sc), _ptr(d_rot), _stream(dev)),
                 "sgr_rasterize_backward")
     grec = blobs[3]
@@ -226,7 +226,7 @@ def _backward_impl(ctx: _Ctx, means3D, opacities, colors_precomp, shs, cov3D_pre
     return d_means3D, d_means2D, d_sh, d_col, d_op, d_sc, d_rot, d_cov, grec
 
 
-def _fwd_common(ctx, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, st):
+def _fwd_common(ctx, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, st, epilogue=None):
     # fp32-only op: inputs are cast here, so an enclosing autocast region (gs.py:98) cannot downcast them
     opt = lambda t: None if t is None or t.numel() == 0 else _f32c(t)
     means3D = _f32c(means3D)
@@ -246,15 +246,16 @@ def _fwd_common(ctx, means3D, sh, colors_precomp, opacities, scales, rotations, 
     ctx.has = (sh is not None, colors_precomp is not None, scales is not None, cov3Ds_precomp is not None)
     # the outputs go through save_for_backward (a plain attribute would create a ctx -> output -> grad_fn -> ctx cycle and keep
     # every step's buffers alive until the garbage collector runs)
-    ctx.save_for_backward(means3D, opacities, colors_precomp, sh, cov3Ds_precomp, scales, rotations, color, depth, alpha)
+    extra = epilogue(color) if epilogue is not None else ()          # fused image-loss epilogue: tensors it needs in backward
+    ctx.save_for_backward(means3D, opacities, colors_precomp, sh, cov3Ds_precomp, scales, rotations, color, depth, alpha, *extra)
     return color, radii, depth, alpha
 
 
-def _bwd_common(ctx, grad_color, grad_depth, grad_alpha):
-    means3D, opacities, colors_precomp, sh, cov3Ds_precomp, scales, rotations, color, depth, alpha = ctx.saved_tensors
+def _bwd_common(ctx, grad_color, grad_depth, grad_alpha, grad_color_scale=None):
+    means3D, opacities, colors_precomp, sh, cov3Ds_precomp, scales, rotations, color, depth, alpha = ctx.saved_tensors[:10]
     d_means3D, d_means2D, d_sh, d_col, d_op, d_sc, d_rot, d_cov, _ = _backward_impl(
         ctx.sgr, means3D, opacities, colors_precomp, sh, cov3Ds_precomp, scales, rotations, ctx.st, grad_color, grad_depth,
-        grad_alpha, (color, depth, alpha))
+        grad_alpha, (color, depth, alpha), grad_color_scale)
     has_sh, has_col, has_sr, has_cov = ctx.has
     return (d_means3D, d_means2D if ctx.has_means2D else None, d_sh if has_sh else None, d_col if has_col else None, d_op.unsqueeze(-1),
             d_sc if has_sr else None, d_rot if has_sr else None, d_cov if has_cov else None)
@@ -283,6 +284,55 @@ def rasterize_gaussians_batched(means3D, means2D, sh, colors_precomp, opacities,
     """
     return _RasterizeGaussiansBatched.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                                             raster_settings)
+
+
+class _RasterizeL1Batched(torch.autograd.Function):
+    """Rasterizer + fused clamp/L1 image loss as ONE autograd node: the loss kernel runs right behind the
+    compositing kernel and leaves dL/dcolor for the backward, which takes the upstream scalar dL/dloss as a device pointer
+    (no elementwise kernel, no second Python autograd node).  == clamped_l1_loss(rasterize_gaussians_batched(...)[0], ...)."""
+
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, st, target, mask, weight):
+        L = _cabi.lib()
+        out = {}
+
+        def epilogue(color):
+            nv, _, H, W = color.shape
+            tgt = _f32c(target)
+            msk = None if mask is None else _f32c(mask)
+            gimg = torch.empty_like(color)
+            sums = torch.empty(nv + 1, dtype=torch.float32, device=color.device)      # [per-view partial sums | total]
+            p = sums.data_ptr()
+            _cabi.check(L.sgr_clamped_l1_loss(nv, H, W, color.data_ptr(), _ptr(tgt), _ptr(msk), float(weight), gimg.data_ptr(),
+                                              p, p + 4 * nv, _stream(color.device)), "sgr_clamped_l1_loss")
+            out["sums"] = sums
+            return (gimg,)
+
+        color, radii, depth, alpha = _fwd_common(ctx, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, st,
+                                                 epilogue)
+        ctx.has_means2D = means2D is not None
+        nv = color.shape[0]
+        loss, per_view = out["sums"][nv], out["sums"][:nv]
+        ctx.mark_non_differentiable(radii, per_view)
+        return loss, per_view, color, radii, depth, alpha
+
+    @staticmethod
+    def backward(ctx, g_loss, g_per_view, g_color, g_radii, g_depth, g_alpha):
+        gimg = ctx.saved_tensors[10]
+        if g_loss is None and g_color is None:
+            g_color, scale = torch.zeros_like(gimg), None
+        elif g_color is None:
+            g_color, scale = gimg, g_loss.reshape(1).to(torch.float32)        # the common case: only the loss is used
+        else:
+            g_color, scale = (g_color if g_loss is None else g_color + gimg * g_loss), None
+        return _bwd_common(ctx, g_color, g_depth, g_alpha, scale) + (None, None, None, None)
+
+
+def rasterize_l1_loss_batched(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                              raster_settings: BatchedRasterizationSettings, target, mask=None, weight: float = 1.0):
+    """-> (loss, per_view_loss [n_views], color, radii, depth, alpha);  loss = weight * sum(mask * |clamp(color, 0, 1) - target|)."""
+    return _RasterizeL1Batched.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                                     raster_settings, target, mask, weight)
 
 
 class _RasterizeGaussians(torch.autograd.Function):

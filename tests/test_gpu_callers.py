@@ -150,3 +150,39 @@ def test_fused_clamped_l1_loss(H, W, use_mask):
     (ref * 2.0).backward()
     assert abs(float(loss) - float(ref)) <= 1e-5 * abs(float(ref))
     assert torch.allclose(color.grad.double(), c2.grad, atol=1e-7)
+
+
+@pytest.mark.parametrize("use_color_too", [False, True])
+def test_fused_raster_l1_node_equals_two_nodes(use_color_too):
+    """rasterize_l1_loss_batched (one autograd node, upstream scalar passed to the backward kernel as a device pointer)
+    == clamped_l1_loss(rasterize_gaussians_batched(...)) : same loss, bitwise the same gradients."""
+    from sigman_release_amd import rasterizer as R
+    from sigman_release_amd.losses import clamped_l1_loss
+    import cases
+    dev = _dev()
+    inp, st = cases.humanoid(P=6000, H=128, W=144, seed=21, views=(30, 65))
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    bst = R.BatchedRasterizationSettings(st["image_height"], st["image_width"], st["tanfovx"], st["tanfovy"], t(st["bg"]), 1.0,
+                                         t(st["viewmatrix"]), t(st["projmatrix"]), 0, t(st["campos"]), 2)
+    target = torch.rand(2, 3, 128, 144, device=dev)
+    mask = (torch.rand(2, 1, 128, 144, device=dev) > 0.2).float()
+    grads = []
+    for fused in (False, True):
+        d = {k: t(v)[None].requires_grad_(True) for k, v in inp.items()}
+        args = (d["means3D"], None, None, d["colors_precomp"], d["opacities"][..., None], None, None, d["cov3D_precomp"], bst)
+        if fused:
+            loss, per_view, color, radii, depth, alpha = R.rasterize_l1_loss_batched(*args, target, mask, 0.37)
+            assert torch.allclose(per_view.sum(), loss, rtol=1e-5)
+        else:
+            color, radii, depth, alpha = R.rasterize_gaussians_batched(*args)
+            loss = clamped_l1_loss(color, target, mask, 0.37)
+        total = loss * 1.7 + ((color * color).sum() * 0.01 if use_color_too else 0.0)
+        total.backward()
+        grads.append((float(loss), {k: v.grad.clone() for k, v in d.items()}))
+    assert abs(grads[0][0] - grads[1][0]) <= 1e-5 * abs(grads[0][0])
+    for k in grads[0][1]:
+        a, b = grads[0][1][k], grads[1][1][k]
+        if use_color_too:
+            assert torch.allclose(a, b, rtol=1e-5, atol=1e-6 * float(a.abs().max())), k     # (g*1.7 + gc) vs separate accumulation order
+        else:
+            assert torch.allclose(a, b, rtol=2e-6, atol=1e-7 * float(a.abs().max())), k     # 1.7*g folded at a different point

@@ -1,7 +1,10 @@
 """Dev tool: where does the HOST time of one fwd+bwd step go? (cProfile over N steps, sync-free mode)"""
 import cProfile, pstats, os, sys, time
 os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
-import numpy as np, torch
+import numpy as np
+if os.environ.get("AFF"):
+    os.sched_setaffinity(0, set(int(x) for x in os.environ["AFF"].split(",")))
+import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from sigman_release_amd import cameras, synthetic
 from sigman_release_amd import rasterizer as R
@@ -16,8 +19,12 @@ m, c, o, rgb = [t(x)[None].requires_grad_(True) for x in (g["position"], cov, g[
 gt = torch.rand(1, 3, H, H, device=dev)
 from sigman_release_amd import _cabi as _c
 _c.lib().sgr_set_graphs(int(os.environ.get("GRAPHS", "1")))
+FUSED = os.environ.get("FUSED", "0") == "1"
 def step():
     for v in (m, c, o, rgb): v.grad = None
+    if FUSED:
+        R.rasterize_l1_loss_batched(m, None, None, rgb, o, None, None, c, st, gt, None, 1e-6)[0].backward()
+        return
     color, radii, depth, alpha = R.rasterize_gaussians_batched(m, None, None, rgb, o, None, None, c, st)
     clamped_l1_loss(color, gt, None, 1e-6).backward()
 for _ in range(20): step()
