@@ -142,6 +142,7 @@ def main():
                                            None, norm)[0]
 
     leaves = {k: v.clone().requires_grad_(True) for k, v in subj.items()}
+    one = torch.ones((), device=dev)
     packed = parallel.pack_attributes(subj["means3D"], subj["cov3D"], subj["opacity"], subj["rgb"])
 
     def step():
@@ -149,7 +150,7 @@ def main():
             for v in leaves.values():
                 v.grad = None
             loss = render_loss(leaves["means3D"], leaves["cov3D"], leaves["opacity"], leaves["rgb"])
-            loss.backward()
+            loss.backward(one)              # explicit seed: autograd would otherwise launch a ones_like fill kernel every step
             return loss
         loss, grad = parallel.view_parallel_step(packed, all_views, lambda m, c, o, r, mine: render_loss(m, c, o, r, mine))
         return loss

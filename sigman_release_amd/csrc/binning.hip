@@ -288,7 +288,9 @@ template <int ITEMS>
 __global__ __launch_bounds__(kThreads) void wide_downsweep_kernel(const uint64_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
                                                                   uint64_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, uint32_t n_host,
                                                                   const uint64_t *__restrict__ n_dev, int shift, uint32_t nblocks,
-                                                                  const uint32_t *__restrict__ hist, const uint32_t *__restrict__ totals) {
+                                                                  const uint32_t *__restrict__ hist, const uint32_t *__restrict__ totals,
+                                                                  uint2 *__restrict__ ranges, uint32_t tiles_total,
+                                                                  uint32_t *__restrict__ worklist) {
     const uint32_t n = n_dev ? (uint32_t)min((uint64_t)n_host, *n_dev) : n_host;
     __shared__ uint32_t digit_base[kWide];
     __shared__ uint32_t wave_cnt[4][kWide];
@@ -313,6 +315,12 @@ __global__ __launch_bounds__(kThreads) void wide_downsweep_kernel(const uint64_t
         for (int j = 0; j < PER; j++) {
             const uint32_t d = t * PER + j;
             digit_base[d] = run + hist[(size_t)d * nblocks + blockIdx.x];
+            // F5 for free: the digit IS the tile id, so the scanned totals are the tile ranges (and the occupied tiles the
+            // per-tile sort's worklist, whose counter the duplicate kernel cleared)
+            if (ranges && blockIdx.x == 0 && d < tiles_total) {
+                ranges[d] = v[j] ? make_uint2(run, run + v[j]) : make_uint2(0u, 0u);
+                if (v[j] && worklist) worklist[1 + atomicAdd(&worklist[0], 1u)] = d;
+            }
             run += v[j];
 #pragma unroll
             for (int w = 0; w < 4; w++) wave_cnt[w][d] = 0;
@@ -580,15 +588,25 @@ __device__ __forceinline__ void seg_sort_passes(uint32_t n, uint32_t *ka, uint32
 // launch, one workgroup per tile, appends the long tiles to a worklist that a fixed-size large-class grid then drains)
 // (a launch with few tiles -- one 512^2 view -- skips the small class: tile_ranges_kernel puts every occupied tile on the worklist
 // and the large-class workgroups take one each, all resident at once, so the two classes no longer run back to back)
+struct SortPrep {               // optional piggy-back job of the large-class launch's spare last workgroup (sgr_fwd_prepare)
+    uint2 *desc; size_t n_desc; uint32_t *order; uint32_t tiles_total; int enabled;
+};
+
 template <int NT, int CAP, bool SMALL_CLASS>
 __global__ __launch_bounds__(NT) void tile_sort_kernel(const uint2 *__restrict__ ranges, uint64_t *__restrict__ src_keys,
                                                        uint32_t *__restrict__ src_vals, uint64_t *__restrict__ dst_keys,
-                                                       uint32_t *__restrict__ dst_vals, uint32_t *__restrict__ worklist /*[0]=count, [1..]=tiles*/) {
+                                                       uint32_t *__restrict__ dst_vals, uint32_t *__restrict__ worklist /*[0]=count, [1..]=tiles*/,
+                                                       SortPrep prep) {
     __shared__ uint32_t ka[CAP], va[CAP], kb[CAP], vb[CAP];
     __shared__ uint32_t hist[kRadix], digit_base[kRadix], wave_cnt[NT / 64][kRadix], wtot[4];
     const uint32_t t = threadIdx.x;
+    uint32_t nsort = gridDim.x;
+    if (!SMALL_CLASS && NT == 1024 && prep.enabled) {
+        nsort = gridDim.x - 1;
+        if (blockIdx.x == nsort) { sgr_fwd_prepare(ranges, prep.tiles_total, prep.desc, prep.n_desc, prep.order, hist); return; }
+    }
     const uint32_t nwork = SMALL_CLASS ? 1u : worklist[0];
-    for (uint32_t wi = SMALL_CLASS ? 0u : blockIdx.x; wi < nwork; wi += gridDim.x) {
+    for (uint32_t wi = SMALL_CLASS ? 0u : blockIdx.x; wi < nwork; wi += nsort) {
     const uint32_t tile_id = SMALL_CLASS ? blockIdx.x : worklist[1 + wi];
     const uint2 range = ranges[tile_id];
     const uint32_t n = range.y - range.x;
@@ -665,7 +683,8 @@ extern "C" size_t sgr_bin_workspace_bytes(uint64_t R, uint64_t tiles_total) {
 int sgr_bin_ex(const SgrProblem *pb, float *rec, const int32_t *radii, const uint32_t *rect,
                const uint32_t *block_offsets, uint64_t R, const uint64_t *num_rendered_dev, uint64_t *keys_a,
                uint64_t *keys_b, uint32_t *vals_a, uint32_t *vals_b, void *workspace, size_t workspace_bytes,
-               uint32_t *ranges, int32_t *result_in_b_host, bool self_scan, uint64_t *nr_host, void *stream_) {
+               uint32_t *ranges, int32_t *result_in_b_host, bool self_scan, uint64_t *nr_host, void *prep_desc, size_t prep_n_desc,
+               uint32_t *prep_order, int *prep_done, void *stream_) {
     if (sgr_validate_problem(pb)) return 1;
     hipStream_t stream = (hipStream_t)stream_;
     const int Tx = (pb->W + SGR_TILE - 1) / SGR_TILE, Ty = (pb->H + SGR_TILE - 1) / SGR_TILE;
@@ -673,6 +692,7 @@ int sgr_bin_ex(const SgrProblem *pb, float *rec, const int32_t *radii, const uin
     if (tiles_total >= (1ull << 32)) { sgr_set_error("too many tiles (%llu)", (unsigned long long)tiles_total); return 1; }
     if (R > 0xFFFFFFF0ull) { sgr_set_error("num_rendered %llu exceeds the 32-bit instance index", (unsigned long long)R); return 1; }
     if (result_in_b_host) *result_in_b_host = 0;
+    if (prep_done) *prep_done = 0;
     const bool fold_clear = R > 0 && pb->P > 0 && tiles_total * 2 <= (1u << 20);     // small: cleared by the duplicate kernel
     if (!fold_clear) SGR_CHECK_HIP(hipMemsetAsync(ranges, 0, tiles_total * 2 * sizeof(uint32_t), stream));
     if (R == 0 || pb->P == 0) return 0;
@@ -717,7 +737,8 @@ int sgr_bin_ex(const SgrProblem *pb, float *rec, const int32_t *radii, const uin
         if (wide) {
             hipLaunchKernelGGL(wide_upsweep_kernel<kItemsSmall>, dim3(nblocks), dim3(kThreads), 0, stream, kin, n, num_rendered_dev, 32, nblocks, hist);
             hipLaunchKernelGGL(wide_rowscan_kernel, dim3(kWide / 4), dim3(kThreads), 0, stream, hist, nblocks, hist + (size_t)nblocks * kWide);
-            hipLaunchKernelGGL(wide_downsweep_kernel<kItemsSmall>, dim3(nblocks), dim3(kThreads), 0, stream, kin, vin, kout, vout, n, num_rendered_dev, 32, nblocks, hist, hist + (size_t)nblocks * kWide);
+            hipLaunchKernelGGL(wide_downsweep_kernel<kItemsSmall>, dim3(nblocks), dim3(kThreads), 0, stream, kin, vin, kout, vout, n, num_rendered_dev, 32, nblocks, hist, hist + (size_t)nblocks * kWide,
+                               (uint2 *)ranges, (uint32_t)tiles_total, worklist);
             SGR_CHECK_LAUNCH("wide tile-bit pass");
             uint64_t *tk = kin; kin = kout; kout = tk;
             uint32_t *tv = vin; vin = vout; vout = tv;
@@ -734,17 +755,23 @@ int sgr_bin_ex(const SgrProblem *pb, float *rec, const int32_t *radii, const uin
             uint32_t *tv = vin; vin = vout; vout = tv;
         }
         }
-        { SgrProfScope _pr(SGR_K_RANGES, stream);
+        if (!wide) {                                            // (the wide pass wrote the ranges and the worklist itself)
+        SgrProfScope _pr(SGR_K_RANGES, stream);
         hipLaunchKernelGGL(tile_ranges_kernel, dim3((n + kThreads - 1) / kThreads), dim3(kThreads), 0, stream, kin, n, num_rendered_dev, (uint2 *)ranges, worklist, all_large ? 1 : 0);
         SGR_CHECK_LAUNCH("tile_ranges_kernel");
         }
         { SgrProfScope _ps(SGR_K_SORT, stream);
         const uint32_t big_grid = (uint32_t)(tiles_total < 512 ? tiles_total : 512);
+        SortPrep sp;
+        sp.desc = (uint2 *)prep_desc; sp.n_desc = prep_n_desc; sp.order = prep_order; sp.tiles_total = (uint32_t)tiles_total;
+        sp.enabled = (prep_order || prep_desc) ? 1 : 0;
+        SortPrep none = sp; none.enabled = 0;
         if (!all_large)
             hipLaunchKernelGGL((tile_sort_kernel<256, kSegCapSmall, true>), dim3((uint32_t)tiles_total), dim3(256), 0, stream,
-                               (const uint2 *)ranges, kin, vin, kout, vout, worklist);
-        hipLaunchKernelGGL((tile_sort_kernel<1024, kSegCapLarge, false>), dim3(big_grid), dim3(1024), 0, stream,
-                           (const uint2 *)ranges, kin, vin, kout, vout, worklist);
+                               (const uint2 *)ranges, kin, vin, kout, vout, worklist, none);
+        hipLaunchKernelGGL((tile_sort_kernel<1024, kSegCapLarge, false>), dim3(big_grid + (sp.enabled ? 1u : 0u)), dim3(1024), 0, stream,
+                           (const uint2 *)ranges, kin, vin, kout, vout, worklist, sp);
+        if (sp.enabled && prep_done) *prep_done = 1;
         SGR_CHECK_LAUNCH("tile_sort_kernel");
         }
         if (result_in_b_host) *result_in_b_host = (kout == keys_b) ? 1 : 0;
@@ -800,5 +827,5 @@ extern "C" int sgr_bin(const SgrProblem *pb, float *rec, const int32_t *radii, c
                        uint64_t *keys_b, uint32_t *vals_a, uint32_t *vals_b, void *workspace, size_t workspace_bytes,
                        uint32_t *ranges, int32_t *result_in_b_host, void *stream_) {
     return sgr_bin_ex(pb, rec, radii, rect, block_offsets, R, num_rendered_dev, keys_a, keys_b, vals_a, vals_b, workspace,
-                      workspace_bytes, ranges, result_in_b_host, false, nullptr, stream_);
+                      workspace_bytes, ranges, result_in_b_host, false, nullptr, nullptr, 0, nullptr, nullptr, stream_);
 }

@@ -43,7 +43,12 @@ int sgr_preprocess_forward_ex(const SgrProblem *pb, float *rec, int32_t *radii, 
                               uint64_t *num_rendered, uint64_t capacity, bool skip_scan, void *stream_);
 int sgr_bin_ex(const SgrProblem *pb, float *rec, const int32_t *radii, const uint32_t *rect, const uint32_t *block_offsets, uint64_t R,
                const uint64_t *num_rendered_dev, uint64_t *keys_a, uint64_t *keys_b, uint32_t *vals_a, uint32_t *vals_b, void *workspace,
-               size_t workspace_bytes, uint32_t *ranges, int32_t *result_in_b_host, bool self_scan, uint64_t *nr_host, void *stream_);
+               size_t workspace_bytes, uint32_t *ranges, int32_t *result_in_b_host, bool self_scan, uint64_t *nr_host, void *prep_desc,
+               size_t prep_n_desc, uint32_t *prep_order, int *prep_done, void *stream_);
+int sgr_render_forward_wants_prepare(const SgrProblem *pb, uint64_t R, bool use_aux, size_t *n_desc_out);
+int sgr_render_forward_ex(const SgrProblem *pb, const uint32_t *ranges, const uint32_t *point_list, const float *rec, float *out_color,
+                          float *out_depth, float *out_alpha, float *final_T, uint32_t *n_contrib, uint64_t R, void *aux_compact,
+                          void *aux_ckpt_tc, void *aux_ckpt_da, void *aux_desc, uint32_t *aux_order, bool prepared, void *stream_);
 int sgr_get_forward_mode();
 
 // ROCm 7.2's hipGraph "packet capture" (pre-recorded AQL packets, on by default) is not safe next to large host<->device
@@ -79,18 +84,24 @@ static int forward_launches(const SgrProblem *pb, uint64_t capacity, uint64_t R,
         if (nr_pinned_host && !self_scan) SGR_CHECK_HIP(hipMemcpyAsync(nr_pinned_host, num_rendered, 16, hipMemcpyDeviceToHost, stream));
     }
     int32_t in_b = 0;
+    const bool aux_on = st->with_aux != 0;
+    // the forward's one-workgroup prepare step (tile order + descriptor clear) rides in the tile-sort launch when there is one
+    size_t n_desc = 0;
+    const bool want_prep = sgr_render_forward_wants_prepare(pb, R, aux_on, &n_desc) != 0;
+    int prep_done = 0;
     if (sgr_bin_ex(pb, rec, out_radii, rect, block_offsets, R, capacity > 0 ? num_rendered : nullptr, (uint64_t *)(binning + st->off_keys_a),
                    (uint64_t *)(binning + st->off_keys_b), (uint32_t *)(binning + st->off_vals_a), (uint32_t *)(binning + st->off_vals_b),
                    binning + st->off_sort_ws, (size_t)sgr_bin_workspace_bytes(R, (uint64_t)((pb->W + SGR_TILE - 1) / SGR_TILE) * ((pb->H + SGR_TILE - 1) / SGR_TILE) * pb->n_views),
-                   (uint32_t *)(image + st->off_ranges), &in_b, self_scan, self_scan ? nr_pinned_host : nullptr, stream)) return 1;
+                   (uint32_t *)(image + st->off_ranges), &in_b, self_scan, self_scan ? nr_pinned_host : nullptr,
+                   want_prep && aux_on ? image + st->off_desc : nullptr, n_desc, want_prep ? (uint32_t *)(image + st->off_order) : nullptr,
+                   &prep_done, stream)) return 1;
     st->result_in_b = in_b;
     const uint32_t *point_list = (const uint32_t *)(binning + (in_b ? st->off_vals_b : st->off_vals_a));
-    const bool aux_on = st->with_aux != 0;
-    return sgr_render_forward(pb, (const uint32_t *)(image + st->off_ranges), point_list, rec, out_color, out_depth, out_alpha,
+    return sgr_render_forward_ex(pb, (const uint32_t *)(image + st->off_ranges), point_list, rec, out_color, out_depth, out_alpha,
                               (float *)(image + st->off_final_T), (uint32_t *)(image + st->off_n_contrib), R,
                               aux_on ? image + st->off_compact : nullptr, aux_on ? image + st->off_ckpt_tc : nullptr,
                               aux_on ? image + st->off_ckpt_da : nullptr, aux_on ? image + st->off_desc : nullptr,
-                              (uint32_t *)(image + st->off_order), stream);
+                              (uint32_t *)(image + st->off_order), prep_done != 0, stream);
 }
 
 extern "C" int sgr_rasterize_forward(const SgrProblem *pb, uint64_t capacity, int32_t with_aux, sgr_alloc_fn alloc, void *user,

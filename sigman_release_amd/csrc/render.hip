@@ -478,28 +478,8 @@ __global__ __launch_bounds__(kSegThreads, 4) void render_fwd_seg_kernel(int W, i
 // -------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void fwd_prepare_kernel(const uint2 *__restrict__ ranges, uint32_t tiles_total, uint2 *__restrict__ desc,
                                                            size_t n_desc, uint32_t *__restrict__ order) {
-    __shared__ uint32_t sHist[33], sCur[33];
-    const uint32_t t = threadIdx.x;
-    if (desc) for (size_t i = t; i < n_desc; i += 1024) desc[i] = make_uint2(0u, 0u);
-    if (!order) return;
-    if (t < 33) sHist[t] = 0;
-    __syncthreads();
-    // class 0 = longest lists ... class 31 = 1..127 entries, class 32 = empty tiles (they still have to write the background)
-    for (uint32_t tile = t; tile < tiles_total; tile += 1024) {
-        const uint2 r = ranges[tile];
-        atomicAdd(&sHist[r.y > r.x ? 31u - min(31u, (r.y - r.x) >> 7) : 32u], 1u);
-    }
-    __syncthreads();
-    if (t == 0) {
-        uint32_t run = 0;
-        for (int c = 0; c < 33; c++) { sCur[c] = run; run += sHist[c]; }
-        order[0] = run;                                          // == tiles_total
-    }
-    __syncthreads();
-    for (uint32_t tile = t; tile < tiles_total; tile += 1024) {
-        const uint2 r = ranges[tile];
-        order[1u + atomicAdd(&sCur[r.y > r.x ? 31u - min(31u, (r.y - r.x) >> 7) : 32u], 1u)] = tile;
-    }
+    __shared__ uint32_t sTmp[66];
+    sgr_fwd_prepare(ranges, tiles_total, desc, n_desc, order, sTmp);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -853,10 +833,19 @@ static FwdAux make_aux(void *compact, void *ckpt_tc, void *ckpt_da, void *desc, 
     return a;
 }
 
-extern "C" int sgr_render_forward(const SgrProblem *pb, const uint32_t *ranges, const uint32_t *point_list, const float *rec,
-                                  float *out_color, float *out_depth, float *out_alpha, float *final_T, uint32_t *n_contrib,
-                                  uint64_t R, void *aux_compact, void *aux_ckpt_tc, void *aux_ckpt_da, void *aux_desc,
-                                  uint32_t *aux_order, void *stream_) {
+// does this launch want the one-workgroup prepare step (tile order + descriptor clear), and how many descriptors are there?
+int sgr_render_forward_wants_prepare(const SgrProblem *pb, uint64_t R, bool use_aux, size_t *n_desc_out) {
+    const uint64_t tiles_total = (uint64_t)((pb->W + SGR_TILE - 1) / SGR_TILE) * ((pb->H + SGR_TILE - 1) / SGR_TILE) * pb->n_views;
+    const size_t n_desc = use_aux ? (size_t)4 * sgr_bucket_slots(R, tiles_total) : 0;
+    if (n_desc_out) *n_desc_out = n_desc;
+    const bool seg = sgr_fwd_mode == 2 || (sgr_fwd_mode == 0 && tiles_total <= 2048);
+    return seg && n_desc <= (1u << 17) ? 1 : 0;
+}
+
+int sgr_render_forward_ex(const SgrProblem *pb, const uint32_t *ranges, const uint32_t *point_list, const float *rec,
+                          float *out_color, float *out_depth, float *out_alpha, float *final_T, uint32_t *n_contrib,
+                          uint64_t R, void *aux_compact, void *aux_ckpt_tc, void *aux_ckpt_da, void *aux_desc,
+                          uint32_t *aux_order, bool prepared, void *stream_) {
     if (sgr_validate_problem(pb)) return 1;
     const int Tx = (pb->W + SGR_TILE - 1) / SGR_TILE, Ty = (pb->H + SGR_TILE - 1) / SGR_TILE;
     const uint32_t tiles = (uint32_t)Tx * Ty;
@@ -869,9 +858,9 @@ extern "C" int sgr_render_forward(const SgrProblem *pb, const uint32_t *ranges, 
     const bool seg = sgr_fwd_mode == 2 || (sgr_fwd_mode == 0 && tiles_total <= 2048);
     const size_t n_desc = use_aux ? (size_t)4 * aux.NS : 0;
     const bool prep = seg && (aux_order || (use_aux && n_desc <= (1u << 17)));     // one workgroup orders the tiles and clears the descriptors
-    if (use_aux && !(prep && n_desc <= (1u << 17))) SGR_CHECK_HIP(hipMemsetAsync(aux_desc, 0, n_desc * sizeof(uint2), stream));
+    if (use_aux && !(prep && n_desc <= (1u << 17)) && !prepared) SGR_CHECK_HIP(hipMemsetAsync(aux_desc, 0, n_desc * sizeof(uint2), stream));
     SgrProfScope _p(SGR_K_RENDER_FWD, stream);
-    if (prep) {
+    if (prep && !prepared) {                                    // (prepared: the tile-sort launch's spare workgroup already did it)
         hipLaunchKernelGGL(fwd_prepare_kernel, dim3(1), dim3(1024), 0, stream, (const uint2 *)ranges, (uint32_t)tiles_total,
                            (use_aux && n_desc <= (1u << 17)) ? (uint2 *)aux_desc : (uint2 *)nullptr, n_desc, aux_order);
         SGR_CHECK_LAUNCH("fwd_prepare_kernel");
@@ -898,6 +887,14 @@ extern "C" int sgr_render_forward(const SgrProblem *pb, const uint32_t *ranges, 
                            final_T, n_contrib, aux);
     SGR_CHECK_LAUNCH("render_fwd_kernel");
     return 0;
+}
+
+extern "C" int sgr_render_forward(const SgrProblem *pb, const uint32_t *ranges, const uint32_t *point_list, const float *rec,
+                                  float *out_color, float *out_depth, float *out_alpha, float *final_T, uint32_t *n_contrib,
+                                  uint64_t R, void *aux_compact, void *aux_ckpt_tc, void *aux_ckpt_da, void *aux_desc,
+                                  uint32_t *aux_order, void *stream_) {
+    return sgr_render_forward_ex(pb, ranges, point_list, rec, out_color, out_depth, out_alpha, final_T, n_contrib, R, aux_compact,
+                                 aux_ckpt_tc, aux_ckpt_da, aux_desc, aux_order, false, stream_);
 }
 
 extern "C" int sgr_render_backward(const SgrProblem *pb, const uint32_t *ranges, const uint32_t *point_list, const float *rec,
