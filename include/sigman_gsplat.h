@@ -96,12 +96,12 @@ typedef struct SgrForwardState {
     uint64_t R_alloc;            /* size of the binning buffers in tile instances: exact num_rendered, or the capacity */
     uint64_t true_rendered;      /* exact mode: num_rendered; sync-free mode: ~0 (read nr_pinned_host after nr_event) */
     uint64_t NS;                 /* bucket slots per quadrant */
-    int32_t with_aux, result_in_b;
+    int32_t with_aux, result_in_b, flags_cleared, _pad;
     void *geom, *binning, *image;
     uint64_t geom_bytes, binning_bytes, image_bytes;
     uint64_t off_rec, off_rect, off_clamped, off_block_offsets, off_num_rendered;               /* in geom   */
     uint64_t off_keys_a, off_keys_b, off_vals_a, off_vals_b, off_sort_ws;                        /* in binning */
-    uint64_t off_ranges, off_final_T, off_n_contrib, off_compact, off_ckpt_tc, off_ckpt_da, off_desc, off_order;   /* in image */
+    uint64_t off_ranges, off_final_T, off_n_contrib, off_compact, off_ckpt_tc, off_ckpt_da, off_desc, off_order, off_flags;   /* in image */
 } SgrForwardState;
 
 /*
@@ -110,11 +110,13 @@ typedef struct SgrForwardState {
  * capacity > 0: sync-free mode; binning buffers sized for `capacity` instances; the true count is copied asynchronously to
  *               nr_pinned_host[0] (and [1] = overflow flag) and `nr_event` (a hipEvent_t, may be NULL) is recorded right after.
  * with_aux != 0 also records what the bucket-parallel backward needs.
+ * caller_clear / caller_clear_bytes: optional device buffer (multiple of 4 bytes) that the call zeroes on the side of its own
+ * kernels (no extra launch): the accumulators of a loss kernel the caller runs right behind the forward.
  * Outputs: out_color [n_views,3,H,W], out_depth/out_alpha [n_views,1,H,W], out_radii i32 [n_views,P].
  */
 int sgr_rasterize_forward(const SgrProblem *pb, uint64_t capacity, int32_t with_aux, sgr_alloc_fn alloc, void *user,
                           float *out_color, float *out_depth, float *out_alpha, int32_t *out_radii, uint64_t *nr_pinned_host,
-                          void *nr_event, SgrForwardState *state, void *stream);
+                          void *nr_event, void *caller_clear, uint64_t caller_clear_bytes, SgrForwardState *state, void *stream);
 
 /*
  * == upstream _C.rasterize_gaussians_backward (reached from train_vae.py:166).  Gradient outputs as in
@@ -259,10 +261,12 @@ int sgr_cov3d_backward(int32_t n, const float *scale_raw, const float *rotation,
  *   loss_per_view[v] = weight * sum_{c,p} mask * |clamp(color,0,1) - target|      (zeroed by the call)
  *   grad_color       = weight * mask * sign(clamp(color) - target) * 1[0 < color < 1]
  *   loss_total       = sum_v loss_per_view[v]   (optional, may be NULL; zeroed by the call; saves the caller a reduction launch)
+ * sums_already_zero != 0: the caller guarantees both accumulators are zero (e.g. cleared by sgr_rasterize_forward's caller_clear)
  * color/target/grad_color [n_views,3,H,W]; mask [n_views,1,H,W] or NULL.
  */
 int sgr_clamped_l1_loss(int32_t n_views, int32_t H, int32_t W, const float *color, const float *target, const float *mask,
-                        float weight, float *grad_color, float *loss_per_view, float *loss_total, void *stream);
+                        float weight, float *grad_color, float *loss_per_view, float *loss_total, int32_t sums_already_zero,
+                        void *stream);
 
 /* ---- optional per-kernel profiler (HIP events on the launch stream; used by bench.py) -------- */
 enum {

@@ -29,11 +29,12 @@ class SgrProblem(C.Structure):
 
 class SgrForwardState(C.Structure):
     _fields_ = [("R_alloc", C.c_uint64), ("true_rendered", C.c_uint64), ("NS", C.c_uint64), ("with_aux", C.c_int32), ("result_in_b", C.c_int32),
+                ("flags_cleared", C.c_int32), ("_pad", C.c_int32),
                 ("geom", C.c_void_p), ("binning", C.c_void_p), ("image", C.c_void_p),
                 ("geom_bytes", C.c_uint64), ("binning_bytes", C.c_uint64), ("image_bytes", C.c_uint64)] + \
                [(n, C.c_uint64) for n in ("off_rec", "off_rect", "off_clamped", "off_block_offsets", "off_num_rendered", "off_keys_a",
                                           "off_keys_b", "off_vals_a", "off_vals_b", "off_sort_ws", "off_ranges", "off_final_T",
-                                          "off_n_contrib", "off_compact", "off_ckpt_tc", "off_ckpt_da", "off_desc", "off_order")]
+                                          "off_n_contrib", "off_compact", "off_ckpt_tc", "off_ckpt_da", "off_desc", "off_order", "off_flags")]
 
 
 ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_int32, C.c_size_t)
@@ -43,7 +44,8 @@ _SIGNATURES = {
     "sgr_last_error": (C.c_char_p, []),
     "sgr_preprocess_blocks_per_view": (C.c_int32, [C.c_int32]),
     "sgr_rasterize_forward": (C.c_int, [C.POINTER(SgrProblem), C.c_uint64, C.c_int32, ALLOC_FN, C.c_void_p, C.c_void_p, C.c_void_p,
-                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(SgrForwardState), C.c_void_p]),
+                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
+                                        C.POINTER(SgrForwardState), C.c_void_p]),
     "sgr_rasterize_backward": (C.c_int, [C.POINTER(SgrProblem), C.POINTER(SgrForwardState)] + [C.c_void_p] * 8 + [ALLOC_FN, C.c_void_p]
                                + [C.c_void_p] * 9),
     "sgr_preprocess_forward": (C.c_int, [C.POINTER(SgrProblem)] + [C.c_void_p] * 6 + [C.c_uint64, C.c_void_p]),
@@ -66,7 +68,7 @@ _SIGNATURES = {
     "sgr_cov3d_forward": (C.c_int, [C.c_int32] + [C.c_void_p] * 5),
     "sgr_cov3d_backward": (C.c_int, [C.c_int32] + [C.c_void_p] * 7),
     "sgr_clamped_l1_loss": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p,
-                                      C.c_void_p, C.c_void_p, C.c_void_p]),
+                                      C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "sgr_prof_configure": (C.c_int, [C.c_uint32]),
     "sgr_prof_collect": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_uint32)]),
 }

@@ -30,8 +30,8 @@ struct DupExtra {
     uint64_t *num_rendered;             // [2] device counter + overflow flag (self-scan mode)
     uint64_t *nr_host;                  // optional pinned host copy of the same
     unsigned long long capacity;
-    uint32_t *zero_ptr;                 // optional buffer to clear
-    uint32_t zero_words;
+    uint32_t *zero_ptr[3];              // optional buffers to clear on the side: tile ranges, backward flags, a caller buffer
+    uint32_t zero_words[3];
     uint32_t *zero_one;                 // optional single word to clear (the tile-sort worklist counter)
 };
 
@@ -50,8 +50,10 @@ __global__ __launch_bounds__(kThreads) void duplicate_keys_kernel(int P, int Tx,
     __shared__ unsigned long long red64[4];
     const int view = blockIdx.y;
     // piggy-backed clear of a small buffer the later kernels expect zeroed (the tile ranges): replaces a memset launch
-    for (uint32_t z = (blockIdx.y * gridDim.x + blockIdx.x) * kThreads + threadIdx.x; z < ex.zero_words; z += gridDim.x * gridDim.y * kThreads)
-        ex.zero_ptr[z] = 0u;
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+        for (uint32_t z = (blockIdx.y * gridDim.x + blockIdx.x) * kThreads + threadIdx.x; z < ex.zero_words[c]; z += gridDim.x * gridDim.y * kThreads)
+            ex.zero_ptr[c][z] = 0u;
     if (ex.zero_one && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *ex.zero_one = 0u;
     const int i = blockIdx.x * kThreads + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -684,7 +686,8 @@ int sgr_bin_ex(const SgrProblem *pb, float *rec, const int32_t *radii, const uin
                const uint32_t *block_offsets, uint64_t R, const uint64_t *num_rendered_dev, uint64_t *keys_a,
                uint64_t *keys_b, uint32_t *vals_a, uint32_t *vals_b, void *workspace, size_t workspace_bytes,
                uint32_t *ranges, int32_t *result_in_b_host, bool self_scan, uint64_t *nr_host, void *prep_desc, size_t prep_n_desc,
-               uint32_t *prep_order, int *prep_done, void *stream_) {
+               uint32_t *prep_order, int *prep_done, uint32_t *const *clear_ptr /*[2] or NULL*/, const uint64_t *clear_words /*[2]*/,
+               int *clear_done /*[2]*/, void *stream_) {
     if (sgr_validate_problem(pb)) return 1;
     hipStream_t stream = (hipStream_t)stream_;
     const int Tx = (pb->W + SGR_TILE - 1) / SGR_TILE, Ty = (pb->H + SGR_TILE - 1) / SGR_TILE;
@@ -693,6 +696,7 @@ int sgr_bin_ex(const SgrProblem *pb, float *rec, const int32_t *radii, const uin
     if (R > 0xFFFFFFF0ull) { sgr_set_error("num_rendered %llu exceeds the 32-bit instance index", (unsigned long long)R); return 1; }
     if (result_in_b_host) *result_in_b_host = 0;
     if (prep_done) *prep_done = 0;
+    if (clear_done) clear_done[0] = clear_done[1] = 0;
     const bool fold_clear = R > 0 && pb->P > 0 && tiles_total * 2 <= (1u << 20);     // small: cleared by the duplicate kernel
     if (!fold_clear) SGR_CHECK_HIP(hipMemsetAsync(ranges, 0, tiles_total * 2 * sizeof(uint32_t), stream));
     if (R == 0 || pb->P == 0) return 0;
@@ -707,7 +711,12 @@ int sgr_bin_ex(const SgrProblem *pb, float *rec, const int32_t *radii, const uin
     const uint32_t nblk = (uint32_t)nbx * (uint32_t)pb->n_views;
     ex.self_sums = self_scan ? block_offsets + (nblk + 1) : nullptr;
     ex.num_rendered = const_cast<uint64_t *>(num_rendered_dev); ex.nr_host = self_scan ? nr_host : nullptr; ex.capacity = R;
-    ex.zero_ptr = fold_clear ? ranges : nullptr; ex.zero_words = fold_clear ? (uint32_t)(tiles_total * 2) : 0u;
+    ex.zero_ptr[0] = fold_clear ? ranges : nullptr; ex.zero_words[0] = fold_clear ? (uint32_t)(tiles_total * 2) : 0u;
+    for (int c = 0; c < 2; c++) {
+        const bool ok = clear_ptr && clear_ptr[c] && clear_words && clear_words[c] <= (1ull << 26);
+        ex.zero_ptr[1 + c] = ok ? clear_ptr[c] : nullptr; ex.zero_words[1 + c] = ok ? (uint32_t)clear_words[c] : 0u;
+        if (clear_done) clear_done[c] = ok ? 1 : 0;
+    }
     ex.zero_one = all_large ? (uint32_t *)((char *)workspace + sgr_bin_workspace_bytes(R, 0)) : nullptr;
     if (self_scan && !num_rendered_dev) { sgr_set_error("sgr_bin: self-scan needs the device counter"); return 1; }
     hipLaunchKernelGGL(duplicate_keys_kernel, dim3(nbx, pb->n_views), dim3(kThreads), 0, stream, pb->P, Tx, Tx * Ty,
@@ -827,5 +836,5 @@ extern "C" int sgr_bin(const SgrProblem *pb, float *rec, const int32_t *radii, c
                        uint64_t *keys_b, uint32_t *vals_a, uint32_t *vals_b, void *workspace, size_t workspace_bytes,
                        uint32_t *ranges, int32_t *result_in_b_host, void *stream_) {
     return sgr_bin_ex(pb, rec, radii, rect, block_offsets, R, num_rendered_dev, keys_a, keys_b, vals_a, vals_b, workspace,
-                      workspace_bytes, ranges, result_in_b_host, false, nullptr, nullptr, 0, nullptr, nullptr, stream_);
+                      workspace_bytes, ranges, result_in_b_host, false, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, stream_);
 }

@@ -67,15 +67,17 @@ __global__ __launch_bounds__(kT) void clamped_l1_kernel(const float *__restrict_
 
 extern "C" int sgr_clamped_l1_loss(int32_t n_views, int32_t H, int32_t W, const float *color, const float *target,
                                    const float *mask, float weight, float *grad_color, float *loss_per_view, float *loss_total,
-                                   void *stream_) {
+                                   int32_t sums_already_zero, void *stream_) {
     if (n_views <= 0 || H <= 0 || W <= 0) return 0;
     if (!color || !target || !grad_color || !loss_per_view) { sgr_set_error("sgr_clamped_l1_loss: NULL pointer"); return 1; }
     const int hw = H * W;
     const bool vec_ok = !((((uintptr_t)color | (uintptr_t)target | (uintptr_t)grad_color | (uintptr_t)mask) & 15) || (hw & 3));
     hipStream_t stream = (hipStream_t)stream_;
     const bool adjacent = loss_total == loss_per_view + n_views;            // the usual layout: [n_views | total], one memset
-    SGR_CHECK_HIP(hipMemsetAsync(loss_per_view, 0, sizeof(float) * (n_views + (adjacent ? 1 : 0)), stream));
-    if (loss_total && !adjacent) SGR_CHECK_HIP(hipMemsetAsync(loss_total, 0, sizeof(float), stream));
+    if (!sums_already_zero) {
+        SGR_CHECK_HIP(hipMemsetAsync(loss_per_view, 0, sizeof(float) * (n_views + (adjacent ? 1 : 0)), stream));
+        if (loss_total && !adjacent) SGR_CHECK_HIP(hipMemsetAsync(loss_total, 0, sizeof(float), stream));
+    }
     SgrProfScope _p(SGR_K_LOSS, stream);
     const int n4 = hw >> 2;
     int bx = (n4 + kT - 1) / kT;

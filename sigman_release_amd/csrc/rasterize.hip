@@ -28,7 +28,8 @@ struct FwdKey {
     SgrProblem pb;
     uint64_t capacity;
     int32_t with_aux, fwd_mode;
-    void *color, *depth, *alpha, *radii, *nr_host, *geom, *binning, *image, *stream;
+    void *color, *depth, *alpha, *radii, *nr_host, *geom, *binning, *image, *stream, *clear;
+    uint64_t clear_bytes;
 };
 struct FwdEntry { FwdKey key; hipGraphExec_t exec; SgrForwardState st; uint64_t stamp; };
 constexpr int kGraphSlots = 16;
@@ -44,7 +45,13 @@ int sgr_preprocess_forward_ex(const SgrProblem *pb, float *rec, int32_t *radii, 
 int sgr_bin_ex(const SgrProblem *pb, float *rec, const int32_t *radii, const uint32_t *rect, const uint32_t *block_offsets, uint64_t R,
                const uint64_t *num_rendered_dev, uint64_t *keys_a, uint64_t *keys_b, uint32_t *vals_a, uint32_t *vals_b, void *workspace,
                size_t workspace_bytes, uint32_t *ranges, int32_t *result_in_b_host, bool self_scan, uint64_t *nr_host, void *prep_desc,
-               size_t prep_n_desc, uint32_t *prep_order, int *prep_done, void *stream_);
+               size_t prep_n_desc, uint32_t *prep_order, int *prep_done, uint32_t *const *clear_ptr, const uint64_t *clear_words,
+               int *clear_done, void *stream_);
+int sgr_render_backward_ex(const SgrProblem *pb, const uint32_t *ranges, const uint32_t *point_list, const float *rec, const float *final_T,
+                           const uint32_t *n_contrib, const float *out_color, const float *out_depth, const float *out_alpha,
+                           const float *grad_color, const float *grad_depth, const float *grad_alpha, const float *grad_color_scale,
+                           uint64_t R, const void *aux_compact, const void *aux_ckpt_tc, const void *aux_ckpt_da, const void *aux_desc,
+                           float *grec, float *part, uint32_t *flags, bool flags_cleared, void *stream_);
 int sgr_render_forward_wants_prepare(const SgrProblem *pb, uint64_t R, bool use_aux, size_t *n_desc_out);
 int sgr_render_forward_ex(const SgrProblem *pb, const uint32_t *ranges, const uint32_t *point_list, const float *rec, float *out_color,
                           float *out_depth, float *out_alpha, float *final_T, uint32_t *n_contrib, uint64_t R, void *aux_compact,
@@ -68,7 +75,8 @@ extern "C" int sgr_set_graphs(int enable) { g_graphs_enabled = enable == 1 ? -1 
 extern "C" int sgr_graph_stats(uint64_t *hits, uint64_t *misses) { if (hits) *hits = g_graph_hits; if (misses) *misses = g_graph_misses; return 0; }
 
 static int forward_launches(const SgrProblem *pb, uint64_t capacity, uint64_t R, SgrForwardState *st, float *out_color, float *out_depth,
-                            float *out_alpha, int32_t *out_radii, uint64_t *nr_pinned_host, bool preprocess_done, hipStream_t stream) {
+                            float *out_alpha, int32_t *out_radii, uint64_t *nr_pinned_host, bool preprocess_done, void *caller_clear,
+                            uint64_t caller_clear_bytes, hipStream_t stream) {
     char *geom = (char *)st->geom, *binning = (char *)st->binning, *image = (char *)st->image;
     float *rec = (float *)(geom + st->off_rec);
     uint32_t *rect = (uint32_t *)(geom + st->off_rect);
@@ -89,12 +97,19 @@ static int forward_launches(const SgrProblem *pb, uint64_t capacity, uint64_t R,
     size_t n_desc = 0;
     const bool want_prep = sgr_render_forward_wants_prepare(pb, R, aux_on, &n_desc) != 0;
     int prep_done = 0;
+    // buffers the later stages expect zeroed are cleared on the side by the duplicate kernel: the backward's flags and an optional
+    // caller buffer (the fused loss node's accumulators)
+    uint32_t *clear_ptr[2] = {aux_on ? (uint32_t *)(image + st->off_flags) : nullptr, (uint32_t *)caller_clear};
+    const uint64_t clear_words[2] = {aux_on ? (R + 0) : 0, (caller_clear_bytes + 3) / 4};
+    int clear_done[2] = {0, 0};
     if (sgr_bin_ex(pb, rec, out_radii, rect, block_offsets, R, capacity > 0 ? num_rendered : nullptr, (uint64_t *)(binning + st->off_keys_a),
                    (uint64_t *)(binning + st->off_keys_b), (uint32_t *)(binning + st->off_vals_a), (uint32_t *)(binning + st->off_vals_b),
                    binning + st->off_sort_ws, (size_t)sgr_bin_workspace_bytes(R, (uint64_t)((pb->W + SGR_TILE - 1) / SGR_TILE) * ((pb->H + SGR_TILE - 1) / SGR_TILE) * pb->n_views),
                    (uint32_t *)(image + st->off_ranges), &in_b, self_scan, self_scan ? nr_pinned_host : nullptr,
                    want_prep && aux_on ? image + st->off_desc : nullptr, n_desc, want_prep ? (uint32_t *)(image + st->off_order) : nullptr,
-                   &prep_done, stream)) return 1;
+                   &prep_done, clear_ptr, clear_words, clear_done, stream)) return 1;
+    st->flags_cleared = clear_done[0];
+    if (caller_clear && caller_clear_bytes && !clear_done[1]) SGR_CHECK_HIP(hipMemsetAsync(caller_clear, 0, (size_t)caller_clear_bytes, stream));
     st->result_in_b = in_b;
     const uint32_t *point_list = (const uint32_t *)(binning + (in_b ? st->off_vals_b : st->off_vals_a));
     return sgr_render_forward_ex(pb, (const uint32_t *)(image + st->off_ranges), point_list, rec, out_color, out_depth, out_alpha,
@@ -106,7 +121,8 @@ static int forward_launches(const SgrProblem *pb, uint64_t capacity, uint64_t R,
 
 extern "C" int sgr_rasterize_forward(const SgrProblem *pb, uint64_t capacity, int32_t with_aux, sgr_alloc_fn alloc, void *user,
                                      float *out_color, float *out_depth, float *out_alpha, int32_t *out_radii,
-                                     uint64_t *nr_pinned_host, void *nr_event, SgrForwardState *st, void *stream_) {
+                                     uint64_t *nr_pinned_host, void *nr_event, void *caller_clear, uint64_t caller_clear_bytes,
+                                     SgrForwardState *st, void *stream_) {
     if (!pb || !alloc || !st || !out_color || !out_depth || !out_alpha || (!out_radii && pb->P > 0)) { sgr_set_error("sgr_rasterize_forward: NULL argument"); return 1; }
     hipStream_t stream = (hipStream_t)stream_;
     const uint64_t nq = (uint64_t)pb->n_views * (uint64_t)(pb->P > 0 ? pb->P : 0);
@@ -171,6 +187,7 @@ extern "C" int sgr_rasterize_forward(const SgrProblem *pb, uint64_t capacity, in
     st->off_n_contrib = o; o = align_up(o + hw * 4);
     st->off_order = o; o = align_up(o + (tiles_total + 1) * 4);
     if (aux_on) {
+        st->off_flags = o; o = align_up(o + R * 4);                // one byte per (tile instance, quadrant): partial record written by the backward
         st->off_compact = o; o = align_up(o + 4 * R * 8);
         st->off_ckpt_tc = o; o = align_up(o + 4 * NS * 4 * 64 * 16);
         st->off_ckpt_da = o; o = align_up(o + 4 * NS * 4 * 64 * 8);
@@ -188,6 +205,7 @@ extern "C" int sgr_rasterize_forward(const SgrProblem *pb, uint64_t capacity, in
         key.pb = *pb; key.capacity = capacity; key.with_aux = with_aux; key.fwd_mode = sgr_get_forward_mode();
         key.color = out_color; key.depth = out_depth; key.alpha = out_alpha; key.radii = out_radii; key.nr_host = nullptr;
         key.geom = geom; key.binning = binning; key.image = image; key.stream = nullptr;
+        key.clear = caller_clear; key.clear_bytes = caller_clear_bytes;
         int found = -1;
         for (int i = 0; i < g_fwd_n; i++)
             if (memcmp(&g_fwd[i].key, &key, sizeof(key)) == 0) { found = i; break; }
@@ -219,7 +237,8 @@ extern "C" int sgr_rasterize_forward(const SgrProblem *pb, uint64_t capacity, in
             hipGraph_t graph = nullptr;
             hipGraphExec_t exec = nullptr;
             if (g_graphs_enabled > 0 && hipStreamBeginCapture(cap_stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-                const int rc = forward_launches(pb, capacity, R, st, out_color, out_depth, out_alpha, out_radii, nullptr, false, cap_stream);
+                const int rc = forward_launches(pb, capacity, R, st, out_color, out_depth, out_alpha, out_radii, nullptr, false, caller_clear,
+                                                caller_clear_bytes, cap_stream);
                 const hipError_t e1 = hipStreamEndCapture(cap_stream, &graph);
                 if (rc == 0 && e1 == hipSuccess && graph && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess) {
                     (void)hipGraphDestroy(graph);
@@ -236,7 +255,7 @@ extern "C" int sgr_rasterize_forward(const SgrProblem *pb, uint64_t capacity, in
         }
     }
     if (forward_launches(pb, capacity, R, st, out_color, out_depth, out_alpha, out_radii, capacity > 0 ? nr_pinned_host : nullptr,
-                         preprocess_done, stream)) return 1;
+                         preprocess_done, caller_clear, caller_clear_bytes, stream)) return 1;
     if (capacity > 0 && nr_event) SGR_CHECK_HIP(hipEventRecord((hipEvent_t)nr_event, stream));
     return 0;
 }
@@ -253,19 +272,19 @@ extern "C" int sgr_rasterize_backward(const SgrProblem *pb, const SgrForwardStat
     const bool aux_on = st->with_aux != 0;
     // scratch: bucket-parallel path = partial records [4*R][12] f32 + flags [R] u32; pixel-parallel path = grec [nq][12] f32
     const uint64_t part_bytes = align_up(st->R_alloc * 4 * SGR_REC_FLOATS * 4);
-    const uint64_t scratch_bytes = aux_on ? part_bytes + align_up(st->R_alloc * 4) : nq * SGR_REC_FLOATS * 4;
+    const uint64_t scratch_bytes = aux_on ? part_bytes : nq * SGR_REC_FLOATS * 4;
     char *scratch = alloc(user, 3, (size_t)scratch_bytes);
     if (!scratch) { sgr_set_error("scratch allocator returned NULL"); return 1; }
     float *part = aux_on ? (float *)scratch : nullptr;
-    uint32_t *flags = aux_on ? (uint32_t *)(scratch + part_bytes) : nullptr;
+    uint32_t *flags = aux_on ? (uint32_t *)((char *)st->image + st->off_flags) : nullptr;     // lives in the forward's image blob
     float *grec = aux_on ? nullptr : (float *)scratch;
     const char *geom = (const char *)st->geom, *binning = (const char *)st->binning, *image = (const char *)st->image;
     const float *rec = (const float *)(geom + st->off_rec);
     const uint32_t *point_list = (const uint32_t *)(binning + (st->result_in_b ? st->off_vals_b : st->off_vals_a));
-    if (sgr_render_backward(pb, (const uint32_t *)(image + st->off_ranges), point_list, rec, (const float *)(image + st->off_final_T),
+    if (sgr_render_backward_ex(pb, (const uint32_t *)(image + st->off_ranges), point_list, rec, (const float *)(image + st->off_final_T),
                             (const uint32_t *)(image + st->off_n_contrib), out_color, out_depth, out_alpha, grad_color, grad_depth,
                             grad_alpha, grad_color_scale, st->R_alloc, aux_on ? image + st->off_compact : nullptr, aux_on ? image + st->off_ckpt_tc : nullptr,
-                            aux_on ? image + st->off_ckpt_da : nullptr, aux_on ? image + st->off_desc : nullptr, grec, part, flags, stream_))
+                            aux_on ? image + st->off_ckpt_da : nullptr, aux_on ? image + st->off_desc : nullptr, grec, part, flags, st->flags_cleared != 0, stream_))
         return 1;
     return sgr_preprocess_backward(pb, radii, pb->shs ? (const uint8_t *)(geom + st->off_clamped) : nullptr, grec, rec, part, flags,
                                    dL_dmeans3D, dL_dmeans2D, dL_dopacity, dL_dcolors, dL_dsh, dL_dcov3D, dL_dscales, dL_drotations,

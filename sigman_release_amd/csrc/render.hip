@@ -897,19 +897,19 @@ extern "C" int sgr_render_forward(const SgrProblem *pb, const uint32_t *ranges, 
                                  aux_ckpt_tc, aux_ckpt_da, aux_desc, aux_order, false, stream_);
 }
 
-extern "C" int sgr_render_backward(const SgrProblem *pb, const uint32_t *ranges, const uint32_t *point_list, const float *rec,
-                                   const float *final_T, const uint32_t *n_contrib, const float *out_color,
-                                   const float *out_depth, const float *out_alpha, const float *grad_color,
-                                   const float *grad_depth, const float *grad_alpha, const float *grad_color_scale, uint64_t R,
-                                   const void *aux_compact, const void *aux_ckpt_tc, const void *aux_ckpt_da, const void *aux_desc,
-                                   float *grec, float *part, uint32_t *flags, void *stream_) {
+int sgr_render_backward_ex(const SgrProblem *pb, const uint32_t *ranges, const uint32_t *point_list, const float *rec,
+                           const float *final_T, const uint32_t *n_contrib, const float *out_color,
+                           const float *out_depth, const float *out_alpha, const float *grad_color,
+                           const float *grad_depth, const float *grad_alpha, const float *grad_color_scale, uint64_t R,
+                           const void *aux_compact, const void *aux_ckpt_tc, const void *aux_ckpt_da, const void *aux_desc,
+                           float *grec, float *part, uint32_t *flags, bool flags_cleared, void *stream_) {
     if (sgr_validate_problem(pb)) return 1;
     hipStream_t stream = (hipStream_t)stream_;
     const int Tx = (pb->W + SGR_TILE - 1) / SGR_TILE, Ty = (pb->H + SGR_TILE - 1) / SGR_TILE;
     const uint32_t tiles = (uint32_t)Tx * Ty;
     const bool use_aux = aux_compact && aux_ckpt_tc && aux_ckpt_da && aux_desc && out_color && out_depth && out_alpha && part && flags;
     if (use_aux) {
-        if (R > 0) SGR_CHECK_HIP(hipMemsetAsync(flags, 0, (size_t)R * 4, stream));
+        if (R > 0 && !flags_cleared) SGR_CHECK_HIP(hipMemsetAsync(flags, 0, (size_t)R * 4, stream));   // (else: cleared by the forward chain)
     } else {
         if (!grec) { sgr_set_error("sgr_render_backward: grec required for the pixel-parallel kernel"); return 1; }
         if (pb->P > 0) SGR_CHECK_HIP(hipMemsetAsync(grec, 0, (size_t)pb->n_views * pb->P * SGR_REC_FLOATS * sizeof(float), stream));
@@ -935,4 +935,15 @@ extern "C" int sgr_render_backward(const SgrProblem *pb, const uint32_t *ranges,
                        grad_alpha, grad_color_scale, grec);
     SGR_CHECK_LAUNCH("render_bwd_kernel");
     return 0;
+}
+
+extern "C" int sgr_render_backward(const SgrProblem *pb, const uint32_t *ranges, const uint32_t *point_list, const float *rec,
+                                   const float *final_T, const uint32_t *n_contrib, const float *out_color,
+                                   const float *out_depth, const float *out_alpha, const float *grad_color,
+                                   const float *grad_depth, const float *grad_alpha, const float *grad_color_scale, uint64_t R,
+                                   const void *aux_compact, const void *aux_ckpt_tc, const void *aux_ckpt_da, const void *aux_desc,
+                                   float *grec, float *part, uint32_t *flags, void *stream_) {
+    return sgr_render_backward_ex(pb, ranges, point_list, rec, final_T, n_contrib, out_color, out_depth, out_alpha, grad_color, grad_depth,
+                                  grad_alpha, grad_color_scale, R, aux_compact, aux_ckpt_tc, aux_ckpt_da, aux_desc, grec, part, flags, false,
+                                  stream_);
 }

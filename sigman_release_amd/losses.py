@@ -25,7 +25,7 @@ class _ClampedL1(torch.autograd.Function):
         sums = torch.empty(nv + 1, dtype=torch.float32, device=color.device)      # [per-view partial sums | total]
         p = sums.data_ptr()
         _cabi.check(L.sgr_clamped_l1_loss(nv, H, W, _ptr(color), _ptr(target), _ptr(mask), float(weight), _ptr(grad),
-                                          p, p + 4 * nv, _stream(color.device)), "sgr_clamped_l1_loss")
+                                          p, p + 4 * nv, 0, _stream(color.device)), "sgr_clamped_l1_loss")
         ctx.save_for_backward(grad)
         ctx.per_view = sums[:nv]
         return sums[nv]

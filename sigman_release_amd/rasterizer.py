@@ -157,7 +157,7 @@ def _make_problem(means3D, opacities, colors_precomp, shs, cov3D_precomp, scales
 
 
 def _forward_impl(means3D, opacities, colors_precomp, shs, cov3D_precomp, scales, rotations, st: BatchedRasterizationSettings,
-                  need_ctx: bool, with_aux: bool = True):
+                  need_ctx: bool, with_aux: bool = True, clear: Optional[torch.Tensor] = None):
     L = _cabi.lib()
     dev = means3D.device
     if dev.type != "cuda":
@@ -179,7 +179,8 @@ def _forward_impl(means3D, opacities, colors_precomp, shs, cov3D_precomp, scales
     use_aux = 1 if (need_ctx and with_aux and not _USE_BWD_V1) else 0
     _cabi.check(L.sgr_rasterize_forward(C.byref(pb), capacity, use_aux, _ALLOC, None, color.data_ptr(), depth.data_ptr(),
                                         alpha.data_ptr(), radii.data_ptr(), nr_ptr,
-                                        nr_handle if capacity > 0 else None, C.byref(state), _stream(dev)),
+                                        nr_handle if capacity > 0 else None, None if clear is None else clear.data_ptr(),
+                                        0 if clear is None else clear.numel() * clear.element_size(), C.byref(state), _stream(dev)),
                 "sgr_rasterize_forward")
     ctx = None
     if need_ctx:
@@ -226,7 +227,7 @@ def _backward_impl(ctx: _Ctx, means3D, opacities, colors_precomp, shs, cov3D_pre
     return d_means3D, d_means2D, d_sh, d_col, d_op, d_sc, d_rot, d_cov, grec
 
 
-def _fwd_common(ctx, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, st, epilogue=None):
+def _fwd_common(ctx, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, st, epilogue=None, clear=None):
     # fp32-only op: inputs are cast here, so an enclosing autocast region (gs.py:98) cannot downcast them
     opt = lambda t: None if t is None or t.numel() == 0 else _f32c(t)
     means3D = _f32c(means3D)
@@ -237,7 +238,7 @@ def _fwd_common(ctx, means3D, sh, colors_precomp, opacities, scales, rotations, 
             and st.viewmatrix.is_contiguous() and st.projmatrix.is_contiguous() and st.campos.is_contiguous() and st.bg.is_contiguous()):
         st = st._replace(viewmatrix=_f32c(st.viewmatrix), projmatrix=_f32c(st.projmatrix), campos=_f32c(st.campos), bg=_f32c(st.bg))
     color, radii, depth, alpha, c = _forward_impl(means3D, opacities, colors_precomp, sh, cov3Ds_precomp, scales, rotations,
-                                                  st, need_ctx=True)
+                                                  st, need_ctx=True, clear=clear)
     ctx.sgr = c
     ctx.st = st
     # unused outputs (depth / alpha on the reference path, gs.py:99,107-109) then arrive as None in backward instead of as
@@ -294,25 +295,24 @@ class _RasterizeL1Batched(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, st, target, mask, weight):
         L = _cabi.lib()
-        out = {}
+        nv = st.viewmatrix.shape[0]
+        # [per-view partial sums | total]: zeroed on the side by the rasterizer's own kernels (caller_clear), no memset launch
+        sums = torch.empty(nv + 1, dtype=torch.float32, device=means3D.device)
 
         def epilogue(color):
-            nv, _, H, W = color.shape
+            _, _, H, W = color.shape
             tgt = _f32c(target)
             msk = None if mask is None else _f32c(mask)
             gimg = torch.empty_like(color)
-            sums = torch.empty(nv + 1, dtype=torch.float32, device=color.device)      # [per-view partial sums | total]
             p = sums.data_ptr()
             _cabi.check(L.sgr_clamped_l1_loss(nv, H, W, color.data_ptr(), _ptr(tgt), _ptr(msk), float(weight), gimg.data_ptr(),
-                                              p, p + 4 * nv, _stream(color.device)), "sgr_clamped_l1_loss")
-            out["sums"] = sums
+                                              p, p + 4 * nv, 1, _stream(color.device)), "sgr_clamped_l1_loss")
             return (gimg,)
 
         color, radii, depth, alpha = _fwd_common(ctx, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, st,
-                                                 epilogue)
+                                                 epilogue, clear=sums)
         ctx.has_means2D = means2D is not None
-        nv = color.shape[0]
-        loss, per_view = out["sums"][nv], out["sums"][:nv]
+        loss, per_view = sums[nv], sums[:nv]
         ctx.mark_non_differentiable(radii, per_view)
         return loss, per_view, color, radii, depth, alpha
 
