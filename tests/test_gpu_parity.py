@@ -524,3 +524,89 @@ def test_graphs_off_without_the_runtime_flag():
     env = {k: v for k, v in os.environ.items() if k != "DEBUG_CLR_GRAPH_PACKET_CAPTURE"}
     r = subprocess.run([sys.executable, "-c", script, root], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0 and "HOSTCOPY_OK 0" in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-1500:])
+
+
+def _humanoid_inputs(P, seed, dev):
+    from sigman_release_amd import synthetic
+    g = synthetic.humanoid(P, seed)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    return t(g["position"]), t(g["opacity"].reshape(P, 1)), t(g["rgb"]), t(synthetic.covariance_from_gaussians(g))
+
+
+def test_full_size_c3_batch_8x8_views_512():
+    """BASELINE.json configs[2] shape on one GPU: 8 subjects x 8 views at 512x512 (64 view slots = 65 536 tiles: serial forward kernel,
+    whole-key sort), forward + backward.  Size-independent properties instead of a 64-view CPU oracle run:
+      * every view slot of the batch is BITWISE the single-view render of that subject/camera (different kernel flavours:
+        segment-parallel forward, segmented sort) for radii and n_contrib, and within 2e-6 for the images;
+      * linearity: the batch gradient of subject s equals the sum of its 8 single-view gradients."""
+    from sigman_release_amd import cameras
+    from sigman_release_amd import rasterizer as R
+    dev = _dev()
+    S, V, P, H = 8, 8, 20_000, 512
+    views = [30, 37, 45, 53, 65, 85, 0, 8]
+    subj = [_humanoid_inputs(P, 100 + s, dev) for s in range(S)]
+    m, o, c, cov = [torch.stack([x[k] for x in subj]).requires_grad_(True) for k in range(4)]
+    cv, cvp, cp = cameras.make_cameras(views * S)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    bg = torch.tensor([1.0, 1.0, 1.0], device=dev)
+    bst = R.BatchedRasterizationSettings(H, H, cameras.TAN_HALF_FOV, cameras.TAN_HALF_FOV, bg, 1.0, t(cv), t(cvp), 0, t(cp), V)
+    color, radii, depth, alpha = R.rasterize_gaussians_batched(m, None, None, c, o, None, None, cov, bst)
+    gC = torch.randn(S * V, 3, H, H, device=dev, generator=torch.Generator(device=dev).manual_seed(5)) / (H * H)
+    (color * gC).sum().backward()
+    a = alpha.detach()
+    assert torch.isfinite(color).all() and float(a.min()) >= 0 and float(a.max()) <= 1 + 1e-5
+    for s, v in ((0, 0), (3, 5), (7, 7)):
+        i = s * V + v
+        one = bst._replace(viewmatrix=bst.viewmatrix[i:i + 1], projmatrix=bst.projmatrix[i:i + 1], campos=bst.campos[i:i + 1], views_per_subject=1)
+        c1, r1, d1, a1 = R.rasterize_gaussians_batched(m[s:s + 1].detach(), None, None, c[s:s + 1].detach(), o[s:s + 1].detach(), None, None,
+                                                       cov[s:s + 1].detach(), one)
+        assert torch.equal(r1[0], radii[i])
+        assert float((c1[0] - color[i].detach()).abs().max()) <= 2e-6 and float((d1[0] - depth[i].detach()).abs().max()) <= 2e-5
+    s = 2
+    leaves = [x[s:s + 1].detach().clone().requires_grad_(True) for x in (m, c, o, cov)]
+    for v in range(V):
+        i = s * V + v
+        one = bst._replace(viewmatrix=bst.viewmatrix[i:i + 1], projmatrix=bst.projmatrix[i:i + 1], campos=bst.campos[i:i + 1], views_per_subject=1)
+        c1 = R.rasterize_gaussians_batched(leaves[0], None, None, leaves[1], leaves[2], None, None, leaves[3], one)[0]
+        (c1[0] * gC[i]).sum().backward()
+    for got, want, nm in ((m.grad[s], leaves[0].grad[0], "means3D"), (c.grad[s], leaves[1].grad[0], "colors"),
+                          (o.grad[s], leaves[2].grad[0], "opacity"), (cov.grad[s], leaves[3].grad[0], "cov3D")):
+        err = float((got - want).abs().max()) / max(float(want.abs().max()), 1e-20)
+        assert err <= GRAD_TOL, f"{nm}: batch gradient vs sum of per-view gradients {err:.3e}"
+
+
+def test_full_size_c4_200k_90_views_1024_forward():
+    """BASELINE.json configs[3]: 200 000 Gaussians, 90-view orbit at 1024x1024, forward only (4.4e7 tile instances: the onesweep
+    sort and the serial forward kernel at full size).  Properties: the sorted key list is non-decreasing, the tile ranges partition
+    it, alpha in [0,1] and colour = C + (1 - alpha) * bg, and three view slots are bitwise the single-view renders."""
+    from sigman_release_amd import cameras
+    from sigman_release_amd import rasterizer as R
+    dev = _dev()
+    P, H, NV = 200_000, 1024, 90
+    m, o, c, cov = _humanoid_inputs(P, 77, dev)
+    cv, cvp, cp = cameras.make_cameras(list(range(NV)))
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    bg = torch.tensor([0.2, 0.9, 0.4], device=dev)
+    bst = R.BatchedRasterizationSettings(H, H, cameras.TAN_HALF_FOV, cameras.TAN_HALF_FOV, bg, 1.0, t(cv), t(cvp), 0, t(cp), NV)
+    with torch.no_grad():
+        d = R.forward_debug(m[None], o[None], colors_precomp=c[None], cov3D_precomp=cov[None], settings=bst)
+        Rn = d["num_rendered"]
+        assert Rn > 20_000_000
+        keys = d["keys"]
+        assert bool((keys[1:] >= keys[:-1]).all()), "sorted (tile | depth) keys must be non-decreasing"
+        rng = d["ranges"].reshape(-1, 2).to(torch.int64)
+        occ = rng[rng[:, 1] > rng[:, 0]]
+        assert int((occ[:, 1] - occ[:, 0]).sum()) == Rn and int(occ[0, 0]) == 0 and int(occ[-1, 1]) == Rn
+        assert bool((occ[1:, 0] == occ[:-1, 1]).all()), "tile ranges must tile [0, R) without gaps"
+        tile_of_start = (keys[occ[:, 0]] >> 32)
+        assert bool((tile_of_start[1:] > tile_of_start[:-1]).all())
+        color, alpha = d["color"], d["alpha"]
+        assert float(alpha.min()) >= 0 and float(alpha.max()) <= 1 + 1e-5
+        black = R.rasterize_gaussians_batched(m[None], None, None, c[None], o[None], None, None, cov[None],
+                                              bst._replace(bg=torch.zeros(3, device=dev)))[0]
+        assert float((color - (black + (1 - alpha) * bg[None, :, None, None])).abs().max()) <= 5e-6
+        for i in (0, 44, 89):
+            one = bst._replace(viewmatrix=bst.viewmatrix[i:i + 1], projmatrix=bst.projmatrix[i:i + 1], campos=bst.campos[i:i + 1], views_per_subject=1)
+            d1 = R.forward_debug(m[None], o[None], colors_precomp=c[None], cov3D_precomp=cov[None], settings=one)
+            assert torch.equal(d1["radii"][0], d["radii"][i]) and torch.equal(d1["n_contrib"][0], d["n_contrib"][i])
+            assert float((d1["color"][0] - color[i]).abs().max()) <= 2e-6
