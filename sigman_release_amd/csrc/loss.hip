@@ -7,14 +7,14 @@
 #include "common.h"
 
 namespace {
-constexpr int kT = 256;
+constexpr int kT = 1024;     // few, fat workgroups: every workgroup ends in two same-address float atomics, which serialise in L2
 
 // grid: (blocks over H*W/4, n_views).  loss_view[v] += sum_{c,p} w * mask * |clamp(color) - target|
 // grad[v,c,p] = w * mask * sign(clamp(color) - target) * 1[0 < color < 1]      (clamp kills the gradient where saturated)
 __global__ __launch_bounds__(kT) void clamped_l1_kernel(const float *__restrict__ color, const float *__restrict__ target,
                                                         const float *__restrict__ mask, float weight, int hw, int vec,
                                                         float *__restrict__ grad, float *__restrict__ loss_view, float *__restrict__ loss_total) {
-    __shared__ float red[4];
+    __shared__ float red[kT / 64];
     const int v = blockIdx.y;
     const size_t base = (size_t)v * 3 * hw;
     float acc = 0.f;
@@ -58,7 +58,10 @@ __global__ __launch_bounds__(kT) void clamped_l1_kernel(const float *__restrict_
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
     if (threadIdx.x == 0) {
-        const float part = weight * ((red[0] + red[1]) + (red[2] + red[3]));
+        float sum = 0.f;
+#pragma unroll
+        for (int w = 0; w < kT / 64; w++) sum += red[w];
+        const float part = weight * sum;
         sgr_atomic_add(&loss_view[v], part);
         if (loss_total) sgr_atomic_add(loss_total, part);
     }
@@ -81,7 +84,7 @@ extern "C" int sgr_clamped_l1_loss(int32_t n_views, int32_t H, int32_t W, const 
     SgrProfScope _p(SGR_K_LOSS, stream);
     const int n4 = hw >> 2;
     int bx = (n4 + kT - 1) / kT;
-    bx = bx < 1 ? 1 : (bx > 256 ? 256 : bx);
+    bx = bx < 1 ? 1 : (bx > 64 ? 64 : bx);
     hipLaunchKernelGGL(clamped_l1_kernel, dim3(vec_ok ? bx : 1, n_views), dim3(kT), 0, stream, color, target, mask, weight, hw,
                        vec_ok ? 1 : 0, grad_color, loss_per_view, loss_total);
     SGR_CHECK_LAUNCH("clamped_l1_kernel");
