@@ -12,7 +12,9 @@ gs.py:98-106), white background, loss = mean |clamp(img,0,1) - gt| with gt = ren
 
 One "step" = one pass of the hot path over one batch: at N=1 ONE view (rig view 0030) per step.  At N>1 the views
 [30,37,45,53,65,85,0,8] of the same subject are sharded one-view-per-GPU (weak scaling: per-GPU work fixed) with the
-exchange steps of sigman_release_amd/parallel.py (attribute broadcast, loss all-reduce, gradient all-reduce; RCCL).
+exchange of sigman_release_amd/parallel.py: by default what BASELINE.json's north_star names -- replicated attributes, RCCL
+all-reduce of the image-space loss, overlapped with the backward; `--exchange full` adds the attribute broadcast and the
+all-reduce of the attribute gradients.
 
 `value` = views/s of the whole job with inputs resident in HBM.  `roofline` is for the dominant kernel, timed with HIP
 events recorded by the library on the launch stream inside the timed region.  `cpu_baseline` is the CPU oracle
@@ -92,6 +94,9 @@ def main():
     ap.add_argument("--gaussians", type=int, default=100_000)
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--views-per-step", type=int, default=1, help="views per GPU per step (C2 = 1)")
+    ap.add_argument("--exchange", choices=("loss", "full"), default="loss",
+                    help="N>1: 'loss' = north_star's protocol (replicated attributes, loss all-reduce overlapped with the backward); "
+                         "'full' = attribute broadcast + all-reduce of gradients and loss (sigman_release_amd/parallel.py)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--exact-sync", action="store_true", help="read num_rendered back every step (upstream behaviour) instead of the sync-free capacity mode")
     args = ap.parse_args()
@@ -152,7 +157,8 @@ def main():
             loss = render_loss(leaves["means3D"], leaves["cov3D"], leaves["opacity"], leaves["rgb"])
             loss.backward(one)              # explicit seed: autograd would otherwise launch a ones_like fill kernel every step
             return loss
-        loss, grad = parallel.view_parallel_step(packed, all_views, lambda m, c, o, r, mine: render_loss(m, c, o, r, mine))
+        loss, grad = parallel.view_parallel_step(packed, all_views, lambda m, c, o, r, mine: render_loss(m, c, o, r, mine),
+                                                 exchange=args.exchange, seed_grad=one)
         return loss
 
     L = _cabi.lib()
@@ -236,7 +242,8 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"C2: procedural humanoid (SMPL-X stand-in), {P} Gaussians, {len(my_views)} view(s)/GPU/step "
                                f"{H}x{W}, fwd+bwd, colors_precomp+cov3D_precomp, clamp+L1 loss",
-                   "views_per_step_total": n_total_views, "parallelism": f"view-parallel x{world}" if world > 1 else "single GPU",
+                   "views_per_step_total": n_total_views,
+                   "parallelism": (f"view-parallel x{world}, exchange={args.exchange}" if world > 1 else "single GPU"),
                    "num_rendered_per_gpu": Rn, "gaussian_pixel_visits_per_gpu": S_visits,
                    "binning_buffers": "exact (D2H read of num_rendered per step)" if args.exact_sync else f"pre-sized, max_rendered={st.max_rendered} (sync-free)"},
         "gaussian_pixel_ops_per_s_per_gpu": round(S_visits / (ms_per_step * 1e-3), 1),

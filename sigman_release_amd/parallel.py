@@ -11,7 +11,15 @@ xGMI is point-to-point (7 links x ~153 GB/s); 5.2 MB at P=1e5 is latency-bound (
 kept as ONE contiguous tensor = one collective each way: the loss scalar rides in the last element of the gradient
 buffer ([13*P + 1]), so 2 and 3 are a single all-reduce.
 
-The render function is injected, so the sharding/collective logic is testable on CPU with gloo (tests/test_parallel.py).
+Two exchange protocols (view_parallel_step(exchange=...)):
+  "loss"  exactly what BASELINE.json's north_star names: the attributes are already replicated (in a DDP job every rank runs the
+          same decoder on the same subject), each rank renders its views, and ONLY the image-space loss is all-reduced -- issued
+          right after the forward and overlapped with the backward.  The returned gradient is the rank's partial sum over its own
+          views; it flows into the rank's decoder replica, whose parameter gradients DDP reduces anyway.
+  "full"  for callers without a replicated producer: steps 1 + 2 + 3 above (global loss AND global attribute gradient on every
+          rank).
+
+The render function is injected, so the sharding/collective logic is testable on CPU with gloo (tests/test_parallel_cpu.py).
 """
 from __future__ import annotations
 
@@ -42,16 +50,39 @@ def unpack_attributes(packed: torch.Tensor):
 
 
 def view_parallel_step(packed: torch.Tensor, view_ids: Sequence[int], render_loss: Callable, *, src: int = 0, group=None,
-                       broadcast: bool = True):
+                       broadcast: bool = True, exchange: str = "full", seed_grad: torch.Tensor = None):
     """One fwd+bwd step of a subject whose views are sharded over the ranks of `group`.
 
-    packed      flat [13*P] attributes (pack_attributes); only rank `src` needs valid contents when broadcast=True
+    packed      flat [13*P] attributes (pack_attributes); exchange="full": only rank `src` needs valid contents when broadcast=True
     view_ids    all views of the subject (same list on every rank)
     render_loss (means3D, cov3D, opacity, rgb, my_view_ids) -> scalar loss SUM over my views (differentiable)
-    returns     (global loss = sum over all views, global gradient, flat [13*P] in the same layout)
+    exchange    "full": returns (global loss, GLOBAL gradient flat [13*P]);  "loss": returns (global loss, this rank's PARTIAL
+                gradient) with the loss all-reduce overlapped with the backward (module docstring)
+    seed_grad   optional 0-d ones tensor for loss.backward() (saves the fill kernel autograd would launch for it)
     """
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
+    if exchange not in ("full", "loss"):
+        raise ValueError("exchange must be 'full' or 'loss'")
+    if exchange == "loss":
+        leaves = [x.detach().requires_grad_(True) for x in unpack_attributes(packed)]
+        mine = [view_ids[i] for i in shard_views(len(view_ids), rank, world)]
+        work = None
+        if mine:
+            loss = render_loss(*leaves, mine)
+            loss_val = loss.detach().reshape(1).clone()
+        else:
+            loss, loss_val = None, torch.zeros(1, device=packed.device, dtype=packed.dtype)
+        if world > 1:
+            work = dist.all_reduce(loss_val, op=dist.ReduceOp.SUM, group=group, async_op=True)   # travels while the backward runs
+        if loss is not None:
+            loss.backward(seed_grad)
+            grad = torch.cat([(l.grad if l.grad is not None else torch.zeros_like(l)).reshape(-1) for l in leaves])
+        else:
+            grad = torch.zeros_like(packed)
+        if work is not None:
+            work.wait()
+        return loss_val[0], grad
     if world > 1 and broadcast:
         dist.broadcast(packed, src=src, group=group)
     # the four attributes are contiguous views of the flat buffer: separate autograd leaves without any copy
@@ -59,7 +90,7 @@ def view_parallel_step(packed: torch.Tensor, view_ids: Sequence[int], render_los
     mine = [view_ids[i] for i in shard_views(len(view_ids), rank, world)]
     if mine:
         loss = render_loss(*leaves, mine)
-        loss.backward()
+        loss.backward(seed_grad)
         buf = torch.cat([(l.grad if l.grad is not None else torch.zeros_like(l)).reshape(-1) for l in leaves]
                         + [loss.detach().reshape(1).to(packed.dtype)])
     else:

@@ -53,7 +53,12 @@ def _worker(rank, world, port, q):
     if rank != 0:
         packed = torch.zeros_like(packed)               # only the producer rank holds the attributes
     loss, grad = parallel.view_parallel_step(packed, VIEWS, _render_loss_factory(st, H, W), src=0)
-    q.put((rank, float(loss), grad.numpy()))
+    # north_star protocol: replicated attributes (here: what the broadcast above left on every rank), loss all-reduce only,
+    # overlapped with the backward; the gradient stays the rank's partial sum over its own views
+    loss2, grad2 = parallel.view_parallel_step(packed, VIEWS, _render_loss_factory(st, H, W), exchange="loss")
+    gsum = grad2.clone()
+    dist.all_reduce(gsum)
+    q.put((rank, float(loss), grad.numpy(), float(loss2), gsum.numpy(), float(grad2.abs().sum())))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -72,9 +77,15 @@ def test_view_parallel_gloo_matches_single_process():
     res = [q.get(timeout=300) for _ in range(2)]
     [p.join(timeout=60) for p in procs]
     assert all(p.exitcode == 0 for p in procs)
-    for rank, loss, grad in res:
+    partial_norms = []
+    for rank, loss, grad, loss2, gsum, pnorm in res:
         assert abs(loss - float(loss1)) <= 1e-6 * max(1.0, abs(float(loss1)))
         np.testing.assert_allclose(grad, grad1.numpy(), atol=1e-6 * np.abs(grad1.numpy()).max())
+        # exchange="loss": same global loss; the rank-local partial gradients add up to the global gradient
+        assert abs(loss2 - float(loss1)) <= 1e-6 * max(1.0, abs(float(loss1)))
+        np.testing.assert_allclose(gsum, grad1.numpy(), atol=1e-6 * np.abs(grad1.numpy()).max())
+        partial_norms.append(pnorm)
+    assert all(p > 0 for p in partial_norms) and abs(partial_norms[0] - partial_norms[1]) > 0      # really partial, really different
 
 
 def test_shard_views():
