@@ -130,9 +130,6 @@ __global__ __launch_bounds__(kBlock) void render_fwd_kernel(int W, int H, int Tx
                 dst[g] = make_uint2(sId[j], (uint32_t)(r * kBlock) + j);
             }
         }
-#ifdef SGR_DBG_NOCOMPUTE
-        if (cnt > 100000)
-#endif
         for (uint32_t g = 0; g < cnt && active; g += SGR_FWD_G) {
             int js[SGR_FWD_G];
 #pragma unroll
@@ -141,11 +138,7 @@ __global__ __launch_bounds__(kBlock) void render_fwd_kernel(int W, int H, int Tx
             float al[SGR_FWD_G];
             bool valid[SGR_FWD_G];
 #pragma unroll
-#ifdef SGR_DBG_NOLDS
-            for (int u = 0; u < SGR_FWD_G; u++) { const float f = (float)js[u]; a[u] = make_float4(x0 + f * 0.06f, y0 + f * 0.05f, 0.1f, 0.01f); b[u] = make_float4(0.12f, 0.5f, 2.f + f, 0.3f); c[u] = make_float4(0.2f, 0.4f, 1.f, 1.f); }
-#else
             for (int u = 0; u < SGR_FWD_G; u++) { a[u] = sA[js[u]]; b[u] = sB[js[u]]; c[u] = sC[js[u]]; }
-#endif
 #pragma unroll
             for (int u = 0; u < SGR_FWD_G; u++) {
                 const float dx = a[u].x - pxf, dy = a[u].y - pyf;
@@ -219,9 +212,6 @@ __global__ __launch_bounds__(kBlock) void render_fwd_kernel(int W, int H, int Tx
 // survivors (only the last one of a list is shorter) keeps all four 16-lane rows of the backward's waves busy.
 // -------------------------------------------------------------------------------------------------
 constexpr int kSegThreads = 512, kSegWaves = 8, kSegRing = 1024, kSegPer = 64;
-#ifdef SGR_DBG_TIMING
-__device__ uint32_t g_dbg_timing[4 * 16384];      // per block: start, end (100 MHz ticks), list length, rounds
-#endif
 
 __device__ __forceinline__ bool cull_quadrant(const float4 &a, const float4 &c, float qx0, float qy0) {
     const float hx = c.z, hy = c.w;
@@ -271,10 +261,6 @@ __global__ __launch_bounds__(kSegThreads, 4) void render_fwd_seg_kernel(int W, i
     size_t slot_next = (size_t)q * aux.NS + (range.x >> 6) + (size_t)bid;
     if (t < 64) sTstop[t] = -1.f;
     bool pix_done = !inside;
-#ifdef SGR_DBG_TIMING
-    const uint64_t dbg_t0 = wall_clock64();
-    uint32_t dbg_rounds = 0;
-#endif
     // ---- software pipeline of the list: records of sub-chunk `commit` and ids of sub-chunk `commit + 1` live in registers
     int commit = 0;                                             // first list entry of the sub-chunk held in (ra, rb, rc, rid)
     float4 ra, rb, rc;
@@ -425,9 +411,6 @@ __global__ __launch_bounds__(kSegThreads, 4) void render_fwd_seg_kernel(int W, i
             }
             slot_next += (m + 63u) >> 6;
         }
-#ifdef SGR_DBG_TIMING
-        dbg_rounds++;
-#endif
         kbase += m;
         qhead = (qhead + m) & (kSegRing - 1);
         qcount -= m;
@@ -461,12 +444,6 @@ __global__ __launch_bounds__(kSegThreads, 4) void render_fwd_seg_kernel(int W, i
         out_depth[vb + pix] = rD;
         out_alpha[vb + pix] = rA;
     }
-#ifdef SGR_DBG_TIMING
-    if (t == 0 && blockIdx.x < 16384) {
-        g_dbg_timing[4 * blockIdx.x + 0] = (uint32_t)dbg_t0; g_dbg_timing[4 * blockIdx.x + 1] = (uint32_t)wall_clock64();
-        g_dbg_timing[4 * blockIdx.x + 2] = (uint32_t)n; g_dbg_timing[4 * blockIdx.x + 3] = dbg_rounds | (kbase << 8);
-    }
-#endif
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -816,9 +793,6 @@ int sgr_validate_problem(const SgrProblem *pb);
 
 // 0 = automatic, 1 = serial per-tile kernel, 2 = segment-parallel kernel (dev/test override: sgr_set_forward_mode)
 static int sgr_fwd_mode = 0;
-#ifdef SGR_DBG_TIMING
-extern "C" int sgr_dbg_timing_read(uint32_t *host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_dbg_timing), sizeof(uint32_t) * 4 * 16384); }
-#endif
 extern "C" int sgr_set_forward_mode(int mode) { sgr_fwd_mode = mode; return 0; }
 int sgr_get_forward_mode() { return sgr_fwd_mode; }
 

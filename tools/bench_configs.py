@@ -1,6 +1,7 @@
 """All five BASELINE.json configs on one MI355X (evidence for DESIGN.md / README; bench.py stays the driver's contract = C2).
 Prints one JSON line per config."""
 import json, os, sys, time
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
 from types import SimpleNamespace
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -35,11 +36,12 @@ def raster_case(g, cov, views, H, bwd, da_grads=False):
     def step():
         with torch.set_grad_enabled(bwd):
             for v in (m, c, o, rgb): v.grad = None
-            color, radii, depth, alpha = R.rasterize_gaussians_batched(m, None, None, rgb, o, None, None, c, st)
             if bwd:
-                loss = clamped_l1_loss(color, gt, None, 1e-6)
+                loss, _, color, radii, depth, alpha = R.rasterize_l1_loss_batched(m, None, None, rgb, o, None, None, c, st, gt, None, 1e-6)
                 if da_grads: loss = loss + 1e-6 * (depth.sum() + alpha.sum())
                 loss.backward()
+            else:
+                R.rasterize_gaussians_batched(m, None, None, rgb, o, None, None, c, st)
     return step, Rn, S
 
 
@@ -53,6 +55,7 @@ ts = []
 for i in range(4):
     t0 = time.perf_counter(); r = oracle.forward(g["position"], g["opacity"].reshape(-1), colors_precomp=g["rgb"], cov3D_precomp=cov, **kw)
     oracle.backward(r, np.ones((3, 256, 256), np.float32) / 65536); ts.append(time.perf_counter() - t0)
+os.sched_setaffinity(0, {0, 1, 2, 3})      # like bench.py: the GPU steps are driven by two host threads; keep them on one CCX
 step, Rn, S = raster_case(g, cov, [30], 256, True)
 dt = timeit(step, 50, 10)
 out.append(dict(config="C1 10k random, 1 view 256x256, fwd+bwd", cpu_oracle_views_per_s=round(1 / np.median(ts[1:]), 2), cpu_cores=os.cpu_count(), gpu_views_per_s=round(1 / dt, 1), num_rendered=Rn, visits=S))
