@@ -9,6 +9,7 @@
 #include <string.h>
 
 #include <cstdlib>
+#include <mutex>
 #include "common.h"
 
 namespace {
@@ -35,8 +36,9 @@ struct FwdEntry { FwdKey key; hipGraphExec_t exec; SgrForwardState st; uint64_t 
 constexpr int kGraphSlots = 16;
 FwdEntry g_fwd[kGraphSlots];
 int g_fwd_n = 0;
-uint64_t g_stamp = 0, g_graph_misses = 0, g_graph_hits = 0;
+uint64_t g_stamp = 0, g_graph_misses = 0, g_graph_hits = 0, g_miss_streak = 0;
 int g_graphs_enabled = -1;       // -1 = not decided yet (see graphs_allowed)
+std::mutex g_graph_mu;           // the cache below is process-global: forwards issued from several host threads take turns
 }  // namespace
 
 int sgr_prof_active();
@@ -200,6 +202,7 @@ extern "C" int sgr_rasterize_forward(const SgrProblem *pb, uint64_t capacity, in
 
     const bool try_graph = graphs_allowed() && capacity > 0 && pb->P > 0 && !sgr_prof_active();
     if (try_graph) {
+        std::lock_guard<std::mutex> graph_lock(g_graph_mu);
         FwdKey key;
         memset(&key, 0, sizeof(key));
         key.pb = *pb; key.capacity = capacity; key.with_aux = with_aux; key.fwd_mode = sgr_get_forward_mode();
@@ -210,7 +213,7 @@ extern "C" int sgr_rasterize_forward(const SgrProblem *pb, uint64_t capacity, in
         for (int i = 0; i < g_fwd_n; i++)
             if (memcmp(&g_fwd[i].key, &key, sizeof(key)) == 0) { found = i; break; }
         if (found >= 0 && g_fwd[found].exec) {
-            g_fwd[found].stamp = ++g_stamp; g_graph_hits++;
+            g_fwd[found].stamp = ++g_stamp; g_graph_hits++; g_miss_streak = 0;
             *st = g_fwd[found].st;
             SGR_CHECK_HIP(hipGraphLaunch(g_fwd[found].exec, stream));
             if (nr_pinned_host) SGR_CHECK_HIP(hipMemcpyAsync(nr_pinned_host, num_rendered, 16, hipMemcpyDeviceToHost, stream));
@@ -218,7 +221,7 @@ extern "C" int sgr_rasterize_forward(const SgrProblem *pb, uint64_t capacity, in
             return 0;
         }
         g_graph_misses++;
-        if (g_graph_misses > 64 && g_graph_hits < g_graph_misses) g_graphs_enabled = 0;   // pointers are not stable here: stop trying
+        if (++g_miss_streak > 256) g_graphs_enabled = 0;          // 256 forwards in a row without one repeat: pointers are not stable here, stop trying
         if (found < 0) {
             // first sighting of this argument set: run it with plain launches (this also makes sure every kernel's code object is
             // loaded before anything is captured) and only remember the key; it is captured when it shows up again

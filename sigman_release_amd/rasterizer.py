@@ -110,12 +110,15 @@ _ring = _PinnedRing()
 
 # one persistent allocator callback for the C ABI (creating a ctypes callback per call costs ~10 us); it serves the call
 # that is currently in flight on this thread: PyTorch allocates, the library only receives the pointer.
-_alloc_target = {"dev": None, "blobs": None}
+# (thread-local: ctypes releases the GIL during the C call, and the forward (caller's thread) and a backward (autograd engine
+# thread) of different graphs may be in flight at the same time)
+import threading as _threading
+_alloc_target = _threading.local()
 
 
 def _alloc_cb(_user, which, nbytes):
-    t = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=_alloc_target["dev"])
-    _alloc_target["blobs"][which] = t
+    t = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=_alloc_target.dev)
+    _alloc_target.blobs[which] = t
     return t.data_ptr()
 
 
@@ -175,7 +178,7 @@ def _forward_impl(means3D, opacities, colors_precomp, shs, cov3D_precomp, scales
     nr_host, nr_event, nr_ptr, nr_handle = _ring.next()
     state = _cabi.SgrForwardState()
     blobs = [None, None, None, None]
-    _alloc_target["dev"], _alloc_target["blobs"] = dev, blobs
+    _alloc_target.dev, _alloc_target.blobs = dev, blobs
     use_aux = 1 if (need_ctx and with_aux and not _USE_BWD_V1) else 0
     _cabi.check(L.sgr_rasterize_forward(C.byref(pb), capacity, use_aux, _ALLOC, None, color.data_ptr(), depth.data_ptr(),
                                         alpha.data_ptr(), radii.data_ptr(), nr_ptr,
@@ -217,7 +220,7 @@ def _backward_impl(ctx: _Ctx, means3D, opacities, colors_precomp, shs, cov3D_pre
     d_sc = torch.empty(S, P, 3, dtype=f32, device=dev) if scales is not None else None
     d_rot = torch.empty(S, P, 4, dtype=f32, device=dev) if scales is not None else None
     blobs = ctx.blobs
-    _alloc_target["dev"], _alloc_target["blobs"] = dev, blobs
+    _alloc_target.dev, _alloc_target.blobs = dev, blobs
     _cabi.check(L.sgr_rasterize_backward(C.byref(pb), C.byref(ctx.state), _ptr(ctx.radii), _ptr(img[0]), _ptr(img[1]), _ptr(img[2]),
                                          _ptr(gC), _ptr(gD), _ptr(gA), _ptr(grad_color_scale), _ALLOC, None, _ptr(d_means3D), _ptr(d_means2D), _ptr(d_op),
                                          _ptr(d_col), _ptr(d_sh), _ptr(d_cov), _ptr(d_sc), _ptr(d_rot), _stream(dev)),

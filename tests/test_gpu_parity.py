@@ -448,7 +448,7 @@ def test_side_stream_and_graph_replay(oracle):
     side = torch.cuda.Stream()
     grads = []
     with torch.cuda.stream(side):
-        for it in range(6):
+        for it in range(14):      # the allocator alternates between two pointer sets; each is seen once, captured once, then replayed
             for v in d.values():
                 v.grad = None
             color, radii, depth, alpha = R.rasterize_gaussians_batched(d["means3D"], None, None, d["colors_precomp"],
