@@ -73,6 +73,19 @@ class GaussianRenderer:
         self.bg_color = torch.tensor([1, 1, 1], dtype=torch.float32, device=device)
         self.tan_half_fov = float(np.tan(0.5 * self.opt.FoVy))
 
+    # 3DGS PLY I/O with the reference's semantics (gs.py:120-252); implementation in ply.py
+    def save_ply(self, gaussians, path, compatible=True):
+        from . import ply
+        ply.save_ply(gaussians, path, compatible)
+
+    def load_ply(self, path, compatible=True):
+        from . import ply
+        return ply.load_ply(path, compatible)
+
+    def load_gaussians_from_ply(self, path):
+        from . import ply
+        return ply.load_gaussians_from_ply(path)
+
     def render(self, gaussians, cam_view, cam_view_proj, cam_pos, bg_color=None, scale_modifier=0.5):
         B, V = cam_view.shape[:2]
         H, W = self.opt.output_size_h, self.opt.output_size_w

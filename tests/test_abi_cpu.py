@@ -55,3 +55,38 @@ def test_product_never_imports_the_oracle():
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in txt.replace("dense autograd oracle", "").replace("CPU oracle", "") or f in (), \
                     f"{f} mentions the oracle package"
+
+
+def test_ply_roundtrip_and_checkpoint_loader(tmp_path):
+    """3DGS PLY I/O with the reference's semantics (gs.py:120-252): prune, inverse activations, property order, BGR flip."""
+    import numpy as np
+    import torch
+    from sigman_release_amd import ply
+    rng = np.random.default_rng(3)
+    N = 500
+    g = np.concatenate([rng.normal(size=(N, 3)), rng.uniform(0.0, 1.0, (N, 1)), rng.uniform(0.002, 0.05, (N, 3)),
+                        rng.normal(size=(N, 4)), rng.uniform(0.05, 0.95, (N, 3))], 1).astype(np.float32)
+    g[:7, 3] = 0.001                                              # below the 0.005 prune threshold
+    g[7:, 3] = np.clip(g[7:, 3], 0.01, 0.99)
+    t = torch.from_numpy(g)[None]
+    for compatible in (True, False):
+        path = str(tmp_path / f"g_{compatible}.ply")
+        ply.save_ply(t, path, compatible)
+        head = open(path, "rb").read(600).decode("ascii", "replace")
+        names = [l.split()[-1] for l in head.split("end_header")[0].splitlines() if l.startswith("property")]
+        assert names == ["x", "y", "z", "f_dc_0", "f_dc_1", "f_dc_2", "opacity", "scale_0", "scale_1", "scale_2", "rot_0", "rot_1", "rot_2", "rot_3"]
+        back = ply.load_ply(path, compatible).numpy()
+        assert back.shape == (N - 7, 14)
+        np.testing.assert_allclose(back, g[7:], rtol=2e-5, atol=2e-6)
+    # a "training checkpoint" style file: pre-activation values + f_rest_*; ascii format on purpose
+    raw = ply.read_vertex_ply(str(tmp_path / "g_True.ply"))
+    cols = [(k, raw[k]) for k in ("x", "y", "z", "f_dc_0", "f_dc_1", "f_dc_2")] + [(f"f_rest_{i}", np.zeros(N - 7, np.float32)) for i in range(45)] + \
+           [(k, raw[k]) for k in ("opacity", "scale_0", "scale_1", "scale_2", "rot_0", "rot_1", "rot_2", "rot_3")]
+    p2 = str(tmp_path / "ckpt.ply")
+    with open(p2, "w") as f:
+        f.write("ply\nformat ascii 1.0\ncomment test\nelement vertex %d\n" % (N - 7) + "".join(f"property float {k}\n" for k, _ in cols) + "end_header\n")
+        np.savetxt(f, np.stack([c for _, c in cols], 1), fmt="%.9g")
+    ck = ply.load_gaussians_from_ply(p2).numpy()
+    np.testing.assert_allclose(ck[:, :7], g[7:, :7], rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(ck[:, 7:11], g[7:, 7:11] / np.linalg.norm(g[7:, 7:11], axis=1, keepdims=True), rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(ck[:, 11:], g[7:, 11:][:, [2, 1, 0]], rtol=2e-5, atol=2e-6)
