@@ -69,6 +69,19 @@ def humanoid(P=20000, H=256, W=256, seed=1, views=(30,)):
     return inp, _settings(views, H, W)
 
 
+def deep_tiles(P=9000, H=48, W=48, seed=9):
+    """A few tiles with very long lists of faint Gaussians (no pixel saturates): several rounds of the segment-parallel forward's
+    LDS ring per (tile, quadrant) incl. wrap-around, balanced last rounds, and backward buckets strung across rounds."""
+    rng = np.random.default_rng(seed)
+    g = synthetic.random_cloud(P, seed)
+    g["position"] = (g["position"] * np.array([0.12, 0.12, 0.8])).astype(np.float32)      # a thin column in front of the camera
+    g["world_scale"] = np.full((P, 3), 0.012, np.float32)
+    g["opacity"] = (rng.uniform(0.01, 0.04, (P, 1))).astype(np.float32)
+    inp = dict(means3D=g["position"], opacities=g["opacity"].reshape(P), colors_precomp=g["rgb"],
+               cov3D_precomp=synthetic.covariance_from_gaussians(g))
+    return inp, _settings((30,), H, W)
+
+
 CASES = {
     "cloud_precomp": lambda: cloud_precomp(),
     "cloud_precomp_ragged": lambda: cloud_precomp(P=257, H=50, W=70, seed=11, bg=np.array([0.1, 0.7, 0.3], np.float32)),
@@ -79,6 +92,7 @@ CASES = {
     "single_gaussian": lambda: cloud_precomp(P=1, H=33, W=17, seed=4, scale_mul=20.0),
     "c1_10k_256": lambda: cloud_precomp(P=10000, H=256, W=256, seed=0, scale_mul=1.0),
     "humanoid_20k_256": lambda: humanoid(),
+    "deep_tiles": lambda: deep_tiles(),
 }
 
 
