@@ -344,6 +344,9 @@ __global__ __launch_bounds__(kSegThreads, 4) void render_fwd_seg_kernel(int W, i
         const bool done_at_start = done;
         float d0 = 0.f, d1 = 0.f, d2 = 0.f, dD = 0.f, dA = 0.f;
         uint32_t contributed = 0;
+        // (a segment behind the point where all 64 pixels have stopped skips the loop: the code below is branch-free, so it would cost
+        // the full 51 instructions per survivor for nothing -- a third of the evaluated pairs on the opaque C2 subject)
+        if (__ballot(!done))
         for (uint32_t s = s0; s < s1; s += 4) {
             if (AUX && s != s0 && ((s - s0) & 15u) == 0u) {
                 // state at survivor 16 / 32 / 48 of my segment, relative to the segment start (the start's absolute sums are only
