@@ -158,7 +158,7 @@ def main():
             loss.backward(one)              # explicit seed: autograd would otherwise launch a ones_like fill kernel every step
             return loss
         loss, grad = parallel.view_parallel_step(packed, all_views, lambda m, c, o, r, mine: render_loss(m, c, o, r, mine),
-                                                 exchange=args.exchange, seed_grad=one)
+                                                 exchange=args.exchange, seed_grad=one, pack_grad=False)
         return loss
 
     L = _cabi.lib()

@@ -50,7 +50,7 @@ def unpack_attributes(packed: torch.Tensor):
 
 
 def view_parallel_step(packed: torch.Tensor, view_ids: Sequence[int], render_loss: Callable, *, src: int = 0, group=None,
-                       broadcast: bool = True, exchange: str = "full", seed_grad: torch.Tensor = None):
+                       broadcast: bool = True, exchange: str = "full", seed_grad: torch.Tensor = None, pack_grad: bool = True):
     """One fwd+bwd step of a subject whose views are sharded over the ranks of `group`.
 
     packed      flat [13*P] attributes (pack_attributes); exchange="full": only rank `src` needs valid contents when broadcast=True
@@ -59,6 +59,8 @@ def view_parallel_step(packed: torch.Tensor, view_ids: Sequence[int], render_los
     exchange    "full": returns (global loss, GLOBAL gradient flat [13*P]);  "loss": returns (global loss, this rank's PARTIAL
                 gradient) with the loss all-reduce overlapped with the backward (module docstring)
     seed_grad   optional 0-d ones tensor for loss.backward() (saves the fill kernel autograd would launch for it)
+    pack_grad   exchange="loss" only: False returns the partial gradient as the tuple (d_means3D, d_cov3D, d_opacity, d_rgb) of the
+                autograd leaves instead of one concatenated [13*P] buffer (saves a copy kernel when the caller consumes them separately)
     """
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -77,9 +79,10 @@ def view_parallel_step(packed: torch.Tensor, view_ids: Sequence[int], render_los
             work = dist.all_reduce(loss_val, op=dist.ReduceOp.SUM, group=group, async_op=True)   # travels while the backward runs
         if loss is not None:
             loss.backward(seed_grad)
-            grad = torch.cat([(l.grad if l.grad is not None else torch.zeros_like(l)).reshape(-1) for l in leaves])
+            grads = [(l.grad if l.grad is not None else torch.zeros_like(l)) for l in leaves]
         else:
-            grad = torch.zeros_like(packed)
+            grads = [torch.zeros_like(l) for l in leaves]
+        grad = torch.cat([g.reshape(-1) for g in grads]) if pack_grad else tuple(grads)
         if work is not None:
             work.wait()
         return loss_val[0], grad

@@ -90,3 +90,27 @@ def test_ply_roundtrip_and_checkpoint_loader(tmp_path):
     np.testing.assert_allclose(ck[:, :7], g[7:, :7], rtol=2e-5, atol=2e-6)
     np.testing.assert_allclose(ck[:, 7:11], g[7:, 7:11] / np.linalg.norm(g[7:, 7:11], axis=1, keepdims=True), rtol=2e-5, atol=2e-6)
     np.testing.assert_allclose(ck[:, 11:], g[7:, 11:][:, [2, 1, 0]], rtol=2e-5, atol=2e-6)
+
+
+def test_ctypes_structs_match_the_c_header(tmp_path):
+    """The ctypes mirror of SgrProblem / SgrForwardState must have the C compiler's size and field offsets (no GPU needed)."""
+    import ctypes as C
+    import os
+    import subprocess
+    from sigman_release_amd import _cabi
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    fields = {"SgrProblem": [n for n, _ in _cabi.SgrProblem._fields_], "SgrForwardState": [n for n, _ in _cabi.SgrForwardState._fields_]}
+    src = ['#include <stdio.h>', '#include <stddef.h>', '#include "sigman_gsplat.h"', 'int main(void) {']
+    for st, names in fields.items():
+        src.append(f'printf("{st} %zu\\n", sizeof({st}));')
+        src += [f'printf("{st}.{n} %zu\\n", offsetof({st}, {n}));' for n in names]
+    src += ['return 0; }']
+    c_file, exe = tmp_path / "abi.c", tmp_path / "abi"
+    c_file.write_text("\n".join(src))
+    subprocess.check_call(["gcc", "-I", os.path.join(root, "include"), str(c_file), "-o", str(exe)])
+    out = dict(l.split() for l in subprocess.check_output([str(exe)], text=True).splitlines())
+    for st in fields:
+        cls = getattr(_cabi, st)
+        assert int(out[st]) == C.sizeof(cls), st
+        for n in fields[st]:
+            assert int(out[f"{st}.{n}"]) == getattr(cls, n).offset, f"{st}.{n}"
