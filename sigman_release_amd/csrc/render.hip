@@ -227,7 +227,7 @@ __global__ __launch_bounds__(kSegThreads, 4) void render_fwd_seg_kernel(int W, i
                                                                      float *__restrict__ out_color, float *__restrict__ out_depth,
                                                                      float *__restrict__ out_alpha, float *__restrict__ final_T,
                                                                      uint32_t *__restrict__ n_contrib, FwdAux aux,
-                                                                     const uint32_t *__restrict__ order) {
+                                                                     const uint32_t *__restrict__ order, uint32_t n_slots) {
     // survivor ring, one float4 per field group at the same index (one address computation serves all three reads):
     __shared__ float4 sA[kSegRing], sB[kSegRing], sC[kSegRing];   // (x, y, kxx, kxy), (kyy, opacity, depth, r), (g, b, list index + 1, -)
     __shared__ float sT[kSegWaves][64];
@@ -237,8 +237,12 @@ __global__ __launch_bounds__(kSegThreads, 4) void render_fwd_seg_kernel(int W, i
     __shared__ uint32_t sWaveCnt[kSegWaves];
     __shared__ uint32_t sContrib[kSegWaves];
     // work order: longest lists first (fwd_prepare_kernel); the tail of the grid are the empty tiles, which only write the background
-    uint32_t bid = blockIdx.x >> 2;
-    const uint32_t q = blockIdx.x & 3u;
+    // XCD placement: consecutive workgroup ids go round-robin over the 8 XCDs (each with its own L2), so the four quadrant workgroups
+    // of a tile -- which gather the same records -- are given ids b, b+8, b+16, b+24: same XCD, dispatched back to back
+    const uint32_t slot = (blockIdx.x >> 5) * 8u + (blockIdx.x & 7u);
+    const uint32_t q = (blockIdx.x >> 3) & 3u;
+    if (slot >= n_slots) return;                                 // (grid padded to a multiple of 32)
+    uint32_t bid = slot;
     if (order) bid = order[1 + bid];
     const uint32_t view = bid / tiles_per_view, tile = bid - view * tiles_per_view;
     const uint32_t tx = tile % Tx, ty = tile / Tx;
@@ -646,8 +650,11 @@ __global__ __launch_bounds__(kBlock) void render_bwd_bucket_kernel(int W, int H,
     __shared__ float4 sPixB[4][64];           //           (g1, g2, gD, gA)
     __shared__ float2 sDyn[4][4][64];         // per wave, per row: (T, Rem) of pixel p at the start of the row
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const size_t slot = (size_t)blockIdx.x * 4 + wv;
-    if (slot >= (size_t)4 * aux.NS) return;
+    // XCD placement as in the forward: workgroup ids b, b+8, b+16, b+24 (same XCD) take the same stretch of bucket slots in the four
+    // quadrants, i.e. buckets of the same tiles, which gather the same records
+    const uint32_t qb = (blockIdx.x >> 3) & 3u, idx = (blockIdx.x >> 5) * 8u + (blockIdx.x & 7u);
+    if ((size_t)idx * 4 + wv >= (size_t)aux.NS) return;
+    const size_t slot = (size_t)qb * aux.NS + (size_t)idx * 4 + wv;
     const uint2 desc_v = aux.desc[slot];
     // the descriptor is wave-uniform: move it to SGPRs so the step loop below is a scalar loop
     const uint32_t desc_y = (uint32_t)__builtin_amdgcn_readfirstlane((int)desc_v.y);
@@ -657,7 +664,7 @@ __global__ __launch_bounds__(kBlock) void render_bwd_bucket_kernel(int W, int H,
     const uint32_t count = desc_y & 127u;
     if (count == 0) return;                                   // unused bucket slot (no block-level barrier is used below)
     const uint32_t start = desc_y >> 7;                        // ordinal of this bucket's first survivor in the quadrant list
-    const uint32_t q = (uint32_t)(slot / aux.NS);
+    const uint32_t q = qb;
     const uint32_t view = bid / tiles_per_view, tile = bid - view * tiles_per_view;
     const uint32_t tx = tile % Tx, ty = tile / Tx;
     const uint32_t rx = ranges[bid].x;
@@ -843,14 +850,15 @@ int sgr_render_forward_ex(const SgrProblem *pb, const uint32_t *ranges, const ui
         SGR_CHECK_LAUNCH("fwd_prepare_kernel");
     }
     if (seg) {
+        const uint32_t seg_grid = (uint32_t)((tiles_total + 7) / 8) * 32u;       // 8 tile slots x 4 quadrants per group of 32 ids
         if (use_aux)
-            hipLaunchKernelGGL(render_fwd_seg_kernel<true>, dim3(tiles * pb->n_views * 4), dim3(kSegThreads), 0, stream, pb->W, pb->H,
+            hipLaunchKernelGGL(render_fwd_seg_kernel<true>, dim3(seg_grid), dim3(kSegThreads), 0, stream, pb->W, pb->H,
                                Tx, tiles, (const uint2 *)ranges, point_list, (const float4 *)rec, pb->bg, out_color, out_depth,
-                               out_alpha, final_T, n_contrib, aux, (const uint32_t *)aux_order);
+                               out_alpha, final_T, n_contrib, aux, (const uint32_t *)aux_order, (uint32_t)tiles_total);
         else
-            hipLaunchKernelGGL(render_fwd_seg_kernel<false>, dim3(tiles * pb->n_views * 4), dim3(kSegThreads), 0, stream, pb->W, pb->H,
+            hipLaunchKernelGGL(render_fwd_seg_kernel<false>, dim3(seg_grid), dim3(kSegThreads), 0, stream, pb->W, pb->H,
                                Tx, tiles, (const uint2 *)ranges, point_list, (const float4 *)rec, pb->bg, out_color, out_depth,
-                               out_alpha, final_T, n_contrib, aux, (const uint32_t *)aux_order);
+                               out_alpha, final_T, n_contrib, aux, (const uint32_t *)aux_order, (uint32_t)tiles_total);
         SGR_CHECK_LAUNCH("render_fwd_seg_kernel");
         return 0;
     }
@@ -895,7 +903,7 @@ int sgr_render_backward_ex(const SgrProblem *pb, const uint32_t *ranges, const u
     if (use_aux) {
         FwdAux aux = make_aux((void *)aux_compact, (void *)aux_ckpt_tc, (void *)aux_ckpt_da, (void *)aux_desc, R,
                               (uint64_t)tiles * pb->n_views);
-        const uint32_t nblocks = aux.NS;                        // 4*NS waves, 4 waves per workgroup
+        const uint32_t nblocks = ((aux.NS + 3u) / 4u + 7u) / 8u * 32u;     // per quadrant ceil(NS / 4) workgroups of 4 waves, in groups of 8 x 4 quadrants
         if (grad_depth || grad_alpha)
             hipLaunchKernelGGL(render_bwd_bucket_kernel<true>, dim3(nblocks), dim3(kBlock), 0, stream, pb->W, pb->H, Tx, tiles,
                                (const uint2 *)ranges, (const float4 *)rec, n_contrib, out_color, out_depth, out_alpha, grad_color,
