@@ -114,3 +114,30 @@ def test_ctypes_structs_match_the_c_header(tmp_path):
         assert int(out[st]) == C.sizeof(cls), st
         for n in fields[st]:
             assert int(out[f"{st}.{n}"]) == getattr(cls, n).offset, f"{st}.{n}"
+
+
+def test_c_program_links_against_the_library(tmp_path):
+    """A plain C translation unit including include/sigman_gsplat.h links against libsigman_gsplat.so and can call the entry points
+    that need no GPU (the boundary really is a C ABI: no C++ names, no torch types)."""
+    import os
+    import subprocess
+    from sigman_release_amd import _cabi
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    _cabi.lib()                                                    # raises with build instructions if the library is missing
+    src = r'''
+#include <stdio.h>
+#include "sigman_gsplat.h"
+int main(void) {
+    SgrProblem pb; SgrForwardState st; (void)pb; (void)st;
+    printf("%d %llu %llu\n", sgr_abi_version(), (unsigned long long)sgr_bucket_slots(1000, 16),
+           (unsigned long long)sgr_bin_workspace_bytes(1000, 16));
+    return sgr_last_error() == 0;
+}
+'''
+    c_file, exe = tmp_path / "link.c", tmp_path / "link"
+    c_file.write_text(src)
+    libdir = os.path.dirname(_cabi.LIB_PATH)
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(root, "include"), str(c_file), "-o", str(exe),
+                           "-L", libdir, "-lsigman_gsplat", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.check_output([str(exe)], text=True).split()
+    assert int(out[0]) == 1 and int(out[1]) == (1000 >> 6) + 16 + 1 and int(out[2]) > 0
