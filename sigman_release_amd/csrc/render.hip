@@ -15,6 +15,7 @@
 //
 // Roofline: algorithmic HBM bytes are 44 B per tile instance + 24 B (fwd) / 28 B (bwd) per pixel
 // (SURVEY.md 8d); with 3-4 px splats the inner loop is VALU-bound, not HBM-bound -- see DESIGN.md.
+#include <cstdlib>
 #include "common.h"
 
 namespace {
@@ -212,6 +213,7 @@ __global__ __launch_bounds__(kBlock) void render_fwd_kernel(int W, int H, int Tx
 // survivors (only the last one of a list is shorter) keeps all four 16-lane rows of the backward's waves busy.
 // -------------------------------------------------------------------------------------------------
 constexpr int kSegThreads = 512, kSegWaves = 8, kSegRing = 1024, kSegPer = 64;
+typedef float v2f __attribute__((ext_vector_type(2)));      // <2 x float>: the backend selects v_pk_{add,mul,fma}_f32 for it
 
 __device__ __forceinline__ bool cull_quadrant(const float4 &a, const float4 &c, float qx0, float qy0) {
     const float hx = c.z, hy = c.w;
@@ -228,8 +230,11 @@ __global__ __launch_bounds__(kSegThreads, 4) void render_fwd_seg_kernel(int W, i
                                                                      float *__restrict__ out_alpha, float *__restrict__ final_T,
                                                                      uint32_t *__restrict__ n_contrib, FwdAux aux,
                                                                      const uint32_t *__restrict__ order, uint32_t n_slots) {
-    // survivor ring, one float4 per field group at the same index (one address computation serves all three reads):
-    __shared__ float4 sA[kSegRing], sB[kSegRing], sC[kSegRing];   // (x, y, kxx, kxy), (kyy, opacity, depth, r), (g, b, list index + 1, -)
+    // survivor ring, stored as PAIRS of consecutive survivors with the two survivors' values of each field adjacent, so that the
+    // per-pixel arithmetic of both runs as packed fp32 (v_pk_*: two survivors per instruction) straight out of ds_read_b128:
+    __shared__ float4 pA[kSegRing / 2], pB[kSegRing / 2], pC[kSegRing / 2];   // (x0,x1,y0,y1) (kxx0,kxx1,kxy0,kxy1) (kyy0,kyy1,op0,op1)
+    __shared__ float4 pD[kSegRing / 2], pE[kSegRing / 2];                     // (r0,g0,r1,g1) (b0,depth0,b1,depth1): per-survivor channel pairs
+    __shared__ uint2 pI[kSegRing / 2];                                        // (list index + 1) of both
     __shared__ float sT[kSegWaves][64];
     __shared__ float sAcc[kSegWaves][5][64];
     __shared__ float sTstop[64];
@@ -290,9 +295,14 @@ __global__ __launch_bounds__(kSegThreads, 4) void render_fwd_seg_kernel(int W, i
             if (bit) {
                 const uint32_t ord = qcount + woff + (uint32_t)__popcll(bal & lt_mask);     // position behind the ring head
                 const uint32_t s = (qhead + ord) & (kSegRing - 1);
-                sA[s] = make_float4(ra.x, ra.y, kHalfLog2e * ra.z, kLog2e * ra.w);
-                sB[s] = make_float4(kHalfLog2e * rb.x, rb.y, rb.z, rb.w);
-                sC[s] = make_float4(rc.x, rc.y, __uint_as_float((uint32_t)idx + 1u), 0.f);
+                const uint32_t pr = s >> 1, h = s & 1u;
+                float *fa = (float *)&pA[pr], *fb = (float *)&pB[pr], *fc = (float *)&pC[pr], *fd = (float *)&pD[pr], *fe = (float *)&pE[pr];
+                fa[h] = ra.x; fa[2 + h] = ra.y;
+                fb[h] = kHalfLog2e * ra.z; fb[2 + h] = kLog2e * ra.w;
+                fc[h] = kHalfLog2e * rb.x; fc[2 + h] = rb.y;
+                fd[2 * h] = rb.w; fd[2 * h + 1] = rc.x;
+                fe[2 * h] = rc.y; fe[2 * h + 1] = rb.z;
+                ((uint32_t *)&pI[pr])[h] = (uint32_t)idx + 1u;
                 if (AUX) aux.compact[(size_t)q * aux.R + range.x + kbase + ord] = make_uint2(rid, (uint32_t)idx);
             }
             qcount += m;
@@ -317,23 +327,31 @@ __global__ __launch_bounds__(kSegThreads, 4) void render_fwd_seg_kernel(int W, i
         // qhead and every segment start are multiples of 4, so a group of four never wraps around the ring.
         if ((m & 3u) && (uint32_t)t < 4u - (m & 3u)) {
             const uint32_t s = (qhead + m + (uint32_t)t) & (kSegRing - 1);
-            sA[s] = make_float4(0.f, 0.f, 0.f, 0.f); sB[s] = sA[s]; sC[s] = sA[s];
+            const uint32_t pr = s >> 1, h = s & 1u;
+            float *fa = (float *)&pA[pr], *fb = (float *)&pB[pr], *fc = (float *)&pC[pr], *fd = (float *)&pD[pr], *fe = (float *)&pE[pr];
+            fa[h] = 0.f; fa[2 + h] = 0.f; fb[h] = 0.f; fb[2 + h] = 0.f; fc[h] = 0.f; fc[2 + h] = 0.f;      // opacity 0: never valid
+            fd[2 * h] = 0.f; fd[2 * h + 1] = 0.f; fe[2 * h] = 0.f; fe[2 * h + 1] = 0.f;
+            ((uint32_t *)&pI[pr])[h] = 0u;
         }
         if (m & 3u) __syncthreads();
 #define SGR_RING(S) ((qhead + (S)) & (kSegRing - 1))
         // ---- phase 1: transmittance product of my segment
         float Tseg = 1.f;
+        const v2f px2 = {pxf, pxf}, py2 = {pyf, pyf};
         for (uint32_t s = s0; s < s1; s += 4) {
             float om[4];
-            const uint32_t sb = SGR_RING(s);
+            const uint32_t pb = SGR_RING(s) >> 1;
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const float4 ga = sA[sb + u], gb = sB[sb + u];
-                const float dx = ga.x - pxf, dy = ga.y - pyf;
-                const float power = (ga.z * dx) * dx + ((gb.x * dy) * dy + (ga.w * dx) * dy);
-                const float alpha = fminf(0.99f, gb.y * __builtin_amdgcn_exp2f(power));
-                const bool valid = (power <= 0.f) & (alpha >= (1.0f / 255.0f));
-                om[u] = valid ? 1.f - alpha : 1.f;
+            for (int u = 0; u < 2; u++) {                                  // two pairs = four survivors
+                const float4 qa = pA[pb + u], qb = pB[pb + u], qc = pC[pb + u];
+                const v2f gx = {qa.x, qa.y}, gy = {qa.z, qa.w}, kxx = {qb.x, qb.y}, kxy = {qb.z, qb.w}, kyy = {qc.x, qc.y}, op = {qc.z, qc.w};
+                const v2f dx = gx - px2, dy = gy - py2;
+                const v2f power = (kxx * dx) * dx + ((kyy * dy) * dy + (kxy * dx) * dy);
+                const v2f G = {__builtin_amdgcn_exp2f(power.x), __builtin_amdgcn_exp2f(power.y)};
+                const v2f og = op * G;
+                const float a0 = fminf(0.99f, og.x), a1 = fminf(0.99f, og.y);
+                om[2 * u] = ((power.x <= 0.f) & (a0 >= (1.0f / 255.0f))) ? 1.f - a0 : 1.f;
+                om[2 * u + 1] = ((power.y <= 0.f) & (a1 >= (1.0f / 255.0f))) ? 1.f - a1 : 1.f;
             }
             Tseg = (((Tseg * om[0]) * om[1]) * om[2]) * om[3];
         }
@@ -346,7 +364,8 @@ __global__ __launch_bounds__(kSegThreads, 4) void render_fwd_seg_kernel(int W, i
         float T = Tin;
         bool done = !inside | (Tin < 0.0001f);
         const bool done_at_start = done;
-        float d0 = 0.f, d1 = 0.f, d2 = 0.f, dD = 0.f, dA = 0.f;
+        v2f d01 = {0.f, 0.f}, d2D = {0.f, 0.f};
+        float dA = 0.f;
         uint32_t contributed = 0;
         // (a segment behind the point where all 64 pixels have stopped skips the loop: the code below is branch-free, so it would cost
         // the full 51 instructions per survivor for nothing -- a third of the evaluated pairs on the opaque C2 subject)
@@ -356,21 +375,28 @@ __global__ __launch_bounds__(kSegThreads, 4) void render_fwd_seg_kernel(int W, i
                 // state at survivor 16 / 32 / 48 of my segment, relative to the segment start (the start's absolute sums are only
                 // known after the cross-wave prefix below; the backward adds the two)
                 const size_t sl = ((slot_next + (s0 >> 6)) * 4 + brow0 + ((s - s0) >> 4)) * 64 + lane;
-                aux.ckpt_tc[sl] = make_float4(T, d0, d1, d2);
-                aux.ckpt_da[sl] = make_float2(dD, dA);
+                aux.ckpt_tc[sl] = make_float4(T, d01.x, d01.y, d2D.x);
+                aux.ckpt_da[sl] = make_float2(d2D.y, dA);
             }
             float al[4];
-            float4 gb4[4], gc2[4];
-            const uint32_t sb = SGR_RING(s);
+            v2f rg[4], bd[4];                                              // (r, g) and (b, depth) of the four survivors
+            uint32_t li[4];
+            const uint32_t pb = SGR_RING(s) >> 1;
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const float4 ga = sA[sb + u];
-                gb4[u] = sB[sb + u]; gc2[u] = sC[sb + u];
-                const float dx = ga.x - pxf, dy = ga.y - pyf;
-                const float power = (ga.z * dx) * dx + ((gb4[u].x * dy) * dy + (ga.w * dx) * dy);
-                const float alpha = fminf(0.99f, gb4[u].y * __builtin_amdgcn_exp2f(power));
-                const bool valid = (power <= 0.f) & (alpha >= (1.0f / 255.0f));
-                al[u] = valid ? alpha : 0.f;
+            for (int u = 0; u < 2; u++) {
+                const float4 qa = pA[pb + u], qb = pB[pb + u], qc = pC[pb + u], qd = pD[pb + u], qe = pE[pb + u];
+                const uint2 qi = pI[pb + u];
+                const v2f gx = {qa.x, qa.y}, gy = {qa.z, qa.w}, kxx = {qb.x, qb.y}, kxy = {qb.z, qb.w}, kyy = {qc.x, qc.y}, op = {qc.z, qc.w};
+                const v2f dx = gx - px2, dy = gy - py2;
+                const v2f power = (kxx * dx) * dx + ((kyy * dy) * dy + (kxy * dx) * dy);
+                const v2f G = {__builtin_amdgcn_exp2f(power.x), __builtin_amdgcn_exp2f(power.y)};
+                const v2f og = op * G;
+                const float a0 = fminf(0.99f, og.x), a1 = fminf(0.99f, og.y);
+                al[2 * u] = ((power.x <= 0.f) & (a0 >= (1.0f / 255.0f))) ? a0 : 0.f;
+                al[2 * u + 1] = ((power.y <= 0.f) & (a1 >= (1.0f / 255.0f))) ? a1 : 0.f;
+                rg[2 * u] = (v2f){qd.x, qd.y}; rg[2 * u + 1] = (v2f){qd.z, qd.w};
+                bd[2 * u] = (v2f){qe.x, qe.y}; bd[2 * u + 1] = (v2f){qe.z, qe.w};
+                li[2 * u] = qi.x; li[2 * u + 1] = qi.y;
             }
 #pragma unroll
             for (int u = 0; u < 4; u++) {
@@ -378,14 +404,16 @@ __global__ __launch_bounds__(kSegThreads, 4) void render_fwd_seg_kernel(int W, i
                 done = done | (test_T < 0.0001f);                 // the crossing Gaussian is NOT composited
                 const bool contrib = (al[u] > 0.f) & !done;
                 const float w = contrib ? al[u] * T : 0.f;
-                d0 = fmaf(gb4[u].w, w, d0); d1 = fmaf(gc2[u].x, w, d1); d2 = fmaf(gc2[u].y, w, d2);
-                dD = fmaf(gb4[u].z, w, dD);
+                const v2f w2 = {w, w};
+                d01 = rg[u] * w2 + d01;                           // (d0, d1) += (r, g) * w   -- one v_pk_fma_f32
+                d2D = bd[u] * w2 + d2D;                           // (d2, dD) += (b, depth) * w
                 dA += w;
                 T = contrib ? test_T : T;
-                last = contrib ? __float_as_uint(gc2[u].z) : last;
+                last = contrib ? li[u] : last;
                 contributed |= contrib ? 1u : 0u;
             }
         }
+        const float d0 = d01.x, d1 = d01.y, d2 = d2D.x, dD = d2D.y;
 #undef SGR_RING
         if (done && !done_at_start) Tstop = T;                   // I am the segment in which this pixel stopped
         C0 += d0; C1 += d1; C2 += d2; D += dD; A += dA;
