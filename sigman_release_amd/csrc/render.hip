@@ -663,7 +663,10 @@ __device__ __forceinline__ float row_shift_in(float v, float feed) {
 // pixel states are fed into lane 0 of every row from LDS, one per step, and move one lane up per step (DPP row_shr:1), so
 // pixel p meets the row's Gaussians in front-to-back order.  79 steps per bucket instead of the 127 a single 64-lane
 // pipeline needs (fill/drain is 15 steps instead of 63).
-template <bool HAS_DA>
+// SPLIT (launches with few buckets, i.e. one or two views): TWO waves per bucket, each streaming one half of the quadrant's pixels (47
+// steps instead of 79) -- 19 % more wave-steps but twice the waves, which is what a 4 000-bucket launch on 1 024 SIMDs lacks; the
+// second wave's per-Gaussian sums are added to the first's through LDS before the single partial record is written.
+template <bool HAS_DA, bool SPLIT>
 __global__ __launch_bounds__(kBlock) void render_bwd_bucket_kernel(int W, int H, int Tx, uint32_t tiles_per_view,
                                                                    const uint2 *__restrict__ ranges,
                                                                    const float4 *__restrict__ rec,
@@ -681,8 +684,12 @@ __global__ __launch_bounds__(kBlock) void render_bwd_bucket_kernel(int W, int H,
     // XCD placement as in the forward: workgroup ids b, b+8, b+16, b+24 (same XCD) take the same stretch of bucket slots in the four
     // quadrants, i.e. buckets of the same tiles, which gather the same records
     const uint32_t qb = (blockIdx.x >> 3) & 3u, idx = (blockIdx.x >> 5) * 8u + (blockIdx.x & 7u);
-    if ((size_t)idx * 4 + wv >= (size_t)aux.NS) return;
-    const size_t slot = (size_t)qb * aux.NS + (size_t)idx * 4 + wv;
+    constexpr int NPIX = SPLIT ? 32 : 64;                      // pixels streamed by one wave
+    const uint32_t half = SPLIT ? (uint32_t)(wv & 1) : 0u;     // which half of the quadrant's pixels
+    const uint32_t sub = SPLIT ? (uint32_t)(wv >> 1) : (uint32_t)wv;          // bucket of this workgroup (2 or 4 per workgroup)
+    constexpr uint32_t BPW = SPLIT ? 2u : 4u;
+    if ((size_t)idx * BPW + sub >= (size_t)aux.NS) return;
+    const size_t slot = (size_t)qb * aux.NS + (size_t)idx * BPW + sub;
     const uint2 desc_v = aux.desc[slot];
     // the descriptor is wave-uniform: move it to SGPRs so the step loop below is a scalar loop
     const uint32_t desc_y = (uint32_t)__builtin_amdgcn_readfirstlane((int)desc_v.y);
@@ -690,7 +697,7 @@ __global__ __launch_bounds__(kBlock) void render_bwd_bucket_kernel(int W, int H,
     const uint32_t bid = desc_x & 0x3FFFFFFFu;
     const uint32_t rps = (desc_x >> 30) + 1u;                  // rows per forward segment: rows with r % rps == 0 hold absolute sums
     const uint32_t count = desc_y & 127u;
-    if (count == 0) return;                                   // unused bucket slot (no block-level barrier is used below)
+    if (count == 0) return;                                   // unused bucket slot (both waves of a SPLIT pair leave together; ended waves do not count at barriers)
     const uint32_t start = desc_y >> 7;                        // ordinal of this bucket's first survivor in the quadrant list
     const uint32_t q = qb;
     const uint32_t view = bid / tiles_per_view, tile = bid - view * tiles_per_view;
@@ -712,8 +719,8 @@ __global__ __launch_bounds__(kBlock) void render_bwd_bucket_kernel(int W, int H,
     const float kL2e = 1.4426950408889634f;
     const float kxx = -0.5f * kL2e * cxx, kyy = -0.5f * kL2e * cyy, kxy = -kL2e * cxy;
     // ---- pixel p = lane: static data and the four row start states go to LDS (the per-step feeders)
-    {
-        const int p = lane;
+    if (lane < NPIX) {
+        const int p = lane + (int)half * NPIX;
         const int px = (int)tx * 16 + (int)(q & 1u) * 8 + (p & 7);
         const int py = (int)ty * 16 + (int)(q >> 1) * 8 + (p >> 3);
         const bool inside = px < W && py < H;
@@ -734,8 +741,8 @@ __global__ __launch_bounds__(kBlock) void render_bwd_bucket_kernel(int W, int H,
                 O += out_depth[vb + pix] * gd + out_alpha[vb + pix] * ga;
             }
         }
-        sPixA[wv][p] = make_float4((float)px, (float)py, __uint_as_float(last), g0);
-        sPixB[wv][p] = make_float4(g1, g2, gd, ga);
+        sPixA[wv][lane] = make_float4((float)px, (float)py, __uint_as_float(last), g0);
+        sPixB[wv][lane] = make_float4(g1, g2, gd, ga);
         float T0 = 1.f, Pre0 = 0.f;
         if (inside && start) {
             const float4 tc = aux.ckpt_tc[slot * 256 + p];
@@ -743,7 +750,7 @@ __global__ __launch_bounds__(kBlock) void render_bwd_bucket_kernel(int W, int H,
             Pre0 = tc.y * g0 + tc.z * g1 + tc.w * g2;
             if (HAS_DA) { const float2 da = aux.ckpt_da[slot * 256 + p]; Pre0 += da.x * gd + da.y * ga; }
         }
-        sDyn[wv][0][p] = make_float2(T0, O - Pre0);
+        sDyn[wv][0][lane] = make_float2(T0, O - Pre0);
         float PreSeg = Pre0;                                   // composited-so-far at the start of the forward segment the row is in
 #pragma unroll
         for (int r = 1; r < 4; r++) {
@@ -756,7 +763,7 @@ __global__ __launch_bounds__(kBlock) void render_bwd_bucket_kernel(int W, int H,
                 if (((uint32_t)r & (rps - 1u)) == 0u) PreSeg = dotv;      // rps is 1, 2 or 4
                 Prer = (((uint32_t)r & (rps - 1u)) == 0u) ? dotv : PreSeg + dotv;
             }
-            sDyn[wv][r][p] = make_float2(Tr, O - Prer);
+            sDyn[wv][r][lane] = make_float2(Tr, O - Prer);
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -769,16 +776,16 @@ __global__ __launch_bounds__(kBlock) void render_bwd_bucket_kernel(int W, int H,
     PixState A = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 1.f, 0.f}, B = A;
     // per-Gaussian moment accumulators of v = G * dL/dalpha over the pixels (constant factors applied once at the end)
     float S1 = 0.f, Sx = 0.f, Sy = 0.f, Sxx = 0.f, Sxy = 0.f, Syy = 0.f, aD = 0.f, a7 = 0.f, a8 = 0.f, a9 = 0.f;
-    const int nsteps = 64 + (int)min(count, 16u) - 1;
+    const int nsteps = NPIX + (int)min(count, 16u) - 1;
     const float4 *pa = &sPixA[wv][0], *pb = &sPixB[wv][0];
     const float2 *pd = &sDyn[wv][row][0];
 #define SGR_BWD_STEP(IN, OUT, S)                                                                                        \
     {                                                                                                                   \
-        const int sp = min((S), 63);                                                                                    \
+        const int sp = min((S), NPIX - 1);                                                                              \
         float4 fa = pa[sp];                                                                                             \
         const float4 fb = pb[sp];                                                                                       \
         const float2 fd = pd[sp];                                                                                       \
-        if ((S) >= 64) fa.z = 0.f; /* drain: n_contrib = 0 -> never valid */                                           \
+        if ((S) >= NPIX) fa.z = 0.f; /* drain: n_contrib = 0 -> never valid */                                         \
         OUT.px = row_shift_in(IN.px, fa.x); OUT.py = row_shift_in(IN.py, fa.y); OUT.last = row_shift_in(IN.last, fa.z); \
         OUT.g0 = row_shift_in(IN.g0, fa.w); OUT.g1 = row_shift_in(IN.g1, fb.x); OUT.g2 = row_shift_in(IN.g2, fb.y);     \
         if (HAS_DA) { OUT.gd = row_shift_in(IN.gd, fb.z); OUT.ga = row_shift_in(IN.ga, fb.w); }                         \
@@ -811,6 +818,18 @@ __global__ __launch_bounds__(kBlock) void render_bwd_bucket_kernel(int W, int H,
     }
     if (s < nsteps) SGR_BWD_STEP(A, B, s)
 #undef SGR_BWD_STEP
+    if (SPLIT) {
+        // the odd wave hands its sums to the even wave of the same bucket
+        __shared__ float sComb[2][10][64];
+        if (half == 1u) {
+            float *c = &sComb[sub][0][lane];
+            c[0] = S1; c[64] = Sx; c[128] = Sy; c[192] = Sxx; c[256] = Sxy; c[320] = Syy; c[384] = aD; c[448] = a7; c[512] = a8; c[576] = a9;
+        }
+        __syncthreads();
+        if (half == 1u) return;
+        const float *c = &sComb[sub][0][lane];
+        S1 += c[0]; Sx += c[64]; Sy += c[128]; Sxx += c[192]; Sxy += c[256]; Syy += c[320]; aD += c[384]; a7 += c[448]; a8 += c[512]; a9 += c[576];
+    }
     if (has_g) {
         // one NON-atomic 40-byte partial record per (tile instance, quadrant); preprocess_bwd gathers them in a fixed order
         const uint32_t off = __float_as_uint(rd.x), rmin = __float_as_uint(rd.y), rmax = __float_as_uint(rd.z);
@@ -931,13 +950,24 @@ int sgr_render_backward_ex(const SgrProblem *pb, const uint32_t *ranges, const u
     if (use_aux) {
         FwdAux aux = make_aux((void *)aux_compact, (void *)aux_ckpt_tc, (void *)aux_ckpt_da, (void *)aux_desc, R,
                               (uint64_t)tiles * pb->n_views);
-        const uint32_t nblocks = ((aux.NS + 3u) / 4u + 7u) / 8u * 32u;     // per quadrant ceil(NS / 4) workgroups of 4 waves, in groups of 8 x 4 quadrants
-        if (grad_depth || grad_alpha)
-            hipLaunchKernelGGL(render_bwd_bucket_kernel<true>, dim3(nblocks), dim3(kBlock), 0, stream, pb->W, pb->H, Tx, tiles,
+        // few buckets (one or two views): two waves per bucket (SPLIT) to give the SIMDs enough waves to hide latencies
+        const bool split = (uint64_t)tiles * pb->n_views <= 2048;
+        const uint32_t bpw = split ? 2u : 4u;                            // buckets per workgroup
+        const uint32_t nblocks = ((aux.NS + bpw - 1u) / bpw + 7u) / 8u * 32u;      // per quadrant ceil(NS / bpw) workgroups, in groups of 8 x 4 quadrants
+        if (split && (grad_depth || grad_alpha))
+            hipLaunchKernelGGL((render_bwd_bucket_kernel<true, true>), dim3(nblocks), dim3(kBlock), 0, stream, pb->W, pb->H, Tx, tiles,
+                               (const uint2 *)ranges, (const float4 *)rec, n_contrib, out_color, out_depth, out_alpha, grad_color,
+                               grad_depth, grad_alpha, grad_color_scale, aux, (float4 *)part, (uint8_t *)flags);
+        else if (split)
+            hipLaunchKernelGGL((render_bwd_bucket_kernel<false, true>), dim3(nblocks), dim3(kBlock), 0, stream, pb->W, pb->H, Tx, tiles,
+                               (const uint2 *)ranges, (const float4 *)rec, n_contrib, out_color, out_depth, out_alpha, grad_color,
+                               grad_depth, grad_alpha, grad_color_scale, aux, (float4 *)part, (uint8_t *)flags);
+        else if (grad_depth || grad_alpha)
+            hipLaunchKernelGGL((render_bwd_bucket_kernel<true, false>), dim3(nblocks), dim3(kBlock), 0, stream, pb->W, pb->H, Tx, tiles,
                                (const uint2 *)ranges, (const float4 *)rec, n_contrib, out_color, out_depth, out_alpha, grad_color,
                                grad_depth, grad_alpha, grad_color_scale, aux, (float4 *)part, (uint8_t *)flags);
         else
-            hipLaunchKernelGGL(render_bwd_bucket_kernel<false>, dim3(nblocks), dim3(kBlock), 0, stream, pb->W, pb->H, Tx, tiles,
+            hipLaunchKernelGGL((render_bwd_bucket_kernel<false, false>), dim3(nblocks), dim3(kBlock), 0, stream, pb->W, pb->H, Tx, tiles,
                                (const uint2 *)ranges, (const float4 *)rec, n_contrib, out_color, out_depth, out_alpha, grad_color,
                                grad_depth, grad_alpha, grad_color_scale, aux, (float4 *)part, (uint8_t *)flags);
         SGR_CHECK_LAUNCH("render_bwd_bucket_kernel");
