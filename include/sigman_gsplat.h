@@ -110,6 +110,8 @@ typedef struct SgrForwardState {
  * capacity > 0: sync-free mode; binning buffers sized for `capacity` instances; the true count is copied asynchronously to
  *               nr_pinned_host[0] (and [1] = overflow flag) and `nr_event` (a hipEvent_t, may be NULL) is recorded right after.
  * with_aux != 0 also records what the bucket-parallel backward needs.
+ * alloc may be NULL if state->geom / binning / image and their *_bytes capacities are pre-filled by the caller (sizes as reported in
+ * the state of an earlier call with the same shapes): no callbacks; returns 2 (nothing useful launched) if a blob is too small.
  * caller_clear / caller_clear_bytes: optional device buffer (multiple of 4 bytes) that the call zeroes on the side of its own
  * kernels (no extra launch): the accumulators of a loss kernel the caller runs right behind the forward.
  * Outputs: out_color [n_views,3,H,W], out_depth/out_alpha [n_views,1,H,W], out_radii i32 [n_views,P].

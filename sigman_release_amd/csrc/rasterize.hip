@@ -125,7 +125,17 @@ extern "C" int sgr_rasterize_forward(const SgrProblem *pb, uint64_t capacity, in
                                      float *out_color, float *out_depth, float *out_alpha, int32_t *out_radii,
                                      uint64_t *nr_pinned_host, void *nr_event, void *caller_clear, uint64_t caller_clear_bytes,
                                      SgrForwardState *st, void *stream_) {
-    if (!pb || !alloc || !st || !out_color || !out_depth || !out_alpha || (!out_radii && pb->P > 0)) { sgr_set_error("sgr_rasterize_forward: NULL argument"); return 1; }
+    if (!pb || !st || !out_color || !out_depth || !out_alpha || (!out_radii && pb->P > 0)) { sgr_set_error("sgr_rasterize_forward: NULL argument"); return 1; }
+    // alloc == NULL: the caller pre-allocated the three blobs (state->geom / binning / image with their *_bytes capacities, e.g. from the
+    // sizes a previous call with the same shapes reported): no callbacks.  A blob that is too small -> return 2 with the needed sizes in
+    // state->*_bytes (nothing launched yet for the geometry blob; the caller retries with the allocator).
+    const SgrForwardState pre = *st;
+    if (!alloc && !(pre.geom && pre.binning && pre.image)) { sgr_set_error("sgr_rasterize_forward: no allocator and no pre-allocated blobs"); return 1; }
+    auto get_blob = [&](int which, uint64_t bytes) -> char * {
+        if (alloc) return alloc(user, which, (size_t)bytes);
+        const uint64_t have = which == 0 ? pre.geom_bytes : (which == 1 ? pre.binning_bytes : pre.image_bytes);
+        return have >= bytes ? (char *)(which == 0 ? pre.geom : (which == 1 ? pre.binning : pre.image)) : nullptr;
+    };
     hipStream_t stream = (hipStream_t)stream_;
     const uint64_t nq = (uint64_t)pb->n_views * (uint64_t)(pb->P > 0 ? pb->P : 0);
     const int Tx = (pb->W + SGR_TILE - 1) / SGR_TILE, Ty = (pb->H + SGR_TILE - 1) / SGR_TILE;
@@ -141,8 +151,8 @@ extern "C" int sgr_rasterize_forward(const SgrProblem *pb, uint64_t capacity, in
     st->off_block_offsets = o; o = align_up(o + 2 * nbo * 4);
     st->off_num_rendered = o; o = align_up(o + 16);
     st->geom_bytes = o;
-    char *geom = alloc(user, 0, (size_t)o);
-    if (!geom) { sgr_set_error("geometry allocator returned NULL"); return 1; }
+    char *geom = get_blob(0, o);
+    if (!geom) { sgr_set_error(alloc ? "geometry allocator returned NULL" : "pre-allocated geometry blob too small"); return alloc ? 1 : 2; }
     st->geom = geom;
     uint64_t *num_rendered = (uint64_t *)(geom + st->off_num_rendered);
     uint64_t R = 0;
@@ -176,8 +186,8 @@ extern "C" int sgr_rasterize_forward(const SgrProblem *pb, uint64_t capacity, in
     st->off_vals_b = o; o = align_up(o + Rn * 4);
     st->off_sort_ws = o; o = align_up(o + sgr_bin_workspace_bytes(R, tiles_total));
     st->binning_bytes = o;
-    char *binning = alloc(user, 1, (size_t)o);
-    if (!binning) { sgr_set_error("binning allocator returned NULL"); return 1; }
+    char *binning = get_blob(1, o);
+    if (!binning) { sgr_set_error(alloc ? "binning allocator returned NULL" : "pre-allocated binning blob too small"); return alloc ? 1 : 2; }
     st->binning = binning;
     // ---- image blob
     const bool aux_on = with_aux && R > 0;
@@ -196,8 +206,8 @@ extern "C" int sgr_rasterize_forward(const SgrProblem *pb, uint64_t capacity, in
         st->off_desc = o; o = align_up(o + 4 * NS * 8);
     }
     st->image_bytes = o;
-    char *image = alloc(user, 2, (size_t)o);
-    if (!image) { sgr_set_error("image allocator returned NULL"); return 1; }
+    char *image = get_blob(2, o);
+    if (!image) { sgr_set_error(alloc ? "image allocator returned NULL" : "pre-allocated image blob too small"); return alloc ? 1 : 2; }
     st->image = image;
 
     const bool try_graph = graphs_allowed() && capacity > 0 && pb->P > 0 && !sgr_prof_active();

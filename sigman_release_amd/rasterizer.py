@@ -101,9 +101,11 @@ class _PinnedRing:
             self.slots = [self.buf[k] for k in range(self.n)]
             self.ptrs = [x.data_ptr() for x in self.slots]
             self.handles = [e.cuda_event for e in self.ev]
+            self.np = self.buf.numpy()         # same memory: cheap host-side reads / sentinel writes
         k = self.i
         self.i = (self.i + 1) % self.n
-        return self.slots[k], self.ev[k], self.ptrs[k], self.handles[k]
+        self.np[k, 0] = -1                     # sentinel: "the count has not arrived yet"
+        return self.np[k], self.ev[k], self.ptrs[k], self.handles[k]
 
 
 _ring = _PinnedRing()
@@ -123,6 +125,7 @@ def _alloc_cb(_user, which, nbytes):
 
 
 _ALLOC = _cabi.ALLOC_FN(_alloc_cb)
+_NO_ALLOC = _cabi.ALLOC_FN(0)                 # NULL allocator: the blobs are pre-allocated (sgr_rasterize_forward, include/sigman_gsplat.h)
 
 
 class _Ctx:
@@ -132,8 +135,9 @@ class _Ctx:
     def check_overflow(self):
         """Sync-free mode: raise if the forward needed more tile instances than `max_rendered` (cheap: the copy finished long ago)."""
         if self.nr_event is not None:
-            self.nr_event.synchronize()
-            nr = self.nr_host.tolist()
+            if self.nr_host[0] == -1:          # not there yet (it normally is: the copy was queued before the whole backward)
+                self.nr_event.synchronize()
+            nr = (int(self.nr_host[0]), int(self.nr_host[1]))
             self.nr_event = None
             self.true_rendered = int(nr[0])
             if nr[1] != 0:
@@ -146,17 +150,27 @@ class _Ctx:
         return self.blobs[which][off: off + count * esz].view(dtype)
 
 
+_pb_cache = _threading.local()       # last problem struct per thread: a training loop presents the same shapes and pointers step after step
+
+
 def _make_problem(means3D, opacities, colors_precomp, shs, cov3D_precomp, scales, rotations, st: BatchedRasterizationSettings):
     S, P = means3D.shape[0], means3D.shape[1]
     nv = st.viewmatrix.shape[0]
     if nv != S * st.views_per_subject:
         raise RuntimeError(f"viewmatrix has {nv} views but inputs describe {S} subjects x {st.views_per_subject} views")
     M = 0 if shs is None else shs.shape[2]
-    pb = _cabi.SgrProblem(P, nv, st.views_per_subject, int(st.image_height), int(st.image_width), int(st.sh_degree), M,
-                          float(st.tanfovx), float(st.tanfovy), float(st.scale_modifier),
-                          _ptr(means3D), _ptr(opacities), _ptr(colors_precomp), _ptr(shs), _ptr(cov3D_precomp), _ptr(scales),
-                          _ptr(rotations), _ptr(st.viewmatrix), _ptr(st.projmatrix), _ptr(st.campos), _ptr(st.bg))
+    sig = (P, nv, st.views_per_subject, int(st.image_height), int(st.image_width), int(st.sh_degree), M,
+           float(st.tanfovx), float(st.tanfovy), float(st.scale_modifier),
+           _ptr(means3D), _ptr(opacities), _ptr(colors_precomp), _ptr(shs), _ptr(cov3D_precomp), _ptr(scales),
+           _ptr(rotations), _ptr(st.viewmatrix), _ptr(st.projmatrix), _ptr(st.campos), _ptr(st.bg))
+    if getattr(_pb_cache, "sig", None) == sig:
+        return _pb_cache.pb             # (the struct is only read by the library)
+    pb = _cabi.SgrProblem(*sig)
+    _pb_cache.sig, _pb_cache.pb = sig, pb
     return pb
+
+
+_blob_sizes = {}      # (P, n_views, H, W, capacity, aux, has_sh) -> (geom, binning, image) bytes of the last forward with these shapes
 
 
 def _forward_impl(means3D, opacities, colors_precomp, shs, cov3D_precomp, scales, rotations, st: BatchedRasterizationSettings,
@@ -178,13 +192,29 @@ def _forward_impl(means3D, opacities, colors_precomp, shs, cov3D_precomp, scales
     nr_host, nr_event, nr_ptr, nr_handle = _ring.next()
     state = _cabi.SgrForwardState()
     blobs = [None, None, None, None]
-    _alloc_target.dev, _alloc_target.blobs = dev, blobs
     use_aux = 1 if (need_ctx and with_aux and not _USE_BWD_V1) else 0
-    _cabi.check(L.sgr_rasterize_forward(C.byref(pb), capacity, use_aux, _ALLOC, None, color.data_ptr(), depth.data_ptr(),
-                                        alpha.data_ptr(), radii.data_ptr(), nr_ptr,
-                                        nr_handle if capacity > 0 else None, None if clear is None else clear.data_ptr(),
-                                        0 if clear is None else clear.numel() * clear.element_size(), C.byref(state), _stream(dev)),
-                "sgr_rasterize_forward")
+    clear_ptr, clear_bytes = (None, 0) if clear is None else (clear.data_ptr(), clear.numel() * clear.element_size())
+    args = (C.byref(pb), capacity, use_aux)
+    outs = (color.data_ptr(), depth.data_ptr(), alpha.data_ptr(), radii.data_ptr(), nr_ptr, nr_handle if capacity > 0 else None,
+            clear_ptr, clear_bytes, C.byref(state), _stream(dev))
+    # sync-free mode: blob sizes only depend on the shapes, so from the second call on the blobs are allocated here and handed over
+    # directly (no allocator callbacks through ctypes)
+    size_key = (P, nv, H, W, capacity, use_aux, shs is not None) if capacity > 0 else None
+    sizes = _blob_sizes.get(size_key) if size_key is not None else None
+    status = 2
+    if sizes is not None:
+        u8 = torch.uint8
+        blobs[0], blobs[1], blobs[2] = (torch.empty(sizes[0], dtype=u8, device=dev), torch.empty(sizes[1], dtype=u8, device=dev),
+                                        torch.empty(sizes[2], dtype=u8, device=dev))
+        state.geom, state.binning, state.image = blobs[0].data_ptr(), blobs[1].data_ptr(), blobs[2].data_ptr()
+        state.geom_bytes, state.binning_bytes, state.image_bytes = sizes
+        status = L.sgr_rasterize_forward(*args, _NO_ALLOC, None, *outs)
+    if status == 2:                        # first call with these shapes (or sizes changed): the library asks for memory through the callback
+        _alloc_target.dev, _alloc_target.blobs = dev, blobs
+        status = L.sgr_rasterize_forward(*args, _ALLOC, None, *outs)
+        if status == 0 and size_key is not None:
+            _blob_sizes[size_key] = (max(int(state.geom_bytes), 256), max(int(state.binning_bytes), 256), max(int(state.image_bytes), 256))
+    _cabi.check(status, "sgr_rasterize_forward")
     ctx = None
     if need_ctx:
         ctx = _Ctx()
