@@ -270,8 +270,11 @@ def _fwd_common(ctx, means3D, sh, colors_precomp, opacities, scales, rotations, 
     if not (st.viewmatrix.dtype is f32 and st.projmatrix.dtype is f32 and st.campos.dtype is f32 and st.bg.dtype is f32
             and st.viewmatrix.is_contiguous() and st.projmatrix.is_contiguous() and st.campos.is_contiguous() and st.bg.is_contiguous()):
         st = st._replace(viewmatrix=_f32c(st.viewmatrix), projmatrix=_f32c(st.projmatrix), campos=_f32c(st.campos), bg=_f32c(st.bg))
+    # inference (no input needs a gradient, e.g. under torch.no_grad()): skip the backward's auxiliary outputs (compact lists,
+    # per-row checkpoints, bucket descriptors) -- the forward kernels then run their lighter variant
+    wants_grad = any(ctx.needs_input_grad)
     color, radii, depth, alpha, c = _forward_impl(means3D, opacities, colors_precomp, sh, cov3Ds_precomp, scales, rotations,
-                                                  st, need_ctx=True, clear=clear)
+                                                  st, need_ctx=True, with_aux=wants_grad, clear=clear)
     ctx.sgr = c
     ctx.st = st
     # unused outputs (depth / alpha on the reference path, gs.py:99,107-109) then arrive as None in backward instead of as
