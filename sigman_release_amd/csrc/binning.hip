@@ -410,9 +410,24 @@ __global__ __launch_bounds__(kThreads) void radix_hist_all_kernel(const uint64_t
     const uint32_t n = n_dev ? (uint32_t)min((uint64_t)n_host, *n_dev) : n_host;
     for (int p = 0; p < passes; p++) h[p][threadIdx.x] = 0;
     __syncthreads();
-    for (uint32_t k = blockIdx.x * kThreads + threadIdx.x; k < n; k += gridDim.x * kThreads) {
-        const uint64_t key = keys[k];
-        for (int p = 0; p < passes; p++) atomicAdd(&h[p][(uint32_t)(key >> (p * kRadixBits)) & (kRadix - 1)], 1u);
+    const uint32_t lane = threadIdx.x & 63;
+    // (uniform trip count per wave, so the ballots below are well defined)
+    for (uint32_t k0 = blockIdx.x * kThreads + (threadIdx.x & ~63u); k0 < n; k0 += gridDim.x * kThreads) {
+        const uint32_t k = k0 + lane;
+        const bool valid = k < n;
+        const uint64_t key = valid ? keys[k] : 0ull;
+        const uint64_t vmask = __ballot(valid);
+        for (int p = 0; p < passes; p++) {
+            const uint32_t d = (uint32_t)(key >> (p * kRadixBits)) & (kRadix - 1);
+            // keys arrive grouped by view and tile row, so in the upper digits a whole wave usually agrees: one atomic instead of a
+            // 64-way same-address LDS conflict
+            const uint32_t d0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)d);
+            if (__ballot(valid && d != d0) == 0ull) {
+                if (lane == (uint32_t)__builtin_ctzll(vmask | (1ull << 63)) && vmask) atomicAdd(&h[p][d0], (uint32_t)__popcll(vmask));
+            } else if (valid) {
+                atomicAdd(&h[p][d], 1u);
+            }
+        }
     }
     __syncthreads();
     for (int p = 0; p < passes; p++) {
