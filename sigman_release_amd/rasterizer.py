@@ -54,6 +54,10 @@ class BatchedRasterizationSettings(NamedTuple):
     # 0: exact mode (one device->host read of num_rendered per batched forward, like upstream does per view).
     # >0: sync-free mode: binning buffers are pre-sized for this many tile instances; an overflow raises at backward /
     #     at the next call (checked through an async copy + event, never on the critical path).
+    # -1: automatic: the first call with a given (P, n_views, H, W) runs in exact mode and remembers its count; later calls are
+    #     sync-free with 1.3x that capacity.  The count reaches a pinned host slot right after the duplicate kernel, i.e. while the
+    #     host is still queueing the rest of the forward: it is checked once everything is queued, and an overflow silently re-runs
+    #     the forward in exact mode (and raises the remembered capacity) -- no blocking read, no user-visible failure mode.
     max_rendered: int = 0
 
 
@@ -170,6 +174,7 @@ def _make_problem(means3D, opacities, colors_precomp, shs, cov3D_precomp, scales
     return pb
 
 
+_auto_capacity = {}   # (P, n_views, H, W) -> remembered capacity of max_rendered = -1 (automatic) mode
 _blob_sizes = {}      # (P, n_views, H, W, capacity, aux, has_sh) -> (geom, binning, image) bytes of the last forward with these shapes
 
 
@@ -189,6 +194,10 @@ def _forward_impl(means3D, opacities, colors_precomp, shs, cov3D_precomp, scales
     alpha = torch.empty(nv, 1, H, W, dtype=f32, device=dev)
     radii = torch.empty(nv, P, dtype=torch.int32, device=dev)
     capacity = int(getattr(st, "max_rendered", 0) or 0)
+    auto_key = None
+    if capacity < 0:                                   # automatic mode: exact the first time, then sync-free with the remembered capacity
+        auto_key = (P, nv, H, W)
+        capacity = _auto_capacity.get(auto_key, 0)
     nr_host, nr_event, nr_ptr, nr_handle = _ring.next()
     state = _cabi.SgrForwardState()
     blobs = [None, None, None, None]
@@ -215,12 +224,31 @@ def _forward_impl(means3D, opacities, colors_precomp, shs, cov3D_precomp, scales
         if status == 0 and size_key is not None:
             _blob_sizes[size_key] = (max(int(state.geom_bytes), 256), max(int(state.binning_bytes), 256), max(int(state.image_bytes), 256))
     _cabi.check(status, "sgr_rasterize_forward")
+    checked = False
+    if auto_key is not None and P > 0:
+        if capacity == 0:
+            count = int(state.true_rendered)
+        else:
+            # everything is queued; the count was published right after the duplicate kernel (or by the copy behind the scan kernel)
+            spins = 0
+            while nr_host[0] == -1 and spins < 20000:
+                spins += 1
+            if nr_host[0] == -1:
+                nr_event.synchronize()
+            count, overflow = int(nr_host[0]), int(nr_host[1])
+            checked = True
+            if overflow:
+                _auto_capacity[auto_key] = 0               # re-run exactly; the exact run below re-learns the capacity
+                return _forward_impl(means3D, opacities, colors_precomp, shs, cov3D_precomp, scales, rotations, st, need_ctx,
+                                     with_aux, clear)
+        if capacity == 0 or count * 1.1 > capacity:
+            _auto_capacity[auto_key] = min(int(count * 1.3) + 4096, 0xFFFFFFE0)
     ctx = None
     if need_ctx:
         ctx = _Ctx()
         ctx.state, ctx.blobs, ctx.radii = state, blobs, radii
         ctx.dims = (S, P, nv, H, W)
-        ctx.nr_host, ctx.nr_event, ctx.capacity = nr_host, (nr_event if capacity > 0 and P > 0 else None), capacity
+        ctx.nr_host, ctx.nr_event, ctx.capacity = nr_host, (nr_event if capacity > 0 and P > 0 and not checked else None), capacity
         ctx.true_rendered = int(state.true_rendered) if capacity == 0 else None
         ctx.keep = (st.viewmatrix, st.projmatrix, st.campos, st.bg)
         ctx.pb = pb            # the backward sees the same tensors (saved_tensors share their storage), so the struct is reused
@@ -381,7 +409,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         rs = raster_settings
         st = BatchedRasterizationSettings(rs.image_height, rs.image_width, rs.tanfovx, rs.tanfovy, rs.bg, rs.scale_modifier,
                                           rs.viewmatrix.reshape(1, 4, 4), rs.projmatrix.reshape(1, 4, 4), rs.sh_degree,
-                                          rs.campos.reshape(1, 3), 1, rs.debug)
+                                          rs.campos.reshape(1, 3), 1, rs.debug, -1)      # automatic sync-free mode
         u = lambda t: None if t is None or t.numel() == 0 else t.unsqueeze(0)
         P = means3D.shape[0]
         color, radii, depth, alpha = _fwd_common(ctx, means3D.unsqueeze(0), u(sh), u(colors_precomp), opacities.reshape(1, P, 1),

@@ -97,7 +97,7 @@ class GaussianRenderer:
         st = BatchedRasterizationSettings(H, W, self.tan_half_fov, self.tan_half_fov,
                                           self.bg_color if bg_color is None else bg_color, scale_modifier,
                                           cam_view.reshape(B * V, 4, 4), cam_view_proj.reshape(B * V, 4, 4), 0,
-                                          cam_pos.reshape(B * V, 3), V)
+                                          cam_pos.reshape(B * V, 3), V, False, -1)      # max_rendered = -1: automatic sync-free mode
         color, radii, depth, alpha = rasterize_gaussians_batched(position, None, None, gaussians["rgb"].float(),
                                                                  gaussians["opacity"].float(), None, None, cov3D, st)
         return {"image": color.clamp(0, 1).view(B, V, 3, H, W), "alpha": alpha.view(B, V, 1, H, W)}

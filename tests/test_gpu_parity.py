@@ -670,3 +670,31 @@ def test_seeded_random_configurations(seed, oracle, fwd_mode):
         assert np.isfinite(got).all(), k
         err = float(np.abs(got - want).max()) / max(float(np.abs(want).max()), 1e-20)
         assert err <= GRAD_TOL, f"seed {seed}: grad {k} rel-to-max err {err:.3e}"
+
+
+def test_automatic_capacity_mode_is_transparent():
+    """max_rendered = -1: exact the first time, sync-free afterwards; a forward that needs more tile instances than remembered is
+    re-run exactly without the caller noticing.  Same outputs and gradients as exact mode in every call."""
+    from sigman_release_amd import rasterizer as R
+    dev = _dev()
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    P, H, W = 6000, 160, 144
+    inp, st = cases.humanoid(P=P, H=H, W=W, seed=31)
+    R._auto_capacity.pop((P, 1, H, W), None)
+    results = []
+    # splat size multiplier per call: small (learns a small capacity), same, 3x (overflows the remembered capacity), 3x again, small
+    for mul in (0.4, 0.4, 3.0, 3.0, 0.4):
+        per_mode = []
+        for max_rendered in (0, -1):
+            d = {k: t(v)[None].requires_grad_(True) for k, v in inp.items()}
+            cov = (d["cov3D_precomp"] * (mul * mul))
+            bst = _batched_settings(st, dev, 1)._replace(max_rendered=max_rendered)
+            color, radii, depth, alpha = R.rasterize_gaussians_batched(d["means3D"], None, None, d["colors_precomp"], d["opacities"][..., None],
+                                                                       None, None, cov, bst)
+            (color * color).sum().backward()
+            per_mode.append((color.detach().clone(), radii.clone(), d["means3D"].grad.clone(), d["cov3D_precomp"].grad.clone()))
+        for a, b in zip(*per_mode):
+            assert torch.equal(a, b)
+        results.append(int((per_mode[0][1] > 0).sum()))
+    cap = R._auto_capacity[(P, 1, H, W)]
+    assert cap > 0 and results[2] >= results[0]
