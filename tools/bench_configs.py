@@ -78,6 +78,25 @@ def c3():
     clamped_l1_loss(o["image"].view(B * V, 3, H, H), gt, None, 1.0 / (B * V * 3 * H * H)).backward()
 dt = timeit(c3, 10, 3)
 out.append(dict(config="C3 VAE render-loss step on one GPU: 8 subjects x 8 views 512x512, GaussianRenderer.render (3-NN, covariance, raster) + loss, fwd+bwd", ms_per_step=round(dt * 1e3, 3), views_per_s=round(B * V / dt, 1)))
+# C3 again, but driven exactly like the reference's gs.py:62-109: a Python double loop over subjects and views through the
+# upstream-signature GaussianRasterizer (one launch chain per view), same 3-NN / covariance / loss ops around it
+from sigman_release_amd.renderer import dist_cuda2, covariance_from_scale_rotation
+def c3_per_view():
+    for v in gauss.values(): v.grad = None
+    imgs = []
+    for b in range(B):
+        with torch.no_grad():
+            d2 = dist_cuda2(gauss["position"][b])
+        cov_b = covariance_from_scale_rotation(gauss["scale"][b:b + 1], gauss["cov3d"][b:b + 1], d2[None])[0]
+        for v in range(V):
+            rs = R.GaussianRasterizationSettings(H, H, cameras.TAN_HALF_FOV, cameras.TAN_HALF_FOV, torch.ones(3, device=dev), 0.5,
+                                                 cam_view[b, v], cam_view_proj[b, v], 0, cam_pos[b, v], False, False)
+            img, radii, depth, alpha = R.GaussianRasterizer(rs)(means3D=gauss["position"][b], means2D=torch.zeros_like(gauss["position"][b]),
+                                                                opacities=gauss["opacity"][b], colors_precomp=gauss["rgb"][b], cov3D_precomp=cov_b)
+            imgs.append(img.clamp(0, 1))
+    clamped_l1_loss(torch.stack(imgs), gt, None, 1.0 / (B * V * 3 * H * H)).backward()
+dt = timeit(c3_per_view, 6, 2)
+out.append(dict(config="C3 through the reference's own call pattern (gs.py:62-109): Python loop over 8 subjects x 8 views, upstream-signature GaussianRasterizer per view, fwd+bwd", ms_per_step=round(dt * 1e3, 3), views_per_s=round(B * V / dt, 1)))
 # C4: decode path, 200k Gaussians, 90-view orbit at 1024^2, forward only
 g = synthetic.humanoid(200_000, 3); cov = synthetic.covariance_from_gaussians(g)
 step, Rn, S = raster_case(g, cov, list(range(90)), 1024, False)
