@@ -38,7 +38,8 @@ extern "C" {
 
 #define SGR_ABI_VERSION 1
 #define SGR_TILE 16                 /* 16x16 pixel tiles, as the published algorithm */
-#define SGR_REC_FLOATS 12           /* floats of a gradient record (grec / partial records) */
+#define SGR_REC_FLOATS 12           /* floats of a gradient record (grec, pixel-parallel backward) */
+#define SGR_PART_FLOATS 10          /* floats of a partial gradient record (bucket-parallel backward): 40 B, 8-byte aligned */
 #define SGR_REC_STRIDE 16           /* floats of the packed per-(view,Gaussian) record `rec` (64 B, one cache line) */
 
 /* Problem description shared by every staged call. */
@@ -208,7 +209,7 @@ int sgr_render_forward(const SgrProblem *pb, const uint32_t *ranges, const uint3
  * B1: gradient records from the image gradients.  grad_depth / grad_alpha may be NULL (treated as zero).
  * With the forward's aux buffers (and the forward's output images) the bucket-parallel kernel runs: one wave per
  * <=64-Gaussian bucket, lanes own Gaussians, pixel states rotate through the wave (no reductions, no LDS, NO ATOMICS):
- * each lane writes one partial record part[(4*instance + quadrant)*12 .. +10] and sets flags byte [4*instance + quadrant]
+ * each lane writes one partial record part[(4*instance + quadrant)*10 .. +10] and sets flags byte [4*instance + quadrant]
  * (part f32 [4*R*12], flags u32 [R], flags zeroed by this call); sgr_preprocess_backward gathers them in a fixed order,
  * so gradients are bitwise reproducible.  grec may be NULL on this path.
  * Without the aux buffers (NULL) the pixel-parallel reverse walk runs: needs final_T and grec [n_views*P*12], which is

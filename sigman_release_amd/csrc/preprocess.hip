@@ -334,7 +334,7 @@ __global__ __launch_bounds__(kPreThreads) void preprocess_bwd_kernel(SgrProblem 
                                                                      const float4 *__restrict__ grec,
                                                                      const float4 *__restrict__ rec,
                                                                      const float4 *__restrict__ part,
-                                                                     const uint32_t *__restrict__ flags,
+                                                                     const uint32_t *__restrict__ flags, uint32_t n_inst,
                                                                      float *__restrict__ dL_dmeans3D,
                                                                      float *__restrict__ dL_dmeans2D,
                                                                      float *__restrict__ dL_dopacity,
@@ -374,16 +374,17 @@ __global__ __launch_bounds__(kPreThreads) void preprocess_bwd_kernel(SgrProblem 
             const uint32_t ntile = ((rmax & 0xFFFFu) - (rmin & 0xFFFFu)) * ((rmax >> 16) - (rmin >> 16));
             g0 = make_float4(0.f, 0.f, 0.f, 0.f); g1 = g0; g2 = g0;
             for (uint32_t k = 0; k < ntile; k++) {
+                if (off + k >= n_inst) break;                   // sync-free mode after an overflow: instances beyond the buffers do not exist
                 const uint32_t f = flags[off + k];
                 if (!f) continue;
 #pragma unroll
                 for (uint32_t qd = 0; qd < 4; qd++) {
                     if (!((f >> (8 * qd)) & 0xFFu)) continue;
-                    const float4 *pp = part + ((size_t)(off + k) * 4 + qd) * 3;
-                    const float4 p0 = pp[0], p1 = pp[1], p2 = pp[2];
-                    g0.x += p0.x; g0.y += p0.y; g0.z += p0.z; g0.w += p0.w;
-                    g1.x += p1.x; g1.y += p1.y; g1.z += p1.z; g1.w += p1.w;
-                    g2.x += p2.x; g2.y += p2.y;
+                    const float2 *pp = reinterpret_cast<const float2 *>(part) + ((size_t)(off + k) * 4 + qd) * (SGR_PART_FLOATS / 2);
+                    const float2 p0 = pp[0], p1 = pp[1], p2 = pp[2], p3 = pp[3], p4 = pp[4];
+                    g0.x += p0.x; g0.y += p0.y; g0.z += p1.x; g0.w += p1.y;
+                    g1.x += p2.x; g1.y += p2.y; g1.z += p3.x; g1.w += p3.y;
+                    g2.x += p4.x; g2.y += p4.y;
                 }
             }
         } else {
@@ -596,10 +597,11 @@ extern "C" int sgr_preprocess_forward(const SgrProblem *pb, float *rec, int32_t 
     return sgr_preprocess_forward_ex(pb, rec, radii, rect, clamped, block_offsets, num_rendered, capacity, false, stream_);
 }
 
-extern "C" int sgr_preprocess_backward(const SgrProblem *pb, const int32_t *radii, const uint8_t *clamped, const float *grec,
-                                       const float *rec, const float *part, const uint32_t *flags, float *dL_dmeans3D, float *dL_dmeans2D, float *dL_dopacity, float *dL_dcolors,
-                                       float *dL_dsh, float *dL_dcov3D, float *dL_dscales, float *dL_drotations,
-                                       void *stream_) {
+// n_inst: number of tile instances part / flags were sized for (the gather never reads beyond it)
+int sgr_preprocess_backward_ex(const SgrProblem *pb, const int32_t *radii, const uint8_t *clamped, const float *grec,
+                               const float *rec, const float *part, const uint32_t *flags, uint64_t n_inst, float *dL_dmeans3D, float *dL_dmeans2D,
+                               float *dL_dopacity, float *dL_dcolors, float *dL_dsh, float *dL_dcov3D, float *dL_dscales, float *dL_drotations,
+                               void *stream_) {
     if (validate_problem(pb)) return 1;
     if (pb->P == 0) return 0;
     if (!grec && !(part && flags && rec)) { sgr_set_error("sgr_preprocess_backward: need grec, or rec + part + flags"); return 1; }
@@ -612,13 +614,21 @@ extern "C" int sgr_preprocess_backward(const SgrProblem *pb, const int32_t *radi
     { SgrProfScope _p(SGR_K_PREPROCESS_BWD, stream);
     if (pb->shs)
         hipLaunchKernelGGL(preprocess_bwd_kernel<true>, grid, dim3(kPreThreads), 0, stream, *pb, radii, clamped, (const float4 *)grec,
-                           (const float4 *)rec, (const float4 *)part, flags, dL_dmeans3D, dL_dmeans2D, dL_dopacity, dL_dcolors, dL_dsh, dL_dcov3D, dL_dscales, dL_drotations);
+                           (const float4 *)rec, (const float4 *)part, flags, (uint32_t)(n_inst > 0xFFFFFFFFull ? 0xFFFFFFFFull : n_inst), dL_dmeans3D, dL_dmeans2D, dL_dopacity, dL_dcolors, dL_dsh, dL_dcov3D, dL_dscales, dL_drotations);
     else
         hipLaunchKernelGGL(preprocess_bwd_kernel<false>, grid, dim3(kPreThreads), 0, stream, *pb, radii, clamped, (const float4 *)grec,
-                           (const float4 *)rec, (const float4 *)part, flags, dL_dmeans3D, dL_dmeans2D, dL_dopacity, dL_dcolors, dL_dsh, dL_dcov3D, dL_dscales, dL_drotations);
+                           (const float4 *)rec, (const float4 *)part, flags, (uint32_t)(n_inst > 0xFFFFFFFFull ? 0xFFFFFFFFull : n_inst), dL_dmeans3D, dL_dmeans2D, dL_dopacity, dL_dcolors, dL_dsh, dL_dcov3D, dL_dscales, dL_drotations);
     SGR_CHECK_LAUNCH("preprocess_bwd_kernel");
     }
     return 0;
+}
+
+extern "C" int sgr_preprocess_backward(const SgrProblem *pb, const int32_t *radii, const uint8_t *clamped, const float *grec,
+                                       const float *rec, const float *part, const uint32_t *flags, float *dL_dmeans3D, float *dL_dmeans2D, float *dL_dopacity, float *dL_dcolors,
+                                       float *dL_dsh, float *dL_dcov3D, float *dL_dscales, float *dL_drotations,
+                                       void *stream_) {
+    return sgr_preprocess_backward_ex(pb, radii, clamped, grec, rec, part, flags, ~0ull, dL_dmeans3D, dL_dmeans2D, dL_dopacity, dL_dcolors, dL_dsh,
+                                      dL_dcov3D, dL_dscales, dL_drotations, stream_);
 }
 
 extern "C" int sgr_mark_visible(int32_t P, const float *means3D, const float *viewmatrix, uint8_t *present, void *stream_) {

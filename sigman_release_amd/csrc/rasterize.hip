@@ -54,6 +54,9 @@ int sgr_render_backward_ex(const SgrProblem *pb, const uint32_t *ranges, const u
                            const float *grad_color, const float *grad_depth, const float *grad_alpha, const float *grad_color_scale,
                            uint64_t R, const void *aux_compact, const void *aux_ckpt_tc, const void *aux_ckpt_da, const void *aux_desc,
                            float *grec, float *part, uint32_t *flags, bool flags_cleared, void *stream_);
+int sgr_preprocess_backward_ex(const SgrProblem *pb, const int32_t *radii, const uint8_t *clamped, const float *grec, const float *rec,
+                               const float *part, const uint32_t *flags, uint64_t n_inst, float *dL_dmeans3D, float *dL_dmeans2D, float *dL_dopacity,
+                               float *dL_dcolors, float *dL_dsh, float *dL_dcov3D, float *dL_dscales, float *dL_drotations, void *stream_);
 int sgr_render_forward_wants_prepare(const SgrProblem *pb, uint64_t R, bool use_aux, size_t *n_desc_out);
 int sgr_render_forward_ex(const SgrProblem *pb, const uint32_t *ranges, const uint32_t *point_list, const float *rec, float *out_color,
                           float *out_depth, float *out_alpha, float *final_T, uint32_t *n_contrib, uint64_t R, void *aux_compact,
@@ -283,8 +286,8 @@ extern "C" int sgr_rasterize_backward(const SgrProblem *pb, const SgrForwardStat
     if (pb->P <= 0) return 0;
     const uint64_t nq = (uint64_t)pb->n_views * (uint64_t)pb->P;
     const bool aux_on = st->with_aux != 0;
-    // scratch: bucket-parallel path = partial records [4*R][12] f32 + flags [R] u32; pixel-parallel path = grec [nq][12] f32
-    const uint64_t part_bytes = align_up(st->R_alloc * 4 * SGR_REC_FLOATS * 4);
+    // scratch: bucket-parallel path = partial records [4*R][10] f32 + flags [R] u32; pixel-parallel path = grec [nq][12] f32
+    const uint64_t part_bytes = align_up(st->R_alloc * 4 * SGR_PART_FLOATS * 4);
     const uint64_t scratch_bytes = aux_on ? part_bytes : nq * SGR_REC_FLOATS * 4;
     char *scratch = alloc(user, 3, (size_t)scratch_bytes);
     if (!scratch) { sgr_set_error("scratch allocator returned NULL"); return 1; }
@@ -299,7 +302,7 @@ extern "C" int sgr_rasterize_backward(const SgrProblem *pb, const SgrForwardStat
                             grad_alpha, grad_color_scale, st->R_alloc, aux_on ? image + st->off_compact : nullptr, aux_on ? image + st->off_ckpt_tc : nullptr,
                             aux_on ? image + st->off_ckpt_da : nullptr, aux_on ? image + st->off_desc : nullptr, grec, part, flags, st->flags_cleared != 0, stream_))
         return 1;
-    return sgr_preprocess_backward(pb, radii, pb->shs ? (const uint8_t *)(geom + st->off_clamped) : nullptr, grec, rec, part, flags,
+    return sgr_preprocess_backward_ex(pb, radii, pb->shs ? (const uint8_t *)(geom + st->off_clamped) : nullptr, grec, rec, part, flags, st->R_alloc,
                                    dL_dmeans3D, dL_dmeans2D, dL_dopacity, dL_dcolors, dL_dsh, dL_dcov3D, dL_dscales, dL_drotations,
                                    stream_);
 }

@@ -836,10 +836,12 @@ __global__ __launch_bounds__(kBlock) void render_bwd_bucket_kernel(int W, int H,
         const uint32_t inst = off + (ty - (rmin >> 16)) * ((rmax & 0xFFFFu) - (rmin & 0xFFFFu)) + (tx - (rmin & 0xFFFFu));
         const float a0 = -0.5f * (float)W * op * (cxx * Sx + cxy * Sy);       // dL/dNDC x (includes 0.5*W like upstream)
         const float a1 = -0.5f * (float)H * op * (cyy * Sy + cxy * Sx);
-        float4 *pp = part + ((size_t)inst * 4 + q) * 3;
-        pp[0] = make_float4(a0, a1, -0.5f * op * Sxx, -0.5f * op * Sxy);
-        pp[1] = make_float4(-0.5f * op * Syy, S1, aD, a7);
-        pp[2] = make_float4(a8, a9, 0.f, 0.f);
+        float2 *pp = reinterpret_cast<float2 *>(part) + ((size_t)inst * 4 + q) * (SGR_PART_FLOATS / 2);      // 40 B, 8-byte aligned
+        pp[0] = make_float2(a0, a1);
+        pp[1] = make_float2(-0.5f * op * Sxx, -0.5f * op * Sxy);
+        pp[2] = make_float2(-0.5f * op * Syy, S1);
+        pp[3] = make_float2(aD, a7);
+        pp[4] = make_float2(a8, a9);
         flags[(size_t)inst * 4 + q] = 1;
     }
 }
