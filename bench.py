@@ -1,24 +1,33 @@
 #!/usr/bin/env python
 """bench.py -- rasterizer hot-path benchmark (contract in the task brief; metric from BASELINE.json).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+    python bench.py [--gpus N] [--config c2|c3|c4|c5] [--steps K] [--warmup W]
 
-Workload (BASELINE.json configs[1], "C2"): one procedural-humanoid subject of 100 000 Gaussians
-(sigman_release_amd.synthetic.humanoid, seed 1; stands in for the SMPL-X subdivided template), rendered at
-512x512 from the reference camera rig, forward + backward, fp32, reference mode (colors_precomp + cov3D_precomp,
-gs.py:98-106), white background, loss = mean |clamp(img,0,1) - gt| with gt = render of a perturbed copy
-(stand-in for the masked L1 of core/loss/whole_loss.py:126-131).
+`--gpus N` with N > 1 LAUNCHES ITS OWN N RANKS (one process per GPU, `python -m torch.distributed.run --nnodes=1
+--nproc-per-node N --master-addr 127.0.0.1 ...` re-executing this file) when it is not already running under a launcher
+(WORLD_SIZE unset); under the driver's own `torch.distributed.run` command line it just joins.  It never falls back to
+fewer ranks: `n_gpus` in the JSON line is `dist.get_world_size()`, and a mismatch with `--gpus`, or fewer visible GPUs
+than ranks on the RCCL backend, ends with a non-zero exit code.  (`SIGMAN_BENCH_BACKEND=gloo` lets a 1-GPU box run the
+N > 1 code path with all ranks on cuda:0 -- a plumbing check, not a measurement.)
 
-One "step" = one pass of the hot path over one batch: at N=1 ONE view (rig view 0030) per step.  At N>1 the views
-[30,37,45,53,65,85,0,8] of the same subject are sharded one-view-per-GPU (weak scaling: per-GPU work fixed) with the
-exchange of sigman_release_amd/parallel.py: by default what BASELINE.json's north_star names -- replicated attributes, RCCL
-all-reduce of the image-space loss, overlapped with the backward; `--exchange full` adds the attribute broadcast and the
-all-reduce of the attribute gradients.
+Configs (BASELINE.json `configs`; subjects are procedural humanoids, sigman_release_amd.synthetic):
+  c2 (default, the configuration the metric is quoted on): 100 000 Gaussians, 1 view 512x512 per GPU per step, fwd+bwd,
+      clamp+L1 loss.  Weak scaling: rank r renders view VIEWS[r] of the same subject.
+  c3  VAE render-loss step: 8 subjects x 8 views [30,37,45,53,65,85,0,8] at 512x512, 100 000 Gaussians each, fwd+bwd.
+      STRONG scaling: the 8 views of every subject are sharded {v : v mod N = r}; at N=8 one view per GPU per subject.
+  c4  decode path: 200 000 Gaussians, the 90-view orbit at 1024x1024, forward only.  Strong scaling (90 views -> 11-12 per GPU).
+  c5  1M-Gaussian stress (10 jittered layers), 512x512, depth + alpha gradients on, fwd+bwd.  Weak scaling (1 view per GPU).
+For N > 1 the exchange is sigman_release_amd/parallel.py: by default what BASELINE.json's north_star names -- replicated
+attributes, RCCL all-reduce of the image-space loss, overlapped with the backward; `--exchange full` adds the attribute
+broadcast and the all-reduce of the attribute gradients (c2/c5 only).  c4 is forward-only and needs no collective.
 
-`value` = views/s of the whole job with inputs resident in HBM.  `roofline` is for the dominant kernel, timed with HIP
-events recorded by the library on the launch stream inside the timed region.  `cpu_baseline` is the CPU oracle
-(oracle/gsplat_ref.c, OpenMP) on the same inputs, rank 0 at N=1 only.
+One "step" = one pass of the hot path over one batch (all view slots of this rank in ONE launch chain).  `value` = views/s
+of the whole job with inputs resident in HBM.  The timed step is the rasterizer (+ fused loss): distCUDA2 + get_covariance
+(gs.py:70-73) run once per subject outside it; their cost is reported as `frontend_ms_per_subject`.
+`roofline` is for the dominant kernel, timed with HIP events recorded by the library on the launch stream inside the
+timed region; `roofline.traffic` comes from the committed rocprofv3 PMC summary of this same command
+(profiles/r02_pmc_<config>.json; null when there is none for the workload).  `cpu_baseline` is the CPU oracle
+(oracle/gsplat_ref.c, OpenMP) on a bounded sample of the same inputs, rank 0 at N=1 only.
 """
 from __future__ import annotations
 
@@ -26,10 +35,50 @@ import argparse
 import ctypes as C
 import json
 import os
+import subprocess
 import sys
 import time
 
 os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")   # before torch/HIP initialise: see sigman_release_amd/__init__.py
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--config", choices=("c2", "c3", "c4", "c5"), default="c2")
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--gaussians", type=int, default=None, help="override the config's Gaussians per subject")
+    ap.add_argument("--size", type=int, default=None, help="override the config's image size")
+    ap.add_argument("--views-per-step", type=int, default=1, help="c2/c5: views per GPU per step")
+    ap.add_argument("--exchange", choices=("loss", "full"), default="loss",
+                    help="N>1: 'loss' = north_star's protocol (replicated attributes, loss all-reduce overlapped with the backward); "
+                         "'full' = attribute broadcast + all-reduce of gradients and loss (sigman_release_amd/parallel.py)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-variants", action="store_true", help="skip the unpinned / graphs-off / per-view-loop re-runs (N=1, c2/c3)")
+    ap.add_argument("--exact-sync", action="store_true", help="read num_rendered back every step (upstream behaviour) instead of the sync-free capacity mode")
+    return ap.parse_args(argv)
+
+
+def _self_launch(args) -> int:
+    """--gpus N without a launcher: start N ranks of this file under torch.distributed.run and hand their exit code back."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print(f"[bench] --gpus {args.gpus} without a launcher: starting {args.gpus} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    return subprocess.call(cmd)
+
+
+if __name__ == "__main__":
+    _ARGS = parse_args()
+    if _ARGS.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(_self_launch(_ARGS))          # (before any thread pinning: children inherit the affinity mask)
 
 
 def _pin_host_threads():
@@ -55,110 +104,158 @@ def _pin_host_threads():
 
 _ORIG_AFFINITY = _pin_host_threads()
 
-import numpy as np
-import torch
-import torch.distributed as dist
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
 
-ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from sigman_release_amd import _cabi, cameras, parallel, synthetic  # noqa: E402
 from sigman_release_amd import rasterizer as R  # noqa: E402
-from sigman_release_amd.losses import clamped_l1_loss  # noqa: E402
 
 VIEWS = (30, 37, 45, 53, 65, 85, 0, 8)
 KERNELS = {0: "preprocess_fwd", 1: "scan_block_sums", 2: "duplicate_keys", 3: "radix_sort(all passes)", 4: "tile_ranges",
            5: "render_fwd", 6: "render_bwd", 7: "preprocess_bwd"}
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s peak (6.3 TB/s achievable)
 
+# name -> (Gaussians per subject, image size, subjects, backward?, depth+alpha grads?, scaling, steps, warmup)
+CONFIGS = {
+    "c2": dict(P=100_000, size=512, subjects=1, bwd=True, da=False, scaling="weak", steps=200, warmup=20,
+               label="C2: procedural humanoid (SMPL-X stand-in)"),
+    "c3": dict(P=100_000, size=512, subjects=8, bwd=True, da=False, scaling="strong", steps=20, warmup=4,
+               label="C3: VAE render-loss step, 8 subjects x 8 views"),
+    "c4": dict(P=200_000, size=1024, subjects=1, bwd=False, da=False, scaling="strong", steps=10, warmup=3,
+               label="C4: decode path, 90-view orbit, forward only"),
+    "c5": dict(P=1_000_000, size=512, subjects=1, bwd=True, da=True, scaling="weak", steps=30, warmup=5,
+               label="C5: 1M-Gaussian stress (10 jittered layers), depth+alpha gradients on"),
+}
 
-def algorithmic_bytes(kid: int, P: int, Rn: int, HW: int, tiles: int, views: int) -> float:
-    """SURVEY.md 8(d) per-view figures x views per launch."""
-    per_view = {0: 76 * P, 1: 8 * P, 2: 20 * P + 12 * Rn, 3: 24 * Rn, 4: 8 * Rn + 8 * tiles, 5: 44 * Rn + 24 * HW,
-                6: 88 * Rn + 28 * HW, 7: 108 * P}[kid]
-    return float(per_view)     # Rn is already the batch total when views > 1 are launched together
+
+def algorithmic_bytes(kid: int, P: int, Rn: int, HW: int, tiles: int, bwd_da: bool = True) -> float:
+    """SURVEY.md 8(d) per-view figures; P, Rn, HW, tiles are totals over the view slots of one launch."""
+    return float({0: 76 * P, 1: 8 * P, 2: 20 * P + 12 * Rn, 3: 24 * Rn, 4: 8 * Rn + 8 * tiles, 5: 44 * Rn + 24 * HW,
+                  6: 88 * Rn + 28 * HW, 7: 108 * P}[kid])
 
 
-def build_subject(P: int, seed: int, dev):
-    g = synthetic.humanoid(P, seed)
+def build_subject(cfg_name: str, P: int, seed: int, dev):
+    g = synthetic.humanoid_layers(P, seed, layers=10) if cfg_name == "c5" else synthetic.humanoid(P, seed)
+    if cfg_name == "c4":
+        g["position"] = np.clip(g["position"], -1.0, 1.0)      # SURVEY 8d: decode-path positions are clamped to [-1,1]^3
     cov = synthetic.covariance_from_gaussians(g)       # host stand-in for distCUDA2 + get_covariance (gs.py:70-73), untimed
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     return dict(means3D=t(g["position"]), cov3D=t(cov), opacity=t(g["opacity"].reshape(P, 1)), rgb=t(g["rgb"])), g, cov
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--gaussians", type=int, default=100_000)
-    ap.add_argument("--size", type=int, default=512)
-    ap.add_argument("--views-per-step", type=int, default=1, help="views per GPU per step (C2 = 1)")
-    ap.add_argument("--exchange", choices=("loss", "full"), default="loss",
-                    help="N>1: 'loss' = north_star's protocol (replicated attributes, loss all-reduce overlapped with the backward); "
-                         "'full' = attribute broadcast + all-reduce of gradients and loss (sigman_release_amd/parallel.py)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--exact-sync", action="store_true", help="read num_rendered back every step (upstream behaviour) instead of the sync-free capacity mode")
-    args = ap.parse_args()
+def fail(msg: str, code: int = 2):
+    print(f"[bench] ERROR: {msg}", file=sys.stderr, flush=True)
+    sys.exit(code)
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+
+def main(args):
+    cfg = dict(CONFIGS[args.config])
+    steps = args.steps if args.steps is not None else cfg["steps"]
+    warmup = args.warmup if args.warmup is not None else cfg["warmup"]
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback for the product path)"
-    local_rank %= max(torch.cuda.device_count(), 1)     # (lets a 1-GPU box exercise the N>1 code path with gloo)
+    backend = os.environ.get("SIGMAN_BENCH_BACKEND", "nccl")
+    if not torch.cuda.is_available():
+        fail("bench.py needs an MI355X (there is no CPU fallback for the product path)")
+    if world_env != args.gpus:
+        fail(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world_env} ranks; refusing to report a different rank count")
+    ndev = torch.cuda.device_count()
+    if world_env > ndev and backend == "nccl":
+        fail(f"{world_env} ranks but only {ndev} visible GPU(s): RCCL needs one GPU per rank (SIGMAN_BENCH_BACKEND=gloo shares cuda:0 for a plumbing check)")
+    local_rank %= max(ndev, 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    world = 1
+    if world_env > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(os.environ.get("SIGMAN_BENCH_BACKEND", "nccl"), **({"device_id": dev} if os.environ.get("SIGMAN_BENCH_BACKEND", "nccl") == "nccl" else {}))
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+        dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
+        world = dist.get_world_size()
+        if world != args.gpus:
+            fail(f"process group has {world} ranks, --gpus {args.gpus}")
 
-    P, H, W = args.gaussians, args.size, args.size
-    vps = args.views_per_step
-    subj, g_host, cov_host = build_subject(P, 1, dev)
-    all_views = [VIEWS[i % len(VIEWS)] for i in range(world * vps)]
-    my_views = [all_views[i] for i in parallel.shard_views(len(all_views), rank, world)]
+    P = args.gaussians or cfg["P"]
+    H = W = args.size or cfg["size"]
+    S = cfg["subjects"]
+    bwd, da = cfg["bwd"], cfg["da"]
+    # ---- the view slots of this rank
+    if args.config in ("c2", "c5"):
+        vps = args.views_per_step
+        all_views = [VIEWS[i % len(VIEWS)] for i in range(world * vps)]            # weak: one more view per extra GPU
+    elif args.config == "c3":
+        all_views = list(VIEWS)                                                    # per subject; strong
+    else:
+        all_views = list(range(90))
+    mine = [all_views[i] for i in parallel.shard_views(len(all_views), rank, world)]
+    n_total_views = S * len(all_views)
+    n_local = S * len(mine)
+    seeds = {"c2": [1], "c3": [100 + b for b in range(S)], "c4": [3], "c5": [4]}[args.config]
+    subs = [build_subject(args.config, P, s, dev) for s in seeds]
+    subj = {k: torch.stack([x[0][k] for x in subs]) for k in ("means3D", "cov3D", "opacity", "rgb")}      # [S,P,...]
+    g_host, cov_host = subs[0][1], subs[0][2]
     bg = torch.ones(3, device=dev)
-    cv, cvp, cp = cameras.make_cameras(my_views)
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-    st = R.BatchedRasterizationSettings(H, W, cameras.TAN_HALF_FOV, cameras.TAN_HALF_FOV, bg, 0.5, t(cv), t(cvp), 0, t(cp), len(my_views))
-    if not args.exact_sync:
-        # sync-free mode: size the binning buffers from one exact (untimed) forward, +25 % head-room; an overflow would raise
-        with torch.no_grad():
-            probe = R.forward_debug(subj["means3D"][None], subj["opacity"][None], colors_precomp=subj["rgb"][None],
-                                    cov3D_precomp=subj["cov3D"][None], settings=st)
-        st = st._replace(max_rendered=int(probe["num_rendered"] * 1.25) + 4096)
-        del probe
-    n_total_views = len(all_views)
+    st = None
+    if n_local:
+        cv, cvp, cp = cameras.make_cameras(mine * S)                               # slot v -> subject v // len(mine)
+        st = R.BatchedRasterizationSettings(H, W, cameras.TAN_HALF_FOV, cameras.TAN_HALF_FOV, bg, 0.5, t(cv), t(cvp), 0, t(cp), len(mine))
+        if not args.exact_sync:
+            # sync-free mode: size the binning buffers from one exact (untimed) forward, +25 % head-room; an overflow would raise
+            with torch.no_grad():
+                probe = R.forward_debug(subj["means3D"], subj["opacity"], colors_precomp=subj["rgb"], cov3D_precomp=subj["cov3D"], settings=st)
+            st = st._replace(max_rendered=int(probe["num_rendered"] * 1.25) + 4096)
+            del probe
     norm = 1.0 / (n_total_views * 3 * H * W)
 
-    # ground truth: render of a perturbed copy (untimed)
-    with torch.no_grad():
-        rng = torch.Generator(device="cpu").manual_seed(1234)
-        pert = lambda x, s: x + s * torch.randn(x.shape, generator=rng).to(dev)
-        gt, _, _, _ = R.rasterize_gaussians_batched(pert(subj["means3D"], 2e-3)[None], None, None,
-                                                    (subj["rgb"] * 0.9)[None], subj["opacity"][None], None, None,
-                                                    subj["cov3D"][None], st)
-        gt = gt.clamp(0, 1)
+    gt = gD = gA = None
+    if bwd and n_local:
+        # ground truth: render of a perturbed copy (untimed); stand-in for the dataset image of whole_loss.py:126-131
+        with torch.no_grad():
+            rng = torch.Generator(device="cpu").manual_seed(1234)
+            pert = lambda x, s: x + s * torch.randn(x.shape, generator=rng).to(dev)
+            gt = R.rasterize_gaussians_batched(pert(subj["means3D"], 2e-3), None, None, subj["rgb"] * 0.9, subj["opacity"], None, None,
+                                               subj["cov3D"], st)[0].clamp(0, 1)
+        if da:
+            gen = torch.Generator(device="cpu").manual_seed(77)
+            gD = (torch.randn(n_local, 1, H, W, generator=gen) * norm).to(dev)
+            gA = (torch.randn(n_local, 1, H, W, generator=gen) * norm).to(dev)
+    one = torch.ones((), device=dev)
 
     def render_loss(means3D, cov3D, opacity, rgb, _views=None):
         # gs.py:98-107 rasterize + clamp, whole_loss.py:126-131 L1: one autograd node, loss kernel right behind the compositing kernel
-        return R.rasterize_l1_loss_batched(means3D[None], None, None, rgb[None], opacity[None], None, None, cov3D[None], st, gt,
-                                           None, norm)[0]
+        sp = lambda x, k: x.reshape(S, P, k)
+        out = R.rasterize_l1_loss_batched(sp(means3D, 3), None, None, sp(rgb, 3), sp(opacity, 1), None, None, sp(cov3D, 6), st, gt, None, norm)
+        return out if da else out[0]
 
     leaves = {k: v.clone().requires_grad_(True) for k, v in subj.items()}
-    one = torch.ones((), device=dev)
-    packed = parallel.pack_attributes(subj["means3D"], subj["cov3D"], subj["opacity"], subj["rgb"])
+    packed = parallel.pack_attributes(subj["means3D"].reshape(S * P, 3), subj["cov3D"].reshape(S * P, 6), subj["opacity"].reshape(S * P),
+                                      subj["rgb"].reshape(S * P, 3))
+
+    def backward_of(out):
+        if da:      # C5: non-zero dL/ddepth and dL/dalpha go straight into the rasterizer node (no reduction kernels in the step)
+            torch.autograd.backward([out[0], out[4], out[5]], [one, gD, gA])
+            return out[0]
+        out.backward(one)                 # explicit seed: autograd would otherwise launch a ones_like fill kernel every step
+        return out
 
     def step():
+        if not bwd:
+            with torch.no_grad():
+                if n_local:
+                    R.rasterize_gaussians_batched(subj["means3D"], None, None, subj["rgb"], subj["opacity"], None, None, subj["cov3D"], st)
+            return None
         if world == 1:
             for v in leaves.values():
                 v.grad = None
-            loss = render_loss(leaves["means3D"], leaves["cov3D"], leaves["opacity"], leaves["rgb"])
-            loss.backward(one)              # explicit seed: autograd would otherwise launch a ones_like fill kernel every step
-            return loss
-        loss, grad = parallel.view_parallel_step(packed, all_views, lambda m, c, o, r, mine: render_loss(m, c, o, r, mine),
-                                                 exchange=args.exchange, seed_grad=one, pack_grad=False)
+            return backward_of(render_loss(leaves["means3D"], leaves["cov3D"], leaves["opacity"], leaves["rgb"]))
+        def rl(m, c, o, r, mv):
+            out = render_loss(m, c, o, r, mv)
+            return (out[0], [out[4], out[5]], [gD, gA]) if da else out     # C5: dL/ddepth, dL/dalpha seeded with the loss in one backward
+        loss, _grad = parallel.view_parallel_step(packed, all_views, rl, exchange=args.exchange if args.config in ("c2", "c5") else "loss",
+                                                  seed_grad=one, pack_grad=False)
         return loss
 
     L = _cabi.lib()
@@ -178,16 +275,16 @@ def main():
             torch.cuda.synchronize()
 
     # ---- warmup (untimed), with a full per-kernel profile of the last 3 warmup steps to pick the dominant kernel
-    for i in range(args.warmup):
-        if i == max(args.warmup - 3, 0):
+    for i in range(warmup):
+        if i == max(warmup - 3, 0):
             torch.cuda.synchronize()
             L.sgr_prof_configure(0xFFFF)
         step()
     torch.cuda.synchronize()
     prof_all = collect()
-    nprof = max(args.warmup - max(args.warmup - 3, 0), 1)
+    nprof = max(warmup - max(warmup - 3, 0), 1)
     breakdown = {KERNELS[k]: round(v[0] / nprof, 4) for k, v in prof_all.items() if k in KERNELS}
-    dominant = max(prof_all, key=lambda k: prof_all[k][0]) if prof_all else 6
+    dominant = max(prof_all, key=lambda k: prof_all[k][0]) if prof_all else 5
     L.sgr_prof_configure(0)
     for _ in range(3):                           # re-warm without the profiler (lets the launch-graph cache fill)
         step()
@@ -195,7 +292,8 @@ def main():
     # ---- timed region (no per-kernel events here: event pairs would force plain launches instead of graph replay)
     sync_all()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    loss = None
+    for _ in range(steps):
         loss = step()
     sync_all()
     elapsed = time.perf_counter() - t0
@@ -205,88 +303,176 @@ def main():
         elapsed = float(tt.item())
     # ---- the same K steps again with HIP-event pairs around the dominant kernel (live roofline measurement)
     L.sgr_prof_configure(1 << dominant)
-    for _ in range(args.steps):
+    for _ in range(steps):
         step()
     torch.cuda.synchronize()
     dom = collect()
     L.sgr_prof_configure(0)
 
     # ---- workload counters (from the run's own buffers)
-    with torch.no_grad():
-        dbg = R.forward_debug(subj["means3D"][None], subj["opacity"][None], colors_precomp=subj["rgb"][None],
-                              cov3D_precomp=subj["cov3D"][None], settings=st._replace(max_rendered=0))
-        Rn = int(dbg["num_rendered"])
-        S_visits = int(dbg["n_contrib"].to(torch.int64).sum().item())
-    ms_per_step = elapsed / args.steps * 1e3
+    Rn = S_visits = 0
+    if n_local:
+        with torch.no_grad():
+            dbg = R.forward_debug(subj["means3D"], subj["opacity"], colors_precomp=subj["rgb"], cov3D_precomp=subj["cov3D"],
+                                  settings=st._replace(max_rendered=0))
+            Rn = int(dbg["num_rendered"])
+            S_visits = int(dbg["n_contrib"].to(torch.int64).sum().item())
+            del dbg
+    ms_per_step = elapsed / steps * 1e3
     views_per_s = n_total_views / (ms_per_step * 1e-3)
     tiles = ((W + 15) // 16) * ((H + 15) // 16)
     dom_ms, dom_n = dom.get(dominant, (0.0, 0))
     dom_avg_ms = dom_ms / max(dom_n, 1)
-    abytes = algorithmic_bytes(dominant, P * len(my_views), Rn, H * W * len(my_views), tiles * len(my_views), len(my_views))
+    abytes = algorithmic_bytes(dominant, P * n_local, Rn, H * W * n_local, tiles * n_local)
     achieved = abytes / (dom_avg_ms * 1e-3) / 1e9 if dom_avg_ms > 0 else 0.0
+    step_bytes = ((212 if bwd else 104) * P * n_local + (176 if bwd else 88) * Rn + (52 if bwd else 24) * H * W * n_local + 8 * tiles * n_local)
 
     # HBM traffic of the dominant kernel from the committed rocprofv3 PMC summary of this same command (separate --pmc passes,
     # gfx950 FETCH_SIZE correction applied as MI355X_MICROARCH.md prescribes); null when no summary matches this workload
-    traffic = None
+    traffic, traffic_src = None, None
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_c2.json")))
-        if P == 100_000 and H == 512 and len(my_views) == 1:
+        path = os.path.join(ROOT, "profiles", f"r02_pmc_{args.config}.json")
+        pmc = json.load(open(path))
+        if pmc.get("P") == P and pmc.get("size") == H and pmc.get("view_slots") == n_local:
             traffic = pmc["kernels"].get(KERNELS.get(dominant, ""), {}).get("hbm_bytes_corrected")
+            traffic_src = f"profiles/r02_pmc_{args.config}.json (kernels of commit {pmc.get('commit', '?')})"
     except Exception:
         traffic = None
 
     out = {
-        "metric": f"rendered views/sec (fwd+bwd) at {H}x{W}, {P} Gaussians/view",
-        "value": round(views_per_s, 3), "unit": "views/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "metric": f"rendered views/sec ({'fwd+bwd' if bwd else 'fwd'}) at {H}x{W}, {P} Gaussians/view",
+        "value": round(views_per_s, 3), "unit": "views/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": cfg["scaling"], "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"C2: procedural humanoid (SMPL-X stand-in), {P} Gaussians, {len(my_views)} view(s)/GPU/step "
-                               f"{H}x{W}, fwd+bwd, colors_precomp+cov3D_precomp, clamp+L1 loss",
-                   "views_per_step_total": n_total_views,
-                   "parallelism": (f"view-parallel x{world}, exchange={args.exchange}" if world > 1 else "single GPU"),
-                   "num_rendered_per_gpu": Rn, "gaussian_pixel_visits_per_gpu": S_visits,
-                   "binning_buffers": "exact (D2H read of num_rendered per step)" if args.exact_sync else f"pre-sized, max_rendered={st.max_rendered} (sync-free)"},
+        "config": {"workload": f"{cfg['label']}, {P} Gaussians/subject, {S} subject(s) x {len(mine)} view(s) on this GPU per step, "
+                               f"{H}x{W}, {'fwd+bwd' if bwd else 'forward only'}, colors_precomp+cov3D_precomp"
+                               + (", clamp+L1 loss" if bwd else "") + (", dL/ddepth and dL/dalpha non-zero" if da else ""),
+                   "name": args.config, "views_per_step_total": n_total_views, "view_slots_this_gpu": n_local,
+                   "parallelism": (f"view-parallel x{world} ({backend}), exchange={'none (forward only)' if not bwd else args.exchange}" if world > 1 else "single GPU"),
+                   "ranks_seen": world, "num_rendered_per_gpu": Rn, "gaussian_pixel_visits_per_gpu": S_visits,
+                   "binning_buffers": "exact (D2H read of num_rendered per step)" if args.exact_sync else (f"pre-sized, max_rendered={st.max_rendered} (sync-free)" if st else "-")},
         "gaussian_pixel_ops_per_s_per_gpu": round(S_visits / (ms_per_step * 1e-3), 1),
         "tile_instances_per_s_per_gpu": round(Rn / (ms_per_step * 1e-3), 1),
+        "step_hbm": {"algorithmic_bytes_per_step_per_gpu": step_bytes, "achieved_GBps": round(step_bytes / (ms_per_step * 1e-3) / 1e9, 1),
+                     "frac_of_peak": round(step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
         "roofline": {"bound": "hbm", "kernel": KERNELS.get(dominant, str(dominant)), "achieved": round(achieved, 2),
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                     "algorithmic_bytes_per_launch": abytes, "avg_launch_ms": round(dom_avg_ms, 5), "launches": dom_n},
+                     "traffic_source": traffic_src, "algorithmic_bytes_per_launch": abytes, "avg_launch_ms": round(dom_avg_ms, 5), "launches": dom_n},
         "kernel_ms_per_step": breakdown,
-        "loss": float(loss.detach()),
+        "loss": None if loss is None else float(loss.detach()),
     }
-
     out["config"]["host_threads"] = ("pinned to cores %s" % sorted(os.sched_getaffinity(0))) if _ORIG_AFFINITY is not None else "not pinned"
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        if _ORIG_AFFINITY is not None:
-            os.sched_setaffinity(0, _ORIG_AFFINITY)      # the OpenMP oracle gets every host core
-        out["cpu_baseline"] = cpu_baseline(g_host, cov_host, my_views[0], H, W, gt[0].cpu().numpy(), norm)
+    if rank == 0 and world == 1:
+        out["frontend_ms_per_subject"] = frontend_ms(g_host, dev)
+        if not args.no_variants and args.config in ("c2", "c3"):
+            out["variants"] = variants(args, subj, st, gt, norm, S, P, H, W, mine, dev)
+        if not args.no_cpu_baseline:
+            if _ORIG_AFFINITY is not None:
+                os.sched_setaffinity(0, _ORIG_AFFINITY)      # the OpenMP oracle gets every host core
+            out["cpu_baseline"] = cpu_baseline(g_host, cov_host, mine[0], H, W, None if gt is None else gt[0].cpu().numpy(), norm, bwd, da)
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 
-def cpu_baseline(g_host, cov_host, view, H, W, gt, norm):
-    """CPU oracle (test infrastructure) fwd+bwd on the same C2 inputs; bounded sample, all host cores via OpenMP."""
+def frontend_ms(g_host, dev):
+    """distCUDA2 + get_covariance (gs.py:70-73) for one subject: what GaussianRenderer.render pays once per subject before the
+    rasterizer; outside the timed step (the metric is the rasterizer's), reported next to it."""
+    from sigman_release_amd.renderer import covariance_from_scale_rotation, dist_cuda2
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    pos, sc, rot = t(g_host["position"]), t(g_host["scale"]), t(g_host["cov3d"])
+
+    def run():
+        with torch.no_grad():
+            covariance_from_scale_rotation(sc[None], rot[None], dist_cuda2(pos)[None])
+    for _ in range(3):
+        run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        run()
+    torch.cuda.synchronize()
+    return round((time.perf_counter() - t0) / 10 * 1e3, 4)
+
+
+def variants(args, subj, st, gt, norm, S, P, H, W, mine, dev):
+    """The same workload under the conditions the headline does NOT assume (N=1 only):
+      per_view_loop_*      the reference's own call pattern (gs.py:62-109): Python loop over subjects and views through the
+                           upstream-signature GaussianRasterizer (one launch chain + one autograd node per view), then clamp/stack/L1
+      unpinned_*, graphs_off_*   the batched step re-run in a subprocess without host-thread pinning / with hipGraph replay off"""
+    from sigman_release_amd.losses import clamped_l1_loss
+    out = {}
+    leaves = {k: v.clone().requires_grad_(True) for k, v in subj.items()}
+    vm, pm, cp = st.viewmatrix, st.projmatrix, st.campos
+    V = len(mine)
+
+    def per_view():
+        for v in leaves.values():
+            v.grad = None
+        imgs = []
+        for b in range(S):
+            for v in range(V):
+                i = b * V + v
+                rs = R.GaussianRasterizationSettings(H, W, cameras.TAN_HALF_FOV, cameras.TAN_HALF_FOV, st.bg, 0.5, vm[i], pm[i], 0, cp[i], False, False)
+                img, _radii, _depth, _alpha = R.GaussianRasterizer(rs)(
+                    means3D=leaves["means3D"][b], means2D=torch.zeros_like(leaves["means3D"][b]), opacities=leaves["opacity"][b],
+                    colors_precomp=leaves["rgb"][b], cov3D_precomp=leaves["cov3D"][b])
+                imgs.append(img.clamp(0, 1))
+        clamped_l1_loss(torch.stack(imgs), gt, None, norm).backward()
+    n = 30 if S * V == 1 else 5
+    for _ in range(3):
+        per_view()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        per_view()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
+    out["per_view_loop_ms_per_step"] = round(dt * 1e3, 4)
+    out["per_view_loop_views_per_s"] = round(S * V / dt, 1)
+    base = [sys.executable, os.path.abspath(__file__), "--config", args.config, "--no-cpu-baseline", "--no-variants"]
+    for key, env in (("unpinned", {"SIGMAN_NO_PIN": "1"}), ("graphs_off", {"SIGMAN_GRAPHS": "0"})):
+        try:
+            if _ORIG_AFFINITY is not None:
+                os.sched_setaffinity(0, _ORIG_AFFINITY)
+            r = subprocess.run(base, capture_output=True, text=True, timeout=600, env={**os.environ, **env})
+            line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+            out[f"{key}_ms_per_step"] = json.loads(line)["ms_per_step"]
+        except Exception as e:      # noqa: BLE001  (a variant that cannot run is reported, not fatal)
+            out[f"{key}_ms_per_step"] = f"failed: {e}"
+    return out
+
+
+def cpu_baseline(g_host, cov_host, view, H, W, gt, norm, bwd, da):
+    """CPU oracle (test infrastructure) on the same inputs; bounded sample (ONE view slot of the workload, 3 repetitions),
+    all host cores via OpenMP."""
     from oracle import ref
     cv, cvp, cp = cameras.make_cameras([view])
     P = g_host["position"].shape[0]
     kw = dict(viewmatrix=cv[0], projmatrix=cvp[0], campos=cp[0], bg=np.ones(3, np.float32), tanfovx=cameras.TAN_HALF_FOV,
               tanfovy=cameras.TAN_HALF_FOV, image_height=H, image_width=W)
+    rng = np.random.default_rng(77)
     times = []
     for i in range(4):
         t0 = time.perf_counter()
         st = ref.forward(g_host["position"], g_host["opacity"].reshape(P), colors_precomp=g_host["rgb"], cov3D_precomp=cov_host, **kw)
-        img = np.clip(st.color, 0, 1)
-        loss_cpu = float(np.abs(img - gt).sum() * norm)   # noqa: F841  (same clamp + L1 epilogue as the GPU step)
-        gC = (np.sign(img - gt) * ((st.color > 0) & (st.color < 1)) * norm).astype(np.float32)
-        ref.backward(st, gC)
+        if bwd:
+            img = np.clip(st.color, 0, 1)
+            loss_cpu = float(np.abs(img - gt).sum() * norm)   # noqa: F841  (same clamp + L1 epilogue as the GPU step)
+            gC = (np.sign(img - gt) * ((st.color >= 0) & (st.color <= 1)) * norm).astype(np.float32)
+            if da:
+                ref.backward(st, gC, (rng.normal(size=(1, H, W)) * norm).astype(np.float32), (rng.normal(size=(1, H, W)) * norm).astype(np.float32))
+            else:
+                ref.backward(st, gC)
         times.append(time.perf_counter() - t0)
     med = float(np.median(times[1:]))
     return {"value": round(1.0 / med, 4), "unit": "views/s", "cores": os.cpu_count(), "kind": "port",
-            "sample": "median of 3 x (1 view fwd+bwd, same C2 inputs) after 1 warm-up; oracle/gsplat_ref.c with OpenMP on all host cores",
+            "sample": f"median of 3 x (1 view slot of this workload, {'fwd+bwd' if bwd else 'forward only'}, {P} Gaussians, {H}x{W}) after 1 warm-up; "
+                      "oracle/gsplat_ref.c with OpenMP on all host cores",
             "seconds_per_view": round(med, 4)}
 
 
 if __name__ == "__main__":
-    main()
+    main(_ARGS)

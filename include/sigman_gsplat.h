@@ -108,8 +108,10 @@ typedef struct SgrForwardState {
 /*
  * == upstream _C.rasterize_gaussians (gs.py:98-106), for all n_views view slots at once.
  * capacity = 0: exact mode, ONE blocking read of num_rendered per call (upstream: one per view).
- * capacity > 0: sync-free mode; binning buffers sized for `capacity` instances; the true count is copied asynchronously to
- *               nr_pinned_host[0] (and [1] = overflow flag) and `nr_event` (a hipEvent_t, may be NULL) is recorded right after.
+ * capacity > 0: sync-free mode; binning buffers sized for `capacity` instances; the true count reaches nr_pinned_host[0]
+ *               asynchronously as ONE 8-byte word, count | overflow << 63 (a single store / 8-byte copy, so the host can never
+ *               see the count without its flag), and `nr_event` (a hipEvent_t, may be NULL) is recorded right after.
+ *               (exact mode fills nr_pinned_host[0] = count, [1] = overflow flag before it returns.)
  * with_aux != 0 also records what the bucket-parallel backward needs.
  * alloc may be NULL if state->geom / binning / image and their *_bytes capacities are pre-filled by the caller (sizes as reported in
  * the state of an earlier call with the same shapes): no callbacks; returns 2 (nothing useful launched) if a blob is too small.
@@ -142,6 +144,10 @@ int sgr_rasterize_backward(const SgrProblem *pb, const SgrForwardState *state, c
  *   0 = plain launches;   2 = force replay (caller guarantees the runtime is safe).
  */
 int sgr_set_graphs(int enable);
+/* upstream's `debug=True` (error conventions): while enabled, every kernel launch of the calling thread is followed by a
+ * device synchronise, and a fault is reported as a failure of the entry point with the name of the kernel in sgr_last_error();
+ * graph replay is bypassed.  Thread-local; returns the previous value. */
+int sgr_set_debug(int enable);
 int sgr_graph_stats(uint64_t *hits, uint64_t *misses);
 
 /* ---- staged, batched API -------------------------------------------------------------------- */
@@ -154,8 +160,8 @@ int32_t sgr_preprocess_blocks_per_view(int32_t P);
  * exclusive scan.  Outputs: rec [n_views*P*16], radii i32 [n_views*P], rect u32 [n_views*P*2]
  * (minx | miny<<16, maxx | maxy<<16), clamped u8 [n_views*P] (SH clamp bits, may be NULL without shs),
  * block_offsets u32 [2*(n_views*blocks_per_view + 1)] (first half: exclusive offsets, entry n = R; second half:
- * scratch for the un-scanned sums), num_rendered u64 [2] ([0] = R, [1] = 1 if R overflows the 32-bit instance index or
- * `capacity`).  capacity = 0: none (the caller reads R back and sizes the binning buffers exactly, like upstream);
+ * scratch for the un-scanned sums), num_rendered u64 [4] ([0] = R, [1] = 1 if R overflows the 32-bit instance index or
+ * `capacity`, [2] = R | overflow << 63: the word the sync-free mode publishes to the host, [3] unused).  capacity = 0: none (the caller reads R back and sizes the binning buffers exactly, like upstream);
  * capacity > 0: the caller pre-sized its binning buffers for `capacity` instances and never reads R on the critical path.
  */
 int sgr_preprocess_forward(const SgrProblem *pb, float *rec, int32_t *radii, uint32_t *rect, uint8_t *clamped,
@@ -210,7 +216,7 @@ int sgr_render_forward(const SgrProblem *pb, const uint32_t *ranges, const uint3
  * With the forward's aux buffers (and the forward's output images) the bucket-parallel kernel runs: one wave per
  * <=64-Gaussian bucket, lanes own Gaussians, pixel states rotate through the wave (no reductions, no LDS, NO ATOMICS):
  * each lane writes one partial record part[(4*instance + quadrant)*10 .. +10] and sets flags byte [4*instance + quadrant]
- * (part f32 [4*R*12], flags u32 [R], flags zeroed by this call); sgr_preprocess_backward gathers them in a fixed order,
+ * (part f32 [4*R*SGR_PART_FLOATS] = [4*R*10], flags u32 [R], flags zeroed by this call); sgr_preprocess_backward gathers them in a fixed order,
  * so gradients are bitwise reproducible.  grec may be NULL on this path.
  * Without the aux buffers (NULL) the pixel-parallel reverse walk runs: needs final_T and grec [n_views*P*12], which is
  * zeroed by this call and accumulated with hardware float atomics (one set per tile and Gaussian).
@@ -262,7 +268,7 @@ int sgr_cov3d_backward(int32_t n, const float *scale_raw, const float *rotation,
 /*
  * Fused image-space loss epilogue (gs.py:107 clamp + whole_loss.py:126-131 masked L1), one pass:
  *   loss_per_view[v] = weight * sum_{c,p} mask * |clamp(color,0,1) - target|      (zeroed by the call)
- *   grad_color       = weight * mask * sign(clamp(color) - target) * 1[0 < color < 1]
+ *   grad_color       = weight * mask * sign(clamp(color) - target) * 1[0 <= color <= 1]   (inclusive, like torch.clamp's backward)
  *   loss_total       = sum_v loss_per_view[v]   (optional, may be NULL; zeroed by the call; saves the caller a reduction launch)
  * sums_already_zero != 0: the caller guarantees both accumulators are zero (e.g. cleared by sgr_rasterize_forward's caller_clear)
  * color/target/grad_color [n_views,3,H,W]; mask [n_views,1,H,W] or NULL.

@@ -56,6 +56,7 @@ _SIGNATURES = {
     "sgr_bucket_slots": (C.c_uint64, [C.c_uint64, C.c_uint64]),
     "sgr_set_forward_mode": (C.c_int, [C.c_int]),
     "sgr_set_graphs": (C.c_int, [C.c_int]),
+    "sgr_set_debug": (C.c_int, [C.c_int]),
     "sgr_set_sort_mode": (C.c_int, [C.c_int]),
     "sgr_graph_stats": (C.c_int, [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "sgr_render_forward": (C.c_int, [C.POINTER(SgrProblem)] + [C.c_void_p] * 8 + [C.c_uint64] + [C.c_void_p] * 6),

@@ -19,6 +19,10 @@ void sgr_set_error(const char *fmt, ...) {
 extern "C" const char *sgr_last_error(void) { return g_err; }
 extern "C" int sgr_abi_version(void) { return SGR_ABI_VERSION; }
 
+static thread_local int g_debug = 0;
+int sgr_debug_enabled() { return g_debug; }
+extern "C" int sgr_set_debug(int enable) { const int old = g_debug; g_debug = enable ? 1 : 0; return old; }
+
 // ---------------------------------------------------------------------------------------------
 // profiler: hipEventRecord pairs on the launch stream around selected kernels (off by default; when off the
 // cost is one predictable branch per launch).  Single-threaded use only (bench.py).

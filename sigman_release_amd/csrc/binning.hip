@@ -94,8 +94,9 @@ __global__ __launch_bounds__(kThreads) void duplicate_keys_kernel(int P, int Tx,
         base = b == 0 ? 0u : (uint32_t)tot;
         if (b == 0 && threadIdx.x == 0) {
             const unsigned long long ovf = (tot > 0xFFFFFFF0ull || tot > ex.capacity) ? 1ull : 0ull;
-            ex.num_rendered[0] = tot; ex.num_rendered[1] = ovf;
-            if (ex.nr_host) { ex.nr_host[0] = tot; ex.nr_host[1] = ovf; __threadfence_system(); }
+            ex.num_rendered[0] = tot; ex.num_rendered[1] = ovf; ex.num_rendered[2] = tot | (ovf << 63);
+            // ONE 8-byte store: the host can never observe the count without its overflow flag
+            if (ex.nr_host) { __hip_atomic_store(ex.nr_host, tot | (ovf << 63), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); __threadfence_system(); }
         }
     } else {
         base = block_offsets[(size_t)view * gridDim.x + blockIdx.x];

@@ -20,12 +20,20 @@ void sgr_set_error(const char *fmt, ...);
             return 1;                                                                            \
         }                                                                                        \
     } while (0)
+int sgr_debug_enabled();        // api.hip: upstream's debug=True (thread-local)
 #define SGR_CHECK_LAUNCH(name)                                                                   \
     do {                                                                                         \
         hipError_t _e = hipGetLastError();                                                       \
         if (_e != hipSuccess) {                                                                  \
             sgr_set_error("launch of %s failed: %s", name, hipGetErrorString(_e));               \
             return 1;                                                                            \
+        }                                                                                        \
+        if (sgr_debug_enabled()) {                                                               \
+            _e = hipDeviceSynchronize();                                                         \
+            if (_e != hipSuccess) {                                                              \
+                sgr_set_error("debug: %s failed on the device: %s", name, hipGetErrorString(_e)); \
+                return 1;                                                                        \
+            }                                                                                    \
         }                                                                                        \
     } while (0)
 

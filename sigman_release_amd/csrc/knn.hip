@@ -54,6 +54,15 @@ __device__ __forceinline__ KnnSet knn_set(const KnnBatch &kb, int set) {
 __device__ __forceinline__ int f2ord(float f) { int i = __float_as_int(f); return i >= 0 ? i : i ^ 0x7FFFFFFF; }
 __device__ __forceinline__ float ord2f(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7FFFFFFF); }
 
+// per set: bbox words (min = +max ordered, max = -max ordered) and zeroed cell counters / fill cursors, in ONE launch for all sets
+// (no pageable host->device copies: nothing here blocks the host or dangles under stream capture)
+__global__ __launch_bounds__(kT) void knn_init_kernel(KnnBatch kb) {
+    const KnnSet ks = knn_set(kb, blockIdx.y);
+    if (blockIdx.x == 0 && threadIdx.x < 8) ks.bb[threadIdx.x] = threadIdx.x < 3 ? 0x7F7FFFFF : (threadIdx.x < 6 ? (int)0x80800000 : 0);
+    const size_t n = (size_t)2 * kb.max_cells + 1;            // cell_start [max_cells + 1] and cell_fill [max_cells] are adjacent
+    for (size_t i = (size_t)blockIdx.x * kT + threadIdx.x; i < n; i += (size_t)gridDim.x * kT) ks.cell_start[i] = 0u;
+}
+
 __global__ __launch_bounds__(kT) void bbox_kernel(KnnBatch kb) {
     const KnnSet ks = knn_set(kb, blockIdx.y);
     const int P = kb.P; const float *pts = ks.pts; int *bb = ks.bb;
@@ -332,15 +341,11 @@ extern "C" int sgr_knn_dist2_batched(int32_t n_sets, int32_t P, const float *poi
     KnnBatch kb;
     kb.P = P; kb.max_cells = max_cells; kb.points = points; kb.out = out_dist2; kb.ws = (char *)workspace; kb.ws_stride = stride;
     SgrProfScope _p(SGR_K_KNN, stream);
-    // per set: bbox init (min = +max ordered, max = -max ordered) and zeroed cell counters / fill cursors
-    const int init[8] = {0x7F7FFFFF, 0x7F7FFFFF, 0x7F7FFFFF, (int)0x80800000, (int)0x80800000, (int)0x80800000, 0, 0};
-    for (int s = 0; s < n_sets; s++) {
-        char *w = (char *)workspace + (size_t)s * stride;
-        SGR_CHECK_HIP(hipMemcpyAsync(w, init, sizeof(init), hipMemcpyHostToDevice, stream));
-        SGR_CHECK_HIP(hipMemsetAsync(w + (24 + 1024) * 4, 0, ((size_t)2 * max_cells + 1) * sizeof(uint32_t), stream));
-    }
     const int nb = (P + kT - 1) / kT;
     const int scan_blocks = (max_cells + 1 + kScanTile - 1) / kScanTile;
+    const size_t init_want = ((size_t)2 * max_cells + 1 + kT * 4 - 1) / (kT * 4);
+    const int init_blocks = (int)(init_want < 1024 ? init_want : 1024);
+    hipLaunchKernelGGL(knn_init_kernel, dim3(init_blocks, n_sets), dim3(kT), 0, stream, kb);
     hipLaunchKernelGGL(bbox_kernel, dim3(min(nb, 64), n_sets), dim3(kT), 0, stream, kb);
     hipLaunchKernelGGL(grid_setup_kernel, dim3(1, n_sets), dim3(64), 0, stream, kb);
     hipLaunchKernelGGL(cell_count_kernel, dim3(nb, n_sets), dim3(kT), 0, stream, kb);

@@ -10,7 +10,7 @@ namespace {
 constexpr int kT = 1024;     // few, fat workgroups: every workgroup ends in two same-address float atomics, which serialise in L2
 
 // grid: (blocks over H*W/4, n_views).  loss_view[v] += sum_{c,p} w * mask * |clamp(color) - target|
-// grad[v,c,p] = w * mask * sign(clamp(color) - target) * 1[0 < color < 1]      (clamp kills the gradient where saturated)
+// grad[v,c,p] = w * mask * sign(clamp(color) - target) * 1[0 <= color <= 1]    (torch.clamp's backward mask is INCLUSIVE: exactly 0 / 1 pass)
 __global__ __launch_bounds__(kT) void clamped_l1_kernel(const float *__restrict__ color, const float *__restrict__ target,
                                                         const float *__restrict__ mask, float weight, int hw, int vec,
                                                         float *__restrict__ grad, float *__restrict__ loss_view, float *__restrict__ loss_total) {
@@ -33,7 +33,7 @@ __global__ __launch_bounds__(kT) void clamped_l1_kernel(const float *__restrict_
         const float d = (xc - T) * M;                                             \
         acc += fabsf(d);                                                          \
         const float s = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);                   \
-        G = (X > 0.f && X < 1.f) ? weight * M * s : 0.f;                          \
+        G = (X >= 0.f && X <= 1.f) ? weight * M * s : 0.f;                          \
     }
             SGR_L1(x.x, t.x, m.x, g.x) SGR_L1(x.y, t.y, m.y, g.y) SGR_L1(x.z, t.z, m.z, g.z) SGR_L1(x.w, t.w, m.w, g.w)
 #undef SGR_L1
@@ -50,7 +50,7 @@ __global__ __launch_bounds__(kT) void clamped_l1_kernel(const float *__restrict_
                 const float d = (xc - t) * m;
                 acc += fabsf(d);
                 const float s = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
-                grad[base + (size_t)c * hw + p] = (x > 0.f && x < 1.f) ? weight * m * s : 0.f;
+                grad[base + (size_t)c * hw + p] = (x >= 0.f && x <= 1.f) ? weight * m * s : 0.f;
             }
         }
     }

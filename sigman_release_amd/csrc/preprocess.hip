@@ -319,8 +319,10 @@ __global__ __launch_bounds__(1024) void scan_block_sums_kernel(const uint32_t *_
     }
     if (t == 0) {
         out[n] = (uint32_t)carry;
+        const unsigned long long ovf = (carry > 0xFFFFFFF0ull || carry > capacity) ? 1ull : 0ull;
         num_rendered[0] = carry;
-        num_rendered[1] = (carry > 0xFFFFFFF0ull || carry > capacity) ? 1ull : 0ull;
+        num_rendered[1] = ovf;
+        num_rendered[2] = carry | (ovf << 63);          // the one word the sync-free mode copies to the host
     }
 }
 

@@ -94,7 +94,7 @@ static int forward_launches(const SgrProblem *pb, uint64_t capacity, uint64_t R,
     const bool self_scan = !preprocess_done && capacity > 0 && nblk <= 2048;
     if (!preprocess_done) {
         if (sgr_preprocess_forward_ex(pb, rec, out_radii, rect, clamped, block_offsets, num_rendered, capacity, self_scan, stream)) return 1;
-        if (nr_pinned_host && !self_scan) SGR_CHECK_HIP(hipMemcpyAsync(nr_pinned_host, num_rendered, 16, hipMemcpyDeviceToHost, stream));
+        if (nr_pinned_host && !self_scan) SGR_CHECK_HIP(hipMemcpyAsync(nr_pinned_host, num_rendered + 2, 8, hipMemcpyDeviceToHost, stream));   // count | overflow << 63
     }
     int32_t in_b = 0;
     const bool aux_on = st->with_aux != 0;
@@ -152,7 +152,7 @@ extern "C" int sgr_rasterize_forward(const SgrProblem *pb, uint64_t capacity, in
     st->off_rect = o; o = align_up(o + (nq ? nq : 1) * 8);
     st->off_clamped = o; o = align_up(o + (pb->shs ? (nq ? nq : 1) : 0));
     st->off_block_offsets = o; o = align_up(o + 2 * nbo * 4);
-    st->off_num_rendered = o; o = align_up(o + 16);
+    st->off_num_rendered = o; o = align_up(o + 32);
     st->geom_bytes = o;
     char *geom = get_blob(0, o);
     if (!geom) { sgr_set_error(alloc ? "geometry allocator returned NULL" : "pre-allocated geometry blob too small"); return alloc ? 1 : 2; }
@@ -175,7 +175,7 @@ extern "C" int sgr_rasterize_forward(const SgrProblem *pb, uint64_t capacity, in
     } else if (pb->P > 0) {
         R = capacity;                             // sync-free: buffers pre-sized, the true count goes to the host asynchronously
     } else {
-        SGR_CHECK_HIP(hipMemsetAsync(num_rendered, 0, 16, stream));
+        SGR_CHECK_HIP(hipMemsetAsync(num_rendered, 0, 32, stream));
         preprocess_done = true;
     }
     st->R_alloc = R;
@@ -213,7 +213,7 @@ extern "C" int sgr_rasterize_forward(const SgrProblem *pb, uint64_t capacity, in
     if (!image) { sgr_set_error(alloc ? "image allocator returned NULL" : "pre-allocated image blob too small"); return alloc ? 1 : 2; }
     st->image = image;
 
-    const bool try_graph = graphs_allowed() && capacity > 0 && pb->P > 0 && !sgr_prof_active();
+    const bool try_graph = graphs_allowed() && capacity > 0 && pb->P > 0 && !sgr_prof_active() && !sgr_debug_enabled();
     if (try_graph) {
         std::lock_guard<std::mutex> graph_lock(g_graph_mu);
         FwdKey key;
@@ -229,7 +229,7 @@ extern "C" int sgr_rasterize_forward(const SgrProblem *pb, uint64_t capacity, in
             g_fwd[found].stamp = ++g_stamp; g_graph_hits++; g_miss_streak = 0;
             *st = g_fwd[found].st;
             SGR_CHECK_HIP(hipGraphLaunch(g_fwd[found].exec, stream));
-            if (nr_pinned_host) SGR_CHECK_HIP(hipMemcpyAsync(nr_pinned_host, num_rendered, 16, hipMemcpyDeviceToHost, stream));
+            if (nr_pinned_host) SGR_CHECK_HIP(hipMemcpyAsync(nr_pinned_host, num_rendered + 2, 8, hipMemcpyDeviceToHost, stream));
             if (nr_event) SGR_CHECK_HIP(hipEventRecord((hipEvent_t)nr_event, stream));
             return 0;
         }
@@ -260,7 +260,7 @@ extern "C" int sgr_rasterize_forward(const SgrProblem *pb, uint64_t capacity, in
                     (void)hipGraphDestroy(graph);
                     g_fwd[found].exec = exec; g_fwd[found].st = *st; g_fwd[found].stamp = ++g_stamp;
                     SGR_CHECK_HIP(hipGraphLaunch(exec, stream));
-                    if (nr_pinned_host) SGR_CHECK_HIP(hipMemcpyAsync(nr_pinned_host, num_rendered, 16, hipMemcpyDeviceToHost, stream));
+                    if (nr_pinned_host) SGR_CHECK_HIP(hipMemcpyAsync(nr_pinned_host, num_rendered + 2, 8, hipMemcpyDeviceToHost, stream));
                     if (nr_event) SGR_CHECK_HIP(hipEventRecord((hipEvent_t)nr_event, stream));
                     return 0;
                 }

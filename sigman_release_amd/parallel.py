@@ -49,13 +49,28 @@ def unpack_attributes(packed: torch.Tensor):
             packed[10 * P:].view(P, 3))
 
 
+def _split(res):
+    if isinstance(res, tuple):
+        return res[0], list(res[1]), list(res[2])
+    return res, [], []
+
+
+def _backward(loss, seed_grad, extra_out, extra_grad):
+    if extra_out:
+        torch.autograd.backward([loss] + extra_out, [seed_grad if seed_grad is not None else torch.ones_like(loss)] + extra_grad)
+    else:
+        loss.backward(seed_grad)
+
+
 def view_parallel_step(packed: torch.Tensor, view_ids: Sequence[int], render_loss: Callable, *, src: int = 0, group=None,
                        broadcast: bool = True, exchange: str = "full", seed_grad: torch.Tensor = None, pack_grad: bool = True):
     """One fwd+bwd step of a subject whose views are sharded over the ranks of `group`.
 
     packed      flat [13*P] attributes (pack_attributes); exchange="full": only rank `src` needs valid contents when broadcast=True
     view_ids    all views of the subject (same list on every rank)
-    render_loss (means3D, cov3D, opacity, rgb, my_view_ids) -> scalar loss SUM over my views (differentiable)
+    render_loss (means3D, cov3D, opacity, rgb, my_view_ids) -> scalar loss SUM over my views (differentiable), or a tuple
+                (loss, extra_outputs, extra_grads): further outputs of the same graph with fixed upstream gradients (e.g. the
+                rasterizer's depth / alpha maps with dL/ddepth, dL/dalpha) that are seeded together with the loss in ONE backward
     exchange    "full": returns (global loss, GLOBAL gradient flat [13*P]);  "loss": returns (global loss, this rank's PARTIAL
                 gradient) with the loss all-reduce overlapped with the backward (module docstring)
     seed_grad   optional 0-d ones tensor for loss.backward() (saves the fill kernel autograd would launch for it)
@@ -71,14 +86,14 @@ def view_parallel_step(packed: torch.Tensor, view_ids: Sequence[int], render_los
         mine = [view_ids[i] for i in shard_views(len(view_ids), rank, world)]
         work = None
         if mine:
-            loss = render_loss(*leaves, mine)
+            loss, extra_out, extra_grad = _split(render_loss(*leaves, mine))
             loss_val = loss.detach().reshape(1).clone()
         else:
             loss, loss_val = None, torch.zeros(1, device=packed.device, dtype=packed.dtype)
         if world > 1:
             work = dist.all_reduce(loss_val, op=dist.ReduceOp.SUM, group=group, async_op=True)   # travels while the backward runs
         if loss is not None:
-            loss.backward(seed_grad)
+            _backward(loss, seed_grad, extra_out, extra_grad)
             grads = [(l.grad if l.grad is not None else torch.zeros_like(l)) for l in leaves]
         else:
             grads = [torch.zeros_like(l) for l in leaves]
@@ -92,8 +107,8 @@ def view_parallel_step(packed: torch.Tensor, view_ids: Sequence[int], render_los
     leaves = [x.detach().requires_grad_(True) for x in unpack_attributes(packed)]
     mine = [view_ids[i] for i in shard_views(len(view_ids), rank, world)]
     if mine:
-        loss = render_loss(*leaves, mine)
-        loss.backward(seed_grad)
+        loss, extra_out, extra_grad = _split(render_loss(*leaves, mine))
+        _backward(loss, seed_grad, extra_out, extra_grad)
         buf = torch.cat([(l.grad if l.grad is not None else torch.zeros_like(l)).reshape(-1) for l in leaves]
                         + [loss.detach().reshape(1).to(packed.dtype)])
     else:

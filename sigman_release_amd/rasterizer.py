@@ -52,8 +52,10 @@ class BatchedRasterizationSettings(NamedTuple):
     views_per_subject: int
     debug: bool = False
     # 0: exact mode (one device->host read of num_rendered per batched forward, like upstream does per view).
-    # >0: sync-free mode: binning buffers are pre-sized for this many tile instances; an overflow raises at backward /
-    #     at the next call (checked through an async copy + event, never on the critical path).
+    # >0: sync-free mode: binning buffers are pre-sized for this many tile instances and the count reaches the host through an async
+    #     copy into a pinned slot (one slot per pending forward).  An overflow raises RuntimeError: in the call itself when no input
+    #     needs a gradient (inference: nothing else would ever look), otherwise at its backward -- or at the start of this thread's
+    #     next forward / at check_pending_overflows(), whichever comes first.  Never a memory fault (the kernels bounds-check).
     # -1: automatic: the first call with a given (P, n_views, H, W) runs in exact mode and remembers its count; later calls are
     #     sync-free with 1.3x that capacity.  The count reaches a pinned host slot right after the duplicate kernel, i.e. while the
     #     host is still queueing the rest of the forward: it is checked once everything is queued, and an overflow silently re-runs
@@ -89,30 +91,106 @@ def _f32c(t: torch.Tensor) -> torch.Tensor:
     return t.contiguous()
 
 
-class _PinnedRing:
-    """Small ring of pinned host slots + events for the asynchronous num_rendered read-back (allocating pinned memory or
-    events per call would cost more than the sync it replaces)."""
-
-    def __init__(self, n=32):
-        self.n, self.i, self.buf, self.ev = n, 0, None, None
-
-    def next(self):
-        if self.buf is None:
-            self.buf = torch.zeros(self.n, 2, dtype=torch.int64).pin_memory()
-            self.ev = [torch.cuda.Event() for _ in range(self.n)]
-            for e in self.ev:
-                e.record()                     # materialises the underlying hipEvent_t so its handle can cross the C ABI
-            self.slots = [self.buf[k] for k in range(self.n)]
-            self.ptrs = [x.data_ptr() for x in self.slots]
-            self.handles = [e.cuda_event for e in self.ev]
-            self.np = self.buf.numpy()         # same memory: cheap host-side reads / sentinel writes
-        k = self.i
-        self.i = (self.i + 1) % self.n
-        self.np[k, 0] = -1                     # sentinel: "the count has not arrived yet"
-        return self.np[k], self.ev[k], self.ptrs[k], self.handles[k]
+_OVF_BIT = 1 << 63
 
 
-_ring = _PinnedRing()
+class _Slot:
+    """One pinned 16-byte host slot + one event for the asynchronous num_rendered read-back of ONE forward.  Sync-free mode: the
+    library publishes word [0] = count | overflow << 63 (a single 8-byte store / copy; -1 = not there yet).  Exact mode: [0] = count,
+    [1] = overflow flag, both final when the call returns."""
+    __slots__ = ("pool", "np", "ptr", "ev", "handle", "capacity", "checked", "result")
+
+    def arrived(self):
+        return int(self.np[0]) != -1
+
+    def read(self, block: bool):
+        """(count, overflow) or None if the word has not arrived and block is False."""
+        if int(self.np[0]) == -1:
+            if not block:
+                return None
+            self.ev.synchronize()
+        w = int(self.np[0]) & 0xFFFFFFFFFFFFFFFF
+        return w & (_OVF_BIT - 1), 1 if (w & _OVF_BIT) else 0
+
+
+class _SlotPool:
+    """Per-device pool of _Slot objects (allocating pinned memory or events per call would cost more than the sync it replaces).
+    Every forward takes its OWN slot and hands it back once its count has been looked at, so any number of forwards may be pending
+    (the reference's loop issues B*V = 64 forwards before one backward, gs.py:62-109); the pool grows in chunks of 32."""
+
+    def __init__(self):
+        self.free, self.chunks = [], []
+
+    def _grow(self, n=32):
+        buf = torch.zeros(n, 2, dtype=torch.int64).pin_memory()
+        arr = buf.numpy()                       # same memory: cheap host-side reads / sentinel writes
+        self.chunks.append(buf)
+        for k in range(n):
+            sl = _Slot()
+            sl.pool, sl.np, sl.ptr = self, arr[k], buf[k].data_ptr()
+            sl.ev = torch.cuda.Event()
+            sl.ev.record()                      # materialises the underlying hipEvent_t so its handle can cross the C ABI
+            sl.handle = sl.ev.cuda_event
+            self.free.append(sl)
+
+    def acquire(self, capacity):
+        if not self.free:
+            self._grow()
+        sl = self.free.pop()
+        sl.np[0] = -1                           # sentinel: "the count has not arrived yet"
+        sl.np[1] = 0
+        sl.capacity, sl.checked, sl.result = capacity, False, None
+        return sl
+
+    def release(self, sl):
+        if sl is not None and sl.pool is self:
+            sl.pool = None                      # (guards double release)
+            fresh = _Slot()
+            fresh.pool, fresh.np, fresh.ptr, fresh.ev, fresh.handle = self, sl.np, sl.ptr, sl.ev, sl.handle
+            self.free.append(fresh)
+
+
+_slot_pools = {}      # device index -> _SlotPool
+
+
+def _pool(dev: torch.device) -> _SlotPool:
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    p = _slot_pools.get(idx)
+    if p is None:
+        with torch.cuda.device(idx):
+            p = _slot_pools[idx] = _SlotPool()
+    return p
+
+
+def _overflow_error(count, capacity, earlier=False):
+    which = "an EARLIER forward of this thread (reported now: nobody had looked at its count yet) are" if earlier else "this forward are"
+    return RuntimeError(f"num_rendered {count} exceeds max_rendered {capacity}: results of {which} truncated; "
+                        "raise BatchedRasterizationSettings.max_rendered (or use 0 = exact mode)")
+
+
+def check_pending_overflows(block: bool = True):
+    """Sync-free mode (max_rendered > 0): look at the counts of this thread's earlier forwards that nobody has checked yet (a forward
+    whose backward never ran, e.g. under torch.no_grad() or when its output was dropped) and raise if one of them was truncated.
+    Called without blocking at the start of every forward; call it yourself with block=True after the last forward of a loop."""
+    pend = getattr(_pending, "slots", None)
+    if not pend:
+        return
+    keep, err = [], None
+    for sl in pend:
+        if sl.checked:
+            continue
+        r = sl.read(block)
+        if r is None:
+            keep.append(sl)
+            continue
+        sl.checked, sl.result = True, r
+        sl.pool.release(sl)
+        if r[1] and err is None:
+            err = _overflow_error(r[0], sl.capacity, earlier=True)
+    _pending.slots = keep
+    if err is not None:
+        raise err
+
 
 # one persistent allocator callback for the C ABI (creating a ctypes callback per call costs ~10 us); it serves the call
 # that is currently in flight on this thread: PyTorch allocates, the library only receives the pointer.
@@ -120,6 +198,7 @@ _ring = _PinnedRing()
 # thread) of different graphs may be in flight at the same time)
 import threading as _threading
 _alloc_target = _threading.local()
+_pending = _threading.local()          # .slots: this thread's forwards whose instance count nobody has looked at yet
 
 
 def _alloc_cb(_user, which, nbytes):
@@ -134,19 +213,20 @@ _NO_ALLOC = _cabi.ALLOC_FN(0)                 # NULL allocator: the blobs are pr
 
 class _Ctx:
     """What the forward leaves behind for the backward (== upstream geomBuffer / binningBuffer / imgBuffer + num_rendered)."""
-    __slots__ = ("state", "blobs", "radii", "dims", "nr_host", "nr_event", "capacity", "true_rendered", "keep", "pb")
+    __slots__ = ("state", "blobs", "radii", "dims", "slot", "capacity", "true_rendered", "keep", "pb")
 
     def check_overflow(self):
         """Sync-free mode: raise if the forward needed more tile instances than `max_rendered` (cheap: the copy finished long ago)."""
-        if self.nr_event is not None:
-            if self.nr_host[0] == -1:          # not there yet (it normally is: the copy was queued before the whole backward)
-                self.nr_event.synchronize()
-            nr = (int(self.nr_host[0]), int(self.nr_host[1]))
-            self.nr_event = None
-            self.true_rendered = int(nr[0])
-            if nr[1] != 0:
-                raise RuntimeError(f"num_rendered {nr[0]} exceeds max_rendered {self.capacity}: results of this forward are truncated; "
-                                   "raise BatchedRasterizationSettings.max_rendered (or use 0 = exact mode)")
+        sl = self.slot
+        if sl is not None:
+            self.slot = None
+            if not sl.checked:
+                sl.checked, sl.result = True, sl.read(True)
+                sl.pool.release(sl)
+            count, overflow = sl.result
+            self.true_rendered = count
+            if overflow:
+                raise _overflow_error(count, self.capacity)
 
     def view(self, which, off, count, dtype):
         """Typed tensor view into one of the three blobs (debug / parity tests)."""
@@ -174,8 +254,25 @@ def _make_problem(means3D, opacities, colors_precomp, shs, cov3D_precomp, scales
     return pb
 
 
-_auto_capacity = {}   # (P, n_views, H, W) -> remembered capacity of max_rendered = -1 (automatic) mode
-_blob_sizes = {}      # (P, n_views, H, W, capacity, aux, has_sh) -> (geom, binning, image) bytes of the last forward with these shapes
+_auto_capacity = {}   # (device, P, n_views, H, W) -> remembered capacity of max_rendered = -1 (automatic) mode
+_blob_sizes = {}      # (device, P, n_views, H, W, capacity, aux, has_sh) -> (geom, binning, image) bytes of the last forward with these shapes
+
+
+class _debug_scope:
+    """upstream's debug=True: every kernel launch of the enclosed library calls is followed by a device synchronise and a fault
+    names the kernel (sgr_set_debug, include/sigman_gsplat.h)."""
+
+    def __init__(self, on):
+        self.on = bool(on)
+
+    def __enter__(self):
+        if self.on:
+            self.old = _cabi.lib().sgr_set_debug(1)
+
+    def __exit__(self, *exc):
+        if self.on:
+            _cabi.lib().sgr_set_debug(self.old)
+        return False
 
 
 def _forward_impl(means3D, opacities, colors_precomp, shs, cov3D_precomp, scales, rotations, st: BatchedRasterizationSettings,
@@ -193,12 +290,15 @@ def _forward_impl(means3D, opacities, colors_precomp, shs, cov3D_precomp, scales
     depth = torch.empty(nv, 1, H, W, dtype=f32, device=dev)
     alpha = torch.empty(nv, 1, H, W, dtype=f32, device=dev)
     radii = torch.empty(nv, P, dtype=torch.int32, device=dev)
+    check_pending_overflows(block=False)               # an earlier sync-free forward that nobody checked (no backward ran)
     capacity = int(getattr(st, "max_rendered", 0) or 0)
     auto_key = None
+    didx = dev.index if dev.index is not None else torch.cuda.current_device()
     if capacity < 0:                                   # automatic mode: exact the first time, then sync-free with the remembered capacity
-        auto_key = (P, nv, H, W)
+        auto_key = (didx, P, nv, H, W)
         capacity = _auto_capacity.get(auto_key, 0)
-    nr_host, nr_event, nr_ptr, nr_handle = _ring.next()
+    slot = _pool(dev).acquire(capacity)
+    nr_host, nr_event, nr_ptr, nr_handle = slot.np, slot.ev, slot.ptr, slot.handle
     state = _cabi.SgrForwardState()
     blobs = [None, None, None, None]
     use_aux = 1 if (need_ctx and with_aux and not _USE_BWD_V1) else 0
@@ -208,50 +308,68 @@ def _forward_impl(means3D, opacities, colors_precomp, shs, cov3D_precomp, scales
             clear_ptr, clear_bytes, C.byref(state), _stream(dev))
     # sync-free mode: blob sizes only depend on the shapes, so from the second call on the blobs are allocated here and handed over
     # directly (no allocator callbacks through ctypes)
-    size_key = (P, nv, H, W, capacity, use_aux, shs is not None) if capacity > 0 else None
+    size_key = (didx, P, nv, H, W, capacity, use_aux, shs is not None) if capacity > 0 else None
     sizes = _blob_sizes.get(size_key) if size_key is not None else None
     status = 2
-    if sizes is not None:
-        u8 = torch.uint8
-        blobs[0], blobs[1], blobs[2] = (torch.empty(sizes[0], dtype=u8, device=dev), torch.empty(sizes[1], dtype=u8, device=dev),
-                                        torch.empty(sizes[2], dtype=u8, device=dev))
-        state.geom, state.binning, state.image = blobs[0].data_ptr(), blobs[1].data_ptr(), blobs[2].data_ptr()
-        state.geom_bytes, state.binning_bytes, state.image_bytes = sizes
-        status = L.sgr_rasterize_forward(*args, _NO_ALLOC, None, *outs)
-    if status == 2:                        # first call with these shapes (or sizes changed): the library asks for memory through the callback
-        _alloc_target.dev, _alloc_target.blobs = dev, blobs
-        status = L.sgr_rasterize_forward(*args, _ALLOC, None, *outs)
-        if status == 0 and size_key is not None:
-            _blob_sizes[size_key] = (max(int(state.geom_bytes), 256), max(int(state.binning_bytes), 256), max(int(state.image_bytes), 256))
+    with _debug_scope(getattr(st, "debug", False)):
+        if sizes is not None:
+            u8 = torch.uint8
+            blobs[0], blobs[1], blobs[2] = (torch.empty(sizes[0], dtype=u8, device=dev), torch.empty(sizes[1], dtype=u8, device=dev),
+                                            torch.empty(sizes[2], dtype=u8, device=dev))
+            state.geom, state.binning, state.image = blobs[0].data_ptr(), blobs[1].data_ptr(), blobs[2].data_ptr()
+            state.geom_bytes, state.binning_bytes, state.image_bytes = sizes
+            status = L.sgr_rasterize_forward(*args, _NO_ALLOC, None, *outs)
+        if status == 2:                    # first call with these shapes (or sizes changed): the library asks for memory through the callback
+            _alloc_target.dev, _alloc_target.blobs = dev, blobs
+            status = L.sgr_rasterize_forward(*args, _ALLOC, None, *outs)
+            if status == 0 and size_key is not None:
+                _blob_sizes[size_key] = (max(int(state.geom_bytes), 256), max(int(state.binning_bytes), 256), max(int(state.image_bytes), 256))
+    if status != 0:
+        _pool(dev).release(slot)
     _cabi.check(status, "sgr_rasterize_forward")
-    checked = False
+    pending = capacity > 0 and P > 0           # sync-free: the count is still on its way to the pinned slot
+    if pending and (auto_key is not None or not use_aux):
+        # automatic mode, and explicit sync-free forwards that will never see a backward (no input needs a gradient: torch.no_grad(),
+        # eval, a ground-truth render): look at the count now.  Everything is queued; the count was published right after the
+        # duplicate kernel (or by the copy behind the scan kernel / the replayed graph), so this wait is short and the GPU stays busy.
+        spins = 0
+        while not slot.arrived() and spins < 20000:
+            spins += 1
+        count, overflow = slot.read(True)
+        slot.checked, slot.result = True, (count, overflow)
+        pending = False
+        if overflow:
+            if auto_key is None:
+                _pool(dev).release(slot)
+                raise _overflow_error(count, capacity)
+            _pool(dev).release(slot)
+            _auto_capacity[auto_key] = 0               # re-run exactly; the exact run below re-learns the capacity
+            return _forward_impl(means3D, opacities, colors_precomp, shs, cov3D_precomp, scales, rotations, st, need_ctx,
+                                 with_aux, clear)
     if auto_key is not None and P > 0:
-        if capacity == 0:
-            count = int(state.true_rendered)
-        else:
-            # everything is queued; the count was published right after the duplicate kernel (or by the copy behind the scan kernel)
-            spins = 0
-            while nr_host[0] == -1 and spins < 20000:
-                spins += 1
-            if nr_host[0] == -1:
-                nr_event.synchronize()
-            count, overflow = int(nr_host[0]), int(nr_host[1])
-            checked = True
-            if overflow:
-                _auto_capacity[auto_key] = 0               # re-run exactly; the exact run below re-learns the capacity
-                return _forward_impl(means3D, opacities, colors_precomp, shs, cov3D_precomp, scales, rotations, st, need_ctx,
-                                     with_aux, clear)
+        count = int(state.true_rendered) if capacity == 0 else slot.result[0]
         if capacity == 0 or count * 1.1 > capacity:
             _auto_capacity[auto_key] = min(int(count * 1.3) + 4096, 0xFFFFFFE0)
+    if pending:
+        pend = getattr(_pending, "slots", None)
+        if pend is None:
+            pend = _pending.slots = []
+        pend.append(slot)                      # found again by the backward's check, or by the next forward if no backward ever runs
+        if len(pend) > 256:
+            check_pending_overflows(block=True)
+    elif not slot.checked:
+        slot.checked, slot.result = True, ((int(state.true_rendered), 0) if capacity == 0 and P > 0 else (0, 0))
     ctx = None
     if need_ctx:
         ctx = _Ctx()
         ctx.state, ctx.blobs, ctx.radii = state, blobs, radii
         ctx.dims = (S, P, nv, H, W)
-        ctx.nr_host, ctx.nr_event, ctx.capacity = nr_host, (nr_event if capacity > 0 and P > 0 and not checked else None), capacity
-        ctx.true_rendered = int(state.true_rendered) if capacity == 0 else None
+        ctx.slot, ctx.capacity = (slot if pending else None), capacity
+        ctx.true_rendered = slot.result[0] if slot.result is not None else None
         ctx.keep = (st.viewmatrix, st.projmatrix, st.campos, st.bg)
         ctx.pb = pb            # the backward sees the same tensors (saved_tensors share their storage), so the struct is reused
+    if not pending:
+        _pool(dev).release(slot)
     return color, radii, depth, alpha, ctx
 
 
@@ -279,10 +397,11 @@ def _backward_impl(ctx: _Ctx, means3D, opacities, colors_precomp, shs, cov3D_pre
     d_rot = torch.empty(S, P, 4, dtype=f32, device=dev) if scales is not None else None
     blobs = ctx.blobs
     _alloc_target.dev, _alloc_target.blobs = dev, blobs
-    _cabi.check(L.sgr_rasterize_backward(C.byref(pb), C.byref(ctx.state), _ptr(ctx.radii), _ptr(img[0]), _ptr(img[1]), _ptr(img[2]),
-                                         _ptr(gC), _ptr(gD), _ptr(gA), _ptr(grad_color_scale), _ALLOC, None, _ptr(d_means3D), _ptr(d_means2D), _ptr(d_op),
-                                         _ptr(d_col), _ptr(d_sh), _ptr(d_cov), _ptr(d_sc), _ptr(d_rot), _stream(dev)),
-                "sgr_rasterize_backward")
+    with _debug_scope(getattr(st, "debug", False)):
+        _cabi.check(L.sgr_rasterize_backward(C.byref(pb), C.byref(ctx.state), _ptr(ctx.radii), _ptr(img[0]), _ptr(img[1]), _ptr(img[2]),
+                                             _ptr(gC), _ptr(gD), _ptr(gA), _ptr(grad_color_scale), _ALLOC, None, _ptr(d_means3D), _ptr(d_means2D), _ptr(d_op),
+                                             _ptr(d_col), _ptr(d_sh), _ptr(d_cov), _ptr(d_sc), _ptr(d_rot), _stream(dev)),
+                    "sgr_rasterize_backward")
     grec = blobs[3]
     ctx.check_overflow()        # after the backward is queued: the host never idles the GPU while it waits for the forward's counter
     return d_means3D, d_means2D, d_sh, d_col, d_op, d_sc, d_rot, d_cov, grec
@@ -404,26 +523,67 @@ class _RasterizeGaussians(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
-        if means3D.ndim != 2 or means3D.shape[1] != 3:
-            raise RuntimeError("means3D must have dimensions (num_points, 3)")
         rs = raster_settings
+        if not rs.debug and (means3D.ndim != 2 or means3D.shape[1] != 3):
+            raise RuntimeError("means3D must have dimensions (num_points, 3)")
         st = BatchedRasterizationSettings(rs.image_height, rs.image_width, rs.tanfovx, rs.tanfovy, rs.bg, rs.scale_modifier,
                                           rs.viewmatrix.reshape(1, 4, 4), rs.projmatrix.reshape(1, 4, 4), rs.sh_degree,
                                           rs.campos.reshape(1, 3), 1, rs.debug, -1)      # automatic sync-free mode
         u = lambda t: None if t is None or t.numel() == 0 else t.unsqueeze(0)
         P = means3D.shape[0]
-        color, radii, depth, alpha = _fwd_common(ctx, means3D.unsqueeze(0), u(sh), u(colors_precomp), opacities.reshape(1, P, 1),
-                                                 u(scales), u(rotations), u(cov3Ds_precomp), st)
+        if rs.debug:
+            # upstream's debug=True: the library synchronises after every kernel (st.debug -> sgr_set_debug) and a failure -- argument
+            # errors included, upstream raises them from inside the native call -- leaves a snapshot of the inputs behind before it
+            # is re-raised
+            cpu_args = _cpu_copy((means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, tuple(rs)))
+            try:
+                if means3D.ndim != 2 or means3D.shape[1] != 3:
+                    raise RuntimeError("means3D must have dimensions (num_points, 3)")
+                color, radii, depth, alpha = _fwd_common(ctx, means3D.unsqueeze(0), u(sh), u(colors_precomp), opacities.reshape(1, P, 1),
+                                                         u(scales), u(rotations), u(cov3Ds_precomp), st)
+                torch.cuda.synchronize(means3D.device)
+            except Exception:
+                torch.save(cpu_args, "snapshot_fw.dump")
+                print("\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
+                raise
+        else:
+            color, radii, depth, alpha = _fwd_common(ctx, means3D.unsqueeze(0), u(sh), u(colors_precomp), opacities.reshape(1, P, 1),
+                                                     u(scales), u(rotations), u(cov3Ds_precomp), st)
+        if rs.prefiltered and P > 0:
+            # upstream traps ("Point is filtered although prefiltered is set. This shouldn't happen!") when a caller that promised
+            # pre-filtered input hands over a point behind the near plane; here it is a Python error (costs one tiny kernel + a sync,
+            # only when the flag is set -- the reference never sets it, gs.py:93)
+            if not bool(mark_visible(means3D.detach(), rs.viewmatrix).all()):
+                raise RuntimeError("Point is filtered although prefiltered is set. This shouldn't happen!")
         color, radii, depth, alpha = color[0], radii[0], depth[0], alpha[0]
         ctx.has_means2D = means2D is not None
+        ctx.debug = bool(rs.debug)
         ctx.mark_non_differentiable(radii)
         return color, radii, depth, alpha
 
     @staticmethod
     def backward(ctx, grad_color, grad_radii, grad_depth, grad_alpha):
         ub = lambda t: None if t is None else t.unsqueeze(0)
-        g = _bwd_common(ctx, ub(grad_color), ub(grad_depth), ub(grad_alpha))
+        if ctx.debug:
+            cpu_args = _cpu_copy((grad_color, grad_depth, grad_alpha) + tuple(ctx.saved_tensors[:7]))
+            try:
+                g = _bwd_common(ctx, ub(grad_color), ub(grad_depth), ub(grad_alpha))
+                torch.cuda.synchronize(ctx.saved_tensors[0].device)
+            except Exception:
+                torch.save(cpu_args, "snapshot_bw.dump")
+                print("\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")
+                raise
+        else:
+            g = _bwd_common(ctx, ub(grad_color), ub(grad_depth), ub(grad_alpha))
         return tuple(None if x is None else x[0] for x in g) + (None,)
+
+
+def _cpu_copy(obj):
+    if isinstance(obj, torch.Tensor):
+        return obj.detach().cpu().clone()
+    if isinstance(obj, (tuple, list)):
+        return tuple(_cpu_copy(x) for x in obj)
+    return obj
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):

@@ -343,7 +343,51 @@ def test_sort_flavours_bit_exact(name, sort_mode, oracle):
         _cabi.lib().sgr_set_sort_mode(3)
 
 
-def _full_size_check(oracle, inp, st, with_depth_alpha_grads):
+_OBSERVED_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "full_size_observed.json")
+
+
+def _check_against_observed(name, stats):
+    """Full-size parity bookkeeping.  fp32 exp on the GPU (v_exp_f32 in the exp2 domain) and libm expf on the CPU differ in the last
+    ulp, so out of ~1e7..1e9 pixel-Gaussian visits a handful land on the other side of the published `alpha < 1/255 -> skip` /
+    `T < 1e-4 -> stop` decisions; such a flip moves a pixel by at most alpha*T <= 1/255 and the gradient of the Gaussians involved.
+    The number and size of these excursions is DETERMINISTIC for a given build, so it is recorded (tests/golden/full_size_observed.json,
+    written from a GPU run by tools/record_full_size_observed.py) and a run may exceed the record by at most 2x (count: max(2n, 4);
+    size: 2x) -- a regression that doubles the decision flips fails.  `stats`: {key: (n_beyond_tolerance, max_error)}."""
+    import json
+    print("FULL_SIZE_OBSERVED " + json.dumps({name: {k: [int(v[0]), float(v[1])] for k, v in stats.items()}}))
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    try:
+        os.makedirs(out_dir, exist_ok=True)
+        with open(os.path.join(out_dir, f"full_size_observed_{name}.json"), "w") as f:
+            json.dump({name: {k: [int(v[0]), float(v[1])] for k, v in stats.items()}}, f)
+    except OSError:
+        pass
+    rec = {}
+    if os.path.exists(_OBSERVED_PATH):
+        rec = json.load(open(_OBSERVED_PATH)).get(name, {})
+    if os.environ.get("SIGMAN_RECORD_OBSERVED") == "1":          # recording run: the hard ceilings of the caller still apply
+        return
+    assert rec, (f"no committed observation for '{name}' in tests/golden/full_size_observed.json (run the GPU tests with "
+                 "SIGMAN_RECORD_OBSERVED=1, then tools/record_full_size_observed.py)")
+    for k, (n, mx) in stats.items():
+        n0, mx0 = rec[k]
+        assert n <= max(2 * n0, 4), f"{name}/{k}: {n} values beyond tolerance, recorded {n0}"
+        assert mx <= max(2.0 * mx0, 1.2e-4), f"{name}/{k}: max error {mx:.3e}, recorded {mx0:.3e}"
+
+
+def _parity_stats(color, depth, alpha, grads, ref, gref):
+    """(count beyond the north_star tolerance, max error) per output; gradients relative to max|g| of the tensor."""
+    st = {}
+    for k, got, want, tol in (("color", color, ref.color, IMG_TOL), ("depth", depth, ref.depth, IMG_TOL), ("alpha", alpha, ref.alpha, IMG_TOL)):
+        e = np.abs(got - want)
+        st[k] = (int((e > tol).sum()), float(e.max()))
+    for k, (got, want) in grads.items():
+        e = np.abs(got - want) / max(np.abs(want).max(), 1e-20)
+        st["grad_" + k] = (int((e > GRAD_TOL).sum()), float(e.max()))
+    return st
+
+
+def _full_size_check(oracle, inp, st, with_depth_alpha_grads, name):
     from sigman_release_amd import rasterizer as R
     dev = _dev()
     H, W = st["image_height"], st["image_width"]
@@ -368,28 +412,22 @@ def _full_size_check(oracle, inp, st, with_depth_alpha_grads):
     # ---- full-size parity against the oracle (a few hundred ms of CPU at these sizes)
     ref = oracle.forward(**inp, **cases.single_view(st))
     np.testing.assert_array_equal(radii[0].cpu().numpy(), ref.radii)
-    err_c = np.abs(c - ref.color)
-    # fp32 exp on the GPU and libm expf on the CPU differ in the last ulp, so out of ~2e7 pixel-Gaussian visits a couple land on the
-    # other side of the published `alpha < 1/255 -> skip` rule; such a flip changes a pixel by at most alpha*T <= 1/255.
-    # Everything else must be within 1e-4; flips are bounded in number (<= 1e-5 of the values) and size (<= 1/255 + 1e-4).
-    assert (err_c > IMG_TOL).mean() <= 1e-5 and err_c.max() <= 1.0 / 255.0 + IMG_TOL, \
-        f"colour max err {err_c.max():.3e} on {(err_c > IMG_TOL).sum()} values"
-    err_d = np.abs(depth[0].detach().cpu().numpy() - ref.depth)
-    assert (err_d > IMG_TOL * 4).mean() <= 1e-5 and err_d.max() <= 4.0 / 255.0 + IMG_TOL, f"depth max err {err_d.max():.3e}"
     g = oracle.backward(ref, gC, gD if with_depth_alpha_grads else None, gA if with_depth_alpha_grads else None)
-    for nm, got, want in (("means3D", d["means3D"].grad[0], g["means3D"]), ("opacities", d["opacities"].grad[0], g["opacities"][:, 0]),
-                          ("colors", d["colors_precomp"].grad[0], g["colors_precomp"]), ("cov3D", d["cov3D_precomp"].grad[0], g["cov3D_precomp"])):
-        e = np.abs(got.cpu().numpy() - want) / max(np.abs(want).max(), 1e-20)
-        # a decision flip (see above) moves the gradient of the one or two Gaussians involved at that pixel; all others must agree
-        nbad = int((e > GRAD_TOL).sum())
-        assert nbad <= max(12, int(1e-5 * e.size)) and e.max() <= 2e-2, f"{nm}: {nbad} entries beyond {GRAD_TOL}, max {e.max():.3e}"
+    stats = _parity_stats(c, depth[0].detach().cpu().numpy(), alpha[0].detach().cpu().numpy(),
+                          {"means3D": (d["means3D"].grad[0].cpu().numpy(), g["means3D"]), "opacities": (d["opacities"].grad[0].cpu().numpy(), g["opacities"][:, 0]),
+                           "colors": (d["colors_precomp"].grad[0].cpu().numpy(), g["colors_precomp"]),
+                           "cov3D": (d["cov3D_precomp"].grad[0].cpu().numpy(), g["cov3D_precomp"])}, ref, g)
+    # hard ceilings (what ONE decision flip can do), then the recorded counts
+    assert stats["color"][1] <= 1.0 / 255.0 + IMG_TOL and stats["depth"][1] <= 4.0 / 255.0 + IMG_TOL and stats["alpha"][1] <= 1.0 / 255.0 + IMG_TOL, stats
+    assert all(v[1] <= 2e-2 for k, v in stats.items() if k.startswith("grad_")), stats
+    _check_against_observed(name, stats)
     return ref
 
 
 def test_full_size_c2_100k_512(oracle):
     """BASELINE.json configs[1] at full size: 100 000-Gaussian humanoid, 512x512, forward + backward, oracle parity + properties."""
     inp, st = cases.humanoid(P=100_000, H=512, W=512, seed=1)
-    ref = _full_size_check(oracle, inp, st, with_depth_alpha_grads=False)
+    ref = _full_size_check(oracle, inp, st, with_depth_alpha_grads=False, name="c2")
     assert ref.R > 150_000
 
 
@@ -400,7 +438,7 @@ def test_full_size_c5_1m_stress(oracle):
     inp = dict(means3D=g["position"], opacities=g["opacity"].reshape(-1), colors_precomp=g["rgb"],
                cov3D_precomp=synthetic.covariance_from_gaussians(g))
     _, st = cases.humanoid(P=10, H=512, W=512, seed=1)
-    ref = _full_size_check(oracle, inp, st, with_depth_alpha_grads=True)
+    ref = _full_size_check(oracle, inp, st, with_depth_alpha_grads=True, name="c5")
     assert ref.P == 1_000_000
 
 
@@ -533,44 +571,74 @@ def _humanoid_inputs(P, seed, dev):
     return t(g["position"]), t(g["opacity"].reshape(P, 1)), t(g["rgb"]), t(synthetic.covariance_from_gaussians(g))
 
 
-def test_full_size_c3_batch_8x8_views_512():
-    """BASELINE.json configs[2] shape on one GPU: 8 subjects x 8 views at 512x512 (64 view slots = 65 536 tiles: serial forward kernel,
-    whole-key sort), forward + backward.  Size-independent properties instead of a 64-view CPU oracle run:
-      * every view slot of the batch is BITWISE the single-view render of that subject/camera (different kernel flavours:
-        segment-parallel forward, segmented sort) for radii and n_contrib, and within 2e-6 for the images;
-      * linearity: the batch gradient of subject s equals the sum of its 8 single-view gradients."""
-    from sigman_release_amd import cameras
+def test_full_size_c3_batch_8x8_views_512(oracle):
+    """BASELINE.json configs[2] at FULL size on one GPU: 8 subjects x 8 views at 512x512, 100 000 Gaussians per subject (64 view
+    slots = 65 536 tiles, ~1.3e7 tile instances), forward + backward, all 64 views in one launch chain.
+      * oracle parity on the 8 view slots of subject 2 plus slots (0,0) and (7,7): radii bit-exact, images within 1e-4 (up to the
+        recorded decision flips), and the per-SUBJECT gradient of subject 2 (= sum over its 8 views, gs.py:62-117 +
+        whole_loss.py:126-131) against the sum of the oracle's 8 backward passes;
+      * every checked view slot of the batch is BITWISE the single-view render of that subject/camera (different kernel flavours:
+        segment-parallel forward, per-tile sort) for radii, and within 2e-6 for the images;
+      * linearity: the batch gradient of subject 5 equals the sum of its 8 single-view gradients."""
+    from sigman_release_amd import cameras, synthetic
     from sigman_release_amd import rasterizer as R
     dev = _dev()
-    S, V, P, H = 8, 8, 20_000, 512
+    S, V, P, H = 8, 8, 100_000, 512
     views = [30, 37, 45, 53, 65, 85, 0, 8]
-    subj = [_humanoid_inputs(P, 100 + s, dev) for s in range(S)]
-    m, o, c, cov = [torch.stack([x[k] for x in subj]).requires_grad_(True) for k in range(4)]
-    cv, cvp, cp = cameras.make_cameras(views * S)
+    host = [synthetic.humanoid(P, 100 + s) for s in range(S)]
+    hcov = [synthetic.covariance_from_gaussians(g) for g in host]
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    m, o, c, cov = [torch.stack(x).requires_grad_(True) for x in ([t(g["position"]) for g in host], [t(g["opacity"].reshape(P, 1)) for g in host],
+                                                                  [t(g["rgb"]) for g in host], [t(k) for k in hcov])]
+    cv, cvp, cp = cameras.make_cameras(views * S)
     bg = torch.tensor([1.0, 1.0, 1.0], device=dev)
     bst = R.BatchedRasterizationSettings(H, H, cameras.TAN_HALF_FOV, cameras.TAN_HALF_FOV, bg, 1.0, t(cv), t(cvp), 0, t(cp), V)
     color, radii, depth, alpha = R.rasterize_gaussians_batched(m, None, None, c, o, None, None, cov, bst)
-    gC = torch.randn(S * V, 3, H, H, device=dev, generator=torch.Generator(device=dev).manual_seed(5)) / (H * H)
+    gC = torch.randn(S * V, 3, H, H, device=dev, generator=torch.Generator(device=dev).manual_seed(5)) / (H * H) * 100
     (color * gC).sum().backward()
+    torch.cuda.synchronize()
     a = alpha.detach()
     assert torch.isfinite(color).all() and float(a.min()) >= 0 and float(a.max()) <= 1 + 1e-5
-    for s, v in ((0, 0), (3, 5), (7, 7)):
-        i = s * V + v
+    # ---- oracle parity
+    kw = dict(bg=np.ones(3, np.float32), tanfovx=cameras.TAN_HALF_FOV, tanfovy=cameras.TAN_HALF_FOV, image_height=H, image_width=H)
+    n_bad, e_max, acc = 0, 0.0, None
+    for s_, v in [(2, k) for k in range(V)] + [(0, 0), (7, 7)]:
+        i = s_ * V + v
+        g = host[s_]
+        r = oracle.forward(g["position"], g["opacity"].reshape(P), colors_precomp=g["rgb"], cov3D_precomp=hcov[s_], viewmatrix=cv[i],
+                           projmatrix=cvp[i], campos=cp[i], **kw)
+        np.testing.assert_array_equal(radii[i].cpu().numpy(), r.radii)
+        e = np.abs(color[i].detach().cpu().numpy() - r.color)
+        n_bad += int((e > IMG_TOL).sum())
+        e_max = max(e_max, float(e.max()))
+        assert np.abs(alpha[i].detach().cpu().numpy() - r.alpha).max() <= 1.0 / 255.0 + IMG_TOL
+        if s_ == 2:
+            gr = oracle.backward(r, gC[i].cpu().numpy())
+            acc = gr if acc is None else {k: acc[k] + gr[k] for k in acc}
+    stats = {"color": (n_bad, e_max)}
+    for nm, got, want in (("means3D", m.grad[2], acc["means3D"]), ("opacities", o.grad[2], acc["opacities"]), ("colors", c.grad[2], acc["colors_precomp"]),
+                          ("cov3D", cov.grad[2], acc["cov3D_precomp"])):
+        e = np.abs(got.cpu().numpy().reshape(want.shape) - want) / max(np.abs(want).max(), 1e-20)
+        stats["grad_" + nm] = (int((e > GRAD_TOL).sum()), float(e.max()))
+    assert stats["color"][1] <= 1.0 / 255.0 + IMG_TOL and all(v[1] <= 2e-2 for k, v in stats.items() if k.startswith("grad_")), stats
+    _check_against_observed("c3", stats)
+    # ---- batch == single-view renders, linearity
+    for s_, v in ((0, 0), (3, 5), (7, 7)):
+        i = s_ * V + v
         one = bst._replace(viewmatrix=bst.viewmatrix[i:i + 1], projmatrix=bst.projmatrix[i:i + 1], campos=bst.campos[i:i + 1], views_per_subject=1)
-        c1, r1, d1, a1 = R.rasterize_gaussians_batched(m[s:s + 1].detach(), None, None, c[s:s + 1].detach(), o[s:s + 1].detach(), None, None,
-                                                       cov[s:s + 1].detach(), one)
+        c1, r1, d1, a1 = R.rasterize_gaussians_batched(m[s_:s_ + 1].detach(), None, None, c[s_:s_ + 1].detach(), o[s_:s_ + 1].detach(), None, None,
+                                                       cov[s_:s_ + 1].detach(), one)
         assert torch.equal(r1[0], radii[i])
         assert float((c1[0] - color[i].detach()).abs().max()) <= 2e-6 and float((d1[0] - depth[i].detach()).abs().max()) <= 2e-5
-    s = 2
-    leaves = [x[s:s + 1].detach().clone().requires_grad_(True) for x in (m, c, o, cov)]
+    s_ = 5
+    leaves = [x[s_:s_ + 1].detach().clone().requires_grad_(True) for x in (m, c, o, cov)]
     for v in range(V):
-        i = s * V + v
+        i = s_ * V + v
         one = bst._replace(viewmatrix=bst.viewmatrix[i:i + 1], projmatrix=bst.projmatrix[i:i + 1], campos=bst.campos[i:i + 1], views_per_subject=1)
         c1 = R.rasterize_gaussians_batched(leaves[0], None, None, leaves[1], leaves[2], None, None, leaves[3], one)[0]
         (c1[0] * gC[i]).sum().backward()
-    for got, want, nm in ((m.grad[s], leaves[0].grad[0], "means3D"), (c.grad[s], leaves[1].grad[0], "colors"),
-                          (o.grad[s], leaves[2].grad[0], "opacity"), (cov.grad[s], leaves[3].grad[0], "cov3D")):
+    for got, want, nm in ((m.grad[s_], leaves[0].grad[0], "means3D"), (c.grad[s_], leaves[1].grad[0], "colors"),
+                          (o.grad[s_], leaves[2].grad[0], "opacity"), (cov.grad[s_], leaves[3].grad[0], "cov3D")):
         err = float((got - want).abs().max()) / max(float(want.abs().max()), 1e-20)
         assert err <= GRAD_TOL, f"{nm}: batch gradient vs sum of per-view gradients {err:.3e}"
 
@@ -680,7 +748,7 @@ def test_automatic_capacity_mode_is_transparent():
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     P, H, W = 6000, 160, 144
     inp, st = cases.humanoid(P=P, H=H, W=W, seed=31)
-    R._auto_capacity.pop((P, 1, H, W), None)
+    R._auto_capacity.pop((0, P, 1, H, W), None)
     results = []
     # splat size multiplier per call: small (learns a small capacity), same, 3x (overflows the remembered capacity), 3x again, small
     for mul in (0.4, 0.4, 3.0, 3.0, 0.4):
@@ -696,5 +764,5 @@ def test_automatic_capacity_mode_is_transparent():
         for a, b in zip(*per_mode):
             assert torch.equal(a, b)
         results.append(int((per_mode[0][1] > 0).sum()))
-    cap = R._auto_capacity[(P, 1, H, W)]
+    cap = R._auto_capacity[(0, P, 1, H, W)]
     assert cap > 0 and results[2] >= results[0]
