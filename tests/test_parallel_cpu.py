@@ -93,3 +93,39 @@ def test_shard_views():
     assert parallel.shard_views(90, 0, 8) == list(range(0, 90, 8))
     assert sorted(sum((parallel.shard_views(90, r, 8) for r in range(8)), [])) == list(range(90))
     assert parallel.shard_views(2, 5, 8) == []
+
+
+def test_extra_outputs_are_seeded_with_the_loss():
+    """render_loss may return (loss, extra_outputs, extra_grads): the extras are seeded in the SAME backward (how bench.py's C5 step
+    feeds dL/ddepth and dL/dalpha into the rasterizer node without reduction kernels)."""
+    P = 7
+    packed = torch.arange(13 * P, dtype=torch.float32) / 10.0
+    w = torch.linspace(0.5, 1.5, 3 * P).reshape(P, 3)
+
+    def rl_scalar(m, c, o, r, mine):
+        return (m * m).sum() + ((m * 2.0) * w).sum()
+
+    def rl_tuple(m, c, o, r, mine):
+        return (m * m).sum(), [m * 2.0], [w]
+    for exchange in ("full", "loss"):
+        l1, g1 = parallel.view_parallel_step(packed.clone(), [30], rl_scalar, exchange=exchange)
+        l2, g2 = parallel.view_parallel_step(packed.clone(), [30], rl_tuple, exchange=exchange, seed_grad=torch.ones(()))
+        assert torch.allclose(g1, g2) and float(g1.abs().sum()) > 0
+        assert abs(float(l2) - float((packed[:3 * P] ** 2).sum())) < 1e-4
+
+
+def test_bench_refuses_to_report_fewer_ranks_than_asked():
+    """`bench.py --gpus 2` launches its own two ranks (no launcher needed) and, when they cannot run (no GPU here), exits non-zero
+    instead of printing a single-process line with n_gpus: 1 (missing #2)."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], capture_output=True, text=True,
+                       timeout=600, env=env)
+    assert r.returncode != 0
+    assert "starting 2 ranks" in r.stderr and "torch.distributed.run" in r.stderr
+    assert '"n_gpus"' not in r.stdout
+    # under a launcher that started a different number of ranks than --gpus: refuse as well
+    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "0"], capture_output=True, text=True,
+                        timeout=600, env=env2)
+    assert r2.returncode != 0 and '"n_gpus"' not in r2.stdout
