@@ -658,30 +658,14 @@ struct SortPrep {               // optional piggy-back job of the large-class la
     uint2 *desc; size_t n_desc; uint32_t *order; uint32_t tiles_total; int enabled;
 };
 
-template <int NT, int CAP, bool SMALL_CLASS>
-__global__ __launch_bounds__(NT) void tile_sort_kernel(const uint2 *__restrict__ ranges, uint64_t *__restrict__ src_keys,
-                                                       uint32_t *__restrict__ src_vals, uint64_t *__restrict__ dst_keys,
-                                                       uint32_t *__restrict__ dst_vals, uint32_t *__restrict__ worklist /*[0]=count, [1..]=tiles*/,
-                                                       SortPrep prep) {
-    __shared__ uint32_t ka[CAP], va[CAP], kb[CAP], vb[CAP];
-    __shared__ uint32_t hist[kRadix], digit_base[kRadix], wave_cnt[NT / 64][kRadix], wtot[4];
+// sorts ONE tile's segment by its depth bits (stable), src -> dst; all NT threads of the workgroup take part
+template <int NT, int CAP>
+__device__ __forceinline__ void sort_one_tile(const uint2 range, uint64_t *__restrict__ src_keys, uint32_t *__restrict__ src_vals,
+                                              uint64_t *__restrict__ dst_keys, uint32_t *__restrict__ dst_vals, uint32_t *ka, uint32_t *va,
+                                              uint32_t *kb, uint32_t *vb, uint32_t *hist, uint32_t *digit_base,
+                                              uint32_t (*wave_cnt)[kRadix], uint32_t *wtot) {
     const uint32_t t = threadIdx.x;
-    uint32_t nsort = gridDim.x;
-    if (!SMALL_CLASS && NT == 1024 && prep.enabled) {
-        nsort = gridDim.x - 1;
-        if (blockIdx.x == nsort) { sgr_fwd_prepare(ranges, prep.tiles_total, prep.desc, prep.n_desc, prep.order, hist); return; }
-    }
-    const uint32_t nwork = SMALL_CLASS ? 1u : worklist[0];
-    for (uint32_t wi = SMALL_CLASS ? 0u : blockIdx.x; wi < nwork; wi += nsort) {
-    const uint32_t tile_id = SMALL_CLASS ? blockIdx.x : worklist[1 + wi];
-    const uint2 range = ranges[tile_id];
     const uint32_t n = range.y - range.x;
-    if (n == 0) return;
-    if (SMALL_CLASS && n > (uint32_t)kSegCapSmall) {
-        if (t == 0) worklist[1 + atomicAdd(&worklist[0], 1u)] = tile_id;
-        return;
-    }
-    __syncthreads();                                               // (large class: LDS reuse between worklist items)
     uint64_t *gsrc_k = src_keys + range.x, *gdst_k = dst_keys + range.x;
     uint32_t *gsrc_v = src_vals + range.x, *gdst_v = dst_vals + range.x;
     bool in_b = false;
@@ -701,6 +685,555 @@ __global__ __launch_bounds__(NT) void tile_sort_kernel(const uint2 *__restrict__
         if (!in_b)                                               // result sits in src: move it to dst
             for (uint32_t k = t; k < n; k += NT) { gdst_k[k] = gsrc_k[k]; gdst_v[k] = gsrc_v[k]; }
     }
+}
+
+template <int NT, int CAP, bool SMALL_CLASS>
+__global__ __launch_bounds__(NT) void tile_sort_kernel(const uint2 *__restrict__ ranges, uint64_t *__restrict__ src_keys,
+                                                       uint32_t *__restrict__ src_vals, uint64_t *__restrict__ dst_keys,
+                                                       uint32_t *__restrict__ dst_vals, uint32_t *__restrict__ worklist /*[0]=count, [1..]=tiles*/,
+                                                       SortPrep prep) {
+    __shared__ uint32_t ka[CAP], va[CAP], kb[CAP], vb[CAP];
+    __shared__ uint32_t hist[kRadix], digit_base[kRadix], wave_cnt[NT / 64][kRadix], wtot[4];
+    const uint32_t t = threadIdx.x;
+    uint32_t nsort = gridDim.x;
+    if (!SMALL_CLASS && NT == 1024 && prep.enabled) {
+        nsort = gridDim.x - 1;
+        if (blockIdx.x == nsort) { sgr_fwd_prepare(ranges, prep.tiles_total, prep.desc, prep.n_desc, prep.order, hist); return; }
+    }
+    const uint32_t nwork = SMALL_CLASS ? 1u : worklist[0];
+    for (uint32_t wi = SMALL_CLASS ? 0u : blockIdx.x; wi < nwork; wi += nsort) {
+        const uint32_t tile_id = SMALL_CLASS ? blockIdx.x : worklist[1 + wi];
+        const uint2 range = ranges[tile_id];
+        const uint32_t n = range.y - range.x;
+        if (n == 0) return;
+        if (SMALL_CLASS && n > (uint32_t)kSegCapSmall) {
+            if (t == 0) worklist[1 + atomicAdd(&worklist[0], 1u)] = tile_id;
+            return;
+        }
+        __syncthreads();                                               // (large class: LDS reuse between worklist items)
+        sort_one_tile<NT, CAP>(range, src_keys, src_vals, dst_keys, dst_vals, ka, va, kb, vb, hist, digit_base, wave_cnt, wtot);
+    }
+}
+
+// the same for the view-segmented flavour: a fixed grid of workgroups drains a worklist of occupied tiles through an atomic ticket
+// (tile lists differ 100x in length, so a static round-robin would leave most of the grid idle behind the long ones)
+struct TileWork { const uint32_t *list; uint32_t *ticket; const uint32_t *count; };
+
+template <int NT, int CAP>
+__global__ __launch_bounds__(NT) void tile_sort_dyn_kernel(const uint2 *__restrict__ ranges, uint64_t *__restrict__ src_keys,
+                                                           uint32_t *__restrict__ src_vals, uint64_t *__restrict__ dst_keys,
+                                                           uint32_t *__restrict__ dst_vals, TileWork w) {
+    __shared__ uint32_t ka[CAP], va[CAP], kb[CAP], vb[CAP];
+    __shared__ uint32_t hist[kRadix], digit_base[kRadix], wave_cnt[NT / 64][kRadix], wtot[4];
+    __shared__ uint32_t s_item;
+    const uint32_t nwork = *w.count;
+    for (;;) {
+        __syncthreads();                                               // LDS (and s_item) reuse between worklist items
+        if (threadIdx.x == 0) s_item = atomicAdd(w.ticket, 1u);
+        __syncthreads();
+        const uint32_t wi = s_item;
+        if (wi >= nwork) return;
+        const uint2 range = ranges[w.list[wi]];
+        if (range.y > range.x) sort_one_tile<NT, CAP>(range, src_keys, src_vals, dst_keys, dst_vals, ka, va, kb, vb, hist, digit_base, wave_cnt, wtot);
+    }
+}
+
+// ---- per-tile depth sort IN REGISTERS ----------------------------------------------------------------------------------
+// One wave per tile, the tile's entries held as 64-bit composites (depth bits << 32 | value) in IPT registers per lane.  The value
+// (view * P + Gaussian index) grows with the emission order, so ordering the composites IS the stable sort by depth -- any comparison
+// network will do, and a bitonic network runs entirely in VGPRs: compare-exchanges between registers of a lane for partner distances
+// < IPT, and for the larger distances a lane exchange (DPP quad / row permutes, ds_swizzle, v_permlane32_swap: no LDS memory, no
+// barriers, nothing to wait for but the ALU).  "Flip" formulation: every merge of two sorted halves first pairs e with e ^ (k - 1),
+// then e with e ^ j for j = k/4 .. 1, so every compare-exchange puts the smaller composite at the lower index and no direction
+// flags are needed.  Element e lives in lane e / IPT, register e % IPT.  Tiles shorter than 64 * IPT are padded with all-ones.
+// n log^2 n compare-exchanges instead of the radix sort's 3 passes, but nothing waits on LDS round trips or workgroup barriers and no
+// LDS capacity limits the number of tiles in flight (measured on MI355X, tools/micro/bench_tile_sort.hip, 12 000 tiles: 250-entry
+// tiles 98 us vs 176 us for the LDS radix sort, 1000-entry tiles 224 vs 215 us, 3000 x 2000 entries 164 vs 208 us; tiles beyond the
+// LDS radix sort's 4096-entry capacity -- which went through global memory, ~100 us per tile -- stay in registers up to 16384).
+template <int M>
+__device__ __forceinline__ uint32_t sgr_xlane(uint32_t v) {                       // value of lane (l ^ M), M a compile-time constant
+    if constexpr (M == 1) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);          // quad_perm [1,0,3,2]
+    else if constexpr (M == 2) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false);     // quad_perm [2,3,0,1]
+    else if constexpr (M == 3) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x1B, 0xF, 0xF, false);     // quad_perm [3,2,1,0]
+    else if constexpr (M == 7) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, false);    // row_half_mirror
+    else if constexpr (M == 15) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, false);   // row_mirror
+    else if constexpr (M < 32) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x1F | (M << 10));             // bit-mask mode: xor within 32 lanes
+    else return (uint32_t)__shfl_xor((int)v, M, 64);
+}
+
+// value of lane (l ^ M) for a 32- or 64-bit composite
+template <int M, typename T>
+__device__ __forceinline__ T sgr_xlane_t(T v) {
+    if constexpr (sizeof(T) == 8) return ((uint64_t)sgr_xlane<M>((uint32_t)(v >> 32)) << 32) | sgr_xlane<M>((uint32_t)v);
+    else return sgr_xlane<M>(v);
+}
+
+// compare-exchange with the lane M away; TOP = the highest bit of M: lanes with that bit clear keep the smaller composite
+template <int M, int TOP, typename T>
+__device__ __forceinline__ T sgr_cex_lane(T a, uint32_t lane) {
+    const bool upper = (lane & (uint32_t)TOP) != 0u;
+    if constexpr (M == 32) {
+        // v_permlane32_swap: afterwards [0] holds the LOWER partner's value and [1] the UPPER partner's value in every lane
+        T x, y;
+        if constexpr (sizeof(T) == 8) {
+            const auto lo = __builtin_amdgcn_permlane32_swap((uint32_t)a, (uint32_t)a, false, false);
+            const auto hi = __builtin_amdgcn_permlane32_swap((uint32_t)(a >> 32), (uint32_t)(a >> 32), false, false);
+            x = ((uint64_t)hi[0] << 32) | lo[0]; y = ((uint64_t)hi[1] << 32) | lo[1];
+        } else {
+            const auto r = __builtin_amdgcn_permlane32_swap(a, a, false, false);
+            x = r[0]; y = r[1];
+        }
+        const T mn = y < x ? y : x, mx = y < x ? x : y;
+        return upper ? mx : mn;
+    } else {
+        const T b = sgr_xlane_t<M, T>(a);
+        if constexpr (sizeof(T) == 8) return ((b < a) != upper) ? b : a;
+        else { const T mn = b < a ? b : a, mx = b < a ? a : b; return upper ? mx : mn; }     // v_min_u32 / v_max_u32 / v_cndmask
+    }
+}
+
+// Every register index and every lane permutation must be a compile-time constant, but the network must NOT be unrolled into one
+// straight line of code: a 1024-entry sort is 55 stages of ~100 instructions, executed once per tile -- as straight-line code
+// (32 KB for IPT = 16, 200 KB for IPT = 64) every wave streams its instructions from L2 and the kernel is instruction-fetch bound
+// (measured: 385 us for the <= 1024-entry tiles of C3 instead of 134 us).  So: ONE copy of each distinct stage body (flip K, shift J),
+// selected by a switch inside rolled loops over K and J.
+template <typename T, int IPT, int K>
+__device__ __forceinline__ void sgr_bitonic_flip(T (&a)[IPT], uint32_t lane) {
+    if constexpr (K <= IPT) {
+#pragma unroll
+        for (int r = 0; r < IPT; r++) {
+            const int p = r ^ (K - 1);
+            if (p > r) { const T x = a[r], y = a[p]; const bool sw = y < x; a[r] = sw ? y : x; a[p] = sw ? x : y; }
+        }
+    } else if constexpr (K <= 64 * IPT) {
+        // partner: lane ^ (K / IPT - 1), register IPT - 1 - r; lanes whose top bit of that mask is clear keep the smaller composite
+        constexpr int M = K / IPT - 1, TOP = K / IPT / 2;
+        const bool upper = (lane & (uint32_t)TOP) != 0u;
+#pragma unroll
+        for (int r = 0; r < IPT / 2; r++) {                                      // registers r and IPT - 1 - r trade partners
+            constexpr int dummy = 0; (void)dummy;
+            const int q = IPT - 1 - r;
+            const T br = sgr_xlane_t<M, T>(a[q]), bq = sgr_xlane_t<M, T>(a[r]);
+            if constexpr (sizeof(T) == 8) { a[r] = ((br < a[r]) != upper) ? br : a[r]; a[q] = ((bq < a[q]) != upper) ? bq : a[q]; }
+            else {
+                const T mnr = br < a[r] ? br : a[r], mxr = br < a[r] ? a[r] : br, mnq = bq < a[q] ? bq : a[q], mxq = bq < a[q] ? a[q] : bq;
+                a[r] = upper ? mxr : mnr; a[q] = upper ? mxq : mnq;
+            }
+        }
+    }
+}
+
+template <typename T, int IPT, int J>
+__device__ __forceinline__ void sgr_bitonic_shift(T (&a)[IPT], uint32_t lane) {
+    if constexpr (J < IPT) {
+#pragma unroll
+        for (int r = 0; r < IPT; r++)
+            if ((r & J) == 0) { const T x = a[r], y = a[r | J]; const bool sw = y < x; a[r] = sw ? y : x; a[r | J] = sw ? x : y; }
+    } else if constexpr (J < 64 * IPT) {
+#pragma unroll
+        for (int r = 0; r < IPT; r++) a[r] = sgr_cex_lane<J / IPT, J / IPT, T>(a[r], lane);
+    }
+}
+
+template <typename T, int IPT>
+__device__ __forceinline__ void sgr_stage_flip(T (&a)[IPT], uint32_t lane, int K) {
+    switch (K) {
+        case 2: sgr_bitonic_flip<T, IPT, 2>(a, lane); break;
+        case 4: sgr_bitonic_flip<T, IPT, 4>(a, lane); break;
+        case 8: sgr_bitonic_flip<T, IPT, 8>(a, lane); break;
+        case 16: sgr_bitonic_flip<T, IPT, 16>(a, lane); break;
+        case 32: sgr_bitonic_flip<T, IPT, 32>(a, lane); break;
+        case 64: sgr_bitonic_flip<T, IPT, 64>(a, lane); break;
+        case 128: sgr_bitonic_flip<T, IPT, 128>(a, lane); break;
+        case 256: sgr_bitonic_flip<T, IPT, 256>(a, lane); break;
+        case 512: sgr_bitonic_flip<T, IPT, 512>(a, lane); break;
+        default: sgr_bitonic_flip<T, IPT, 1024>(a, lane); break;
+    }
+}
+template <typename T, int IPT>
+__device__ __forceinline__ void sgr_stage_shift(T (&a)[IPT], uint32_t lane, int J) {
+    switch (J) {
+        case 1: sgr_bitonic_shift<T, IPT, 1>(a, lane); break;
+        case 2: sgr_bitonic_shift<T, IPT, 2>(a, lane); break;
+        case 4: sgr_bitonic_shift<T, IPT, 4>(a, lane); break;
+        case 8: sgr_bitonic_shift<T, IPT, 8>(a, lane); break;
+        case 16: sgr_bitonic_shift<T, IPT, 16>(a, lane); break;
+        case 32: sgr_bitonic_shift<T, IPT, 32>(a, lane); break;
+        case 64: sgr_bitonic_shift<T, IPT, 64>(a, lane); break;
+        case 128: sgr_bitonic_shift<T, IPT, 128>(a, lane); break;
+        case 256: sgr_bitonic_shift<T, IPT, 256>(a, lane); break;
+        default: sgr_bitonic_shift<T, IPT, 512>(a, lane); break;
+    }
+}
+
+// all shift steps of one wave's 64 * IPT elements (the tail of a merge level whose upper steps ran across waves)
+template <typename T, int IPT>
+__device__ __forceinline__ void sgr_local_shifts(T (&a)[IPT], uint32_t lane, int j_from) {
+#pragma nounroll
+    for (int j = j_from; j >= 1; j >>= 1) sgr_stage_shift<T, IPT>(a, lane, j);
+}
+
+// `nw` waves (a sub-group of the workgroup, nw a RUNTIME power of two) sort nw * 64 * IPT composites: wave `sub` holds elements
+// [sub * 64 * IPT, (sub + 1) * 64 * IPT) in registers; merge steps whose partner distance reaches into another wave exchange whole
+// register sets through LDS (gx: [nw][IPT * 64] composites, stored register-major so that lanes hit consecutive banks): flip = partner
+// wave sub ^ (K / (64 IPT) - 1), mirrored position; shift = partner wave sub ^ (j / (64 IPT)), same position; the lower wave keeps the
+// smaller composite.  ONE call site per stage kind for all modes, so the code exists once whatever nw is (the instruction cache holds
+// 64 KB for two CUs; three inlined copies of the IPT = 16 network made the unified kernel twice as slow as its parts).
+// Every wave of the WORKGROUP executes the same number of __syncthreads() for a given nw, whatever its tile holds.
+template <typename T, int IPT>
+__device__ __forceinline__ void sgr_bitonic_sort_group(T (&a)[IPT], uint32_t lane, uint32_t sub, int nw, T *gx) {
+    static_assert(IPT <= 16, "one wave sorts at most 1024 composites; longer tiles use several waves");
+    constexpr int WAVE_ELEMS = 64 * IPT;
+    T *mine = gx + sub * (uint32_t)WAVE_ELEMS;
+    const int Kmax = WAVE_ELEMS * nw;
+#pragma nounroll
+    for (int K = 2; K <= Kmax; K <<= 1) {
+        // one merge level: the flip (partner e ^ (K - 1)), then shifts (partner e ^ j) for j = K/4, K/8, .., 1
+#pragma nounroll
+        for (int step = 0;; step++) {
+            const bool first = step == 0;
+            const int j = first ? 0 : (K >> 1) >> step;
+            if (!first && j < 1) break;
+            const bool cross = first ? (K > WAVE_ELEMS) : (j >= WAVE_ELEMS);
+            if (cross) {
+                // ---- partner in another wave of the sub-group
+                const int jw = first ? (K / WAVE_ELEMS - 1) : (j / WAVE_ELEMS);
+                const int top = first ? (K / WAVE_ELEMS) >> 1 : jw;
+                const T *theirs = gx + (sub ^ (uint32_t)jw) * (uint32_t)WAVE_ELEMS;
+                __syncthreads();                                                 // everyone is done reading the previous exchange
+#pragma unroll
+                for (int r = 0; r < IPT; r++) mine[r * 64 + lane] = a[r];
+                __syncthreads();
+                const bool upper = (sub & (uint32_t)top) != 0u;
+#pragma unroll
+                for (int r = 0; r < IPT; r++) {
+                    const T b = first ? theirs[(IPT - 1 - r) * 64 + (63 - lane)] : theirs[r * 64 + lane];
+                    a[r] = ((b < a[r]) != upper) ? b : a[r];
+                }
+            } else if (first) {
+                sgr_stage_flip<T, IPT>(a, lane, K);
+            } else {
+                sgr_stage_shift<T, IPT>(a, lane, j);
+            }
+        }
+    }
+}
+
+// after the sort, element e sits in lane e / IPT, register e % IPT: a lane would store IPT consecutive entries (64 partial lines per
+// store instruction).  One trip through LDS (row stride IPT + 1: conflict-free both ways) re-deals the elements as e = r * 64 + lane,
+// so that every global store of the caller is one contiguous run across the wave.  tb: this wave's 64 * (IPT + 1) composites.
+template <typename T, int IPT>
+__device__ __forceinline__ void sgr_redeal_coalesced(T (&a)[IPT], uint32_t lane, T *tb) {
+#pragma unroll
+    for (int r = 0; r < IPT; r++) tb[lane * (IPT + 1) + r] = a[r];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int r = 0; r < IPT; r++) a[r] = tb[((uint32_t)r * (64u / IPT) + lane / IPT) * (IPT + 1) + lane % IPT];
+}
+
+// 64-bit composites (depth bits << 32 | value).  n == 0: nothing is read or written, the network runs on padding (barrier parity).
+// gx: the sub-group's [nw][64 * 17] composites of LDS.
+template <int IPT>
+__device__ __forceinline__ void sgr_sort_tile_regs64(const uint64_t *__restrict__ gk, const uint32_t *__restrict__ gv, uint64_t *__restrict__ ok,
+                                                     uint32_t *__restrict__ ov, uint32_t n, uint32_t lane, uint32_t sub, int nw, uint64_t *gx) {
+    uint64_t a[IPT];
+    const uint32_t hi = n ? (uint32_t)(gk[0] >> 32) : 0u;                      // tile id, identical for the whole segment
+    const uint32_t wbase = sub * (64u * IPT);
+#pragma unroll
+    for (int r = 0; r < IPT; r++) {                                            // coalesced; the input order is irrelevant to the result
+        const uint32_t k = wbase + (uint32_t)r * 64u + lane;
+        a[r] = k < n ? (((uint64_t)(uint32_t)gk[k] << 32) | gv[k]) : ~0ull;
+    }
+    sgr_bitonic_sort_group<uint64_t, IPT>(a, lane, sub, nw, gx);
+    if (nw > 1) __syncthreads();                                               // the other waves are done with the last exchange
+    sgr_redeal_coalesced<uint64_t, IPT>(a, lane, gx + sub * (64u * 17u));
+#pragma unroll
+    for (int r = 0; r < IPT; r++) {
+        const uint32_t e = wbase + (uint32_t)r * 64u + lane;
+        if (e < n) { ok[e] = ((uint64_t)hi << 32) | (a[r] >> 32); ov[e] = (uint32_t)a[r]; }
+    }
+}
+
+// ONE launch for every tile of <= NW * 1024 entries: a fixed grid of NW-wave workgroups drains the worklists class by class, longest
+// tiles first: class m (tiles of <= 1024 << m entries) is sorted by sub-groups of 2^m waves, NW >> m tiles per workgroup at a time.
+// (Separate launches per class cost a ramp-up and a tail each -- with four classes that was more than the sorting itself at C3.)
+// Tickets are drawn for a workgroup's worth of tiles at a time (and four rounds' worth for the single-wave class): returning atomics
+// on one address complete one every ~9 ns on this part, so one ticket per tile made the 41 000 short tiles of C4 a 0.37 ms serial section.
+struct TileWork4 { TileWork w[5]; };        // [m]: tiles with <= 1024 << m entries
+
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void tile_sort_regs_kernel(const uint2 *__restrict__ ranges, const uint64_t *__restrict__ src_keys,
+                                                                 const uint32_t *__restrict__ src_vals, uint64_t *__restrict__ dst_keys,
+                                                                 uint32_t *__restrict__ dst_vals, TileWork4 tw, int m_hi, int m_lo) {
+    __shared__ uint64_t xbuf[NW * 64 * 17];                                      // per wave 64 x (16 + 1) composites: exchange + final re-deal
+    __shared__ uint32_t s_item;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+#pragma nounroll
+    for (int m = m_hi; m >= m_lo; m--) {
+        const int nw = 1 << m;
+        const uint32_t groups = (uint32_t)(NW >> m), grp = wave >> m, sub = wave & (uint32_t)(nw - 1);
+        const uint32_t rounds = m == 0 ? 4u : 1u;
+        const TileWork w = tw.w[m];
+        const uint32_t nwork = *w.count;
+        uint64_t *gx = xbuf + grp * (uint32_t)(nw * 64 * 17);
+        for (;;) {
+            __syncthreads();
+            if (threadIdx.x == 0) s_item = atomicAdd(w.ticket, groups * rounds);
+            __syncthreads();
+            const uint32_t w0 = s_item;
+            if (w0 >= nwork) break;                                              // workgroup-uniform
+#pragma nounroll
+            for (uint32_t rd = 0; rd < rounds; rd++) {
+                const uint32_t wi = w0 + rd * groups + grp;
+                uint2 range = make_uint2(0u, 0u);
+                if (wi < nwork) range = ranges[w.list[wi]];
+                const uint32_t n = range.y - range.x;
+                if (m == 0 && n <= 256u) {                                       // (single-wave class: no workgroup barriers inside the sort)
+                    if (n) sgr_sort_tile_regs64<4>(src_keys + range.x, src_vals + range.x, dst_keys + range.x, dst_vals + range.x, n, lane, 0u, 1, gx);
+                } else {
+                    sgr_sort_tile_regs64<16>(src_keys + range.x, src_vals + range.x, dst_keys + range.x, dst_vals + range.x, n, lane, sub, nw, gx);
+                }
+            }
+        }
+    }
+}
+
+// ---- F4 + F5, VIEW-SEGMENTED flavour for multi-view batches and large launches -----------------------------------
+// The emission is view-major (duplicate_keys: blockIdx.y = view, offsets from the scan of the per-block counts), so the view bits of
+// the key are sorted before the sort starts: what remains is, per view, a sort by (tile-in-view, depth).  ONE stable counting pass per
+// view over the tile id (<= 4096 tiles per view: 1024^2 images) puts every tile's instances into one contiguous segment, still in
+// emission order, and yields the tile ranges (F5) and the worklist of occupied tiles as by-products of its scan; the depth bits are
+// then sorted per tile in LDS (tile_sort_dyn_kernel).  Per key: 8 B (histogram) + 24 B (scatter) + 24 B (per-tile sort) of HBM
+// traffic instead of 6-7 whole-key passes of 32 B.
+//   vseg_view_totals -> vseg_plan   per-view key ranges from the per-block emission counts; the keys are cut into CHUNKS of
+//                                   256 * ITEMS keys that never straddle a view: chunk_map[c] = (view, first key, count)
+//   vseg_upsweep                    per-chunk tile histogram, hist[c][tile]
+//   vseg_scan (one workgroup/view)  hist[c][tile] <- keys of that tile in earlier chunks of the view; tile totals -> ranges, worklists
+//   vseg_downsweep                  stable scatter: every wave owns a contiguous quarter of the chunk, positions from per-(wave, tile)
+//                                   running counters in LDS -- three workgroup barriers per chunk instead of three per 256 keys
+// All sizes come from device memory (sync-free mode: the host only knows the capacity).
+struct VsegPlan { uint32_t n_chunks, pad[7], count[8], ticket[8]; };      // worklists by tile size: <= 1024, <= 2048, <= 4096, <= 8192, <= 16384, longer
+constexpr int kVsegMaxViews = 4096, kVsegMaxBins = 4096;
+
+__global__ __launch_bounds__(kThreads) void vseg_view_totals_kernel(const uint32_t *__restrict__ sums, uint32_t nbx,
+                                                                    unsigned long long *__restrict__ view_total) {
+    __shared__ unsigned long long red[4];
+    const uint32_t *row = sums + (size_t)blockIdx.x * nbx;
+    unsigned long long acc = 0;
+    for (uint32_t k = threadIdx.x; k < nbx; k += kThreads) acc += row[k];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) view_total[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// one workgroup of 1024 threads; n_views <= 4096
+__global__ __launch_bounds__(1024) void vseg_plan_kernel(const unsigned long long *__restrict__ view_total, uint32_t n_views, uint32_t cap,
+                                                         const uint64_t *__restrict__ n_dev, uint32_t chunk_keys, uint32_t max_chunks,
+                                                         VsegPlan *__restrict__ plan, uint32_t *__restrict__ view_key_start,
+                                                         uint32_t *__restrict__ view_chunk_start, uint4 *__restrict__ chunk_map) {
+    __shared__ uint32_t s_key[kVsegMaxViews + 1], s_chunk[kVsegMaxViews + 1];
+    __shared__ unsigned long long s_wave[16];
+    __shared__ uint32_t s_wave32[16];
+    const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const unsigned long long n_true = n_dev ? min((unsigned long long)cap, (unsigned long long)*n_dev) : (unsigned long long)cap;
+    // ---- exclusive scan of the view totals (4 consecutive views per thread), clamped to the keys that exist in the buffers
+    unsigned long long tot[4], sum = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) { const uint32_t v = t * 4 + j; tot[j] = v < n_views ? view_total[v] : 0ull; sum += tot[j]; }
+    unsigned long long inc = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const unsigned long long nb = __shfl_up(inc, off, 64); if (lane >= (uint32_t)off) inc += nb; }
+    if (lane == 63) s_wave[wave] = inc;
+    __syncthreads();
+    unsigned long long run = inc - sum;
+    for (uint32_t w = 0; w < wave; w++) run += s_wave[w];
+    uint32_t nch[4], csum = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const uint32_t v = t * 4 + j;
+        const unsigned long long a = min(run, n_true), b = min(run + tot[j], n_true);
+        run += tot[j];
+        nch[j] = (uint32_t)((b - a + chunk_keys - 1) / chunk_keys);
+        csum += nch[j];
+        if (v < n_views) s_key[v] = (uint32_t)a;
+        if (v + 1 == n_views) s_key[n_views] = (uint32_t)b;
+    }
+    uint32_t cinc = csum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const uint32_t nb = __shfl_up(cinc, off, 64); if (lane >= (uint32_t)off) cinc += nb; }
+    if (lane == 63) s_wave32[wave] = cinc;
+    __syncthreads();
+    uint32_t crun = cinc - csum;
+    for (uint32_t w = 0; w < wave; w++) crun += s_wave32[w];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const uint32_t v = t * 4 + j;
+        if (v < n_views) s_chunk[v] = crun;
+        crun += nch[j];
+        if (v + 1 == n_views) s_chunk[n_views] = crun;
+    }
+    __syncthreads();
+    const uint32_t n_chunks = min(s_chunk[n_views], max_chunks);
+    if (t == 0) plan->n_chunks = n_chunks;
+    if (t < 8) { plan->count[t] = 0; plan->ticket[t] = 0; }
+    for (uint32_t v = t; v <= n_views; v += 1024) { view_key_start[v] = s_key[v]; view_chunk_start[v] = min(s_chunk[v], max_chunks); }
+    // ---- chunk map: chunk c belongs to the last view whose first chunk is <= c
+    for (uint32_t c = t; c < n_chunks; c += 1024) {
+        uint32_t lo = 0, hi = n_views;                       // invariant: s_chunk[lo] <= c < s_chunk[hi]
+        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (s_chunk[mid] <= c) lo = mid; else hi = mid; }
+        const uint32_t k0 = s_key[lo] + (c - s_chunk[lo]) * chunk_keys;
+        chunk_map[c] = make_uint4(lo, k0, min(chunk_keys, s_key[lo + 1] - k0), 0u);
+    }
+}
+
+template <int ITEMS>
+__global__ __launch_bounds__(kThreads) void vseg_upsweep_kernel(const uint64_t *__restrict__ keys, const VsegPlan *__restrict__ plan,
+                                                                const uint4 *__restrict__ chunk_map, uint32_t tiles_per_view,
+                                                                uint32_t *__restrict__ hist) {
+    __shared__ uint32_t h[kVsegMaxBins];
+    const uint32_t c = blockIdx.x;
+    if (c >= plan->n_chunks) return;
+    const uint4 cm = chunk_map[c];
+    for (uint32_t d = threadIdx.x; d < tiles_per_view; d += kThreads) h[d] = 0;
+    __syncthreads();
+    const uint32_t tbase = cm.x * tiles_per_view;
+#pragma unroll
+    for (int it = 0; it < ITEMS; it++) {
+        const uint32_t k = it * kThreads + threadIdx.x;
+        if (k < cm.z) atomicAdd(&h[(uint32_t)(keys[cm.y + k] >> 32) - tbase], 1u);
+    }
+    __syncthreads();
+    uint32_t *out = hist + (size_t)c * tiles_per_view;
+    for (uint32_t d = threadIdx.x; d < tiles_per_view; d += kThreads) out[d] = h[d];
+}
+
+// column scan: workgroup (view, slab of 256 tiles): per tile, exclusive prefix over the view's chunks (in place) and the tile total
+__global__ __launch_bounds__(kThreads) void vseg_colscan_kernel(uint32_t *__restrict__ hist, const uint32_t *__restrict__ view_chunk_start,
+                                                                uint32_t tiles_per_view, uint32_t *__restrict__ tile_total) {
+    const uint32_t v = blockIdx.y, d = blockIdx.x * kThreads + threadIdx.x;
+    if (d >= tiles_per_view) return;
+    const uint32_t c0 = view_chunk_start[v], c1 = view_chunk_start[v + 1];
+    uint32_t *col = hist + (size_t)c0 * tiles_per_view + d;
+    uint32_t run = 0, c = c0;
+    for (; c + 8 <= c1; c += 8, col += 8 * (size_t)tiles_per_view) {          // 8 independent loads in flight per thread
+        uint32_t x[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) x[j] = col[(size_t)j * tiles_per_view];
+#pragma unroll
+        for (int j = 0; j < 8; j++) { col[(size_t)j * tiles_per_view] = run; run += x[j]; }
+    }
+    for (; c < c1; c++, col += tiles_per_view) { const uint32_t x = *col; *col = run; run += x; }
+    tile_total[(size_t)v * tiles_per_view + d] = run;
+}
+
+// one workgroup (1024 threads) per view: exclusive scan of the tile totals in tile order -> ranges (F5) + the worklists of occupied
+// tiles by size class for the per-tile depth sort
+__global__ __launch_bounds__(1024) void vseg_scan_kernel(const uint32_t *__restrict__ tile_total, const uint32_t *__restrict__ view_key_start,
+                                                         uint32_t tiles_per_view, uint2 *__restrict__ ranges, VsegPlan *__restrict__ plan,
+                                                         uint32_t *__restrict__ lists /*[6][tiles_total]: one worklist per size class*/, uint32_t tiles_total) {
+    __shared__ uint32_t s_wave[16];
+    __shared__ uint32_t s_carry, s_cnt[8], s_base[8];
+    const uint32_t v = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    if (t == 0) s_carry = view_key_start[v];
+    for (uint32_t d0 = 0; d0 < tiles_per_view; d0 += 1024) {
+        const uint32_t d = d0 + t;
+        const uint32_t run = d < tiles_per_view ? tile_total[(size_t)v * tiles_per_view + d] : 0u;
+        uint32_t inc = run;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const uint32_t nb = __shfl_up(inc, off, 64); if (lane >= (uint32_t)off) inc += nb; }
+        if (lane == 63) s_wave[wave] = inc;
+        __syncthreads();
+        uint32_t start = s_carry + inc - run;
+        uint32_t all = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < 16; w++) { const uint32_t x = s_wave[w]; if (w < wave) start += x; all += x; }
+        // worklists: ranks inside the workgroup from LDS counters, ONE global atomic per class and 1024 tiles (a returning global atomic
+        // per tile serialises on four addresses: 52 000 of them cost 0.46 ms at C4)
+        if (t < 8) s_cnt[t] = 0;
+        __syncthreads();
+        uint32_t cls = 8, local = 0;
+        if (d < tiles_per_view) {
+            ranges[v * tiles_per_view + d] = run ? make_uint2(start, start + run) : make_uint2(0u, 0u);
+            if (run) {                                                   // (single-key tiles too: the sort kernel moves them to the destination buffer)
+                cls = run <= 1024u ? 0u : (run <= 2048u ? 1u : (run <= 4096u ? 2u : (run <= 8192u ? 3u : (run <= 16384u ? 4u : 5u))));
+                local = atomicAdd(&s_cnt[cls], 1u);
+            }
+        }
+        __syncthreads();
+        if (t < 8 && s_cnt[t]) s_base[t] = atomicAdd(&plan->count[t], s_cnt[t]);
+        __syncthreads();
+        if (cls < 8) lists[(size_t)cls * tiles_total + s_base[cls] + local] = v * tiles_per_view + d;
+        __syncthreads();
+        if (t == 0) s_carry += all;
+        __syncthreads();
+    }
+}
+
+template <int MAXB, int ITEMS>
+__global__ __launch_bounds__(kThreads) void vseg_downsweep_kernel(const uint64_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
+                                                                  uint64_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out,
+                                                                  const VsegPlan *__restrict__ plan, const uint4 *__restrict__ chunk_map,
+                                                                  uint32_t tiles_per_view, const uint32_t *__restrict__ hist,
+                                                                  const uint2 *__restrict__ ranges) {
+    __shared__ uint32_t pos[4][MAXB];                 // phase 1: per-wave tile histogram; phase 3: next output position per (wave, tile)
+    const uint32_t c = blockIdx.x;
+    if (c >= plan->n_chunks) return;
+    const uint4 cm = chunk_map[c];
+    const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    for (uint32_t d = t; d < tiles_per_view; d += kThreads) { pos[0][d] = 0; pos[1][d] = 0; pos[2][d] = 0; pos[3][d] = 0; }
+    __syncthreads();
+    const uint32_t tbase = cm.x * tiles_per_view;
+    // wave w owns keys [w * 64 * ITEMS, (w + 1) * 64 * ITEMS) of the chunk, consumed 64 at a time in memory order.
+    // (straight-line code on purpose: clamped loads + validity predicates instead of branches; with conditional loads and an early exit
+    // in the unrolled loop the compiler produced 436 VGPRs of copies)
+    uint64_t key[ITEMS];
+    uint32_t val[ITEMS];
+    const uint32_t wbase = wave * (64 * ITEMS);
+    const uint32_t last = cm.z - 1u;                             // (cm.z >= 1 for every mapped chunk)
+#pragma unroll
+    for (int it = 0; it < ITEMS; it++) {
+        const uint32_t k = min(wbase + it * 64 + lane, last);
+        key[it] = keys_in[cm.y + k]; val[it] = vals_in[cm.y + k];
+    }
+#pragma unroll
+    for (int it = 0; it < ITEMS; it++) {
+        const uint32_t k = wbase + it * 64 + lane;
+        if (k < cm.z) atomicAdd(&pos[wave][(uint32_t)(key[it] >> 32) - tbase], 1u);
+    }
+    __syncthreads();
+    const uint32_t *hrow = hist + (size_t)c * tiles_per_view;
+    for (uint32_t d = t; d < tiles_per_view; d += kThreads) {
+        const uint32_t h0 = pos[0][d], h1 = pos[1][d], h2 = pos[2][d];
+        const uint32_t g = ranges[tbase + d].x + hrow[d];        // first output slot of this chunk's keys of tile d
+        pos[0][d] = g; pos[1][d] = g + h0; pos[2][d] = g + h0 + h1; pos[3][d] = g + h0 + h1 + h2;
+    }
+    __syncthreads();
+    const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    uint32_t *mypos = pos[wave];
+#pragma unroll
+    for (int it = 0; it < ITEMS; it++) {
+        const uint32_t k = wbase + it * 64 + lane;
+        const bool valid = k < cm.z;
+        const uint32_t d = (uint32_t)(key[it] >> 32) - tbase;
+        uint64_t peers = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 12; b++) {
+            if ((1u << b) >= (uint32_t)MAXB) break;
+            const bool bit = (d >> b) & 1;
+            const uint64_t m = __ballot(bit);
+            peers &= bit ? m : ~m;
+        }
+        const uint32_t rank = (uint32_t)__popcll(peers & lt_mask);
+        // the leader of every group of equal tiles moves the tile's counter on with one returning LDS atomic (a wave's LDS atomics
+        // execute in program order: later steps get later slots) and hands the old value to its group
+        uint32_t old = 0;
+        if (valid && rank == 0) old = atomicAdd(&mypos[d], (uint32_t)__popcll(peers));
+        const uint32_t base = (uint32_t)__shfl((int)old, valid ? __builtin_ctzll(peers) : 0, 64);
+        if (valid) { keys_out[base + rank] = key[it]; vals_out[base + rank] = val[it]; }
     }
 }
 
@@ -725,9 +1258,28 @@ __global__ __launch_bounds__(kThreads) void tile_ranges_kernel(const uint64_t *_
     if (append_all && first) worklist[1 + atomicAdd(&worklist[0], 1u)] = tile;
 }
 
-// 3 = automatic (default, by instance count: measured crossovers on MI355X), 2 = segmented (tile bits globally, depth bits per tile in LDS),
-// 0 = onesweep, 1 = three kernels per pass
+// 3 = automatic (default), 4 = view-segmented (per-view tile pass + per-tile depth sort), 2 = segmented (global passes over the tile bits,
+// depth bits per tile in LDS), 0 = onesweep, 1 = three kernels per pass
 int sgr_sort_mode = 3;
+
+struct VsegLayout { size_t plan, totals, key_start, chunk_start, chunk_map, hist, tile_total, lists, end; uint32_t chunk_keys, max_chunks; };
+inline VsegLayout vseg_layout(uint64_t R, uint64_t tiles_total, uint32_t n_views, uint32_t tiles_per_view) {
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    VsegLayout L;
+    L.chunk_keys = tiles_per_view > 1024 ? 8192u : 4096u;                    // = 256 * ITEMS of the kernels instantiated below
+    L.max_chunks = (uint32_t)(R / L.chunk_keys + n_views + 1);
+    size_t o = 0;
+    L.plan = o; o = al(o + sizeof(VsegPlan));
+    L.totals = o; o = al(o + (size_t)n_views * 8);
+    L.key_start = o; o = al(o + ((size_t)n_views + 1) * 4);
+    L.chunk_start = o; o = al(o + ((size_t)n_views + 1) * 4);
+    L.chunk_map = o; o = al(o + (size_t)L.max_chunks * 16);
+    L.hist = o; o = al(o + (size_t)L.max_chunks * tiles_per_view * 4);
+    L.tile_total = o; o = al(o + (size_t)tiles_total * 4);
+    L.lists = o; o = al(o + (size_t)tiles_total * 4 * 6);
+    L.end = o;
+    return L;
+}
 
 inline int bits_for(uint64_t v) { int b = 0; while ((1ull << b) < v) b++; return b; }   // smallest b with 2^b >= v
 
@@ -740,8 +1292,10 @@ extern "C" int sgr_set_sort_mode(int mode) { sgr_sort_mode = mode; return 0; }
 extern "C" size_t sgr_bin_workspace_bytes(uint64_t R, uint64_t tiles_total) {
     const uint64_t nblocks = (R + kThreads * kItemsSmall - 1) / (kThreads * kItemsSmall);
     // onesweep: [ghist 8x256][tickets 8][err][pad] + status [8 passes][tiles][256]; three-kernel path: [hist tiles x 256][totals 256]
+    // + [worklist 64 + tiles] of the segmented flavour; the view-segmented flavour lays its plan / chunk map / histograms / two worklists
+    // over the whole area from the start (<= 2 R + R / 256 + 80 B per tile + 64 KB: see vseg_layout)
     return (size_t)((kMaxPasses * (nblocks > 0 ? nblocks : 1) + kMaxPasses + 2) * kRadix * sizeof(uint32_t) + 1024 +
-                    (tiles_total ? (tiles_total + 64) * sizeof(uint32_t) : 0));
+                    (tiles_total ? (tiles_total + 64) * sizeof(uint32_t) + tiles_total * 128 + 65536 : 0));
 }
 
 // self_scan: the caller skipped the F2 scan kernel (sgr_preprocess_forward_ex) and block_offsets + n + 1 holds the un-scanned
@@ -799,7 +1353,57 @@ int sgr_bin_ex(const SgrProblem *pb, float *rec, const int32_t *radii, const uin
     // sort flavour: 2 (default) = tile bits globally + depth bits per tile in LDS; 0 = onesweep over the whole key; 1 = three kernels
     // automatic: segmented up to 2^19 instances (one 512^2 view: 74 vs 82 vs 100 us), three-kernel up to 2^23 (16 views: 285 vs
     // 323 vs 360 us), onesweep beyond (64 views: 1041 vs 1176 vs 1186 us; 90 views at 1024^2: 3.57 vs 3.82 vs 3.87 ms)
-    const int mode = sgr_sort_mode != 3 ? sgr_sort_mode : (R <= (1ull << 19) ? 2 : (R <= (1ull << 23) ? 1 : 0));
+    // automatic: one or two 512^2 views (<= 2048 tiles, <= 2^19 instances): segmented with the single wide tile pass (74 vs 82 vs 100 us
+    // at C2); everything else with <= 4096 tiles per view: view-segmented; beyond that the whole-key passes
+    const uint32_t tpv = (uint32_t)Tx * (uint32_t)Ty;
+    const VsegLayout VL = vseg_layout(R, tiles_total, (uint32_t)pb->n_views, tpv);
+    const bool vseg_ok = tpv <= (uint32_t)kVsegMaxBins && pb->n_views <= kVsegMaxViews && VL.end <= workspace_bytes;
+    int mode = sgr_sort_mode;
+    // (launches whose tile lists are deep on average -- C5: 1M Gaussians on 1024 tiles -- would sort most tiles through global memory in
+    // the per-tile step: those keep the whole-key passes)
+    const bool deep = R > tiles_total * 1024ull;
+    if (mode == 3) mode = (R <= (1ull << 19) && tiles_total <= 2048) ? 2 : ((vseg_ok && !deep) ? 4 : (R <= (1ull << 23) ? 1 : 0));
+    if (mode == 4 && !vseg_ok) mode = R <= (1ull << 23) ? 1 : 0;
+    if (mode == 4) {
+        char *ws = (char *)workspace;
+        VsegPlan *plan = (VsegPlan *)(ws + VL.plan);
+        unsigned long long *totals = (unsigned long long *)(ws + VL.totals);
+        uint32_t *key_start = (uint32_t *)(ws + VL.key_start), *chunk_start = (uint32_t *)(ws + VL.chunk_start);
+        uint4 *chunk_map = (uint4 *)(ws + VL.chunk_map);
+        uint32_t *vhist = (uint32_t *)(ws + VL.hist), *tile_total = (uint32_t *)(ws + VL.tile_total), *lists = (uint32_t *)(ws + VL.lists);
+        const uint32_t nblk = (uint32_t)nbx * (uint32_t)pb->n_views;
+        const uint32_t *sums = block_offsets + (nblk + 1);                   // un-scanned per-block emission counts, [view][block]
+        { SgrProfScope _ps(SGR_K_SORT, stream);
+        hipLaunchKernelGGL(vseg_view_totals_kernel, dim3(pb->n_views), dim3(kThreads), 0, stream, sums, (uint32_t)nbx, totals);
+        hipLaunchKernelGGL(vseg_plan_kernel, dim3(1), dim3(1024), 0, stream, totals, (uint32_t)pb->n_views, n, num_rendered_dev, VL.chunk_keys,
+                           VL.max_chunks, plan, key_start, chunk_start, chunk_map);
+        if (VL.chunk_keys == 4096u) hipLaunchKernelGGL(vseg_upsweep_kernel<16>, dim3(VL.max_chunks), dim3(kThreads), 0, stream, kin, plan, chunk_map, tpv, vhist);
+        else hipLaunchKernelGGL(vseg_upsweep_kernel<32>, dim3(VL.max_chunks), dim3(kThreads), 0, stream, kin, plan, chunk_map, tpv, vhist);
+        hipLaunchKernelGGL(vseg_colscan_kernel, dim3((tpv + kThreads - 1) / kThreads, pb->n_views), dim3(kThreads), 0, stream, vhist, chunk_start, tpv, tile_total);
+        hipLaunchKernelGGL(vseg_scan_kernel, dim3(pb->n_views), dim3(1024), 0, stream, tile_total, key_start, tpv, (uint2 *)ranges, plan, lists,
+                           (uint32_t)tiles_total);
+        if (VL.chunk_keys == 4096u)
+            hipLaunchKernelGGL((vseg_downsweep_kernel<1024, 16>), dim3(VL.max_chunks), dim3(kThreads), 0, stream, kin, vin, kout, vout, plan, chunk_map,
+                               tpv, vhist, (const uint2 *)ranges);
+        else
+            hipLaunchKernelGGL((vseg_downsweep_kernel<4096, 32>), dim3(VL.max_chunks), dim3(kThreads), 0, stream, kin, vin, kout, vout, plan, chunk_map,
+                               tpv, vhist, (const uint2 *)ranges);
+        SGR_CHECK_LAUNCH("view-segmented tile pass");
+        // depth bits per tile: keys now sit tile-bucketed in (kout, vout); the sorted list goes back into (kin, vin)
+        auto work = [&](int cls) { TileWork w = {lists + (size_t)cls * tiles_total, &plan->ticket[cls], &plan->count[cls]}; return w; };
+        auto grid = [&](uint32_t per_cu) { const uint64_t g = (uint64_t)per_cu * 256u; return (uint32_t)(tiles_total < g ? tiles_total : g); };
+        // longest tiles first; tiles beyond the LDS capacity go through the global ping-pong buffers, a whole workgroup per tile
+        const uint2 *rg = (const uint2 *)ranges;
+        TileWork4 tw4;
+        for (int c = 0; c < 5; c++) tw4.w[c] = work(c);
+        // beyond 16384 entries: a whole workgroup per tile through the global ping-pong buffers; everything else in ONE launch
+        hipLaunchKernelGGL((tile_sort_dyn_kernel<1024, kSegCapLarge>), dim3(grid(1)), dim3(1024), 0, stream, rg, kout, vout, kin, vin, work(5));
+        hipLaunchKernelGGL(tile_sort_regs_kernel<16>, dim3(grid(1)), dim3(1024), 0, stream, rg, kout, vout, kin, vin, tw4, 4, 0);
+        SGR_CHECK_LAUNCH("tile_sort_dyn_kernel");
+        }
+        if (result_in_b_host) *result_in_b_host = (kin == keys_b) ? 1 : 0;
+        return 0;
+    }
     const bool segmented = mode == 2;
     if (segmented) {
         uint32_t *worklist = (uint32_t *)((char *)workspace + sgr_bin_workspace_bytes(R, 0));   // [1 + tiles_total] behind the radix scratch

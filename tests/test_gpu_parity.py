@@ -320,7 +320,7 @@ def test_no_buffer_leak_across_steps():
         gc.enable()
 
 
-@pytest.mark.parametrize("sort_mode", [0, 1, 2], ids=["onesweep", "three_kernel", "segmented"])
+@pytest.mark.parametrize("sort_mode", [0, 1, 2, 4], ids=["onesweep", "three_kernel", "segmented", "view_segmented"])
 @pytest.mark.parametrize("name", ["humanoid_20k_256", "c1_10k_256"])
 def test_sort_flavours_bit_exact(name, sort_mode, oracle):
     """Both radix-sort implementations must reproduce the oracle's sorted keys / point list bit for bit."""
@@ -344,6 +344,54 @@ def test_sort_flavours_bit_exact(name, sort_mode, oracle):
 
 
 _OBSERVED_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "full_size_observed.json")
+
+
+@pytest.mark.parametrize("sort_mode", [0, 1, 2, 4, 3], ids=["onesweep", "three_kernel", "segmented", "view_segmented", "automatic"])
+def test_sort_flavours_bit_exact_multiview(sort_mode, oracle):
+    """A 5-view batch (one view sees nothing: an empty key range in the middle of the emission) through every sort flavour, exact and
+    sync-free: sorted keys, point list and tile ranges must be the per-view oracle lists, concatenated in view order."""
+    from sigman_release_amd import _cabi
+    from sigman_release_amd import rasterizer as R
+    from sigman_release_amd import cameras
+    dev = _dev()
+    views = (30, 0, 30, 65, 85)
+    inp, st = cases.humanoid(P=30_000, H=304, W=272, seed=13, views=views)           # 19 x 17 = 323 tiles per view (not a power of two)
+    # view slot 2 looks away from the subject (camera behind it, same direction): nothing lands in its frustum
+    cv, cvp, cp = cameras.make_cameras(views)
+    away = cameras.rig_w2c(30).copy()
+    away[2, 3] = -2.5 - 3.0                                                         # subject 3 m BEHIND the camera
+    cv[2] = away.T
+    cvp[2] = (cv[2] @ cameras.projection_matrix().T).astype(np.float32)
+    st = dict(st, viewmatrix=cv, projmatrix=cvp, campos=cp)
+    tiles = ((272 + 15) // 16) * ((304 + 15) // 16)
+    P = inp["means3D"].shape[0]
+    keys, plist, ranges = [], [], []
+    off = 0
+    for v in range(len(views)):
+        r = oracle.forward(**inp, **cases.single_view(st, v), render=False)
+        keys.append(r.keys + (np.uint64(v * tiles) << np.uint64(32)))
+        plist.append(r.point_list.astype(np.uint32) + np.uint32(v * P))
+        rg = r.ranges.astype(np.uint32).copy()
+        occ = rg[:, 1] > rg[:, 0]
+        rg[occ] += np.uint32(off)
+        ranges.append(rg)
+        off += r.R
+        if v == 2:
+            assert r.R == 0
+    keys, plist, ranges = np.concatenate(keys), np.concatenate(plist), np.stack(ranges)
+    d = _to_dev(inp, dev)
+    _cabi.lib().sgr_set_sort_mode(sort_mode)
+    try:
+        for cap in (0, off + 777):
+            out = R.forward_debug(d["means3D"][None], d["opacities"][None], colors_precomp=d["colors_precomp"][None],
+                                  cov3D_precomp=d["cov3D_precomp"][None], settings=_batched_settings(st, dev, len(views))._replace(max_rendered=cap))
+            torch.cuda.synchronize()
+            assert out["num_rendered"] == off
+            np.testing.assert_array_equal(out["keys"].cpu().numpy().view(np.uint64), keys)
+            np.testing.assert_array_equal(out["point_list"].cpu().numpy().astype(np.uint32), plist)
+            np.testing.assert_array_equal(out["ranges"].cpu().numpy().astype(np.uint32), ranges)
+    finally:
+        _cabi.lib().sgr_set_sort_mode(3)
 
 
 def _check_against_observed(name, stats):
