@@ -97,7 +97,7 @@ typedef struct SgrForwardState {
     uint64_t R_alloc;            /* size of the binning buffers in tile instances: exact num_rendered, or the capacity */
     uint64_t true_rendered;      /* exact mode: num_rendered; sync-free mode: ~0 (read nr_pinned_host after nr_event) */
     uint64_t NS;                 /* bucket slots per quadrant */
-    int32_t with_aux, result_in_b, flags_cleared, _pad;
+    int32_t with_aux /* 0 none, 1 compact checkpoints, 2 row checkpoints */, result_in_b, flags_cleared, _pad;
     void *geom, *binning, *image;
     uint64_t geom_bytes, binning_bytes, image_bytes;
     uint64_t off_rec, off_rect, off_clamped, off_block_offsets, off_num_rendered;               /* in geom   */
@@ -196,13 +196,19 @@ uint64_t sgr_bucket_slots(uint64_t R, uint64_t tiles_total);
  * otherwise), 1 = serial, 2 = segment-parallel.  Both produce the same outputs. */
 int sgr_set_forward_mode(int mode);
 
+/* checkpoint layout of the auxiliary forward outputs: 0 = automatic (default: "rows" unless that allocation would exceed
+ * SIGMAN_AUX_ROWS_MAX_BYTES, 8 GiB if unset), 1 = compact, 2 = rows.  sgr_rasterize_forward records its choice in state->with_aux. */
+int sgr_set_aux_layout(int mode);
+
 /*
  * F6: per-tile front-to-back compositing.  out_color [n_views,3,H,W], out_depth [n_views,1,H,W],
  * out_alpha [n_views,1,H,W], final_T f32 [n_views,H,W], n_contrib u32 [n_views,H,W].
  * Optional auxiliary outputs for the bucket-parallel backward (pass all four or none; NS = sgr_bucket_slots(R, n_views*tiles)):
  *   aux_compact  u32 [4][R][2]   per (tile, 8x8 quadrant) culled list: (record id, index in the tile list)
- *   aux_ckpt_tc  f32 [4*NS][4][64][4], aux_ckpt_da f32 [4*NS][4][64][2]   per-pixel (T,C) / (D,A) before each 16-survivor row of each
- *                <=64-survivor bucket: T absolute; sums absolute on rows that start a forward segment, else relative to that row
+ *   aux_ckpt_tc  f32 [4*NS][rows][64][4], aux_ckpt_da f32 [4*NS][rows][64][2]   per-pixel (T,C) / (D,A) checkpoints of each <=64-survivor bucket.
+ *                Layout "rows" (rows = 4; default): one record before each 16-survivor row -- T absolute; sums absolute on rows that start a
+ *                forward segment, else relative to that row.  Layout "compact" (rows = 1): the absolute state before the bucket's first
+ *                survivor only; the backward rebuilds the inner rows (4x smaller, backward ~1.5x slower).  sgr_set_aux_layout chooses.
  *   aux_desc     u32 [4*NS][2]   bucket descriptors (tile | (rows per segment - 1) << 30, (start << 7) | count); zeroed by this call
  * aux_order (optional, u32 [1 + n_views*tiles]) receives the work order of the segment-parallel kernel (longest tile lists
  * first, empty tiles last); NULL = tiles in index order.

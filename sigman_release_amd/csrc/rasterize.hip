@@ -53,15 +53,16 @@ int sgr_render_backward_ex(const SgrProblem *pb, const uint32_t *ranges, const u
                            const uint32_t *n_contrib, const float *out_color, const float *out_depth, const float *out_alpha,
                            const float *grad_color, const float *grad_depth, const float *grad_alpha, const float *grad_color_scale,
                            uint64_t R, const void *aux_compact, const void *aux_ckpt_tc, const void *aux_ckpt_da, const void *aux_desc,
-                           float *grec, float *part, uint32_t *flags, bool flags_cleared, void *stream_);
+                           float *grec, float *part, uint32_t *flags, bool flags_cleared, int aux_layout, void *stream_);
 int sgr_preprocess_backward_ex(const SgrProblem *pb, const int32_t *radii, const uint8_t *clamped, const float *grec, const float *rec,
                                const float *part, const uint32_t *flags, uint64_t n_inst, float *dL_dmeans3D, float *dL_dmeans2D, float *dL_dopacity,
                                float *dL_dcolors, float *dL_dsh, float *dL_dcov3D, float *dL_dscales, float *dL_drotations, void *stream_);
 int sgr_render_forward_wants_prepare(const SgrProblem *pb, uint64_t R, bool use_aux, size_t *n_desc_out);
 int sgr_render_forward_ex(const SgrProblem *pb, const uint32_t *ranges, const uint32_t *point_list, const float *rec, float *out_color,
                           float *out_depth, float *out_alpha, float *final_T, uint32_t *n_contrib, uint64_t R, void *aux_compact,
-                          void *aux_ckpt_tc, void *aux_ckpt_da, void *aux_desc, uint32_t *aux_order, bool prepared, void *stream_);
+                          void *aux_ckpt_tc, void *aux_ckpt_da, void *aux_desc, uint32_t *aux_order, bool prepared, int aux_layout, void *stream_);
 int sgr_get_forward_mode();
+int sgr_aux_layout_for(uint64_t NS);
 
 // ROCm 7.2's hipGraph "packet capture" (pre-recorded AQL packets, on by default) is not safe next to large host<->device
 // copies issued by the same process: a few replays after e.g. a 5 MB pageable D2H copy the command processor faults
@@ -121,7 +122,7 @@ static int forward_launches(const SgrProblem *pb, uint64_t capacity, uint64_t R,
                               (float *)(image + st->off_final_T), (uint32_t *)(image + st->off_n_contrib), R,
                               aux_on ? image + st->off_compact : nullptr, aux_on ? image + st->off_ckpt_tc : nullptr,
                               aux_on ? image + st->off_ckpt_da : nullptr, aux_on ? image + st->off_desc : nullptr,
-                              (uint32_t *)(image + st->off_order), prep_done != 0, stream);
+                              (uint32_t *)(image + st->off_order), prep_done != 0, st->with_aux, stream);
 }
 
 extern "C" int sgr_rasterize_forward(const SgrProblem *pb, uint64_t capacity, int32_t with_aux, sgr_alloc_fn alloc, void *user,
@@ -195,7 +196,7 @@ extern "C" int sgr_rasterize_forward(const SgrProblem *pb, uint64_t capacity, in
     // ---- image blob
     const bool aux_on = with_aux && R > 0;
     const uint64_t NS = sgr_bucket_slots(R, tiles_total);
-    st->NS = NS; st->with_aux = aux_on ? 1 : 0;
+    st->NS = NS; st->with_aux = aux_on ? sgr_aux_layout_for(NS) : 0;       // 0 none, 1 compact checkpoints, 2 one checkpoint per 16-survivor row
     o = 0;
     st->off_ranges = o; o = align_up(o + tiles_total * 8);
     st->off_final_T = o; o = align_up(o + hw * 4);
@@ -204,8 +205,9 @@ extern "C" int sgr_rasterize_forward(const SgrProblem *pb, uint64_t capacity, in
     if (aux_on) {
         st->off_flags = o; o = align_up(o + R * 4);                // one byte per (tile instance, quadrant): partial record written by the backward
         st->off_compact = o; o = align_up(o + 4 * R * 8);
-        st->off_ckpt_tc = o; o = align_up(o + 4 * NS * 4 * 64 * 16);
-        st->off_ckpt_da = o; o = align_up(o + 4 * NS * 4 * 64 * 8);
+        const uint64_t rows = st->with_aux == 2 ? 4 : 1;                    // checkpoint records per pixel and 64-survivor bucket
+        st->off_ckpt_tc = o; o = align_up(o + 4 * NS * rows * 64 * 16);
+        st->off_ckpt_da = o; o = align_up(o + 4 * NS * rows * 64 * 8);
         st->off_desc = o; o = align_up(o + 4 * NS * 8);
     }
     st->image_bytes = o;
@@ -218,7 +220,7 @@ extern "C" int sgr_rasterize_forward(const SgrProblem *pb, uint64_t capacity, in
         std::lock_guard<std::mutex> graph_lock(g_graph_mu);
         FwdKey key;
         memset(&key, 0, sizeof(key));
-        key.pb = *pb; key.capacity = capacity; key.with_aux = with_aux; key.fwd_mode = sgr_get_forward_mode();
+        key.pb = *pb; key.capacity = capacity; key.with_aux = st->with_aux; key.fwd_mode = sgr_get_forward_mode();
         key.color = out_color; key.depth = out_depth; key.alpha = out_alpha; key.radii = out_radii; key.nr_host = nullptr;
         key.geom = geom; key.binning = binning; key.image = image; key.stream = nullptr;
         key.clear = caller_clear; key.clear_bytes = caller_clear_bytes;
@@ -300,7 +302,7 @@ extern "C" int sgr_rasterize_backward(const SgrProblem *pb, const SgrForwardStat
     if (sgr_render_backward_ex(pb, (const uint32_t *)(image + st->off_ranges), point_list, rec, (const float *)(image + st->off_final_T),
                             (const uint32_t *)(image + st->off_n_contrib), out_color, out_depth, out_alpha, grad_color, grad_depth,
                             grad_alpha, grad_color_scale, st->R_alloc, aux_on ? image + st->off_compact : nullptr, aux_on ? image + st->off_ckpt_tc : nullptr,
-                            aux_on ? image + st->off_ckpt_da : nullptr, aux_on ? image + st->off_desc : nullptr, grec, part, flags, st->flags_cleared != 0, stream_))
+                            aux_on ? image + st->off_ckpt_da : nullptr, aux_on ? image + st->off_desc : nullptr, grec, part, flags, st->flags_cleared != 0, st->with_aux, stream_))
         return 1;
     return sgr_preprocess_backward_ex(pb, radii, pb->shs ? (const uint8_t *)(geom + st->off_clamped) : nullptr, grec, rec, part, flags, st->R_alloc,
                                    dL_dmeans3D, dL_dmeans2D, dL_dopacity, dL_dcolors, dL_dsh, dL_dcov3D, dL_dscales, dL_drotations,

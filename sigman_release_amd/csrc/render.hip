@@ -47,14 +47,18 @@ __device__ __forceinline__ uint32_t cull_mask(const float4 &a, const float4 &c, 
 // auxiliary forward outputs that feed the bucket-parallel backward (all optional; see sgr_render_forward)
 struct FwdAux {
     uint2 *compact;       // [4][R]  per (tile, quadrant) culled list in order: (record id, 0-based index in the tile list)
-    float4 *ckpt_tc;      // [4*NS][4][64]  per bucket, per 16-survivor row, per pixel: (T, C0, C1, C2) before the row's first survivor.
-                          //                T is absolute.  With rps = rows per forward segment (1..4, in the descriptor): rows with
-                          //                r % rps == 0 start a segment and hold ABSOLUTE composited sums, the others hold the sums
-                          //                accumulated since their segment's start (row r - r % rps).  The row at ordinal 0 of a list
-                          //                is not stored (T = 1, sums = 0).
-    float2 *ckpt_da;      // [4*NS][4][64]  same for (D, A)
-    uint2 *desc;          // [4*NS]  (global tile id | (rps - 1) << 30, (start << 7) | count): `count` (<= 64) survivors starting at
-                          //          ordinal `start` (a multiple of 64) of the (tile, quadrant) list; count == 0 -> slot unused
+    // Checkpoints, two layouts (AUX template argument of the forward kernels / ROWS of the backward):
+    //   AUX = 2 "rows" (default, fastest):  [4*NS][4][64]  per bucket, per 16-survivor row, per pixel: (T, C0, C1, C2) before the row's first
+    //           survivor.  T is absolute.  With rps = rows per forward segment (1..4, in the descriptor): rows with r % rps == 0 start a
+    //           segment and hold ABSOLUTE composited sums, the others hold the sums accumulated since their segment's start (row r - r % rps).
+    //   AUX = 1 "compact":  [4*NS][64]  per bucket, per pixel: the absolute state before the bucket's first survivor only; the backward
+    //           rebuilds the states in front of rows 1..3 with a 48-step walk.  4x less checkpoint footprint and traffic, backward +55 %
+    //           (measured at C3: 1.33 -> 2.06 ms for a forward gain of 0.12 ms; selected when the row layout would not fit, rasterize.hip).
+    //   The row / bucket at ordinal 0 of a list is never stored (T = 1, sums = 0).
+    float4 *ckpt_tc;
+    float2 *ckpt_da;      // same for (D, A)
+    uint2 *desc;          // [4*NS]  (global tile id | (rps - 1) << 30, (start << 7) | count): `count` (<= 64) survivors starting at ordinal `start`
+                          //          (a multiple of 64) of the (tile, quadrant) list; count == 0 -> slot unused
     uint32_t R, NS;
 };
 
@@ -62,7 +66,7 @@ struct FwdAux {
 // F6.  AUX=true additionally records what the bucket-parallel backward needs: the per-quadrant culled
 // lists, a per-pixel state checkpoint every 64 surviving Gaussians, and one descriptor per bucket.
 // -------------------------------------------------------------------------------------------------
-template <bool AUX>
+template <int AUX>
 __global__ __launch_bounds__(kBlock) void render_fwd_kernel(int W, int H, int Tx, uint32_t tiles_per_view,
                                                             const uint2 *__restrict__ ranges,
                                                             const uint32_t *__restrict__ point_list,
@@ -87,7 +91,7 @@ __global__ __launch_bounds__(kBlock) void render_fwd_kernel(int W, int H, int Tx
     const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     bool done = !inside;
     float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f, D = 0.f, A = 0.f;
-    float B0 = 0.f, B1 = 0.f, B2 = 0.f, BD = 0.f, BA = 0.f;   // composited sums at the start of the current 64-survivor bucket (AUX)
+    float B0 = 0.f, B1 = 0.f, B2 = 0.f, BD = 0.f, BA = 0.f;   // AUX = 2: composited sums at the start of the current 64-survivor bucket
     uint32_t last = 0, lastk = 0;
     uint32_t kbase = 0;                                  // survivors of this wave's quadrant in earlier batches
     const int n = (int)(range.y - range.x);
@@ -152,12 +156,20 @@ __global__ __launch_bounds__(kBlock) void render_fwd_kernel(int W, int H, int Tx
 #pragma unroll
             for (int u = 0; u < SGR_FWD_G; u++) {
                 const uint32_t ord = kbase + g + u;                       // ordinal of this survivor in the quadrant list
-                if (AUX && (ord & 15u) == 0u && ord != 0u && g + u < cnt) {
-                    const uint32_t row = (ord >> 4) & 3u;
-                    const size_t s = ((slot0 + (ord >> 6)) * 4 + row) * 64 + lane;
-                    if (row == 0u) { B0 = C0; B1 = C1; B2 = C2; BD = D; BA = A; }       // bucket start: absolute state
-                    aux.ckpt_tc[s] = row ? make_float4(T, C0 - B0, C1 - B1, C2 - B2) : make_float4(T, C0, C1, C2);
-                    aux.ckpt_da[s] = row ? make_float2(D - BD, A - BA) : make_float2(D, A);
+                if constexpr (AUX == 2) {
+                    if ((ord & 15u) == 0u && ord != 0u && g + u < cnt) {
+                        const uint32_t row = (ord >> 4) & 3u;
+                        const size_t s = ((slot0 + (ord >> 6)) * 4 + row) * 64 + lane;
+                        if (row == 0u) { B0 = C0; B1 = C1; B2 = C2; BD = D; BA = A; }       // bucket start: absolute state
+                        aux.ckpt_tc[s] = row ? make_float4(T, C0 - B0, C1 - B1, C2 - B2) : make_float4(T, C0, C1, C2);
+                        aux.ckpt_da[s] = row ? make_float2(D - BD, A - BA) : make_float2(D, A);
+                    }
+                } else if constexpr (AUX == 1) {
+                    if ((ord & 63u) == 0u && ord != 0u && g + u < cnt) {                    // bucket start: absolute state
+                        const size_t s = (slot0 + (ord >> 6)) * 64 + lane;
+                        aux.ckpt_tc[s] = make_float4(T, C0, C1, C2);
+                        aux.ckpt_da[s] = make_float2(D, A);
+                    }
                 }
                 const float test_T = T * (1.f - al[u]);
                 done = done | (valid[u] & (test_T < 0.0001f));            // the crossing Gaussian is NOT composited
@@ -221,7 +233,7 @@ __device__ __forceinline__ bool cull_quadrant(const float4 &a, const float4 &c, 
     return (a.x + hx >= qx0) && (a.x - hx <= qx0 + 7.f) && (a.y + hy >= qy0) && (a.y - hy <= qy0 + 7.f);
 }
 
-template <bool AUX>
+template <int AUX>
 __global__ __launch_bounds__(kSegThreads, 4) void render_fwd_seg_kernel(int W, int H, int Tx, uint32_t tiles_per_view,
                                                                      const uint2 *__restrict__ ranges,
                                                                      const uint32_t *__restrict__ point_list,
@@ -371,12 +383,14 @@ __global__ __launch_bounds__(kSegThreads, 4) void render_fwd_seg_kernel(int W, i
         // the full 51 instructions per survivor for nothing -- a third of the evaluated pairs on the opaque C2 subject)
         if (__ballot(!done))
         for (uint32_t s = s0; s < s1; s += 4) {
-            if (AUX && s != s0 && ((s - s0) & 15u) == 0u) {
-                // state at survivor 16 / 32 / 48 of my segment, relative to the segment start (the start's absolute sums are only
-                // known after the cross-wave prefix below; the backward adds the two)
-                const size_t sl = ((slot_next + (s0 >> 6)) * 4 + brow0 + ((s - s0) >> 4)) * 64 + lane;
-                aux.ckpt_tc[sl] = make_float4(T, d01.x, d01.y, d2D.x);
-                aux.ckpt_da[sl] = make_float2(d2D.y, dA);
+            if constexpr (AUX == 2) {
+                if (s != s0 && ((s - s0) & 15u) == 0u) {
+                    // state at survivor 16 / 32 / 48 of my segment, relative to the segment start (the start's absolute sums are only
+                    // known after the cross-wave prefix below; the backward adds the two)
+                    const size_t sl = ((slot_next + (s0 >> 6)) * 4 + brow0 + ((s - s0) >> 4)) * 64 + lane;
+                    aux.ckpt_tc[sl] = make_float4(T, d01.x, d01.y, d2D.x);
+                    aux.ckpt_da[sl] = make_float2(d2D.y, dA);
+                }
             }
             float al[4];
             v2f rg[4], bd[4];                                              // (r, g) and (b, depth) of the four survivors
@@ -436,9 +450,16 @@ __global__ __launch_bounds__(kSegThreads, 4) void render_fwd_seg_kernel(int W, i
                 for (int w = 0; w < kSegWaves; w++) if ((((uint32_t)w * per) >> 6) == (s0 >> 6)) live |= sContrib[w];
                 if (live) {
                     const size_t slot = slot_next + (s0 >> 6);
-                    if (kbase + s0 != 0u) {
-                        aux.ckpt_tc[(slot * 4 + brow0) * 64 + lane] = make_float4(Tin, p0, p1, p2);
-                        aux.ckpt_da[(slot * 4 + brow0) * 64 + lane] = make_float2(pD, pA);
+                    if constexpr (AUX == 2) {
+                        if (kbase + s0 != 0u) {
+                            aux.ckpt_tc[(slot * 4 + brow0) * 64 + lane] = make_float4(Tin, p0, p1, p2);
+                            aux.ckpt_da[(slot * 4 + brow0) * 64 + lane] = make_float2(pD, pA);
+                        }
+                    } else {
+                        if ((s0 & 63u) == 0u && kbase + s0 != 0u) {                // my segment starts a bucket: its absolute start state
+                            aux.ckpt_tc[slot * 64 + lane] = make_float4(Tin, p0, p1, p2);
+                            aux.ckpt_da[slot * 64 + lane] = make_float2(pD, pA);
+                        }
                     }
                     if (lane == 0 && (s0 & 63u) == 0u)
                         aux.desc[slot] = make_uint2(bid | (((per >> 4) - 1u) << 30), ((kbase + s0) << 7) | min(64u, m - s0));
@@ -666,7 +687,7 @@ __device__ __forceinline__ float row_shift_in(float v, float feed) {
 // SPLIT (launches with few buckets, i.e. one or two views): TWO waves per bucket, each streaming one half of the quadrant's pixels (47
 // steps instead of 79) -- 19 % more wave-steps but twice the waves, which is what a 4 000-bucket launch on 1 024 SIMDs lacks; the
 // second wave's per-Gaussian sums are added to the first's through LDS before the single partial record is written.
-template <bool HAS_DA, bool SPLIT>
+template <bool HAS_DA, bool SPLIT, bool ROWS>
 __global__ __launch_bounds__(kBlock) void render_bwd_bucket_kernel(int W, int H, int Tx, uint32_t tiles_per_view,
                                                                    const uint2 *__restrict__ ranges,
                                                                    const float4 *__restrict__ rec,
@@ -695,7 +716,7 @@ __global__ __launch_bounds__(kBlock) void render_bwd_bucket_kernel(int W, int H,
     const uint32_t desc_y = (uint32_t)__builtin_amdgcn_readfirstlane((int)desc_v.y);
     const uint32_t desc_x = (uint32_t)__builtin_amdgcn_readfirstlane((int)desc_v.x);
     const uint32_t bid = desc_x & 0x3FFFFFFFu;
-    const uint32_t rps = (desc_x >> 30) + 1u;                  // rows per forward segment: rows with r % rps == 0 hold absolute sums
+    const uint32_t rps = (desc_x >> 30) + 1u;                  // ROWS: rows per forward segment; rows with r % rps == 0 hold absolute sums
     const uint32_t count = desc_y & 127u;
     if (count == 0) return;                                   // unused bucket slot (both waves of a SPLIT pair leave together; ended waves do not count at barriers)
     const uint32_t start = desc_y >> 7;                        // ordinal of this bucket's first survivor in the quadrant list
@@ -719,6 +740,8 @@ __global__ __launch_bounds__(kBlock) void render_bwd_bucket_kernel(int W, int H,
     const float kL2e = 1.4426950408889634f;
     const float kxx = -0.5f * kL2e * cxx, kyy = -0.5f * kL2e * cyy, kxy = -kL2e * cxy;
     // ---- pixel p = lane: static data and the four row start states go to LDS (the per-step feeders)
+    float wT = 1.f, wRem = 0.f, wpx = 0.f, wpy = 0.f, wg0 = 0.f, wg1 = 0.f, wg2 = 0.f, wgd = 0.f, wga = 0.f;
+    uint32_t wlast = 0;
     if (lane < NPIX) {
         const int p = lane + (int)half * NPIX;
         const int px = (int)tx * 16 + (int)(q & 1u) * 8 + (p & 7);
@@ -745,25 +768,56 @@ __global__ __launch_bounds__(kBlock) void render_bwd_bucket_kernel(int W, int H,
         sPixB[wv][lane] = make_float4(g1, g2, gd, ga);
         float T0 = 1.f, Pre0 = 0.f;
         if (inside && start) {
-            const float4 tc = aux.ckpt_tc[slot * 256 + p];
+            const float4 tc = aux.ckpt_tc[ROWS ? slot * 256 + p : slot * 64 + p];
             T0 = tc.x;
             Pre0 = tc.y * g0 + tc.z * g1 + tc.w * g2;
-            if (HAS_DA) { const float2 da = aux.ckpt_da[slot * 256 + p]; Pre0 += da.x * gd + da.y * ga; }
+            if (HAS_DA) { const float2 da = aux.ckpt_da[ROWS ? slot * 256 + p : slot * 64 + p]; Pre0 += da.x * gd + da.y * ga; }
         }
         sDyn[wv][0][lane] = make_float2(T0, O - Pre0);
-        float PreSeg = Pre0;                                   // composited-so-far at the start of the forward segment the row is in
+        if constexpr (ROWS) {
+            float PreSeg = Pre0;                               // composited-so-far at the start of the forward segment the row is in
+#pragma unroll
+            for (int r = 1; r < 4; r++) {
+                float Tr = 1.f, Prer = Pre0;
+                if (inside && (uint32_t)(16 * r) < count) {
+                    const float4 tc = aux.ckpt_tc[(slot * 4 + r) * 64 + p];
+                    Tr = tc.x;
+                    float dotv = tc.y * g0 + tc.z * g1 + tc.w * g2;
+                    if (HAS_DA) { const float2 da = aux.ckpt_da[(slot * 4 + r) * 64 + p]; dotv += da.x * gd + da.y * ga; }
+                    if (((uint32_t)r & (rps - 1u)) == 0u) PreSeg = dotv;      // rps is 1, 2 or 4
+                    Prer = (((uint32_t)r & (rps - 1u)) == 0u) ? dotv : PreSeg + dotv;
+                }
+                sDyn[wv][r][lane] = make_float2(Tr, O - Prer);
+            }
+        }
+        wT = T0; wRem = O - Pre0; wpx = (float)px; wpy = (float)py; wlast = last; wg0 = g0; wg1 = g1; wg2 = g2; wgd = gd; wga = ga;
+    }
+    if constexpr (!ROWS) {
+        // compact checkpoints: the forward stored the pixel state at the bucket's start only; the states in front of rows 1..3 are rebuilt by
+        // walking the bucket's first 48 survivors with the same arithmetic as the step loop below (lanes = pixels, the survivor's record
+        // broadcast from its owner lane)
 #pragma unroll
         for (int r = 1; r < 4; r++) {
-            float Tr = 1.f, Prer = Pre0;
-            if (inside && (uint32_t)(16 * r) < count) {
-                const float4 tc = aux.ckpt_tc[(slot * 4 + r) * 64 + p];
-                Tr = tc.x;
-                float dotv = tc.y * g0 + tc.z * g1 + tc.w * g2;
-                if (HAS_DA) { const float2 da = aux.ckpt_da[(slot * 4 + r) * 64 + p]; dotv += da.x * gd + da.y * ga; }
-                if (((uint32_t)r & (rps - 1u)) == 0u) PreSeg = dotv;      // rps is 1, 2 or 4
-                Prer = (((uint32_t)r & (rps - 1u)) == 0u) ? dotv : PreSeg + dotv;
+            const uint32_t j1 = min(count, (uint32_t)(16 * r));
+            for (uint32_t j = (uint32_t)(16 * (r - 1)); j < j1; j++) {                  // wave-uniform trip count
+#define SGR_BCAST(v) __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), (int)j))
+                const float jx = SGR_BCAST(gx), jy = SGR_BCAST(gy), jkxx = SGR_BCAST(kxx), jkyy = SGR_BCAST(kyy), jkxy = SGR_BCAST(kxy);
+                const float jop = SGR_BCAST(op), jcr = SGR_BCAST(cr), jcg = SGR_BCAST(cg), jcb = SGR_BCAST(cb);
+                const uint32_t jidx = (uint32_t)__builtin_amdgcn_readlane((int)gidx, (int)j);
+                const float dx = jx - wpx, dy = jy - wpy;
+                const float p2 = (jkxx * dx) * dx + ((jkyy * dy) * dy + (jkxy * dx) * dy);
+                const float G = __builtin_amdgcn_exp2f(p2);
+                const float alpha = fminf(0.99f, jop * G);
+                if (jidx < wlast && p2 <= 0.f && alpha >= (1.0f / 255.0f)) {
+                    const float w = alpha * wT;
+                    float qj = jcr * wg0 + jcg * wg1 + jcb * wg2;
+                    if (HAS_DA) qj += SGR_BCAST(gdep) * wgd + wga;
+                    wRem -= w * qj;
+                    wT *= 1.f - alpha;
+                }
+#undef SGR_BCAST
             }
-            sDyn[wv][r][lane] = make_float2(Tr, O - Prer);
+            if (lane < NPIX) sDyn[wv][r][lane] = make_float2(wT, wRem);
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -859,6 +913,17 @@ int sgr_get_forward_mode() { return sgr_fwd_mode; }
 // slot base (range.x >> 6) + tile id leaves exactly that room
 extern "C" uint64_t sgr_bucket_slots(uint64_t R, uint64_t tiles_total) { return (R >> 6) + tiles_total + 1; }
 
+// checkpoint layout: 0 = automatic (rows unless their allocation would exceed SIGMAN_AUX_ROWS_MAX_BYTES, default 8 GiB), 1 = compact, 2 = rows
+static int sgr_aux_layout_mode = 0;
+extern "C" int sgr_set_aux_layout(int mode) { sgr_aux_layout_mode = mode; return 0; }
+// -> 2 (rows) or 1 (compact) for a launch with NS bucket slots per quadrant
+int sgr_aux_layout_for(uint64_t NS) {
+    if (sgr_aux_layout_mode == 1 || sgr_aux_layout_mode == 2) return sgr_aux_layout_mode;
+    static uint64_t limit = 0;
+    if (!limit) { const char *e = getenv("SIGMAN_AUX_ROWS_MAX_BYTES"); limit = e ? strtoull(e, nullptr, 10) : (8ull << 30); if (!limit) limit = 1; }
+    return 4 * NS * 4 * 64 * 24 > limit ? 1 : 2;
+}
+
 static FwdAux make_aux(void *compact, void *ckpt_tc, void *ckpt_da, void *desc, uint64_t R, uint64_t tiles_total) {
     FwdAux a;
     a.compact = (uint2 *)compact; a.ckpt_tc = (float4 *)ckpt_tc; a.ckpt_da = (float2 *)ckpt_da; a.desc = (uint2 *)desc;
@@ -878,7 +943,7 @@ int sgr_render_forward_wants_prepare(const SgrProblem *pb, uint64_t R, bool use_
 int sgr_render_forward_ex(const SgrProblem *pb, const uint32_t *ranges, const uint32_t *point_list, const float *rec,
                           float *out_color, float *out_depth, float *out_alpha, float *final_T, uint32_t *n_contrib,
                           uint64_t R, void *aux_compact, void *aux_ckpt_tc, void *aux_ckpt_da, void *aux_desc,
-                          uint32_t *aux_order, bool prepared, void *stream_) {
+                          uint32_t *aux_order, bool prepared, int aux_layout /* 1 compact, 2 rows */, void *stream_) {
     if (sgr_validate_problem(pb)) return 1;
     const int Tx = (pb->W + SGR_TILE - 1) / SGR_TILE, Ty = (pb->H + SGR_TILE - 1) / SGR_TILE;
     const uint32_t tiles = (uint32_t)Tx * Ty;
@@ -900,25 +965,25 @@ int sgr_render_forward_ex(const SgrProblem *pb, const uint32_t *ranges, const ui
     }
     if (seg) {
         const uint32_t seg_grid = (uint32_t)((tiles_total + 7) / 8) * 32u;       // 8 tile slots x 4 quadrants per group of 32 ids
-        if (use_aux)
-            hipLaunchKernelGGL(render_fwd_seg_kernel<true>, dim3(seg_grid), dim3(kSegThreads), 0, stream, pb->W, pb->H,
-                               Tx, tiles, (const uint2 *)ranges, point_list, (const float4 *)rec, pb->bg, out_color, out_depth,
-                               out_alpha, final_T, n_contrib, aux, (const uint32_t *)aux_order, (uint32_t)tiles_total);
-        else
-            hipLaunchKernelGGL(render_fwd_seg_kernel<false>, dim3(seg_grid), dim3(kSegThreads), 0, stream, pb->W, pb->H,
-                               Tx, tiles, (const uint2 *)ranges, point_list, (const float4 *)rec, pb->bg, out_color, out_depth,
-                               out_alpha, final_T, n_contrib, aux, (const uint32_t *)aux_order, (uint32_t)tiles_total);
+#define SGR_LAUNCH_SEG(A)                                                                                                   \
+        hipLaunchKernelGGL(render_fwd_seg_kernel<A>, dim3(seg_grid), dim3(kSegThreads), 0, stream, pb->W, pb->H, Tx, tiles,        \
+                           (const uint2 *)ranges, point_list, (const float4 *)rec, pb->bg, out_color, out_depth, out_alpha, final_T,  \
+                           n_contrib, aux, (const uint32_t *)aux_order, (uint32_t)tiles_total)
+        if (!use_aux) SGR_LAUNCH_SEG(0);
+        else if (aux_layout == 2) SGR_LAUNCH_SEG(2);
+        else SGR_LAUNCH_SEG(1);
+#undef SGR_LAUNCH_SEG
         SGR_CHECK_LAUNCH("render_fwd_seg_kernel");
         return 0;
     }
-    if (use_aux)
-        hipLaunchKernelGGL(render_fwd_kernel<true>, dim3(tiles * pb->n_views), dim3(kBlock), 0, stream, pb->W, pb->H, Tx, tiles,
-                           (const uint2 *)ranges, point_list, (const float4 *)rec, pb->bg, out_color, out_depth, out_alpha,
-                           final_T, n_contrib, aux);
-    else
-        hipLaunchKernelGGL(render_fwd_kernel<false>, dim3(tiles * pb->n_views), dim3(kBlock), 0, stream, pb->W, pb->H, Tx, tiles,
-                           (const uint2 *)ranges, point_list, (const float4 *)rec, pb->bg, out_color, out_depth, out_alpha,
-                           final_T, n_contrib, aux);
+#define SGR_LAUNCH_FWD(A)                                                                                                   \
+    hipLaunchKernelGGL(render_fwd_kernel<A>, dim3(tiles * pb->n_views), dim3(kBlock), 0, stream, pb->W, pb->H, Tx, tiles,          \
+                       (const uint2 *)ranges, point_list, (const float4 *)rec, pb->bg, out_color, out_depth, out_alpha, final_T,      \
+                       n_contrib, aux)
+    if (!use_aux) SGR_LAUNCH_FWD(0);
+    else if (aux_layout == 2) SGR_LAUNCH_FWD(2);
+    else SGR_LAUNCH_FWD(1);
+#undef SGR_LAUNCH_FWD
     SGR_CHECK_LAUNCH("render_fwd_kernel");
     return 0;
 }
@@ -927,8 +992,9 @@ extern "C" int sgr_render_forward(const SgrProblem *pb, const uint32_t *ranges, 
                                   float *out_color, float *out_depth, float *out_alpha, float *final_T, uint32_t *n_contrib,
                                   uint64_t R, void *aux_compact, void *aux_ckpt_tc, void *aux_ckpt_da, void *aux_desc,
                                   uint32_t *aux_order, void *stream_) {
+    const uint64_t tiles_total = (uint64_t)((pb->W + SGR_TILE - 1) / SGR_TILE) * ((pb->H + SGR_TILE - 1) / SGR_TILE) * pb->n_views;
     return sgr_render_forward_ex(pb, ranges, point_list, rec, out_color, out_depth, out_alpha, final_T, n_contrib, R, aux_compact,
-                                 aux_ckpt_tc, aux_ckpt_da, aux_desc, aux_order, false, stream_);
+                                 aux_ckpt_tc, aux_ckpt_da, aux_desc, aux_order, false, sgr_aux_layout_for(sgr_bucket_slots(R, tiles_total)), stream_);
 }
 
 int sgr_render_backward_ex(const SgrProblem *pb, const uint32_t *ranges, const uint32_t *point_list, const float *rec,
@@ -936,7 +1002,7 @@ int sgr_render_backward_ex(const SgrProblem *pb, const uint32_t *ranges, const u
                            const float *out_depth, const float *out_alpha, const float *grad_color,
                            const float *grad_depth, const float *grad_alpha, const float *grad_color_scale, uint64_t R,
                            const void *aux_compact, const void *aux_ckpt_tc, const void *aux_ckpt_da, const void *aux_desc,
-                           float *grec, float *part, uint32_t *flags, bool flags_cleared, void *stream_) {
+                           float *grec, float *part, uint32_t *flags, bool flags_cleared, int aux_layout /* 1 compact, 2 rows */, void *stream_) {
     if (sgr_validate_problem(pb)) return 1;
     hipStream_t stream = (hipStream_t)stream_;
     const int Tx = (pb->W + SGR_TILE - 1) / SGR_TILE, Ty = (pb->H + SGR_TILE - 1) / SGR_TILE;
@@ -956,22 +1022,19 @@ int sgr_render_backward_ex(const SgrProblem *pb, const uint32_t *ranges, const u
         const bool split = (uint64_t)tiles * pb->n_views <= 2048;
         const uint32_t bpw = split ? 2u : 4u;                            // buckets per workgroup
         const uint32_t nblocks = ((aux.NS + bpw - 1u) / bpw + 7u) / 8u * 32u;      // per quadrant ceil(NS / bpw) workgroups, in groups of 8 x 4 quadrants
-        if (split && (grad_depth || grad_alpha))
-            hipLaunchKernelGGL((render_bwd_bucket_kernel<true, true>), dim3(nblocks), dim3(kBlock), 0, stream, pb->W, pb->H, Tx, tiles,
-                               (const uint2 *)ranges, (const float4 *)rec, n_contrib, out_color, out_depth, out_alpha, grad_color,
-                               grad_depth, grad_alpha, grad_color_scale, aux, (float4 *)part, (uint8_t *)flags);
-        else if (split)
-            hipLaunchKernelGGL((render_bwd_bucket_kernel<false, true>), dim3(nblocks), dim3(kBlock), 0, stream, pb->W, pb->H, Tx, tiles,
-                               (const uint2 *)ranges, (const float4 *)rec, n_contrib, out_color, out_depth, out_alpha, grad_color,
-                               grad_depth, grad_alpha, grad_color_scale, aux, (float4 *)part, (uint8_t *)flags);
-        else if (grad_depth || grad_alpha)
-            hipLaunchKernelGGL((render_bwd_bucket_kernel<true, false>), dim3(nblocks), dim3(kBlock), 0, stream, pb->W, pb->H, Tx, tiles,
-                               (const uint2 *)ranges, (const float4 *)rec, n_contrib, out_color, out_depth, out_alpha, grad_color,
-                               grad_depth, grad_alpha, grad_color_scale, aux, (float4 *)part, (uint8_t *)flags);
-        else
-            hipLaunchKernelGGL((render_bwd_bucket_kernel<false, false>), dim3(nblocks), dim3(kBlock), 0, stream, pb->W, pb->H, Tx, tiles,
-                               (const uint2 *)ranges, (const float4 *)rec, n_contrib, out_color, out_depth, out_alpha, grad_color,
-                               grad_depth, grad_alpha, grad_color_scale, aux, (float4 *)part, (uint8_t *)flags);
+#define SGR_LAUNCH_BWD(DA, SP, RW)                                                                                          \
+        hipLaunchKernelGGL((render_bwd_bucket_kernel<DA, SP, RW>), dim3(nblocks), dim3(kBlock), 0, stream, pb->W, pb->H, Tx, tiles,    \
+                           (const uint2 *)ranges, (const float4 *)rec, n_contrib, out_color, out_depth, out_alpha, grad_color,         \
+                           grad_depth, grad_alpha, grad_color_scale, aux, (float4 *)part, (uint8_t *)flags)
+        const bool da = grad_depth || grad_alpha, rows = aux_layout == 2;
+        if (rows) {
+            if (split && da) SGR_LAUNCH_BWD(true, true, true); else if (split) SGR_LAUNCH_BWD(false, true, true);
+            else if (da) SGR_LAUNCH_BWD(true, false, true); else SGR_LAUNCH_BWD(false, false, true);
+        } else {
+            if (split && da) SGR_LAUNCH_BWD(true, true, false); else if (split) SGR_LAUNCH_BWD(false, true, false);
+            else if (da) SGR_LAUNCH_BWD(true, false, false); else SGR_LAUNCH_BWD(false, false, false);
+        }
+#undef SGR_LAUNCH_BWD
         SGR_CHECK_LAUNCH("render_bwd_bucket_kernel");
         return 0;
     }
@@ -988,7 +1051,8 @@ extern "C" int sgr_render_backward(const SgrProblem *pb, const uint32_t *ranges,
                                    const float *grad_depth, const float *grad_alpha, const float *grad_color_scale, uint64_t R,
                                    const void *aux_compact, const void *aux_ckpt_tc, const void *aux_ckpt_da, const void *aux_desc,
                                    float *grec, float *part, uint32_t *flags, void *stream_) {
+    const uint64_t tiles_total = (uint64_t)((pb->W + SGR_TILE - 1) / SGR_TILE) * ((pb->H + SGR_TILE - 1) / SGR_TILE) * pb->n_views;
     return sgr_render_backward_ex(pb, ranges, point_list, rec, final_T, n_contrib, out_color, out_depth, out_alpha, grad_color, grad_depth,
                                   grad_alpha, grad_color_scale, R, aux_compact, aux_ckpt_tc, aux_ckpt_da, aux_desc, grec, part, flags, false,
-                                  stream_);
+                                  sgr_aux_layout_for(sgr_bucket_slots(R, tiles_total)), stream_);
 }

@@ -124,6 +124,43 @@ def test_backward_gradients(name, oracle, fwd_mode):
         assert err <= GRAD_TOL, f"{name}: grad {nm} rel-to-max err {err:.3e} (max|g| {scale:.3e})"
 
 
+@pytest.mark.parametrize("name", ["humanoid_20k_256", "deep_tiles", "opaque_stack", "cloud_sh3"])
+def test_compact_checkpoint_layout(name, oracle, fwd_mode):
+    """The forward's checkpoints for the bucket-parallel backward exist in two layouts (include/sigman_gsplat.h, sgr_set_aux_layout):
+    one record per 16-survivor row (default) or one per 64-survivor bucket with the inner rows rebuilt by the backward (4x smaller;
+    chosen automatically when the row layout would not fit).  Both must give the oracle's gradients."""
+    from sigman_release_amd import _cabi
+    from sigman_release_amd import rasterizer as R
+    dev = _dev()
+    inp, st = cases.CASES[name]()
+    H, W = st["image_height"], st["image_width"]
+    gC, gD, gA = cases.grads_for(H, W)
+    ref = oracle.forward(**inp, **cases.single_view(st))
+    gref = oracle.backward(ref, gC, gD, gA)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    res = {}
+    try:
+        for layout in (2, 1):
+            _cabi.lib().sgr_set_aux_layout(layout)
+            d = {k: t(v)[None].requires_grad_(True) for k, v in inp.items()}
+            color, radii, depth, alpha = R.rasterize_gaussians_batched(
+                d["means3D"], None, d.get("shs"), d.get("colors_precomp"), d["opacities"][..., None], d.get("scales"), d.get("rotations"),
+                d.get("cov3D_precomp"), _batched_settings(st, dev, 1))
+            ((color[0] * t(gC)).sum() + (depth[0] * t(gD)).sum() + (alpha[0] * t(gA)).sum()).backward()
+            torch.cuda.synchronize()
+            res[layout] = {k: v.grad[0].cpu().numpy() for k, v in d.items()}
+    finally:
+        _cabi.lib().sgr_set_aux_layout(0)
+    names = {"means3D": "means3D", "opacities": "opacities", "colors_precomp": "colors_precomp", "cov3D_precomp": "cov3D_precomp", "shs": "sh",
+             "scales": "scales", "rotations": "rotations"}
+    for k in res[1]:
+        want = gref[names[k]].reshape(res[1][k].shape)
+        scale = max(np.abs(want).max(), 1e-20)
+        for layout in (1, 2):
+            assert np.abs(res[layout][k] - want).max() / scale <= GRAD_TOL, (k, layout)
+        assert np.abs(res[1][k] - res[2][k]).max() / scale <= 2e-5, k
+
+
 def test_empty_and_degenerate():
     """P = 0 and an identity camera (everything culled) must give the pure background, not crash."""
     from sigman_release_amd import rasterizer as R
