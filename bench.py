@@ -39,7 +39,7 @@ import subprocess
 import sys
 import time
 
-os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")   # before torch/HIP initialise: see sigman_release_amd/__init__.py
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")   # before torch/HIP initialise: lets the graphs_on variant (SIGMAN_GRAPHS=1) replay safely
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 
@@ -115,7 +115,7 @@ from sigman_release_amd import rasterizer as R  # noqa: E402
 
 VIEWS = (30, 37, 45, 53, 65, 85, 0, 8)
 KERNELS = {0: "preprocess_fwd", 1: "scan_block_sums", 2: "duplicate_keys", 3: "radix_sort(all passes)", 4: "tile_ranges",
-           5: "render_fwd", 6: "render_bwd", 7: "preprocess_bwd"}
+           5: "render_fwd", 6: "render_bwd", 7: "preprocess_bwd", 10: "clamped_l1"}
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s peak (6.3 TB/s achievable)
 
 # name -> (Gaussians per subject, image size, subjects, backward?, depth+alpha grads?, scaling, steps, warmup)
@@ -134,7 +134,7 @@ CONFIGS = {
 def algorithmic_bytes(kid: int, P: int, Rn: int, HW: int, tiles: int, bwd_da: bool = True) -> float:
     """SURVEY.md 8(d) per-view figures; P, Rn, HW, tiles are totals over the view slots of one launch."""
     return float({0: 76 * P, 1: 8 * P, 2: 20 * P + 12 * Rn, 3: 24 * Rn, 4: 8 * Rn + 8 * tiles, 5: 44 * Rn + 24 * HW,
-                  6: 88 * Rn + 28 * HW, 7: 108 * P}[kid])
+                  6: 88 * Rn + 28 * HW, 7: 108 * P, 10: 36 * HW}[kid])
 
 
 def build_subject(cfg_name: str, P: int, seed: int, dev):
@@ -275,21 +275,23 @@ def main(args):
             torch.cuda.synchronize()
 
     # ---- warmup (untimed), with a full per-kernel profile of the last 3 warmup steps to pick the dominant kernel
+    prof_from = max(warmup - 3, min(1, warmup - 1), 0)      # (never the very first step: code-object loads would be billed to its kernels)
     for i in range(warmup):
-        if i == max(warmup - 3, 0):
+        if i == prof_from:
             torch.cuda.synchronize()
             L.sgr_prof_configure(0xFFFF)
         step()
     torch.cuda.synchronize()
     prof_all = collect()
-    nprof = max(warmup - max(warmup - 3, 0), 1)
+    nprof = max(warmup - prof_from, 1)
     breakdown = {KERNELS[k]: round(v[0] / nprof, 4) for k, v in prof_all.items() if k in KERNELS}
-    dominant = max(prof_all, key=lambda k: prof_all[k][0]) if prof_all else 5
+    cand = {k: v for k, v in prof_all.items() if k in KERNELS}
+    dominant = max(cand, key=lambda k: cand[k][0]) if cand else 5
     L.sgr_prof_configure(0)
-    for _ in range(3):                           # re-warm without the profiler (lets the launch-graph cache fill)
+    for _ in range(3):                           # re-warm without the profiler
         step()
 
-    # ---- timed region (no per-kernel events here: event pairs would force plain launches instead of graph replay)
+    # ---- timed region (no per-kernel events here)
     sync_all()
     t0 = time.perf_counter()
     loss = None
@@ -401,7 +403,7 @@ def variants(args, subj, st, gt, norm, S, P, H, W, mine, dev):
     """The same workload under the conditions the headline does NOT assume (N=1 only):
       per_view_loop_*      the reference's own call pattern (gs.py:62-109): Python loop over subjects and views through the
                            upstream-signature GaussianRasterizer (one launch chain + one autograd node per view), then clamp/stack/L1
-      unpinned_*, graphs_off_*   the batched step re-run in a subprocess without host-thread pinning / with hipGraph replay off"""
+      unpinned_*, graphs_on_*    the batched step re-run in a subprocess without host-thread pinning / with hipGraph replay of the forward chain on"""
     from sigman_release_amd.losses import clamped_l1_loss
     out = {}
     leaves = {k: v.clone().requires_grad_(True) for k, v in subj.items()}
@@ -433,7 +435,7 @@ def variants(args, subj, st, gt, norm, S, P, H, W, mine, dev):
     out["per_view_loop_ms_per_step"] = round(dt * 1e3, 4)
     out["per_view_loop_views_per_s"] = round(S * V / dt, 1)
     base = [sys.executable, os.path.abspath(__file__), "--config", args.config, "--no-cpu-baseline", "--no-variants"]
-    for key, env in (("unpinned", {"SIGMAN_NO_PIN": "1"}), ("graphs_off", {"SIGMAN_GRAPHS": "0"})):
+    for key, env in (("unpinned", {"SIGMAN_NO_PIN": "1"}), ("graphs_on", {"SIGMAN_GRAPHS": "1"})):
         try:
             if _ORIG_AFFINITY is not None:
                 os.sched_setaffinity(0, _ORIG_AFFINITY)

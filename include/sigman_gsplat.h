@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SGR_ABI_VERSION 1
+#define SGR_ABI_VERSION 2
 #define SGR_TILE 16                 /* 16x16 pixel tiles, as the published algorithm */
 #define SGR_REC_FLOATS 12           /* floats of a gradient record (grec, pixel-parallel backward) */
 #define SGR_PART_FLOATS 10          /* floats of a partial gradient record (bucket-parallel backward): 40 B, 8-byte aligned */
@@ -135,13 +135,14 @@ int sgr_rasterize_backward(const SgrProblem *pb, const SgrForwardState *state, c
                            float *dL_drotations, void *stream);
 
 /*
- * hipGraph replay of the forward launch chain (sync-free mode only).  The chain is captured once per distinct argument
- * set (problem + pointers) and replayed with one hipGraphLaunch.
- *   1 = auto (default): replay only if DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 is in the process environment -- ROCm 7.2's
- *       pre-recorded graph packets fault after large host<->device copies in the same process, so that runtime feature
- *       has to be off (set the variable before the HIP runtime initialises; the Python package does so when it is imported
- *       before torch, bench.py and tests/conftest.py always do);
- *   0 = plain launches;   2 = force replay (caller guarantees the runtime is safe).
+ * hipGraph replay of the forward launch chain (sync-free mode only): the chain is captured once per distinct argument set (problem +
+ * pointers) and replayed with one hipGraphLaunch.  OPT-IN:
+ *   0 = plain launches (default: on ROCm 7.2 replay is no faster than the 8 plain launches of a forward, and the instance count of the
+ *       sync-free modes reaches the host earlier without it);
+ *   1 = replay only if DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 is in the process environment -- ROCm 7.2's pre-recorded graph packets fault after
+ *       large host<->device copies in the same process, so that runtime feature has to be off (set the variable before the HIP runtime
+ *       initialises);
+ *   2 = force replay (caller guarantees the runtime is safe).
  */
 int sgr_set_graphs(int enable);
 /* upstream's `debug=True` (error conventions): while enabled, every kernel launch of the calling thread is followed by a
@@ -157,8 +158,8 @@ int32_t sgr_preprocess_blocks_per_view(int32_t P);
 
 /*
  * F1 + F2: cull/project/cov2D/conic/radius/rect per (view,Gaussian), block-wise tile counts and their
- * exclusive scan.  Outputs: rec [n_views*P*16], radii i32 [n_views*P], rect u32 [n_views*P*2]
- * (minx | miny<<16, maxx | maxy<<16), clamped u8 [n_views*P] (SH clamp bits, may be NULL without shs),
+ * exclusive scan.  Outputs: rec [n_views*P*16], radii i32 [n_views*P], rect u32 [n_views*P*4]
+ * (minx | miny<<16, maxx | maxy<<16, depth key bits, 0: one 16-byte record for the emission kernel), clamped u8 [n_views*P] (SH clamp bits, may be NULL without shs),
  * block_offsets u32 [2*(n_views*blocks_per_view + 1)] (first half: exclusive offsets, entry n = R; second half:
  * scratch for the un-scanned sums), num_rendered u64 [4] ([0] = R, [1] = 1 if R overflows the 32-bit instance index or
  * `capacity`, [2] = R | overflow << 63: the word the sync-free mode publishes to the host, [3] unused).  capacity = 0: none (the caller reads R back and sizes the binning buffers exactly, like upstream);
@@ -239,7 +240,7 @@ int sgr_render_backward(const SgrProblem *pb, const uint32_t *ranges, const uint
  * B2 + B3: per-(view,Gaussian) gradient records (either `grec`, or `rec` + `part` + `flags` from the bucket-parallel
  * sgr_render_backward) -> per-subject parameter gradients, summed over the
  * subject's views in a fixed order (no atomics).  Outputs are fully written (no pre-zeroing needed):
- *   dL_dmeans3D [S,P,3], dL_dmeans2D [n_views,P,3] (NDC units like upstream, z = 0),
+ *   dL_dmeans3D [S,P,3], dL_dmeans2D [n_views,P,3] (NDC units like upstream, z = 0; may be NULL: not written),
  *   dL_dopacity [S,P], dL_dcolors [S,P,3] (or dL_dsh [S,P,M,3] when shs), dL_dcov3D [S,P,6],
  *   dL_dscales [S,P,3] / dL_drotations [S,P,4] (only when scales given; else may be NULL)
  */

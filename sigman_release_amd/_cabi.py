@@ -91,9 +91,9 @@ def lib():
             fn = getattr(L, name)          # AttributeError if a declared symbol is not exported
             fn.restype = res
             fn.argtypes = args
-        if L.sgr_abi_version() != 1:
-            raise RuntimeError(f"ABI version mismatch: library reports {L.sgr_abi_version()}, binding expects 1")
-        if os.environ.get("SIGMAN_GRAPHS", "1") in ("0", "2"):    # 0: plain launches (e.g. rocprofv3 --pmc runs); 2: force replay
+        if L.sgr_abi_version() != 2:
+            raise RuntimeError(f"ABI version mismatch: library reports {L.sgr_abi_version()}, binding expects 2")
+        if os.environ.get("SIGMAN_GRAPHS", "0") in ("1", "2"):    # opt-in hipGraph replay of the forward chain (include/sigman_gsplat.h, sgr_set_graphs)
             L.sgr_set_graphs(int(os.environ["SIGMAN_GRAPHS"]))
         _lib = L
     return _lib

@@ -42,7 +42,7 @@ struct DupExtra {
 __global__ __launch_bounds__(kThreads) void duplicate_keys_kernel(int P, int Tx, int tiles_per_view,
                                                                   float4 *__restrict__ rec,
                                                                   const int32_t *__restrict__ radii,
-                                                                  const uint2 *__restrict__ rect,
+                                                                  const uint4 *__restrict__ rect,
                                                                   const uint32_t *__restrict__ block_offsets, uint32_t cap,
                                                                   uint64_t *__restrict__ keys, uint32_t *__restrict__ vals,
                                                                   DupExtra ex) {
@@ -57,13 +57,14 @@ __global__ __launch_bounds__(kThreads) void duplicate_keys_kernel(int P, int Tx,
     if (ex.zero_one && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *ex.zero_one = 0u;
     const int i = blockIdx.x * kThreads + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t cnt = 0;
+    uint32_t cnt = 0, depth_bits = 0;
     int minx = 0, miny = 0, maxx = 0, maxy = 0;
     size_t q = 0;
     if (i < P) {
         q = (size_t)view * P + i;
         if (radii[q] > 0) {
-            const uint2 r = rect[q];
+            const uint4 r = rect[q];
+            depth_bits = r.z;
             minx = r.x & 0xFFFF; miny = r.x >> 16; maxx = r.y & 0xFFFF; maxy = r.y >> 16;
             cnt = (uint32_t)((maxx - minx) * (maxy - miny));
         }
@@ -114,7 +115,7 @@ __global__ __launch_bounds__(kThreads) void duplicate_keys_kernel(int P, int Tx,
     s_w[threadIdx.x] = (uint32_t)(maxx - minx);
     if (threadIdx.x == kThreads - 1) s_off[kThreads] = off - block_base + cnt;
     if (cnt) {
-        s_dep[threadIdx.x] = __float_as_uint(rec[q * 4 + 1].z);
+        s_dep[threadIdx.x] = depth_bits;
         rec[q * 4 + 3].x = __uint_as_float(off);           // first tile-instance index of this Gaussian (backward gather)
     }
     __syncthreads();
@@ -1338,7 +1339,7 @@ int sgr_bin_ex(const SgrProblem *pb, float *rec, const int32_t *radii, const uin
     ex.zero_one = all_large ? (uint32_t *)((char *)workspace + sgr_bin_workspace_bytes(R, 0)) : nullptr;
     if (self_scan && !num_rendered_dev) { sgr_set_error("sgr_bin: self-scan needs the device counter"); return 1; }
     hipLaunchKernelGGL(duplicate_keys_kernel, dim3(nbx, pb->n_views), dim3(kThreads), 0, stream, pb->P, Tx, Tx * Ty,
-                       (float4 *)rec, radii, (const uint2 *)rect, block_offsets, n, keys_a, vals_a, ex);
+                       (float4 *)rec, radii, (const uint4 *)rect, block_offsets, n, keys_a, vals_a, ex);
     SGR_CHECK_LAUNCH("duplicate_keys_kernel");
     }
     const bool small = n <= (1u << 19);

@@ -173,7 +173,7 @@ __device__ __forceinline__ uint32_t block_sum_u32(uint32_t v, uint32_t *lds4) {
 // -------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kPreThreads) void preprocess_fwd_kernel(SgrProblem pb, float4 *__restrict__ rec,
                                                                      int32_t *__restrict__ radii,
-                                                                     uint2 *__restrict__ rect,
+                                                                     uint4 *__restrict__ rect,
                                                                      uint8_t *__restrict__ clamped,
                                                                      uint32_t *__restrict__ block_sums) {
     __shared__ uint32_t red[4];
@@ -267,7 +267,9 @@ __global__ __launch_bounds__(kPreThreads) void preprocess_fwd_kernel(SgrProblem 
         rec[q * 4 + 0] = r0; rec[q * 4 + 1] = r1; rec[q * 4 + 2] = r2;
         rec[q * 4 + 3] = make_float4(0.f, __uint_as_float(rect_out.x), __uint_as_float(rect_out.y), 0.f);   // .x = first instance index (sgr_bin)
         radii[q] = rad_out;
-        rect[q] = rect_out;
+        // (rect min, rect max, depth key bits, 0): everything the emission kernel needs, in one coalesced 16-byte record -- it used to fetch
+        // the depth from the 64-byte `rec` line of every visible Gaussian
+        rect[q] = make_uint4(rect_out.x, rect_out.y, __float_as_uint(r1.z), 0u);
         if (clamped) clamped[q] = clamp_bits;
     }
     const uint32_t tot = block_sum_u32(tiles, red);
@@ -365,8 +367,8 @@ __global__ __launch_bounds__(kPreThreads) void preprocess_bwd_kernel(SgrProblem 
     for (int vv = 0; vv < pb.views_per_subject; vv++) {
         const int view = v0 + vv;
         const size_t q = (size_t)view * pb.P + i;
-        float *g2out = dL_dmeans2D + q * 3;
-        if (!(radii[q] > 0)) { g2out[0] = g2out[1] = g2out[2] = 0.f; continue; }
+        float *g2out = dL_dmeans2D ? dL_dmeans2D + q * 3 : nullptr;      // (NULL: nobody wants dL/dNDC)
+        if (!(radii[q] > 0)) { if (g2out) { g2out[0] = g2out[1] = g2out[2] = 0.f; } continue; }
         float4 g0, g1, g2;
         if (part) {
             // deterministic gather of the bucket-parallel backward's partial records: one per (tile instance, quadrant),
@@ -475,7 +477,7 @@ __global__ __launch_bounds__(kPreThreads) void preprocess_bwd_kernel(SgrProblem 
         }
         gop += g1.y;
         gmean[0] += gm[0]; gmean[1] += gm[1]; gmean[2] += gm[2];
-        g2out[0] = g2x; g2out[1] = g2y; g2out[2] = 0.f;
+        if (g2out) { g2out[0] = g2x; g2out[1] = g2y; g2out[2] = 0.f; }
     }
 #pragma unroll
     for (int k = 0; k < 3; k++) dL_dmeans3D[sp * 3 + k] = gmean[k];
@@ -581,7 +583,7 @@ int sgr_preprocess_forward_ex(const SgrProblem *pb, float *rec, int32_t *radii, 
     uint32_t *sums = block_offsets + (n + 1);
     dim3 grid(nbx, pb->n_views);
     { SgrProfScope _p(SGR_K_PREPROCESS_FWD, stream);
-    hipLaunchKernelGGL(preprocess_fwd_kernel, grid, dim3(kPreThreads), 0, stream, *pb, (float4 *)rec, radii, (uint2 *)rect,
+    hipLaunchKernelGGL(preprocess_fwd_kernel, grid, dim3(kPreThreads), 0, stream, *pb, (float4 *)rec, radii, (uint4 *)rect,
                        clamped, sums);
     SGR_CHECK_LAUNCH("preprocess_fwd_kernel");
     }

@@ -37,7 +37,7 @@ constexpr int kGraphSlots = 16;
 FwdEntry g_fwd[kGraphSlots];
 int g_fwd_n = 0;
 uint64_t g_stamp = 0, g_graph_misses = 0, g_graph_hits = 0, g_miss_streak = 0;
-int g_graphs_enabled = -1;       // -1 = not decided yet (see graphs_allowed)
+int g_graphs_enabled = 0;        // 0 = plain launches (default); -1 = automatic, not decided yet (see graphs_allowed); > 0 = replay
 std::mutex g_graph_mu;           // the cache below is process-global: forwards issued from several host threads take turns
 }  // namespace
 
@@ -68,8 +68,10 @@ int sgr_aux_layout_for(uint64_t NS);
 // copies issued by the same process: a few replays after e.g. a 5 MB pageable D2H copy the command processor faults
 // ("write access to a read-only page", no wave involved; reproduced with tests/test_gpu_parity.py::test_graph_replay_survives_
 // host_copies).  With DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 in the environment BEFORE the HIP runtime initialises, replay is
-// stable.  So: graph replay is used only when that variable is visibly "0" (the Python package and bench.py set it before
-// importing torch), or when the caller forces it with sgr_set_graphs(2).
+// stable.  Graph replay is therefore OPT-IN (sgr_set_graphs / SIGMAN_GRAPHS): mode 1 replays only when that variable is visibly "0",
+// mode 2 forces it.  The default is plain launches -- on this runtime replay no longer pays anyway (C2 step 0.188 ms with replay,
+// 0.176 ms without, BENCH r02a), and in automatic-capacity mode the instance count then reaches the host while the rest of the chain
+// is still being queued instead of behind the whole graph (per-view path of gs.py:62-109: 318 -> 235 us per view).
 static bool graphs_allowed() {
     if (g_graphs_enabled < 0) {
         const char *e = getenv("DEBUG_CLR_GRAPH_PACKET_CAPTURE");
@@ -150,7 +152,7 @@ extern "C" int sgr_rasterize_forward(const SgrProblem *pb, uint64_t capacity, in
     // ---- geometry blob
     uint64_t o = 0;
     st->off_rec = o; o = align_up(o + (nq ? nq : 1) * SGR_REC_STRIDE * 4);
-    st->off_rect = o; o = align_up(o + (nq ? nq : 1) * 8);
+    st->off_rect = o; o = align_up(o + (nq ? nq : 1) * 16);
     st->off_clamped = o; o = align_up(o + (pb->shs ? (nq ? nq : 1) : 0));
     st->off_block_offsets = o; o = align_up(o + 2 * nbo * 4);
     st->off_num_rendered = o; o = align_up(o + 32);

@@ -374,7 +374,7 @@ def _forward_impl(means3D, opacities, colors_precomp, shs, cov3D_precomp, scales
 
 
 def _backward_impl(ctx: _Ctx, means3D, opacities, colors_precomp, shs, cov3D_precomp, scales, rotations,
-                   st: BatchedRasterizationSettings, grad_color, grad_depth, grad_alpha, img, grad_color_scale=None):
+                   st: BatchedRasterizationSettings, grad_color, grad_depth, grad_alpha, img, grad_color_scale=None, want_means2D=True):
     L = _cabi.lib()
     S, P, nv, H, W = ctx.dims
     dev = means3D.device
@@ -388,7 +388,7 @@ def _backward_impl(ctx: _Ctx, means3D, opacities, colors_precomp, shs, cov3D_pre
     gD = None if grad_depth is None else _f32c(grad_depth)
     gA = None if grad_alpha is None else _f32c(grad_alpha)
     d_means3D = torch.empty(S, P, 3, dtype=f32, device=dev)
-    d_means2D = torch.empty(nv, P, 3, dtype=f32, device=dev)
+    d_means2D = torch.empty(nv, P, 3, dtype=f32, device=dev) if want_means2D else None     # (dL/dNDC: a [n_views,P,3] write nobody reads on the reference path)
     d_op = torch.empty(S, P, dtype=f32, device=dev)
     d_cov = torch.empty(S, P, 6, dtype=f32, device=dev)
     d_col = torch.empty(S, P, 3, dtype=f32, device=dev) if shs is None else None
@@ -439,7 +439,7 @@ def _bwd_common(ctx, grad_color, grad_depth, grad_alpha, grad_color_scale=None):
     means3D, opacities, colors_precomp, sh, cov3Ds_precomp, scales, rotations, color, depth, alpha = ctx.saved_tensors[:10]
     d_means3D, d_means2D, d_sh, d_col, d_op, d_sc, d_rot, d_cov, _ = _backward_impl(
         ctx.sgr, means3D, opacities, colors_precomp, sh, cov3Ds_precomp, scales, rotations, ctx.st, grad_color, grad_depth,
-        grad_alpha, (color, depth, alpha), grad_color_scale)
+        grad_alpha, (color, depth, alpha), grad_color_scale, want_means2D=ctx.has_means2D)
     has_sh, has_col, has_sr, has_cov = ctx.has
     return (d_means3D, d_means2D if ctx.has_means2D else None, d_sh if has_sh else None, d_col if has_col else None, d_op.unsqueeze(-1),
             d_sc if has_sr else None, d_rot if has_sr else None, d_cov if has_cov else None)
@@ -449,7 +449,7 @@ class _RasterizeGaussiansBatched(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, st):
         color, radii, depth, alpha = _fwd_common(ctx, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, st)
-        ctx.has_means2D = means2D is not None
+        ctx.has_means2D = means2D is not None and ctx.needs_input_grad[1]
         ctx.mark_non_differentiable(radii)
         return color, radii, depth, alpha
 
@@ -494,7 +494,7 @@ class _RasterizeL1Batched(torch.autograd.Function):
 
         color, radii, depth, alpha = _fwd_common(ctx, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, st,
                                                  epilogue, clear=sums)
-        ctx.has_means2D = means2D is not None
+        ctx.has_means2D = means2D is not None and ctx.needs_input_grad[1]
         loss, per_view = sums[nv], sums[:nv]
         ctx.mark_non_differentiable(radii, per_view)
         return loss, per_view, color, radii, depth, alpha
@@ -556,7 +556,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             if not bool(mark_visible(means3D.detach(), rs.viewmatrix).all()):
                 raise RuntimeError("Point is filtered although prefiltered is set. This shouldn't happen!")
         color, radii, depth, alpha = color[0], radii[0], depth[0], alpha[0]
-        ctx.has_means2D = means2D is not None
+        ctx.has_means2D = means2D is not None and ctx.needs_input_grad[1]
         ctx.debug = bool(rs.debug)
         ctx.mark_non_differentiable(radii)
         return color, radii, depth, alpha
@@ -600,6 +600,9 @@ def mark_visible(positions: torch.Tensor, viewmatrix: torch.Tensor) -> torch.Ten
     return out.bool()
 
 
+_EMPTY = torch.Tensor([])          # upstream passes torch.Tensor([]) for every missing optional; one shared instance (never written)
+
+
 class GaussianRasterizer(torch.nn.Module):
     """Same constructor / markVisible / forward contract as upstream's GaussianRasterizer (gs.py:96-106)."""
 
@@ -618,7 +621,7 @@ class GaussianRasterizer(torch.nn.Module):
         if ((scales is None or rotations is None) and cov3D_precomp is None) or \
                 ((scales is not None or rotations is not None) and cov3D_precomp is not None):
             raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
-        e = torch.Tensor([])
+        e = _EMPTY
         shs = e if shs is None else shs
         colors_precomp = e if colors_precomp is None else colors_precomp
         scales = e if scales is None else scales
@@ -649,7 +652,7 @@ def forward_debug(means3D, opacities, *, colors_precomp=None, shs=None, cov3D_pr
         in_b = bool(s_.result_in_b)
         return dict(color=color, radii=radii, depth=depth, alpha=alpha,
                     rec=c.view(0, s_.off_rec, nv * P * 16, f32).view(nv, P, 16),
-                    rect=c.view(0, s_.off_rect, nv * P * 2, i32).view(nv, P, 2),
+                    rect=c.view(0, s_.off_rect, nv * P * 4, i32).view(nv, P, 4)[:, :, :2],
                     clamped=c.view(0, s_.off_clamped, nv * P, u8) if shs is not None else None,
                     point_list=c.view(1, s_.off_vals_b if in_b else s_.off_vals_a, R, i32),
                     keys=c.view(1, s_.off_keys_b if in_b else s_.off_keys_a, R, i64),

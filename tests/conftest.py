@@ -1,7 +1,7 @@
 import os
 import sys
 
-os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")   # before torch/HIP initialise (hipGraph replay gate, csrc/rasterize.hip)
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")   # before torch/HIP initialise: the tests that opt into hipGraph replay need it (csrc/rasterize.hip)
 
 import pytest
 

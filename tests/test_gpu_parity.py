@@ -568,23 +568,26 @@ def test_side_stream_and_graph_replay(oracle):
     bst = _batched_settings(st, dev, 1)._replace(max_rendered=ref.R + 5000)
     h0, m0 = C.c_uint64(0), C.c_uint64(0)
     _cabi.lib().sgr_graph_stats(C.byref(h0), C.byref(m0))
+    _cabi.lib().sgr_set_graphs(1)                            # replay is opt-in; conftest.py exported DEBUG_CLR_GRAPH_PACKET_CAPTURE=0
     side = torch.cuda.Stream()
-    grads = []
+    first, same = None, []
     with torch.cuda.stream(side):
-        for it in range(14):      # the allocator alternates between two pointer sets; each is seen once, captured once, then replayed
+        for it in range(14):      # the allocator alternates between a few pointer sets; each is seen once, captured once, then replayed
             for v in d.values():
                 v.grad = None
             color, radii, depth, alpha = R.rasterize_gaussians_batched(d["means3D"], None, None, d["colors_precomp"],
                                                                        d["opacities"][..., None], None, None, d["cov3D_precomp"], bst)
             (color * color).sum().backward()
-            grads.append(d["means3D"].grad.clone())
+            if first is None:
+                first = d["means3D"].grad.clone()             # (one clone only: a growing list of live clones would shift every later allocation)
+            same.append(torch.equal(d["means3D"].grad, first))  # replayed graph == plain launches, bit for bit
             del color, radii, depth, alpha
     side.synchronize()
-    for g in grads[1:]:
-        assert torch.equal(g, grads[0])                      # replayed graph == plain launches, bit for bit
+    _cabi.lib().sgr_set_graphs(0)
+    assert all(same), same
     h1, m1 = C.c_uint64(0), C.c_uint64(0)
     _cabi.lib().sgr_graph_stats(C.byref(h1), C.byref(m1))
-    assert h1.value > h0.value, "the launch graph was never replayed"
+    assert h1.value > h0.value, f"the launch graph was never replayed (hits {h0.value} -> {h1.value}, misses {m0.value} -> {m1.value})"
 
 
 _HOST_COPY_SCRIPT = r"""
@@ -596,6 +599,7 @@ import numpy as np, torch
 import cases
 from sigman_release_amd import _cabi, cameras
 from sigman_release_amd import rasterizer as R
+_cabi.lib().sgr_set_graphs(1)                                # opt in: replay if the runtime flag is visibly off
 dev = torch.device("cuda", 0)
 inp, st = cases.humanoid(P=20000, H=256, W=256, seed=3)
 t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
@@ -637,7 +641,7 @@ def test_graph_replay_survives_host_copies():
 
 
 def test_graphs_off_without_the_runtime_flag():
-    """Without DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 in the environment the library must not replay graphs (plain launches only)."""
+    """Mode 1 (automatic) without DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 in the environment: the library must not replay graphs."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

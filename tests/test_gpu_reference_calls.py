@@ -266,9 +266,13 @@ def test_debug_and_prefiltered_flags(tmp_path, monkeypatch):
     c0, g0 = run(False)
     h0, m0 = C.c_uint64(0), C.c_uint64(0)
     _cabi.lib().sgr_graph_stats(C.byref(h0), C.byref(m0))
-    for _ in range(4):
-        c1, g1 = run(True)
-        assert torch.equal(c0, c1) and torch.equal(g0, g1)
+    _cabi.lib().sgr_set_graphs(2)                                           # even with replay forced on ...
+    try:
+        for _ in range(4):
+            c1, g1 = run(True)
+            assert torch.equal(c0, c1) and torch.equal(g0, g1)
+    finally:
+        _cabi.lib().sgr_set_graphs(0)
     h1, m1 = C.c_uint64(0), C.c_uint64(0)
     _cabi.lib().sgr_graph_stats(C.byref(h1), C.byref(m1))
     assert h1.value == h0.value, "debug mode must not replay launch graphs"

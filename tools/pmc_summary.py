@@ -1,37 +1,87 @@
-"""Dev tool: turn two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of `bench.py` into profiles/<name>.json.
-usage: python tools/pmc_summary.py <dir_fetch> <dir_write> <out.json> "<workload note>"
-Correction (MI355X_MICROARCH.md, HBM / rocprofv3 section): on gfx950 FETCH_SIZE counts 64 B per 128-B request for 16 B/lane loads,
-so read bytes ~= 2 x FETCH_SIZE (KB); WRITE_SIZE is taken as is (KB)."""
-import csv, glob, json, statistics, sys
+"""Dev tool: turn two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) + a --kernel-trace --stats pass of `bench.py --config <c>` into
+profiles/r02_pmc_<c>.json (what bench.py reads `roofline.traffic` from) and print a per-kernel table (markdown) with the algorithmic
+bytes of SURVEY.md 8(d) next to the counters.
+usage: python tools/pmc_summary.py <config> <dir_fetch> <dir_write> <kernel_stats.csv> <bench.json> <out.json>
+Correction (MI355X_MICROARCH.md, HBM section): on gfx950 FETCH_SIZE counts 64 B per 128-B request for wide coalesced reads, so read bytes
+~= 2 x FETCH_SIZE (KB); WRITE_SIZE is taken as is (KB).  Calibration on this code: clamped_l1_kernel reads color + target and writes the
+gradient image, 3 x 4 B per pixel and channel each way -- see the `calibration` entry of the output."""
+import csv, glob, json, re, statistics, subprocess, sys
 
-SHORT = {"render_bwd_bucket": "render_bwd", "render_bwd_kernel": "render_bwd", "render_fwd": "render_fwd", "tile_sort": "tile_sort",
-         "wide_downsweep": "radix_downsweep", "wide_upsweep": "radix_upsweep", "wide_rowscan": "radix_rowscan",
-         "radix_downsweep": "radix_downsweep", "radix_upsweep": "radix_upsweep", "radix_rowscan": "radix_rowscan",
-         "preprocess_bwd": "preprocess_bwd", "preprocess_fwd": "preprocess_fwd", "duplicate_keys": "duplicate_keys",
-         "clamped_l1": "clamped_l1", "tile_ranges": "tile_ranges", "scan_block_sums": "scan_block_sums", "fwd_prepare": "fwd_prepare"}
+GROUPS = [  # (bench kernel id name, regex over rocprof kernel names)
+    ("preprocess_fwd", r"preprocess_fwd_kernel"), ("scan_block_sums", r"scan_block_sums_kernel"), ("duplicate_keys", r"duplicate_keys_kernel"),
+    ("radix_sort(all passes)", r"(wide_|radix_|vseg_|tile_sort)"), ("tile_ranges", r"tile_ranges_kernel"),
+    ("render_fwd", r"(render_fwd|fwd_prepare)"), ("render_bwd", r"render_bwd"), ("preprocess_bwd", r"preprocess_bwd_kernel"),
+    ("clamped_l1", r"clamped_l1_kernel"),
+]
 
 
-def load(d, counter):
+def short(name):
+    m = re.search(r"(\w+_kernel(<[^>]*>)?)", name)
+    return m.group(1) if m else name[:60]
+
+
+def load_pmc(d, counter):
     per = {}
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            if r["Counter_Name"] != counter:
-                continue
-            name = next((v for k, v in SHORT.items() if k in r["Kernel_Name"]), None)
-            if name:
-                per.setdefault(name, []).append(float(r["Counter_Value"]))
+            if r["Counter_Name"] == counter:
+                per.setdefault(short(r["Kernel_Name"]), []).append(float(r["Counter_Value"]))
     return per
 
 
-fetch, write = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
-out = {"command": "SIGMAN_GRAPHS=0 rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- python bench.py "
-                  "--no-cpu-baseline --steps 5 --warmup 3 (two separate passes)",
-       "units": "KB per launch (median over launches), raw counter values; MI355X_MICROARCH.md: on gfx950 FETCH_SIZE counts 64 B per "
-                "128-B request for 16 B/lane loads -> read bytes ~= 2 x FETCH_SIZE; WRITE_SIZE uncalibrated",
-       "workload": sys.argv[4], "kernels": {}}
-for k in sorted(set(fetch) | set(write)):
-    f = statistics.median(fetch.get(k, [0.0])); w = statistics.median(write.get(k, [0.0]))
-    out["kernels"][k] = {"launches_per_run": len(fetch.get(k, [])), "fetch_size_kb": round(f, 1), "write_size_kb": round(w, 1),
-                         "hbm_bytes_corrected": int((2 * f + w) * 1024)}
-json.dump(out, open(sys.argv[3], "w"), indent=1)
-print(json.dumps(out["kernels"], indent=1))
+def main():
+    cfg, dfetch, dwrite, stats_csv, bench_json, out_path = sys.argv[1:7]
+    fetch, write = load_pmc(dfetch, "FETCH_SIZE"), load_pmc(dwrite, "WRITE_SIZE")
+    bench = json.loads([l for l in open(bench_json) if l.startswith("{")][-1])
+    stats = {short(r["Name"]): (float(r["AverageNs"]) / 1e3, int(r["Calls"])) for r in csv.DictReader(open(stats_csv))}
+    c = bench["config"]
+    P, HW = int(re.search(r"(\d+) Gaussians/subject", c["workload"]).group(1)), None
+    size = int(re.search(r"(\d+)x\d+,", c["workload"]).group(1))
+    slots, Rn = c["view_slots_this_gpu"], c["num_rendered_per_gpu"]
+    bwd = "fwd+bwd" in c["workload"]
+    HW, tiles = size * size * slots, ((size + 15) // 16) ** 2 * slots
+    nq = P * slots
+    alg = {"preprocess_fwd": 76 * nq, "scan_block_sums": 8 * nq, "duplicate_keys": 20 * nq + 12 * Rn, "radix_sort(all passes)": 24 * Rn,
+           "tile_ranges": 8 * Rn + 8 * tiles, "render_fwd": 44 * Rn + 24 * HW, "render_bwd": 88 * Rn + 28 * HW, "preprocess_bwd": 108 * nq,
+           "clamped_l1": 36 * HW}
+    # launches per step: total calls / steps is unreliable under warm-up; use median KB per launch x launches of one step (= kernels that share a group)
+    out = {"config": cfg, "P": P, "size": size, "view_slots": slots, "num_rendered": Rn,
+           "command": f"SIGMAN_GRAPHS=0 rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- python bench.py --config {cfg} "
+                      "--no-cpu-baseline --no-variants --steps 5 --warmup 3 (two separate passes); durations from a third pass with --kernel-trace --stats",
+           "units": "bytes per launch group and step: sum over the group's kernels of (median counter KB per launch x 1024); reads corrected 2 x FETCH_SIZE "
+                    "(MI355X_MICROARCH.md: FETCH_SIZE tallies 128-B requests at 64 B on gfx950); WRITE_SIZE as is",
+           "kernels": {}, "per_kernel": {}}
+    try:
+        out["commit"] = subprocess.check_output(["git", "rev-parse", "--short", "HEAD"], text=True).strip()
+    except Exception:
+        pass
+    calls = {k: v[1] for k, v in stats.items()}
+    n_fwd = max(calls.get("duplicate_keys_kernel", 1), 1)                      # forwards in the profiled run (timed steps + probe / gt renders)
+    for k in sorted(set(fetch) | set(write)):
+        f, w = statistics.median(fetch.get(k, [0.0])), statistics.median(write.get(k, [0.0]))
+        us, n = stats.get(k, (0.0, 0))
+        fwd_chain = bool(re.search(r"(preprocess_fwd|scan_block|duplicate|wide_|radix_|vseg_|tile_sort|tile_ranges|fwd_prepare)", k))
+        per_step = max(1, round(n / n_fwd)) if fwd_chain else 1                # launches of this kernel per forward (radix passes: several)
+        out["per_kernel"][k] = {"fetch_size_kb": round(f, 1), "write_size_kb": round(w, 1), "hbm_bytes_corrected": int((2 * f + w) * 1024),
+                                "avg_us": round(us, 2), "launches_per_step": per_step}
+    print(f"| kernel(s) | us / step | algorithmic MB | achieved GB/s | frac of 8 TB/s | counter MB | traffic / algorithmic |\n|---|---|---|---|---|---|---|")
+    for g, rx in GROUPS:
+        ks = [k for k in out["per_kernel"] if re.search(rx, k)]
+        if g == "render_fwd" and bwd:      # the untimed gt / counter renders use the kernel without auxiliary outputs: keep the training variant only
+            ks = [k for k in ks if "<0>" not in k] or ks
+        if not ks:
+            continue
+        tot = sum(out["per_kernel"][k]["hbm_bytes_corrected"] * out["per_kernel"][k]["launches_per_step"] for k in ks)
+        us = sum(out["per_kernel"][k]["avg_us"] * out["per_kernel"][k]["launches_per_step"] for k in ks)
+        out["kernels"][g] = {"members": ks, "hbm_bytes_corrected": tot, "us": round(us, 2), "algorithmic_bytes": alg.get(g)}
+        a = alg.get(g, 0)
+        if us > 0 and a:
+            print(f"| {g} | {us:.1f} | {a / 1e6:.2f} | {a / us / 1e3:.0f} | {a / us / 1e3 / 8000:.3f} | {tot / 1e6:.2f} | {tot / a:.1f}x |")
+    if "clamped_l1_kernel" in out["per_kernel"]:
+        k = out["per_kernel"]["clamped_l1_kernel"]
+        out["calibration"] = {"kernel": "clamped_l1_kernel", "known_read_bytes": 24 * HW, "known_write_bytes": 12 * HW,
+                              "fetch_size_x2_bytes": int(2 * k["fetch_size_kb"] * 1024), "write_size_bytes": int(k["write_size_kb"] * 1024)}
+    json.dump(out, open(out_path, "w"), indent=1)
+
+
+main()
