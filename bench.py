@@ -241,6 +241,8 @@ def main(args):
         out.backward(one)                 # explicit seed: autograd would otherwise launch a ones_like fill kernel every step
         return out
 
+    pending = []          # N > 1, exchange="loss": the previous step's loss all-reduce
+
     def step():
         if not bwd:
             with torch.no_grad():
@@ -254,8 +256,16 @@ def main(args):
         def rl(m, c, o, r, mv):
             out = render_loss(m, c, o, r, mv)
             return (out[0], [out[4], out[5]], [gD, gA]) if da else out     # C5: dL/ddepth, dL/dalpha seeded with the loss in one backward
-        loss, _grad = parallel.view_parallel_step(packed, all_views, rl, exchange=args.exchange if args.config in ("c2", "c5") else "loss",
-                                                  seed_grad=one, pack_grad=False)
+        ex = args.exchange if args.config in ("c2", "c5") else "loss"
+        if ex == "loss":
+            # the loss value is only read after the timed region: its all-reduce is waited for one step later (it overlaps the backward AND the
+            # next forward; the 4-byte collective's latency never sits between two steps)
+            loss, _grad, work = parallel.view_parallel_step(packed, all_views, rl, exchange="loss", seed_grad=one, pack_grad=False, wait=False)
+            if pending and pending[0] is not None:
+                pending[0].wait()
+            pending[:] = [work]
+            return loss
+        loss, _grad = parallel.view_parallel_step(packed, all_views, rl, exchange=ex, seed_grad=one, pack_grad=False)
         return loss
 
     L = _cabi.lib()
@@ -269,6 +279,9 @@ def main(args):
         return {k: (ms[k], cnt[k]) for k in range(16) if cnt[k]}
 
     def sync_all():
+        if pending and pending[0] is not None:
+            pending[0].wait()
+            pending[:] = []
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()

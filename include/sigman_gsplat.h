@@ -97,7 +97,9 @@ typedef struct SgrForwardState {
     uint64_t R_alloc;            /* size of the binning buffers in tile instances: exact num_rendered, or the capacity */
     uint64_t true_rendered;      /* exact mode: num_rendered; sync-free mode: ~0 (read nr_pinned_host after nr_event) */
     uint64_t NS;                 /* bucket slots per quadrant */
-    int32_t with_aux /* 0 none, 1 compact checkpoints, 2 row checkpoints */, result_in_b, flags_cleared, _pad;
+    int32_t with_aux /* 0 none, 1 compact checkpoints, 2 row checkpoints */, result_in_b, flags_cleared;
+    int32_t nr_by_copy;          /* sync-free mode: 1 = the count reaches nr_pinned_host through an async device-to-host COPY (not byte-atomic: wait for
+                                    nr_event before reading it); 0 = through one 8-byte store of a kernel (the word may be polled) */
     void *geom, *binning, *image;
     uint64_t geom_bytes, binning_bytes, image_bytes;
     uint64_t off_rec, off_rect, off_clamped, off_block_offsets, off_num_rendered;               /* in geom   */
@@ -109,8 +111,9 @@ typedef struct SgrForwardState {
  * == upstream _C.rasterize_gaussians (gs.py:98-106), for all n_views view slots at once.
  * capacity = 0: exact mode, ONE blocking read of num_rendered per call (upstream: one per view).
  * capacity > 0: sync-free mode; binning buffers sized for `capacity` instances; the true count reaches nr_pinned_host[0]
- *               asynchronously as ONE 8-byte word, count | overflow << 63 (a single store / 8-byte copy, so the host can never
- *               see the count without its flag), and `nr_event` (a hipEvent_t, may be NULL) is recorded right after.
+ *               asynchronously as ONE 8-byte word, count | overflow << 63 (the host can never see the count without its flag), and
+ *               `nr_event` (a hipEvent_t, may be NULL) is recorded right after.  state->nr_by_copy tells how the word travels: a
+ *               kernel's single 8-byte store (poll-able) or an async copy (a copy engine may write it piecewise: wait for nr_event).
  *               (exact mode fills nr_pinned_host[0] = count, [1] = overflow flag before it returns.)
  * with_aux != 0 also records what the bucket-parallel backward needs.
  * alloc may be NULL if state->geom / binning / image and their *_bytes capacities are pre-filled by the caller (sizes as reported in

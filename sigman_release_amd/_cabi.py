@@ -29,7 +29,7 @@ class SgrProblem(C.Structure):
 
 class SgrForwardState(C.Structure):
     _fields_ = [("R_alloc", C.c_uint64), ("true_rendered", C.c_uint64), ("NS", C.c_uint64), ("with_aux", C.c_int32), ("result_in_b", C.c_int32),
-                ("flags_cleared", C.c_int32), ("_pad", C.c_int32),
+                ("flags_cleared", C.c_int32), ("nr_by_copy", C.c_int32),
                 ("geom", C.c_void_p), ("binning", C.c_void_p), ("image", C.c_void_p),
                 ("geom_bytes", C.c_uint64), ("binning_bytes", C.c_uint64), ("image_bytes", C.c_uint64)] + \
                [(n, C.c_uint64) for n in ("off_rec", "off_rect", "off_clamped", "off_block_offsets", "off_num_rendered", "off_keys_a",

@@ -98,6 +98,7 @@ static int forward_launches(const SgrProblem *pb, uint64_t capacity, uint64_t R,
     if (!preprocess_done) {
         if (sgr_preprocess_forward_ex(pb, rec, out_radii, rect, clamped, block_offsets, num_rendered, capacity, self_scan, stream)) return 1;
         if (nr_pinned_host && !self_scan) SGR_CHECK_HIP(hipMemcpyAsync(nr_pinned_host, num_rendered + 2, 8, hipMemcpyDeviceToHost, stream));   // count | overflow << 63
+        st->nr_by_copy = self_scan ? 0 : 1;
     }
     int32_t in_b = 0;
     const bool aux_on = st->with_aux != 0;
@@ -232,6 +233,7 @@ extern "C" int sgr_rasterize_forward(const SgrProblem *pb, uint64_t capacity, in
         if (found >= 0 && g_fwd[found].exec) {
             g_fwd[found].stamp = ++g_stamp; g_graph_hits++; g_miss_streak = 0;
             *st = g_fwd[found].st;
+            st->nr_by_copy = 1;
             SGR_CHECK_HIP(hipGraphLaunch(g_fwd[found].exec, stream));
             if (nr_pinned_host) SGR_CHECK_HIP(hipMemcpyAsync(nr_pinned_host, num_rendered + 2, 8, hipMemcpyDeviceToHost, stream));
             if (nr_event) SGR_CHECK_HIP(hipEventRecord((hipEvent_t)nr_event, stream));
@@ -263,6 +265,7 @@ extern "C" int sgr_rasterize_forward(const SgrProblem *pb, uint64_t capacity, in
                 if (rc == 0 && e1 == hipSuccess && graph && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess) {
                     (void)hipGraphDestroy(graph);
                     g_fwd[found].exec = exec; g_fwd[found].st = *st; g_fwd[found].stamp = ++g_stamp;
+                    st->nr_by_copy = 1;
                     SGR_CHECK_HIP(hipGraphLaunch(exec, stream));
                     if (nr_pinned_host) SGR_CHECK_HIP(hipMemcpyAsync(nr_pinned_host, num_rendered + 2, 8, hipMemcpyDeviceToHost, stream));
                     if (nr_event) SGR_CHECK_HIP(hipEventRecord((hipEvent_t)nr_event, stream));

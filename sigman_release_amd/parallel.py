@@ -63,7 +63,8 @@ def _backward(loss, seed_grad, extra_out, extra_grad):
 
 
 def view_parallel_step(packed: torch.Tensor, view_ids: Sequence[int], render_loss: Callable, *, src: int = 0, group=None,
-                       broadcast: bool = True, exchange: str = "full", seed_grad: torch.Tensor = None, pack_grad: bool = True):
+                       broadcast: bool = True, exchange: str = "full", seed_grad: torch.Tensor = None, pack_grad: bool = True,
+                       wait: bool = True):
     """One fwd+bwd step of a subject whose views are sharded over the ranks of `group`.
 
     packed      flat [13*P] attributes (pack_attributes); exchange="full": only rank `src` needs valid contents when broadcast=True
@@ -76,6 +77,9 @@ def view_parallel_step(packed: torch.Tensor, view_ids: Sequence[int], render_los
     seed_grad   optional 0-d ones tensor for loss.backward() (saves the fill kernel autograd would launch for it)
     pack_grad   exchange="loss" only: False returns the partial gradient as the tuple (d_means3D, d_cov3D, d_opacity, d_rgb) of the
                 autograd leaves instead of one concatenated [13*P] buffer (saves a copy kernel when the caller consumes them separately)
+    wait        exchange="loss" only: False does not wait for the loss all-reduce: returns (loss tensor, grad, work) and the caller calls
+                work.wait() before it READS the loss (a training loop only logs it) -- the collective then overlaps the next step as well,
+                and the 4-byte all-reduce's latency never sits between two steps
     """
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -98,6 +102,8 @@ def view_parallel_step(packed: torch.Tensor, view_ids: Sequence[int], render_los
         else:
             grads = [torch.zeros_like(l) for l in leaves]
         grad = torch.cat([g.reshape(-1) for g in grads]) if pack_grad else tuple(grads)
+        if not wait:
+            return loss_val[0], grad, work
         if work is not None:
             work.wait()
         return loss_val[0], grad

@@ -98,14 +98,16 @@ class _Slot:
     """One pinned 16-byte host slot + one event for the asynchronous num_rendered read-back of ONE forward.  Sync-free mode: the
     library publishes word [0] = count | overflow << 63 (a single 8-byte store / copy; -1 = not there yet).  Exact mode: [0] = count,
     [1] = overflow flag, both final when the call returns."""
-    __slots__ = ("pool", "np", "ptr", "ev", "handle", "capacity", "checked", "result")
+    __slots__ = ("pool", "np", "ptr", "ev", "handle", "capacity", "checked", "result", "by_copy")
 
     def arrived(self):
-        return int(self.np[0]) != -1
+        # a kernel publishes the word with ONE 8-byte store: polling it is safe.  An async device-to-host copy may land piecewise
+        # (observed: bytes 0-4 of the count next to three bytes of the -1 sentinel), so there only the event says "complete".
+        return self.ev.query() if self.by_copy else int(self.np[0]) != -1
 
     def read(self, block: bool):
         """(count, overflow) or None if the word has not arrived and block is False."""
-        if int(self.np[0]) == -1:
+        if not self.arrived():
             if not block:
                 return None
             self.ev.synchronize()
@@ -139,7 +141,7 @@ class _SlotPool:
         sl = self.free.pop()
         sl.np[0] = -1                           # sentinel: "the count has not arrived yet"
         sl.np[1] = 0
-        sl.capacity, sl.checked, sl.result = capacity, False, None
+        sl.capacity, sl.checked, sl.result, sl.by_copy = capacity, False, None, True
         return sl
 
     def release(self, sl):
@@ -327,6 +329,7 @@ def _forward_impl(means3D, opacities, colors_precomp, shs, cov3D_precomp, scales
     if status != 0:
         _pool(dev).release(slot)
     _cabi.check(status, "sgr_rasterize_forward")
+    slot.by_copy = bool(state.nr_by_copy)
     pending = capacity > 0 and P > 0           # sync-free: the count is still on its way to the pinned slot
     if pending and (auto_key is not None or not use_aux):
         # automatic mode, and explicit sync-free forwards that will never see a backward (no input needs a gradient: torch.no_grad(),

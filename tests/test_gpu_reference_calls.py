@@ -303,3 +303,24 @@ def test_loss_gradient_at_exact_zero_and_one():
     assert abs(float(got) - float(want)) <= 1e-5 * abs(float(want))
     assert torch.equal(color.grad, ref_in.grad)
     assert float(color.grad[0, 0, 0, 0].abs()) > 0 or float(mask[0, 0, 0, 0]) == 0      # x == 0.0 exactly: gradient passes
+
+
+def test_count_published_by_copy_is_never_read_torn():
+    """Large sync-free launches (> 2048 preprocess workgroups) publish the instance count through an async device-to-host copy instead of
+    a kernel store; a copy engine may write the 8-byte word piecewise, so the host must wait for the event instead of polling the word
+    (seen as 'num_rendered 9223370937365261137 exceeds max_rendered' in the 2-rank C4 bench).  Automatic-capacity mode polls after every
+    forward: 40 forwards must all agree with exact mode."""
+    from sigman_release_amd import rasterizer as R
+    dev = _dev()
+    V, P, H = 12, 60_000, 256
+    g = synthetic.humanoid(P, 5)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    cv, cvp, cp = cameras.make_cameras([30, 37, 45, 53, 65, 85, 0, 8, 10, 20, 40, 50])
+    st = R.BatchedRasterizationSettings(H, H, cameras.TAN_HALF_FOV, cameras.TAN_HALF_FOV, torch.ones(3, device=dev), 1.0, t(cv), t(cvp), 0, t(cp), V)
+    args = (t(g["position"])[None], None, None, t(g["rgb"])[None], t(g["opacity"])[None], None, None, t(synthetic.covariance_from_gaussians(g))[None])
+    with torch.no_grad():
+        want = R.rasterize_gaussians_batched(*args, st)[0]
+        for it in range(40):
+            got = R.rasterize_gaussians_batched(*args, st._replace(max_rendered=-1))[0]
+            assert torch.equal(got, want), it
+    R.check_pending_overflows(block=True)

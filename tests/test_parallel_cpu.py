@@ -56,6 +56,11 @@ def _worker(rank, world, port, q):
     # north_star protocol: replicated attributes (here: what the broadcast above left on every rank), loss all-reduce only,
     # overlapped with the backward; the gradient stays the rank's partial sum over its own views
     loss2, grad2 = parallel.view_parallel_step(packed, VIEWS, _render_loss_factory(st, H, W), exchange="loss")
+    # deferred wait: same numbers, the caller waits before it reads the loss
+    loss3, grad3, work = parallel.view_parallel_step(packed, VIEWS, _render_loss_factory(st, H, W), exchange="loss", wait=False)
+    if work is not None:
+        work.wait()
+    assert float(loss3) == float(loss2) and torch.equal(grad3, grad2)
     gsum = grad2.clone()
     dist.all_reduce(gsum)
     q.put((rank, float(loss), grad.numpy(), float(loss2), gsum.numpy(), float(grad2.abs().sum())))

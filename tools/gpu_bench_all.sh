@@ -1,0 +1,10 @@
+# all bench configs on one GPU (+ the 2-rank plumbing check over gloo): JSON lines under gpurun_out/<tag>/      usage: gpu_bench_all.sh <tag>
+set -x
+O=gpurun_out/$1; mkdir -p $O
+timeout 900 python bench.py > $O/bench_c2.json 2> $O/bench_c2.err; tail -c 2500 $O/bench_c2.json
+for c in c3 c4 c5; do timeout 900 python bench.py --config $c > $O/bench_$c.json 2> $O/bench_$c.err; python -c "
+import json; d=json.load(open('$O/bench_$c.json')); print('$c', d['value'], d['ms_per_step'], d['roofline'], d['kernel_ms_per_step'], d.get('variants'))"; tail -3 $O/bench_$c.err; done
+SIGMAN_BENCH_BACKEND=gloo timeout 600 python bench.py --gpus 2 --steps 50 --warmup 10 > $O/bench_c2_n2gloo.json 2> $O/bench_c2_n2gloo.err; tail -c 600 $O/bench_c2_n2gloo.json; tail -3 $O/bench_c2_n2gloo.err
+SIGMAN_BENCH_BACKEND=gloo timeout 600 python bench.py --gpus 2 --config c3 --steps 5 --warmup 2 > $O/bench_c3_n2gloo.json 2> $O/bench_c3_n2gloo.err; tail -c 600 $O/bench_c3_n2gloo.json
+SIGMAN_BENCH_BACKEND=gloo timeout 600 python bench.py --gpus 2 --config c5 --steps 10 --warmup 3 > $O/bench_c5_n2gloo.json 2> $O/bench_c5_n2gloo.err; tail -c 600 $O/bench_c5_n2gloo.json; tail -3 $O/bench_c5_n2gloo.err
+SIGMAN_BENCH_BACKEND=gloo timeout 600 python bench.py --gpus 2 --config c4 --steps 5 --warmup 2 > $O/bench_c4_n2gloo.json 2> $O/bench_c4_n2gloo.err; tail -c 600 $O/bench_c4_n2gloo.json; tail -3 $O/bench_c4_n2gloo.err
