@@ -99,6 +99,28 @@ def lib():
     return _lib
 
 
+_node = False
+
+
+def torch_node():
+    """The C++ autograd node of the single-view op (csrc/torch_node.cpp -> lib/sgr_torch_node.so), or None if it is not built or
+    SIGMAN_PY_NODE=1 asks for the Python node (both drive the same C ABI; the C++ one only costs less host time per call)."""
+    global _node
+    if _node is False:
+        _node = None
+        path = os.path.join(_HERE, "lib", "sgr_torch_node.so")
+        if os.environ.get("SIGMAN_PY_NODE", "0") != "1" and os.path.exists(path):
+            lib()                                               # libsigman_gsplat.so first (the node links against it)
+            import importlib.util
+            spec = importlib.util.spec_from_file_location("sgr_torch_node", path)
+            mod = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(mod)
+            if mod.abi_version() != 2:
+                raise RuntimeError("sgr_torch_node.so was built against another ABI version of libsigman_gsplat.so: rebuild (make -C sigman_release_amd/csrc)")
+            _node = mod
+    return _node
+
+
 def check(status: int, what: str):
     if status != 0:
         msg = lib().sgr_last_error().decode("utf-8", "replace")

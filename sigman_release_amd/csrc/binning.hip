@@ -1447,6 +1447,13 @@ int sgr_bin_ex(const SgrProblem *pb, float *rec, const int32_t *radii, const uin
         if (!all_large)
             hipLaunchKernelGGL((tile_sort_kernel<256, kSegCapSmall, true>), dim3((uint32_t)tiles_total), dim3(256), 0, stream,
                                (const uint2 *)ranges, kin, vin, kout, vout, worklist, none);
+        // one or two views: every occupied tile is a workgroup of this launch, at most one per CU is resident anyway -- so give it 150 KB of
+        // LDS and keep tiles of up to 8192 entries out of the global-memory fallback (side views of the humanoid have 6000-entry tiles:
+        // 66 -> ~45 us for the launch, whose duration is its heaviest tile's)
+        if (all_large)
+            hipLaunchKernelGGL((tile_sort_kernel<1024, 2 * kSegCapLarge, false>), dim3(big_grid + (sp.enabled ? 1u : 0u)), dim3(1024), 0, stream,
+                               (const uint2 *)ranges, kin, vin, kout, vout, worklist, sp);
+        else
         hipLaunchKernelGGL((tile_sort_kernel<1024, kSegCapLarge, false>), dim3(big_grid + (sp.enabled ? 1u : 0u)), dim3(1024), 0, stream,
                            (const uint2 *)ranges, kin, vin, kout, vout, worklist, sp);
         if (sp.enabled && prep_done) *prep_done = 1;

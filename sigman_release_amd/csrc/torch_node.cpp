@@ -1,0 +1,334 @@
+// torch_node.cpp -- the upstream-signature single-view op (`rasterize_gaussians`, what /root/reference/core/gaussians/gs.py:98-106
+// reaches once per view through GaussianRasterizer.forward, and train_vae.py:166 through its backward) as a C++ autograd node
+// above the C ABI of libsigman_gsplat.so.
+//
+// Why it exists: the reference calls the rasterizer B*V = 64 times per step from a Python loop.  With the node written in Python
+// (sigman_release_amd/rasterizer.py, _RasterizeGaussians) the host needs ~150 us to issue one forward and ~65 us for one backward
+// -- more than the ~170 us the single-view kernels take -- so that loop was host-bound ("the reference's own
+// call pattern").  This file does the same bookkeeping natively: fp32 / contiguity normalisation, the automatic sync-free capacity
+// (exact the first time a shape is seen, then pre-sized buffers with the instance count polled from a pinned word that the
+// emission kernel stores, transparent exact re-run on overflow), PyTorch-owned output / workspace tensors handed to the library
+// through the allocator callback of include/sigman_gsplat.h, saved state for the backward.
+//
+// Count check policy (the point of this node).  The automatic mode has to know whether the forward fitted its pre-sized buffers.  Waiting
+// for the count inside the call -- what the Python node does -- stops the host from running ahead of the GPU: the count of view v+1 is
+// queued behind view v's sort and compositing kernels, so every view pays its launch latencies in the open (measured: 160 us of
+// forward pipeline per view for 114 us of kernels).  Here a shape's capacity is LEARNED with inline checks (exact first call, then
+// inline until it has been stable for 8 calls), then raised to 2x the largest count seen and the check is DEFERRED: the count of a
+// forward is looked at by the next forwards of the thread (it has long arrived) or by its own backward, whichever comes first.  A
+// deferred overflow cannot be repaired (the truncated image has been handed out), so it raises RuntimeError from that later call,
+// re-enters the learning phase and names the numbers; the reference's caller swallows exceptions of the render call
+// (core/modules/autoencoder.py:349-361), upstream's own failure mode for exhausted buffers.  SIGMAN_COUNT_CHECK=inline keeps the
+// inline check forever.
+//
+// PyTorch is plumbing here (tensors, streams, autograd graph); every kernel launch happens inside sgr_rasterize_forward /
+// sgr_rasterize_backward.  Built by csrc/Makefile with g++ against the installed torch headers (no device code in this file).
+// The Python node stays as the reference implementation of the same logic (debug / prefiltered calls and builds without this
+// module use it); tests/test_gpu_reference_calls.py runs both.
+#include <torch/extension.h>
+#include <c10/hip/HIPStream.h>
+#include <hip/hip_runtime_api.h>
+
+#include <array>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "../../include/sigman_gsplat.h"
+
+namespace {
+
+using at::Tensor;
+using torch::autograd::AutogradContext;
+using torch::autograd::variable_list;
+
+#define SGR_TORCH_CHECK_HIP(expr) do { hipError_t e_ = (expr); TORCH_CHECK(e_ == hipSuccess, #expr, " failed: ", hipGetErrorString(e_)); } while (0)
+
+// ---- pinned words + events for the asynchronous instance count: one per forward whose count nobody has looked at yet
+struct CountSlot { uint64_t *host = nullptr; hipEvent_t ev = nullptr; int dev = 0; };
+struct Pending { CountSlot slot; std::tuple<int, int64_t, int64_t, int64_t> key; uint64_t capacity; bool by_copy; bool checked = false; uint64_t count = 0; bool overflow = false, reported = false; int64_t id = 0; };
+struct ThreadState {
+    std::vector<CountSlot> free_slots;
+    std::vector<std::shared_ptr<Pending>> pending;       // deferred checks of this thread, oldest first
+};
+ThreadState &tstate() { thread_local ThreadState t; return t; }
+CountSlot acquire_slot(int dev) {
+    ThreadState &t = tstate();
+    for (size_t i = 0; i < t.free_slots.size(); i++)
+        if (t.free_slots[i].dev == dev) { CountSlot s = t.free_slots[i]; t.free_slots.erase(t.free_slots.begin() + (long)i); return s; }
+    CountSlot s;
+    s.dev = dev;
+    SGR_TORCH_CHECK_HIP(hipHostMalloc((void **)&s.host, 16, hipHostMallocDefault));
+    SGR_TORCH_CHECK_HIP(hipEventCreateWithFlags(&s.ev, hipEventDisableTiming));
+    return s;
+}
+void release_slot(const CountSlot &s) { tstate().free_slots.push_back(s); }
+
+struct KeyState { uint64_t capacity = 0, max_count = 0; int stable = 0; bool deferred = false; };
+std::mutex g_mu, g_pend_mu;            // g_pend_mu: a Pending is shared by the issuing thread's list and the autograd thread's backward
+std::map<int64_t, std::shared_ptr<Pending>> g_by_id;     // deferred checks a backward may still want to look at
+int64_t g_next_id = 1;
+std::map<std::tuple<int, int64_t, int64_t, int64_t>, KeyState> g_keys;                            // (device, P, H, W) -> learned capacity and check policy
+std::map<std::tuple<int, int64_t, int64_t, int64_t, uint64_t, int, int>, std::array<uint64_t, 3>> g_blob_sizes;
+
+struct AllocCtx { c10::Device dev{c10::kCUDA, 0}; Tensor blob[4]; };
+char *alloc_cb(void *user, int32_t which, size_t bytes) {
+    AllocCtx *a = (AllocCtx *)user;
+    a->blob[which] = at::empty({(int64_t)(bytes < 256 ? 256 : bytes)}, at::TensorOptions().dtype(at::kByte).device(a->dev));
+    return (char *)a->blob[which].data_ptr();
+}
+
+inline Tensor f32c(const Tensor &t) { return (t.scalar_type() == at::kFloat && t.is_contiguous()) ? t : t.to(at::kFloat).contiguous(); }
+inline const float *fptr(const Tensor &t) { return (t.defined() && t.numel() > 0) ? t.data_ptr<float>() : nullptr; }
+
+bool inline_forever() { static const bool v = [] { const char *e = getenv("SIGMAN_COUNT_CHECK"); return e && std::string(e) == "inline"; }(); return v; }
+
+// reads a slot's word if it is there (block: wait for it); true = resolved
+bool resolve(Pending &p, bool block) {
+    std::lock_guard<std::mutex> pl(g_pend_mu);
+    if (p.checked) return true;
+    volatile uint64_t *w = p.slot.host;
+    bool there = p.by_copy ? hipEventQuery(p.slot.ev) == hipSuccess : *w != ~0ull;
+    if (!there) {
+        if (!block) return false;
+        SGR_TORCH_CHECK_HIP(hipEventSynchronize(p.slot.ev));
+    }
+    const uint64_t word = *w;
+    p.count = word & ~(1ull << 63); p.overflow = (word >> 63) != 0; p.checked = true;
+    release_slot(p.slot);
+    g_by_id.erase(p.id);
+    std::lock_guard<std::mutex> l(g_mu);
+    KeyState &k = g_keys[p.key];
+    if (p.overflow) { k = KeyState(); return true; }            // back to the learning phase (exact next call)
+    if (p.count > k.max_count) k.max_count = p.count;
+    if (k.deferred && p.count * 10 > k.capacity * 6) {            // getting close: more head-room for the calls to come
+        uint64_t c = 2 * p.count + 4096;
+        k.capacity = c > 0xFFFFFFE0ull ? 0xFFFFFFE0ull : c;
+    }
+    return true;
+}
+[[noreturn]] void raise_deferred(Pending &p) {
+    p.reported = true;
+    TORCH_CHECK(false, "num_rendered ", p.count, " exceeded the automatic capacity ", p.capacity, " of an EARLIER forward of this thread, whose image is "
+                "therefore truncated (its count is checked after the fact once a shape's capacity has been stable; the capacity is being re-learned now; "
+                "SIGMAN_COUNT_CHECK=inline keeps the check inside every call)");
+}
+// deferred checks of earlier forwards: non-blocking unless too many are outstanding
+void poll_pending() {
+    ThreadState &t = tstate();
+    std::shared_ptr<Pending> bad;
+    size_t keep = 0;
+    for (size_t i = 0; i < t.pending.size(); i++) {
+        Pending &p = *t.pending[i];
+        const bool done = p.checked || resolve(p, t.pending.size() - i > 128);
+        if (done && p.overflow && !p.reported && !bad) bad = t.pending[i];
+        if (!done) t.pending[keep++] = t.pending[i];
+    }
+    t.pending.resize(keep);
+    if (bad) raise_deferred(*bad);
+}
+
+void check_status(int status, const char *what) { TORCH_CHECK(status == 0, what, " failed: ", sgr_last_error()); }
+
+SgrProblem make_problem(int64_t P, int64_t H, int64_t W, int64_t sh_degree, int64_t M, double tfx, double tfy, double smod, const Tensor &means3D,
+                        const Tensor &opac, const Tensor &colors, const Tensor &sh, const Tensor &cov, const Tensor &scales, const Tensor &rot,
+                        const Tensor &vm, const Tensor &pm, const Tensor &campos, const Tensor &bg) {
+    SgrProblem pb;
+    pb.P = (int32_t)P; pb.n_views = 1; pb.views_per_subject = 1; pb.H = (int32_t)H; pb.W = (int32_t)W; pb.sh_degree = (int32_t)sh_degree; pb.M = (int32_t)M;
+    pb.tanfovx = (float)tfx; pb.tanfovy = (float)tfy; pb.scale_modifier = (float)smod;
+    pb.means3D = fptr(means3D); pb.opacities = fptr(opac); pb.colors_precomp = fptr(colors); pb.shs = fptr(sh); pb.cov3D_precomp = fptr(cov);
+    pb.scales = fptr(scales); pb.rotations = fptr(rot); pb.viewmatrix = fptr(vm); pb.projmatrix = fptr(pm); pb.campos = fptr(campos); pb.bg = fptr(bg);
+    return pb;
+}
+
+struct RasterizeGaussiansNode : public torch::autograd::Function<RasterizeGaussiansNode> {
+    static variable_list forward(AutogradContext *ctx, Tensor means3D_, Tensor means2D, Tensor sh_, Tensor colors_, Tensor opac_, Tensor scales_,
+                                 Tensor rot_, Tensor cov_, int64_t H, int64_t W, double tfx, double tfy, Tensor bg_, double smod, Tensor vm_,
+                                 Tensor pm_, int64_t sh_degree, Tensor campos_) {
+        TORCH_CHECK(means3D_.dim() == 2 && means3D_.size(1) == 3, "means3D must have dimensions (num_points, 3)");
+        TORCH_CHECK(means3D_.is_cuda(), "sigman_release_amd rasterizer needs tensors on a ROCm device (there is no CPU fallback)");
+        const c10::Device dev = means3D_.device();
+        c10::DeviceGuard guard(dev);
+        const int didx = dev.index();
+        const int64_t P = means3D_.size(0);
+        auto opt = [](const Tensor &t) { return (t.defined() && t.numel() > 0) ? f32c(t) : Tensor(); };
+        // fp32-only op: inputs are cast here, so an enclosing autocast region (gs.py:98) cannot downcast them
+        const Tensor means3D = f32c(means3D_), opac = f32c(opac_).reshape({P}), sh = opt(sh_), colors = opt(colors_), scales = opt(scales_),
+                     rot = opt(rot_), cov = opt(cov_);
+        const Tensor vm = f32c(vm_), pm = f32c(pm_), campos = f32c(campos_), bg = f32c(bg_);
+        const int64_t M = sh.defined() ? sh.size(1) : 0;
+        const bool wants_grad = means3D_.requires_grad() || opac_.requires_grad() || (sh_.defined() && sh_.requires_grad()) ||
+                                (colors_.defined() && colors_.requires_grad()) || (scales_.defined() && scales_.requires_grad()) ||
+                                (rot_.defined() && rot_.requires_grad()) || (cov_.defined() && cov_.requires_grad()) ||
+                                (means2D.defined() && means2D.requires_grad());
+        const auto f32 = at::TensorOptions().dtype(at::kFloat).device(dev);
+        Tensor color = at::empty({3, H, W}, f32), depth = at::empty({1, H, W}, f32), alpha = at::empty({1, H, W}, f32);
+        Tensor radii = at::empty({P}, f32.dtype(at::kInt));
+        const SgrProblem pb = make_problem(P, H, W, sh_degree, M, tfx, tfy, smod, means3D, opac, colors, sh, cov, scales, rot, vm, pm, campos, bg);
+        hipStream_t stream = c10::hip::getCurrentHIPStream((c10::DeviceIndex)didx).stream();
+        const int with_aux = wants_grad ? 1 : 0;
+        const auto cap_key = std::make_tuple(didx, P, H, W);
+        poll_pending();                                                      // earlier forwards whose count nobody has looked at yet
+        SgrForwardState st;
+        AllocCtx ac;
+        ac.dev = dev;
+        std::shared_ptr<Pending> mine;                                        // set when this forward's check is deferred
+        for (int attempt = 0;; attempt++) {
+            uint64_t capacity = 0;
+            bool deferred = false;
+            { std::lock_guard<std::mutex> l(g_mu); const KeyState &k = g_keys[cap_key]; capacity = k.capacity; deferred = k.deferred && capacity > 0; }
+            CountSlot slot = acquire_slot(didx);
+            slot.host[0] = ~0ull; slot.host[1] = 0;                          // sentinel: "the count has not arrived yet"
+            memset(&st, 0, sizeof(st));
+            int status = 2;
+            const auto size_key = std::make_tuple(didx, P, H, W, capacity, with_aux, sh.defined() ? 1 : 0);
+            if (capacity > 0) {
+                std::array<uint64_t, 3> sizes{0, 0, 0};
+                bool have = false;
+                { std::lock_guard<std::mutex> l(g_mu); auto it = g_blob_sizes.find(size_key); if (it != g_blob_sizes.end()) { sizes = it->second; have = true; } }
+                if (have) {
+                    // sizes only depend on the shapes: from the second call on the three blobs are allocated here (no allocator callbacks)
+                    for (int k = 0; k < 3; k++) ac.blob[k] = at::empty({(int64_t)sizes[k]}, f32.dtype(at::kByte));
+                    st.geom = ac.blob[0].data_ptr(); st.binning = ac.blob[1].data_ptr(); st.image = ac.blob[2].data_ptr();
+                    st.geom_bytes = sizes[0]; st.binning_bytes = sizes[1]; st.image_bytes = sizes[2];
+                    status = sgr_rasterize_forward(&pb, capacity, with_aux, nullptr, nullptr, color.data_ptr<float>(), depth.data_ptr<float>(),
+                                                   alpha.data_ptr<float>(), radii.data_ptr<int32_t>(), slot.host, slot.ev, nullptr, 0, &st, stream);
+                }
+            }
+            if (status == 2) {                                               // first call with these shapes: the library asks for memory through the callback
+                memset(&st, 0, sizeof(st));
+                status = sgr_rasterize_forward(&pb, capacity, with_aux, alloc_cb, &ac, color.data_ptr<float>(), depth.data_ptr<float>(),
+                                               alpha.data_ptr<float>(), radii.data_ptr<int32_t>(), slot.host, slot.ev, nullptr, 0, &st, stream);
+                if (status == 0 && capacity > 0) {
+                    std::lock_guard<std::mutex> l(g_mu);
+                    g_blob_sizes[size_key] = {st.geom_bytes < 256 ? 256 : st.geom_bytes, st.binning_bytes < 256 ? 256 : st.binning_bytes,
+                                              st.image_bytes < 256 ? 256 : st.image_bytes};
+                }
+            }
+            if (status != 0) release_slot(slot);
+            check_status(status, "sgr_rasterize_forward");
+            if (P == 0) { release_slot(slot); break; }
+            if (capacity > 0 && deferred) {
+                // steady state: the host does not wait; this forward's backward or the thread's next forwards look at the count
+                mine = std::make_shared<Pending>();
+                mine->slot = slot; mine->key = cap_key; mine->capacity = capacity; mine->by_copy = st.nr_by_copy != 0;
+                { std::lock_guard<std::mutex> pl(g_pend_mu); mine->id = g_next_id++; g_by_id[mine->id] = mine; }
+                tstate().pending.push_back(mine);
+                break;
+            }
+            uint64_t count = st.true_rendered, overflow = 0;
+            if (capacity > 0) {
+                // learning phase: everything is queued; the emission kernel stores the count into the pinned word right after it has summed the
+                // block counts (large launches: an async copy behind the scan kernel -- then only the event says "complete")
+                volatile uint64_t *w = slot.host;
+                if (!st.nr_by_copy) for (int spins = 0; *w == ~0ull && spins < 200000; spins++) {}
+                if (st.nr_by_copy || *w == ~0ull) SGR_TORCH_CHECK_HIP(hipEventSynchronize(slot.ev));
+                const uint64_t word = *w;
+                count = word & ~(1ull << 63); overflow = word >> 63;
+            }
+            release_slot(slot);
+            if (overflow && attempt == 0) {                                  // does not fit the remembered capacity: re-run exactly (and re-learn it)
+                std::lock_guard<std::mutex> l(g_mu);
+                g_keys[cap_key] = KeyState();
+                continue;
+            }
+            TORCH_CHECK(!overflow, "num_rendered ", count, " exceeds the 32-bit instance index");
+            {
+                std::lock_guard<std::mutex> l(g_mu);
+                KeyState &k = g_keys[cap_key];
+                if (count > k.max_count) k.max_count = count;
+                if (capacity == 0 || count * 11 > capacity * 10) {          // (re-)learn: 1.3x the count, and the stability counter starts over
+                    uint64_t c = count + count * 3 / 10 + 4096;
+                    k.capacity = c > 0xFFFFFFE0ull ? 0xFFFFFFE0ull : c;
+                    k.stable = 0;
+                } else if (++k.stable >= 8 && !inline_forever()) {            // stable: 2x the largest count seen, checks deferred from now on
+                    uint64_t c = 2 * k.max_count + 4096;
+                    k.capacity = c > 0xFFFFFFE0ull ? 0xFFFFFFE0ull : c;
+                    k.deferred = true;
+                }
+            }
+            break;
+        }
+        // ---- what the backward needs
+        ctx->set_materialize_grads(false);       // unused outputs (depth / alpha on the reference path) then arrive undefined: no fill kernels
+        ctx->mark_non_differentiable({radii});
+        Tensor st_bytes = at::empty({(int64_t)sizeof(SgrForwardState)}, at::TensorOptions().dtype(at::kByte));
+        memcpy(st_bytes.data_ptr(), &st, sizeof(st));
+        ctx->save_for_backward({means3D, opac, colors, sh, cov, scales, rot, color, depth, alpha, radii, ac.blob[0], ac.blob[1], ac.blob[2], vm, pm,
+                                campos, bg});
+        ctx->saved_data["st"] = st_bytes;
+        if (mine) ctx->saved_data["pending"] = mine->id;
+        ctx->saved_data["dims"] = std::vector<int64_t>{P, H, W, sh_degree, M, means2D.defined() && means2D.requires_grad() ? 1 : 0};
+        ctx->saved_data["scal"] = std::vector<double>{tfx, tfy, smod};
+        return {color, radii, depth, alpha};
+    }
+
+    static variable_list backward(AutogradContext *ctx, variable_list grads) {
+        const auto saved = ctx->get_saved_variables();
+        const Tensor &means3D = saved[0], &opac = saved[1], &colors = saved[2], &sh = saved[3], &cov = saved[4], &scales = saved[5], &rot = saved[6],
+                     &color = saved[7], &depth = saved[8], &alpha = saved[9], &radii = saved[10], &vm = saved[14], &pm = saved[15], &campos = saved[16],
+                     &bg = saved[17];
+        const auto dims = ctx->saved_data["dims"].toIntVector();
+        const auto scal = ctx->saved_data["scal"].toDoubleVector();
+        const int64_t P = dims[0], H = dims[1], W = dims[2], sh_degree = dims[3], M = dims[4];
+        const bool want_means2D = dims[5] != 0;
+        const c10::Device dev = means3D.device();
+        c10::DeviceGuard guard(dev);
+        SgrForwardState st;
+        memcpy(&st, ctx->saved_data["st"].toTensor().data_ptr(), sizeof(st));
+        const auto f32 = at::TensorOptions().dtype(at::kFloat).device(dev);
+        Tensor gC = grads[0].defined() ? f32c(grads[0]) : at::zeros({3, H, W}, f32);
+        Tensor gD = grads[2].defined() ? f32c(grads[2]) : Tensor(), gA = grads[3].defined() ? f32c(grads[3]) : Tensor();
+        Tensor d_means3D = at::empty({P, 3}, f32), d_op = at::empty({P, 1}, f32), d_cov = at::empty({P, 6}, f32);
+        Tensor d_means2D = want_means2D ? at::empty({P, 3}, f32) : Tensor();
+        Tensor d_col = sh.defined() ? Tensor() : at::empty({P, 3}, f32);
+        Tensor d_sh = sh.defined() ? at::empty_like(sh) : Tensor();
+        Tensor d_sc = scales.defined() ? at::empty({P, 3}, f32) : Tensor(), d_rot = scales.defined() ? at::empty({P, 4}, f32) : Tensor();
+        const SgrProblem pb = make_problem(P, H, W, sh_degree, M, scal[0], scal[1], scal[2], means3D, opac, colors, sh, cov, scales, rot, vm, pm, campos, bg);
+        hipStream_t stream = c10::hip::getCurrentHIPStream(dev.index()).stream();
+        AllocCtx ac;
+        ac.dev = dev;
+        auto mp = [](const Tensor &t) -> float * { return (t.defined() && t.numel() > 0) ? t.data_ptr<float>() : nullptr; };
+        std::shared_ptr<Pending> mine;
+        if (ctx->saved_data.count("pending")) {                               // still unchecked? (else the issuing thread has looked at it already)
+            std::lock_guard<std::mutex> pl(g_pend_mu);
+            auto it = g_by_id.find(ctx->saved_data["pending"].toInt());
+            if (it != g_by_id.end()) mine = it->second;
+        }
+        if (P > 0)
+            check_status(sgr_rasterize_backward(&pb, &st, radii.data_ptr<int32_t>(), color.data_ptr<float>(), depth.data_ptr<float>(), alpha.data_ptr<float>(),
+                                                gC.data_ptr<float>(), mp(gD), mp(gA), nullptr, alloc_cb, &ac, mp(d_means3D), mp(d_means2D), mp(d_op),
+                                                mp(d_col), mp(d_sh), mp(d_cov), mp(d_sc), mp(d_rot), stream),
+                         "sgr_rasterize_backward");
+        if (mine) {                                                           // after the backward is queued: the count arrived long ago
+            resolve(*mine, true);
+            if (mine->overflow && !mine->reported) raise_deferred(*mine);
+        }
+        // gradients in forward-argument order: means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, then the 10 settings
+        variable_list out = {d_means3D, d_means2D, d_sh, colors.defined() ? d_col : Tensor(), d_op, d_sc, d_rot, cov.defined() ? d_cov : Tensor()};
+        for (int k = 0; k < 10; k++) out.push_back(Tensor());
+        return out;
+    }
+};
+
+std::vector<Tensor> rasterize_gaussians(Tensor means3D, Tensor means2D, Tensor sh, Tensor colors, Tensor opac, Tensor scales, Tensor rot, Tensor cov,
+                                        int64_t H, int64_t W, double tfx, double tfy, Tensor bg, double smod, Tensor vm, Tensor pm, int64_t sh_degree,
+                                        Tensor campos) {
+    return RasterizeGaussiansNode::apply(means3D, means2D, sh, colors, opac, scales, rot, cov, H, W, tfx, tfy, bg, smod, vm, pm, sh_degree, campos);
+}
+
+}  // namespace
+
+PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
+    m.doc() = "C++ autograd node of the single-view upstream-signature rasterizer op above the C ABI of libsigman_gsplat.so";
+    m.def("rasterize_gaussians", &rasterize_gaussians, "== diff_gaussian_rasterization.rasterize_gaussians for one view (automatic sync-free capacity)");
+    m.def("abi_version", []() { return sgr_abi_version(); });
+    m.def("check_pending", []() { ThreadState &t = tstate(); for (auto &p : t.pending) resolve(*p, true); poll_pending(); },
+          "wait for and check the deferred instance counts of this thread's earlier forwards (raises if one overflowed)");
+    m.def("reset", []() { std::lock_guard<std::mutex> l(g_mu); g_keys.clear(); }, "forget the learned capacities (tests)");
+    m.def("key_state", [](int dev, int64_t P, int64_t H, int64_t W) { std::lock_guard<std::mutex> l(g_mu); const KeyState &k = g_keys[std::make_tuple(dev, P, H, W)];
+                                                                     return std::make_tuple(k.capacity, k.max_count, k.stable, k.deferred); });
+}

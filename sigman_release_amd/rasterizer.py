@@ -67,6 +67,9 @@ class BatchedRasterizationSettings(NamedTuple):
 _USE_BWD_V1 = os.environ.get("SIGMAN_BWD_V1", "0") == "1"
 
 
+_EMPTY = torch.Tensor([])          # upstream passes torch.Tensor([]) for every missing optional; one shared instance (never written)
+
+
 def _ptr(t: Optional[torch.Tensor]):
     return None if t is None or t.numel() == 0 else t.data_ptr()
 
@@ -590,6 +593,14 @@ def _cpu_copy(obj):
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
+    rs = raster_settings
+    node = _cabi.torch_node()
+    if node is not None and not rs.debug and not rs.prefiltered:
+        # the same op as a C++ autograd node (csrc/torch_node.cpp): the reference calls this once per view from a Python loop
+        # (gs.py:75-106), and the host time of the Python node below exceeded the kernels' time
+        return tuple(node.rasterize_gaussians(means3D, _EMPTY if means2D is None else means2D, sh, colors_precomp, opacities, scales, rotations,
+                                              cov3Ds_precomp, int(rs.image_height), int(rs.image_width), float(rs.tanfovx), float(rs.tanfovy), rs.bg,
+                                              float(rs.scale_modifier), rs.viewmatrix, rs.projmatrix, int(rs.sh_degree), rs.campos))
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                                      raster_settings)
 
@@ -601,9 +612,6 @@ def mark_visible(positions: torch.Tensor, viewmatrix: torch.Tensor) -> torch.Ten
     vm = _f32c(viewmatrix)
     _cabi.check(L.sgr_mark_visible(positions.shape[0], _ptr(positions), _ptr(vm), _ptr(out), _stream(positions.device)), "sgr_mark_visible")
     return out.bool()
-
-
-_EMPTY = torch.Tensor([])          # upstream passes torch.Tensor([]) for every missing optional; one shared instance (never written)
 
 
 class GaussianRasterizer(torch.nn.Module):

@@ -324,3 +324,96 @@ def test_count_published_by_copy_is_never_read_torn():
             got = R.rasterize_gaussians_batched(*args, st._replace(max_rendered=-1))[0]
             assert torch.equal(got, want), it
     R.check_pending_overflows(block=True)
+
+
+@pytest.mark.parametrize("name", ["humanoid_20k_256", "cloud_sh3", "cull_and_clamp"])
+def test_cpp_autograd_node_equals_python_node(name):
+    """The single-view upstream-signature op exists twice above the same C ABI: as a C++ autograd node (csrc/torch_node.cpp, the default:
+    the reference calls it once per view and the Python node's host time exceeded the kernels') and as the Python node
+    (rasterizer._RasterizeGaussians).  Same outputs and gradients, bit for bit, over repeated calls (exact first call, sync-free later)."""
+    from sigman_release_amd import _cabi
+    from sigman_release_amd import rasterizer as R
+    dev = _dev()
+    node = _cabi.torch_node()
+    assert node is not None, "lib/sgr_torch_node.so is not built (make -C sigman_release_amd/csrc)"
+    inp, st = cases.CASES[name]()
+    H, W = st["image_height"], st["image_width"]
+    gC, gD, gA = cases.grads_for(H, W)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    sv = cases.single_view(st)
+    rs = R.GaussianRasterizationSettings(H, W, st["tanfovx"], st["tanfovy"], t(st["bg"]), st["scale_modifier"], t(sv["viewmatrix"]), t(sv["projmatrix"]),
+                                         st["sh_degree"], t(sv["campos"]), False, False)
+    P = inp["means3D"].shape[0]
+
+    def run():
+        d = {k: t(v).requires_grad_(True) for k, v in inp.items()}
+        means2D = torch.zeros(P, 3, device=dev, requires_grad=True)
+        color, radii, depth, alpha = R.GaussianRasterizer(rs)(means3D=d["means3D"], means2D=means2D, opacities=d["opacities"].reshape(P, 1), shs=d.get("shs"),
+                                                              colors_precomp=d.get("colors_precomp"), scales=d.get("scales"), rotations=d.get("rotations"),
+                                                              cov3D_precomp=d.get("cov3D_precomp"))
+        ((color * t(gC)).sum() + (depth * t(gD)).sum() + (alpha * t(gA)).sum()).backward()
+        torch.cuda.synchronize()
+        return [color.detach(), radii, depth.detach(), alpha.detach(), means2D.grad] + [d[k].grad for k in sorted(d)]
+
+    try:
+        a = [run() for _ in range(3)]
+        _cabi._node = None                                                  # force the Python node
+        b = [run() for _ in range(3)]
+    finally:
+        _cabi._node = node
+    for x in a[1:] + b:
+        for u, v in zip(a[0], x):
+            assert torch.equal(u, v)
+
+
+def test_cpp_node_deferred_count_check():
+    """Steady state of the C++ node: once a shape's capacity has been stable for 8 calls the instance count is no longer waited for inside
+    the call (the host runs ahead of the GPU like in the batched path); results stay identical; a forward that does not fit is reported by
+    the NEXT call (or its own backward) as RuntimeError, after which the capacity is re-learned."""
+    from sigman_release_amd import _cabi
+    from sigman_release_amd import rasterizer as R
+    dev = _dev()
+    node = _cabi.torch_node()
+    assert node is not None
+    node.reset()
+    inp, st = cases.humanoid(P=7000, H=144, W=144, seed=41)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    sv = cases.single_view(st)
+    rs = R.GaussianRasterizationSettings(144, 144, st["tanfovx"], st["tanfovy"], t(st["bg"]), 1.0, t(sv["viewmatrix"]), t(sv["projmatrix"]), 0, t(sv["campos"]),
+                                         False, False)
+    P = 7000
+    m, o, c = t(inp["means3D"]), t(inp["opacities"]).reshape(P, 1), t(inp["colors_precomp"])
+    cov = t(inp["cov3D_precomp"])
+
+    def fwd(cov_, grad=False):
+        mm = m.clone().requires_grad_(grad)
+        out = R.GaussianRasterizer(rs)(means3D=mm, means2D=torch.zeros_like(m), opacities=o, colors_precomp=c, cov3D_precomp=cov_)
+        return out, mm
+
+    first = fwd(cov)[0][0].clone()
+    for i in range(14):
+        assert torch.equal(fwd(cov)[0][0], first)
+    node.check_pending()
+    capacity, max_count, stable, deferred = node.key_state(0, P, 144, 144)
+    assert deferred and capacity >= 2 * max_count, (capacity, max_count, stable, deferred)
+    # gradients through a deferred forward
+    (out, mm) = fwd(cov, grad=True)
+    out[0].sum().backward()
+    assert torch.isfinite(mm.grad).all()
+    # a forward that needs > 2x the largest count seen: reported by the next call
+    big = cov * 25.0
+    fwd(big)
+    torch.cuda.synchronize()
+    with pytest.raises(RuntimeError, match="EARLIER forward"):
+        fwd(cov)
+    # ... or by its own backward, whichever comes first
+    assert torch.equal(fwd(cov)[0][0], first)                                # re-learning: exact again, same image
+    for i in range(12):
+        fwd(cov)
+    node.check_pending()
+    assert node.key_state(0, P, 144, 144)[3]
+    (out, mm) = fwd(big, grad=True)
+    with pytest.raises(RuntimeError, match="EARLIER forward"):
+        out[0].sum().backward()
+    torch.cuda.synchronize()
+    node.reset()
