@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SGR_ABI_VERSION 2
+#define SGR_ABI_VERSION 3
 #define SGR_TILE 16                 /* 16x16 pixel tiles, as the published algorithm */
 #define SGR_REC_FLOATS 12           /* floats of a gradient record (grec, pixel-parallel backward) */
 #define SGR_PART_FLOATS 10          /* floats of a partial gradient record (bucket-parallel backward): 40 B, 8-byte aligned */
@@ -73,7 +73,7 @@ typedef struct SgrProblem {
  *   rec[0..3]   = pixel x, pixel y, conic.xx, conic.xy
  *   rec[4..7]   = conic.yy, opacity, view depth, r
  *   rec[8..11]  = g, b, hx, hy      (hx,hy: half extents of the exact alpha >= 1/255 bound; <0 = never visible)
- *   rec[12..15] = bits: first tile-instance index of this Gaussian (written by sgr_bin), rect min, rect max, 0
+ *   rec[12..15] = padding (the record is one 64-byte line)
  * The gradient record written by sgr_render_backward has the same shape:
  *   grec[0..3] = dL/dNDCx, dL/dNDCy, dL/dconic.xx, dL/dconic.xy
  *   grec[4..7] = dL/dconic.yy, dL/dopacity, dL/ddepth, dL/dr
@@ -162,7 +162,8 @@ int32_t sgr_preprocess_blocks_per_view(int32_t P);
 /*
  * F1 + F2: cull/project/cov2D/conic/radius/rect per (view,Gaussian), block-wise tile counts and their
  * exclusive scan.  Outputs: rec [n_views*P*16], radii i32 [n_views*P], rect u32 [n_views*P*4]
- * (minx | miny<<16, maxx | maxy<<16, depth key bits, 0: one 16-byte record for the emission kernel), clamped u8 [n_views*P] (SH clamp bits, may be NULL without shs),
+ * (minx | miny<<16, maxx | maxy<<16, depth key bits, first tile-instance index -- written by sgr_bin: one 16-byte record for the emission
+ * kernel and the backward's gathers), clamped u8 [n_views*P] (SH clamp bits, may be NULL without shs),
  * block_offsets u32 [2*(n_views*blocks_per_view + 1)] (first half: exclusive offsets, entry n = R; second half:
  * scratch for the un-scanned sums), num_rendered u64 [4] ([0] = R, [1] = 1 if R overflows the 32-bit instance index or
  * `capacity`, [2] = R | overflow << 63: the word the sync-free mode publishes to the host, [3] unused).  capacity = 0: none (the caller reads R back and sizes the binning buffers exactly, like upstream);
@@ -188,7 +189,7 @@ size_t sgr_bin_workspace_bytes(uint64_t R, uint64_t tiles_total /* n_views * til
  * keys/vals: two buffers of R entries each (ping-pong).  On return *result_in_b_host tells which
  * buffer holds the sorted list.  ranges u32 [n_views*tiles*2] (start,end) into the sorted list.
  */
-int sgr_bin(const SgrProblem *pb, float *rec, const int32_t *radii, const uint32_t *rect,
+int sgr_bin(const SgrProblem *pb, const int32_t *radii, uint32_t *rect /* [3] of every record is written */,
             const uint32_t *block_offsets, uint64_t R, const uint64_t *num_rendered_dev, uint64_t *keys_a, uint64_t *keys_b,
             uint32_t *vals_a, uint32_t *vals_b, void *workspace, size_t workspace_bytes, uint32_t *ranges,
             int32_t *result_in_b_host, void *stream);
@@ -232,7 +233,7 @@ int sgr_render_forward(const SgrProblem *pb, const uint32_t *ranges, const uint3
  * Without the aux buffers (NULL) the pixel-parallel reverse walk runs: needs final_T and grec [n_views*P*12], which is
  * zeroed by this call and accumulated with hardware float atomics (one set per tile and Gaussian).
  */
-int sgr_render_backward(const SgrProblem *pb, const uint32_t *ranges, const uint32_t *point_list, const float *rec,
+int sgr_render_backward(const SgrProblem *pb, const uint32_t *ranges, const uint32_t *point_list, const float *rec, const uint32_t *rect,
                         const float *final_T, const uint32_t *n_contrib, const float *out_color, const float *out_depth,
                         const float *out_alpha, const float *grad_color, const float *grad_depth, const float *grad_alpha,
                         const float *grad_color_scale /* optional device scalar on grad_color, or NULL */,
@@ -240,7 +241,7 @@ int sgr_render_backward(const SgrProblem *pb, const uint32_t *ranges, const uint
                         const void *aux_desc, float *grec, float *part, uint32_t *flags, void *stream);
 
 /*
- * B2 + B3: per-(view,Gaussian) gradient records (either `grec`, or `rec` + `part` + `flags` from the bucket-parallel
+ * B2 + B3: per-(view,Gaussian) gradient records (either `grec`, or `rect` + `part` + `flags` from the bucket-parallel
  * sgr_render_backward) -> per-subject parameter gradients, summed over the
  * subject's views in a fixed order (no atomics).  Outputs are fully written (no pre-zeroing needed):
  *   dL_dmeans3D [S,P,3], dL_dmeans2D [n_views,P,3] (NDC units like upstream, z = 0; may be NULL: not written),
@@ -248,7 +249,7 @@ int sgr_render_backward(const SgrProblem *pb, const uint32_t *ranges, const uint
  *   dL_dscales [S,P,3] / dL_drotations [S,P,4] (only when scales given; else may be NULL)
  */
 int sgr_preprocess_backward(const SgrProblem *pb, const int32_t *radii, const uint8_t *clamped, const float *grec,
-                            const float *rec, const float *part, const uint32_t *flags, float *dL_dmeans3D, float *dL_dmeans2D, float *dL_dopacity, float *dL_dcolors,
+                            const uint32_t *rect, const float *part, const uint32_t *flags, float *dL_dmeans3D, float *dL_dmeans2D, float *dL_dopacity, float *dL_dcolors,
                             float *dL_dsh, float *dL_dcov3D, float *dL_dscales, float *dL_drotations,
                             void *stream);
 

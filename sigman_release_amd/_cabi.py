@@ -50,7 +50,7 @@ _SIGNATURES = {
                                + [C.c_void_p] * 9),
     "sgr_preprocess_forward": (C.c_int, [C.POINTER(SgrProblem)] + [C.c_void_p] * 6 + [C.c_uint64, C.c_void_p]),
     "sgr_bin_workspace_bytes": (C.c_size_t, [C.c_uint64, C.c_uint64]),
-    "sgr_bin": (C.c_int, [C.POINTER(SgrProblem), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
+    "sgr_bin": (C.c_int, [C.POINTER(SgrProblem), C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_int32),
                           C.c_void_p]),
     "sgr_bucket_slots": (C.c_uint64, [C.c_uint64, C.c_uint64]),
@@ -61,7 +61,7 @@ _SIGNATURES = {
     "sgr_set_sort_mode": (C.c_int, [C.c_int]),
     "sgr_graph_stats": (C.c_int, [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "sgr_render_forward": (C.c_int, [C.POINTER(SgrProblem)] + [C.c_void_p] * 8 + [C.c_uint64] + [C.c_void_p] * 6),
-    "sgr_render_backward": (C.c_int, [C.POINTER(SgrProblem)] + [C.c_void_p] * 12 + [C.c_uint64] + [C.c_void_p] * 8),
+    "sgr_render_backward": (C.c_int, [C.POINTER(SgrProblem)] + [C.c_void_p] * 13 + [C.c_uint64] + [C.c_void_p] * 8),
     "sgr_preprocess_backward": (C.c_int, [C.POINTER(SgrProblem)] + [C.c_void_p] * 15),
     "sgr_mark_visible": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sgr_knn_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
@@ -91,8 +91,8 @@ def lib():
             fn = getattr(L, name)          # AttributeError if a declared symbol is not exported
             fn.restype = res
             fn.argtypes = args
-        if L.sgr_abi_version() != 2:
-            raise RuntimeError(f"ABI version mismatch: library reports {L.sgr_abi_version()}, binding expects 2")
+        if L.sgr_abi_version() != 3:
+            raise RuntimeError(f"ABI version mismatch: library reports {L.sgr_abi_version()}, binding expects 3")
         if os.environ.get("SIGMAN_GRAPHS", "0") in ("1", "2"):    # opt-in hipGraph replay of the forward chain (include/sigman_gsplat.h, sgr_set_graphs)
             L.sgr_set_graphs(int(os.environ["SIGMAN_GRAPHS"]))
         _lib = L
@@ -115,7 +115,7 @@ def torch_node():
             spec = importlib.util.spec_from_file_location("sgr_torch_node", path)
             mod = importlib.util.module_from_spec(spec)
             spec.loader.exec_module(mod)
-            if mod.abi_version() != 2:
+            if mod.abi_version() != 3:
                 raise RuntimeError("sgr_torch_node.so was built against another ABI version of libsigman_gsplat.so: rebuild (make -C sigman_release_amd/csrc)")
             _node = mod
     return _node

@@ -40,9 +40,8 @@ struct DupExtra {
 // the block offset from F2, so the per-Gaussian offsets array of the published algorithm is never
 // materialised in HBM.
 __global__ __launch_bounds__(kThreads) void duplicate_keys_kernel(int P, int Tx, int tiles_per_view,
-                                                                  float4 *__restrict__ rec,
                                                                   const int32_t *__restrict__ radii,
-                                                                  const uint4 *__restrict__ rect,
+                                                                  uint4 *__restrict__ rect,
                                                                   const uint32_t *__restrict__ block_offsets, uint32_t cap,
                                                                   uint64_t *__restrict__ keys, uint32_t *__restrict__ vals,
                                                                   DupExtra ex) {
@@ -116,7 +115,7 @@ __global__ __launch_bounds__(kThreads) void duplicate_keys_kernel(int P, int Tx,
     if (threadIdx.x == kThreads - 1) s_off[kThreads] = off - block_base + cnt;
     if (cnt) {
         s_dep[threadIdx.x] = depth_bits;
-        rec[q * 4 + 3].x = __uint_as_float(off);           // first tile-instance index of this Gaussian (backward gather)
+        rect[q].w = off;                                   // first tile-instance index of this Gaussian (backward gathers); the 16-byte record was just read
     }
     __syncthreads();
     const uint32_t total = s_off[kThreads];
@@ -1301,7 +1300,7 @@ extern "C" size_t sgr_bin_workspace_bytes(uint64_t R, uint64_t tiles_total) {
 
 // self_scan: the caller skipped the F2 scan kernel (sgr_preprocess_forward_ex) and block_offsets + n + 1 holds the un-scanned
 // counts; num_rendered_dev is then WRITTEN by the duplicate kernel (capacity mode only).  nr_host: optional pinned host slot.
-int sgr_bin_ex(const SgrProblem *pb, float *rec, const int32_t *radii, const uint32_t *rect,
+int sgr_bin_ex(const SgrProblem *pb, const int32_t *radii, uint32_t *rect,
                const uint32_t *block_offsets, uint64_t R, const uint64_t *num_rendered_dev, uint64_t *keys_a,
                uint64_t *keys_b, uint32_t *vals_a, uint32_t *vals_b, void *workspace, size_t workspace_bytes,
                uint32_t *ranges, int32_t *result_in_b_host, bool self_scan, uint64_t *nr_host, void *prep_desc, size_t prep_n_desc,
@@ -1339,7 +1338,7 @@ int sgr_bin_ex(const SgrProblem *pb, float *rec, const int32_t *radii, const uin
     ex.zero_one = all_large ? (uint32_t *)((char *)workspace + sgr_bin_workspace_bytes(R, 0)) : nullptr;
     if (self_scan && !num_rendered_dev) { sgr_set_error("sgr_bin: self-scan needs the device counter"); return 1; }
     hipLaunchKernelGGL(duplicate_keys_kernel, dim3(nbx, pb->n_views), dim3(kThreads), 0, stream, pb->P, Tx, Tx * Ty,
-                       (float4 *)rec, radii, (const uint4 *)rect, block_offsets, n, keys_a, vals_a, ex);
+                       radii, (uint4 *)rect, block_offsets, n, keys_a, vals_a, ex);
     SGR_CHECK_LAUNCH("duplicate_keys_kernel");
     }
     const bool small = n <= (1u << 19);
@@ -1507,10 +1506,10 @@ int sgr_bin_ex(const SgrProblem *pb, float *rec, const int32_t *radii, const uin
     return 0;
 }
 
-extern "C" int sgr_bin(const SgrProblem *pb, float *rec, const int32_t *radii, const uint32_t *rect,
+extern "C" int sgr_bin(const SgrProblem *pb, const int32_t *radii, uint32_t *rect,
                        const uint32_t *block_offsets, uint64_t R, const uint64_t *num_rendered_dev, uint64_t *keys_a,
                        uint64_t *keys_b, uint32_t *vals_a, uint32_t *vals_b, void *workspace, size_t workspace_bytes,
                        uint32_t *ranges, int32_t *result_in_b_host, void *stream_) {
-    return sgr_bin_ex(pb, rec, radii, rect, block_offsets, R, num_rendered_dev, keys_a, keys_b, vals_a, vals_b, workspace,
+    return sgr_bin_ex(pb, radii, rect, block_offsets, R, num_rendered_dev, keys_a, keys_b, vals_a, vals_b, workspace,
                       workspace_bytes, ranges, result_in_b_host, false, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, stream_);
 }

@@ -44,17 +44,17 @@ std::mutex g_graph_mu;           // the cache below is process-global: forwards 
 int sgr_prof_active();
 int sgr_preprocess_forward_ex(const SgrProblem *pb, float *rec, int32_t *radii, uint32_t *rect, uint8_t *clamped, uint32_t *block_offsets,
                               uint64_t *num_rendered, uint64_t capacity, bool skip_scan, void *stream_);
-int sgr_bin_ex(const SgrProblem *pb, float *rec, const int32_t *radii, const uint32_t *rect, const uint32_t *block_offsets, uint64_t R,
+int sgr_bin_ex(const SgrProblem *pb, const int32_t *radii, uint32_t *rect, const uint32_t *block_offsets, uint64_t R,
                const uint64_t *num_rendered_dev, uint64_t *keys_a, uint64_t *keys_b, uint32_t *vals_a, uint32_t *vals_b, void *workspace,
                size_t workspace_bytes, uint32_t *ranges, int32_t *result_in_b_host, bool self_scan, uint64_t *nr_host, void *prep_desc,
                size_t prep_n_desc, uint32_t *prep_order, int *prep_done, uint32_t *const *clear_ptr, const uint64_t *clear_words,
                int *clear_done, void *stream_);
-int sgr_render_backward_ex(const SgrProblem *pb, const uint32_t *ranges, const uint32_t *point_list, const float *rec, const float *final_T,
+int sgr_render_backward_ex(const SgrProblem *pb, const uint32_t *ranges, const uint32_t *point_list, const float *rec, const uint32_t *rect, const float *final_T,
                            const uint32_t *n_contrib, const float *out_color, const float *out_depth, const float *out_alpha,
                            const float *grad_color, const float *grad_depth, const float *grad_alpha, const float *grad_color_scale,
                            uint64_t R, const void *aux_compact, const void *aux_ckpt_tc, const void *aux_ckpt_da, const void *aux_desc,
                            float *grec, float *part, uint32_t *flags, bool flags_cleared, int aux_layout, void *stream_);
-int sgr_preprocess_backward_ex(const SgrProblem *pb, const int32_t *radii, const uint8_t *clamped, const float *grec, const float *rec,
+int sgr_preprocess_backward_ex(const SgrProblem *pb, const int32_t *radii, const uint8_t *clamped, const float *grec, const uint32_t *rect,
                                const float *part, const uint32_t *flags, uint64_t n_inst, float *dL_dmeans3D, float *dL_dmeans2D, float *dL_dopacity,
                                float *dL_dcolors, float *dL_dsh, float *dL_dcov3D, float *dL_dscales, float *dL_drotations, void *stream_);
 int sgr_render_forward_wants_prepare(const SgrProblem *pb, uint64_t R, bool use_aux, size_t *n_desc_out);
@@ -111,7 +111,7 @@ static int forward_launches(const SgrProblem *pb, uint64_t capacity, uint64_t R,
     uint32_t *clear_ptr[2] = {aux_on ? (uint32_t *)(image + st->off_flags) : nullptr, (uint32_t *)caller_clear};
     const uint64_t clear_words[2] = {aux_on ? (R + 0) : 0, (caller_clear_bytes + 3) / 4};
     int clear_done[2] = {0, 0};
-    if (sgr_bin_ex(pb, rec, out_radii, rect, block_offsets, R, capacity > 0 ? num_rendered : nullptr, (uint64_t *)(binning + st->off_keys_a),
+    if (sgr_bin_ex(pb, out_radii, rect, block_offsets, R, capacity > 0 ? num_rendered : nullptr, (uint64_t *)(binning + st->off_keys_a),
                    (uint64_t *)(binning + st->off_keys_b), (uint32_t *)(binning + st->off_vals_a), (uint32_t *)(binning + st->off_vals_b),
                    binning + st->off_sort_ws, (size_t)sgr_bin_workspace_bytes(R, (uint64_t)((pb->W + SGR_TILE - 1) / SGR_TILE) * ((pb->H + SGR_TILE - 1) / SGR_TILE) * pb->n_views),
                    (uint32_t *)(image + st->off_ranges), &in_b, self_scan, self_scan ? nr_pinned_host : nullptr,
@@ -303,13 +303,14 @@ extern "C" int sgr_rasterize_backward(const SgrProblem *pb, const SgrForwardStat
     float *grec = aux_on ? nullptr : (float *)scratch;
     const char *geom = (const char *)st->geom, *binning = (const char *)st->binning, *image = (const char *)st->image;
     const float *rec = (const float *)(geom + st->off_rec);
+    const uint32_t *rect = (const uint32_t *)(geom + st->off_rect);
     const uint32_t *point_list = (const uint32_t *)(binning + (st->result_in_b ? st->off_vals_b : st->off_vals_a));
-    if (sgr_render_backward_ex(pb, (const uint32_t *)(image + st->off_ranges), point_list, rec, (const float *)(image + st->off_final_T),
+    if (sgr_render_backward_ex(pb, (const uint32_t *)(image + st->off_ranges), point_list, rec, rect, (const float *)(image + st->off_final_T),
                             (const uint32_t *)(image + st->off_n_contrib), out_color, out_depth, out_alpha, grad_color, grad_depth,
                             grad_alpha, grad_color_scale, st->R_alloc, aux_on ? image + st->off_compact : nullptr, aux_on ? image + st->off_ckpt_tc : nullptr,
                             aux_on ? image + st->off_ckpt_da : nullptr, aux_on ? image + st->off_desc : nullptr, grec, part, flags, st->flags_cleared != 0, st->with_aux, stream_))
         return 1;
-    return sgr_preprocess_backward_ex(pb, radii, pb->shs ? (const uint8_t *)(geom + st->off_clamped) : nullptr, grec, rec, part, flags, st->R_alloc,
+    return sgr_preprocess_backward_ex(pb, radii, pb->shs ? (const uint8_t *)(geom + st->off_clamped) : nullptr, grec, rect, part, flags, st->R_alloc,
                                    dL_dmeans3D, dL_dmeans2D, dL_dopacity, dL_dcolors, dL_dsh, dL_dcov3D, dL_dscales, dL_drotations,
                                    stream_);
 }

@@ -691,6 +691,7 @@ template <bool HAS_DA, bool SPLIT, bool ROWS>
 __global__ __launch_bounds__(kBlock) void render_bwd_bucket_kernel(int W, int H, int Tx, uint32_t tiles_per_view,
                                                                    const uint2 *__restrict__ ranges,
                                                                    const float4 *__restrict__ rec,
+                                                                   const uint4 *__restrict__ rect,
                                                                    const uint32_t *__restrict__ n_contrib,
                                                                    const float *__restrict__ out_color,
                                                                    const float *__restrict__ out_depth,
@@ -733,8 +734,8 @@ __global__ __launch_bounds__(kBlock) void render_bwd_bucket_kernel(int W, int H,
     // a lane without a Gaussian gets list index 0xFFFFFFFF, which no pixel's n_contrib exceeds -> never valid
     const uint32_t gidx = e.y;
     float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra, rc = ra;
-    float4 rd = ra;
-    if (has_g) { ra = rec[(size_t)e.x * 4 + 0]; rb = rec[(size_t)e.x * 4 + 1]; rc = rec[(size_t)e.x * 4 + 2]; rd = rec[(size_t)e.x * 4 + 3]; }
+    uint4 rd = make_uint4(0u, 0u, 0u, 0u);                     // (rect min, rect max, depth bits, first tile-instance index)
+    if (has_g) { ra = rec[(size_t)e.x * 4 + 0]; rb = rec[(size_t)e.x * 4 + 1]; rc = rec[(size_t)e.x * 4 + 2]; rd = rect[e.x]; }
     const float gx = ra.x, gy = ra.y, cxx = ra.z, cxy = ra.w, cyy = rb.x, op = rb.y, gdep = rb.z, cr = rb.w, cg = rc.x, cb = rc.y;
     // conic pre-scaled into the exp2 domain: G = exp(power) = exp2(kxx dx^2 + kyy dy^2 + kxy dx dy)
     const float kL2e = 1.4426950408889634f;
@@ -886,7 +887,7 @@ __global__ __launch_bounds__(kBlock) void render_bwd_bucket_kernel(int W, int H,
     }
     if (has_g) {
         // one NON-atomic 40-byte partial record per (tile instance, quadrant); preprocess_bwd gathers them in a fixed order
-        const uint32_t off = __float_as_uint(rd.x), rmin = __float_as_uint(rd.y), rmax = __float_as_uint(rd.z);
+        const uint32_t off = rd.w, rmin = rd.x, rmax = rd.y;
         const uint32_t inst = off + (ty - (rmin >> 16)) * ((rmax & 0xFFFFu) - (rmin & 0xFFFFu)) + (tx - (rmin & 0xFFFFu));
         const float a0 = -0.5f * (float)W * op * (cxx * Sx + cxy * Sy);       // dL/dNDC x (includes 0.5*W like upstream)
         const float a1 = -0.5f * (float)H * op * (cyy * Sy + cxy * Sx);
@@ -997,7 +998,7 @@ extern "C" int sgr_render_forward(const SgrProblem *pb, const uint32_t *ranges, 
                                  aux_ckpt_tc, aux_ckpt_da, aux_desc, aux_order, false, sgr_aux_layout_for(sgr_bucket_slots(R, tiles_total)), stream_);
 }
 
-int sgr_render_backward_ex(const SgrProblem *pb, const uint32_t *ranges, const uint32_t *point_list, const float *rec,
+int sgr_render_backward_ex(const SgrProblem *pb, const uint32_t *ranges, const uint32_t *point_list, const float *rec, const uint32_t *rect,
                            const float *final_T, const uint32_t *n_contrib, const float *out_color,
                            const float *out_depth, const float *out_alpha, const float *grad_color,
                            const float *grad_depth, const float *grad_alpha, const float *grad_color_scale, uint64_t R,
@@ -1007,7 +1008,7 @@ int sgr_render_backward_ex(const SgrProblem *pb, const uint32_t *ranges, const u
     hipStream_t stream = (hipStream_t)stream_;
     const int Tx = (pb->W + SGR_TILE - 1) / SGR_TILE, Ty = (pb->H + SGR_TILE - 1) / SGR_TILE;
     const uint32_t tiles = (uint32_t)Tx * Ty;
-    const bool use_aux = aux_compact && aux_ckpt_tc && aux_ckpt_da && aux_desc && out_color && out_depth && out_alpha && part && flags;
+    const bool use_aux = aux_compact && aux_ckpt_tc && aux_ckpt_da && aux_desc && out_color && out_depth && out_alpha && part && flags && rect;
     if (use_aux) {
         if (R > 0 && !flags_cleared) SGR_CHECK_HIP(hipMemsetAsync(flags, 0, (size_t)R * 4, stream));   // (else: cleared by the forward chain)
     } else {
@@ -1024,7 +1025,7 @@ int sgr_render_backward_ex(const SgrProblem *pb, const uint32_t *ranges, const u
         const uint32_t nblocks = ((aux.NS + bpw - 1u) / bpw + 7u) / 8u * 32u;      // per quadrant ceil(NS / bpw) workgroups, in groups of 8 x 4 quadrants
 #define SGR_LAUNCH_BWD(DA, SP, RW)                                                                                          \
         hipLaunchKernelGGL((render_bwd_bucket_kernel<DA, SP, RW>), dim3(nblocks), dim3(kBlock), 0, stream, pb->W, pb->H, Tx, tiles,    \
-                           (const uint2 *)ranges, (const float4 *)rec, n_contrib, out_color, out_depth, out_alpha, grad_color,         \
+                           (const uint2 *)ranges, (const float4 *)rec, (const uint4 *)rect, n_contrib, out_color, out_depth, out_alpha, grad_color, \
                            grad_depth, grad_alpha, grad_color_scale, aux, (float4 *)part, (uint8_t *)flags)
         const bool da = grad_depth || grad_alpha, rows = aux_layout == 2;
         if (rows) {
@@ -1045,14 +1046,14 @@ int sgr_render_backward_ex(const SgrProblem *pb, const uint32_t *ranges, const u
     return 0;
 }
 
-extern "C" int sgr_render_backward(const SgrProblem *pb, const uint32_t *ranges, const uint32_t *point_list, const float *rec,
+extern "C" int sgr_render_backward(const SgrProblem *pb, const uint32_t *ranges, const uint32_t *point_list, const float *rec, const uint32_t *rect,
                                    const float *final_T, const uint32_t *n_contrib, const float *out_color,
                                    const float *out_depth, const float *out_alpha, const float *grad_color,
                                    const float *grad_depth, const float *grad_alpha, const float *grad_color_scale, uint64_t R,
                                    const void *aux_compact, const void *aux_ckpt_tc, const void *aux_ckpt_da, const void *aux_desc,
                                    float *grec, float *part, uint32_t *flags, void *stream_) {
     const uint64_t tiles_total = (uint64_t)((pb->W + SGR_TILE - 1) / SGR_TILE) * ((pb->H + SGR_TILE - 1) / SGR_TILE) * pb->n_views;
-    return sgr_render_backward_ex(pb, ranges, point_list, rec, final_T, n_contrib, out_color, out_depth, out_alpha, grad_color, grad_depth,
+    return sgr_render_backward_ex(pb, ranges, point_list, rec, rect, final_T, n_contrib, out_color, out_depth, out_alpha, grad_color, grad_depth,
                                   grad_alpha, grad_color_scale, R, aux_compact, aux_ckpt_tc, aux_ckpt_da, aux_desc, grec, part, flags, false,
                                   sgr_aux_layout_for(sgr_bucket_slots(R, tiles_total)), stream_);
 }
