@@ -542,7 +542,9 @@ __global__ __launch_bounds__(kThreads) void radix_onesweep_kernel(const uint64_t
 // the same code through the global ping-pong buffers.  The result is bit-identical to one stable sort of the full key.
 constexpr int kSegCapSmall = 1024, kSegCapLarge = 4096;
 
-template <int NT, bool IN_LDS>
+// BY_VAL (global path only): the digits are taken from the VALUE instead of the depth bits -- the first half of a sort by the
+// (depth, value) composite for segments whose entries arrive in arbitrary order (view-segmented flavour, tiles beyond 16384 entries)
+template <int NT, bool IN_LDS, bool BY_VAL = false>
 __device__ __forceinline__ void seg_sort_passes(uint32_t n, uint32_t *ka, uint32_t *va, uint32_t *kb, uint32_t *vb,
                                                 uint64_t *gka, uint32_t *gva, uint64_t *gkb, uint32_t *gvb, bool &in_b,
                                                 uint32_t *hist, uint32_t *digit_base, uint32_t (*wave_cnt)[kRadix], uint32_t *wtot) {
@@ -554,7 +556,7 @@ __device__ __forceinline__ void seg_sort_passes(uint32_t n, uint32_t *ka, uint32
         if (t < kRadix) hist[t] = 0;
         __syncthreads();
         for (uint32_t k = t; k < n; k += NT) {
-            const uint32_t key = IN_LDS ? (in_b ? kb[k] : ka[k]) : (uint32_t)(in_b ? gkb[k] : gka[k]);
+            const uint32_t key = IN_LDS ? (in_b ? kb[k] : ka[k]) : (BY_VAL ? (in_b ? gvb[k] : gva[k]) : (uint32_t)(in_b ? gkb[k] : gka[k]));
             atomicAdd(&hist[(key >> shift) & (kRadix - 1)], 1u);
         }
         __syncthreads();
@@ -594,7 +596,7 @@ __device__ __forceinline__ void seg_sort_passes(uint32_t n, uint32_t *ka, uint32
                 if (IN_LDS) { key = in_b ? kb[k] : ka[k]; val = in_b ? vb[k] : va[k]; }
                 else { key64 = in_b ? gkb[k] : gka[k]; key = (uint32_t)key64; val = in_b ? gvb[k] : gva[k]; }
             }
-            const uint32_t d = (key >> shift) & (kRadix - 1);
+            const uint32_t d = ((BY_VAL ? val : key) >> shift) & (kRadix - 1);
             if (!TWO_LEVEL) {
                 if (t < kRadix) {
 #pragma unroll
@@ -658,8 +660,10 @@ struct SortPrep {               // optional piggy-back job of the large-class la
     uint2 *desc; size_t n_desc; uint32_t *order; uint32_t tiles_total; int enabled;
 };
 
-// sorts ONE tile's segment by its depth bits (stable), src -> dst; all NT threads of the workgroup take part
-template <int NT, int CAP>
+// sorts ONE tile's segment by its depth bits (stable), src -> dst; all NT threads of the workgroup take part.
+// UNORDERED: the entries do not arrive in emission order (view-segmented flavour): stable passes over the value bits first, then over
+// the depth bits = order by the (depth, value) composite, through the global ping-pong pair whatever the length.
+template <int NT, int CAP, bool UNORDERED = false>
 __device__ __forceinline__ void sort_one_tile(const uint2 range, uint64_t *__restrict__ src_keys, uint32_t *__restrict__ src_vals,
                                               uint64_t *__restrict__ dst_keys, uint32_t *__restrict__ dst_vals, uint32_t *ka, uint32_t *va,
                                               uint32_t *kb, uint32_t *vb, uint32_t *hist, uint32_t *digit_base,
@@ -669,7 +673,14 @@ __device__ __forceinline__ void sort_one_tile(const uint2 range, uint64_t *__res
     uint64_t *gsrc_k = src_keys + range.x, *gdst_k = dst_keys + range.x;
     uint32_t *gsrc_v = src_vals + range.x, *gdst_v = dst_vals + range.x;
     bool in_b = false;
-    if (n <= (uint32_t)CAP) {
+    if (UNORDERED) {
+        seg_sort_passes<NT, false, true>(n, nullptr, nullptr, nullptr, nullptr, gsrc_k, gsrc_v, gdst_k, gdst_v, in_b, hist, digit_base, wave_cnt, wtot);
+        seg_sort_passes<NT, false, false>(n, nullptr, nullptr, nullptr, nullptr, gsrc_k, gsrc_v, gdst_k, gdst_v, in_b, hist, digit_base, wave_cnt, wtot);
+        __threadfence_block();
+        __syncthreads();
+        if (!in_b)
+            for (uint32_t k = t; k < n; k += NT) { gdst_k[k] = gsrc_k[k]; gdst_v[k] = gsrc_v[k]; }
+    } else if (n <= (uint32_t)CAP) {
         const uint32_t hi = (uint32_t)(gsrc_k[0] >> 32);                      // tile id, identical for the whole segment
         for (uint32_t k = t; k < n; k += NT) { ka[k] = (uint32_t)gsrc_k[k]; va[k] = gsrc_v[k]; }
         __syncthreads();
@@ -734,7 +745,7 @@ __global__ __launch_bounds__(NT) void tile_sort_dyn_kernel(const uint2 *__restri
         const uint32_t wi = s_item;
         if (wi >= nwork) return;
         const uint2 range = ranges[w.list[wi]];
-        if (range.y > range.x) sort_one_tile<NT, CAP>(range, src_keys, src_vals, dst_keys, dst_vals, ka, va, kb, vb, hist, digit_base, wave_cnt, wtot);
+        if (range.y > range.x) sort_one_tile<NT, CAP, true>(range, src_keys, src_vals, dst_keys, dst_vals, ka, va, kb, vb, hist, digit_base, wave_cnt, wtot);
     }
 }
 
@@ -1003,16 +1014,15 @@ __global__ __launch_bounds__(64 * NW) void tile_sort_regs_kernel(const uint2 *__
 // ---- F4 + F5, VIEW-SEGMENTED flavour for multi-view batches and large launches -----------------------------------
 // The emission is view-major (duplicate_keys: blockIdx.y = view, offsets from the scan of the per-block counts), so the view bits of
 // the key are sorted before the sort starts: what remains is, per view, a sort by (tile-in-view, depth).  ONE stable counting pass per
-// view over the tile id (<= 4096 tiles per view: 1024^2 images) puts every tile's instances into one contiguous segment, still in
-// emission order, and yields the tile ranges (F5) and the worklist of occupied tiles as by-products of its scan; the depth bits are
+// view over the tile id (<= 4096 tiles per view: 1024^2 images) puts every tile's instances into one contiguous segment and yields the tile ranges (F5) and the worklist of occupied tiles as by-products of its scan; the depth bits are
 // then sorted per tile in LDS (tile_sort_dyn_kernel).  Per key: 8 B (histogram) + 24 B (scatter) + 24 B (per-tile sort) of HBM
 // traffic instead of 6-7 whole-key passes of 32 B.
 //   vseg_view_totals -> vseg_plan   per-view key ranges from the per-block emission counts; the keys are cut into CHUNKS of
 //                                   256 * ITEMS keys that never straddle a view: chunk_map[c] = (view, first key, count)
 //   vseg_upsweep                    per-chunk tile histogram, hist[c][tile]
 //   vseg_scan (one workgroup/view)  hist[c][tile] <- keys of that tile in earlier chunks of the view; tile totals -> ranges, worklists
-//   vseg_downsweep                  stable scatter: every wave owns a contiguous quarter of the chunk, positions from per-(wave, tile)
-//                                   running counters in LDS -- three workgroup barriers per chunk instead of three per 256 keys
+//   vseg_scatter                    every key claims the next slot of its tile with one returning LDS atomic (no stability needed: the
+//                                   per-tile sort orders (depth, value) composites, and the value grows with the emission order)
 // All sizes come from device memory (sync-free mode: the host only knows the capacity).
 struct VsegPlan { uint32_t n_chunks, pad[7], count[8], ticket[8]; };      // worklists by tile size: <= 1024, <= 2048, <= 4096, <= 8192, <= 16384, longer
 constexpr int kVsegMaxViews = 4096, kVsegMaxBins = 4096;
@@ -1173,67 +1183,40 @@ __global__ __launch_bounds__(1024) void vseg_scan_kernel(const uint32_t *__restr
     }
 }
 
+// scatter: the per-tile sort orders (depth, value) composites, so the tile pass needs NO stability -- every key simply claims the next free
+// slot of its tile with one returning LDS atomic: one 16-KB counter array per workgroup whatever the number of waves (the stable version
+// kept a counter array per wave: 64 KB at 4096 tiles per view, two workgroups per CU, 0.85 ms at C4), no match-any ballots.
 template <int MAXB, int ITEMS>
-__global__ __launch_bounds__(kThreads) void vseg_downsweep_kernel(const uint64_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
-                                                                  uint64_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out,
-                                                                  const VsegPlan *__restrict__ plan, const uint4 *__restrict__ chunk_map,
-                                                                  uint32_t tiles_per_view, const uint32_t *__restrict__ hist,
-                                                                  const uint2 *__restrict__ ranges) {
-    __shared__ uint32_t pos[4][MAXB];                 // phase 1: per-wave tile histogram; phase 3: next output position per (wave, tile)
+__global__ __launch_bounds__(kThreads) void vseg_scatter_kernel(const uint64_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
+                                                                uint64_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out,
+                                                                const VsegPlan *__restrict__ plan, const uint4 *__restrict__ chunk_map,
+                                                                uint32_t tiles_per_view, const uint32_t *__restrict__ hist,
+                                                                const uint2 *__restrict__ ranges) {
+    __shared__ uint32_t pos[MAXB];                    // next output position per tile for THIS chunk's keys
     const uint32_t c = blockIdx.x;
     if (c >= plan->n_chunks) return;
     const uint4 cm = chunk_map[c];
-    const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    for (uint32_t d = t; d < tiles_per_view; d += kThreads) { pos[0][d] = 0; pos[1][d] = 0; pos[2][d] = 0; pos[3][d] = 0; }
-    __syncthreads();
+    const uint32_t t = threadIdx.x;
     const uint32_t tbase = cm.x * tiles_per_view;
-    // wave w owns keys [w * 64 * ITEMS, (w + 1) * 64 * ITEMS) of the chunk, consumed 64 at a time in memory order.
-    // (straight-line code on purpose: clamped loads + validity predicates instead of branches; with conditional loads and an early exit
-    // in the unrolled loop the compiler produced 436 VGPRs of copies)
+    // (straight-line code: clamped loads + validity predicates instead of branches)
     uint64_t key[ITEMS];
     uint32_t val[ITEMS];
-    const uint32_t wbase = wave * (64 * ITEMS);
     const uint32_t last = cm.z - 1u;                             // (cm.z >= 1 for every mapped chunk)
 #pragma unroll
     for (int it = 0; it < ITEMS; it++) {
-        const uint32_t k = min(wbase + it * 64 + lane, last);
+        const uint32_t k = min((uint32_t)it * kThreads + t, last);
         key[it] = keys_in[cm.y + k]; val[it] = vals_in[cm.y + k];
     }
-#pragma unroll
-    for (int it = 0; it < ITEMS; it++) {
-        const uint32_t k = wbase + it * 64 + lane;
-        if (k < cm.z) atomicAdd(&pos[wave][(uint32_t)(key[it] >> 32) - tbase], 1u);
-    }
-    __syncthreads();
     const uint32_t *hrow = hist + (size_t)c * tiles_per_view;
-    for (uint32_t d = t; d < tiles_per_view; d += kThreads) {
-        const uint32_t h0 = pos[0][d], h1 = pos[1][d], h2 = pos[2][d];
-        const uint32_t g = ranges[tbase + d].x + hrow[d];        // first output slot of this chunk's keys of tile d
-        pos[0][d] = g; pos[1][d] = g + h0; pos[2][d] = g + h0 + h1; pos[3][d] = g + h0 + h1 + h2;
-    }
+    for (uint32_t d = t; d < tiles_per_view; d += kThreads) pos[d] = ranges[tbase + d].x + hrow[d];   // first slot of this chunk's keys of tile d
     __syncthreads();
-    const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    uint32_t *mypos = pos[wave];
 #pragma unroll
     for (int it = 0; it < ITEMS; it++) {
-        const uint32_t k = wbase + it * 64 + lane;
-        const bool valid = k < cm.z;
-        const uint32_t d = (uint32_t)(key[it] >> 32) - tbase;
-        uint64_t peers = __ballot(valid);
-#pragma unroll
-        for (int b = 0; b < 12; b++) {
-            if ((1u << b) >= (uint32_t)MAXB) break;
-            const bool bit = (d >> b) & 1;
-            const uint64_t m = __ballot(bit);
-            peers &= bit ? m : ~m;
+        const uint32_t k = (uint32_t)it * kThreads + t;
+        if (k < cm.z) {
+            const uint32_t slot = atomicAdd(&pos[(uint32_t)(key[it] >> 32) - tbase], 1u);
+            keys_out[slot] = key[it]; vals_out[slot] = val[it];
         }
-        const uint32_t rank = (uint32_t)__popcll(peers & lt_mask);
-        // the leader of every group of equal tiles moves the tile's counter on with one returning LDS atomic (a wave's LDS atomics
-        // execute in program order: later steps get later slots) and hands the old value to its group
-        uint32_t old = 0;
-        if (valid && rank == 0) old = atomicAdd(&mypos[d], (uint32_t)__popcll(peers));
-        const uint32_t base = (uint32_t)__shfl((int)old, valid ? __builtin_ctzll(peers) : 0, 64);
-        if (valid) { keys_out[base + rank] = key[it]; vals_out[base + rank] = val[it]; }
     }
 }
 
@@ -1383,10 +1366,10 @@ int sgr_bin_ex(const SgrProblem *pb, const int32_t *radii, uint32_t *rect,
         hipLaunchKernelGGL(vseg_scan_kernel, dim3(pb->n_views), dim3(1024), 0, stream, tile_total, key_start, tpv, (uint2 *)ranges, plan, lists,
                            (uint32_t)tiles_total);
         if (VL.chunk_keys == 4096u)
-            hipLaunchKernelGGL((vseg_downsweep_kernel<1024, 16>), dim3(VL.max_chunks), dim3(kThreads), 0, stream, kin, vin, kout, vout, plan, chunk_map,
+            hipLaunchKernelGGL((vseg_scatter_kernel<1024, 16>), dim3(VL.max_chunks), dim3(kThreads), 0, stream, kin, vin, kout, vout, plan, chunk_map,
                                tpv, vhist, (const uint2 *)ranges);
         else
-            hipLaunchKernelGGL((vseg_downsweep_kernel<4096, 32>), dim3(VL.max_chunks), dim3(kThreads), 0, stream, kin, vin, kout, vout, plan, chunk_map,
+            hipLaunchKernelGGL((vseg_scatter_kernel<4096, 32>), dim3(VL.max_chunks), dim3(kThreads), 0, stream, kin, vin, kout, vout, plan, chunk_map,
                                tpv, vhist, (const uint2 *)ranges);
         SGR_CHECK_LAUNCH("view-segmented tile pass");
         // depth bits per tile: keys now sit tile-bucketed in (kout, vout); the sorted list goes back into (kin, vin)

@@ -431,6 +431,52 @@ def test_sort_flavours_bit_exact_multiview(sort_mode, oracle):
         _cabi.lib().sgr_set_sort_mode(3)
 
 
+def test_view_segmented_sort_with_oversize_tiles(oracle):
+    """View-segmented flavour with tiles beyond every register-sort class: 45 000 small Gaussians in a thin column (a handful of tiles hold
+    > 16 384 entries each, one of them far more) next to ordinary tiles, two views.  The tile pass hands its segments over in arbitrary
+    order, so the oversize fallback has to order (depth, value) composites itself; many depth ties (quantised depths) make the value
+    order matter.  Keys, point list and ranges must be the oracle's."""
+    from sigman_release_amd import _cabi, synthetic
+    from sigman_release_amd import rasterizer as R
+    dev = _dev()
+    rng = np.random.default_rng(77)
+    P = 45_000
+    g = synthetic.random_cloud(P, 7)
+    pos = g["position"] * np.array([0.02, 0.02, 0.9])
+    pos[:, 2] = np.round(pos[:, 2] * 40) / 40                                     # 73 distinct depths: plenty of exact (tile, depth) ties
+    pos[-6000:] = g["position"][-6000:]                                            # ... and some ordinary splats all over the image
+    g["position"] = pos.astype(np.float32)
+    g["world_scale"] = np.full((P, 3), 0.004, np.float32)
+    inp = dict(means3D=g["position"], opacities=g["opacity"].reshape(P), colors_precomp=g["rgb"], cov3D_precomp=synthetic.covariance_from_gaussians(g))
+    views = (30, 65)
+    _, st = cases.cloud_precomp(P=4, H=160, W=176, seed=1, views=views)
+    tiles = (176 // 16) * (160 // 16)
+    keys, plist, ranges, off, longest = [], [], [], 0, []
+    for v in range(len(views)):
+        r = oracle.forward(**inp, **cases.single_view(st, v), render=False)
+        longest.append(int(np.bincount((r.keys >> np.uint64(32)).astype(np.int64), minlength=tiles).max()))
+        keys.append(r.keys + (np.uint64(v * tiles) << np.uint64(32)))
+        plist.append(r.point_list.astype(np.uint32) + np.uint32(v * P))
+        rg = r.ranges.astype(np.uint32).copy()
+        rg[rg[:, 1] > rg[:, 0]] += np.uint32(off)
+        ranges.append(rg)
+        off += r.R
+    keys, plist, ranges = np.concatenate(keys), np.concatenate(plist), np.stack(ranges)
+    assert max(longest) > 16384 and 4096 < min(longest) <= 16384, longest          # the global fallback AND the 16-wave register class
+    d = _to_dev(inp, dev)
+    _cabi.lib().sgr_set_sort_mode(4)
+    try:
+        for cap in (0, off + 1000):
+            out = R.forward_debug(d["means3D"][None], d["opacities"][None], colors_precomp=d["colors_precomp"][None],
+                                  cov3D_precomp=d["cov3D_precomp"][None], settings=_batched_settings(st, dev, len(views))._replace(max_rendered=cap))
+            torch.cuda.synchronize()
+            np.testing.assert_array_equal(out["keys"].cpu().numpy().view(np.uint64), keys)
+            np.testing.assert_array_equal(out["point_list"].cpu().numpy().astype(np.uint32), plist)
+            np.testing.assert_array_equal(out["ranges"].cpu().numpy().astype(np.uint32), ranges)
+    finally:
+        _cabi.lib().sgr_set_sort_mode(3)
+
+
 def _check_against_observed(name, stats):
     """Full-size parity bookkeeping.  fp32 exp on the GPU (v_exp_f32 in the exp2 domain) and libm expf on the CPU differ in the last
     ulp, so out of ~1e7..1e9 pixel-Gaussian visits a handful land on the other side of the published `alpha < 1/255 -> skip` /
