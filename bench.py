@@ -152,6 +152,11 @@ def fail(msg: str, code: int = 2):
 
 
 def main(args):
+    # stdout carries exactly ONE line (the JSON): libraries that print to fd 1 (gloo's connection banner, RCCL with NCCL_DEBUG set)
+    # go to stderr for the length of the run
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     cfg = dict(CONFIGS[args.config])
     steps = args.steps if args.steps is not None else cfg["steps"]
     warmup = args.warmup if args.warmup is not None else cfg["warmup"]
@@ -386,7 +391,8 @@ def main(args):
                 os.sched_setaffinity(0, _ORIG_AFFINITY)      # the OpenMP oracle gets every host core
             out["cpu_baseline"] = cpu_baseline(g_host, cov_host, mine[0], H, W, None if gt is None else gt[0].cpu().numpy(), norm, bwd, da)
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

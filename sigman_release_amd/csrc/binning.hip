@@ -761,13 +761,28 @@ __global__ __launch_bounds__(NT) void tile_sort_dyn_kernel(const uint2 *__restri
 // LDS capacity limits the number of tiles in flight (measured on MI355X, tools/micro/bench_tile_sort.hip, 12 000 tiles: 250-entry
 // tiles 98 us vs 176 us for the LDS radix sort, 1000-entry tiles 224 vs 215 us, 3000 x 2000 entries 164 vs 208 us; tiles beyond the
 // LDS radix sort's 4096-entry capacity -- which went through global memory, ~100 us per tile -- stay in registers up to 16384).
+// Composites are built as bit patterns of POSITIVE FINITE doubles (high word = the bits of a depth > 0.2, clamped below the
+// all-ones exponent; low word = the value), for which the order as doubles IS the order as 64-bit integers: a compare-exchange is one
+// v_min_f64 + one v_max_f64 (full rate on CDNA4) instead of v_cmp_u64 + 4 v_cndmask + the SGPR wait states between them.
+// (binning.o is compiled with -fno-honor-nans so that no canonicalising v_max_f64 x, x is put in front of every operand.)
+constexpr uint32_t kCompositeHiMax = 0x7FEFFFFFu;
+constexpr uint64_t kCompositePad = 0x7FEFFFFFFFFFFFFFull;
+template <typename T> __device__ __forceinline__ T sgr_min_t(T x, T y) {
+    if constexpr (sizeof(T) == 8) return __builtin_bit_cast(uint64_t, __builtin_fmin(__builtin_bit_cast(double, x), __builtin_bit_cast(double, y)));
+    else return x < y ? x : y;
+}
+template <typename T> __device__ __forceinline__ T sgr_max_t(T x, T y) {
+    if constexpr (sizeof(T) == 8) return __builtin_bit_cast(uint64_t, __builtin_fmax(__builtin_bit_cast(double, x), __builtin_bit_cast(double, y)));
+    else return x < y ? y : x;
+}
+
 template <int M>
 __device__ __forceinline__ uint32_t sgr_xlane(uint32_t v) {                       // value of lane (l ^ M), M a compile-time constant
-    if constexpr (M == 1) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);          // quad_perm [1,0,3,2]
-    else if constexpr (M == 2) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false);     // quad_perm [2,3,0,1]
-    else if constexpr (M == 3) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x1B, 0xF, 0xF, false);     // quad_perm [3,2,1,0]
-    else if constexpr (M == 7) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, false);    // row_half_mirror
-    else if constexpr (M == 15) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, false);   // row_mirror
+    if constexpr (M == 1) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);          // quad_perm [1,0,3,2]
+    else if constexpr (M == 2) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);     // quad_perm [2,3,0,1]
+    else if constexpr (M == 3) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x1B, 0xF, 0xF, true);     // quad_perm [3,2,1,0]
+    else if constexpr (M == 7) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true);    // row_half_mirror
+    else if constexpr (M == 15) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, true);   // row_mirror
     else if constexpr (M < 32) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x1F | (M << 10));             // bit-mask mode: xor within 32 lanes
     else return (uint32_t)__shfl_xor((int)v, M, 64);
 }
@@ -794,12 +809,12 @@ __device__ __forceinline__ T sgr_cex_lane(T a, uint32_t lane) {
             const auto r = __builtin_amdgcn_permlane32_swap(a, a, false, false);
             x = r[0]; y = r[1];
         }
-        const T mn = y < x ? y : x, mx = y < x ? x : y;
+        const T mn = sgr_min_t(x, y), mx = sgr_max_t(x, y);
         return upper ? mx : mn;
     } else {
         const T b = sgr_xlane_t<M, T>(a);
-        if constexpr (sizeof(T) == 8) return ((b < a) != upper) ? b : a;
-        else { const T mn = b < a ? b : a, mx = b < a ? a : b; return upper ? mx : mn; }     // v_min_u32 / v_max_u32 / v_cndmask
+        const T mn = sgr_min_t(a, b), mx = sgr_max_t(a, b);
+        return upper ? mx : mn;
     }
 }
 
@@ -814,7 +829,7 @@ __device__ __forceinline__ void sgr_bitonic_flip(T (&a)[IPT], uint32_t lane) {
 #pragma unroll
         for (int r = 0; r < IPT; r++) {
             const int p = r ^ (K - 1);
-            if (p > r) { const T x = a[r], y = a[p]; const bool sw = y < x; a[r] = sw ? y : x; a[p] = sw ? x : y; }
+            if (p > r) { const T x = a[r], y = a[p]; a[r] = sgr_min_t(x, y); a[p] = sgr_max_t(x, y); }
         }
     } else if constexpr (K <= 64 * IPT) {
         // partner: lane ^ (K / IPT - 1), register IPT - 1 - r; lanes whose top bit of that mask is clear keep the smaller composite
@@ -825,11 +840,8 @@ __device__ __forceinline__ void sgr_bitonic_flip(T (&a)[IPT], uint32_t lane) {
             constexpr int dummy = 0; (void)dummy;
             const int q = IPT - 1 - r;
             const T br = sgr_xlane_t<M, T>(a[q]), bq = sgr_xlane_t<M, T>(a[r]);
-            if constexpr (sizeof(T) == 8) { a[r] = ((br < a[r]) != upper) ? br : a[r]; a[q] = ((bq < a[q]) != upper) ? bq : a[q]; }
-            else {
-                const T mnr = br < a[r] ? br : a[r], mxr = br < a[r] ? a[r] : br, mnq = bq < a[q] ? bq : a[q], mxq = bq < a[q] ? a[q] : bq;
-                a[r] = upper ? mxr : mnr; a[q] = upper ? mxq : mnq;
-            }
+            const T mnr = sgr_min_t(a[r], br), mxr = sgr_max_t(a[r], br), mnq = sgr_min_t(a[q], bq), mxq = sgr_max_t(a[q], bq);
+            a[r] = upper ? mxr : mnr; a[q] = upper ? mxq : mnq;
         }
     }
 }
@@ -839,49 +851,47 @@ __device__ __forceinline__ void sgr_bitonic_shift(T (&a)[IPT], uint32_t lane) {
     if constexpr (J < IPT) {
 #pragma unroll
         for (int r = 0; r < IPT; r++)
-            if ((r & J) == 0) { const T x = a[r], y = a[r | J]; const bool sw = y < x; a[r] = sw ? y : x; a[r | J] = sw ? x : y; }
+            if ((r & J) == 0) { const T x = a[r], y = a[r | J]; a[r] = sgr_min_t(x, y); a[r | J] = sgr_max_t(x, y); }
     } else if constexpr (J < 64 * IPT) {
 #pragma unroll
         for (int r = 0; r < IPT; r++) a[r] = sgr_cex_lane<J / IPT, J / IPT, T>(a[r], lane);
     }
 }
 
+// lane-crossing stages, selected by the LANE mask (element distance / IPT): one copy of each body behind a switch
 template <typename T, int IPT>
-__device__ __forceinline__ void sgr_stage_flip(T (&a)[IPT], uint32_t lane, int K) {
-    switch (K) {
-        case 2: sgr_bitonic_flip<T, IPT, 2>(a, lane); break;
-        case 4: sgr_bitonic_flip<T, IPT, 4>(a, lane); break;
-        case 8: sgr_bitonic_flip<T, IPT, 8>(a, lane); break;
-        case 16: sgr_bitonic_flip<T, IPT, 16>(a, lane); break;
-        case 32: sgr_bitonic_flip<T, IPT, 32>(a, lane); break;
-        case 64: sgr_bitonic_flip<T, IPT, 64>(a, lane); break;
-        case 128: sgr_bitonic_flip<T, IPT, 128>(a, lane); break;
-        case 256: sgr_bitonic_flip<T, IPT, 256>(a, lane); break;
-        case 512: sgr_bitonic_flip<T, IPT, 512>(a, lane); break;
-        default: sgr_bitonic_flip<T, IPT, 1024>(a, lane); break;
+__device__ __forceinline__ void sgr_stage_flip_lanes(T (&a)[IPT], uint32_t lane, int lanes /* K / IPT: 2 .. 64 */) {
+    switch (lanes) {
+        case 2: sgr_bitonic_flip<T, IPT, 2 * IPT>(a, lane); break;
+        case 4: sgr_bitonic_flip<T, IPT, 4 * IPT>(a, lane); break;
+        case 8: sgr_bitonic_flip<T, IPT, 8 * IPT>(a, lane); break;
+        case 16: sgr_bitonic_flip<T, IPT, 16 * IPT>(a, lane); break;
+        case 32: sgr_bitonic_flip<T, IPT, 32 * IPT>(a, lane); break;
+        default: sgr_bitonic_flip<T, IPT, 64 * IPT>(a, lane); break;
     }
 }
 template <typename T, int IPT>
-__device__ __forceinline__ void sgr_stage_shift(T (&a)[IPT], uint32_t lane, int J) {
-    switch (J) {
-        case 1: sgr_bitonic_shift<T, IPT, 1>(a, lane); break;
-        case 2: sgr_bitonic_shift<T, IPT, 2>(a, lane); break;
-        case 4: sgr_bitonic_shift<T, IPT, 4>(a, lane); break;
-        case 8: sgr_bitonic_shift<T, IPT, 8>(a, lane); break;
-        case 16: sgr_bitonic_shift<T, IPT, 16>(a, lane); break;
-        case 32: sgr_bitonic_shift<T, IPT, 32>(a, lane); break;
-        case 64: sgr_bitonic_shift<T, IPT, 64>(a, lane); break;
-        case 128: sgr_bitonic_shift<T, IPT, 128>(a, lane); break;
-        case 256: sgr_bitonic_shift<T, IPT, 256>(a, lane); break;
-        default: sgr_bitonic_shift<T, IPT, 512>(a, lane); break;
+__device__ __forceinline__ void sgr_stage_shift_lanes(T (&a)[IPT], uint32_t lane, int lanes /* J / IPT: 1 .. 32 */) {
+    switch (lanes) {
+        case 1: sgr_bitonic_shift<T, IPT, IPT>(a, lane); break;
+        case 2: sgr_bitonic_shift<T, IPT, 2 * IPT>(a, lane); break;
+        case 4: sgr_bitonic_shift<T, IPT, 4 * IPT>(a, lane); break;
+        case 8: sgr_bitonic_shift<T, IPT, 8 * IPT>(a, lane); break;
+        case 16: sgr_bitonic_shift<T, IPT, 16 * IPT>(a, lane); break;
+        default: sgr_bitonic_shift<T, IPT, 32 * IPT>(a, lane); break;
     }
 }
 
-// all shift steps of one wave's 64 * IPT elements (the tail of a merge level whose upper steps ran across waves)
-template <typename T, int IPT>
-__device__ __forceinline__ void sgr_local_shifts(T (&a)[IPT], uint32_t lane, int j_from) {
-#pragma nounroll
-    for (int j = j_from; j >= 1; j >>= 1) sgr_stage_shift<T, IPT>(a, lane, j);
+// the stages that stay inside a lane's IPT registers, as straight-line code (two instructions per compare-exchange, and only the
+// final assignment of a fused run has to land in the loop-carried registers):
+//   head = levels K = 2 .. IPT (every lane sorts its own registers);  tail = the shifts IPT/2 .. 1 that end every later level
+template <typename T, int IPT, int J>
+__device__ __forceinline__ void sgr_tail_from(T (&a)[IPT], uint32_t lane) {
+    if constexpr (J >= 1) { sgr_bitonic_shift<T, IPT, J>(a, lane); sgr_tail_from<T, IPT, J / 2>(a, lane); }
+}
+template <typename T, int IPT, int K>
+__device__ __forceinline__ void sgr_head_from(T (&a)[IPT], uint32_t lane) {
+    if constexpr (K <= IPT) { sgr_bitonic_flip<T, IPT, K>(a, lane); sgr_tail_from<T, IPT, K / 4>(a, lane); sgr_head_from<T, IPT, K * 2>(a, lane); }
 }
 
 // `nw` waves (a sub-group of the workgroup, nw a RUNTIME power of two) sort nw * 64 * IPT composites: wave `sub` holds elements
@@ -897,14 +907,15 @@ __device__ __forceinline__ void sgr_bitonic_sort_group(T (&a)[IPT], uint32_t lan
     constexpr int WAVE_ELEMS = 64 * IPT;
     T *mine = gx + sub * (uint32_t)WAVE_ELEMS;
     const int Kmax = WAVE_ELEMS * nw;
+    sgr_head_from<T, IPT, 2>(a, lane);
 #pragma nounroll
-    for (int K = 2; K <= Kmax; K <<= 1) {
-        // one merge level: the flip (partner e ^ (K - 1)), then shifts (partner e ^ j) for j = K/4, K/8, .., 1
+    for (int K = 2 * IPT; K <= Kmax; K <<= 1) {
+        // one merge level: the flip (partner e ^ (K - 1)), then shifts (partner e ^ j) for j = K/4, K/8, .., IPT, then the in-lane tail
 #pragma nounroll
         for (int step = 0;; step++) {
             const bool first = step == 0;
             const int j = first ? 0 : (K >> 1) >> step;
-            if (!first && j < 1) break;
+            if (!first && j < IPT) break;
             const bool cross = first ? (K > WAVE_ELEMS) : (j >= WAVE_ELEMS);
             if (cross) {
                 // ---- partner in another wave of the sub-group
@@ -919,14 +930,16 @@ __device__ __forceinline__ void sgr_bitonic_sort_group(T (&a)[IPT], uint32_t lan
 #pragma unroll
                 for (int r = 0; r < IPT; r++) {
                     const T b = first ? theirs[(IPT - 1 - r) * 64 + (63 - lane)] : theirs[r * 64 + lane];
-                    a[r] = ((b < a[r]) != upper) ? b : a[r];
+                    const T mn = sgr_min_t(a[r], b), mx = sgr_max_t(a[r], b);
+                    a[r] = upper ? mx : mn;
                 }
             } else if (first) {
-                sgr_stage_flip<T, IPT>(a, lane, K);
+                sgr_stage_flip_lanes<T, IPT>(a, lane, K / IPT);
             } else {
-                sgr_stage_shift<T, IPT>(a, lane, j);
+                sgr_stage_shift_lanes<T, IPT>(a, lane, j / IPT);
             }
         }
+        sgr_tail_from<T, IPT, IPT / 2>(a, lane);
     }
 }
 
@@ -955,7 +968,7 @@ __device__ __forceinline__ void sgr_sort_tile_regs64(const uint64_t *__restrict_
 #pragma unroll
     for (int r = 0; r < IPT; r++) {                                            // coalesced; the input order is irrelevant to the result
         const uint32_t k = wbase + (uint32_t)r * 64u + lane;
-        a[r] = k < n ? (((uint64_t)(uint32_t)gk[k] << 32) | gv[k]) : ~0ull;
+        a[r] = k < n ? (((uint64_t)min((uint32_t)gk[k], kCompositeHiMax) << 32) | gv[k]) : kCompositePad;
     }
     sgr_bitonic_sort_group<uint64_t, IPT>(a, lane, sub, nw, gx);
     if (nw > 1) __syncthreads();                                               // the other waves are done with the last exchange
@@ -979,34 +992,58 @@ __global__ __launch_bounds__(64 * NW) void tile_sort_regs_kernel(const uint2 *__
                                                                  const uint32_t *__restrict__ src_vals, uint64_t *__restrict__ dst_keys,
                                                                  uint32_t *__restrict__ dst_vals, TileWork4 tw, int m_hi, int m_lo) {
     __shared__ uint64_t xbuf[NW * 64 * 17];                                      // per wave 64 x (16 + 1) composites: exchange + final re-deal
-    __shared__ uint32_t s_item;
+    __shared__ uint32_t s_item, s_next;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
 #pragma nounroll
-    for (int m = m_hi; m >= m_lo; m--) {
+    for (int m = m_hi; m >= 1 && m >= m_lo; m--) {
+        // ---- tiles of 1024 << (m - 1) < n <= 1024 << m entries: sub-groups of 2^m waves in lock step (the network has workgroup barriers)
         const int nw = 1 << m;
         const uint32_t groups = (uint32_t)(NW >> m), grp = wave >> m, sub = wave & (uint32_t)(nw - 1);
-        const uint32_t rounds = m == 0 ? 4u : 1u;
         const TileWork w = tw.w[m];
         const uint32_t nwork = *w.count;
+        if (nwork == 0u) continue;                                               // workgroup-uniform
         uint64_t *gx = xbuf + grp * (uint32_t)(nw * 64 * 17);
         for (;;) {
             __syncthreads();
-            if (threadIdx.x == 0) s_item = atomicAdd(w.ticket, groups * rounds);
+            if (threadIdx.x == 0) s_item = atomicAdd(w.ticket, groups);
             __syncthreads();
-            const uint32_t w0 = s_item;
-            if (w0 >= nwork) break;                                              // workgroup-uniform
-#pragma nounroll
-            for (uint32_t rd = 0; rd < rounds; rd++) {
-                const uint32_t wi = w0 + rd * groups + grp;
-                uint2 range = make_uint2(0u, 0u);
-                if (wi < nwork) range = ranges[w.list[wi]];
-                const uint32_t n = range.y - range.x;
-                if (m == 0 && n <= 256u) {                                       // (single-wave class: no workgroup barriers inside the sort)
-                    if (n) sgr_sort_tile_regs64<4>(src_keys + range.x, src_vals + range.x, dst_keys + range.x, dst_vals + range.x, n, lane, 0u, 1, gx);
-                } else {
-                    sgr_sort_tile_regs64<16>(src_keys + range.x, src_vals + range.x, dst_keys + range.x, dst_vals + range.x, n, lane, sub, nw, gx);
-                }
-            }
+            const uint32_t wi = s_item + grp;
+            if (s_item >= nwork) break;                                          // workgroup-uniform
+            uint2 range = make_uint2(0u, 0u);
+            if (wi < nwork) range = ranges[w.list[wi]];
+            sgr_sort_tile_regs64<16>(src_keys + range.x, src_vals + range.x, dst_keys + range.x, dst_vals + range.x, range.y - range.x, lane, sub, nw, gx);
+        }
+    }
+    if (m_lo > 0) return;
+    // ---- tiles of <= 1024 entries: one wave each, no workgroup barriers inside the sort.  The workgroup draws BATCHES of tiles with one
+    // returning global atomic (they complete one every ~9 ns on one address: a ticket per tile was a 0.37-ms serial section for the
+    // 41 000 short tiles of C4), its waves then draw single tiles from the batch through an LDS counter, so a wave with short tiles
+    // takes more of them; batches shrink towards the end of the list (guided self-scheduling) to keep the tail short.
+    const TileWork w = tw.w[0];
+    const uint32_t nwork = *w.count;
+    if (nwork == 0u) return;
+    uint64_t *gx = xbuf + wave * (uint32_t)(64 * 17);
+    uint32_t seen = 0;
+    for (;;) {
+        const uint32_t left = nwork - min(nwork, seen);
+        const uint32_t want = min((uint32_t)(4 * NW), max((uint32_t)NW, left / (2u * gridDim.x)));
+        __syncthreads();                                                         // every wave is done with the previous batch
+        if (threadIdx.x == 0) { s_item = atomicAdd(w.ticket, want); s_next = 0u; }
+        __syncthreads();
+        const uint32_t base = s_item;
+        if (base >= nwork) break;                                                // workgroup-uniform
+        seen = base + want;
+        const uint32_t cnt = min(want, nwork - base);
+        for (;;) {
+            uint32_t i = 0;
+            if (lane == 0) i = atomicAdd(&s_next, 1u);
+            i = (uint32_t)__builtin_amdgcn_readfirstlane((int)i);
+            if (i >= cnt) break;
+            const uint2 range = ranges[w.list[base + i]];
+            const uint32_t n = range.y - range.x;
+            if (n == 0u) continue;
+            if (n <= 256u) sgr_sort_tile_regs64<4>(src_keys + range.x, src_vals + range.x, dst_keys + range.x, dst_vals + range.x, n, lane, 0u, 1, gx);
+            else sgr_sort_tile_regs64<16>(src_keys + range.x, src_vals + range.x, dst_keys + range.x, dst_vals + range.x, n, lane, 0u, 1, gx);
         }
     }
 }

@@ -1,5 +1,6 @@
-// Dev micro-benchmark: the per-tile sort kernels of csrc/binning.hip on synthetic tile lists (hipcc, run on the GPU box).
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -munsafe-fp-atomics -I sigman_release_amd/csrc tools/micro/bench_tile_sort.hip -o /tmp/bts
+// Dev micro-benchmark: the per-tile register sort of csrc/binning.hip on synthetic tile lists (hipcc, run on the GPU box).
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -munsafe-fp-atomics -fno-honor-nans tools/micro/bench_tile_sort.hip -o tools/micro/bts
+//   tools/micro/bts [tools/micro/tile_hist_c3.txt ...]      (files: "<tile length> <count>" lines, e.g. from tools/tile_hist.py)
 #include "../../sigman_release_amd/csrc/binning.hip"
 #include "../../sigman_release_amd/csrc/api.hip"
 #include <string.h>
@@ -7,6 +8,7 @@
 #include <random>
 #include <algorithm>
 #include <cstdio>
+#include <string>
 int sgr_validate_problem(const SgrProblem *) { return 0; }
 int32_t sgr_preprocess_blocks_per_view(int32_t P) { return (P + 255) / 256; }
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
@@ -19,51 +21,83 @@ template <typename F> static float time_it(F f, int reps = 5) {
     return best * 1000.f;
 }
 
-int main(int argc, char **argv) {
+static void run_case(const std::string &name, std::vector<uint32_t> len) {
     std::mt19937 rng(1);
-    struct Case { int ntiles, n; };
-    std::vector<Case> cases = {{1, 100}, {1, 1000}, {1, 2000}, {1, 4000}, {1, 8000}, {3000, 1000}, {12000, 1000}, {12000, 500}, {12000, 250}, {3000, 2000}, {1500, 4000}, {600, 8000}, {1, 16000}, {300, 16000}};
-    for (auto c : cases) {
-        const size_t R = (size_t)c.ntiles * c.n;
-        std::vector<uint64_t> hk(R); std::vector<uint32_t> hv(R); std::vector<uint2> hr(c.ntiles); std::vector<uint32_t> hl(c.ntiles);
-        for (int t = 0; t < c.ntiles; t++) {
-            hr[t] = make_uint2((uint32_t)((size_t)t * c.n), (uint32_t)((size_t)(t + 1) * c.n)); hl[t] = t;
-            for (int k = 0; k < c.n; k++) { float z = 2.3f + 0.2f * (rng() % 100000) / 100000.f; uint32_t zb; memcpy(&zb, &z, 4); hk[(size_t)t * c.n + k] = ((uint64_t)t << 32) | zb; hv[(size_t)t * c.n + k] = (uint32_t)((size_t)t * c.n + k); }
+    std::shuffle(len.begin(), len.end(), rng);
+    const int ntiles = (int)len.size();
+    size_t R = 0;
+    std::vector<uint2> hr(ntiles);
+    for (int t = 0; t < ntiles; t++) { hr[t] = make_uint2((uint32_t)R, (uint32_t)(R + len[t])); R += len[t]; }
+    std::vector<uint64_t> hk(R); std::vector<uint32_t> hv(R);
+    for (int t = 0; t < ntiles; t++)
+        for (uint32_t k = 0; k < len[t]; k++) {
+            float z = 2.3f + 0.2f * (rng() % 4000) / 4000.f;                 // few distinct depths: plenty of ties (stability is checked)
+            uint32_t zb; memcpy(&zb, &z, 4);
+            hk[hr[t].x + k] = ((uint64_t)t << 32) | zb; hv[hr[t].x + k] = hr[t].x + k;
         }
-        uint64_t *ka, *kb; uint32_t *va, *vb, *list, *cnt; uint2 *ranges;
-        CK(hipMalloc(&ka, R * 8)); CK(hipMalloc(&kb, R * 8)); CK(hipMalloc(&va, R * 4)); CK(hipMalloc(&vb, R * 4)); CK(hipMalloc(&list, c.ntiles * 4)); CK(hipMalloc(&cnt, 64)); CK(hipMalloc(&ranges, c.ntiles * 8));
-        CK(hipMemcpy(ka, hk.data(), R * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(va, hv.data(), R * 4, hipMemcpyHostToDevice));
-        CK(hipMemcpy(list, hl.data(), c.ntiles * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(ranges, hr.data(), c.ntiles * 8, hipMemcpyHostToDevice));
-        uint32_t h2[2] = {(uint32_t)c.ntiles, 0};
-        auto reset = [&]() { CK(hipMemcpyAsync(cnt, h2, 8, hipMemcpyHostToDevice, 0)); };
-        TileWork w = {list, cnt + 1, cnt};
-        auto grid = [&](uint32_t per_cu) { return std::min<uint32_t>(c.ntiles, per_cu * 256u); };
-        TileWork4 tw4; TileWork none = {list, cnt + 3, cnt + 2};     // cnt[2] = 0 tiles, cnt[3] ticket
-        for (int k = 0; k < 5; k++) tw4.w[k] = none;
-        const int cls = c.n <= 1024 ? 0 : (c.n <= 2048 ? 1 : (c.n <= 4096 ? 2 : (c.n <= 8192 ? 3 : 4)));
-        tw4.w[cls] = w;
-        uint32_t h4[4] = {(uint32_t)c.ntiles, 0, 0, 0};
-        auto reset4 = [&]() { CK(hipMemcpyAsync(cnt, h4, 16, hipMemcpyHostToDevice, 0)); };
-        float us = 0, us64 = 0; const char *which = "regs<16>"; uint32_t nwide = 0;
-        us = time_it([&]() { reset4(); hipLaunchKernelGGL(tile_sort_regs_kernel<16>, dim3(grid(1)), dim3(1024), 0, 0, ranges, ka, va, kb, vb, tw4, 4, 0); });
-        CK(hipDeviceSynchronize());
-        // verify
-        std::vector<uint64_t> ok(R); std::vector<uint32_t> ov(R);
-        CK(hipMemcpy(ok.data(), kb, R * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(ov.data(), vb, R * 4, hipMemcpyDeviceToHost));
-        bool good = true;
-        for (int t = 0; t < std::min(c.ntiles, 50) && good; t++) {
-            std::vector<std::pair<uint64_t, uint32_t>> ref(c.n);
-            for (int k = 0; k < c.n; k++) ref[k] = {hk[(size_t)t * c.n + k], hv[(size_t)t * c.n + k]};
-            std::stable_sort(ref.begin(), ref.end(), [](auto &x, auto &y) { return x.first < y.first; });
-            for (int k = 0; k < c.n; k++) if (ok[(size_t)t * c.n + k] != ref[k].first || ov[(size_t)t * c.n + k] != ref[k].second) { good = false; break; }
-        }
-        // old kernels for comparison
-        float us_old = 0;
-        if (c.n <= 1024) us_old = time_it([&]() { reset(); hipLaunchKernelGGL((tile_sort_dyn_kernel<256, 1024>), dim3(grid(8)), dim3(256), 0, 0, ranges, ka, va, kb, vb, w); });
-        else if (c.n <= 4096) us_old = time_it([&]() { reset(); hipLaunchKernelGGL((tile_sort_dyn_kernel<1024, 4096>), dim3(grid(1)), dim3(1024), 0, 0, ranges, ka, va, kb, vb, w); });
-        float us_wave = 0;
-        printf("tiles %6d x %5d keys: %-10s u32 %8.1f us (%s, %u wide)  u64 %8.1f us   lds-block %8.1f us   lds-wave %8.1f us   keys/us u32 %.0f\n", c.ntiles, c.n, which, us, good ? "ok" : "WRONG", nwide, us64, us_old, us_wave, R / us);
-        hipFree(ka); hipFree(kb); hipFree(va); hipFree(vb); hipFree(list); hipFree(cnt); hipFree(ranges);
+    // scramble the input order inside each tile (the scatter pass is order-free): the sort must order by (depth, value)
+    for (int t = 0; t < ntiles; t++) {
+        std::vector<uint32_t> perm(len[t]);
+        for (uint32_t k = 0; k < len[t]; k++) perm[k] = k;
+        std::shuffle(perm.begin(), perm.end(), rng);
+        std::vector<uint64_t> tk(len[t]); std::vector<uint32_t> tv(len[t]);
+        for (uint32_t k = 0; k < len[t]; k++) { tk[k] = hk[hr[t].x + perm[k]]; tv[k] = hv[hr[t].x + perm[k]]; }
+        std::copy(tk.begin(), tk.end(), hk.begin() + hr[t].x); std::copy(tv.begin(), tv.end(), hv.begin() + hr[t].x);
+    }
+    // worklists by class, like vseg_scan: [m] = tiles of <= 1024 << m entries
+    std::vector<uint32_t> lists[5];
+    for (int t = 0; t < ntiles; t++) {
+        if (!len[t]) continue;
+        int m = 0; while (m < 4 && len[t] > (1024u << m)) m++;
+        if (len[t] > 16384u) { printf("tile too long\n"); exit(1); }
+        lists[m].push_back(t);
+    }
+    uint64_t *ka, *kb; uint32_t *va, *vb, *list, *cnt; uint2 *ranges;
+    CK(hipMalloc(&ka, R * 8 + 64)); CK(hipMalloc(&kb, R * 8 + 64)); CK(hipMalloc(&va, R * 4 + 64)); CK(hipMalloc(&vb, R * 4 + 64));
+    CK(hipMalloc(&list, (size_t)5 * ntiles * 4 + 64)); CK(hipMalloc(&cnt, 64)); CK(hipMalloc(&ranges, (size_t)ntiles * 8));
+    CK(hipMemcpy(ka, hk.data(), R * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(va, hv.data(), R * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(ranges, hr.data(), (size_t)ntiles * 8, hipMemcpyHostToDevice));
+    uint32_t h[16] = {0};
+    TileWork4 tw4;
+    for (int m = 0; m < 5; m++) {
+        if (!lists[m].empty()) CK(hipMemcpy(list + (size_t)m * ntiles, lists[m].data(), lists[m].size() * 4, hipMemcpyHostToDevice));
+        h[m] = (uint32_t)lists[m].size();                                         // cnt[0..4] counts, cnt[8..12] tickets
+        tw4.w[m] = TileWork{list + (size_t)m * ntiles, cnt + 8 + m, cnt + m};
+    }
+    auto reset = [&]() { CK(hipMemcpyAsync(cnt, h, 64, hipMemcpyHostToDevice, 0)); };
+    const float us = time_it([&]() { reset(); hipLaunchKernelGGL(tile_sort_regs_kernel<16>, dim3(256), dim3(1024), 0, 0, ranges, ka, va, kb, vb, tw4, 4, 0); });
+    CK(hipDeviceSynchronize());
+    std::vector<uint64_t> ok(R); std::vector<uint32_t> ov(R);
+    CK(hipMemcpy(ok.data(), kb, R * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(ov.data(), vb, R * 4, hipMemcpyDeviceToHost));
+    size_t bad = 0;
+    for (int t = 0; t < ntiles; t++) {
+        std::vector<std::pair<uint64_t, uint32_t>> ref(len[t]);
+        for (uint32_t k = 0; k < len[t]; k++) ref[k] = {hk[hr[t].x + k], hv[hr[t].x + k]};
+        std::sort(ref.begin(), ref.end());
+        for (uint32_t k = 0; k < len[t]; k++) if (ok[hr[t].x + k] != ref[k].first || ov[hr[t].x + k] != ref[k].second) { bad++; break; }
+    }
+    printf("%-28s tiles %6d keys %9zu classes [%zu %zu %zu %zu %zu]: %8.1f us  %6.1f keys/ns  %s\n", name.c_str(), ntiles, R, lists[0].size(), lists[1].size(),
+           lists[2].size(), lists[3].size(), lists[4].size(), us, R / us / 1000.0, bad ? "WRONG" : "ok");
+    if (bad) printf("   %zu tiles wrong\n", bad);
+    hipFree(ka); hipFree(kb); hipFree(va); hipFree(vb); hipFree(list); hipFree(cnt); hipFree(ranges);
+}
+
+int main(int argc, char **argv) {
+    struct Case { int ntiles; uint32_t n; };
+    const std::vector<Case> cases = {{1, 100}, {1, 1000}, {1, 8000}, {12000, 250}, {12000, 1000}, {6000, 2000}, {3000, 4000}, {1500, 8000}, {750, 16000}, {3000, 1100}, {3000, 2100}};
+    if (const char *only = getenv("BTS_ONLY")) {                                      // e.g. BTS_ONLY=12000x1000 (for rocprofv3 counter runs)
+        int nt; unsigned n;
+        if (sscanf(only, "%dx%u", &nt, &n) == 2) run_case(only, std::vector<uint32_t>(nt, n));
+        return 0;
+    }
+    for (auto c : cases) run_case(std::to_string(c.ntiles) + " x " + std::to_string(c.n), std::vector<uint32_t>(c.ntiles, c.n));
+    for (int i = 1; i < argc; i++) {
+        FILE *f = fopen(argv[i], "r");
+        if (!f) { printf("cannot open %s\n", argv[i]); continue; }
+        std::vector<uint32_t> len; unsigned n, c;
+        while (fscanf(f, "%u %u", &n, &c) == 2) for (unsigned k = 0; k < c; k++) len.push_back(n);
+        fclose(f);
+        run_case(argv[i], len);
     }
     return 0;
 }
