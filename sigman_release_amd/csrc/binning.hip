@@ -667,13 +667,17 @@ template <int NT, int CAP, bool UNORDERED = false>
 __device__ __forceinline__ void sort_one_tile(const uint2 range, uint64_t *__restrict__ src_keys, uint32_t *__restrict__ src_vals,
                                               uint64_t *__restrict__ dst_keys, uint32_t *__restrict__ dst_vals, uint32_t *ka, uint32_t *va,
                                               uint32_t *kb, uint32_t *vb, uint32_t *hist, uint32_t *digit_base,
-                                              uint32_t (*wave_cnt)[kRadix], uint32_t *wtot) {
+                                              uint32_t (*wave_cnt)[kRadix], uint32_t *wtot, uint32_t tile = 0u) {
     const uint32_t t = threadIdx.x;
     const uint32_t n = range.y - range.x;
     uint64_t *gsrc_k = src_keys + range.x, *gdst_k = dst_keys + range.x;
     uint32_t *gsrc_v = src_vals + range.x, *gdst_v = dst_vals + range.x;
     bool in_b = false;
     if (UNORDERED) {
+        // the scatter pass left (depth bits << 32 | value) composites in src_keys: back to (tile | depth) keys and values first
+        for (uint32_t k = t; k < n; k += NT) { const uint64_t c = gsrc_k[k]; gsrc_k[k] = ((uint64_t)tile << 32) | (c >> 32); gsrc_v[k] = (uint32_t)c; }
+        __threadfence_block();
+        __syncthreads();
         seg_sort_passes<NT, false, true>(n, nullptr, nullptr, nullptr, nullptr, gsrc_k, gsrc_v, gdst_k, gdst_v, in_b, hist, digit_base, wave_cnt, wtot);
         seg_sort_passes<NT, false, false>(n, nullptr, nullptr, nullptr, nullptr, gsrc_k, gsrc_v, gdst_k, gdst_v, in_b, hist, digit_base, wave_cnt, wtot);
         __threadfence_block();
@@ -744,8 +748,9 @@ __global__ __launch_bounds__(NT) void tile_sort_dyn_kernel(const uint2 *__restri
         __syncthreads();
         const uint32_t wi = s_item;
         if (wi >= nwork) return;
-        const uint2 range = ranges[w.list[wi]];
-        if (range.y > range.x) sort_one_tile<NT, CAP, true>(range, src_keys, src_vals, dst_keys, dst_vals, ka, va, kb, vb, hist, digit_base, wave_cnt, wtot);
+        const uint32_t tile = w.list[wi];
+        const uint2 range = ranges[tile];
+        if (range.y > range.x) sort_one_tile<NT, CAP, true>(range, src_keys, src_vals, dst_keys, dst_vals, ka, va, kb, vb, hist, digit_base, wave_cnt, wtot, tile);
     }
 }
 
@@ -794,28 +799,17 @@ __device__ __forceinline__ T sgr_xlane_t(T v) {
     else return sgr_xlane<M>(v);
 }
 
-// compare-exchange with the lane M away; TOP = the highest bit of M: lanes with that bit clear keep the smaller composite
-template <int M, int TOP, typename T>
-__device__ __forceinline__ T sgr_cex_lane(T a, uint32_t lane) {
-    const bool upper = (lane & (uint32_t)TOP) != 0u;
-    if constexpr (M == 32) {
-        // v_permlane32_swap: afterwards [0] holds the LOWER partner's value and [1] the UPPER partner's value in every lane
-        T x, y;
-        if constexpr (sizeof(T) == 8) {
-            const auto lo = __builtin_amdgcn_permlane32_swap((uint32_t)a, (uint32_t)a, false, false);
-            const auto hi = __builtin_amdgcn_permlane32_swap((uint32_t)(a >> 32), (uint32_t)(a >> 32), false, false);
-            x = ((uint64_t)hi[0] << 32) | lo[0]; y = ((uint64_t)hi[1] << 32) | lo[1];
-        } else {
-            const auto r = __builtin_amdgcn_permlane32_swap(a, a, false, false);
-            x = r[0]; y = r[1];
-        }
-        const T mn = sgr_min_t(x, y), mx = sgr_max_t(x, y);
-        return upper ? mx : mn;
-    } else {
-        const T b = sgr_xlane_t<M, T>(a);
-        const T mn = sgr_min_t(a, b), mx = sgr_max_t(a, b);
-        return upper ? mx : mn;
-    }
+// Stages whose partner sits in ANOTHER lane (or wave) keep ONE of the two composites: the holder with the partner bit clear the smaller.
+// POLARITY form makes that a single instruction: while a stage is running, holders with the bit set store their composites NEGATED
+// (sign bit of the double flipped).  With own' = own ^ S_me and other' = other ^ S_partner (S_partner = opposite polarity),
+//     v_min_f64(own', -other')  =  min(own, other)                 in the holder with the bit clear
+//                               = -max(own, other)                 in the holder with the bit set: already the polarity form of its result
+// (the negation of the fetched operand is a free VOP3 source modifier).  One v_xor on the high word then moves the result into the NEXT
+// stage's polarity (xhi = S_me ^ S_next, a per-lane mask computed once per stage; 0 for the in-lane stages, which need plain values).
+// Per composite: 2 lane moves + v_min_f64 + v_xor instead of 2 lane moves + v_min_f64 + v_max_f64 + 2 v_cndmask.
+__device__ __forceinline__ uint64_t sgr_take_lower(uint64_t own, uint64_t other, uint32_t xhi) {
+    const double r = __builtin_fmin(__builtin_bit_cast(double, own), -__builtin_bit_cast(double, other));
+    return __builtin_bit_cast(uint64_t, r) ^ ((uint64_t)xhi << 32);
 }
 
 // Every register index and every lane permutation must be a compile-time constant, but the network must NOT be unrolled into one
@@ -824,7 +818,7 @@ __device__ __forceinline__ T sgr_cex_lane(T a, uint32_t lane) {
 // (measured: 385 us for the <= 1024-entry tiles of C3 instead of 134 us).  So: ONE copy of each distinct stage body (flip K, shift J),
 // selected by a switch inside rolled loops over K and J.
 template <typename T, int IPT, int K>
-__device__ __forceinline__ void sgr_bitonic_flip(T (&a)[IPT], uint32_t lane) {
+__device__ __forceinline__ void sgr_bitonic_flip(T (&a)[IPT], uint32_t xhi) {
     if constexpr (K <= IPT) {
 #pragma unroll
         for (int r = 0; r < IPT; r++) {
@@ -832,53 +826,50 @@ __device__ __forceinline__ void sgr_bitonic_flip(T (&a)[IPT], uint32_t lane) {
             if (p > r) { const T x = a[r], y = a[p]; a[r] = sgr_min_t(x, y); a[p] = sgr_max_t(x, y); }
         }
     } else if constexpr (K <= 64 * IPT) {
-        // partner: lane ^ (K / IPT - 1), register IPT - 1 - r; lanes whose top bit of that mask is clear keep the smaller composite
-        constexpr int M = K / IPT - 1, TOP = K / IPT / 2;
-        const bool upper = (lane & (uint32_t)TOP) != 0u;
+        // partner: lane ^ (K / IPT - 1), register IPT - 1 - r (polarity bit: the top bit of that lane mask)
+        constexpr int M = K / IPT - 1;
 #pragma unroll
         for (int r = 0; r < IPT / 2; r++) {                                      // registers r and IPT - 1 - r trade partners
-            constexpr int dummy = 0; (void)dummy;
             const int q = IPT - 1 - r;
             const T br = sgr_xlane_t<M, T>(a[q]), bq = sgr_xlane_t<M, T>(a[r]);
-            const T mnr = sgr_min_t(a[r], br), mxr = sgr_max_t(a[r], br), mnq = sgr_min_t(a[q], bq), mxq = sgr_max_t(a[q], bq);
-            a[r] = upper ? mxr : mnr; a[q] = upper ? mxq : mnq;
+            a[r] = sgr_take_lower(a[r], br, xhi); a[q] = sgr_take_lower(a[q], bq, xhi);
         }
     }
 }
 
 template <typename T, int IPT, int J>
-__device__ __forceinline__ void sgr_bitonic_shift(T (&a)[IPT], uint32_t lane) {
+__device__ __forceinline__ void sgr_bitonic_shift(T (&a)[IPT], uint32_t xhi) {
     if constexpr (J < IPT) {
 #pragma unroll
         for (int r = 0; r < IPT; r++)
             if ((r & J) == 0) { const T x = a[r], y = a[r | J]; a[r] = sgr_min_t(x, y); a[r | J] = sgr_max_t(x, y); }
     } else if constexpr (J < 64 * IPT) {
 #pragma unroll
-        for (int r = 0; r < IPT; r++) a[r] = sgr_cex_lane<J / IPT, J / IPT, T>(a[r], lane);
+        for (int r = 0; r < IPT; r++) a[r] = sgr_take_lower(a[r], sgr_xlane_t<J / IPT, T>(a[r]), xhi);      // (polarity bit: J / IPT)
     }
 }
 
 // lane-crossing stages, selected by the LANE mask (element distance / IPT): one copy of each body behind a switch
 template <typename T, int IPT>
-__device__ __forceinline__ void sgr_stage_flip_lanes(T (&a)[IPT], uint32_t lane, int lanes /* K / IPT: 2 .. 64 */) {
+__device__ __forceinline__ void sgr_stage_flip_lanes(T (&a)[IPT], uint32_t xhi, int lanes /* K / IPT: 2 .. 64 */) {
     switch (lanes) {
-        case 2: sgr_bitonic_flip<T, IPT, 2 * IPT>(a, lane); break;
-        case 4: sgr_bitonic_flip<T, IPT, 4 * IPT>(a, lane); break;
-        case 8: sgr_bitonic_flip<T, IPT, 8 * IPT>(a, lane); break;
-        case 16: sgr_bitonic_flip<T, IPT, 16 * IPT>(a, lane); break;
-        case 32: sgr_bitonic_flip<T, IPT, 32 * IPT>(a, lane); break;
-        default: sgr_bitonic_flip<T, IPT, 64 * IPT>(a, lane); break;
+        case 2: sgr_bitonic_flip<T, IPT, 2 * IPT>(a, xhi); break;
+        case 4: sgr_bitonic_flip<T, IPT, 4 * IPT>(a, xhi); break;
+        case 8: sgr_bitonic_flip<T, IPT, 8 * IPT>(a, xhi); break;
+        case 16: sgr_bitonic_flip<T, IPT, 16 * IPT>(a, xhi); break;
+        case 32: sgr_bitonic_flip<T, IPT, 32 * IPT>(a, xhi); break;
+        default: sgr_bitonic_flip<T, IPT, 64 * IPT>(a, xhi); break;
     }
 }
 template <typename T, int IPT>
-__device__ __forceinline__ void sgr_stage_shift_lanes(T (&a)[IPT], uint32_t lane, int lanes /* J / IPT: 1 .. 32 */) {
+__device__ __forceinline__ void sgr_stage_shift_lanes(T (&a)[IPT], uint32_t xhi, int lanes /* J / IPT: 1 .. 32 */) {
     switch (lanes) {
-        case 1: sgr_bitonic_shift<T, IPT, IPT>(a, lane); break;
-        case 2: sgr_bitonic_shift<T, IPT, 2 * IPT>(a, lane); break;
-        case 4: sgr_bitonic_shift<T, IPT, 4 * IPT>(a, lane); break;
-        case 8: sgr_bitonic_shift<T, IPT, 8 * IPT>(a, lane); break;
-        case 16: sgr_bitonic_shift<T, IPT, 16 * IPT>(a, lane); break;
-        default: sgr_bitonic_shift<T, IPT, 32 * IPT>(a, lane); break;
+        case 1: sgr_bitonic_shift<T, IPT, IPT>(a, xhi); break;
+        case 2: sgr_bitonic_shift<T, IPT, 2 * IPT>(a, xhi); break;
+        case 4: sgr_bitonic_shift<T, IPT, 4 * IPT>(a, xhi); break;
+        case 8: sgr_bitonic_shift<T, IPT, 8 * IPT>(a, xhi); break;
+        case 16: sgr_bitonic_shift<T, IPT, 16 * IPT>(a, xhi); break;
+        default: sgr_bitonic_shift<T, IPT, 32 * IPT>(a, xhi); break;
     }
 }
 
@@ -886,12 +877,12 @@ __device__ __forceinline__ void sgr_stage_shift_lanes(T (&a)[IPT], uint32_t lane
 // final assignment of a fused run has to land in the loop-carried registers):
 //   head = levels K = 2 .. IPT (every lane sorts its own registers);  tail = the shifts IPT/2 .. 1 that end every later level
 template <typename T, int IPT, int J>
-__device__ __forceinline__ void sgr_tail_from(T (&a)[IPT], uint32_t lane) {
-    if constexpr (J >= 1) { sgr_bitonic_shift<T, IPT, J>(a, lane); sgr_tail_from<T, IPT, J / 2>(a, lane); }
+__device__ __forceinline__ void sgr_tail_from(T (&a)[IPT]) {
+    if constexpr (J >= 1) { sgr_bitonic_shift<T, IPT, J>(a, 0u); sgr_tail_from<T, IPT, J / 2>(a); }
 }
 template <typename T, int IPT, int K>
-__device__ __forceinline__ void sgr_head_from(T (&a)[IPT], uint32_t lane) {
-    if constexpr (K <= IPT) { sgr_bitonic_flip<T, IPT, K>(a, lane); sgr_tail_from<T, IPT, K / 4>(a, lane); sgr_head_from<T, IPT, K * 2>(a, lane); }
+__device__ __forceinline__ void sgr_head_from(T (&a)[IPT]) {
+    if constexpr (K <= IPT) { sgr_bitonic_flip<T, IPT, K>(a, 0u); sgr_tail_from<T, IPT, K / 4>(a); sgr_head_from<T, IPT, K * 2>(a); }
 }
 
 // `nw` waves (a sub-group of the workgroup, nw a RUNTIME power of two) sort nw * 64 * IPT composites: wave `sub` holds elements
@@ -907,39 +898,45 @@ __device__ __forceinline__ void sgr_bitonic_sort_group(T (&a)[IPT], uint32_t lan
     constexpr int WAVE_ELEMS = 64 * IPT;
     T *mine = gx + sub * (uint32_t)WAVE_ELEMS;
     const int Kmax = WAVE_ELEMS * nw;
-    sgr_head_from<T, IPT, 2>(a, lane);
+    const uint32_t pid = sub * 64u + lane;                                       // holder id inside the sub-group: bit b <-> element bit IPT * b
+    sgr_head_from<T, IPT, 2>(a);
 #pragma nounroll
     for (int K = 2 * IPT; K <= Kmax; K <<= 1) {
-        // one merge level: the flip (partner e ^ (K - 1)), then shifts (partner e ^ j) for j = K/4, K/8, .., IPT, then the in-lane tail
+        // one merge level: the flip (partner e ^ (K - 1)), then shifts (partner e ^ j) for j = K/4, K/8, .., IPT, then the in-lane tail.
+        // Polarity bit of a stage = the holder bit its partner differs in: K / IPT / 2 for the flip, j / IPT for a shift, none in the tail.
+        uint32_t s_cur = (pid & (uint32_t)(K / IPT / 2)) ? 0x80000000u : 0u;
+#pragma unroll
+        for (int r = 0; r < IPT; r++) a[r] ^= (uint64_t)s_cur << 32;
 #pragma nounroll
-        for (int step = 0;; step++) {
-            const bool first = step == 0;
-            const int j = first ? 0 : (K >> 1) >> step;
-            if (!first && j < IPT) break;
+        for (int j = 0;;) {                                                      // j == 0: the flip
+            const bool first = j == 0;
+            const int jn = first ? K / 4 : j / 2;                                // the stage after this one
+            const uint32_t s_nxt = (jn >= IPT && (pid & (uint32_t)(jn / IPT))) ? 0x80000000u : 0u;
+            const uint32_t xhi = s_cur ^ s_nxt;
             const bool cross = first ? (K > WAVE_ELEMS) : (j >= WAVE_ELEMS);
             if (cross) {
                 // ---- partner in another wave of the sub-group
                 const int jw = first ? (K / WAVE_ELEMS - 1) : (j / WAVE_ELEMS);
-                const int top = first ? (K / WAVE_ELEMS) >> 1 : jw;
                 const T *theirs = gx + (sub ^ (uint32_t)jw) * (uint32_t)WAVE_ELEMS;
                 __syncthreads();                                                 // everyone is done reading the previous exchange
 #pragma unroll
                 for (int r = 0; r < IPT; r++) mine[r * 64 + lane] = a[r];
                 __syncthreads();
-                const bool upper = (sub & (uint32_t)top) != 0u;
 #pragma unroll
                 for (int r = 0; r < IPT; r++) {
                     const T b = first ? theirs[(IPT - 1 - r) * 64 + (63 - lane)] : theirs[r * 64 + lane];
-                    const T mn = sgr_min_t(a[r], b), mx = sgr_max_t(a[r], b);
-                    a[r] = upper ? mx : mn;
+                    a[r] = sgr_take_lower(a[r], b, xhi);
                 }
             } else if (first) {
-                sgr_stage_flip_lanes<T, IPT>(a, lane, K / IPT);
+                sgr_stage_flip_lanes<T, IPT>(a, xhi, K / IPT);
             } else {
-                sgr_stage_shift_lanes<T, IPT>(a, lane, j / IPT);
+                sgr_stage_shift_lanes<T, IPT>(a, xhi, j / IPT);
             }
+            s_cur = s_nxt;
+            j = jn;
+            if (j < IPT) break;
         }
-        sgr_tail_from<T, IPT, IPT / 2>(a, lane);
+        sgr_tail_from<T, IPT, IPT / 2>(a);
     }
 }
 
@@ -957,18 +954,18 @@ __device__ __forceinline__ void sgr_redeal_coalesced(T (&a)[IPT], uint32_t lane,
     for (int r = 0; r < IPT; r++) a[r] = tb[((uint32_t)r * (64u / IPT) + lane / IPT) * (IPT + 1) + lane % IPT];
 }
 
-// 64-bit composites (depth bits << 32 | value).  n == 0: nothing is read or written, the network runs on padding (barrier parity).
-// gx: the sub-group's [nw][64 * 17] composites of LDS.
+// gc: the tile's (depth bits << 32 | value) composites as the scatter pass left them (any order).  n == 0: nothing is read or written,
+// the network runs on padding (barrier parity).  gx: the sub-group's [nw][64 * 17] composites of LDS.
 template <int IPT>
-__device__ __forceinline__ void sgr_sort_tile_regs64(const uint64_t *__restrict__ gk, const uint32_t *__restrict__ gv, uint64_t *__restrict__ ok,
-                                                     uint32_t *__restrict__ ov, uint32_t n, uint32_t lane, uint32_t sub, int nw, uint64_t *gx) {
+__device__ __forceinline__ void sgr_sort_tile_regs64(const uint64_t *__restrict__ gc, uint64_t *__restrict__ ok, uint32_t *__restrict__ ov, uint32_t n,
+                                                     uint32_t tile, uint32_t lane, uint32_t sub, int nw, uint64_t *gx) {
     uint64_t a[IPT];
-    const uint32_t hi = n ? (uint32_t)(gk[0] >> 32) : 0u;                      // tile id, identical for the whole segment
     const uint32_t wbase = sub * (64u * IPT);
 #pragma unroll
     for (int r = 0; r < IPT; r++) {                                            // coalesced; the input order is irrelevant to the result
         const uint32_t k = wbase + (uint32_t)r * 64u + lane;
-        a[r] = k < n ? (((uint64_t)min((uint32_t)gk[k], kCompositeHiMax) << 32) | gv[k]) : kCompositePad;
+        const uint64_t c = k < n ? gc[k] : kCompositePad;
+        a[r] = ((uint64_t)min((uint32_t)(c >> 32), kCompositeHiMax) << 32) | (uint32_t)c;
     }
     sgr_bitonic_sort_group<uint64_t, IPT>(a, lane, sub, nw, gx);
     if (nw > 1) __syncthreads();                                               // the other waves are done with the last exchange
@@ -976,7 +973,7 @@ __device__ __forceinline__ void sgr_sort_tile_regs64(const uint64_t *__restrict_
 #pragma unroll
     for (int r = 0; r < IPT; r++) {
         const uint32_t e = wbase + (uint32_t)r * 64u + lane;
-        if (e < n) { ok[e] = ((uint64_t)hi << 32) | (a[r] >> 32); ov[e] = (uint32_t)a[r]; }
+        if (e < n) { ok[e] = ((uint64_t)tile << 32) | (a[r] >> 32); ov[e] = (uint32_t)a[r]; }
     }
 }
 
@@ -988,9 +985,9 @@ __device__ __forceinline__ void sgr_sort_tile_regs64(const uint64_t *__restrict_
 struct TileWork4 { TileWork w[5]; };        // [m]: tiles with <= 1024 << m entries
 
 template <int NW>
-__global__ __launch_bounds__(64 * NW) void tile_sort_regs_kernel(const uint2 *__restrict__ ranges, const uint64_t *__restrict__ src_keys,
-                                                                 const uint32_t *__restrict__ src_vals, uint64_t *__restrict__ dst_keys,
-                                                                 uint32_t *__restrict__ dst_vals, TileWork4 tw, int m_hi, int m_lo) {
+__global__ __launch_bounds__(64 * NW) void tile_sort_regs_kernel(const uint2 *__restrict__ ranges, const uint64_t *__restrict__ src_comp,
+                                                                 uint64_t *__restrict__ dst_keys, uint32_t *__restrict__ dst_vals, TileWork4 tw,
+                                                                 int m_hi, int m_lo) {
     __shared__ uint64_t xbuf[NW * 64 * 17];                                      // per wave 64 x (16 + 1) composites: exchange + final re-deal
     __shared__ uint32_t s_item, s_next;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -1010,8 +1007,9 @@ __global__ __launch_bounds__(64 * NW) void tile_sort_regs_kernel(const uint2 *__
             const uint32_t wi = s_item + grp;
             if (s_item >= nwork) break;                                          // workgroup-uniform
             uint2 range = make_uint2(0u, 0u);
-            if (wi < nwork) range = ranges[w.list[wi]];
-            sgr_sort_tile_regs64<16>(src_keys + range.x, src_vals + range.x, dst_keys + range.x, dst_vals + range.x, range.y - range.x, lane, sub, nw, gx);
+            uint32_t tile = 0u;
+            if (wi < nwork) { tile = w.list[wi]; range = ranges[tile]; }
+            sgr_sort_tile_regs64<16>(src_comp + range.x, dst_keys + range.x, dst_vals + range.x, range.y - range.x, tile, lane, sub, nw, gx);
         }
     }
     if (m_lo > 0) return;
@@ -1039,11 +1037,12 @@ __global__ __launch_bounds__(64 * NW) void tile_sort_regs_kernel(const uint2 *__
             if (lane == 0) i = atomicAdd(&s_next, 1u);
             i = (uint32_t)__builtin_amdgcn_readfirstlane((int)i);
             if (i >= cnt) break;
-            const uint2 range = ranges[w.list[base + i]];
+            const uint32_t tile = w.list[base + i];
+            const uint2 range = ranges[tile];
             const uint32_t n = range.y - range.x;
             if (n == 0u) continue;
-            if (n <= 256u) sgr_sort_tile_regs64<4>(src_keys + range.x, src_vals + range.x, dst_keys + range.x, dst_vals + range.x, n, lane, 0u, 1, gx);
-            else sgr_sort_tile_regs64<16>(src_keys + range.x, src_vals + range.x, dst_keys + range.x, dst_vals + range.x, n, lane, 0u, 1, gx);
+            if (n <= 256u) sgr_sort_tile_regs64<4>(src_comp + range.x, dst_keys + range.x, dst_vals + range.x, n, tile, lane, 0u, 1, gx);
+            else sgr_sort_tile_regs64<16>(src_comp + range.x, dst_keys + range.x, dst_vals + range.x, n, tile, lane, 0u, 1, gx);
         }
     }
 }
@@ -1230,8 +1229,13 @@ __global__ __launch_bounds__(kThreads) void vseg_scatter_kernel(const uint64_t *
                                                                 uint32_t tiles_per_view, const uint32_t *__restrict__ hist,
                                                                 const uint2 *__restrict__ ranges) {
     __shared__ uint32_t pos[MAXB];                    // next output position per tile for THIS chunk's keys
-    const uint32_t c = blockIdx.x;
-    if (c >= plan->n_chunks) return;
+    // workgroups go round-robin over the 8 XCDs, each with its own L2: XCD x takes the x-th EIGHTH of the chunk list, so that the chunks
+    // whose keys land next to each other in the output (neighbours in the same view) pass through ONE L2 close in time and their
+    // sub-line stores merge there before they reach HBM (at C4 the scattered 8- and 4-byte stores cost 40 B of HBM writes per key
+    // with chunk = blockIdx.x)
+    const uint32_t n_chunks = plan->n_chunks, span = (n_chunks + 7u) >> 3;
+    const uint32_t c = (blockIdx.x & 7u) * span + (blockIdx.x >> 3);
+    if ((blockIdx.x >> 3) >= span || c >= n_chunks) return;
     const uint4 cm = chunk_map[c];
     const uint32_t t = threadIdx.x;
     const uint32_t tbase = cm.x * tiles_per_view;
@@ -1252,7 +1256,7 @@ __global__ __launch_bounds__(kThreads) void vseg_scatter_kernel(const uint64_t *
         const uint32_t k = (uint32_t)it * kThreads + t;
         if (k < cm.z) {
             const uint32_t slot = atomicAdd(&pos[(uint32_t)(key[it] >> 32) - tbase], 1u);
-            keys_out[slot] = key[it]; vals_out[slot] = val[it];
+            keys_out[slot] = (key[it] << 32) | val[it];                      // (depth bits, value) composite: ONE 8-byte store per key
         }
     }
 }
@@ -1403,10 +1407,10 @@ int sgr_bin_ex(const SgrProblem *pb, const int32_t *radii, uint32_t *rect,
         hipLaunchKernelGGL(vseg_scan_kernel, dim3(pb->n_views), dim3(1024), 0, stream, tile_total, key_start, tpv, (uint2 *)ranges, plan, lists,
                            (uint32_t)tiles_total);
         if (VL.chunk_keys == 4096u)
-            hipLaunchKernelGGL((vseg_scatter_kernel<1024, 16>), dim3(VL.max_chunks), dim3(kThreads), 0, stream, kin, vin, kout, vout, plan, chunk_map,
+            hipLaunchKernelGGL((vseg_scatter_kernel<1024, 16>), dim3(VL.max_chunks + 8), dim3(kThreads), 0, stream, kin, vin, kout, vout, plan, chunk_map,
                                tpv, vhist, (const uint2 *)ranges);
         else
-            hipLaunchKernelGGL((vseg_scatter_kernel<4096, 32>), dim3(VL.max_chunks), dim3(kThreads), 0, stream, kin, vin, kout, vout, plan, chunk_map,
+            hipLaunchKernelGGL((vseg_scatter_kernel<4096, 32>), dim3(VL.max_chunks + 8), dim3(kThreads), 0, stream, kin, vin, kout, vout, plan, chunk_map,
                                tpv, vhist, (const uint2 *)ranges);
         SGR_CHECK_LAUNCH("view-segmented tile pass");
         // depth bits per tile: keys now sit tile-bucketed in (kout, vout); the sorted list goes back into (kin, vin)
@@ -1418,7 +1422,7 @@ int sgr_bin_ex(const SgrProblem *pb, const int32_t *radii, uint32_t *rect,
         for (int c = 0; c < 5; c++) tw4.w[c] = work(c);
         // beyond 16384 entries: a whole workgroup per tile through the global ping-pong buffers; everything else in ONE launch
         hipLaunchKernelGGL((tile_sort_dyn_kernel<1024, kSegCapLarge>), dim3(grid(1)), dim3(1024), 0, stream, rg, kout, vout, kin, vin, work(5));
-        hipLaunchKernelGGL(tile_sort_regs_kernel<16>, dim3(grid(1)), dim3(1024), 0, stream, rg, kout, vout, kin, vin, tw4, 4, 0);
+        hipLaunchKernelGGL(tile_sort_regs_kernel<16>, dim3(grid(1)), dim3(1024), 0, stream, rg, kout, kin, vin, tw4, 4, 0);
         SGR_CHECK_LAUNCH("tile_sort_dyn_kernel");
         }
         if (result_in_b_host) *result_in_b_host = (kin == keys_b) ? 1 : 0;

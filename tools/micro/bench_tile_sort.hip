@@ -55,7 +55,8 @@ static void run_case(const std::string &name, std::vector<uint32_t> len) {
     uint64_t *ka, *kb; uint32_t *va, *vb, *list, *cnt; uint2 *ranges;
     CK(hipMalloc(&ka, R * 8 + 64)); CK(hipMalloc(&kb, R * 8 + 64)); CK(hipMalloc(&va, R * 4 + 64)); CK(hipMalloc(&vb, R * 4 + 64));
     CK(hipMalloc(&list, (size_t)5 * ntiles * 4 + 64)); CK(hipMalloc(&cnt, 64)); CK(hipMalloc(&ranges, (size_t)ntiles * 8));
-    CK(hipMemcpy(ka, hk.data(), R * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(va, hv.data(), R * 4, hipMemcpyHostToDevice));
+    { std::vector<uint64_t> hc(R); for (size_t i = 0; i < R; i++) hc[i] = (hk[i] << 32) | hv[i];      // what the scatter pass leaves: (depth, value) composites
+      CK(hipMemcpy(ka, hc.data(), R * 8, hipMemcpyHostToDevice)); }
     CK(hipMemcpy(ranges, hr.data(), (size_t)ntiles * 8, hipMemcpyHostToDevice));
     uint32_t h[16] = {0};
     TileWork4 tw4;
@@ -65,7 +66,7 @@ static void run_case(const std::string &name, std::vector<uint32_t> len) {
         tw4.w[m] = TileWork{list + (size_t)m * ntiles, cnt + 8 + m, cnt + m};
     }
     auto reset = [&]() { CK(hipMemcpyAsync(cnt, h, 64, hipMemcpyHostToDevice, 0)); };
-    const float us = time_it([&]() { reset(); hipLaunchKernelGGL(tile_sort_regs_kernel<16>, dim3(256), dim3(1024), 0, 0, ranges, ka, va, kb, vb, tw4, 4, 0); });
+    const float us = time_it([&]() { reset(); hipLaunchKernelGGL(tile_sort_regs_kernel<16>, dim3(256), dim3(1024), 0, 0, ranges, ka, kb, vb, tw4, 4, 0); });
     CK(hipDeviceSynchronize());
     std::vector<uint64_t> ok(R); std::vector<uint32_t> ov(R);
     CK(hipMemcpy(ok.data(), kb, R * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(ov.data(), vb, R * 4, hipMemcpyDeviceToHost));
