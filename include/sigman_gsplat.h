@@ -172,10 +172,10 @@ int32_t sgr_preprocess_blocks_per_view(int32_t P);
 int sgr_preprocess_forward(const SgrProblem *pb, float *rec, int32_t *radii, uint32_t *rect, uint8_t *clamped,
                            uint32_t *block_offsets, uint64_t *num_rendered, uint64_t capacity, void *stream);
 
-/* sort flavour: 3 = automatic (default); 4 = view-segmented: the emission is view-major, so ONE stable counting pass per view over the
- * tile id (<= 4096 tiles per view) + one stable LDS radix sort of the depth bits per tile; 2 = segmented: global LSD passes over the
- * tile-id bits only, then the per-tile depth sort; 0 = onesweep over the whole key (one kernel per digit, decoupled look-back);
- * 1 = three kernels per digit.  All give bit-identical results. */
+/* sort flavour: 3 = automatic (default); 4 = view-segmented: the emission is view-major, so ONE order-free counting pass per view over the
+ * tile id (<= 4096 tiles per view) + a register sort of (depth bits, value) composites per tile; 2 = segmented: global LSD passes over
+ * the tile-id bits only, then a stable LDS radix sort of the depth bits per tile; 0 = onesweep over the whole key (one kernel per digit,
+ * decoupled look-back); 1 = three kernels per digit.  All give bit-identical sorted keys, values and ranges (for finite depths). */
 int sgr_set_sort_mode(int mode);
 
 /* bytes of scratch sgr_bin needs for R tile instances */

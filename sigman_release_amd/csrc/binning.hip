@@ -1049,10 +1049,11 @@ __global__ __launch_bounds__(64 * NW) void tile_sort_regs_kernel(const uint2 *__
 
 // ---- F4 + F5, VIEW-SEGMENTED flavour for multi-view batches and large launches -----------------------------------
 // The emission is view-major (duplicate_keys: blockIdx.y = view, offsets from the scan of the per-block counts), so the view bits of
-// the key are sorted before the sort starts: what remains is, per view, a sort by (tile-in-view, depth).  ONE stable counting pass per
-// view over the tile id (<= 4096 tiles per view: 1024^2 images) puts every tile's instances into one contiguous segment and yields the tile ranges (F5) and the worklist of occupied tiles as by-products of its scan; the depth bits are
-// then sorted per tile in LDS (tile_sort_dyn_kernel).  Per key: 8 B (histogram) + 24 B (scatter) + 24 B (per-tile sort) of HBM
-// traffic instead of 6-7 whole-key passes of 32 B.
+// the key are sorted before the sort starts: what remains is, per view, a sort by (tile-in-view, depth).  ONE counting pass per view
+// over the tile id (<= 4096 tiles per view: 1024^2 images) puts every tile's instances into one contiguous segment -- as
+// (depth bits << 32 | value) composites, in any order -- and yields the tile ranges (F5) and the worklists of occupied tiles as
+// by-products of its scan; the composites are then sorted per tile in registers (tile_sort_regs_kernel).  Per key: 8 B (histogram)
+// + 20 B (scatter) + 20 B (per-tile sort) of HBM traffic instead of 6-7 whole-key passes of 32 B.
 //   vseg_view_totals -> vseg_plan   per-view key ranges from the per-block emission counts; the keys are cut into CHUNKS of
 //                                   256 * ITEMS keys that never straddle a view: chunk_map[c] = (view, first key, count)
 //   vseg_upsweep                    per-chunk tile histogram, hist[c][tile]

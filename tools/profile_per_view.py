@@ -23,9 +23,15 @@ bg = torch.ones(3, device=dev)
 if "GRAPHS" in os.environ:
     _cabi.lib().sgr_set_graphs(int(os.environ["GRAPHS"]))
 
+NS = int(os.environ.get("STREAMS", "0"))
+streams = [torch.cuda.Stream() for _ in range(NS)]
+
 def forward():
     imgs = []
+    cur = torch.cuda.current_stream()
+    for s in streams: s.wait_stream(cur)
     for v in range(V):
+      with torch.cuda.stream(streams[v % NS]) if NS else torch.cuda.stream(cur):
         rs = R.GaussianRasterizationSettings(image_height=H, image_width=H, tanfovx=cameras.TAN_HALF_FOV, tanfovy=cameras.TAN_HALF_FOV, bg=bg,
                                              scale_modifier=0.5, viewmatrix=cv[v], projmatrix=cvp[v], sh_degree=0, campos=cp[v], prefiltered=False, debug=False)
         rast = R.GaussianRasterizer(raster_settings=rs)
@@ -33,6 +39,7 @@ def forward():
             img, radii, depth, alpha = rast(means3D=m, means2D=torch.zeros_like(m, dtype=torch.float32, device=dev), shs=None, colors_precomp=rgb, opacities=o,
                                             cov3D_precomp=c)
         imgs.append(img.clamp(0, 1))
+    for s in streams: cur.wait_stream(s)
     return clamped_l1_loss(torch.stack(imgs, 0), gt, None, 1e-6)
 
 def step(timing=None):
@@ -53,7 +60,7 @@ torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / N
 tm = []
 for _ in range(N): step(tm)
 a = np.median(np.array(tm), 0) * 1e6 / V
-print(f"V={V} GRAPHS={os.environ.get('GRAPHS','default')}: {dt*1e6/V:.0f} us/view pipelined ({V/dt:.0f} views/s) | per view: fwd issue {a[0]:.0f} us, fwd drained {a[1]:.0f} us, bwd issue {a[2]:.0f} us, bwd drained {a[3]:.0f} us", flush=True)
+print(f"STREAMS={NS} V={V} GRAPHS={os.environ.get('GRAPHS','default')}: {dt*1e6/V:.0f} us/view pipelined ({V/dt:.0f} views/s) | per view: fwd issue {a[0]:.0f} us, fwd drained {a[1]:.0f} us, bwd issue {a[2]:.0f} us, bwd drained {a[3]:.0f} us", flush=True)
 if os.environ.get("PROF"):
     pr = cProfile.Profile(); pr.enable()
     for _ in range(N): forward()
