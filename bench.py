@@ -175,7 +175,10 @@ def main(args):
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     world = 1
-    if world_env > 1:
+    # SIGMAN_BENCH_FORCE_PG=1: build the process group even for one rank (under a launcher), so that the RCCL code path of the N > 1 runs
+    # -- init with device_id, async all-reduce, barriers -- can be exercised on a 1-GPU box
+    dist_on = world_env > 1 or (os.environ.get("SIGMAN_BENCH_FORCE_PG") == "1" and "RANK" in os.environ)
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
         world = dist.get_world_size()
@@ -254,7 +257,7 @@ def main(args):
                 if n_local:
                     R.rasterize_gaussians_batched(subj["means3D"], None, None, subj["rgb"], subj["opacity"], None, None, subj["cov3D"], st)
             return None
-        if world == 1:
+        if not dist_on:
             for v in leaves.values():
                 v.grad = None
             return backward_of(render_loss(leaves["means3D"], leaves["cov3D"], leaves["opacity"], leaves["rgb"]))
@@ -288,7 +291,7 @@ def main(args):
             pending[0].wait()
             pending[:] = []
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -317,7 +320,7 @@ def main(args):
         loss = step()
     sync_all()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if dist_on:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -368,7 +371,7 @@ def main(args):
                                f"{H}x{W}, {'fwd+bwd' if bwd else 'forward only'}, colors_precomp+cov3D_precomp"
                                + (", clamp+L1 loss" if bwd else "") + (", dL/ddepth and dL/dalpha non-zero" if da else ""),
                    "name": args.config, "views_per_step_total": n_total_views, "view_slots_this_gpu": n_local,
-                   "parallelism": (f"view-parallel x{world} ({backend}), exchange={'none (forward only)' if not bwd else args.exchange}" if world > 1 else "single GPU"),
+                   "parallelism": (f"view-parallel x{world} ({backend}), exchange={'none (forward only)' if not bwd else args.exchange}" if dist_on else "single GPU"),
                    "ranks_seen": world, "num_rendered_per_gpu": Rn, "gaussian_pixel_visits_per_gpu": S_visits,
                    "binning_buffers": "exact (D2H read of num_rendered per step)" if args.exact_sync else (f"pre-sized, max_rendered={st.max_rendered} (sync-free)" if st else "-")},
         "gaussian_pixel_ops_per_s_per_gpu": round(S_visits / (ms_per_step * 1e-3), 1),
@@ -393,7 +396,7 @@ def main(args):
     if rank == 0:
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -119,3 +119,29 @@ def test_two_ranks_hip_view_parallel_matches_single_process():
         np.testing.assert_array_equal(grad_l, parts[r][1])                   # the rank's partial == single-process run of its views, bitwise
     np.testing.assert_array_equal(res[0]["full"][1], res[1]["full"][1])      # all-reduced: identical on both ranks
     assert np.abs(res[0]["loss"][1] + res[1]["loss"][1] - grad_all).max() <= 1e-6 * gmax
+
+
+def test_bench_rccl_path_with_one_rank():
+    """bench.py's N > 1 code path over RCCL (backend "nccl": process group bound to the device, asynchronous loss all-reduce waited one step
+    later, gradient all-reduce in "full" mode, barriers around the timed region), exercised with ONE rank under the launcher: the 1-GPU
+    test box cannot hold two RCCL ranks, but every call the 8-GPU run makes is made here."""
+    import json
+    import subprocess
+    for exchange in ("loss", "full"):
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        env = dict(os.environ, SIGMAN_BENCH_FORCE_PG="1")
+        env.pop("SIGMAN_BENCH_BACKEND", None)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5",
+               "--exchange", exchange, "--no-cpu-baseline", "--no-variants"]
+        r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [l for l in r.stdout.splitlines() if l.strip()]
+        assert len(lines) == 1, r.stdout                                   # stdout carries exactly the JSON line
+        out = json.loads(lines[0])
+        assert out["n_gpus"] == 1 and out["config"]["ranks_seen"] == 1
+        assert out["config"]["parallelism"] == f"view-parallel x1 (nccl), exchange={exchange}"
+        assert out["value"] > 0 and out["roofline"]["frac"] > 0
