@@ -1,0 +1,124 @@
+"""-m gpu: sgr_bin (F3 emission + F4 sort + F5 ranges) called DIRECTLY through the C ABI on synthetic rect records, against a
+numpy restatement of the published binning step (duplicateWithKeys -> stable radix sort on (tile | depth bits) -> identifyTileRanges;
+restated in oracle/gsplat_ref.c from the same source).  Every sort flavour must give the same bit-exact keys, values and ranges -- also
+for depth keys the real pipeline rarely produces: massive ties, the smallest / largest positive floats, denormal floats (the register
+sort of the view-segmented flavour orders (depth bits, value) composites as positive doubles: a high word below 0x00100000 is a
+DENORMAL double, one at 0x7F7FFFFF a huge one)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _build(n_views, P, size, seed, depth_kind, big_rects):
+    rng = np.random.default_rng(seed)
+    T = size // 16
+    radii = np.where(rng.random((n_views, P)) < 0.8, 3, 0).astype(np.int32)
+    w = rng.integers(1, 5, (n_views, P))
+    h = rng.integers(1, 5, (n_views, P))
+    if big_rects:
+        big = rng.random((n_views, P)) < 0.01
+        w = np.where(big, rng.integers(8, T + 1, (n_views, P)), w)
+        h = np.where(big, rng.integers(8, T + 1, (n_views, P)), h)
+    minx = (rng.random((n_views, P)) * (T - w + 1)).astype(np.int64)
+    miny = (rng.random((n_views, P)) * (T - h + 1)).astype(np.int64)
+    if big_rects:                                                                # a hot 6x6-tile window: tile lists of several thousand entries
+        hot = rng.random((n_views, P)) < 0.3
+        minx = np.where(hot & ~big, 10 + rng.integers(0, 3, (n_views, P)), minx)
+        miny = np.where(hot & ~big, 7 + rng.integers(0, 3, (n_views, P)), miny)
+    if depth_kind == "normal":
+        depth = rng.uniform(0.2, 50.0, (n_views, P)).astype(np.float32).view(np.uint32)
+    elif depth_kind == "ties":
+        depth = rng.choice(np.array([0.25, 1.0, 1.0000001, 2.5, 7.0], np.float32), (n_views, P)).view(np.uint32)
+    else:
+        pool = np.array([1, 2, 0x7FFFF, 0xFFFFF, 0x00100000, 0x00800000, 0x3F800000, 0x3F800001, 0x7F7FFFFF, 0x7F7FFFFE, 0x7EFFFFFF], np.uint32)
+        depth = np.where(rng.random((n_views, P)) < 0.5, rng.choice(pool, (n_views, P)),
+                         rng.integers(1, 0x7F7FFFFF, (n_views, P), dtype=np.int64).astype(np.uint32)).astype(np.uint32)
+    rect = np.zeros((n_views, P, 4), np.uint32)
+    rect[..., 0] = (minx | (miny << 16)).astype(np.uint32)
+    rect[..., 1] = ((minx + w) | ((miny + h) << 16)).astype(np.uint32)
+    rect[..., 2] = depth
+    cnt = np.where(radii > 0, w * h, 0).astype(np.int64)
+    # ---- expected emission (view-major, Gaussian order, rect row-major), stable sort, ranges
+    keys, vals = [], []
+    for v in range(n_views):
+        for i in np.nonzero(cnt[v])[0]:
+            ys, xs = np.meshgrid(np.arange(miny[v, i], miny[v, i] + h[v, i]), np.arange(minx[v, i], minx[v, i] + w[v, i]), indexing="ij")
+            tile = (v * T * T + ys * T + xs).reshape(-1).astype(np.uint64)
+            keys.append((tile << np.uint64(32)) | np.uint64(depth[v, i]))
+            vals.append(np.full(tile.size, v * P + i, np.uint32))
+    keys, vals = np.concatenate(keys), np.concatenate(vals)
+    order = np.argsort(keys, kind="stable")
+    skeys, svals = keys[order], vals[order]
+    tiles_total = n_views * T * T
+    tid = (skeys >> np.uint64(32)).astype(np.int64)
+    ranges = np.zeros((tiles_total, 2), np.uint32)
+    occ = np.unique(tid)
+    ranges[occ, 0] = np.searchsorted(tid, occ, "left")
+    ranges[occ, 1] = np.searchsorted(tid, occ, "right")
+    first = np.zeros((n_views, P), np.int64)
+    first.reshape(-1)[:] = np.concatenate([[0], np.cumsum(cnt.reshape(-1))[:-1]])
+    return dict(radii=radii, rect=rect, cnt=cnt, keys=skeys, vals=svals, ranges=ranges, first=first, T=T,
+                longest=int((ranges[:, 1] - ranges[:, 0]).max()))
+
+
+@pytest.mark.parametrize("n_views,P,size,depth_kind,big_rects", [
+    (1, 3000, 256, "normal", False),
+    (3, 5000, 512, "ties", True),
+    (4, 60000, 512, "extreme", True),
+    (2, 6000, 1024, "extreme", False),
+])
+def test_sgr_bin_direct_all_flavours(n_views, P, size, depth_kind, big_rects):
+    from sigman_release_amd import _cabi
+    L = _cabi.lib()
+    dev = torch.device("cuda", 0)
+    case = _build(n_views, P, size, 11 + n_views, depth_kind, big_rects)
+    R = int(case["cnt"].sum())
+    if big_rects and P >= 60000:
+        assert case["longest"] > 4096, case["longest"]                           # the multi-wave classes of the register sort are exercised
+    nbx = int(L.sgr_preprocess_blocks_per_view(P))
+    n = nbx * n_views
+    pad = np.zeros((n_views, nbx * 256), np.int64)
+    pad[:, :P] = case["cnt"]
+    sums = pad.reshape(n_views, nbx, 256).sum(-1).reshape(-1)
+    offs = np.zeros(2 * (n + 1), np.uint32)
+    offs[1:n + 1] = np.cumsum(sums)
+    offs[n + 1:2 * n + 1] = sums
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    dummy = torch.zeros(max(P, 1) * 16, dtype=torch.float32, device=dev)
+    cams = torch.zeros(n_views * 16, dtype=torch.float32, device=dev)
+    pb = _cabi.SgrProblem(P=P, n_views=n_views, views_per_subject=n_views, H=size, W=size, sh_degree=0, M=0, tanfovx=1.0, tanfovy=1.0,
+                          scale_modifier=1.0, means3D=dummy.data_ptr(), opacities=dummy.data_ptr(), colors_precomp=dummy.data_ptr(), shs=None,
+                          cov3D_precomp=dummy.data_ptr(), scales=None, rotations=None, viewmatrix=cams.data_ptr(), projmatrix=cams.data_ptr(),
+                          campos=cams.data_ptr(), bg=cams.data_ptr())
+    tiles_total = n_views * case["T"] ** 2
+    ws_bytes = int(L.sgr_bin_workspace_bytes(R, tiles_total))
+    try:
+        for mode in (1, 4, 0, 2, 3):
+            radii, rect, boff = t(case["radii"]), t(case["rect"]), t(offs)
+            ka, kb = (torch.zeros(R, dtype=torch.int64, device=dev) for _ in range(2))
+            va, vb = (torch.zeros(R, dtype=torch.int32, device=dev) for _ in range(2))
+            ws = torch.zeros(ws_bytes, dtype=torch.uint8, device=dev)
+            rg = torch.full((tiles_total, 2), 0x7FFFFFFF, dtype=torch.int32, device=dev)
+            in_b = C.c_int32(-1)
+            L.sgr_set_sort_mode(mode)
+            rc = L.sgr_bin(C.byref(pb), radii.data_ptr(), rect.data_ptr(), boff.data_ptr(), R, None, ka.data_ptr(), kb.data_ptr(),
+                           va.data_ptr(), vb.data_ptr(), ws.data_ptr(), ws_bytes, rg.data_ptr(), C.byref(in_b), None)
+            assert rc == 0, L.sgr_last_error()
+            torch.cuda.synchronize()
+            k = (kb if in_b.value else ka).cpu().numpy().view(np.uint64)
+            v = (vb if in_b.value else va).cpu().numpy().view(np.uint32)
+            np.testing.assert_array_equal(k, case["keys"], err_msg=f"sorted keys, flavour {mode}")
+            np.testing.assert_array_equal(v, case["vals"], err_msg=f"point list, flavour {mode}")
+            got = rg.cpu().numpy().view(np.uint32)
+            occ = case["ranges"][:, 1] > case["ranges"][:, 0]
+            np.testing.assert_array_equal(got[occ], case["ranges"][occ], err_msg=f"tile ranges, flavour {mode}")
+            assert bool((got[~occ, 1] == got[~occ, 0]).all()), f"empty tiles must have empty ranges, flavour {mode}"
+            seen = case["radii"] > 0
+            np.testing.assert_array_equal(rect.cpu().numpy()[..., 3][seen], case["first"][seen].astype(np.uint32),
+                                          err_msg=f"first tile-instance index per Gaussian, flavour {mode}")
+    finally:
+        L.sgr_set_sort_mode(3)
