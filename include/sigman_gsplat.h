@@ -174,8 +174,9 @@ int sgr_preprocess_forward(const SgrProblem *pb, float *rec, int32_t *radii, uin
 
 /* sort flavour: 3 = automatic (default); 4 = view-segmented: the emission is view-major, so ONE order-free counting pass per view over the
  * tile id (<= 4096 tiles per view) + a register sort of (depth bits, value) composites per tile; 2 = segmented: global LSD passes over
- * the tile-id bits only, then a stable LDS radix sort of the depth bits per tile; 0 = onesweep over the whole key (one kernel per digit,
- * decoupled look-back); 1 = three kernels per digit.  All give bit-identical sorted keys, values and ranges (for finite depths). */
+ * the tile-id bits only, then a stable LDS radix sort of the depth bits per tile; 5 = segmented with the register sort per tile (one
+ * order-free 11-bit tile pass; one or two 512^2 views, else like 2); 0 = onesweep over the whole key (one kernel per digit, decoupled
+ * look-back); 1 = three kernels per digit.  All give bit-identical sorted keys, values and ranges (for finite depths). */
 int sgr_set_sort_mode(int mode);
 
 /* bytes of scratch sgr_bin needs for R tile instances */

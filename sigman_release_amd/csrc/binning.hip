@@ -32,7 +32,7 @@ struct DupExtra {
     unsigned long long capacity;
     uint32_t *zero_ptr[3];              // optional buffers to clear on the side: tile ranges, backward flags, a caller buffer
     uint32_t zero_words[3];
-    uint32_t *zero_one;                 // optional single word to clear (the tile-sort worklist counter)
+    uint32_t *zero_small; uint32_t zero_small_n;      // optional few words (<= 256) to clear: the tile-sort worklist counter(s)
 };
 
 // ---- F3 -----------------------------------------------------------------------------------------
@@ -53,7 +53,7 @@ __global__ __launch_bounds__(kThreads) void duplicate_keys_kernel(int P, int Tx,
     for (int c = 0; c < 3; c++)
         for (uint32_t z = (blockIdx.y * gridDim.x + blockIdx.x) * kThreads + threadIdx.x; z < ex.zero_words[c]; z += gridDim.x * gridDim.y * kThreads)
             ex.zero_ptr[c][z] = 0u;
-    if (ex.zero_one && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *ex.zero_one = 0u;
+    if (ex.zero_small && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < ex.zero_small_n) ex.zero_small[threadIdx.x] = 0u;
     const int i = blockIdx.x * kThreads + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t cnt = 0, depth_bits = 0;
@@ -308,7 +308,11 @@ __global__ __launch_bounds__(kThreads) void wide_rowscan_kernel(uint32_t *__rest
     if (lane == 0) totals[d] = carry;
 }
 
-template <int ITEMS>
+// ORDERED: stable (match-any ballots, three barriers per item), writes keys and values, one worklist of occupied tiles.
+// !ORDERED (register per-tile sort behind it): every key claims the next slot of its tile with one returning LDS atomic and leaves a
+// (depth bits << 32 | value) composite there; worklist = [16 counters: count[m] at [m], tickets at [8 + m]] [6][tiles_total] tile ids by
+// length class (<= 1024 << m entries for m = 0..4, longer ones in class 5).
+template <int ITEMS, bool ORDERED>
 __global__ __launch_bounds__(kThreads) void wide_downsweep_kernel(const uint64_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
                                                                   uint64_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, uint32_t n_host,
                                                                   const uint64_t *__restrict__ n_dev, int shift, uint32_t nblocks,
@@ -343,7 +347,12 @@ __global__ __launch_bounds__(kThreads) void wide_downsweep_kernel(const uint64_t
             // per-tile sort's worklist, whose counter the duplicate kernel cleared)
             if (ranges && blockIdx.x == 0 && d < tiles_total) {
                 ranges[d] = v[j] ? make_uint2(run, run + v[j]) : make_uint2(0u, 0u);
-                if (v[j] && worklist) worklist[1 + atomicAdd(&worklist[0], 1u)] = d;
+                if (ORDERED) {
+                    if (v[j] && worklist) worklist[1 + atomicAdd(&worklist[0], 1u)] = d;
+                } else if (v[j]) {
+                    const uint32_t m = v[j] <= 1024u ? 0u : (v[j] <= 2048u ? 1u : (v[j] <= 4096u ? 2u : (v[j] <= 8192u ? 3u : (v[j] <= 16384u ? 4u : 5u))));
+                    worklist[16u + m * tiles_total + atomicAdd(&worklist[m], 1u)] = d;
+                }
             }
             run += v[j];
 #pragma unroll
@@ -361,6 +370,17 @@ __global__ __launch_bounds__(kThreads) void wide_downsweep_kernel(const uint64_t
         if (k < n) { keys_r[it] = keys_in[k]; vals_r[it] = vals_in[k]; }
     }
     __syncthreads();
+    if (!ORDERED) {
+#pragma unroll
+        for (int it = 0; it < ITEMS; it++) {
+            const uint32_t k = base + it * kThreads + t;
+            if (k < n) {
+                const uint32_t d = (uint32_t)(keys_r[it] >> shift) & (kWide - 1);
+                keys_out[atomicAdd(&digit_base[d], 1u)] = (keys_r[it] << 32) | vals_r[it];
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int it = 0; it < ITEMS; it++) {
         const uint32_t k = base + it * kThreads + t;
@@ -730,29 +750,9 @@ __global__ __launch_bounds__(NT) void tile_sort_kernel(const uint2 *__restrict__
     }
 }
 
-// the same for the view-segmented flavour: a fixed grid of workgroups drains a worklist of occupied tiles through an atomic ticket
-// (tile lists differ 100x in length, so a static round-robin would leave most of the grid idle behind the long ones)
+// worklists of occupied tiles (by length class) drained by a fixed grid of workgroups: tile lists differ 100x in length, so a static
+// round-robin alone would leave most of the grid idle behind the long ones
 struct TileWork { const uint32_t *list; uint32_t *ticket; const uint32_t *count; };
-
-template <int NT, int CAP>
-__global__ __launch_bounds__(NT) void tile_sort_dyn_kernel(const uint2 *__restrict__ ranges, uint64_t *__restrict__ src_keys,
-                                                           uint32_t *__restrict__ src_vals, uint64_t *__restrict__ dst_keys,
-                                                           uint32_t *__restrict__ dst_vals, TileWork w) {
-    __shared__ uint32_t ka[CAP], va[CAP], kb[CAP], vb[CAP];
-    __shared__ uint32_t hist[kRadix], digit_base[kRadix], wave_cnt[NT / 64][kRadix], wtot[4];
-    __shared__ uint32_t s_item;
-    const uint32_t nwork = *w.count;
-    for (;;) {
-        __syncthreads();                                               // LDS (and s_item) reuse between worklist items
-        if (threadIdx.x == 0) s_item = atomicAdd(w.ticket, 1u);
-        __syncthreads();
-        const uint32_t wi = s_item;
-        if (wi >= nwork) return;
-        const uint32_t tile = w.list[wi];
-        const uint2 range = ranges[tile];
-        if (range.y > range.x) sort_one_tile<NT, CAP, true>(range, src_keys, src_vals, dst_keys, dst_vals, ka, va, kb, vb, hist, digit_base, wave_cnt, wtot, tile);
-    }
-}
 
 // ---- per-tile depth sort IN REGISTERS ----------------------------------------------------------------------------------
 // One wave per tile, the tile's entries held as 64-bit composites (depth bits << 32 | value) in IPT registers per lane.  The value
@@ -982,61 +982,110 @@ __device__ __forceinline__ void sgr_sort_tile_regs64(const uint64_t *__restrict_
 // (Separate launches per class cost a ramp-up and a tail each -- with four classes that was more than the sorting itself at C3.)
 // Tickets are drawn for a workgroup's worth of tiles at a time (and four rounds' worth for the single-wave class): returning atomics
 // on one address complete one every ~9 ns on this part, so one ticket per tile made the 41 000 short tiles of C4 a 0.37 ms serial section.
-struct TileWork4 { TileWork w[5]; };        // [m]: tiles with <= 1024 << m entries
+struct TileWork4 { TileWork w[6]; };        // [m], m = 0..4: tiles with <= 1024 << m entries; [5]: longer ones (global-memory fallback)
 
 template <int NW>
-__global__ __launch_bounds__(64 * NW) void tile_sort_regs_kernel(const uint2 *__restrict__ ranges, const uint64_t *__restrict__ src_comp,
-                                                                 uint64_t *__restrict__ dst_keys, uint32_t *__restrict__ dst_vals, TileWork4 tw,
-                                                                 int m_hi, int m_lo) {
+__global__ __launch_bounds__(64 * NW) void tile_sort_regs_kernel(const uint2 *__restrict__ ranges, uint64_t *__restrict__ src_comp,
+                                                                 uint32_t *__restrict__ src_scratch, uint64_t *__restrict__ dst_keys,
+                                                                 uint32_t *__restrict__ dst_vals, TileWork4 tw, int m_hi, int m_lo, SortPrep prep) {
     __shared__ uint64_t xbuf[NW * 64 * 17];                                      // per wave 64 x (16 + 1) composites: exchange + final re-deal
     __shared__ uint32_t s_item, s_next;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t nsort = gridDim.x;                                                  // workgroups that sort
+    if (prep.enabled) {                                                          // the spare last workgroup orders the tiles for the forward
+        nsort = gridDim.x - 1;
+        if (blockIdx.x == nsort) { sgr_fwd_prepare(ranges, prep.tiles_total, prep.desc, prep.n_desc, prep.order, (uint32_t *)xbuf); return; }
+    }
+    // all class sizes up front (independent loads: one memory latency instead of one per class on the single-view critical path)
+    uint32_t cnt[6];
+#pragma unroll
+    for (int m = 0; m < 6; m++) cnt[m] = *tw.w[m].count;
+    if (NW == 16 && m_hi >= 4 && cnt[5]) {
+        // ---- tiles beyond 16 384 entries (none in the bench configs): a whole workgroup per tile, LDS-free radix passes over the value
+        // bits and then the depth bits through the global pair (src_comp / src_scratch <-> dst); first: they are the longest jobs
+        const TileWork w = tw.w[5];
+        const uint32_t nwork = cnt[5];
+        uint32_t *l32 = (uint32_t *)xbuf;
+        uint32_t *hist = l32, *digit_base = l32 + kRadix, *wtot = l32 + 2 * kRadix;
+        uint32_t (*wave_cnt)[kRadix] = (uint32_t (*)[kRadix])(l32 + 2 * kRadix + 64);
+        for (;;) {
+            __syncthreads();
+            if (threadIdx.x == 0) s_item = atomicAdd(w.ticket, 1u);
+            __syncthreads();
+            const uint32_t wi = s_item;
+            if (wi >= nwork) break;
+            const uint32_t tile = w.list[wi];
+            const uint2 range = ranges[tile];
+            if (range.y > range.x)
+                sort_one_tile<64 * NW, 1, true>(range, src_comp, src_scratch, dst_keys, dst_vals, nullptr, nullptr, nullptr, nullptr, hist, digit_base,
+                                                wave_cnt, wtot, tile);
+        }
+        __syncthreads();
+    }
+    // Every class deals its FIRST round statically (workgroup -> slot, no atomics) and draws tickets only for what is left, so a launch
+    // with fewer tiles than workgroups (one view) never waits for an atomic round trip.  The slots of a class are rotated by the number
+    // of tiles in the longer classes: the workgroups that just sorted a longer tile get the last slots (beyond the list for one view).
+    uint32_t longer = (NW == 16 && m_hi >= 4) ? cnt[5] : 0u;
 #pragma nounroll
     for (int m = m_hi; m >= 1 && m >= m_lo; m--) {
         // ---- tiles of 1024 << (m - 1) < n <= 1024 << m entries: sub-groups of 2^m waves in lock step (the network has workgroup barriers)
         const int nw = 1 << m;
         const uint32_t groups = (uint32_t)(NW >> m), grp = wave >> m, sub = wave & (uint32_t)(nw - 1);
         const TileWork w = tw.w[m];
-        const uint32_t nwork = *w.count;
+        const uint32_t nwork = cnt[m];
         if (nwork == 0u) continue;                                               // workgroup-uniform
         uint64_t *gx = xbuf + grp * (uint32_t)(nw * 64 * 17);
+        // workgroup barriers a sub-group executes per tile: two per wave-crossing stage (level l of the log2(nw) upper levels has l of
+        // them) + the one before the re-deal; sub-groups without a tile only keep that count (they must not compete for the SIMDs)
+        const int n_barriers = m * (m + 1) + 1;
+        // few tiles (one view): spread them over the workgroups, one sub-group each, instead of filling every sub-group of a few
+        const uint32_t take0 = min(groups, max(1u, (nwork + nsort - 1u) / nsort)), dealt = nsort * take0;
+        const uint32_t rot = longer % nsort;
+        uint32_t take = take0, base = (blockIdx.x >= rot ? blockIdx.x - rot : blockIdx.x + nsort - rot) * take0;
+        longer += nwork;
         for (;;) {
+            if (base >= nwork) break;                                            // workgroup-uniform
+            const uint32_t wi = base + grp;
+            if (grp < take && wi < nwork) {
+                const uint32_t tile = w.list[wi];
+                const uint2 range = ranges[tile];
+                sgr_sort_tile_regs64<16>(src_comp + range.x, dst_keys + range.x, dst_vals + range.x, range.y - range.x, tile, lane, sub, nw, gx);
+            } else {
+#pragma nounroll
+                for (int b = 0; b < n_barriers; b++) __syncthreads();
+            }
+            if (dealt >= nwork) break;                                           // the static round covered the class
+            const uint32_t left = nwork - min(nwork, base + take);
+            take = min(groups, max(1u, (left + nsort - 1u) / nsort));
             __syncthreads();
-            if (threadIdx.x == 0) s_item = atomicAdd(w.ticket, groups);
+            if (threadIdx.x == 0) s_item = dealt + atomicAdd(w.ticket, take);
             __syncthreads();
-            const uint32_t wi = s_item + grp;
-            if (s_item >= nwork) break;                                          // workgroup-uniform
-            uint2 range = make_uint2(0u, 0u);
-            uint32_t tile = 0u;
-            if (wi < nwork) { tile = w.list[wi]; range = ranges[tile]; }
-            sgr_sort_tile_regs64<16>(src_comp + range.x, dst_keys + range.x, dst_vals + range.x, range.y - range.x, tile, lane, sub, nw, gx);
+            base = s_item;
         }
     }
     if (m_lo > 0) return;
-    // ---- tiles of <= 1024 entries: one wave each, no workgroup barriers inside the sort.  The workgroup draws BATCHES of tiles with one
-    // returning global atomic (they complete one every ~9 ns on one address: a ticket per tile was a 0.37-ms serial section for the
-    // 41 000 short tiles of C4), its waves then draw single tiles from the batch through an LDS counter, so a wave with short tiles
-    // takes more of them; batches shrink towards the end of the list (guided self-scheduling) to keep the tail short.
+    // ---- tiles of <= 1024 entries: one wave each, no workgroup barriers inside the sort.  The workgroup takes BATCHES of tiles (the first
+    // one statically, then one returning global atomic per batch: they complete one every ~9 ns on one address -- a ticket per tile was
+    // a 0.37-ms serial section for the 41 000 short tiles of C4), its waves draw single tiles from the batch through an LDS counter, so
+    // a wave with short tiles takes more of them; batches shrink towards the end of the list (guided self-scheduling): short tail.
     const TileWork w = tw.w[0];
-    const uint32_t nwork = *w.count;
+    const uint32_t nwork = cnt[0];
     if (nwork == 0u) return;
     uint64_t *gx = xbuf + wave * (uint32_t)(64 * 17);
-    uint32_t seen = 0;
+    const uint32_t want0 = min((uint32_t)(4 * NW), max(1u, (nwork + 2u * nsort - 1u) / (2u * nsort))), dealt = nsort * want0;
+    const uint32_t rot = longer % nsort;
+    uint32_t want = want0, base = (blockIdx.x >= rot ? blockIdx.x - rot : blockIdx.x + nsort - rot) * want0;
+    __syncthreads();                                                             // (s_next: the classes above are done with LDS)
+    if (threadIdx.x == 0) s_next = 0u;
+    __syncthreads();
     for (;;) {
-        const uint32_t left = nwork - min(nwork, seen);
-        const uint32_t want = min((uint32_t)(4 * NW), max((uint32_t)NW, left / (2u * gridDim.x)));
-        __syncthreads();                                                         // every wave is done with the previous batch
-        if (threadIdx.x == 0) { s_item = atomicAdd(w.ticket, want); s_next = 0u; }
-        __syncthreads();
-        const uint32_t base = s_item;
         if (base >= nwork) break;                                                // workgroup-uniform
-        seen = base + want;
-        const uint32_t cnt = min(want, nwork - base);
+        const uint32_t cntb = min(want, nwork - base);
         for (;;) {
             uint32_t i = 0;
             if (lane == 0) i = atomicAdd(&s_next, 1u);
             i = (uint32_t)__builtin_amdgcn_readfirstlane((int)i);
-            if (i >= cnt) break;
+            if (i >= cntb) break;
             const uint32_t tile = w.list[base + i];
             const uint2 range = ranges[tile];
             const uint32_t n = range.y - range.x;
@@ -1044,6 +1093,13 @@ __global__ __launch_bounds__(64 * NW) void tile_sort_regs_kernel(const uint2 *__
             if (n <= 256u) sgr_sort_tile_regs64<4>(src_comp + range.x, dst_keys + range.x, dst_vals + range.x, n, tile, lane, 0u, 1, gx);
             else sgr_sort_tile_regs64<16>(src_comp + range.x, dst_keys + range.x, dst_vals + range.x, n, tile, lane, 0u, 1, gx);
         }
+        if (dealt >= nwork) break;                                               // the static round covered the class
+        const uint32_t left = nwork - min(nwork, base + want);
+        want = min((uint32_t)(4 * NW), max(1u, left / (2u * nsort)));
+        __syncthreads();                                                         // every wave is done with the previous batch
+        if (threadIdx.x == 0) { s_item = dealt + atomicAdd(w.ticket, want); s_next = 0u; }
+        __syncthreads();
+        base = s_item;
     }
 }
 
@@ -1360,7 +1416,7 @@ int sgr_bin_ex(const SgrProblem *pb, const int32_t *radii, uint32_t *rect,
         ex.zero_ptr[1 + c] = ok ? clear_ptr[c] : nullptr; ex.zero_words[1 + c] = ok ? (uint32_t)clear_words[c] : 0u;
         if (clear_done) clear_done[c] = ok ? 1 : 0;
     }
-    ex.zero_one = all_large ? (uint32_t *)((char *)workspace + sgr_bin_workspace_bytes(R, 0)) : nullptr;
+    ex.zero_small = all_large ? (uint32_t *)((char *)workspace + sgr_bin_workspace_bytes(R, 0)) : nullptr; ex.zero_small_n = 16u;   // [0] worklist counter / class counts + tickets
     if (self_scan && !num_rendered_dev) { sgr_set_error("sgr_bin: self-scan needs the device counter"); return 1; }
     hipLaunchKernelGGL(duplicate_keys_kernel, dim3(nbx, pb->n_views), dim3(kThreads), 0, stream, pb->P, Tx, Tx * Ty,
                        radii, (uint4 *)rect, block_offsets, n, keys_a, vals_a, ex);
@@ -1387,8 +1443,12 @@ int sgr_bin_ex(const SgrProblem *pb, const int32_t *radii, uint32_t *rect,
     // (launches whose tile lists are deep on average -- C5: 1M Gaussians on 1024 tiles -- would sort most tiles through global memory in
     // the per-tile step: those keep the whole-key passes)
     const bool deep = R > tiles_total * 1024ull;
-    if (mode == 3) mode = (R <= (1ull << 19) && tiles_total <= 2048) ? 2 : ((vseg_ok && !deep) ? 4 : (R <= (1ull << 23) ? 1 : 0));
+    if (mode == 3) mode = (R <= (1ull << 19) && tiles_total <= 2048) ? 5 : ((vseg_ok && !deep) ? 4 : (R <= (1ull << 23) ? 1 : 0));
     if (mode == 4 && !vseg_ok) mode = R <= (1ull << 23) ? 1 : 0;
+    // 5 = segmented with the register per-tile sort: needs the single wide tile pass (256 < tiles <= 2048, <= 2^19 instances) and the
+    // class worklists in the area the duplicate kernel cleared (all_large); otherwise the LDS flavour
+    const bool wide_regs = mode == 5 && all_large && small && bits_for(tiles_total) > kRadixBits && bits_for(tiles_total) <= kWideBits;
+    if (mode == 5) mode = 2;
     if (mode == 4) {
         char *ws = (char *)workspace;
         VsegPlan *plan = (VsegPlan *)(ws + VL.plan);
@@ -1420,16 +1480,38 @@ int sgr_bin_ex(const SgrProblem *pb, const int32_t *radii, uint32_t *rect,
         // longest tiles first; tiles beyond the LDS capacity go through the global ping-pong buffers, a whole workgroup per tile
         const uint2 *rg = (const uint2 *)ranges;
         TileWork4 tw4;
-        for (int c = 0; c < 5; c++) tw4.w[c] = work(c);
-        // beyond 16384 entries: a whole workgroup per tile through the global ping-pong buffers; everything else in ONE launch
-        hipLaunchKernelGGL((tile_sort_dyn_kernel<1024, kSegCapLarge>), dim3(grid(1)), dim3(1024), 0, stream, rg, kout, vout, kin, vin, work(5));
-        hipLaunchKernelGGL(tile_sort_regs_kernel<16>, dim3(grid(1)), dim3(1024), 0, stream, rg, kout, kin, vin, tw4, 4, 0);
-        SGR_CHECK_LAUNCH("tile_sort_dyn_kernel");
+        for (int c = 0; c < 6; c++) tw4.w[c] = work(c);
+        SortPrep none; none.desc = nullptr; none.n_desc = 0; none.order = nullptr; none.tiles_total = 0; none.enabled = 0;
+        hipLaunchKernelGGL(tile_sort_regs_kernel<16>, dim3(grid(1)), dim3(1024), 0, stream, rg, kout, vout, kin, vin, tw4, 4, 0, none);
+        SGR_CHECK_LAUNCH("tile_sort_regs_kernel");
         }
         if (result_in_b_host) *result_in_b_host = (kin == keys_b) ? 1 : 0;
         return 0;
     }
     const bool segmented = mode == 2;
+    if (segmented && wide_regs) {
+        uint32_t *wl = (uint32_t *)((char *)workspace + sgr_bin_workspace_bytes(R, 0));     // [16 counters][6][tiles_total]
+        { SgrProfScope _ps(SGR_K_SORT, stream);
+        hipLaunchKernelGGL(wide_upsweep_kernel<kItemsSmall>, dim3(nblocks), dim3(kThreads), 0, stream, kin, n, num_rendered_dev, 32, nblocks, hist);
+        hipLaunchKernelGGL(wide_rowscan_kernel, dim3(kWide / 4), dim3(kThreads), 0, stream, hist, nblocks, hist + (size_t)nblocks * kWide);
+        hipLaunchKernelGGL((wide_downsweep_kernel<kItemsSmall, false>), dim3(nblocks), dim3(kThreads), 0, stream, kin, vin, kout, vout, n, num_rendered_dev, 32,
+                           nblocks, hist, hist + (size_t)nblocks * kWide, (uint2 *)ranges, (uint32_t)tiles_total, wl);
+        SGR_CHECK_LAUNCH("wide tile-bit pass");
+        // composites sit tile-bucketed in kout (vout is scratch); the sorted list goes back into (kin, vin)
+        TileWork4 tw4;
+        for (int c = 0; c < 6; c++) { TileWork w = {wl + 16 + (size_t)c * tiles_total, wl + 8 + c, wl + c}; tw4.w[c] = w; }
+        SortPrep sp;
+        sp.desc = (uint2 *)prep_desc; sp.n_desc = prep_n_desc; sp.order = prep_order; sp.tiles_total = (uint32_t)tiles_total;
+        sp.enabled = (prep_order || prep_desc) ? 1 : 0;
+        const uint32_t g = (uint32_t)(tiles_total < 256 ? tiles_total : 256);
+        hipLaunchKernelGGL(tile_sort_regs_kernel<16>, dim3(g + (sp.enabled ? 1u : 0u)), dim3(1024), 0, stream, (const uint2 *)ranges, kout, vout, kin, vin,
+                           tw4, 4, 0, sp);
+        if (sp.enabled && prep_done) *prep_done = 1;
+        SGR_CHECK_LAUNCH("tile_sort_regs_kernel");
+        }
+        if (result_in_b_host) *result_in_b_host = (kin == keys_b) ? 1 : 0;
+        return 0;
+    }
     if (segmented) {
         uint32_t *worklist = (uint32_t *)((char *)workspace + sgr_bin_workspace_bytes(R, 0));   // [1 + tiles_total] behind the radix scratch
         const int tile_bits = bits_for(tiles_total);
@@ -1439,7 +1521,7 @@ int sgr_bin_ex(const SgrProblem *pb, const int32_t *radii, uint32_t *rect,
         if (wide) {
             hipLaunchKernelGGL(wide_upsweep_kernel<kItemsSmall>, dim3(nblocks), dim3(kThreads), 0, stream, kin, n, num_rendered_dev, 32, nblocks, hist);
             hipLaunchKernelGGL(wide_rowscan_kernel, dim3(kWide / 4), dim3(kThreads), 0, stream, hist, nblocks, hist + (size_t)nblocks * kWide);
-            hipLaunchKernelGGL(wide_downsweep_kernel<kItemsSmall>, dim3(nblocks), dim3(kThreads), 0, stream, kin, vin, kout, vout, n, num_rendered_dev, 32, nblocks, hist, hist + (size_t)nblocks * kWide,
+            hipLaunchKernelGGL((wide_downsweep_kernel<kItemsSmall, true>), dim3(nblocks), dim3(kThreads), 0, stream, kin, vin, kout, vout, n, num_rendered_dev, 32, nblocks, hist, hist + (size_t)nblocks * kWide,
                                (uint2 *)ranges, (uint32_t)tiles_total, worklist);
             SGR_CHECK_LAUNCH("wide tile-bit pass");
             uint64_t *tk = kin; kin = kout; kout = tk;

@@ -67,6 +67,7 @@ def _build(n_views, P, size, seed, depth_kind, big_rects):
 
 @pytest.mark.parametrize("n_views,P,size,depth_kind,big_rects", [
     (1, 3000, 256, "normal", False),
+    (1, 40000, 512, "extreme", True),          # one view, <= 2^19 instances: the wide tile pass + register sort, tiles of every length class
     (3, 5000, 512, "ties", True),
     (4, 60000, 512, "extreme", True),
     (2, 6000, 1024, "extreme", False),
@@ -77,7 +78,7 @@ def test_sgr_bin_direct_all_flavours(n_views, P, size, depth_kind, big_rects):
     dev = torch.device("cuda", 0)
     case = _build(n_views, P, size, 11 + n_views, depth_kind, big_rects)
     R = int(case["cnt"].sum())
-    if big_rects and P >= 60000:
+    if big_rects and P >= 40000:
         assert case["longest"] > 4096, case["longest"]                           # the multi-wave classes of the register sort are exercised
     nbx = int(L.sgr_preprocess_blocks_per_view(P))
     n = nbx * n_views
@@ -97,7 +98,7 @@ def test_sgr_bin_direct_all_flavours(n_views, P, size, depth_kind, big_rects):
     tiles_total = n_views * case["T"] ** 2
     ws_bytes = int(L.sgr_bin_workspace_bytes(R, tiles_total))
     try:
-        for mode in (1, 4, 0, 2, 3):
+        for mode in (1, 4, 0, 2, 5, 3):
             radii, rect, boff = t(case["radii"]), t(case["rect"]), t(offs)
             ka, kb = (torch.zeros(R, dtype=torch.int64, device=dev) for _ in range(2))
             va, vb = (torch.zeros(R, dtype=torch.int32, device=dev) for _ in range(2))

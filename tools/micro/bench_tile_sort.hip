@@ -60,13 +60,14 @@ static void run_case(const std::string &name, std::vector<uint32_t> len) {
     CK(hipMemcpy(ranges, hr.data(), (size_t)ntiles * 8, hipMemcpyHostToDevice));
     uint32_t h[16] = {0};
     TileWork4 tw4;
+    tw4.w[5] = TileWork{list, cnt + 15, cnt + 14};                                     // no tile beyond 16384 entries here: cnt[14] = 0
     for (int m = 0; m < 5; m++) {
         if (!lists[m].empty()) CK(hipMemcpy(list + (size_t)m * ntiles, lists[m].data(), lists[m].size() * 4, hipMemcpyHostToDevice));
         h[m] = (uint32_t)lists[m].size();                                         // cnt[0..4] counts, cnt[8..12] tickets
         tw4.w[m] = TileWork{list + (size_t)m * ntiles, cnt + 8 + m, cnt + m};
     }
     auto reset = [&]() { CK(hipMemcpyAsync(cnt, h, 64, hipMemcpyHostToDevice, 0)); };
-    const float us = time_it([&]() { reset(); hipLaunchKernelGGL(tile_sort_regs_kernel<16>, dim3(256), dim3(1024), 0, 0, ranges, ka, kb, vb, tw4, 4, 0); });
+    const float us = time_it([&]() { reset(); hipLaunchKernelGGL(tile_sort_regs_kernel<16>, dim3(256), dim3(1024), 0, 0, ranges, ka, va, kb, vb, tw4, 4, 0, SortPrep{nullptr, 0, nullptr, 0, 0}); });
     CK(hipDeviceSynchronize());
     std::vector<uint64_t> ok(R); std::vector<uint32_t> ov(R);
     CK(hipMemcpy(ok.data(), kb, R * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(ov.data(), vb, R * 4, hipMemcpyDeviceToHost));
@@ -85,7 +86,7 @@ static void run_case(const std::string &name, std::vector<uint32_t> len) {
 
 int main(int argc, char **argv) {
     struct Case { int ntiles; uint32_t n; };
-    const std::vector<Case> cases = {{1, 100}, {1, 1000}, {1, 8000}, {12000, 250}, {12000, 1000}, {6000, 2000}, {3000, 4000}, {1500, 8000}, {750, 16000}, {3000, 1100}, {3000, 2100}};
+    const std::vector<Case> cases = {{1, 100}, {1, 1000}, {1, 2000}, {1, 4000}, {1, 8000}, {12000, 250}, {12000, 1000}, {6000, 2000}, {3000, 4000}, {1500, 8000}, {750, 16000}, {3000, 1100}, {3000, 2100}};
     if (const char *only = getenv("BTS_ONLY")) {                                      // e.g. BTS_ONLY=12000x1000 (for rocprofv3 counter runs)
         int nt; unsigned n;
         if (sscanf(only, "%dx%u", &nt, &n) == 2) run_case(only, std::vector<uint32_t>(nt, n));
