@@ -202,6 +202,11 @@ uint64_t sgr_bucket_slots(uint64_t R, uint64_t tiles_total);
  * otherwise), 1 = serial, 2 = segment-parallel.  Both produce the same outputs. */
 int sgr_set_forward_mode(int mode);
 
+/* B2 + B3 kernel choice: 0 = automatic (default: on the colors_precomp path with views_per_subject in {2, 4, .., 256} one thread per
+ * (view, Gaussian), the per-view contributions added in view order by one thread per Gaussian; otherwise one thread per Gaussian that
+ * loops over the views), 1 = always the loop.  Both give bit-identical gradients. */
+int sgr_set_backward_gather(int mode);
+
 /* checkpoint layout of the auxiliary forward outputs: 0 = automatic (default: "rows" unless that allocation would exceed
  * SIGMAN_AUX_ROWS_MAX_BYTES, 8 GiB if unset), 1 = compact, 2 = rows.  sgr_rasterize_forward records its choice in state->with_aux. */
 int sgr_set_aux_layout(int mode);

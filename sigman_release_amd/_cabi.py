@@ -56,6 +56,7 @@ _SIGNATURES = {
     "sgr_bucket_slots": (C.c_uint64, [C.c_uint64, C.c_uint64]),
     "sgr_set_forward_mode": (C.c_int, [C.c_int]),
     "sgr_set_aux_layout": (C.c_int, [C.c_int]),
+    "sgr_set_backward_gather": (C.c_int, [C.c_int]),
     "sgr_set_graphs": (C.c_int, [C.c_int]),
     "sgr_set_debug": (C.c_int, [C.c_int]),
     "sgr_set_sort_mode": (C.c_int, [C.c_int]),

@@ -331,156 +331,147 @@ __global__ __launch_bounds__(1024) void scan_block_sums_kernel(const uint32_t *_
 }
 
 // -------------------------------------------------------------------------------------------------
-// B2 + B3: one thread per (subject, Gaussian); loops over the subject's views in order.
+// B2 + B3.  The contribution of ONE view to the gradients of one Gaussian (bwd_view), then the sum over the subject's views in view
+// order and the covariance -> (scale, rotation) chain (bwd_finish).  Two kernels share them:
+//   preprocess_bwd_kernel        one thread per (subject, Gaussian), loops over the views (SH path; any views_per_subject)
+//   preprocess_bwd_lanes_kernel  one thread per (view, Gaussian): the gather's dependent loads (rect -> flags -> partial records) of
+//                                the 8 views of a training subject run side by side instead of one after the other; the per-view
+//                                contributions meet in LDS and ONE thread per Gaussian adds them in view order -- the same additions
+//                                in the same order as the loop, so both kernels give bit-identical gradients
 // -------------------------------------------------------------------------------------------------
+struct ViewGrad { float mean[3], cov[6], op, col[3]; };
+
 // SH=false (the reference's colors_precomp path) compiles without the spherical-harmonics tables: no scratch, half the VGPRs
 template <bool SH>
-__global__ __launch_bounds__(kPreThreads) void preprocess_bwd_kernel(SgrProblem pb, const int32_t *__restrict__ radii,
-                                                                     const uint8_t *__restrict__ clamped,
-                                                                     const float4 *__restrict__ grec,
-                                                                     const uint4 *__restrict__ rect,
-                                                                     const float4 *__restrict__ part,
-                                                                     const uint32_t *__restrict__ flags, uint32_t n_inst,
-                                                                     float *__restrict__ dL_dmeans3D,
-                                                                     float *__restrict__ dL_dmeans2D,
-                                                                     float *__restrict__ dL_dopacity,
-                                                                     float *__restrict__ dL_dcolors,
-                                                                     float *__restrict__ dL_dsh,
-                                                                     float *__restrict__ dL_dcov3D,
-                                                                     float *__restrict__ dL_dscales,
-                                                                     float *__restrict__ dL_drot) {
-    const int subj = blockIdx.y;
-    const int i = blockIdx.x * kPreThreads + threadIdx.x;
-    if (i >= pb.P) return;
-    const size_t sp = (size_t)subj * pb.P + i;
-    const int W = pb.W, H = pb.H;
-    const float fx = (float)W / (2.0f * pb.tanfovx), fy = (float)H / (2.0f * pb.tanfovy);
-    const float p[3] = {pb.means3D[sp * 3 + 0], pb.means3D[sp * 3 + 1], pb.means3D[sp * 3 + 2]};
-    float c6[6];
-    load_cov3d(pb, sp, c6);
-    float gmean[3] = {0.f, 0.f, 0.f}, gcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, gop = 0.f, gcol[3] = {0.f, 0.f, 0.f};
-    const int nsh = SH ? pb.M : 0;
-    // SH gradients are accumulated straight into global memory across the view loop (same thread, fixed order)
-    if (SH) {
-        float *gsh = dL_dsh + sp * (size_t)pb.M * 3;
-        for (int k = 0; k < nsh * 3; k++) gsh[k] = 0.f;
-    }
-    const int v0 = subj * pb.views_per_subject;
-    for (int vv = 0; vv < pb.views_per_subject; vv++) {
-        const int view = v0 + vv;
-        const size_t q = (size_t)view * pb.P + i;
-        float *g2out = dL_dmeans2D ? dL_dmeans2D + q * 3 : nullptr;      // (NULL: nobody wants dL/dNDC)
-        if (!(radii[q] > 0)) { if (g2out) { g2out[0] = g2out[1] = g2out[2] = 0.f; } continue; }
-        float4 g0, g1, g2;
-        if (part) {
-            // deterministic gather of the bucket-parallel backward's partial records: one per (tile instance, quadrant),
-            // summed in tile order then quadrant order -- no atomics anywhere in the backward
-            const uint4 r3 = rect[q];
-            const uint32_t off = r3.w, rmin = r3.x, rmax = r3.y;
-            const uint32_t ntile = ((rmax & 0xFFFFu) - (rmin & 0xFFFFu)) * ((rmax >> 16) - (rmin >> 16));
-            g0 = make_float4(0.f, 0.f, 0.f, 0.f); g1 = g0; g2 = g0;
-            for (uint32_t k = 0; k < ntile; k++) {
-                if (off + k >= n_inst) break;                   // sync-free mode after an overflow: instances beyond the buffers do not exist
-                const uint32_t f = flags[off + k];
-                if (!f) continue;
+__device__ __forceinline__ void bwd_view(const SgrProblem &pb, int view, int i, size_t sp, const float (&p)[3], const float (&c6)[6], float fx, float fy,
+                                         const int32_t *__restrict__ radii, const uint8_t *__restrict__ clamped, const float4 *__restrict__ grec,
+                                         const uint4 *__restrict__ rect, const float4 *__restrict__ part, const uint32_t *__restrict__ flags,
+                                         uint32_t n_inst, float *__restrict__ dL_dmeans2D, float *__restrict__ dL_dsh, ViewGrad &out) {
 #pragma unroll
-                for (uint32_t qd = 0; qd < 4; qd++) {
-                    if (!((f >> (8 * qd)) & 0xFFu)) continue;
-                    const float2 *pp = reinterpret_cast<const float2 *>(part) + ((size_t)(off + k) * 4 + qd) * (SGR_PART_FLOATS / 2);
-                    const float2 p0 = pp[0], p1 = pp[1], p2 = pp[2], p3 = pp[3], p4 = pp[4];
-                    g0.x += p0.x; g0.y += p0.y; g0.z += p1.x; g0.w += p1.y;
-                    g1.x += p2.x; g1.y += p2.y; g1.z += p3.x; g1.w += p3.y;
-                    g2.x += p4.x; g2.y += p4.y;
-                }
+    for (int k = 0; k < 3; k++) { out.mean[k] = 0.f; out.col[k] = 0.f; }
+#pragma unroll
+    for (int k = 0; k < 6; k++) out.cov[k] = 0.f;
+    out.op = 0.f;
+    const size_t q = (size_t)view * pb.P + i;
+    float *g2out = dL_dmeans2D ? dL_dmeans2D + q * 3 : nullptr;      // (NULL: nobody wants dL/dNDC)
+    if (!(radii[q] > 0)) { if (g2out) { g2out[0] = g2out[1] = g2out[2] = 0.f; } return; }
+    float4 g0, g1, g2;
+    if (part) {
+        // deterministic gather of the bucket-parallel backward's partial records: one per (tile instance, quadrant),
+        // summed in tile order then quadrant order -- no atomics anywhere in the backward
+        const uint4 r3 = rect[q];
+        const uint32_t off = r3.w, rmin = r3.x, rmax = r3.y;
+        const uint32_t ntile = ((rmax & 0xFFFFu) - (rmin & 0xFFFFu)) * ((rmax >> 16) - (rmin >> 16));
+        g0 = make_float4(0.f, 0.f, 0.f, 0.f); g1 = g0; g2 = g0;
+        for (uint32_t k = 0; k < ntile; k++) {
+            if (off + k >= n_inst) break;                   // sync-free mode after an overflow: instances beyond the buffers do not exist
+            const uint32_t f = flags[off + k];
+            if (!f) continue;
+#pragma unroll
+            for (uint32_t qd = 0; qd < 4; qd++) {
+                if (!((f >> (8 * qd)) & 0xFFu)) continue;
+                // one 40-byte record, 8-byte aligned: 16 + 16 + 8-byte loads (three requests per lane instead of five)
+                struct __attribute__((packed, aligned(8))) Rec40 { float2 v[5]; };
+                const Rec40 rr = *(reinterpret_cast<const Rec40 *>(part) + ((size_t)(off + k) * 4 + qd));
+                const float2 p0 = rr.v[0], p1 = rr.v[1], p2 = rr.v[2], p3 = rr.v[3], p4 = rr.v[4];
+                g0.x += p0.x; g0.y += p0.y; g0.z += p1.x; g0.w += p1.y;
+                g1.x += p2.x; g1.y += p2.y; g1.z += p3.x; g1.w += p3.y;
+                g2.x += p4.x; g2.y += p4.y;
             }
-        } else {
-            g0 = grec[q * 3 + 0]; g1 = grec[q * 3 + 1]; g2 = grec[q * 3 + 2];
         }
-        const float *V = pb.viewmatrix + 16 * (size_t)view;
-        const float *M = pb.projmatrix + 16 * (size_t)view;
-        float pv[3];
-        xform4x3(V, p, pv);
-        Cov2D cq;
-        cov2d_eval(pv, V, c6, fx, fy, pb.tanfovx, pb.tanfovy, cq);
-        // ---- B2: conic -> (a,b,c) -> Sigma, projection Jacobian
-        const float a = cq.a, b = cq.b, c = cq.c;
-        const float gx = g0.z, gy = g0.w, gz = g1.x;
-        const float denom = a * c - b * b;
-        const float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
-        float dL_da = 0.f, dL_db = 0.f, dL_dc = 0.f;
-        if (denom2inv != 0.f) {
-            dL_da = denom2inv * (-c * c * gx + 2.f * b * c * gy + (denom - a * c) * gz);
-            dL_dc = denom2inv * (-a * a * gz + 2.f * a * b * gy + (denom - a * c) * gx);
-            dL_db = denom2inv * 2.f * (b * c * gx - (denom + 2.f * b * b) * gy + a * b * gz);
-            const float *m0 = cq.m0, *m1 = cq.m1;
-            gcov[0] += m0[0] * m0[0] * dL_da + m0[0] * m1[0] * dL_db + m1[0] * m1[0] * dL_dc;
-            gcov[3] += m0[1] * m0[1] * dL_da + m0[1] * m1[1] * dL_db + m1[1] * m1[1] * dL_dc;
-            gcov[5] += m0[2] * m0[2] * dL_da + m0[2] * m1[2] * dL_db + m1[2] * m1[2] * dL_dc;
-            gcov[1] += 2.f * m0[0] * m0[1] * dL_da + (m0[0] * m1[1] + m0[1] * m1[0]) * dL_db + 2.f * m1[0] * m1[1] * dL_dc;
-            gcov[2] += 2.f * m0[0] * m0[2] * dL_da + (m0[0] * m1[2] + m0[2] * m1[0]) * dL_db + 2.f * m1[0] * m1[2] * dL_dc;
-            gcov[4] += 2.f * m0[2] * m0[1] * dL_da + (m0[1] * m1[2] + m0[2] * m1[1]) * dL_db + 2.f * m1[1] * m1[2] * dL_dc;
-        }
-        float gm0[3], gm1[3];
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-            gm0[k] = 2.f * cq.v0[k] * dL_da + cq.v1[k] * dL_db;
-            gm1[k] = 2.f * cq.v1[k] * dL_dc + cq.v0[k] * dL_db;
-        }
-        float dJ00 = 0.f, dJ02 = 0.f, dJ11 = 0.f, dJ12 = 0.f;
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-            dJ00 += V[4 * k + 0] * gm0[k]; dJ02 += V[4 * k + 2] * gm0[k];
-            dJ11 += V[4 * k + 1] * gm1[k]; dJ12 += V[4 * k + 2] * gm1[k];
-        }
-        const float tz = 1.f / cq.t[2], tz2 = tz * tz, tz3 = tz2 * tz;
-        const float dtx = cq.xmul * -fx * tz2 * dJ02;
-        const float dty = cq.ymul * -fy * tz2 * dJ12;
-        const float dtz = -fx * tz2 * dJ00 - fy * tz2 * dJ11 + (2.f * fx * cq.t[0]) * tz3 * dJ02 + (2.f * fy * cq.t[1]) * tz3 * dJ12;
-        float gm[3];
-#pragma unroll
-        for (int k = 0; k < 3; k++) gm[k] = (V[4 * k + 0] * dtx + V[4 * k + 1] * dty) + V[4 * k + 2] * dtz;
-        // ---- B3: NDC mean -> 3D mean through the full projection
-        float ph[4];
-        xform4x4(M, p, ph);
-        const float mw = 1.0f / (ph[3] + 0.0000001f);
-        const float mul1 = ph[0] * mw * mw, mul2 = ph[1] * mw * mw;
-        const float g2x = g0.x, g2y = g0.y;
-        gm[0] += (M[0] * mw - M[3] * mul1) * g2x + (M[1] * mw - M[3] * mul2) * g2y;
-        gm[1] += (M[4] * mw - M[7] * mul1) * g2x + (M[5] * mw - M[7] * mul2) * g2y;
-        gm[2] += (M[8] * mw - M[11] * mul1) * g2x + (M[9] * mw - M[11] * mul2) * g2y;
-        const float gdep = g1.z;
-        gm[0] += V[2] * gdep; gm[1] += V[6] * gdep; gm[2] += V[10] * gdep;
-        const float gc3[3] = {g1.w, g2.x, g2.y};
-        if constexpr (SH) {
-            const float *cp = pb.campos + 3 * (size_t)view;
-            const float d[3] = {p[0] - cp[0], p[1] - cp[1], p[2] - cp[2]};
-            const float len = sqrtf((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]);
-            const float u[3] = {d[0] / len, d[1] / len, d[2] / len};
-            float B[16], Gb[16][3];
-            const int nb = sh_basis(pb.sh_degree, u, B);
-            sh_basis_grad(pb.sh_degree, u, Gb);
-            const float *sh = pb.shs + sp * (size_t)pb.M * 3;
-            float *gsh = dL_dsh + sp * (size_t)pb.M * 3;
-            const uint8_t cb = clamped[q];
-            float gdir[3] = {0.f, 0.f, 0.f};
-            for (int ch = 0; ch < 3; ch++) {
-                const float gcl = ((cb >> ch) & 1) ? 0.f : gc3[ch];
-                for (int k = 0; k < nb; k++) {
-                    gsh[3 * k + ch] += B[k] * gcl;
-                    const float sg = sh[3 * k + ch] * gcl;
-                    gdir[0] += Gb[k][0] * sg; gdir[1] += Gb[k][1] * sg; gdir[2] += Gb[k][2] * sg;
-                }
-            }
-            const float udot = (u[0] * gdir[0] + u[1] * gdir[1]) + u[2] * gdir[2];
-#pragma unroll
-            for (int k = 0; k < 3; k++) gm[k] += (gdir[k] - u[k] * udot) / len;
-        } else {
-            gcol[0] += gc3[0]; gcol[1] += gc3[1]; gcol[2] += gc3[2];
-        }
-        gop += g1.y;
-        gmean[0] += gm[0]; gmean[1] += gm[1]; gmean[2] += gm[2];
-        if (g2out) { g2out[0] = g2x; g2out[1] = g2y; g2out[2] = 0.f; }
+    } else {
+        g0 = grec[q * 3 + 0]; g1 = grec[q * 3 + 1]; g2 = grec[q * 3 + 2];
     }
+    const float *V = pb.viewmatrix + 16 * (size_t)view;
+    const float *M = pb.projmatrix + 16 * (size_t)view;
+    float pv[3];
+    xform4x3(V, p, pv);
+    Cov2D cq;
+    cov2d_eval(pv, V, c6, fx, fy, pb.tanfovx, pb.tanfovy, cq);
+    // ---- B2: conic -> (a,b,c) -> Sigma, projection Jacobian
+    const float a = cq.a, b = cq.b, c = cq.c;
+    const float gx = g0.z, gy = g0.w, gz = g1.x;
+    const float denom = a * c - b * b;
+    const float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
+    float dL_da = 0.f, dL_db = 0.f, dL_dc = 0.f;
+    if (denom2inv != 0.f) {
+        dL_da = denom2inv * (-c * c * gx + 2.f * b * c * gy + (denom - a * c) * gz);
+        dL_dc = denom2inv * (-a * a * gz + 2.f * a * b * gy + (denom - a * c) * gx);
+        dL_db = denom2inv * 2.f * (b * c * gx - (denom + 2.f * b * b) * gy + a * b * gz);
+        const float *m0 = cq.m0, *m1 = cq.m1;
+        out.cov[0] = m0[0] * m0[0] * dL_da + m0[0] * m1[0] * dL_db + m1[0] * m1[0] * dL_dc;
+        out.cov[3] = m0[1] * m0[1] * dL_da + m0[1] * m1[1] * dL_db + m1[1] * m1[1] * dL_dc;
+        out.cov[5] = m0[2] * m0[2] * dL_da + m0[2] * m1[2] * dL_db + m1[2] * m1[2] * dL_dc;
+        out.cov[1] = 2.f * m0[0] * m0[1] * dL_da + (m0[0] * m1[1] + m0[1] * m1[0]) * dL_db + 2.f * m1[0] * m1[1] * dL_dc;
+        out.cov[2] = 2.f * m0[0] * m0[2] * dL_da + (m0[0] * m1[2] + m0[2] * m1[0]) * dL_db + 2.f * m1[0] * m1[2] * dL_dc;
+        out.cov[4] = 2.f * m0[2] * m0[1] * dL_da + (m0[1] * m1[2] + m0[2] * m1[1]) * dL_db + 2.f * m1[1] * m1[2] * dL_dc;
+    }
+    float gm0[3], gm1[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        gm0[k] = 2.f * cq.v0[k] * dL_da + cq.v1[k] * dL_db;
+        gm1[k] = 2.f * cq.v1[k] * dL_dc + cq.v0[k] * dL_db;
+    }
+    float dJ00 = 0.f, dJ02 = 0.f, dJ11 = 0.f, dJ12 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        dJ00 += V[4 * k + 0] * gm0[k]; dJ02 += V[4 * k + 2] * gm0[k];
+        dJ11 += V[4 * k + 1] * gm1[k]; dJ12 += V[4 * k + 2] * gm1[k];
+    }
+    const float tz = 1.f / cq.t[2], tz2 = tz * tz, tz3 = tz2 * tz;
+    const float dtx = cq.xmul * -fx * tz2 * dJ02;
+    const float dty = cq.ymul * -fy * tz2 * dJ12;
+    const float dtz = -fx * tz2 * dJ00 - fy * tz2 * dJ11 + (2.f * fx * cq.t[0]) * tz3 * dJ02 + (2.f * fy * cq.t[1]) * tz3 * dJ12;
+    float gm[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) gm[k] = (V[4 * k + 0] * dtx + V[4 * k + 1] * dty) + V[4 * k + 2] * dtz;
+    // ---- B3: NDC mean -> 3D mean through the full projection
+    float ph[4];
+    xform4x4(M, p, ph);
+    const float mw = 1.0f / (ph[3] + 0.0000001f);
+    const float mul1 = ph[0] * mw * mw, mul2 = ph[1] * mw * mw;
+    const float g2x = g0.x, g2y = g0.y;
+    gm[0] += (M[0] * mw - M[3] * mul1) * g2x + (M[1] * mw - M[3] * mul2) * g2y;
+    gm[1] += (M[4] * mw - M[7] * mul1) * g2x + (M[5] * mw - M[7] * mul2) * g2y;
+    gm[2] += (M[8] * mw - M[11] * mul1) * g2x + (M[9] * mw - M[11] * mul2) * g2y;
+    const float gdep = g1.z;
+    gm[0] += V[2] * gdep; gm[1] += V[6] * gdep; gm[2] += V[10] * gdep;
+    const float gc3[3] = {g1.w, g2.x, g2.y};
+    if constexpr (SH) {
+        const float *cp = pb.campos + 3 * (size_t)view;
+        const float d[3] = {p[0] - cp[0], p[1] - cp[1], p[2] - cp[2]};
+        const float len = sqrtf((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]);
+        const float u[3] = {d[0] / len, d[1] / len, d[2] / len};
+        float B[16], Gb[16][3];
+        const int nb = sh_basis(pb.sh_degree, u, B);
+        sh_basis_grad(pb.sh_degree, u, Gb);
+        const float *sh = pb.shs + sp * (size_t)pb.M * 3;
+        float *gsh = dL_dsh + sp * (size_t)pb.M * 3;           // accumulated straight into global memory across the caller's view loop
+        const uint8_t cb = clamped[q];
+        float gdir[3] = {0.f, 0.f, 0.f};
+        for (int ch = 0; ch < 3; ch++) {
+            const float gcl = ((cb >> ch) & 1) ? 0.f : gc3[ch];
+            for (int k = 0; k < nb; k++) {
+                gsh[3 * k + ch] += B[k] * gcl;
+                const float sg = sh[3 * k + ch] * gcl;
+                gdir[0] += Gb[k][0] * sg; gdir[1] += Gb[k][1] * sg; gdir[2] += Gb[k][2] * sg;
+            }
+        }
+        const float udot = (u[0] * gdir[0] + u[1] * gdir[1]) + u[2] * gdir[2];
+#pragma unroll
+        for (int k = 0; k < 3; k++) gm[k] += (gdir[k] - u[k] * udot) / len;
+    } else {
+        out.col[0] = gc3[0]; out.col[1] = gc3[1]; out.col[2] = gc3[2];
+    }
+    out.op = g1.y;
+    out.mean[0] = gm[0]; out.mean[1] = gm[1]; out.mean[2] = gm[2];
+    if (g2out) { g2out[0] = g2x; g2out[1] = g2y; g2out[2] = 0.f; }
+}
+
+template <bool SH>
+__device__ __forceinline__ void bwd_finish(const SgrProblem &pb, size_t sp, const float (&gmean)[3], const float (&gcov)[6], float gop, const float (&gcol)[3],
+                                           float *__restrict__ dL_dmeans3D, float *__restrict__ dL_dopacity, float *__restrict__ dL_dcolors,
+                                           float *__restrict__ dL_dcov3D, float *__restrict__ dL_dscales, float *__restrict__ dL_drot) {
 #pragma unroll
     for (int k = 0; k < 3; k++) dL_dmeans3D[sp * 3 + k] = gmean[k];
 #pragma unroll
@@ -525,6 +516,75 @@ __global__ __launch_bounds__(kPreThreads) void preprocess_bwd_kernel(SgrProblem 
         gq[1] = 2.f * (y * (dR[0][1] + dR[1][0]) + z * (dR[0][2] + dR[2][0]) + r * (dR[2][1] - dR[1][2])) - 4.f * x * (dR[1][1] + dR[2][2]);
         gq[2] = 2.f * (x * (dR[0][1] + dR[1][0]) + r * (dR[0][2] - dR[2][0]) + z * (dR[1][2] + dR[2][1])) - 4.f * y * (dR[0][0] + dR[2][2]);
         gq[3] = 2.f * (r * (dR[1][0] - dR[0][1]) + x * (dR[0][2] + dR[2][0]) + y * (dR[1][2] + dR[2][1])) - 4.f * z * (dR[0][0] + dR[1][1]);
+    }
+}
+
+#define SGR_BWD_ARGS                                                                                                              \
+    SgrProblem pb, const int32_t *__restrict__ radii, const uint8_t *__restrict__ clamped, const float4 *__restrict__ grec,        \
+    const uint4 *__restrict__ rect, const float4 *__restrict__ part, const uint32_t *__restrict__ flags, uint32_t n_inst,          \
+    float *__restrict__ dL_dmeans3D, float *__restrict__ dL_dmeans2D, float *__restrict__ dL_dopacity,                              \
+    float *__restrict__ dL_dcolors, float *__restrict__ dL_dsh, float *__restrict__ dL_dcov3D, float *__restrict__ dL_dscales,      \
+    float *__restrict__ dL_drot
+
+template <bool SH>
+__global__ __launch_bounds__(kPreThreads) void preprocess_bwd_kernel(SGR_BWD_ARGS) {
+    const int subj = blockIdx.y;
+    const int i = blockIdx.x * kPreThreads + threadIdx.x;
+    if (i >= pb.P) return;
+    const size_t sp = (size_t)subj * pb.P + i;
+    const float fx = (float)pb.W / (2.0f * pb.tanfovx), fy = (float)pb.H / (2.0f * pb.tanfovy);
+    const float p[3] = {pb.means3D[sp * 3 + 0], pb.means3D[sp * 3 + 1], pb.means3D[sp * 3 + 2]};
+    float c6[6];
+    load_cov3d(pb, sp, c6);
+    float gmean[3] = {0.f, 0.f, 0.f}, gcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, gop = 0.f, gcol[3] = {0.f, 0.f, 0.f};
+    if (SH) {
+        float *gsh = dL_dsh + sp * (size_t)pb.M * 3;
+        for (int k = 0; k < pb.M * 3; k++) gsh[k] = 0.f;
+    }
+    const int v0 = subj * pb.views_per_subject;
+    for (int vv = 0; vv < pb.views_per_subject; vv++) {
+        ViewGrad g;
+        bwd_view<SH>(pb, v0 + vv, i, sp, p, c6, fx, fy, radii, clamped, grec, rect, part, flags, n_inst, dL_dmeans2D, dL_dsh, g);
+#pragma unroll
+        for (int k = 0; k < 6; k++) gcov[k] += g.cov[k];
+        if (!SH) { gcol[0] += g.col[0]; gcol[1] += g.col[1]; gcol[2] += g.col[2]; }
+        gop += g.op;
+        gmean[0] += g.mean[0]; gmean[1] += g.mean[1]; gmean[2] += g.mean[2];
+    }
+    bwd_finish<SH>(pb, sp, gmean, gcov, gop, gcol, dL_dmeans3D, dL_dopacity, dL_dcolors, dL_dcov3D, dL_dscales, dL_drot);
+}
+
+// colors_precomp path, views_per_subject = VPS in {2, 4, .., 256}: thread t of a workgroup = (view t / GPB, Gaussian t % GPB) with
+// GPB = 256 / VPS Gaussians per workgroup (view-major, so the 16-byte rect records of a wave's lanes are contiguous per view)
+__global__ __launch_bounds__(kPreThreads) void preprocess_bwd_lanes_kernel(SGR_BWD_ARGS) {
+    __shared__ float acc[13][kPreThreads];
+    const int subj = blockIdx.y, vps = pb.views_per_subject, gpb = kPreThreads / vps;
+    const int t = threadIdx.x, vv = t / gpb, gl = t - vv * gpb;
+    const int i = blockIdx.x * gpb + gl;
+    const float fx = (float)pb.W / (2.0f * pb.tanfovx), fy = (float)pb.H / (2.0f * pb.tanfovy);
+    ViewGrad g;
+    if (i < pb.P) {
+        const size_t sp = (size_t)subj * pb.P + i;
+        const float p[3] = {pb.means3D[sp * 3 + 0], pb.means3D[sp * 3 + 1], pb.means3D[sp * 3 + 2]};
+        float c6[6];
+        load_cov3d(pb, sp, c6);
+        bwd_view<false>(pb, subj * vps + vv, i, sp, p, c6, fx, fy, radii, clamped, grec, rect, part, flags, n_inst, dL_dmeans2D, dL_dsh, g);
+#pragma unroll
+        for (int k = 0; k < 3; k++) { acc[k][t] = g.mean[k]; acc[10 + k][t] = g.col[k]; }
+#pragma unroll
+        for (int k = 0; k < 6; k++) acc[3 + k][t] = g.cov[k];
+        acc[9][t] = g.op;
+    }
+    __syncthreads();
+    if (t < gpb && i < pb.P) {                                         // (t < gpb: vv == 0, gl == t)
+        float s13[13];
+#pragma unroll
+        for (int k = 0; k < 13; k++) s13[k] = 0.f;
+        for (int w = 0; w < vps; w++)                                  // view order: the additions of preprocess_bwd_kernel's loop
+#pragma unroll
+            for (int k = 0; k < 13; k++) s13[k] += acc[k][w * gpb + t];
+        const float gmean[3] = {s13[0], s13[1], s13[2]}, gcov[6] = {s13[3], s13[4], s13[5], s13[6], s13[7], s13[8]}, gcol[3] = {s13[10], s13[11], s13[12]};
+        bwd_finish<false>(pb, (size_t)subj * pb.P + i, gmean, gcov, s13[9], gcol, dL_dmeans3D, dL_dopacity, dL_dcolors, dL_dcov3D, dL_dscales, dL_drot);
     }
 }
 
@@ -603,6 +663,11 @@ extern "C" int sgr_preprocess_forward(const SgrProblem *pb, float *rec, int32_t 
     return sgr_preprocess_forward_ex(pb, rec, radii, rect, clamped, block_offsets, num_rendered, capacity, false, stream_);
 }
 
+// 0 = automatic (lanes over views on the colors_precomp path when views_per_subject is a power of two in 2..256), 1 = always the
+// one-thread-per-Gaussian kernel (A/B, and the bit-identity test of the two kernels)
+static int g_bwd_view_loop = 0;
+extern "C" int sgr_set_backward_gather(int mode) { g_bwd_view_loop = mode == 1 ? 1 : 0; return 0; }
+
 // n_inst: number of tile instances part / flags were sized for (the gather never reads beyond it)
 int sgr_preprocess_backward_ex(const SgrProblem *pb, const int32_t *radii, const uint8_t *clamped, const float *grec,
                                const uint32_t *rect, const float *part, const uint32_t *flags, uint64_t n_inst, float *dL_dmeans3D, float *dL_dmeans2D,
@@ -621,7 +686,13 @@ int sgr_preprocess_backward_ex(const SgrProblem *pb, const int32_t *radii, const
     if (pb->shs)
         hipLaunchKernelGGL(preprocess_bwd_kernel<true>, grid, dim3(kPreThreads), 0, stream, *pb, radii, clamped, (const float4 *)grec,
                            (const uint4 *)rect, (const float4 *)part, flags, (uint32_t)(n_inst > 0xFFFFFFFFull ? 0xFFFFFFFFull : n_inst), dL_dmeans3D, dL_dmeans2D, dL_dopacity, dL_dcolors, dL_dsh, dL_dcov3D, dL_dscales, dL_drotations);
-    else
+    else if (pb->views_per_subject > 1 && pb->views_per_subject <= kPreThreads && kPreThreads % pb->views_per_subject == 0 && !g_bwd_view_loop) {
+        const int gpb = kPreThreads / pb->views_per_subject;
+        hipLaunchKernelGGL(preprocess_bwd_lanes_kernel, dim3((pb->P + gpb - 1) / gpb, pb->n_views / pb->views_per_subject), dim3(kPreThreads), 0, stream, *pb,
+                           radii, clamped, (const float4 *)grec, (const uint4 *)rect, (const float4 *)part, flags,
+                           (uint32_t)(n_inst > 0xFFFFFFFFull ? 0xFFFFFFFFull : n_inst), dL_dmeans3D, dL_dmeans2D, dL_dopacity, dL_dcolors, dL_dsh, dL_dcov3D,
+                           dL_dscales, dL_drotations);
+    } else
         hipLaunchKernelGGL(preprocess_bwd_kernel<false>, grid, dim3(kPreThreads), 0, stream, *pb, radii, clamped, (const float4 *)grec,
                            (const uint4 *)rect, (const float4 *)part, flags, (uint32_t)(n_inst > 0xFFFFFFFFull ? 0xFFFFFFFFull : n_inst), dL_dmeans3D, dL_dmeans2D, dL_dopacity, dL_dcolors, dL_dsh, dL_dcov3D, dL_dscales, dL_drotations);
     SGR_CHECK_LAUNCH("preprocess_bwd_kernel");

@@ -901,3 +901,48 @@ def test_automatic_capacity_mode_is_transparent():
         results.append(int((per_mode[0][1] > 0).sum()))
     cap = R._auto_capacity[(0, P, 1, H, W)]
     assert cap > 0 and results[2] >= results[0]
+
+
+@pytest.mark.parametrize("views_per_subject,use_scales", [(4, False), (8, True), (2, False)])
+def test_backward_gather_kernels_bit_identical(views_per_subject, use_scales):
+    """B2 + B3 run as one thread per (view, Gaussian) with the per-view contributions added in view order (default for 2..256 views per
+    subject on the colors_precomp path) or as one thread per Gaussian looping over the views (sgr_set_backward_gather(1)): the same
+    additions in the same order -- every gradient tensor must agree BITWISE, dL/dmeans2D included."""
+    from sigman_release_amd import _cabi, cameras, synthetic
+    from sigman_release_amd import rasterizer as R
+    dev = _dev()
+    S, P, H = 2, 7001, 256                                             # P not a multiple of the Gaussians per workgroup
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    gs = [synthetic.humanoid(P, 40 + b) for b in range(S)]
+    views = [30, 37, 45, 53, 65, 85, 0, 8][:views_per_subject]
+    cv, cvp, cp = cameras.make_cameras(views * S)
+    st = R.BatchedRasterizationSettings(H, H, cameras.TAN_HALF_FOV, cameras.TAN_HALF_FOV, torch.ones(3, device=dev), 0.7, t(cv), t(cvp), 0, t(cp),
+                                        views_per_subject)
+    gen = torch.Generator().manual_seed(5)
+    gC = torch.randn(S * views_per_subject, 3, H, H, generator=gen).to(dev)
+    gD = torch.randn(S * views_per_subject, 1, H, H, generator=gen).to(dev)
+    res = {}
+    try:
+        for mode in (0, 1):
+            _cabi.lib().sgr_set_backward_gather(mode)
+            leaf = lambda k: torch.stack([t(g[k]) for g in gs]).requires_grad_(True)
+            m, o, rgb = leaf("position"), leaf("opacity"), leaf("rgb")
+            m2d = torch.zeros(S * views_per_subject, P, 3, device=dev, requires_grad=True)
+            if use_scales:
+                rng = np.random.default_rng(3)
+                sc = t(rng.uniform(0.004, 0.02, (S, P, 3)).astype(np.float32)).requires_grad_(True)
+                rot = t(rng.normal(size=(S, P, 4)).astype(np.float32)).requires_grad_(True)
+                cov = None
+            else:
+                sc = rot = None
+                cov = torch.stack([t(synthetic.covariance_from_gaussians(g)) for g in gs]).requires_grad_(True)
+            color, radii, depth, alpha = R.rasterize_gaussians_batched(m, m2d, None, rgb, o.reshape(S, P, 1), sc, rot, cov, st)
+            ((color * gC).sum() + (depth * gD).sum() + alpha.sum()).backward()
+            torch.cuda.synchronize()
+            res[mode] = {k: v.grad.cpu().numpy() for k, v in dict(means3D=m, opacity=o, rgb=rgb, means2D=m2d, scales=sc, rotations=rot, cov=cov).items()
+                         if v is not None}
+    finally:
+        _cabi.lib().sgr_set_backward_gather(0)
+    for k in res[0]:
+        assert np.abs(res[0][k]).max() > 0, k
+        np.testing.assert_array_equal(res[0][k], res[1][k], err_msg=k)
