@@ -740,21 +740,29 @@ __global__ __launch_bounds__(kBlock) void render_bwd_bucket_kernel(int W, int H,
     // conic pre-scaled into the exp2 domain: G = exp(power) = exp2(kxx dx^2 + kyy dy^2 + kxy dx dy)
     const float kL2e = 1.4426950408889634f;
     const float kxx = -0.5f * kL2e * cxx, kyy = -0.5f * kL2e * cyy, kxy = -kL2e * cxy;
-    // ---- pixel p = lane: static data and the four row start states go to LDS (the per-step feeders)
+    // ---- pixel p = lane: static data and the four row start states go to LDS (the per-step feeders).  Only the pixels that can still
+    // receive a contribution from this bucket are streamed: a pixel whose last contributor lies in front of the bucket's first survivor
+    // (n_contrib <= its list index) is valid for none of the bucket's Gaussians.  The stream keeps the pixel order, so the sums of the
+    // step loop add the same terms in the same order: bit-identical to streaming all 64, in (alive pixels + 15) steps instead of 79.
     float wT = 1.f, wRem = 0.f, wpx = 0.f, wpy = 0.f, wg0 = 0.f, wg1 = 0.f, wg2 = 0.f, wgd = 0.f, wga = 0.f;
     uint32_t wlast = 0;
-    if (lane < NPIX) {
-        const int p = lane + (int)half * NPIX;
-        const int px = (int)tx * 16 + (int)(q & 1u) * 8 + (p & 7);
-        const int py = (int)ty * 16 + (int)(q >> 1) * 8 + (p >> 3);
-        const bool inside = px < W && py < H;
-        const size_t hw = (size_t)H * W;
-        const size_t pix = (size_t)py * W + px;
-        const size_t vb = (size_t)view * hw;
+    const uint32_t gidx0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)gidx);        // list index of the bucket's first survivor (count >= 1)
+    const int p = lane + (int)half * NPIX;
+    const int px = (int)tx * 16 + (int)(q & 1u) * 8 + (p & 7);
+    const int py = (int)ty * 16 + (int)(q >> 1) * 8 + (p >> 3);
+    const bool inside = lane < NPIX && px < W && py < H;
+    const size_t hw = (size_t)H * W;
+    const size_t pix = (size_t)py * W + px;
+    const size_t vb = (size_t)view * hw;
+    uint32_t last = 0;
+    if (inside) last = n_contrib[vb + pix];
+    const bool alive = last > gidx0;
+    const uint64_t alive_mask = __ballot(alive);
+    const int n_alive = (int)__popcll(alive_mask);
+    const int pos = (int)__popcll(alive_mask & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))));       // this pixel's place in the stream
+    if (alive) {
         float g0 = 0.f, g1 = 0.f, g2 = 0.f, gd = 0.f, ga = 0.f, O = 0.f;
-        uint32_t last = 0;
-        if (inside) {
-            last = n_contrib[vb + pix];
+        {
             const float gs = gscale ? *gscale : 1.f;          // optional device scalar on dL/dcolor
             g0 = gs * gC[vb * 3 + pix]; g1 = gs * gC[vb * 3 + hw + pix]; g2 = gs * gC[vb * 3 + 2 * hw + pix];
             // O = out . g: everything the pixel composited (incl. the T_final*bg term), dotted with the upstream gradient
@@ -765,22 +773,22 @@ __global__ __launch_bounds__(kBlock) void render_bwd_bucket_kernel(int W, int H,
                 O += out_depth[vb + pix] * gd + out_alpha[vb + pix] * ga;
             }
         }
-        sPixA[wv][lane] = make_float4((float)px, (float)py, __uint_as_float(last), g0);
-        sPixB[wv][lane] = make_float4(g1, g2, gd, ga);
+        sPixA[wv][pos] = make_float4((float)px, (float)py, __uint_as_float(last), g0);
+        sPixB[wv][pos] = make_float4(g1, g2, gd, ga);
         float T0 = 1.f, Pre0 = 0.f;
-        if (inside && start) {
+        if (start) {
             const float4 tc = aux.ckpt_tc[ROWS ? slot * 256 + p : slot * 64 + p];
             T0 = tc.x;
             Pre0 = tc.y * g0 + tc.z * g1 + tc.w * g2;
             if (HAS_DA) { const float2 da = aux.ckpt_da[ROWS ? slot * 256 + p : slot * 64 + p]; Pre0 += da.x * gd + da.y * ga; }
         }
-        sDyn[wv][0][lane] = make_float2(T0, O - Pre0);
+        sDyn[wv][0][pos] = make_float2(T0, O - Pre0);
         if constexpr (ROWS) {
             float PreSeg = Pre0;                               // composited-so-far at the start of the forward segment the row is in
 #pragma unroll
             for (int r = 1; r < 4; r++) {
                 float Tr = 1.f, Prer = Pre0;
-                if (inside && (uint32_t)(16 * r) < count) {
+                if ((uint32_t)(16 * r) < count) {
                     const float4 tc = aux.ckpt_tc[(slot * 4 + r) * 64 + p];
                     Tr = tc.x;
                     float dotv = tc.y * g0 + tc.z * g1 + tc.w * g2;
@@ -788,7 +796,7 @@ __global__ __launch_bounds__(kBlock) void render_bwd_bucket_kernel(int W, int H,
                     if (((uint32_t)r & (rps - 1u)) == 0u) PreSeg = dotv;      // rps is 1, 2 or 4
                     Prer = (((uint32_t)r & (rps - 1u)) == 0u) ? dotv : PreSeg + dotv;
                 }
-                sDyn[wv][r][lane] = make_float2(Tr, O - Prer);
+                sDyn[wv][r][pos] = make_float2(Tr, O - Prer);
             }
         }
         wT = T0; wRem = O - Pre0; wpx = (float)px; wpy = (float)py; wlast = last; wg0 = g0; wg1 = g1; wg2 = g2; wgd = gd; wga = ga;
@@ -818,7 +826,7 @@ __global__ __launch_bounds__(kBlock) void render_bwd_bucket_kernel(int W, int H,
                 }
 #undef SGR_BCAST
             }
-            if (lane < NPIX) sDyn[wv][r][lane] = make_float2(wT, wRem);
+            if (alive) sDyn[wv][r][pos] = make_float2(wT, wRem);
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -831,16 +839,16 @@ __global__ __launch_bounds__(kBlock) void render_bwd_bucket_kernel(int W, int H,
     PixState A = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 1.f, 0.f}, B = A;
     // per-Gaussian moment accumulators of v = G * dL/dalpha over the pixels (constant factors applied once at the end)
     float S1 = 0.f, Sx = 0.f, Sy = 0.f, Sxx = 0.f, Sxy = 0.f, Syy = 0.f, aD = 0.f, a7 = 0.f, a8 = 0.f, a9 = 0.f;
-    const int nsteps = NPIX + (int)min(count, 16u) - 1;
+    const int nsteps = n_alive ? n_alive + (int)min(count, 16u) - 1 : 0;
     const float4 *pa = &sPixA[wv][0], *pb = &sPixB[wv][0];
     const float2 *pd = &sDyn[wv][row][0];
 #define SGR_BWD_STEP(IN, OUT, S)                                                                                        \
     {                                                                                                                   \
-        const int sp = min((S), NPIX - 1);                                                                              \
+        const int sp = min((S), n_alive - 1);                                                                           \
         float4 fa = pa[sp];                                                                                             \
         const float4 fb = pb[sp];                                                                                       \
         const float2 fd = pd[sp];                                                                                       \
-        if ((S) >= NPIX) fa.z = 0.f; /* drain: n_contrib = 0 -> never valid */                                         \
+        if ((S) >= n_alive) fa.z = 0.f; /* drain: n_contrib = 0 -> never valid */                                      \
         OUT.px = row_shift_in(IN.px, fa.x); OUT.py = row_shift_in(IN.py, fa.y); OUT.last = row_shift_in(IN.last, fa.z); \
         OUT.g0 = row_shift_in(IN.g0, fa.w); OUT.g1 = row_shift_in(IN.g1, fb.x); OUT.g2 = row_shift_in(IN.g2, fb.y);     \
         if (HAS_DA) { OUT.gd = row_shift_in(IN.gd, fb.z); OUT.ga = row_shift_in(IN.ga, fb.w); }                         \
