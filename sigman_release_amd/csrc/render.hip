@@ -893,7 +893,11 @@ __global__ __launch_bounds__(kBlock) void render_bwd_bucket_kernel(int W, int H,
         const float *c = &sComb[sub][0][lane];
         S1 += c[0]; Sx += c[64]; Sy += c[128]; Sxx += c[192]; Sxy += c[256]; Syy += c[320]; aD += c[384]; a7 += c[448]; a8 += c[512]; a9 += c[576];
     }
-    if (has_g) {
+    // a Gaussian that was valid for no pixel of the quadrant (all sums exactly zero) leaves no record: its flag stays clear and the gather
+    // skips it -- adding its zeros would change nothing
+    const bool nonzero = (S1 != 0.f) | (Sx != 0.f) | (Sy != 0.f) | (Sxx != 0.f) | (Sxy != 0.f) | (Syy != 0.f) | (aD != 0.f) | (a7 != 0.f) |
+                         (a8 != 0.f) | (a9 != 0.f);
+    if (has_g && nonzero) {
         // one NON-atomic 40-byte partial record per (tile instance, quadrant); preprocess_bwd gathers them in a fixed order
         const uint32_t off = rd.w, rmin = rd.x, rmax = rd.y;
         const uint32_t inst = off + (ty - (rmin >> 16)) * ((rmax & 0xFFFFu) - (rmin & 0xFFFFu)) + (tx - (rmin & 0xFFFFu));
