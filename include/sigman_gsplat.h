@@ -198,8 +198,9 @@ int sgr_bin(const SgrProblem *pb, const int32_t *radii, uint32_t *rect /* [3] of
 /* number of bucket slots per quadrant for the auxiliary forward outputs: (R >> 6) + tiles_total + 1 */
 uint64_t sgr_bucket_slots(uint64_t R, uint64_t tiles_total);
 
-/* forward compositing kernel choice: 0 = automatic (segment-parallel for launches of <= 2048 tiles, serial per-tile
- * otherwise), 1 = serial, 2 = segment-parallel.  Both produce the same outputs. */
+/* forward compositing kernel choice: 0 = automatic (segment-parallel for launches of <= 2048 tiles, one wave per (tile, quadrant)
+ * otherwise), 1 = serial per tile (one workgroup per tile), 2 = segment-parallel, 3 = one wave per (tile, quadrant).  All produce the same
+ * outputs. */
 int sgr_set_forward_mode(int mode);
 
 /* B2 + B3 kernel choice: 0 = automatic (default: on the colors_precomp path with views_per_subject in {2, 4, .., 256} one thread per

@@ -44,6 +44,13 @@ __device__ __forceinline__ uint32_t cull_mask(const float4 &a, const float4 &c, 
     return (uint32_t)(xl && yt) | ((uint32_t)(xr && yt) << 1) | ((uint32_t)(xl && yb) << 2) | ((uint32_t)(xr && yb) << 3);
 }
 
+// the same test for ONE quadrant whose first pixel is (qx0, qy0)
+__device__ __forceinline__ bool cull_quadrant(const float4 &a, const float4 &c, float qx0, float qy0) {
+    const float hx = c.z, hy = c.w;
+    if (hx < 0.f) return false;
+    return (a.x + hx >= qx0) && (a.x - hx <= qx0 + 7.f) && (a.y + hy >= qy0) && (a.y - hy <= qy0 + 7.f);
+}
+
 // auxiliary forward outputs that feed the bucket-parallel backward (all optional; see sgr_render_forward)
 struct FwdAux {
     uint2 *compact;       // [4][R]  per (tile, quadrant) culled list in order: (record id, 0-based index in the tile list)
@@ -209,6 +216,162 @@ __global__ __launch_bounds__(kBlock) void render_fwd_kernel(int W, int H, int Tx
 }
 
 // -------------------------------------------------------------------------------------------------
+// F6, one WAVE per (tile, quadrant) -- the default for launches that fill the chip (batches of views).  The per-tile kernel above stages
+// 256 entries per workgroup barrier and keeps all four quadrant waves until the last one is done; here every quadrant is its own
+// 64-thread workgroup: it walks the tile list in batches of 64 entries (lane j stages entry j: record prefetched one batch ahead, ids
+// two ahead), culls them for its own 8x8 pixels with one ballot, and composites the survivors with the same arithmetic -- no workgroup
+// barrier anywhere, a quadrant whose pixels have all stopped ends at once and frees its SIMD slot.  The four waves of a tile re-read the
+// tile's records (L2 hits: workgroups b, b+8, b+16, b+24 are the four quadrants of one tile and run on the same XCD).
+// Outputs, auxiliary outputs and bucket layout are identical to render_fwd_kernel's.
+// -------------------------------------------------------------------------------------------------
+constexpr int kWaveBatch = 64;
+template <int AUX>
+__global__ __launch_bounds__(64) void render_fwd_wave_kernel(int W, int H, int Tx, uint32_t tiles_per_view, uint32_t tiles_total,
+                                                             const uint2 *__restrict__ ranges,
+                                                             const uint32_t *__restrict__ point_list,
+                                                             const float4 *__restrict__ rec, const float *__restrict__ bg,
+                                                             float *__restrict__ out_color, float *__restrict__ out_depth,
+                                                             float *__restrict__ out_alpha, float *__restrict__ final_T,
+                                                             uint32_t *__restrict__ n_contrib, FwdAux aux) {
+    __shared__ float4 sA[kWaveBatch + 1], sB[kWaveBatch + 1], sC[kWaveBatch + 1];   // entry 64 = null Gaussian (opacity 0)
+    __shared__ uint32_t sId[kWaveBatch];
+    __shared__ __attribute__((aligned(8))) uint16_t sList[kWaveBatch + 8];
+    const uint32_t logical = (blockIdx.x >> 5) * 8u + (blockIdx.x & 7u), q = (blockIdx.x >> 3) & 3u;
+    if (logical >= tiles_total) return;
+    const uint32_t bid = sgr_xcd_remap(logical, tiles_total);
+    const uint32_t view = bid / tiles_per_view, tile = bid - view * tiles_per_view;
+    const uint32_t tx = tile % Tx, ty = tile / Tx;
+    const uint2 range = ranges[bid];
+    const int lane = threadIdx.x;
+    const int px = (int)tx * 16 + (int)(q & 1u) * 8 + (lane & 7);
+    const int py = (int)ty * 16 + (int)(q >> 1) * 8 + (lane >> 3);
+    const bool inside = px < W && py < H;
+    const float pxf = (float)px, pyf = (float)py;
+    const float qx0 = (float)(tx * 16 + (q & 1u) * 8), qy0 = (float)(ty * 16 + (q >> 1) * 8);
+    const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    bool done = !inside;
+    float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f, D = 0.f, A = 0.f;
+    float B0 = 0.f, B1 = 0.f, B2 = 0.f, BD = 0.f, BA = 0.f;   // AUX = 2: composited sums at the start of the current 64-survivor bucket
+    uint32_t last = 0, lastk = 0;
+    uint32_t kbase = 0;                                  // survivors of this quadrant in earlier batches
+    const int n = (int)(range.y - range.x);
+    const size_t slot0 = (size_t)q * aux.NS + (range.x >> 6) + (size_t)bid;            // first bucket slot of (tile, quadrant)
+    if (lane == 0) { sA[kWaveBatch] = make_float4(0.f, 0.f, 0.f, 0.f); sB[kWaveBatch] = sA[kWaveBatch]; sC[kWaveBatch] = sA[kWaveBatch]; }
+    // software pipeline: (ra, rb, rc, rid) = this lane's entry of the CURRENT batch, id_nx = its entry id of the next batch
+    float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra, rc = make_float4(0.f, 0.f, -1.f, -1.f);
+    uint32_t rid = 0, id_nx = 0;
+    if (lane < n) { rid = point_list[range.x + lane]; ra = rec[(size_t)rid * 4 + 0]; rb = rec[(size_t)rid * 4 + 1]; rc = rec[(size_t)rid * 4 + 2]; }
+    if (lane + kWaveBatch < n) id_nx = point_list[range.x + lane + kWaveBatch];
+    for (int base = 0; base < n; base += kWaveBatch) {
+        if (!__ballot(!done)) break;
+        // ---- stage the current batch (conic pre-scaled into the exp2 domain: exp(power) = exp2(kxx dx^2 + kyy dy^2 + kxy dx dy)) and
+        // cull it for this quadrant
+        const bool have = base + lane < n;
+        bool bit = false;
+        if (have) {
+            sA[lane] = make_float4(ra.x, ra.y, kHalfLog2e * ra.z, kLog2e * ra.w);
+            sB[lane] = make_float4(kHalfLog2e * rb.x, rb.y, rb.z, rb.w);
+            sC[lane] = rc;
+            sId[lane] = rid;
+            bit = cull_quadrant(ra, rc, qx0, qy0);
+        }
+        // ---- next batch: records now, ids of the batch after it
+        {
+            const int nx = base + kWaveBatch + lane;
+            rid = id_nx;
+            rc = make_float4(0.f, 0.f, -1.f, -1.f);
+            if (nx < n) { ra = rec[(size_t)rid * 4 + 0]; rb = rec[(size_t)rid * 4 + 1]; rc = rec[(size_t)rid * 4 + 2]; }
+            if (nx + kWaveBatch < n) id_nx = point_list[range.x + nx + kWaveBatch];
+        }
+        const uint64_t bal = __ballot(bit);
+        const uint32_t cnt = (uint32_t)__popcll(bal);
+        if (bit) sList[(uint32_t)__popcll(bal & lt_mask)] = (uint16_t)lane;
+        if (lane < 4) sList[cnt + lane] = (uint16_t)kWaveBatch;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (AUX) {
+            uint2 *dst = aux.compact + (size_t)q * aux.R + range.x + kbase;
+            if ((uint32_t)lane < cnt) { const uint32_t j = sList[lane]; dst[lane] = make_uint2(sId[j], (uint32_t)base + j); }
+        }
+        uint64_t active = __ballot(!done);
+        for (uint32_t g = 0; g < cnt && active; g += SGR_FWD_G) {
+            int js[SGR_FWD_G];
+#pragma unroll
+            for (int u = 0; u < SGR_FWD_G; u++) js[u] = sList[g + u];
+            float4 a[SGR_FWD_G], b[SGR_FWD_G], c[SGR_FWD_G];
+            float al[SGR_FWD_G];
+            bool valid[SGR_FWD_G];
+#pragma unroll
+            for (int u = 0; u < SGR_FWD_G; u++) { a[u] = sA[js[u]]; b[u] = sB[js[u]]; c[u] = sC[js[u]]; }
+#pragma unroll
+            for (int u = 0; u < SGR_FWD_G; u++) {
+                const float dx = a[u].x - pxf, dy = a[u].y - pyf;
+                const float power = (a[u].z * dx) * dx + ((b[u].x * dy) * dy + (a[u].w * dx) * dy);
+                const float alpha = fminf(0.99f, b[u].y * __builtin_amdgcn_exp2f(power));
+                valid[u] = (power <= 0.f) & (alpha >= (1.0f / 255.0f));
+                al[u] = valid[u] ? alpha : 0.f;
+            }
+            // sequential part, branch-free: the only loop-carried chain is T -> test_T -> (stop) -> T
+#pragma unroll
+            for (int u = 0; u < SGR_FWD_G; u++) {
+                const uint32_t ord = kbase + g + u;                       // ordinal of this survivor in the quadrant list
+                if constexpr (AUX == 2) {
+                    if ((ord & 15u) == 0u && ord != 0u && g + u < cnt) {
+                        const uint32_t row = (ord >> 4) & 3u;
+                        const size_t s = ((slot0 + (ord >> 6)) * 4 + row) * 64 + lane;
+                        if (row == 0u) { B0 = C0; B1 = C1; B2 = C2; BD = D; BA = A; }       // bucket start: absolute state
+                        aux.ckpt_tc[s] = row ? make_float4(T, C0 - B0, C1 - B1, C2 - B2) : make_float4(T, C0, C1, C2);
+                        aux.ckpt_da[s] = row ? make_float2(D - BD, A - BA) : make_float2(D, A);
+                    }
+                } else if constexpr (AUX == 1) {
+                    if ((ord & 63u) == 0u && ord != 0u && g + u < cnt) {                    // bucket start: absolute state
+                        const size_t s = (slot0 + (ord >> 6)) * 64 + lane;
+                        aux.ckpt_tc[s] = make_float4(T, C0, C1, C2);
+                        aux.ckpt_da[s] = make_float2(D, A);
+                    }
+                }
+                const float test_T = T * (1.f - al[u]);
+                done = done | (valid[u] & (test_T < 0.0001f));            // the crossing Gaussian is NOT composited
+                const bool contrib = valid[u] & !done;
+                const float w = contrib ? al[u] * T : 0.f;
+                C0 = fmaf(b[u].w, w, C0); C1 = fmaf(c[u].x, w, C1); C2 = fmaf(c[u].y, w, C2);
+                D = fmaf(b[u].z, w, D);
+                A += w;
+                T = contrib ? test_T : T;
+                last = contrib ? (uint32_t)(base + js[u] + 1) : last;
+                if (AUX) lastk = contrib ? ord + 1 : lastk;
+            }
+            active = __ballot(!done);
+        }
+        kbase += cnt;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");              // the next batch overwrites the staging arrays
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    if (inside) {
+        const size_t hw = (size_t)H * W;
+        const size_t pix = (size_t)py * W + px;
+        const size_t vb = (size_t)view * hw;
+        final_T[vb + pix] = T;
+        n_contrib[vb + pix] = last;
+        out_color[(vb * 3) + pix] = C0 + T * bg[0];
+        out_color[(vb * 3) + hw + pix] = C1 + T * bg[1];
+        out_color[(vb * 3) + 2 * hw + pix] = C2 + T * bg[2];
+        out_depth[vb + pix] = D;
+        out_alpha[vb + pix] = A;
+    }
+    if (AUX) {
+        uint32_t kmax = lastk;                                 // survivors up to the last one that blended anywhere in the quadrant
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, off, 64));
+        const uint32_t nb = (kmax + 63u) >> 6;
+        for (uint32_t bk = lane; bk < nb; bk += 64)
+            aux.desc[slot0 + bk] = make_uint2(bid | (3u << 30), (bk << 13) | min(64u, kmax - (bk << 6)));   // rps = 4: rows 1-3 relative to row 0
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
 // F6, segment-parallel variant for launches that cannot fill the chip (one 512^2 humanoid view has ~200 occupied
 // tiles for 256 CUs, and the serial walk of the longest tile list -- ~2900 entries at C2 -- is the whole critical path).
 // One workgroup = one (tile, quadrant), 8 waves.  The tile list is streamed in 512-entry sub-chunks (software
@@ -227,11 +390,6 @@ __global__ __launch_bounds__(kBlock) void render_fwd_kernel(int W, int H, int Tx
 constexpr int kSegThreads = 512, kSegWaves = 8, kSegRing = 1024, kSegPer = 64;
 typedef float v2f __attribute__((ext_vector_type(2)));      // <2 x float>: the backend selects v_pk_{add,mul,fma}_f32 for it
 
-__device__ __forceinline__ bool cull_quadrant(const float4 &a, const float4 &c, float qx0, float qy0) {
-    const float hx = c.z, hy = c.w;
-    if (hx < 0.f) return false;
-    return (a.x + hx >= qx0) && (a.x - hx <= qx0 + 7.f) && (a.y + hy >= qy0) && (a.y - hy <= qy0 + 7.f);
-}
 
 template <int AUX>
 __global__ __launch_bounds__(kSegThreads, 4) void render_fwd_seg_kernel(int W, int H, int Tx, uint32_t tiles_per_view,
@@ -917,7 +1075,8 @@ __global__ __launch_bounds__(kBlock) void render_bwd_bucket_kernel(int W, int H,
 
 int sgr_validate_problem(const SgrProblem *pb);
 
-// 0 = automatic, 1 = serial per-tile kernel, 2 = segment-parallel kernel (dev/test override: sgr_set_forward_mode)
+// 0 = automatic (segment-parallel for <= 2048 tiles, else one wave per quadrant), 1 = serial per-tile kernel (round 1), 2 = segment-parallel
+// kernel, 3 = one wave per (tile, quadrant) (dev/test override: sgr_set_forward_mode)
 static int sgr_fwd_mode = 0;
 extern "C" int sgr_set_forward_mode(int mode) { sgr_fwd_mode = mode; return 0; }
 int sgr_get_forward_mode() { return sgr_fwd_mode; }
@@ -987,6 +1146,19 @@ int sgr_render_forward_ex(const SgrProblem *pb, const uint32_t *ranges, const ui
         else SGR_LAUNCH_SEG(1);
 #undef SGR_LAUNCH_SEG
         SGR_CHECK_LAUNCH("render_fwd_seg_kernel");
+        return 0;
+    }
+    if (sgr_fwd_mode != 1) {
+        const uint32_t wgrid = (uint32_t)((tiles_total + 7) / 8) * 32u;          // 8 tiles x 4 quadrants per group of 32 ids
+#define SGR_LAUNCH_WAVE(A)                                                                                                  \
+        hipLaunchKernelGGL(render_fwd_wave_kernel<A>, dim3(wgrid), dim3(64), 0, stream, pb->W, pb->H, Tx, tiles, (uint32_t)tiles_total,   \
+                           (const uint2 *)ranges, point_list, (const float4 *)rec, pb->bg, out_color, out_depth, out_alpha, final_T,  \
+                           n_contrib, aux)
+        if (!use_aux) SGR_LAUNCH_WAVE(0);
+        else if (aux_layout == 2) SGR_LAUNCH_WAVE(2);
+        else SGR_LAUNCH_WAVE(1);
+#undef SGR_LAUNCH_WAVE
+        SGR_CHECK_LAUNCH("render_fwd_wave_kernel");
         return 0;
     }
 #define SGR_LAUNCH_FWD(A)                                                                                                   \

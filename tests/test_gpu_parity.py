@@ -23,9 +23,9 @@ def _dev():
     return torch.device("cuda:0")
 
 
-@pytest.fixture(params=[1, 2], ids=["fwd_serial", "fwd_segment_parallel"])
+@pytest.fixture(params=[1, 2, 3], ids=["fwd_serial", "fwd_segment_parallel", "fwd_wave_per_quadrant"])
 def fwd_mode(request):
-    """Run the test once per forward compositing kernel (serial per-tile / segment-parallel); both must match the oracle."""
+    """Run the test once per forward compositing kernel (serial per-tile / segment-parallel / one wave per quadrant); all must match the oracle."""
     from sigman_release_amd import _cabi
     _cabi.lib().sgr_set_forward_mode(request.param)
     yield request.param
