@@ -234,8 +234,7 @@ __global__ __launch_bounds__(64) void render_fwd_wave_kernel(int W, int H, int T
                                                              float *__restrict__ out_alpha, float *__restrict__ final_T,
                                                              uint32_t *__restrict__ n_contrib, FwdAux aux) {
     __shared__ float4 sA[kWaveBatch + 1], sB[kWaveBatch + 1], sC[kWaveBatch + 1];   // entry 64 = null Gaussian (opacity 0)
-    __shared__ uint32_t sId[kWaveBatch];
-    __shared__ __attribute__((aligned(8))) uint16_t sList[kWaveBatch + 8];
+    __shared__ uint16_t sJ[kWaveBatch];                                             // batch-local entry index of survivor g
     const uint32_t logical = (blockIdx.x >> 5) * 8u + (blockIdx.x & 7u), q = (blockIdx.x >> 3) & 3u;
     if (logical >= tiles_total) return;
     const uint32_t bid = sgr_xcd_remap(logical, tiles_total);
@@ -256,7 +255,6 @@ __global__ __launch_bounds__(64) void render_fwd_wave_kernel(int W, int H, int T
     uint32_t kbase = 0;                                  // survivors of this quadrant in earlier batches
     const int n = (int)(range.y - range.x);
     const size_t slot0 = (size_t)q * aux.NS + (range.x >> 6) + (size_t)bid;            // first bucket slot of (tile, quadrant)
-    if (lane == 0) { sA[kWaveBatch] = make_float4(0.f, 0.f, 0.f, 0.f); sB[kWaveBatch] = sA[kWaveBatch]; sC[kWaveBatch] = sA[kWaveBatch]; }
     // software pipeline: (ra, rb, rc, rid) = this lane's entry of the CURRENT batch, id_nx = its entry id of the next batch
     float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra, rc = make_float4(0.f, 0.f, -1.f, -1.f);
     uint32_t rid = 0, id_nx = 0;
@@ -266,15 +264,19 @@ __global__ __launch_bounds__(64) void render_fwd_wave_kernel(int W, int H, int T
         if (!__ballot(!done)) break;
         // ---- stage the current batch (conic pre-scaled into the exp2 domain: exp(power) = exp2(kxx dx^2 + kyy dy^2 + kxy dx dy)) and
         // cull it for this quadrant
-        const bool have = base + lane < n;
-        bool bit = false;
-        if (have) {
-            sA[lane] = make_float4(ra.x, ra.y, kHalfLog2e * ra.z, kLog2e * ra.w);
-            sB[lane] = make_float4(kHalfLog2e * rb.x, rb.y, rb.z, rb.w);
-            sC[lane] = rc;
-            sId[lane] = rid;
-            bit = cull_quadrant(ra, rc, qx0, qy0);
+        // -- only the survivors go to LDS, compacted: survivor g of the batch sits at index g (no index list to read back)
+        const bool bit = (base + lane < n) && cull_quadrant(ra, rc, qx0, qy0);
+        const uint64_t bal = __ballot(bit);
+        const uint32_t cnt = (uint32_t)__popcll(bal);
+        const uint32_t pos = (uint32_t)__popcll(bal & lt_mask);
+        if (bit) {
+            sA[pos] = make_float4(ra.x, ra.y, kHalfLog2e * ra.z, kLog2e * ra.w);
+            sB[pos] = make_float4(kHalfLog2e * rb.x, rb.y, rb.z, rb.w);
+            sC[pos] = rc;
+            sJ[pos] = (uint16_t)lane;
+            if (AUX) aux.compact[(size_t)q * aux.R + range.x + kbase + pos] = make_uint2(rid, (uint32_t)(base + lane));
         }
+        if (lane == 0) { sA[cnt] = make_float4(0.f, 0.f, 0.f, 0.f); sB[cnt] = sA[cnt]; sC[cnt] = sA[cnt]; }      // null Gaussian behind an odd count
         // ---- next batch: records now, ids of the batch after it
         {
             const int nx = base + kWaveBatch + lane;
@@ -283,27 +285,17 @@ __global__ __launch_bounds__(64) void render_fwd_wave_kernel(int W, int H, int T
             if (nx < n) { ra = rec[(size_t)rid * 4 + 0]; rb = rec[(size_t)rid * 4 + 1]; rc = rec[(size_t)rid * 4 + 2]; }
             if (nx + kWaveBatch < n) id_nx = point_list[range.x + nx + kWaveBatch];
         }
-        const uint64_t bal = __ballot(bit);
-        const uint32_t cnt = (uint32_t)__popcll(bal);
-        if (bit) sList[(uint32_t)__popcll(bal & lt_mask)] = (uint16_t)lane;
-        if (lane < 4) sList[cnt + lane] = (uint16_t)kWaveBatch;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (AUX) {
-            uint2 *dst = aux.compact + (size_t)q * aux.R + range.x + kbase;
-            if ((uint32_t)lane < cnt) { const uint32_t j = sList[lane]; dst[lane] = make_uint2(sId[j], (uint32_t)base + j); }
-        }
+        uint32_t lastg = 0xFFFFFFFFu;                                   // survivor of this batch that contributed last to my pixel
         uint64_t active = __ballot(!done);
         for (uint32_t g = 0; g < cnt && active; g += SGR_FWD_G) {
-            int js[SGR_FWD_G];
-#pragma unroll
-            for (int u = 0; u < SGR_FWD_G; u++) js[u] = sList[g + u];
             float4 a[SGR_FWD_G], b[SGR_FWD_G], c[SGR_FWD_G];
             float al[SGR_FWD_G];
             bool valid[SGR_FWD_G];
 #pragma unroll
-            for (int u = 0; u < SGR_FWD_G; u++) { a[u] = sA[js[u]]; b[u] = sB[js[u]]; c[u] = sC[js[u]]; }
+            for (int u = 0; u < SGR_FWD_G; u++) { a[u] = sA[g + u]; b[u] = sB[g + u]; c[u] = sC[g + u]; }
 #pragma unroll
             for (int u = 0; u < SGR_FWD_G; u++) {
                 const float dx = a[u].x - pxf, dy = a[u].y - pyf;
@@ -339,11 +331,12 @@ __global__ __launch_bounds__(64) void render_fwd_wave_kernel(int W, int H, int T
                 D = fmaf(b[u].z, w, D);
                 A += w;
                 T = contrib ? test_T : T;
-                last = contrib ? (uint32_t)(base + js[u] + 1) : last;
+                lastg = contrib ? g + u : lastg;
                 if (AUX) lastk = contrib ? ord + 1 : lastk;
             }
             active = __ballot(!done);
         }
+        if (lastg != 0xFFFFFFFFu) last = (uint32_t)base + sJ[lastg] + 1u;
         kbase += cnt;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");              // the next batch overwrites the staging arrays
         __builtin_amdgcn_wave_barrier();
