@@ -839,7 +839,7 @@ __device__ __forceinline__ float row_shift_in(float v, float feed) {
 // steps instead of 79) -- 19 % more wave-steps but twice the waves, which is what a 4 000-bucket launch on 1 024 SIMDs lacks; the
 // second wave's per-Gaussian sums are added to the first's through LDS before the single partial record is written.
 template <bool HAS_DA, bool SPLIT, bool ROWS>
-__global__ __launch_bounds__(SPLIT ? kBlock : 64) void render_bwd_bucket_kernel(int W, int H, int Tx, uint32_t tiles_per_view,
+__global__ __launch_bounds__(SPLIT ? 128 : 64) void render_bwd_bucket_kernel(int W, int H, int Tx, uint32_t tiles_per_view,
                                                                    const uint2 *__restrict__ ranges,
                                                                    const float4 *__restrict__ rec,
                                                                    const uint4 *__restrict__ rect,
@@ -853,7 +853,7 @@ __global__ __launch_bounds__(SPLIT ? kBlock : 64) void render_bwd_bucket_kernel(
     // !SPLIT (batches of views): ONE wave = one bucket per workgroup.  Most bucket slots of a launch are unused (the slot count is an upper
     // bound from the list lengths: 78 % empty at C3); with four buckets per workgroup a workgroup usually held one real wave and 16 KB of
     // LDS until it was done, which capped a CU at ~10 working waves.
-    constexpr int NWV = SPLIT ? 4 : 1;        // waves per workgroup
+    constexpr int NWV = SPLIT ? 2 : 1;        // waves per workgroup (SPLIT: the two halves of one bucket)
     __shared__ float4 sPixA[NWV][64];         // per wave: (x, y, n_contrib bits, g0) of pixel p
     __shared__ float4 sPixB[NWV][64];         //           (g1, g2, gD, gA)
     __shared__ float2 sDyn[NWV][4][64];       // per wave, per row: (T, Rem) of pixel p at the start of the row
@@ -863,8 +863,8 @@ __global__ __launch_bounds__(SPLIT ? kBlock : 64) void render_bwd_bucket_kernel(
     const uint32_t qb = (blockIdx.x >> 3) & 3u, idx = (blockIdx.x >> 5) * 8u + (blockIdx.x & 7u);
     constexpr int NPIX = SPLIT ? 32 : 64;                      // pixels streamed by one wave
     const uint32_t half = SPLIT ? (uint32_t)(wv & 1) : 0u;     // which half of the quadrant's pixels
-    const uint32_t sub = SPLIT ? (uint32_t)(wv >> 1) : (uint32_t)wv;          // bucket of this workgroup (2 or 4 per workgroup)
-    constexpr uint32_t BPW = SPLIT ? 2u : 1u;
+    const uint32_t sub = 0u;                                                  // (one bucket per workgroup)
+    constexpr uint32_t BPW = 1u;
     if ((size_t)idx * BPW + sub >= (size_t)aux.NS) return;
     const size_t slot = (size_t)qb * aux.NS + (size_t)idx * BPW + sub;
     const uint2 desc_v = aux.desc[slot];
@@ -1038,7 +1038,7 @@ __global__ __launch_bounds__(SPLIT ? kBlock : 64) void render_bwd_bucket_kernel(
 #undef SGR_BWD_STEP
     if (SPLIT) {
         // the odd wave hands its sums to the even wave of the same bucket
-        __shared__ float sComb[2][10][64];
+        __shared__ float sComb[1][10][64];
         if (half == 1u) {
             float *c = &sComb[sub][0][lane];
             c[0] = S1; c[64] = Sx; c[128] = Sy; c[192] = Sxx; c[256] = Sxy; c[320] = Syy; c[384] = aD; c[448] = a7; c[512] = a8; c[576] = a9;
@@ -1202,10 +1202,10 @@ int sgr_render_backward_ex(const SgrProblem *pb, const uint32_t *ranges, const u
                               (uint64_t)tiles * pb->n_views);
         // few buckets (one or two views): two waves per bucket (SPLIT) to give the SIMDs enough waves to hide latencies
         const bool split = (uint64_t)tiles * pb->n_views <= 2048;
-        const uint32_t bpw = split ? 2u : 1u;                            // buckets per workgroup (kernel: BPW)
+        const uint32_t bpw = 1u;                                         // buckets per workgroup (kernel: BPW)
         const uint32_t nblocks = ((aux.NS + bpw - 1u) / bpw + 7u) / 8u * 32u;      // per quadrant ceil(NS / bpw) workgroups, in groups of 8 x 4 quadrants
 #define SGR_LAUNCH_BWD(DA, SP, RW)                                                                                          \
-        hipLaunchKernelGGL((render_bwd_bucket_kernel<DA, SP, RW>), dim3(nblocks), dim3(SP ? kBlock : 64), 0, stream, pb->W, pb->H, Tx, tiles, \
+        hipLaunchKernelGGL((render_bwd_bucket_kernel<DA, SP, RW>), dim3(nblocks), dim3(SP ? 128 : 64), 0, stream, pb->W, pb->H, Tx, tiles, \
                            (const uint2 *)ranges, (const float4 *)rec, (const uint4 *)rect, n_contrib, out_color, out_depth, out_alpha, grad_color, \
                            grad_depth, grad_alpha, grad_color_scale, aux, (float4 *)part, (uint8_t *)flags)
         const bool da = grad_depth || grad_alpha, rows = aux_layout == 2;
