@@ -854,8 +854,8 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64) void render_bwd_bucket_kernel(int
     // bound from the list lengths: 78 % empty at C3); with four buckets per workgroup a workgroup usually held one real wave and 16 KB of
     // LDS until it was done, which capped a CU at ~10 working waves.
     constexpr int NWV = SPLIT ? 2 : 1;        // waves per workgroup (SPLIT: the two halves of one bucket)
-    __shared__ float4 sPixA[NWV][64];         // per wave: (x, y, n_contrib bits, g0) of pixel p
-    __shared__ float4 sPixB[NWV][64];         //           (g1, g2, gD, gA)
+    __shared__ float4 sPixA[NWV][96];         // per wave: (x, y, n_contrib bits, g0) of stream entry i at [16 + i] (16 unread-but-addressable
+    __shared__ float4 sPixB[NWV][96];         //           (g1, g2, gD, gA)                  slots on either side: lanes look 15 entries back and ahead)
     __shared__ float2 sDyn[NWV][4][64];       // per wave, per row: (T, Rem) of pixel p at the start of the row
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     // XCD placement as in the forward: workgroup ids b, b+8, b+16, b+24 (same XCD) take the same stretch of bucket slots in the four
@@ -928,8 +928,8 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64) void render_bwd_bucket_kernel(int
                 O += out_depth[vb + pix] * gd + out_alpha[vb + pix] * ga;
             }
         }
-        sPixA[wv][pos] = make_float4((float)px, (float)py, __uint_as_float(last), g0);
-        sPixB[wv][pos] = make_float4(g1, g2, gd, ga);
+        sPixA[wv][16 + pos] = make_float4((float)px, (float)py, __uint_as_float(last), g0);
+        sPixB[wv][16 + pos] = make_float4(g1, g2, gd, ga);
         float T0 = 1.f, Pre0 = 0.f;
         if (start) {
             const float4 tc = aux.ckpt_tc[ROWS ? slot * 256 + p : slot * 64 + p];
@@ -987,36 +987,35 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64) void render_bwd_bucket_kernel(int
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // ---- per-lane state of the pixel currently in this lane (n_contrib = 0 marks "no pixel here"), kept in TWO register sets
-    // that alternate roles every step: a DPP shift-in writes its result over the freshly loaded feed, so with a single set the
-    // compiler has to copy every state register once per step.
-    struct PixState { float px, py, last, g0, g1, g2, gd, ga, T, Rem; };
-    PixState A = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 1.f, 0.f}, B = A;
+    // ---- the pixel stream moves through the 16 lanes of every row, one lane per step: at step S lane l of a row holds stream entry S - l.
+    // Only the pixel's DYNAMIC state (T, Rem) travels from lane to lane (v_mov_b32_dpp row_shr:1, two register sets that alternate
+    // roles every step: a DPP shift-in writes its result over the fresh feed, so a single set would cost one copy per register and
+    // step); its static data (position, n_contrib, upstream gradient) every lane reads for itself from LDS at [S - l]: consecutive
+    // addresses across the lanes, the same LDS cycles as the broadcast reads they replace, six DPP moves per step fewer.
+    struct PixState { float T, Rem; };
+    PixState A = {1.f, 0.f}, B = A;
     // per-Gaussian moment accumulators of v = G * dL/dalpha over the pixels (constant factors applied once at the end)
     float S1 = 0.f, Sx = 0.f, Sy = 0.f, Sxx = 0.f, Sxy = 0.f, Syy = 0.f, aD = 0.f, a7 = 0.f, a8 = 0.f, a9 = 0.f;
     const int nsteps = n_alive ? n_alive + (int)min(count, 16u) - 1 : 0;
-    const float4 *pa = &sPixA[wv][0], *pb = &sPixB[wv][0];
+    const int rl = lane & 15;
+    const float4 *pa = &sPixA[wv][16 - rl], *pb = &sPixB[wv][16 - rl];          // [S] = stream entry S - rl
     const float2 *pd = &sDyn[wv][row][0];
 #define SGR_BWD_STEP(IN, OUT, S)                                                                                        \
     {                                                                                                                   \
-        const int sp = min((S), n_alive - 1);                                                                           \
-        float4 fa = pa[sp];                                                                                             \
-        const float4 fb = pb[sp];                                                                                       \
-        const float2 fd = pd[sp];                                                                                       \
-        if ((S) >= n_alive) fa.z = 0.f; /* drain: n_contrib = 0 -> never valid */                                      \
-        OUT.px = row_shift_in(IN.px, fa.x); OUT.py = row_shift_in(IN.py, fa.y); OUT.last = row_shift_in(IN.last, fa.z); \
-        OUT.g0 = row_shift_in(IN.g0, fa.w); OUT.g1 = row_shift_in(IN.g1, fb.x); OUT.g2 = row_shift_in(IN.g2, fb.y);     \
-        if (HAS_DA) { OUT.gd = row_shift_in(IN.gd, fb.z); OUT.ga = row_shift_in(IN.ga, fb.w); }                         \
+        const float4 fa = pa[(S)];                                                                                      \
+        const float4 fb = pb[(S)];                                                                                      \
+        const float2 fd = pd[min((S), n_alive - 1)];                                                                    \
+        const bool has = (uint32_t)((S) - rl) < (uint32_t)n_alive;      /* a stream entry sits in this lane */           \
         OUT.T = row_shift_in(IN.T, fd.x); OUT.Rem = row_shift_in(IN.Rem, fd.y);                                         \
-        const float dx = gx - OUT.px, dy = gy - OUT.py;                                                                 \
+        const float dx = gx - fa.x, dy = gy - fa.y;                                                                     \
         const float p2 = (kxx * dx) * dx + ((kyy * dy) * dy + (kxy * dx) * dy);                                         \
         const float G = __builtin_amdgcn_exp2f(p2);                                                                     \
         const float alpha = fminf(0.99f, op * G);                                                                       \
-        const bool valid = gidx < __float_as_uint(OUT.last) && p2 <= 0.f && alpha >= (1.0f / 255.0f);                   \
+        const bool valid = has && gidx < __float_as_uint(fa.z) && p2 <= 0.f && alpha >= (1.0f / 255.0f);                \
         if (valid) {                                                                                                    \
             const float w = alpha * OUT.T;                                                                              \
-            float qj = cr * OUT.g0 + cg * OUT.g1 + cb * OUT.g2;                                                         \
-            if (HAS_DA) qj += gdep * OUT.gd + OUT.ga;                                                                   \
+            float qj = cr * fa.w + cg * fb.x + cb * fb.y;                                                               \
+            if (HAS_DA) qj += gdep * fb.z + fb.w;                                                                       \
             const float oma = 1.f - alpha;                                                                              \
             OUT.Rem -= w * qj;                                                                                          \
             const float dL_dalpha = OUT.T * qj - OUT.Rem * __builtin_amdgcn_rcpf(oma);                                  \
@@ -1025,8 +1024,8 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64) void render_bwd_bucket_kernel(int
             const float vx = v * dx, vy = v * dy;                                                                       \
             S1 += v; Sx += vx; Sy += vy;                                                                                \
             Sxx = fmaf(vx, dx, Sxx); Sxy = fmaf(vx, dy, Sxy); Syy = fmaf(vy, dy, Syy);                                  \
-            if (HAS_DA) aD = fmaf(w, OUT.gd, aD);                                                                       \
-            a7 = fmaf(w, OUT.g0, a7); a8 = fmaf(w, OUT.g1, a8); a9 = fmaf(w, OUT.g2, a9);                               \
+            if (HAS_DA) aD = fmaf(w, fb.z, aD);                                                                         \
+            a7 = fmaf(w, fa.w, a7); a8 = fmaf(w, fb.x, a8); a9 = fmaf(w, fb.y, a9);                                     \
         }                                                                                                               \
     }
     int s = 0;
