@@ -1,3 +1,4 @@
+# full gpu test suite + one bench line per config (+ C3 with the compact checkpoint layout)     usage (on the GPU box): bash tools/gpu_test_bench.sh
 set -x
 O=gpurun_out/r2c; mkdir -p $O
 timeout 2400 python -m pytest tests -m gpu -q -x --timeout=1200 > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
