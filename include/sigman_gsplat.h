@@ -127,6 +127,26 @@ int sgr_rasterize_forward(const SgrProblem *pb, uint64_t capacity, int32_t with_
                           void *nr_event, void *caller_clear, uint64_t caller_clear_bytes, SgrForwardState *state, void *stream);
 
 /*
+ * sgr_rasterize_forward followed by sgr_clamped_l1_loss on the rendered colour, in ONE call (the fused rasterize + image-loss node,
+ * gs.py:98-107 + whole_loss.py:126-131): the loss kernel is queued right behind the compositing kernel instead of after a trip back
+ * through the caller (at one 512^2 view the host, not the GPU, paces the step).  Return codes as sgr_rasterize_forward; on 2 nothing of
+ * the epilogue ran.
+ */
+typedef struct SgrL1Epilogue {
+    const float *target;          /* [n_views,3,H,W] */
+    const float *mask;            /* [n_views,1,H,W] or NULL */
+    float *grad_color;            /* [n_views,3,H,W]  d loss / d color */
+    float *loss_per_view;         /* [n_views] */
+    float *loss_total;            /* [1] or NULL */
+    float weight;
+    int32_t sums_already_zero;    /* 1: the accumulators are cleared by this very call (caller_clear) or were cleared by the caller */
+} SgrL1Epilogue;
+int sgr_rasterize_forward_l1(const SgrProblem *pb, uint64_t capacity, int32_t with_aux, sgr_alloc_fn alloc, void *user,
+                             float *out_color, float *out_depth, float *out_alpha, int32_t *out_radii, uint64_t *nr_pinned_host,
+                             void *nr_event, void *caller_clear, uint64_t caller_clear_bytes, SgrForwardState *state,
+                             const SgrL1Epilogue *l1, void *stream);
+
+/*
  * == upstream _C.rasterize_gaussians_backward (reached from train_vae.py:166).  Gradient outputs as in
  * sgr_preprocess_backward.  out_color/out_depth/out_alpha are the forward's outputs.  grad_color_scale: optional DEVICE scalar
  * multiplied onto grad_color (the upstream gradient of a fused image loss; saves the caller an elementwise kernel), or NULL.

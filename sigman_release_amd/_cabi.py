@@ -37,6 +37,11 @@ class SgrForwardState(C.Structure):
                                           "off_n_contrib", "off_compact", "off_ckpt_tc", "off_ckpt_da", "off_desc", "off_order", "off_flags")]
 
 
+class SgrL1Epilogue(C.Structure):
+    _fields_ = [("target", C.c_void_p), ("mask", C.c_void_p), ("grad_color", C.c_void_p), ("loss_per_view", C.c_void_p),
+                ("loss_total", C.c_void_p), ("weight", C.c_float), ("sums_already_zero", C.c_int32)]
+
+
 ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_int32, C.c_size_t)
 
 _SIGNATURES = {
@@ -46,6 +51,9 @@ _SIGNATURES = {
     "sgr_rasterize_forward": (C.c_int, [C.POINTER(SgrProblem), C.c_uint64, C.c_int32, ALLOC_FN, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
                                         C.POINTER(SgrForwardState), C.c_void_p]),
+    "sgr_rasterize_forward_l1": (C.c_int, [C.POINTER(SgrProblem), C.c_uint64, C.c_int32, ALLOC_FN, C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
+                                           C.POINTER(SgrForwardState), C.POINTER(SgrL1Epilogue), C.c_void_p]),
     "sgr_rasterize_backward": (C.c_int, [C.POINTER(SgrProblem), C.POINTER(SgrForwardState)] + [C.c_void_p] * 8 + [ALLOC_FN, C.c_void_p]
                                + [C.c_void_p] * 9),
     "sgr_preprocess_forward": (C.c_int, [C.POINTER(SgrProblem)] + [C.c_void_p] * 6 + [C.c_uint64, C.c_void_p]),

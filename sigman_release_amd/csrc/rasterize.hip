@@ -283,6 +283,21 @@ extern "C" int sgr_rasterize_forward(const SgrProblem *pb, uint64_t capacity, in
     return 0;
 }
 
+extern "C" int sgr_clamped_l1_loss(int32_t n_views, int32_t H, int32_t W, const float *color, const float *target, const float *mask, float weight,
+                                   float *grad_color, float *loss_per_view, float *loss_total, int32_t sums_already_zero, void *stream_);
+
+extern "C" int sgr_rasterize_forward_l1(const SgrProblem *pb, uint64_t capacity, int32_t with_aux, sgr_alloc_fn alloc, void *user,
+                                        float *out_color, float *out_depth, float *out_alpha, int32_t *out_radii,
+                                        uint64_t *nr_pinned_host, void *nr_event, void *caller_clear, uint64_t caller_clear_bytes,
+                                        SgrForwardState *st, const SgrL1Epilogue *l1, void *stream_) {
+    if (!l1 || !l1->target || !l1->grad_color || !l1->loss_per_view) { sgr_set_error("sgr_rasterize_forward_l1: NULL epilogue argument"); return 1; }
+    const int rc = sgr_rasterize_forward(pb, capacity, with_aux, alloc, user, out_color, out_depth, out_alpha, out_radii, nr_pinned_host, nr_event,
+                                         caller_clear, caller_clear_bytes, st, stream_);
+    if (rc) return rc;
+    return sgr_clamped_l1_loss(pb->n_views, pb->H, pb->W, out_color, l1->target, l1->mask, l1->weight, l1->grad_color, l1->loss_per_view,
+                               l1->loss_total, l1->sums_already_zero, stream_);
+}
+
 extern "C" int sgr_rasterize_backward(const SgrProblem *pb, const SgrForwardState *st, const int32_t *radii, const float *out_color,
                                       const float *out_depth, const float *out_alpha, const float *grad_color,
                                       const float *grad_depth, const float *grad_alpha, const float *grad_color_scale,

@@ -281,7 +281,7 @@ class _debug_scope:
 
 
 def _forward_impl(means3D, opacities, colors_precomp, shs, cov3D_precomp, scales, rotations, st: BatchedRasterizationSettings,
-                  need_ctx: bool, with_aux: bool = True, clear: Optional[torch.Tensor] = None):
+                  need_ctx: bool, with_aux: bool = True, clear: Optional[torch.Tensor] = None, l1=None):
     L = _cabi.lib()
     dev = means3D.device
     if dev.type != "cuda":
@@ -311,6 +311,13 @@ def _forward_impl(means3D, opacities, colors_precomp, shs, cov3D_precomp, scales
     args = (C.byref(pb), capacity, use_aux)
     outs = (color.data_ptr(), depth.data_ptr(), alpha.data_ptr(), radii.data_ptr(), nr_ptr, nr_handle if capacity > 0 else None,
             clear_ptr, clear_bytes, C.byref(state), _stream(dev))
+    forward_fn = L.sgr_rasterize_forward
+    if l1 is not None:
+        # fused image loss (l1 = a callable that, given the colour tensor, returns the filled SgrL1Epilogue): the loss kernel is queued by
+        # the same C call, right behind the compositing kernel
+        ep = l1(color)
+        outs = outs[:-1] + (C.byref(ep), outs[-1])
+        forward_fn = L.sgr_rasterize_forward_l1
     # sync-free mode: blob sizes only depend on the shapes, so from the second call on the blobs are allocated here and handed over
     # directly (no allocator callbacks through ctypes)
     size_key = (didx, P, nv, H, W, capacity, use_aux, shs is not None) if capacity > 0 else None
@@ -323,10 +330,10 @@ def _forward_impl(means3D, opacities, colors_precomp, shs, cov3D_precomp, scales
                                             torch.empty(sizes[2], dtype=u8, device=dev))
             state.geom, state.binning, state.image = blobs[0].data_ptr(), blobs[1].data_ptr(), blobs[2].data_ptr()
             state.geom_bytes, state.binning_bytes, state.image_bytes = sizes
-            status = L.sgr_rasterize_forward(*args, _NO_ALLOC, None, *outs)
+            status = forward_fn(*args, _NO_ALLOC, None, *outs)
         if status == 2:                    # first call with these shapes (or sizes changed): the library asks for memory through the callback
             _alloc_target.dev, _alloc_target.blobs = dev, blobs
-            status = L.sgr_rasterize_forward(*args, _ALLOC, None, *outs)
+            status = forward_fn(*args, _ALLOC, None, *outs)
             if status == 0 and size_key is not None:
                 _blob_sizes[size_key] = (max(int(state.geom_bytes), 256), max(int(state.binning_bytes), 256), max(int(state.image_bytes), 256))
     if status != 0:
@@ -351,7 +358,7 @@ def _forward_impl(means3D, opacities, colors_precomp, shs, cov3D_precomp, scales
             _pool(dev).release(slot)
             _auto_capacity[auto_key] = 0               # re-run exactly; the exact run below re-learns the capacity
             return _forward_impl(means3D, opacities, colors_precomp, shs, cov3D_precomp, scales, rotations, st, need_ctx,
-                                 with_aux, clear)
+                                 with_aux, clear, l1)
     if auto_key is not None and P > 0:
         count = int(state.true_rendered) if capacity == 0 else slot.result[0]
         if capacity == 0 or count * 1.1 > capacity:
@@ -413,7 +420,7 @@ def _backward_impl(ctx: _Ctx, means3D, opacities, colors_precomp, shs, cov3D_pre
     return d_means3D, d_means2D, d_sh, d_col, d_op, d_sc, d_rot, d_cov, grec
 
 
-def _fwd_common(ctx, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, st, epilogue=None, clear=None):
+def _fwd_common(ctx, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, st, epilogue=None, clear=None, l1=None):
     # fp32-only op: inputs are cast here, so an enclosing autocast region (gs.py:98) cannot downcast them
     opt = lambda t: None if t is None or t.numel() == 0 else _f32c(t)
     means3D = _f32c(means3D)
@@ -427,7 +434,7 @@ def _fwd_common(ctx, means3D, sh, colors_precomp, opacities, scales, rotations, 
     # per-row checkpoints, bucket descriptors) -- the forward kernels then run their lighter variant
     wants_grad = any(ctx.needs_input_grad)
     color, radii, depth, alpha, c = _forward_impl(means3D, opacities, colors_precomp, sh, cov3Ds_precomp, scales, rotations,
-                                                  st, need_ctx=True, with_aux=wants_grad, clear=clear)
+                                                  st, need_ctx=True, with_aux=wants_grad, clear=clear, l1=l1)
     ctx.sgr = c
     ctx.st = st
     # unused outputs (depth / alpha on the reference path, gs.py:99,107-109) then arrive as None in backward instead of as
@@ -488,18 +495,19 @@ class _RasterizeL1Batched(torch.autograd.Function):
         # [per-view partial sums | total]: zeroed on the side by the rasterizer's own kernels (caller_clear), no memset launch
         sums = torch.empty(nv + 1, dtype=torch.float32, device=means3D.device)
 
-        def epilogue(color):
-            _, _, H, W = color.shape
+        keep = []
+
+        def l1(color):
             tgt = _f32c(target)
             msk = None if mask is None else _f32c(mask)
             gimg = torch.empty_like(color)
+            keep[:] = [gimg, tgt, msk]
             p = sums.data_ptr()
-            _cabi.check(L.sgr_clamped_l1_loss(nv, H, W, color.data_ptr(), _ptr(tgt), _ptr(msk), float(weight), gimg.data_ptr(),
-                                              p, p + 4 * nv, 1, _stream(color.device)), "sgr_clamped_l1_loss")
-            return (gimg,)
+            return _cabi.SgrL1Epilogue(target=_ptr(tgt), mask=_ptr(msk), grad_color=gimg.data_ptr(), loss_per_view=p, loss_total=p + 4 * nv,
+                                       weight=float(weight), sums_already_zero=1)
 
         color, radii, depth, alpha = _fwd_common(ctx, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, st,
-                                                 epilogue, clear=sums)
+                                                 lambda _color: (keep[0],), clear=sums, l1=l1)
         ctx.has_means2D = means2D is not None and ctx.needs_input_grad[1]
         loss, per_view = sums[nv], sums[:nv]
         ctx.mark_non_differentiable(radii, per_view)

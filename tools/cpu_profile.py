@@ -41,7 +41,7 @@ if os.environ.get("NOPROF"): sys.exit(0)
 pr = cProfile.Profile(); pr.enable()
 for _ in range(N): step()
 pr.disable(); torch.cuda.synchronize()
-pstats.Stats(pr).sort_stats("cumulative").print_stats(28)
+pstats.Stats(pr).sort_stats(os.environ.get("SORT", "cumulative")).print_stats(int(os.environ.get("LINES", "28")))
 import ctypes as C
 from sigman_release_amd import _cabi
 h, m = C.c_uint64(0), C.c_uint64(0)
