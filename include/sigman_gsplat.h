@@ -112,8 +112,9 @@ typedef struct SgrForwardState {
  * capacity = 0: exact mode, ONE blocking read of num_rendered per call (upstream: one per view).
  * capacity > 0: sync-free mode; binning buffers sized for `capacity` instances; the true count reaches nr_pinned_host[0]
  *               asynchronously as ONE 8-byte word, count | overflow << 63 (the host can never see the count without its flag), and
- *               `nr_event` (a hipEvent_t, may be NULL) is recorded right after.  state->nr_by_copy tells how the word travels: a
- *               kernel's single 8-byte store (poll-able) or an async copy (a copy engine may write it piecewise: wait for nr_event).
+ *               state->nr_by_copy tells how the word travels: 0 = a kernel's single 8-byte store (poll the word; nr_event is NOT
+ *               recorded), 1 = an async copy (a copy engine may write it piecewise: `nr_event`, a hipEvent_t, may be NULL, is recorded
+ *               behind the launch chain: wait for it before reading).
  *               (exact mode fills nr_pinned_host[0] = count, [1] = overflow flag before it returns.)
  * with_aux != 0 also records what the bucket-parallel backward needs.
  * alloc may be NULL if state->geom / binning / image and their *_bytes capacities are pre-filled by the caller (sizes as reported in

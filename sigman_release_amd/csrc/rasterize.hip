@@ -279,7 +279,9 @@ extern "C" int sgr_rasterize_forward(const SgrProblem *pb, uint64_t capacity, in
     }
     if (forward_launches(pb, capacity, R, st, out_color, out_depth, out_alpha, out_radii, capacity > 0 ? nr_pinned_host : nullptr,
                          preprocess_done, caller_clear, caller_clear_bytes, stream)) return 1;
-    if (capacity > 0 && nr_event) SGR_CHECK_HIP(hipEventRecord((hipEvent_t)nr_event, stream));
+    // (the event is only needed when the count travels by an asynchronous copy; a kernel's own 8-byte store is polled, and an event
+    // record between the compositing kernel and whatever the caller queues next is a ~5 us bubble on the GPU)
+    if (capacity > 0 && nr_event && st->nr_by_copy) SGR_CHECK_HIP(hipEventRecord((hipEvent_t)nr_event, stream));
     return 0;
 }
 

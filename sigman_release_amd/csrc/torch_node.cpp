@@ -94,7 +94,11 @@ bool resolve(Pending &p, bool block) {
     bool there = p.by_copy ? hipEventQuery(p.slot.ev) == hipSuccess : *w != ~0ull;
     if (!there) {
         if (!block) return false;
-        SGR_TORCH_CHECK_HIP(hipEventSynchronize(p.slot.ev));
+        if (p.by_copy) SGR_TORCH_CHECK_HIP(hipEventSynchronize(p.slot.ev));
+        else {                                                     // stored by the emission kernel itself, no event recorded: poll, then drain
+            for (int spins = 0; *w == ~0ull && spins < 200000; spins++) {}
+            if (*w == ~0ull) SGR_TORCH_CHECK_HIP(hipDeviceSynchronize());
+        }
     }
     const uint64_t word = *w;
     p.count = word & ~(1ull << 63); p.overflow = (word >> 63) != 0; p.checked = true;
@@ -225,7 +229,8 @@ struct RasterizeGaussiansNode : public torch::autograd::Function<RasterizeGaussi
                 // block counts (large launches: an async copy behind the scan kernel -- then only the event says "complete")
                 volatile uint64_t *w = slot.host;
                 if (!st.nr_by_copy) for (int spins = 0; *w == ~0ull && spins < 200000; spins++) {}
-                if (st.nr_by_copy || *w == ~0ull) SGR_TORCH_CHECK_HIP(hipEventSynchronize(slot.ev));
+                if (st.nr_by_copy) SGR_TORCH_CHECK_HIP(hipEventSynchronize(slot.ev));
+                else if (*w == ~0ull) SGR_TORCH_CHECK_HIP(hipDeviceSynchronize());
                 const uint64_t word = *w;
                 count = word & ~(1ull << 63); overflow = word >> 63;
             }

@@ -113,7 +113,16 @@ class _Slot:
         if not self.arrived():
             if not block:
                 return None
-            self.ev.synchronize()
+            if self.by_copy:
+                self.ev.synchronize()
+            else:
+                # the word is stored by the emission kernel itself (no event is recorded for it: an event between two kernels of the
+                # chain costs a ~5 us bubble on the GPU): poll, and drain the device if it takes unusually long
+                spins = 0
+                while int(self.np[0]) == -1:
+                    spins += 1
+                    if spins == 200000:
+                        torch.cuda.synchronize()
         w = int(self.np[0]) & 0xFFFFFFFFFFFFFFFF
         return w & (_OVF_BIT - 1), 1 if (w & _OVF_BIT) else 0
 

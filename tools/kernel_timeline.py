@@ -4,7 +4,8 @@ import csv, sys
 rows = sorted(csv.DictReader(open(sys.argv[1])), key=lambda r: int(r["Start_Timestamp"]))
 first = sys.argv[2] if len(sys.argv) > 2 else "preprocess_fwd_kernel"
 starts = [i for i, r in enumerate(rows) if first in r["Kernel_Name"]]
-a, b = starts[-3], starts[-2]
+k = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+a, b = starts[-k], starts[-k + 1]
 t0 = int(rows[a]["Start_Timestamp"]); prev_end = None
 for r in rows[a:b]:
     s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
