@@ -831,13 +831,13 @@ __device__ __forceinline__ float row_shift_in(float v, float feed) {
 }
 
 // One wave = one bucket of <= 64 consecutive surviving Gaussians of a (tile, quadrant), run as FOUR independent 16-lane
-// pipelines: row r owns survivors 16r..16r+15 and starts from the forward's checkpoint for that row.  The quadrant's 64
-// pixel states are fed into lane 0 of every row from LDS, one per step, and move one lane up per step (DPP row_shr:1), so
-// pixel p meets the row's Gaussians in front-to-back order.  79 steps per bucket instead of the 127 a single 64-lane
-// pipeline needs (fill/drain is 15 steps instead of 63).
-// SPLIT (launches with few buckets, i.e. one or two views): TWO waves per bucket, each streaming one half of the quadrant's pixels (47
-// steps instead of 79) -- 19 % more wave-steps but twice the waves, which is what a 4 000-bucket launch on 1 024 SIMDs lacks; the
-// second wave's per-Gaussian sums are added to the first's through LDS before the single partial record is written.
+// pipelines: row r owns survivors 16r..16r+15 and starts from the forward's checkpoint for that row.  The stream of the quadrant's
+// pixels that can still receive something from the bucket enters lane 0 of every row, one pixel per step, and moves one lane up per
+// step, so a pixel meets the row's Gaussians in front-to-back order: (stream length + 15) steps, at most 79, instead of the 127 a
+// single 64-lane pipeline needs (fill/drain is 15 steps instead of 63).
+// SPLIT (launches with few buckets, i.e. one or two views): TWO waves per bucket, each streaming one half of the quadrant's pixels
+// -- more wave-steps but twice the waves, which is what a 4 000-bucket launch on 1 024 SIMDs lacks; the second wave's per-Gaussian
+// sums are added to the first's through LDS before the single partial record is written.
 template <bool HAS_DA, bool SPLIT, bool ROWS>
 __global__ __launch_bounds__(SPLIT ? 128 : 64) void render_bwd_bucket_kernel(int W, int H, int Tx, uint32_t tiles_per_view,
                                                                    const uint2 *__restrict__ ranges,
@@ -863,10 +863,9 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64) void render_bwd_bucket_kernel(int
     const uint32_t qb = (blockIdx.x >> 3) & 3u, idx = (blockIdx.x >> 5) * 8u + (blockIdx.x & 7u);
     constexpr int NPIX = SPLIT ? 32 : 64;                      // pixels streamed by one wave
     const uint32_t half = SPLIT ? (uint32_t)(wv & 1) : 0u;     // which half of the quadrant's pixels
-    const uint32_t sub = 0u;                                                  // (one bucket per workgroup)
-    constexpr uint32_t BPW = 1u;
-    if ((size_t)idx * BPW + sub >= (size_t)aux.NS) return;
-    const size_t slot = (size_t)qb * aux.NS + (size_t)idx * BPW + sub;
+    constexpr uint32_t sub = 0u;                                              // (one bucket per workgroup)
+    if ((size_t)idx >= (size_t)aux.NS) return;
+    const size_t slot = (size_t)qb * aux.NS + (size_t)idx;
     const uint2 desc_v = aux.desc[slot];
     // the descriptor is wave-uniform: move it to SGPRs so the step loop below is a scalar loop
     const uint32_t desc_y = (uint32_t)__builtin_amdgcn_readfirstlane((int)desc_v.y);
@@ -1201,8 +1200,7 @@ int sgr_render_backward_ex(const SgrProblem *pb, const uint32_t *ranges, const u
                               (uint64_t)tiles * pb->n_views);
         // few buckets (one or two views): two waves per bucket (SPLIT) to give the SIMDs enough waves to hide latencies
         const bool split = (uint64_t)tiles * pb->n_views <= 2048;
-        const uint32_t bpw = 1u;                                         // buckets per workgroup (kernel: BPW)
-        const uint32_t nblocks = ((aux.NS + bpw - 1u) / bpw + 7u) / 8u * 32u;      // per quadrant ceil(NS / bpw) workgroups, in groups of 8 x 4 quadrants
+        const uint32_t nblocks = (aux.NS + 7u) / 8u * 32u;               // one workgroup per (bucket slot, quadrant), in groups of 8 slots x 4 quadrants
 #define SGR_LAUNCH_BWD(DA, SP, RW)                                                                                          \
         hipLaunchKernelGGL((render_bwd_bucket_kernel<DA, SP, RW>), dim3(nblocks), dim3(SP ? 128 : 64), 0, stream, pb->W, pb->H, Tx, tiles, \
                            (const uint2 *)ranges, (const float4 *)rec, (const uint4 *)rect, n_contrib, out_color, out_depth, out_alpha, grad_color, \
