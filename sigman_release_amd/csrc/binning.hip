@@ -1318,6 +1318,73 @@ __global__ __launch_bounds__(kThreads) void vseg_scatter_kernel(const uint64_t *
     }
 }
 
+// The same for views of more than 1024 tiles (1024^2 images): a chunk of 8192 keys then touches ~600 tile segments with ~14 keys each,
+// and 8-byte stores straight into them cost 2.5x their bytes in HBM write requests (the per-XCD L2s cannot keep that many partially
+// written lines open).  Here the workgroup first ORDERS its chunk by tile in LDS -- count per tile, exclusive scan, one returning LDS atomic
+// per key for its place in the staged chunk -- and then copies the staged chunk out: consecutive threads store consecutive composites of
+// a tile's run, so a wave's store covers a handful of runs instead of 64 unrelated lines.
+__global__ __launch_bounds__(1024) void vseg_scatter_staged_kernel(const uint64_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
+                                                                   uint64_t *__restrict__ keys_out, const VsegPlan *__restrict__ plan,
+                                                                   const uint4 *__restrict__ chunk_map, uint32_t tiles_per_view,
+                                                                   const uint32_t *__restrict__ hist, const uint2 *__restrict__ ranges) {
+    constexpr int MAXB = 4096, ITEMS = 8, NT = 1024;                 // chunk = 8192 keys
+    __shared__ uint64_t comp[NT * ITEMS];                            // the chunk, ordered by tile
+    __shared__ uint32_t run[MAXB];                                   // per tile: count -> next free staged slot
+    __shared__ uint32_t delta[MAXB];                                 // per tile: (first output slot of this chunk's keys) - (first staged slot)
+    __shared__ uint16_t tl[NT * ITEMS];                              // tile (in view) of staged entry j
+    __shared__ uint32_t wsum[16];
+    const uint32_t n_chunks = plan->n_chunks, span = (n_chunks + 7u) >> 3;
+    const uint32_t c = (blockIdx.x & 7u) * span + (blockIdx.x >> 3);          // XCD x takes the x-th eighth of the chunk list
+    if ((blockIdx.x >> 3) >= span || c >= n_chunks) return;
+    const uint4 cm = chunk_map[c];
+    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+    const uint32_t tbase = cm.x * tiles_per_view;
+    uint64_t key[ITEMS];
+    uint32_t val[ITEMS];
+    const uint32_t last = cm.z - 1u;
+#pragma unroll
+    for (int it = 0; it < ITEMS; it++) {
+        const uint32_t k = min((uint32_t)it * NT + t, last);
+        key[it] = keys_in[cm.y + k]; val[it] = vals_in[cm.y + k];
+    }
+    for (uint32_t d = t; d < (uint32_t)MAXB; d += NT) run[d] = 0u;
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < ITEMS; it++)
+        if ((uint32_t)it * NT + t < cm.z) atomicAdd(&run[(uint32_t)(key[it] >> 32) - tbase], 1u);
+    __syncthreads();
+    // exclusive scan of the 4096 counts (4 consecutive tiles per thread)
+    uint32_t v[4], sum = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) { v[j] = run[t * 4 + j]; sum += v[j]; }
+    uint32_t inc = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const uint32_t nb = __shfl_up(inc, off, 64); if (lane >= (uint32_t)off) inc += nb; }
+    if (lane == 63u) wsum[wave] = inc;
+    __syncthreads();
+    uint32_t base = inc - sum;
+    for (uint32_t w = 0; w < wave; w++) base += wsum[w];
+    const uint32_t *hrow = hist + (size_t)c * tiles_per_view;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const uint32_t d = t * 4 + j;
+        run[d] = base;
+        if (d < tiles_per_view && v[j]) delta[d] = ranges[tbase + d].x + hrow[d] - base;
+        base += v[j];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < ITEMS; it++)
+        if ((uint32_t)it * NT + t < cm.z) {
+            const uint32_t d = (uint32_t)(key[it] >> 32) - tbase;
+            const uint32_t ls = atomicAdd(&run[d], 1u);
+            comp[ls] = (key[it] << 32) | val[it];
+            tl[ls] = (uint16_t)d;
+        }
+    __syncthreads();
+    for (uint32_t j = t; j < cm.z; j += NT) keys_out[j + delta[tl[j]]] = comp[j];
+}
+
 // ---- F5 -------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kThreads) void tile_ranges_kernel(const uint64_t *__restrict__ keys, uint32_t n_host,
                                                                const uint64_t *__restrict__ n_dev, uint2 *__restrict__ ranges,
@@ -1471,8 +1538,8 @@ int sgr_bin_ex(const SgrProblem *pb, const int32_t *radii, uint32_t *rect,
             hipLaunchKernelGGL((vseg_scatter_kernel<1024, 16>), dim3(VL.max_chunks + 8), dim3(kThreads), 0, stream, kin, vin, kout, vout, plan, chunk_map,
                                tpv, vhist, (const uint2 *)ranges);
         else
-            hipLaunchKernelGGL((vseg_scatter_kernel<4096, 32>), dim3(VL.max_chunks + 8), dim3(kThreads), 0, stream, kin, vin, kout, vout, plan, chunk_map,
-                               tpv, vhist, (const uint2 *)ranges);
+            hipLaunchKernelGGL(vseg_scatter_staged_kernel, dim3(VL.max_chunks + 8), dim3(1024), 0, stream, kin, vin, kout, plan, chunk_map, tpv, vhist,
+                               (const uint2 *)ranges);
         SGR_CHECK_LAUNCH("view-segmented tile pass");
         // depth bits per tile: keys now sit tile-bucketed in (kout, vout); the sorted list goes back into (kin, vin)
         auto work = [&](int cls) { TileWork w = {lists + (size_t)cls * tiles_total, &plan->ticket[cls], &plan->count[cls]}; return w; };
