@@ -1276,58 +1276,21 @@ __global__ __launch_bounds__(1024) void vseg_scan_kernel(const uint32_t *__restr
     }
 }
 
-// scatter: the per-tile sort orders (depth, value) composites, so the tile pass needs NO stability -- every key simply claims the next free
-// slot of its tile with one returning LDS atomic: one 16-KB counter array per workgroup whatever the number of waves (the stable version
-// kept a counter array per wave: 64 KB at 4096 tiles per view, two workgroups per CU, 0.85 ms at C4), no match-any ballots.
+// scatter: the per-tile sort orders (depth, value) composites, so the tile pass needs NO stability -- a key can take ANY free slot of its
+// tile's segment (the stable version kept a counter array per wave and match-any ballots: 64 KB of LDS at 4096 tiles per view, 0.85 ms
+// at C4).  The first order-free version stored every composite straight into its segment (one returning LDS atomic on a 16-KB
+// counter array per key, then an 8-byte store): fine for 1024 tiles per view, but a chunk of 8192 keys of a 4096-tile view touches ~600
+// segments with ~14 keys each, and those scattered stores cost 2.5x their bytes in HBM write requests (the per-XCD L2s cannot keep
+// that many partially written lines open).  So the workgroup first ORDERS its chunk by tile in LDS -- count per tile, exclusive scan, one
+// returning LDS atomic per key for its place in the staged chunk -- and then copies the staged chunk out: consecutive threads store
+// consecutive composites of a tile's run, a wave's store covers a handful of runs instead of 64 unrelated lines (C4: 0.40 -> 0.27 ms,
+// C3: 0.11 -> 0.09 ms).  Chunks are dealt to the XCDs in contiguous eighths (neighbouring chunks' runs meet in one L2).
 template <int MAXB, int ITEMS>
-__global__ __launch_bounds__(kThreads) void vseg_scatter_kernel(const uint64_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
-                                                                uint64_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out,
-                                                                const VsegPlan *__restrict__ plan, const uint4 *__restrict__ chunk_map,
-                                                                uint32_t tiles_per_view, const uint32_t *__restrict__ hist,
-                                                                const uint2 *__restrict__ ranges) {
-    __shared__ uint32_t pos[MAXB];                    // next output position per tile for THIS chunk's keys
-    // workgroups go round-robin over the 8 XCDs, each with its own L2: XCD x takes the x-th EIGHTH of the chunk list, so that the chunks
-    // whose keys land next to each other in the output (neighbours in the same view) pass through ONE L2 close in time and their
-    // sub-line stores merge there before they reach HBM (at C4 the scattered 8- and 4-byte stores cost 40 B of HBM writes per key
-    // with chunk = blockIdx.x)
-    const uint32_t n_chunks = plan->n_chunks, span = (n_chunks + 7u) >> 3;
-    const uint32_t c = (blockIdx.x & 7u) * span + (blockIdx.x >> 3);
-    if ((blockIdx.x >> 3) >= span || c >= n_chunks) return;
-    const uint4 cm = chunk_map[c];
-    const uint32_t t = threadIdx.x;
-    const uint32_t tbase = cm.x * tiles_per_view;
-    // (straight-line code: clamped loads + validity predicates instead of branches)
-    uint64_t key[ITEMS];
-    uint32_t val[ITEMS];
-    const uint32_t last = cm.z - 1u;                             // (cm.z >= 1 for every mapped chunk)
-#pragma unroll
-    for (int it = 0; it < ITEMS; it++) {
-        const uint32_t k = min((uint32_t)it * kThreads + t, last);
-        key[it] = keys_in[cm.y + k]; val[it] = vals_in[cm.y + k];
-    }
-    const uint32_t *hrow = hist + (size_t)c * tiles_per_view;
-    for (uint32_t d = t; d < tiles_per_view; d += kThreads) pos[d] = ranges[tbase + d].x + hrow[d];   // first slot of this chunk's keys of tile d
-    __syncthreads();
-#pragma unroll
-    for (int it = 0; it < ITEMS; it++) {
-        const uint32_t k = (uint32_t)it * kThreads + t;
-        if (k < cm.z) {
-            const uint32_t slot = atomicAdd(&pos[(uint32_t)(key[it] >> 32) - tbase], 1u);
-            keys_out[slot] = (key[it] << 32) | val[it];                      // (depth bits, value) composite: ONE 8-byte store per key
-        }
-    }
-}
-
-// The same for views of more than 1024 tiles (1024^2 images): a chunk of 8192 keys then touches ~600 tile segments with ~14 keys each,
-// and 8-byte stores straight into them cost 2.5x their bytes in HBM write requests (the per-XCD L2s cannot keep that many partially
-// written lines open).  Here the workgroup first ORDERS its chunk by tile in LDS -- count per tile, exclusive scan, one returning LDS atomic
-// per key for its place in the staged chunk -- and then copies the staged chunk out: consecutive threads store consecutive composites of
-// a tile's run, so a wave's store covers a handful of runs instead of 64 unrelated lines.
 __global__ __launch_bounds__(1024) void vseg_scatter_staged_kernel(const uint64_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
                                                                    uint64_t *__restrict__ keys_out, const VsegPlan *__restrict__ plan,
                                                                    const uint4 *__restrict__ chunk_map, uint32_t tiles_per_view,
                                                                    const uint32_t *__restrict__ hist, const uint2 *__restrict__ ranges) {
-    constexpr int MAXB = 4096, ITEMS = 8, NT = 1024;                 // chunk = 8192 keys
+    constexpr int NT = 1024, PER = MAXB / NT;                        // chunk = 1024 * ITEMS keys; PER consecutive tiles per thread in the scan
     __shared__ uint64_t comp[NT * ITEMS];                            // the chunk, ordered by tile
     __shared__ uint32_t run[MAXB];                                   // per tile: count -> next free staged slot
     __shared__ uint32_t delta[MAXB];                                 // per tile: (first output slot of this chunk's keys) - (first staged slot)
@@ -1353,10 +1316,10 @@ __global__ __launch_bounds__(1024) void vseg_scatter_staged_kernel(const uint64_
     for (int it = 0; it < ITEMS; it++)
         if ((uint32_t)it * NT + t < cm.z) atomicAdd(&run[(uint32_t)(key[it] >> 32) - tbase], 1u);
     __syncthreads();
-    // exclusive scan of the 4096 counts (4 consecutive tiles per thread)
-    uint32_t v[4], sum = 0;
+    // exclusive scan of the MAXB counts (PER consecutive tiles per thread)
+    uint32_t v[PER], sum = 0;
 #pragma unroll
-    for (int j = 0; j < 4; j++) { v[j] = run[t * 4 + j]; sum += v[j]; }
+    for (int j = 0; j < PER; j++) { v[j] = run[t * PER + j]; sum += v[j]; }
     uint32_t inc = sum;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) { const uint32_t nb = __shfl_up(inc, off, 64); if (lane >= (uint32_t)off) inc += nb; }
@@ -1366,8 +1329,8 @@ __global__ __launch_bounds__(1024) void vseg_scatter_staged_kernel(const uint64_
     for (uint32_t w = 0; w < wave; w++) base += wsum[w];
     const uint32_t *hrow = hist + (size_t)c * tiles_per_view;
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const uint32_t d = t * 4 + j;
+    for (int j = 0; j < PER; j++) {
+        const uint32_t d = t * PER + j;
         run[d] = base;
         if (d < tiles_per_view && v[j]) delta[d] = ranges[tbase + d].x + hrow[d] - base;
         base += v[j];
@@ -1535,10 +1498,10 @@ int sgr_bin_ex(const SgrProblem *pb, const int32_t *radii, uint32_t *rect,
         hipLaunchKernelGGL(vseg_scan_kernel, dim3(pb->n_views), dim3(1024), 0, stream, tile_total, key_start, tpv, (uint2 *)ranges, plan, lists,
                            (uint32_t)tiles_total);
         if (VL.chunk_keys == 4096u)
-            hipLaunchKernelGGL((vseg_scatter_kernel<1024, 16>), dim3(VL.max_chunks + 8), dim3(kThreads), 0, stream, kin, vin, kout, vout, plan, chunk_map,
-                               tpv, vhist, (const uint2 *)ranges);
+            hipLaunchKernelGGL((vseg_scatter_staged_kernel<1024, 4>), dim3(VL.max_chunks + 8), dim3(1024), 0, stream, kin, vin, kout, plan, chunk_map, tpv, vhist,
+                               (const uint2 *)ranges);
         else
-            hipLaunchKernelGGL(vseg_scatter_staged_kernel, dim3(VL.max_chunks + 8), dim3(1024), 0, stream, kin, vin, kout, plan, chunk_map, tpv, vhist,
+            hipLaunchKernelGGL((vseg_scatter_staged_kernel<4096, 8>), dim3(VL.max_chunks + 8), dim3(1024), 0, stream, kin, vin, kout, plan, chunk_map, tpv, vhist,
                                (const uint2 *)ranges);
         SGR_CHECK_LAUNCH("view-segmented tile pass");
         // depth bits per tile: keys now sit tile-bucketed in (kout, vout); the sorted list goes back into (kin, vin)
