@@ -71,6 +71,7 @@ def _build(n_views, P, size, seed, depth_kind, big_rects):
     (3, 5000, 512, "ties", True),
     (4, 60000, 512, "extreme", True),
     (2, 6000, 1024, "extreme", False),
+    (2, 50000, 1024, "ties", True),            # 4096 tiles per view, many 8192-key chunks per view: the staged tile pass at full width
 ])
 def test_sgr_bin_direct_all_flavours(n_views, P, size, depth_kind, big_rects):
     from sigman_release_amd import _cabi
