@@ -171,27 +171,45 @@ __device__ __forceinline__ uint32_t block_sum_u32(uint32_t v, uint32_t *lds4) {
 // -------------------------------------------------------------------------------------------------
 // F1
 // -------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kPreThreads) void preprocess_fwd_kernel(SgrProblem pb, float4 *__restrict__ rec,
+__global__ __launch_bounds__(kPreThreads) void preprocess_fwd_kernel(SgrProblem pb, int views_per_wg, float4 *__restrict__ rec,
                                                                      int32_t *__restrict__ radii,
                                                                      uint4 *__restrict__ rect,
                                                                      uint8_t *__restrict__ clamped,
                                                                      uint32_t *__restrict__ block_sums) {
-    __shared__ uint32_t red[4];
-    const int view = blockIdx.y;
+    // One thread per Gaussian, looping over `views_per_wg` consecutive views: the per-Gaussian inputs (52 B: mean, covariance, opacity,
+    // colour) stay in registers across the views of a subject.  With one view per workgroup a 90-view launch re-read them from HBM
+    // 90 times (PMC at C4: 0.94 GB of reads beside 1.5 GB of writes).
+    __shared__ uint32_t red[2][4];
+    __shared__ float4 stage[kPreThreads / 64][256];
     const int i = blockIdx.x * kPreThreads + threadIdx.x;
-    const int subj = view / pb.views_per_subject;
     const int W = pb.W, H = pb.H;
     const int Tx = (W + SGR_TILE - 1) / SGR_TILE, Ty = (H + SGR_TILE - 1) / SGR_TILE;
+    const int v0 = blockIdx.y * views_per_wg, v1 = min(v0 + views_per_wg, pb.n_views);
+    const bool live = i < pb.P;
+    int cur_subj = -1;
+    float p[3] = {0.f, 0.f, 0.f}, c6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, op = 0.f, rgb_in[3] = {0.f, 0.f, 0.f};
+    for (int view = v0; view < v1; view++) {
+    const int subj = view / pb.views_per_subject;
     const float *V = pb.viewmatrix + 16 * (size_t)view;
     const float *M = pb.projmatrix + 16 * (size_t)view;
     uint32_t tiles = 0;
-    if (i < pb.P) {
+    float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = make_float4(0.f, 0.f, -1.f, -1.f);
+    if (live) {
         const size_t q = (size_t)view * pb.P + i, sp = (size_t)subj * pb.P + i;
-        float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = make_float4(0.f, 0.f, -1.f, -1.f);
+        if (subj != cur_subj) {                              // uniform: once per subject
+            cur_subj = subj;
+#pragma unroll
+            for (int k = 0; k < 3; k++) p[k] = pb.means3D[sp * 3 + k];
+            load_cov3d(pb, sp, c6);
+            op = pb.opacities[sp];
+            if (pb.colors_precomp) {
+#pragma unroll
+                for (int k = 0; k < 3; k++) rgb_in[k] = pb.colors_precomp[sp * 3 + k];   // untouched, no clamp
+            }
+        }
         int32_t rad_out = 0;
         uint2 rect_out = make_uint2(0u, 0u);
         uint8_t clamp_bits = 0;
-        const float p[3] = {pb.means3D[sp * 3 + 0], pb.means3D[sp * 3 + 1], pb.means3D[sp * 3 + 2]};
         float pv[3];
         xform4x3(V, p, pv);
         if (pv[2] > 0.2f) {                                  // near cull; the lateral test is disabled upstream
@@ -199,8 +217,6 @@ __global__ __launch_bounds__(kPreThreads) void preprocess_fwd_kernel(SgrProblem 
             xform4x4(M, p, ph);
             const float pw = 1.0f / (ph[3] + 0.0000001f);
             const float projx = ph[0] * pw, projy = ph[1] * pw;
-            float c6[6];
-            load_cov3d(pb, sp, c6);
             const float fx = (float)W / (2.0f * pb.tanfovx), fy = (float)H / (2.0f * pb.tanfovy);
             Cov2D cq;
             cov2d_eval(pv, V, c6, fx, fy, pb.tanfovx, pb.tanfovy, cq);
@@ -223,7 +239,7 @@ __global__ __launch_bounds__(kPreThreads) void preprocess_fwd_kernel(SgrProblem 
                     float rgb[3];
                     if (pb.colors_precomp) {
 #pragma unroll
-                        for (int k = 0; k < 3; k++) rgb[k] = pb.colors_precomp[sp * 3 + k];   // untouched, no clamp
+                        for (int k = 0; k < 3; k++) rgb[k] = rgb_in[k];
                     } else {
                         const float *cp = pb.campos + 3 * (size_t)view;
                         float d[3] = {p[0] - cp[0], p[1] - cp[1], p[2] - cp[2]};
@@ -241,7 +257,6 @@ __global__ __launch_bounds__(kPreThreads) void preprocess_fwd_kernel(SgrProblem 
                             rgb[ch] = fmaxf(r, 0.f);
                         }
                     }
-                    const float op = pb.opacities[sp];
                     // exact sub-tile cull bound: alpha = op*exp(power) >= 1/255  <=>  d^T Q d <= 2 ln(255 op);
                     // the bounding box of that ellipse has half extents sqrt(tau*cov_xx), sqrt(tau*cov_yy).
                     // Inflated by 1e-3 relative + 0.02 px so fp32 rounding can never cull a contributing pixel.
@@ -264,9 +279,6 @@ __global__ __launch_bounds__(kPreThreads) void preprocess_fwd_kernel(SgrProblem 
                 }
             }
         }
-        rec[q * 4 + 0] = r0; rec[q * 4 + 1] = r1; rec[q * 4 + 2] = r2;
-        rec[q * 4 + 3] = make_float4(0.f, 0.f, 0.f, 0.f);          // padding, written all the same: 48 of every 64 bytes is a partial-line write
-                                                                   // (measured: preprocess 0.40 -> 0.54 ms at C4 without it)
         radii[q] = rad_out;
         // (rect min, rect max, depth key bits, first tile-instance index -- filled in by the emission kernel): everything the emission kernel and
         // the backward's gathers need besides the compositing record, in one coalesced 16-byte record (the emission kernel used to fetch the depth from
@@ -274,8 +286,30 @@ __global__ __launch_bounds__(kPreThreads) void preprocess_fwd_kernel(SgrProblem 
         rect[q] = make_uint4(rect_out.x, rect_out.y, __float_as_uint(r1.z), 0u);
         if (clamped) clamped[q] = clamp_bits;
     }
-    const uint32_t tot = block_sum_u32(tiles, red);
+    {   // the wave's 64 compositing records (4 KB, padding included) leave as four fully coalesced 1-KB stores: transposed through LDS
+        // (slot swizzle keeps both the 64-B-strided writes and the contiguous reads conflict-free)
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        float4 *sw = stage[wave];
+        const int sz = (lane >> 2) & 3;
+        sw[lane * 4 + (0 ^ sz)] = r0; sw[lane * 4 + (1 ^ sz)] = r1; sw[lane * 4 + (2 ^ sz)] = r2;
+        sw[lane * 4 + (3 ^ sz)] = make_float4(0.f, 0.f, 0.f, 0.f);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int first = blockIdx.x * kPreThreads + wave * 64;
+        const int nrec = pb.P - first;                       // records of this wave that exist (may be <= 0 or > 64)
+        float4 *out = rec + ((size_t)view * pb.P + first) * 4;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int j = k * 64 + lane, r = j >> 2;
+            if (r < nrec) out[j] = sw[r * 4 + ((j & 3) ^ ((r >> 2) & 3))];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    const uint32_t tot = block_sum_u32(tiles, red[(view - v0) & 1]);   // alternating slots: one barrier per view is enough
     if (threadIdx.x == 0) block_sums[(size_t)view * gridDim.x + blockIdx.x] = tot;
+    }
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -643,9 +677,12 @@ int sgr_preprocess_forward_ex(const SgrProblem *pb, float *rec, int32_t *radii, 
     // the un-scanned block sums live in the upper half of a caller buffer? no: scan in place is unsafe with
     // chunked reads, so the sums are staged right behind the offsets (caller allocates 2*(n+1) entries).
     uint32_t *sums = block_offsets + (n + 1);
-    dim3 grid(nbx, pb->n_views);
+    // views per workgroup: as many as keep >= 4096 workgroups in flight, at most 8, never across a subject boundary's worth of reloads
+    int vpw = 1;
+    while (vpw < 8 && vpw * 2 <= pb->views_per_subject && (size_t)nbx * ((pb->n_views + vpw * 2 - 1) / (vpw * 2)) >= 4096) vpw *= 2;
+    dim3 grid(nbx, (pb->n_views + vpw - 1) / vpw);
     { SgrProfScope _p(SGR_K_PREPROCESS_FWD, stream);
-    hipLaunchKernelGGL(preprocess_fwd_kernel, grid, dim3(kPreThreads), 0, stream, *pb, (float4 *)rec, radii, (uint4 *)rect,
+    hipLaunchKernelGGL(preprocess_fwd_kernel, grid, dim3(kPreThreads), 0, stream, *pb, vpw, (float4 *)rec, radii, (uint4 *)rect,
                        clamped, sums);
     SGR_CHECK_LAUNCH("preprocess_fwd_kernel");
     }

@@ -1056,12 +1056,15 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64) void render_bwd_bucket_kernel(int
         const uint32_t inst = off + (ty - (rmin >> 16)) * ((rmax & 0xFFFFu) - (rmin & 0xFFFFu)) + (tx - (rmin & 0xFFFFu));
         const float a0 = -0.5f * (float)W * op * (cxx * Sx + cxy * Sy);       // dL/dNDC x (includes 0.5*W like upstream)
         const float a1 = -0.5f * (float)H * op * (cyy * Sy + cxy * Sx);
-        float2 *pp = reinterpret_cast<float2 *>(part) + ((size_t)inst * 4 + q) * (SGR_PART_FLOATS / 2);      // 40 B, 8-byte aligned
-        pp[0] = make_float2(a0, a1);
-        pp[1] = make_float2(-0.5f * op * Sxx, -0.5f * op * Sxy);
-        pp[2] = make_float2(-0.5f * op * Syy, S1);
-        pp[3] = make_float2(aD, a7);
-        pp[4] = make_float2(a8, a9);
+        // 40 B, 8-byte aligned: 16 + 16 + 8-byte stores (three write requests per record instead of five)
+        struct __attribute__((packed, aligned(8))) Rec40 { float2 v[5]; };
+        Rec40 rr;
+        rr.v[0] = make_float2(a0, a1);
+        rr.v[1] = make_float2(-0.5f * op * Sxx, -0.5f * op * Sxy);
+        rr.v[2] = make_float2(-0.5f * op * Syy, S1);
+        rr.v[3] = make_float2(aD, a7);
+        rr.v[4] = make_float2(a8, a9);
+        *(reinterpret_cast<Rec40 *>(part) + ((size_t)inst * 4 + q)) = rr;
         flags[(size_t)inst * 4 + q] = 1;
     }
 }
