@@ -316,51 +316,85 @@ __global__ __launch_bounds__(kPreThreads) void preprocess_fwd_kernel(SgrProblem 
 // F2: exclusive scan of the per-block tile counts (n is small: n_views * ceil(P/256)), one workgroup.
 // out[0..n) = exclusive prefix, out[n] = total (also stored as u64 in *num_rendered).
 // -------------------------------------------------------------------------------------------------
+constexpr uint32_t kScanTile = 8192;                              // counts per workgroup of the scan (8 consecutive per thread)
+
 __global__ __launch_bounds__(1024) void scan_block_sums_kernel(const uint32_t *__restrict__ in, uint32_t *__restrict__ out,
                                                                uint32_t n, uint64_t *__restrict__ num_rendered,
                                                                unsigned long long capacity) {
-    // tiles of 8192 elements (8 consecutive per thread): wave-level shuffle scan + 16 wave totals, running carry in a register, next
-    // tile prefetched (the first version gave every thread one long private chunk + a 20-barrier LDS scan: 155 us for the 70k counts
-    // of a 90-view launch)
-    __shared__ unsigned long long wtot[2][16];
+    // One workgroup per tile of 8192 counts, no chaining: every workgroup first SUMS all counts before its tile (coalesced 16-byte
+    // loads, independent, at most a few hundred KB out of L2), then scans its own tile -- the workgroups never wait for each other.
+    // (One workgroup walking the tiles with a barrier each -- __syncthreads drains the vector-memory counter, so every tile paid the
+    // load and the store latency -- took 77 us for the 70k counts of a 90-view launch; the first version, one long private chunk
+    // per thread + a 20-barrier LDS scan, 155 us.)
+    struct __attribute__((packed, aligned(4))) U4 { uint32_t x, y, z, w; };
+    __shared__ unsigned long long wbase[16], wtot[16];
     const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    unsigned long long carry = 0;
-    constexpr uint32_t kPer = 8;                                  // consecutive elements per thread and tile (8192 per tile)
-    uint32_t v[kPer], nv[kPer];
+    const uint32_t lo = blockIdx.x * kScanTile;
+    // ---- own tile: loads first, they fly during the sum below
+    uint32_t v[8];
+    {
+        const uint32_t k = lo + t * 8u;
+        if (k + 8u <= n) {
+            const U4 a = *reinterpret_cast<const U4 *>(in + k), b = *reinterpret_cast<const U4 *>(in + k + 4);
+            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+        } else {
 #pragma unroll
-    for (uint32_t j = 0; j < kPer; j++) { const uint32_t k = t * kPer + j; v[j] = k < n ? in[k] : 0u; }
-    int buf = 0;
-    for (uint32_t base = 0; base < n; base += 1024 * kPer, buf ^= 1) {
-        // software pipeline: the next tile's loads are in flight while this one is scanned
-#pragma unroll
-        for (uint32_t j = 0; j < kPer; j++) { const uint32_t k = base + 1024 * kPer + t * kPer + j; nv[j] = k < n ? in[k] : 0u; }
-        unsigned long long sum = 0;
-#pragma unroll
-        for (uint32_t j = 0; j < kPer; j++) sum += v[j];
-        unsigned long long inc = sum;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const unsigned long long nb = __shfl_up(inc, off, 64);
-            if (lane >= (uint32_t)off) inc += nb;
+            for (uint32_t j = 0; j < 8; j++) v[j] = k + j < n ? in[k + j] : 0u;
         }
-        if (lane == 63) wtot[buf][wave] = inc;
-        __syncthreads();                                          // (double-buffered totals: one barrier per tile)
-        unsigned long long pre = carry, all = carry;
-#pragma unroll
-        for (int w = 0; w < 16; w++) { const unsigned long long x = wtot[buf][w]; if (w < (int)wave) pre += x; all += x; }
-        unsigned long long run = pre + inc - sum;
-#pragma unroll
-        for (uint32_t j = 0; j < kPer; j++) { const uint32_t k = base + t * kPer + j; if (k < n) out[k] = (uint32_t)run; run += v[j]; }
-        carry = all;
-#pragma unroll
-        for (uint32_t j = 0; j < kPer; j++) v[j] = nv[j];
     }
-    if (t == 0) {
-        out[n] = (uint32_t)carry;
-        const unsigned long long ovf = (carry > 0xFFFFFFF0ull || carry > capacity) ? 1ull : 0ull;
-        num_rendered[0] = carry;
+    // ---- sum of everything before the tile (lo is a multiple of 8192: whole groups of four)
+    unsigned long long acc = 0;
+    const uint32_t groups = lo / 4u;
+    uint32_t g = t;
+    for (; g + 3u * 1024u < groups; g += 4u * 1024u) {
+        const U4 a = *reinterpret_cast<const U4 *>(in + 4u * g), b = *reinterpret_cast<const U4 *>(in + 4u * (g + 1024u));
+        const U4 c = *reinterpret_cast<const U4 *>(in + 4u * (g + 2048u)), d = *reinterpret_cast<const U4 *>(in + 4u * (g + 3072u));
+        acc += ((unsigned long long)a.x + a.y) + ((unsigned long long)a.z + a.w);
+        acc += ((unsigned long long)b.x + b.y) + ((unsigned long long)b.z + b.w);
+        acc += ((unsigned long long)c.x + c.y) + ((unsigned long long)c.z + c.w);
+        acc += ((unsigned long long)d.x + d.y) + ((unsigned long long)d.z + d.w);
+    }
+    for (; g < groups; g += 1024u) {
+        const U4 a = *reinterpret_cast<const U4 *>(in + 4u * g);
+        acc += ((unsigned long long)a.x + a.y) + ((unsigned long long)a.z + a.w);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    // ---- scan of the tile
+    unsigned long long sum = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < 8; j++) sum += v[j];
+    unsigned long long inc = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned long long nb = __shfl_up(inc, off, 64);
+        if (lane >= (uint32_t)off) inc += nb;
+    }
+    if (lane == 63) wtot[wave] = inc;
+    if (lane == 0) wbase[wave] = acc;
+    __syncthreads();
+    unsigned long long pre = 0, all = 0;
+#pragma unroll
+    for (int w = 0; w < 16; w++) { const unsigned long long x = wtot[w]; if (w < (int)wave) pre += x; all += x; pre += wbase[w]; all += wbase[w]; }
+    unsigned long long run = pre + inc - sum;
+    {
+        const uint32_t k = lo + t * 8u;
+        if (k + 8u <= n) {
+            U4 a, b;
+            a.x = (uint32_t)run; run += v[0]; a.y = (uint32_t)run; run += v[1]; a.z = (uint32_t)run; run += v[2]; a.w = (uint32_t)run; run += v[3];
+            b.x = (uint32_t)run; run += v[4]; b.y = (uint32_t)run; run += v[5]; b.z = (uint32_t)run; run += v[6]; b.w = (uint32_t)run;
+            *reinterpret_cast<U4 *>(out + k) = a; *reinterpret_cast<U4 *>(out + k + 4) = b;
+        } else {
+#pragma unroll
+            for (uint32_t j = 0; j < 8; j++) { if (k + j < n) out[k + j] = (uint32_t)run; run += v[j]; }
+        }
+    }
+    if (t == 0 && blockIdx.x == gridDim.x - 1) {                  // the last tile knows the total
+        out[n] = (uint32_t)all;
+        const unsigned long long ovf = (all > 0xFFFFFFF0ull || all > capacity) ? 1ull : 0ull;
+        num_rendered[0] = all;
         num_rendered[1] = ovf;
-        num_rendered[2] = carry | (ovf << 63);          // the one word the sync-free mode copies to the host
+        num_rendered[2] = all | (ovf << 63);            // the one word the sync-free mode copies to the host
     }
 }
 
@@ -688,7 +722,7 @@ int sgr_preprocess_forward_ex(const SgrProblem *pb, float *rec, int32_t *radii, 
     }
     if (skip_scan) return 0;
     { SgrProfScope _p(SGR_K_SCAN, stream);
-    hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(1024), 0, stream, sums, block_offsets, n, num_rendered,
+    hipLaunchKernelGGL(scan_block_sums_kernel, dim3(n == 0 ? 1u : (n + kScanTile - 1) / kScanTile), dim3(1024), 0, stream, sums, block_offsets, n, num_rendered,
                        (unsigned long long)capacity);
     SGR_CHECK_LAUNCH("scan_block_sums_kernel");
     }
