@@ -431,21 +431,32 @@ __device__ __forceinline__ void bwd_view(const SgrProblem &pb, int view, int i, 
         const uint32_t off = r3.w, rmin = r3.x, rmax = r3.y;
         const uint32_t ntile = ((rmax & 0xFFFFu) - (rmin & 0xFFFFu)) * ((rmax >> 16) - (rmin >> 16));
         g0 = make_float4(0.f, 0.f, 0.f, 0.f); g1 = g0; g2 = g0;
+        // The loop is a chain of dependent memory round trips on a kernel that lives on latency: the flag word of the next instance is
+        // fetched while this one is summed, and the (up to four) quadrant records of an instance are requested TOGETHER -- a quadrant
+        // without a record re-reads the instance's first existing one (same cache line, value discarded) instead of branching around
+        // its loads.  (A branch per quadrant serialised four round trips per instance: some lane of the wave always takes each.)
+        // Adding the +0.0f of a discarded record changes nothing: the sums start at +0.0f and can never become -0.0f.
+        struct __attribute__((packed, aligned(8))) Rec40 { float2 v[5]; };   // 40 bytes, 8-byte aligned: 16 + 16 + 8-byte loads
+        uint32_t f = (ntile && off < n_inst) ? flags[off] : 0u;
         for (uint32_t k = 0; k < ntile; k++) {
             if (off + k >= n_inst) break;                   // sync-free mode after an overflow: instances beyond the buffers do not exist
-            const uint32_t f = flags[off + k];
-            if (!f) continue;
+            const uint32_t fn = (k + 1u < ntile && off + k + 1u < n_inst) ? flags[off + k + 1u] : 0u;
+            if (f) {
+                const Rec40 *base = reinterpret_cast<const Rec40 *>(part) + (size_t)(off + k) * 4;
+                const uint32_t dq = (uint32_t)(__ffs((int)f) - 1) >> 3;
+                Rec40 rr[4];
+                bool on[4];
 #pragma unroll
-            for (uint32_t qd = 0; qd < 4; qd++) {
-                if (!((f >> (8 * qd)) & 0xFFu)) continue;
-                // one 40-byte record, 8-byte aligned: 16 + 16 + 8-byte loads (three requests per lane instead of five)
-                struct __attribute__((packed, aligned(8))) Rec40 { float2 v[5]; };
-                const Rec40 rr = *(reinterpret_cast<const Rec40 *>(part) + ((size_t)(off + k) * 4 + qd));
-                const float2 p0 = rr.v[0], p1 = rr.v[1], p2 = rr.v[2], p3 = rr.v[3], p4 = rr.v[4];
-                g0.x += p0.x; g0.y += p0.y; g0.z += p1.x; g0.w += p1.y;
-                g1.x += p2.x; g1.y += p2.y; g1.z += p3.x; g1.w += p3.y;
-                g2.x += p4.x; g2.y += p4.y;
+                for (uint32_t qd = 0; qd < 4; qd++) { on[qd] = ((f >> (8 * qd)) & 0xFFu) != 0u; rr[qd] = base[on[qd] ? qd : dq]; }
+#pragma unroll
+                for (uint32_t qd = 0; qd < 4; qd++) {
+                    const float2 p0 = rr[qd].v[0], p1 = rr[qd].v[1], p2 = rr[qd].v[2], p3 = rr[qd].v[3], p4 = rr[qd].v[4];
+                    g0.x += on[qd] ? p0.x : 0.f; g0.y += on[qd] ? p0.y : 0.f; g0.z += on[qd] ? p1.x : 0.f; g0.w += on[qd] ? p1.y : 0.f;
+                    g1.x += on[qd] ? p2.x : 0.f; g1.y += on[qd] ? p2.y : 0.f; g1.z += on[qd] ? p3.x : 0.f; g1.w += on[qd] ? p3.y : 0.f;
+                    g2.x += on[qd] ? p4.x : 0.f; g2.y += on[qd] ? p4.y : 0.f;
+                }
             }
+            f = fn;
         }
     } else {
         g0 = grec[q * 3 + 0]; g1 = grec[q * 3 + 1]; g2 = grec[q * 3 + 2];
@@ -624,7 +635,8 @@ __global__ __launch_bounds__(kPreThreads) void preprocess_bwd_kernel(SGR_BWD_ARG
 
 // colors_precomp path, views_per_subject = VPS in {2, 4, .., 256}: thread t of a workgroup = (view t / GPB, Gaussian t % GPB) with
 // GPB = 256 / VPS Gaussians per workgroup (view-major, so the 16-byte rect records of a wave's lanes are contiguous per view)
-__global__ __launch_bounds__(kPreThreads) void preprocess_bwd_lanes_kernel(SGR_BWD_ARGS) {
+// (five waves per SIMD: the gather lives on memory latency, 96 VGPRs instead of 98 buy a fifth wave -- 0.368 -> 0.348 ms at C3; six spill: 0.45)
+__global__ __launch_bounds__(kPreThreads) __attribute__((amdgpu_waves_per_eu(5))) void preprocess_bwd_lanes_kernel(SGR_BWD_ARGS) {
     __shared__ float acc[13][kPreThreads];
     const int subj = blockIdx.y, vps = pb.views_per_subject, gpb = kPreThreads / vps;
     const int t = threadIdx.x, vv = t / gpb, gl = t - vv * gpb;
