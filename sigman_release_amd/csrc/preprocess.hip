@@ -422,12 +422,12 @@ __device__ __forceinline__ void bwd_view(const SgrProblem &pb, int view, int i, 
     out.op = 0.f;
     const size_t q = (size_t)view * pb.P + i;
     float *g2out = dL_dmeans2D ? dL_dmeans2D + q * 3 : nullptr;      // (NULL: nobody wants dL/dNDC)
+    const uint4 r3 = part ? rect[q] : make_uint4(0u, 0u, 0u, 0u);   // requested beside the radius, not behind it (one round trip less)
     if (!(radii[q] > 0)) { if (g2out) { g2out[0] = g2out[1] = g2out[2] = 0.f; } return; }
     float4 g0, g1, g2;
     if (part) {
         // deterministic gather of the bucket-parallel backward's partial records: one per (tile instance, quadrant),
         // summed in tile order then quadrant order -- no atomics anywhere in the backward
-        const uint4 r3 = rect[q];
         const uint32_t off = r3.w, rmin = r3.x, rmax = r3.y;
         const uint32_t ntile = ((rmax & 0xFFFFu) - (rmin & 0xFFFFu)) * ((rmax >> 16) - (rmin >> 16));
         g0 = make_float4(0.f, 0.f, 0.f, 0.f); g1 = g0; g2 = g0;
