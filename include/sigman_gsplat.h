@@ -229,6 +229,10 @@ int sgr_set_forward_mode(int mode);
  * loops over the views), 1 = always the loop.  Both give bit-identical gradients. */
 int sgr_set_backward_gather(int mode);
 
+/* F1: views one workgroup of sgr_preprocess_forward walks with its Gaussians held in registers: 0 = automatic (default: up to 8, as many
+ * as leave >= 4096 workgroups), n >= 1 = exactly n (dev/test override).  The outputs do not depend on it. */
+int sgr_set_preprocess_view_group(int n);
+
 /* checkpoint layout of the auxiliary forward outputs: 0 = automatic (default: "rows" unless that allocation would exceed
  * SIGMAN_AUX_ROWS_MAX_BYTES, 8 GiB if unset), 1 = compact, 2 = rows.  sgr_rasterize_forward records its choice in state->with_aux. */
 int sgr_set_aux_layout(int mode);

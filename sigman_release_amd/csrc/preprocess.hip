@@ -313,7 +313,7 @@ __global__ __launch_bounds__(kPreThreads) void preprocess_fwd_kernel(SgrProblem 
 }
 
 // -------------------------------------------------------------------------------------------------
-// F2: exclusive scan of the per-block tile counts (n is small: n_views * ceil(P/256)), one workgroup.
+// F2: exclusive scan of the per-block tile counts (n = n_views * ceil(P/256)), one workgroup per 8192 counts.
 // out[0..n) = exclusive prefix, out[n] = total (also stored as u64 in *num_rendered).
 // -------------------------------------------------------------------------------------------------
 constexpr uint32_t kScanTile = 8192;                              // counts per workgroup of the scan (8 consecutive per thread)
@@ -710,6 +710,9 @@ int validate_problem(const SgrProblem *pb) {
 
 int sgr_validate_problem(const SgrProblem *pb) { return validate_problem(pb); }
 
+static int g_view_group = 0;
+extern "C" int sgr_set_preprocess_view_group(int n) { g_view_group = n > 0 ? n : 0; return 0; }
+
 extern "C" int32_t sgr_preprocess_blocks_per_view(int32_t P) { return P <= 0 ? 1 : (P + kPreThreads - 1) / kPreThreads; }
 
 // skip_scan: leave the per-workgroup counts un-scanned behind block_offsets; sgr_bin_ex(self_scan = true) folds F2 into F3
@@ -723,9 +726,11 @@ int sgr_preprocess_forward_ex(const SgrProblem *pb, float *rec, int32_t *radii, 
     // the un-scanned block sums live in the upper half of a caller buffer? no: scan in place is unsafe with
     // chunked reads, so the sums are staged right behind the offsets (caller allocates 2*(n+1) entries).
     uint32_t *sums = block_offsets + (n + 1);
-    // views per workgroup: as many as keep >= 4096 workgroups in flight, at most 8, never across a subject boundary's worth of reloads
+    // views per workgroup: as many as keep >= 4096 workgroups in flight, at most 8 and at most a subject's views (a group that straddles
+    // two subjects reloads its Gaussians at the boundary)
     int vpw = 1;
     while (vpw < 8 && vpw * 2 <= pb->views_per_subject && (size_t)nbx * ((pb->n_views + vpw * 2 - 1) / (vpw * 2)) >= 4096) vpw *= 2;
+    if (g_view_group > 0) vpw = g_view_group < pb->n_views ? g_view_group : pb->n_views;
     dim3 grid(nbx, (pb->n_views + vpw - 1) / vpw);
     { SgrProfScope _p(SGR_K_PREPROCESS_FWD, stream);
     hipLaunchKernelGGL(preprocess_fwd_kernel, grid, dim3(kPreThreads), 0, stream, *pb, vpw, (float4 *)rec, radii, (uint4 *)rect,
