@@ -229,6 +229,11 @@ int sgr_set_forward_mode(int mode);
  * loops over the views), 1 = always the loop.  Both give bit-identical gradients. */
 int sgr_set_backward_gather(int mode);
 
+/* sgr_rasterize_forward*: 0 (default) = when the binning ends in the register per-tile sort, only the point list is stored -- the sorted keys
+ * have no reader behind that sort (the tile ranges come from the tile pass); 1 = keep the sorted keys in the binning blob as well
+ * (debug / parity tests).  Returns the previous setting.  sgr_bin itself always returns sorted keys. */
+int sgr_set_keep_sorted_keys(int keep);
+
 /* F1: views one workgroup of sgr_preprocess_forward walks with its Gaussians held in registers: 0 = automatic (default: up to 8, as many
  * as leave >= 4096 workgroups), n >= 1 = exactly n (dev/test override).  The outputs do not depend on it. */
 int sgr_set_preprocess_view_group(int n);

@@ -66,6 +66,7 @@ _SIGNATURES = {
     "sgr_set_aux_layout": (C.c_int, [C.c_int]),
     "sgr_set_backward_gather": (C.c_int, [C.c_int]),
     "sgr_set_preprocess_view_group": (C.c_int, [C.c_int]),
+    "sgr_set_keep_sorted_keys": (C.c_int, [C.c_int]),
     "sgr_set_graphs": (C.c_int, [C.c_int]),
     "sgr_set_debug": (C.c_int, [C.c_int]),
     "sgr_set_sort_mode": (C.c_int, [C.c_int]),

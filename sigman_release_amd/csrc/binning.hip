@@ -976,7 +976,7 @@ __device__ __forceinline__ void sgr_sort_tile_regs64(const uint64_t *__restrict_
 #pragma unroll
     for (int r = 0; r < IPT; r++) {
         const uint32_t e = wbase + (uint32_t)r * 64u + lane;
-        if (e < n) { ok[e] = ((uint64_t)tile << 32) | (a[r] >> 32); ov[e] = (uint32_t)a[r]; }
+        if (e < n) { if (ok) ok[e] = ((uint64_t)tile << 32) | (a[r] >> 32); ov[e] = (uint32_t)a[r]; }
     }
 }
 
@@ -990,7 +990,10 @@ struct TileWork4 { TileWork w[6]; };        // [m], m = 0..4: tiles with <= 1024
 template <int NW>
 __global__ __launch_bounds__(64 * NW) void tile_sort_regs_kernel(const uint2 *__restrict__ ranges, uint64_t *__restrict__ src_comp,
                                                                  uint32_t *__restrict__ src_scratch, uint64_t *__restrict__ dst_keys,
-                                                                 uint32_t *__restrict__ dst_vals, TileWork4 tw, int m_hi, int m_lo, SortPrep prep) {
+                                                                 uint32_t *__restrict__ dst_vals, TileWork4 tw, int m_hi, int m_lo, SortPrep prep,
+                                                                 int keep_keys) {
+    // keep_keys == 0: only the point list is stored (the sorted keys have no reader behind the per-tile sort: the ranges come from the
+    // tile pass); the global-memory fallback for oversize tiles writes both regardless
     __shared__ uint64_t xbuf[NW * 64 * 17];                                      // per wave 64 x (16 + 1) composites: exchange + final re-deal
     __shared__ uint32_t s_item, s_next;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -1052,7 +1055,7 @@ __global__ __launch_bounds__(64 * NW) void tile_sort_regs_kernel(const uint2 *__
             if (grp < take && wi < nwork) {
                 const uint32_t tile = w.list[wi];
                 const uint2 range = ranges[tile];
-                sgr_sort_tile_regs64<16>(src_comp + range.x, dst_keys + range.x, dst_vals + range.x, range.y - range.x, tile, lane, sub, nw, gx);
+                sgr_sort_tile_regs64<16>(src_comp + range.x, keep_keys ? dst_keys + range.x : nullptr, dst_vals + range.x, range.y - range.x, tile, lane, sub, nw, gx);
             } else {
 #pragma nounroll
                 for (int b = 0; b < n_barriers; b++) __syncthreads();
@@ -1093,8 +1096,9 @@ __global__ __launch_bounds__(64 * NW) void tile_sort_regs_kernel(const uint2 *__
             const uint2 range = ranges[tile];
             const uint32_t n = range.y - range.x;
             if (n == 0u) continue;
-            if (n <= 256u) sgr_sort_tile_regs64<4>(src_comp + range.x, dst_keys + range.x, dst_vals + range.x, n, tile, lane, 0u, 1, gx);
-            else sgr_sort_tile_regs64<16>(src_comp + range.x, dst_keys + range.x, dst_vals + range.x, n, tile, lane, 0u, 1, gx);
+            uint64_t *okp = keep_keys ? dst_keys + range.x : nullptr;
+            if (n <= 256u) sgr_sort_tile_regs64<4>(src_comp + range.x, okp, dst_vals + range.x, n, tile, lane, 0u, 1, gx);
+            else sgr_sort_tile_regs64<16>(src_comp + range.x, okp, dst_vals + range.x, n, tile, lane, 0u, 1, gx);
         }
         if (dealt >= nwork) break;                                               // the static round covered the class
         const uint32_t left = nwork - min(nwork, base + want);
@@ -1419,7 +1423,7 @@ int sgr_bin_ex(const SgrProblem *pb, const int32_t *radii, uint32_t *rect,
                uint64_t *keys_b, uint32_t *vals_a, uint32_t *vals_b, void *workspace, size_t workspace_bytes,
                uint32_t *ranges, int32_t *result_in_b_host, bool self_scan, uint64_t *nr_host, void *prep_desc, size_t prep_n_desc,
                uint32_t *prep_order, int *prep_done, uint32_t *const *clear_ptr /*[2] or NULL*/, const uint64_t *clear_words /*[2]*/,
-               int *clear_done /*[2]*/, bool first_index, void *stream_) {
+               int *clear_done /*[2]*/, bool first_index, bool sorted_keys, void *stream_) {
     if (sgr_validate_problem(pb)) return 1;
     hipStream_t stream = (hipStream_t)stream_;
     const int Tx = (pb->W + SGR_TILE - 1) / SGR_TILE, Ty = (pb->H + SGR_TILE - 1) / SGR_TILE;
@@ -1516,7 +1520,7 @@ int sgr_bin_ex(const SgrProblem *pb, const int32_t *radii, uint32_t *rect,
         TileWork4 tw4;
         for (int c = 0; c < 6; c++) tw4.w[c] = work(c);
         SortPrep none; none.desc = nullptr; none.n_desc = 0; none.order = nullptr; none.tiles_total = 0; none.enabled = 0;
-        hipLaunchKernelGGL(tile_sort_regs_kernel<16>, dim3(grid(1)), dim3(1024), 0, stream, rg, kout, vout, kin, vin, tw4, 4, 0, none);
+        hipLaunchKernelGGL(tile_sort_regs_kernel<16>, dim3(grid(1)), dim3(1024), 0, stream, rg, kout, vout, kin, vin, tw4, 4, 0, none, sorted_keys ? 1 : 0);
         SGR_CHECK_LAUNCH("tile_sort_regs_kernel");
         }
         if (result_in_b_host) *result_in_b_host = (kin == keys_b) ? 1 : 0;
@@ -1539,7 +1543,7 @@ int sgr_bin_ex(const SgrProblem *pb, const int32_t *radii, uint32_t *rect,
         sp.enabled = (prep_order || prep_desc) ? 1 : 0;
         const uint32_t g = (uint32_t)(tiles_total < 256 ? tiles_total : 256);
         hipLaunchKernelGGL(tile_sort_regs_kernel<16>, dim3(g + (sp.enabled ? 1u : 0u)), dim3(1024), 0, stream, (const uint2 *)ranges, kout, vout, kin, vin,
-                           tw4, 4, 0, sp);
+                           tw4, 4, 0, sp, sorted_keys ? 1 : 0);
         if (sp.enabled && prep_done) *prep_done = 1;
         SGR_CHECK_LAUNCH("tile_sort_regs_kernel");
         }
@@ -1652,5 +1656,5 @@ extern "C" int sgr_bin(const SgrProblem *pb, const int32_t *radii, uint32_t *rec
                        uint64_t *keys_b, uint32_t *vals_a, uint32_t *vals_b, void *workspace, size_t workspace_bytes,
                        uint32_t *ranges, int32_t *result_in_b_host, void *stream_) {
     return sgr_bin_ex(pb, radii, rect, block_offsets, R, num_rendered_dev, keys_a, keys_b, vals_a, vals_b, workspace,
-                      workspace_bytes, ranges, result_in_b_host, false, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, /*first_index=*/true, stream_);
+                      workspace_bytes, ranges, result_in_b_host, false, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, /*first_index=*/true, /*sorted_keys=*/true, stream_);
 }

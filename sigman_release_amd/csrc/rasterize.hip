@@ -42,13 +42,17 @@ std::mutex g_graph_mu;           // the cache below is process-global: forwards 
 }  // namespace
 
 int sgr_prof_active();
+// 0 (default): a fused forward whose binning ends in the register per-tile sort stores only the point list -- the sorted keys have no
+// reader behind that sort (the tile ranges come from the tile pass); 1: keep them (forward_debug / the parity tests look at them)
+static int g_keep_sorted_keys = 0;
+extern "C" int sgr_set_keep_sorted_keys(int keep) { const int old = g_keep_sorted_keys; g_keep_sorted_keys = keep ? 1 : 0; return old; }
 int sgr_preprocess_forward_ex(const SgrProblem *pb, float *rec, int32_t *radii, uint32_t *rect, uint8_t *clamped, uint32_t *block_offsets,
                               uint64_t *num_rendered, uint64_t capacity, bool skip_scan, void *stream_);
 int sgr_bin_ex(const SgrProblem *pb, const int32_t *radii, uint32_t *rect, const uint32_t *block_offsets, uint64_t R,
                const uint64_t *num_rendered_dev, uint64_t *keys_a, uint64_t *keys_b, uint32_t *vals_a, uint32_t *vals_b, void *workspace,
                size_t workspace_bytes, uint32_t *ranges, int32_t *result_in_b_host, bool self_scan, uint64_t *nr_host, void *prep_desc,
                size_t prep_n_desc, uint32_t *prep_order, int *prep_done, uint32_t *const *clear_ptr, const uint64_t *clear_words,
-               int *clear_done, bool first_index, void *stream_);
+               int *clear_done, bool first_index, bool sorted_keys, void *stream_);
 int sgr_render_backward_ex(const SgrProblem *pb, const uint32_t *ranges, const uint32_t *point_list, const float *rec, const uint32_t *rect, const float *final_T,
                            const uint32_t *n_contrib, const float *out_color, const float *out_depth, const float *out_alpha,
                            const float *grad_color, const float *grad_depth, const float *grad_alpha, const float *grad_color_scale,
@@ -116,7 +120,7 @@ static int forward_launches(const SgrProblem *pb, uint64_t capacity, uint64_t R,
                    binning + st->off_sort_ws, (size_t)sgr_bin_workspace_bytes(R, (uint64_t)((pb->W + SGR_TILE - 1) / SGR_TILE) * ((pb->H + SGR_TILE - 1) / SGR_TILE) * pb->n_views),
                    (uint32_t *)(image + st->off_ranges), &in_b, self_scan, self_scan ? nr_pinned_host : nullptr,
                    want_prep && aux_on ? image + st->off_desc : nullptr, n_desc, want_prep ? (uint32_t *)(image + st->off_order) : nullptr,
-                   &prep_done, clear_ptr, clear_words, clear_done, /*first_index=*/aux_on, stream)) return 1;
+                   &prep_done, clear_ptr, clear_words, clear_done, /*first_index=*/aux_on, /*sorted_keys=*/g_keep_sorted_keys != 0, stream)) return 1;
     st->flags_cleared = clear_done[0];
     if (caller_clear && caller_clear_bytes && !clear_done[1]) SGR_CHECK_HIP(hipMemsetAsync(caller_clear, 0, (size_t)caller_clear_bytes, stream));
     st->result_in_b = in_b;
@@ -223,7 +227,7 @@ extern "C" int sgr_rasterize_forward(const SgrProblem *pb, uint64_t capacity, in
         std::lock_guard<std::mutex> graph_lock(g_graph_mu);
         FwdKey key;
         memset(&key, 0, sizeof(key));
-        key.pb = *pb; key.capacity = capacity; key.with_aux = st->with_aux; key.fwd_mode = sgr_get_forward_mode();
+        key.pb = *pb; key.capacity = capacity; key.with_aux = st->with_aux; key.fwd_mode = sgr_get_forward_mode() | (g_keep_sorted_keys << 8);
         key.color = out_color; key.depth = out_depth; key.alpha = out_alpha; key.radii = out_radii; key.nr_host = nullptr;
         key.geom = geom; key.binning = binning; key.image = image; key.stream = nullptr;
         key.clear = caller_clear; key.clear_bytes = caller_clear_bytes;

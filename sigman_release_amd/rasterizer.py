@@ -667,9 +667,13 @@ def forward_debug(means3D, opacities, *, colors_precomp=None, shs=None, cov3D_pr
         st = settings._replace(viewmatrix=_f32c(settings.viewmatrix), projmatrix=_f32c(settings.projmatrix),
                                campos=_f32c(settings.campos), bg=_f32c(settings.bg))
         opt = lambda t: None if t is None else _f32c(t)
-        color, radii, depth, alpha, c = _forward_impl(_f32c(means3D), _f32c(opacities).reshape(S, P), opt(colors_precomp),
-                                                      opt(shs), opt(cov3D_precomp), opt(scales), opt(rotations), st,
-                                                      need_ctx=True, with_aux=False)
+        old_keep = _cabi.lib().sgr_set_keep_sorted_keys(1)          # the production forward stores only the point list behind the register sort
+        try:
+            color, radii, depth, alpha, c = _forward_impl(_f32c(means3D), _f32c(opacities).reshape(S, P), opt(colors_precomp),
+                                                          opt(shs), opt(cov3D_precomp), opt(scales), opt(rotations), st,
+                                                          need_ctx=True, with_aux=False)
+        finally:
+            _cabi.lib().sgr_set_keep_sorted_keys(old_keep)
         nv = st.viewmatrix.shape[0]
         H, W = int(st.image_height), int(st.image_width)
         tiles = ((W + 15) // 16) * ((H + 15) // 16)
