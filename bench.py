@@ -122,9 +122,9 @@ HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8
 CONFIGS = {
     "c2": dict(P=100_000, size=512, subjects=1, bwd=True, da=False, scaling="weak", steps=200, warmup=20,
                label="C2: procedural humanoid (SMPL-X stand-in)"),
-    "c3": dict(P=100_000, size=512, subjects=8, bwd=True, da=False, scaling="strong", steps=20, warmup=4,
+    "c3": dict(P=100_000, size=512, subjects=8, bwd=True, da=False, scaling="strong", steps=40, warmup=10,
                label="C3: VAE render-loss step, 8 subjects x 8 views"),
-    "c4": dict(P=200_000, size=1024, subjects=1, bwd=False, da=False, scaling="strong", steps=10, warmup=3,
+    "c4": dict(P=200_000, size=1024, subjects=1, bwd=False, da=False, scaling="strong", steps=20, warmup=6,
                label="C4: decode path, 90-view orbit, forward only"),
     "c5": dict(P=1_000_000, size=512, subjects=1, bwd=True, da=True, scaling="weak", steps=30, warmup=5,
                label="C5: 1M-Gaussian stress (10 jittered layers), depth+alpha gradients on"),
