@@ -1098,6 +1098,7 @@ __global__ __launch_bounds__(64 * NW) void tile_sort_regs_kernel(const uint2 *__
             if (n == 0u) continue;
             uint64_t *okp = keep_keys ? dst_keys + range.x : nullptr;
             if (n <= 256u) sgr_sort_tile_regs64<4>(src_comp + range.x, okp, dst_vals + range.x, n, tile, lane, 0u, 1, gx);
+            else if (n <= 512u) sgr_sort_tile_regs64<8>(src_comp + range.x, okp, dst_vals + range.x, n, tile, lane, 0u, 1, gx);
             else sgr_sort_tile_regs64<16>(src_comp + range.x, okp, dst_vals + range.x, n, tile, lane, 0u, 1, gx);
         }
         if (dealt >= nwork) break;                                               // the static round covered the class
