@@ -10,7 +10,7 @@ import csv, glob, json, re, statistics, subprocess, sys
 GROUPS = [  # (bench kernel id name, regex over rocprof kernel names)
     ("preprocess_fwd", r"preprocess_fwd_kernel"), ("scan_block_sums", r"scan_block_sums_kernel"), ("duplicate_keys", r"duplicate_keys_kernel"),
     ("radix_sort(all passes)", r"(wide_|radix_|vseg_|tile_sort)"), ("tile_ranges", r"tile_ranges_kernel"),
-    ("render_fwd", r"(render_fwd|fwd_prepare)"), ("render_bwd", r"render_bwd"), ("preprocess_bwd", r"preprocess_bwd_kernel"),
+    ("render_fwd", r"(render_fwd|fwd_prepare)"), ("render_bwd", r"render_bwd"), ("preprocess_bwd", r"preprocess_bwd(_lanes)?_kernel"),
     ("clamped_l1", r"clamped_l1_kernel"),
 ]
 
