@@ -106,6 +106,8 @@ def lib():
             raise RuntimeError(f"ABI version mismatch: library reports {L.sgr_abi_version()}, binding expects 3")
         if os.environ.get("SIGMAN_GRAPHS", "0") in ("1", "2"):    # opt-in hipGraph replay of the forward chain (include/sigman_gsplat.h, sgr_set_graphs)
             L.sgr_set_graphs(int(os.environ["SIGMAN_GRAPHS"]))
+        if os.environ.get("SIGMAN_SORT_MODE", "") in ("0", "1", "2", "4", "5"):  # A/B knob: sort flavour (sgr_set_sort_mode)
+            L.sgr_set_sort_mode(int(os.environ["SIGMAN_SORT_MODE"]))
         if os.environ.get("SIGMAN_FWD_MODE", "") in ("1", "2", "3"):      # A/B knob: forward compositing kernel (sgr_set_forward_mode)
             L.sgr_set_forward_mode(int(os.environ["SIGMAN_FWD_MODE"]))
         _lib = L
