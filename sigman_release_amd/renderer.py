@@ -19,7 +19,7 @@ import torch
 from . import _cabi
 from .rasterizer import BatchedRasterizationSettings, _f32c, _ptr, _stream, rasterize_gaussians_batched
 
-_KNN_MAX_CELLS = 1 << 21      # upper bound of the uniform grid; the grid actually used is bounded by 8 cells per point
+_KNN_MAX_CELLS = 1 << 21      # upper bound of the uniform grid; the grid actually used is bounded by 16 cells per point
 
 
 def dist_cuda2(points: torch.Tensor) -> torch.Tensor:
@@ -32,7 +32,7 @@ def dist_cuda2(points: torch.Tensor) -> torch.Tensor:
     batched = pts.ndim == 3
     B, P = (pts.shape[0], pts.shape[1]) if batched else (1, pts.shape[0])
     out = torch.empty(B, P, dtype=torch.float32, device=pts.device)
-    max_cells = min(_KNN_MAX_CELLS, max(8 * P, 4096))        # the cell counters are cleared every call: keep them proportional to P
+    max_cells = min(_KNN_MAX_CELLS, max(16 * P, 4096))        # the cell counters are cleared every call: keep them proportional to P
     stride = (L.sgr_knn_workspace_bytes(P, max_cells) + 255) // 256 * 256
     ws = torch.empty(stride * B, dtype=torch.uint8, device=pts.device)
     _cabi.check(L.sgr_knn_dist2_batched(B, P, _ptr(pts), _ptr(out), _ptr(ws), stride * B, max_cells, _stream(pts.device)), "sgr_knn_dist2")
