@@ -214,6 +214,13 @@ __device__ __forceinline__ void push3(float d, float &b0, float &b1, float &b2) 
     }
 }
 
+// branch-free sorted insert (the same three smallest as push3: nested branches cost more than five min/max in the divergent loops below)
+__device__ __forceinline__ void offer3(float d, float &b0, float &b1, float &b2) {
+    const float t0 = fminf(b0, d); d = fmaxf(b0, d); b0 = t0;
+    const float t1 = fminf(b1, d); d = fmaxf(b1, d); b1 = t1;
+    b2 = fminf(b2, d);
+}
+
 __global__ __launch_bounds__(kT) void knn3_kernel(KnnBatch kb) {
     const KnnSet ks = knn_set(kb, blockIdx.y);
     const int P = kb.P; const Grid *gp = ks.grid; const uint32_t *cell_start = ks.cell_start; const float4 *sorted = ks.sorted; float *out = ks.out;
@@ -239,10 +246,10 @@ __global__ __launch_bounds__(kT) void knn3_kernel(KnnBatch kb) {
                 if (!inner) {
                     const uint32_t lo = cell_start[row + xa], hi = cell_start[row + xb + 1];
                     for (uint32_t k = lo; k < hi; k++) {
-                        if ((int)k == s) continue;
                         const float4 o = sorted[k];
                         const float dx = o.x - me.x, dy = o.y - me.y, dz = o.z - me.z;
-                        push3(dx * dx + dy * dy + dz * dz, b0, b1, b2);
+                        const float d = dx * dx + dy * dy + dz * dz;
+                        offer3((int)k == s ? 3.0e38f : d, b0, b1, b2);
                     }
                 } else {
 #pragma unroll
@@ -253,7 +260,7 @@ __global__ __launch_bounds__(kT) void knn3_kernel(KnnBatch kb) {
                         for (uint32_t k = lo; k < hi; k++) {
                             const float4 o = sorted[k];
                             const float dx = o.x - me.x, dy = o.y - me.y, dz = o.z - me.z;
-                            push3(dx * dx + dy * dy + dz * dz, b0, b1, b2);
+                            offer3(dx * dx + dy * dy + dz * dz, b0, b1, b2);
                         }
                     }
                 }
