@@ -221,16 +221,23 @@ __device__ __forceinline__ void offer3(float d, float &b0, float &b1, float &b2)
     b2 = fminf(b2, d);
 }
 
+constexpr int kKnnLanes = 4;                       // lanes per query point
+
 __global__ __launch_bounds__(kT) void knn3_kernel(KnnBatch kb) {
+    // kKnnLanes lanes per query point, each taking every kKnnLanes-th x-row of the cube shell (the walk is a serial chain of short
+    // divergent loops: what it lacks at 100 000 points is waves, 1.5 per SIMD with one lane per point).  Every lane keeps its own three
+    // smallest distances; after a shell the group's three smallest are found by butterfly exchanges (disjoint candidate sets: no
+    // distance is counted twice) and lane 0 carries them on.  The three smallest of a set do not depend on the order of insertion.
     const KnnSet ks = knn_set(kb, blockIdx.y);
     const int P = kb.P; const Grid *gp = ks.grid; const uint32_t *cell_start = ks.cell_start; const float4 *sorted = ks.sorted; float *out = ks.out;
-    const int s = blockIdx.x * kT + threadIdx.x;      // walk points in CELL order: neighbouring threads search the same cells
-    if (s >= P) return;
+    const int s = (blockIdx.x * kT + threadIdx.x) / kKnnLanes;      // points in CELL order: neighbouring groups search the same cells
+    const int j = threadIdx.x % kKnnLanes;
+    if (s >= P) return;                                            // (whole groups leave together)
     const Grid g = *gp;
     const float4 me = sorted[s];
     int cx, cy, cz;
     cell_of(g, me.x, me.y, me.z, cx, cy, cz);
-    float b0 = 3.0e38f, b1 = 3.0e38f, b2 = 3.0e38f;
+    float b0 = 3.0e38f, b1 = 3.0e38f, b2 = 3.0e38f;               // this lane's candidates (lane 0: plus everything found in earlier shells)
     const int rmax = max(g.gx, max(g.gy, g.gz));
     // Growing cubes of Chebyshev radius r = 1, 2, ... around the point's cell.  Cells are stored x-fastest, so a whole x-row of
     // the cube is ONE contiguous run of `sorted` (2 boundary loads, then a streaming loop); rows that were already covered by
@@ -239,35 +246,45 @@ __global__ __launch_bounds__(kT) void knn3_kernel(KnnBatch kb) {
         const int z0 = max(0, cz - r), z1 = min(g.gz - 1, cz + r);
         const int y0 = max(0, cy - r), y1 = min(g.gy - 1, cy + r);
         const int xa = max(0, cx - r), xb = min(g.gx - 1, cx + r);
-        for (int z = z0; z <= z1; z++)
-            for (int y = y0; y <= y1; y++) {
-                const int row = (z * g.gy + y) * g.gx;
-                const bool inner = r > 1 && abs(y - cy) < r && abs(z - cz) < r;
-                if (!inner) {
-                    const uint32_t lo = cell_start[row + xa], hi = cell_start[row + xb + 1];
+        const int ny = y1 - y0 + 1, nrows = ny * (z1 - z0 + 1);
+        for (int ri = j; ri < nrows; ri += kKnnLanes) {
+            const int z = z0 + ri / ny, y = y0 + ri % ny;
+            const int row = (z * g.gy + y) * g.gx;
+            const bool inner = r > 1 && abs(y - cy) < r && abs(z - cz) < r;
+            if (!inner) {
+                const uint32_t lo = cell_start[row + xa], hi = cell_start[row + xb + 1];
+                for (uint32_t k = lo; k < hi; k++) {
+                    const float4 o = sorted[k];
+                    const float dx = o.x - me.x, dy = o.y - me.y, dz = o.z - me.z;
+                    const float d = dx * dx + dy * dy + dz * dz;
+                    offer3((int)k == s ? 3.0e38f : d, b0, b1, b2);
+                }
+            } else {
+#pragma unroll
+                for (int side = 0; side < 2; side++) {
+                    const int x = side ? cx + r : cx - r;
+                    if (x < 0 || x >= g.gx) continue;
+                    const uint32_t lo = cell_start[row + x], hi = cell_start[row + x + 1];
                     for (uint32_t k = lo; k < hi; k++) {
                         const float4 o = sorted[k];
                         const float dx = o.x - me.x, dy = o.y - me.y, dz = o.z - me.z;
-                        const float d = dx * dx + dy * dy + dz * dz;
-                        offer3((int)k == s ? 3.0e38f : d, b0, b1, b2);
-                    }
-                } else {
-#pragma unroll
-                    for (int side = 0; side < 2; side++) {
-                        const int x = side ? cx + r : cx - r;
-                        if (x < 0 || x >= g.gx) continue;
-                        const uint32_t lo = cell_start[row + x], hi = cell_start[row + x + 1];
-                        for (uint32_t k = lo; k < hi; k++) {
-                            const float4 o = sorted[k];
-                            const float dx = o.x - me.x, dy = o.y - me.y, dz = o.z - me.z;
-                            offer3(dx * dx + dy * dy + dz * dz, b0, b1, b2);
-                        }
+                        offer3(dx * dx + dy * dy + dz * dz, b0, b1, b2);
                     }
                 }
             }
+        }
+        // the group's three smallest: butterfly over its lanes (every lane ends up with them)
+        float m0 = b0, m1 = b1, m2 = b2;
+#pragma unroll
+        for (int off = 1; off < kKnnLanes; off <<= 1) {
+            const float o0 = __shfl_xor(m0, off, 64), o1 = __shfl_xor(m1, off, 64), o2 = __shfl_xor(m2, off, 64);
+            offer3(o0, m0, m1, m2); offer3(o1, m0, m1, m2); offer3(o2, m0, m1, m2);
+        }
+        if (j == 0) { b0 = m0; b1 = m1; b2 = m2; } else { b0 = b1 = b2 = 3.0e38f; }
         const float safe = (float)r * g.cell * 0.9999f;            // every unsearched point is at least this far away
-        if (b2 <= safe * safe) break;
+        if (m2 <= safe * safe) break;                              // (group-uniform)
     }
+    if (j != 0) return;
     // fewer than 4 points in total: missing neighbours count as distance 0 (upstream initialises its best[] to FLT_MAX
     // and would return garbage; P < 4 never happens on the reference path)
     if (b2 > 1.0e38f) b2 = 0.f;
@@ -363,7 +380,7 @@ extern "C" int sgr_knn_dist2_batched(int32_t n_sets, int32_t P, const float *poi
     hipLaunchKernelGGL(cell_scan_sums_kernel, dim3(1, n_sets), dim3(1024), 0, stream, kb);
     hipLaunchKernelGGL(cell_scan_kernel, dim3(scan_blocks, n_sets), dim3(kT), 0, stream, kb);
     hipLaunchKernelGGL(cell_scatter_kernel, dim3(nb, n_sets), dim3(kT), 0, stream, kb);
-    hipLaunchKernelGGL(knn3_kernel, dim3(nb, n_sets), dim3(kT), 0, stream, kb);
+    hipLaunchKernelGGL(knn3_kernel, dim3((unsigned)(((size_t)P * kKnnLanes + kT - 1) / kT), n_sets), dim3(kT), 0, stream, kb);
     SGR_CHECK_LAUNCH("knn kernels");
     return 0;
 }
