@@ -16,7 +16,8 @@ def _dev():
     return torch.device("cuda:0")
 
 
-@pytest.mark.parametrize("kind,P", [("humanoid", 20000), ("cloud", 5000), ("dups", 600), ("tiny", 5), ("line", 3000)])
+@pytest.mark.parametrize("kind,P", [("humanoid", 20000), ("humanoid", 100_003), ("cloud", 5000), ("dups", 600), ("tiny", 5), ("line", 3000),
+                                    ("outliers", 4001)])
 def test_dist_cuda2_exact_knn(kind, P):
     from scipy.spatial import cKDTree
     from sigman_release_amd.renderer import dist_cuda2
@@ -29,6 +30,10 @@ def test_dist_cuda2_exact_knn(kind, P):
         pts = np.repeat(rng.normal(size=(P // 4, 3)).astype(np.float32), 4, 0)       # every point has 3 exact duplicates
     elif kind == "tiny":
         pts = rng.normal(size=(P, 3)).astype(np.float32)
+    elif kind == "outliers":
+        # a dense blob and a few far, isolated points: their search grows through many shells (the lanes of a query share the shell's rows)
+        pts = (rng.normal(size=(P, 3)) * 0.05).astype(np.float32)
+        pts[::577] += rng.uniform(2.0, 4.0, size=(len(pts[::577]), 3)).astype(np.float32)
     else:
         pts = np.zeros((P, 3), np.float32); pts[:, 0] = np.sort(rng.uniform(0, 5, P))   # degenerate bbox (y,z extent 0)
     got = dist_cuda2(torch.from_numpy(pts).to(_dev())).cpu().numpy()
