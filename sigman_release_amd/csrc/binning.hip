@@ -326,7 +326,9 @@ __global__ __launch_bounds__(kThreads) void wide_downsweep_kernel(const uint64_t
     __shared__ uint32_t digit_base[kWide];
     __shared__ uint32_t wave_cnt[4][kWide];
     __shared__ uint32_t wtot[4];
+    __shared__ uint32_t s_wl[8];                                  // class worklist fill levels (workgroup 0 is the only one that appends)
     const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    if (t < 8) s_wl[t] = 0u;
     constexpr int PER = kWide / kThreads;                        // 8 consecutive digits per thread
     {   // exclusive scan of the 2048 digit totals + this workgroup's offset inside each digit; wave_cnt starts zeroed
         uint32_t v[PER], sum = 0;
@@ -354,7 +356,9 @@ __global__ __launch_bounds__(kThreads) void wide_downsweep_kernel(const uint64_t
                     if (v[j] && worklist) worklist[1 + atomicAdd(&worklist[0], 1u)] = d;
                 } else if (v[j]) {
                     const uint32_t m = v[j] <= 1024u ? 0u : (v[j] <= 2048u ? 1u : (v[j] <= 4096u ? 2u : (v[j] <= 8192u ? 3u : (v[j] <= 16384u ? 4u : 5u))));
-                    worklist[16u + m * tiles_total + atomicAdd(&worklist[m], 1u)] = d;
+                    // (LDS counters: the ~200 returning device-scope atomics on six words of one line were a serial chain on this
+                    // workgroup's way to its scatter)
+                    worklist[16u + m * tiles_total + atomicAdd(&s_wl[m], 1u)] = d;
                 }
             }
             run += v[j];
@@ -374,6 +378,7 @@ __global__ __launch_bounds__(kThreads) void wide_downsweep_kernel(const uint64_t
     }
     __syncthreads();
     if (!ORDERED) {
+        if (ranges && blockIdx.x == 0 && t < 6u) worklist[t] = s_wl[t];
 #pragma unroll
         for (int it = 0; it < ITEMS; it++) {
             const uint32_t k = base + it * kThreads + t;
