@@ -277,7 +277,7 @@ constexpr int kWideBits = 11, kWide = 1 << kWideBits;
 template <int ITEMS>
 __global__ __launch_bounds__(kThreads) void wide_upsweep_kernel(const uint64_t *__restrict__ keys, uint32_t n_host, const uint64_t *__restrict__ n_dev,
                                                                 int shift, uint32_t nblocks, uint32_t *__restrict__ hist) {
-    __shared__ uint32_t h[kWide];
+    __shared__ __attribute__((aligned(16))) uint32_t h[kWide];
     const uint32_t n = n_dev ? (uint32_t)min((uint64_t)n_host, *n_dev) : n_host;
     for (int d = threadIdx.x; d < kWide; d += kThreads) h[d] = 0;
     __syncthreads();
@@ -288,27 +288,33 @@ __global__ __launch_bounds__(kThreads) void wide_upsweep_kernel(const uint64_t *
         if (k < n) atomicAdd(&h[(uint32_t)(keys[k] >> shift) & (kWide - 1)], 1u);
     }
     __syncthreads();
-    for (int d = threadIdx.x; d < kWide; d += kThreads) hist[(size_t)d * nblocks + blockIdx.x] = h[d];
+    // block-major rows: one coalesced 8-KB store per workgroup (digit-major columns were 2048 scattered 4-byte stores each)
+    uint4 *row = reinterpret_cast<uint4 *>(hist + (size_t)blockIdx.x * kWide);
+    for (int d = threadIdx.x; d < kWide / 4; d += kThreads) row[d] = reinterpret_cast<const uint4 *>(h)[d];
 }
 
-// one wave per digit row (rows are ~200 entries at C2): 4 rows per workgroup, exclusive prefix in place + digit total
-__global__ __launch_bounds__(kThreads) void wide_rowscan_kernel(uint32_t *__restrict__ hist, uint32_t nblocks, uint32_t *__restrict__ totals) {
-    const uint32_t lane = threadIdx.x & 63, d = blockIdx.x * 4 + (threadIdx.x >> 6);
-    uint32_t *row = hist + (size_t)d * nblocks;
-    uint32_t carry = 0;
-    for (uint32_t base = 0; base < nblocks; base += 64) {
-        const uint32_t idx = base + lane;
-        const uint32_t v = idx < nblocks ? row[idx] : 0u;
-        uint32_t inc = v;
+// hist is block-major [nblocks][2048].  One workgroup of 1024 threads per group of 64 consecutive digits: lane = digit (a row's 64
+// counts are one 256-byte run), wave w walks the blocks w, w + 16, ..: per digit an exclusive prefix over the blocks in place + the
+// digit total.  Every wave first sums its blocks, the 16 partial sums per digit meet in LDS, then it rewrites its blocks with the
+// running prefix -- blocks interleave, so wave w's block b needs the sums of ALL waves over blocks < b: done in two phases over
+// contiguous block ranges instead (wave w owns blocks [w * per, (w + 1) * per)).
+__global__ __launch_bounds__(1024) void wide_rowscan_kernel(uint32_t *__restrict__ hist, uint32_t nblocks, uint32_t *__restrict__ totals) {
+    __shared__ uint32_t part[16][64];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, d = blockIdx.x * 64 + lane;
+    const uint32_t per = (nblocks + 15u) / 16u, b0 = min(nblocks, wave * per), b1 = min(nblocks, b0 + per);
+    uint32_t *col = hist + d;
+    constexpr int kMaxPer = 32;                                  // nblocks <= 512 on this path (<= 2^19 keys, 1024 per block)
+    uint32_t v[kMaxPer], sum = 0;
 #pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t nb = __shfl_up(inc, off, 64);
-            if (lane >= (uint32_t)off) inc += nb;
-        }
-        if (idx < nblocks) row[idx] = carry + inc - v;
-        carry += __shfl(inc, 63, 64);
-    }
-    if (lane == 0) totals[d] = carry;
+    for (int i = 0; i < kMaxPer; i++) { const uint32_t b = b0 + (uint32_t)i; v[i] = b < b1 ? col[(size_t)b * kWide] : 0u; sum += v[i]; }
+    part[wave][lane] = sum;
+    __syncthreads();
+    uint32_t run = 0, all = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < 16; w++) { const uint32_t x = part[w][lane]; if (w < wave) run += x; all += x; }
+#pragma unroll
+    for (int i = 0; i < kMaxPer; i++) { const uint32_t b = b0 + (uint32_t)i; if (b < b1) col[(size_t)b * kWide] = run; run += v[i]; }
+    if (wave == 0) totals[d] = all;
 }
 
 // ORDERED: stable (match-any ballots, three barriers per item), writes keys and values, one worklist of occupied tiles.
@@ -347,7 +353,7 @@ __global__ __launch_bounds__(kThreads) void wide_downsweep_kernel(const uint64_t
 #pragma unroll
         for (int j = 0; j < PER; j++) {
             const uint32_t d = t * PER + j;
-            digit_base[d] = run + hist[(size_t)d * nblocks + blockIdx.x];
+            digit_base[d] = run + hist[(size_t)blockIdx.x * kWide + d];
             // F5 for free: the digit IS the tile id, so the scanned totals are the tile ranges (and the occupied tiles the
             // per-tile sort's worklist, whose counter the duplicate kernel cleared)
             if (ranges && blockIdx.x == 0 && d < tiles_total) {
@@ -1541,7 +1547,7 @@ int sgr_bin_ex(const SgrProblem *pb, const int32_t *radii, uint32_t *rect,
         uint32_t *wl = (uint32_t *)((char *)workspace + sgr_bin_workspace_bytes(R, 0));     // [16 counters][6][tiles_total]
         { SgrProfScope _ps(SGR_K_SORT, stream);
         hipLaunchKernelGGL(wide_upsweep_kernel<kItemsSmall>, dim3(nblocks), dim3(kThreads), 0, stream, kin, n, num_rendered_dev, 32, nblocks, hist);
-        hipLaunchKernelGGL(wide_rowscan_kernel, dim3(kWide / 4), dim3(kThreads), 0, stream, hist, nblocks, hist + (size_t)nblocks * kWide);
+        hipLaunchKernelGGL(wide_rowscan_kernel, dim3(kWide / 64), dim3(1024), 0, stream, hist, nblocks, hist + (size_t)nblocks * kWide);
         hipLaunchKernelGGL((wide_downsweep_kernel<kItemsSmall, false>), dim3(nblocks), dim3(kThreads), 0, stream, kin, vin, kout, vout, n, num_rendered_dev, 32,
                            nblocks, hist, hist + (size_t)nblocks * kWide, (uint2 *)ranges, (uint32_t)tiles_total, wl);
         SGR_CHECK_LAUNCH("wide tile-bit pass");
@@ -1568,7 +1574,7 @@ int sgr_bin_ex(const SgrProblem *pb, const int32_t *radii, uint32_t *rect,
         { SgrProfScope _ps(SGR_K_SORT, stream);
         if (wide) {
             hipLaunchKernelGGL(wide_upsweep_kernel<kItemsSmall>, dim3(nblocks), dim3(kThreads), 0, stream, kin, n, num_rendered_dev, 32, nblocks, hist);
-            hipLaunchKernelGGL(wide_rowscan_kernel, dim3(kWide / 4), dim3(kThreads), 0, stream, hist, nblocks, hist + (size_t)nblocks * kWide);
+            hipLaunchKernelGGL(wide_rowscan_kernel, dim3(kWide / 64), dim3(1024), 0, stream, hist, nblocks, hist + (size_t)nblocks * kWide);
             hipLaunchKernelGGL((wide_downsweep_kernel<kItemsSmall, true>), dim3(nblocks), dim3(kThreads), 0, stream, kin, vin, kout, vout, n, num_rendered_dev, 32, nblocks, hist, hist + (size_t)nblocks * kWide,
                                (uint2 *)ranges, (uint32_t)tiles_total, worklist);
             SGR_CHECK_LAUNCH("wide tile-bit pass");
