@@ -131,8 +131,8 @@ __global__ __launch_bounds__(kT) void cell_count_kernel(KnnBatch kb) {
     atomicAdd(&cell_cnt[c], 1u);
 }
 
-// exclusive scan over the cells in three parallel steps (a fine grid has ~1e6 cells: one workgroup walking them serially
-// was the single most expensive kernel of the 3-NN): per-4096-cell block sums, scan of the <= 512 sums, local rescan + offset.
+// exclusive scan over the cells in two parallel steps (a fine grid has ~1e6 cells: one workgroup walking them serially
+// was the single most expensive kernel of the 3-NN): per-4096-cell block sums; local rescan + the sum of the block sums in front (every workgroup adds those <= 1024 values itself).
 // After it cell_start[c] = first slot of cell c and cell_start[ncell] = P.
 constexpr int kScanTile = 4096;
 
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(kT) void cell_blocksum_kernel(KnnBatch kb) {
     if (base >= n) return;
     uint32_t s = 0;
 #pragma unroll
-    for (int k = 0; k < kScanTile / kT; k++) { const uint32_t i = base + k * kT + threadIdx.x; if (i < n) s += data[i]; }
+    for (int k = 0; k < kScanTile / kT; k++) { const uint32_t i = base + k * kT + threadIdx.x; const uint32_t x = data[min(i, n - 1u)]; s += i < n ? x : 0u; }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
@@ -153,28 +153,10 @@ __global__ __launch_bounds__(kT) void cell_blocksum_kernel(KnnBatch kb) {
     if (threadIdx.x == 0) bsum[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 
-__global__ __launch_bounds__(1024) void cell_scan_sums_kernel(KnnBatch kb) {
-    const KnnSet ks = knn_set(kb, blockIdx.y);
-    const Grid *gp = ks.grid; uint32_t *bsum = ks.bsum;
-    __shared__ uint32_t wave_tot[16];
-    const uint32_t n = (uint32_t)(gp->gx * gp->gy * gp->gz) + 1u;
-    const uint32_t nb = (n + kScanTile - 1) / kScanTile;          // <= 1024 by construction (max_cells <= 2^22)
-    const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const uint32_t v = t < nb ? bsum[t] : 0u;
-    uint32_t inc = v;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) { const uint32_t x = __shfl_up(inc, off, 64); if (lane >= (uint32_t)off) inc += x; }
-    if (lane == 63) wave_tot[wave] = inc;
-    __syncthreads();
-    uint32_t pre = inc - v;
-    for (uint32_t w = 0; w < wave; w++) pre += wave_tot[w];
-    if (t < nb) bsum[t] = pre;
-}
-
 __global__ __launch_bounds__(kT) void cell_scan_kernel(KnnBatch kb) {
     const KnnSet ks = knn_set(kb, blockIdx.y);
     const Grid *gp = ks.grid; uint32_t *data = ks.cell_start; const uint32_t *bsum = ks.bsum;
-    __shared__ uint32_t wave_tot[4];
+    __shared__ uint32_t wave_tot[4], wave_pre[4];
     const uint32_t n = (uint32_t)(gp->gx * gp->gy * gp->gz) + 1u;
     const uint32_t base = blockIdx.x * kScanTile;
     if (base >= n) return;
@@ -183,14 +165,21 @@ __global__ __launch_bounds__(kT) void cell_scan_kernel(KnnBatch kb) {
     const uint32_t i0 = base + t * PER;
     uint32_t v[PER];
     uint32_t s = 0;
+    // (unconditional loads: cells past the end re-read the last one and are zeroed -- a predicated load is a branch and a wait of its own)
 #pragma unroll
-    for (int k = 0; k < PER; k++) { v[k] = (i0 + k < n) ? data[i0 + k] : 0u; s += v[k]; }
+    for (int k = 0; k < PER; k++) { const uint32_t x = data[min(i0 + (uint32_t)k, n - 1u)]; v[k] = (i0 + k < n) ? x : 0u; s += v[k]; }
+    // everything in front of this tile: the workgroup sums the (<= 1024) block sums before its own -- no scan kernel in between
+    uint32_t pre = 0;
+    for (uint32_t k = t; k < blockIdx.x; k += kT) pre += bsum[k];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) pre += __shfl_xor(pre, off, 64);
     uint32_t inc = s;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) { const uint32_t x = __shfl_up(inc, off, 64); if (lane >= (uint32_t)off) inc += x; }
     if (lane == 63) wave_tot[wave] = inc;
+    if (lane == 0) wave_pre[wave] = pre;
     __syncthreads();
-    uint32_t e = bsum[blockIdx.x] + inc - s;
+    uint32_t e = ((wave_pre[0] + wave_pre[1]) + (wave_pre[2] + wave_pre[3])) + inc - s;
     for (uint32_t w = 0; w < wave; w++) e += wave_tot[w];
 #pragma unroll
     for (int k = 0; k < PER; k++) { if (i0 + k < n) data[i0 + k] = e; e += v[k]; }
@@ -377,7 +366,6 @@ extern "C" int sgr_knn_dist2_batched(int32_t n_sets, int32_t P, const float *poi
     hipLaunchKernelGGL(grid_setup_kernel, dim3(1, n_sets), dim3(64), 0, stream, kb);
     hipLaunchKernelGGL(cell_count_kernel, dim3(nb, n_sets), dim3(kT), 0, stream, kb);
     hipLaunchKernelGGL(cell_blocksum_kernel, dim3(scan_blocks, n_sets), dim3(kT), 0, stream, kb);
-    hipLaunchKernelGGL(cell_scan_sums_kernel, dim3(1, n_sets), dim3(1024), 0, stream, kb);
     hipLaunchKernelGGL(cell_scan_kernel, dim3(scan_blocks, n_sets), dim3(kT), 0, stream, kb);
     hipLaunchKernelGGL(cell_scatter_kernel, dim3(nb, n_sets), dim3(kT), 0, stream, kb);
     hipLaunchKernelGGL(knn3_kernel, dim3((unsigned)(((size_t)P * kKnnLanes + kT - 1) / kT), n_sets), dim3(kT), 0, stream, kb);
