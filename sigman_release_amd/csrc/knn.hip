@@ -63,6 +63,36 @@ __global__ __launch_bounds__(kT) void knn_init_kernel(KnnBatch kb) {
     for (size_t i = (size_t)blockIdx.x * kT + threadIdx.x; i < n; i += (size_t)gridDim.x * kT) ks.cell_start[i] = 0u;
 }
 
+// derive the grid from the bbox on device (no host round trip): cell = cbrt(volume * 2 / P), clamped so the
+// grid has at most max_cells cells; degenerate extents are padded.
+// (one thread: the last workgroup of bbox_kernel to finish, so no launch of its own)
+__device__ void grid_setup(const KnnBatch &kb, const KnnSet &ks) {
+    const int P = kb.P, max_cells = kb.max_cells; int *bb = ks.bb; Grid *g = ks.grid;
+    float mn[3], ex[3];
+    int bv[6];
+    for (int k = 0; k < 6; k++) bv[k] = __hip_atomic_load(&bb[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // the other workgroups' atomics
+    for (int k = 0; k < 3; k++) { mn[k] = ord2f(bv[k]); ex[k] = fmaxf(ord2f(bv[3 + k]) - mn[k], 1e-6f); }
+    // ~1 point per cell if the cloud fills its bounding volume, ~5 per occupied cell if it is a surface (the reference's
+    // inputs are points on the SMPL-X surface): take the finer of the two estimates.  (The search is bound by its per-lane candidate
+    // loads -- one lane per cycle and CU through the texture addresser -- so the cells are as fine as the stop test allows: with
+    // 0.8 x this edge 100 000 surface points take 71 instead of 93 us, with 0.65 x more queries need a second shell and the scan over
+    // the cells grows: 73 us.)
+    float vol = ex[0] * ex[1] * ex[2];
+    const float area = 2.f * (ex[0] * ex[1] + ex[1] * ex[2] + ex[0] * ex[2]);
+    float cell = fminf(cbrtf(vol * 1.024f / (float)max(P, 1)), sqrtf(area * 1.28f / (float)max(P, 1)));
+    const float longest = fmaxf(ex[0], fmaxf(ex[1], ex[2]));
+    cell = fmaxf(cell, longest / 1024.f);
+    for (int it = 0; it < 64; it++) {
+        const double n = ceil((double)ex[0] / cell + 1e-3) * ceil((double)ex[1] / cell + 1e-3) * ceil((double)ex[2] / cell + 1e-3);
+        if (n <= (double)max_cells) break;
+        cell *= 1.26f;
+    }
+    g->minx = mn[0]; g->miny = mn[1]; g->minz = mn[2];
+    g->cell = cell; g->inv_cell = 1.0f / cell;
+    g->gx = max(1, (int)ceilf(ex[0] / cell + 1e-3f)); g->gy = max(1, (int)ceilf(ex[1] / cell + 1e-3f));
+    g->gz = max(1, (int)ceilf(ex[2] / cell + 1e-3f));
+}
+
 __global__ __launch_bounds__(kT) void bbox_kernel(KnnBatch kb) {
     const KnnSet ks = knn_set(kb, blockIdx.y);
     const int P = kb.P; const float *pts = ks.pts; int *bb = ks.bb;
@@ -87,36 +117,14 @@ __global__ __launch_bounds__(kT) void bbox_kernel(KnnBatch kb) {
         const float a = red[0][k], b = red[1][k], c = red[2][k], d = red[3][k];
         if (k < 3) atomicMin(&bb[k], f2ord(fminf(fminf(a, b), fminf(c, d))));
         else atomicMax(&bb[k], f2ord(fmaxf(fmaxf(a, b), fmaxf(c, d))));
+        __threadfence();                                       // performed before this workgroup's ticket below
     }
-}
-
-// derive the grid from the bbox on device (no host round trip): cell = cbrt(volume * 2 / P), clamped so the
-// grid has at most max_cells cells; degenerate extents are padded.
-__global__ void grid_setup_kernel(KnnBatch kb) {
-    if (threadIdx.x || blockIdx.x) return;
-    const KnnSet ks = knn_set(kb, blockIdx.y);
-    const int P = kb.P, max_cells = kb.max_cells; const int *bb = ks.bb; Grid *g = ks.grid;
-    float mn[3], ex[3];
-    for (int k = 0; k < 3; k++) { mn[k] = ord2f(bb[k]); ex[k] = fmaxf(ord2f(bb[3 + k]) - mn[k], 1e-6f); }
-    // ~1 point per cell if the cloud fills its bounding volume, ~5 per occupied cell if it is a surface (the reference's
-    // inputs are points on the SMPL-X surface): take the finer of the two estimates.  (The search is bound by its per-lane candidate
-    // loads -- one lane per cycle and CU through the texture addresser -- so the cells are as fine as the stop test allows: with
-    // 0.8 x this edge 100 000 surface points take 71 instead of 93 us, with 0.65 x more queries need a second shell and the scan over
-    // the cells grows: 73 us.)
-    float vol = ex[0] * ex[1] * ex[2];
-    const float area = 2.f * (ex[0] * ex[1] + ex[1] * ex[2] + ex[0] * ex[2]);
-    float cell = fminf(cbrtf(vol * 1.024f / (float)max(P, 1)), sqrtf(area * 1.28f / (float)max(P, 1)));
-    const float longest = fmaxf(ex[0], fmaxf(ex[1], ex[2]));
-    cell = fmaxf(cell, longest / 1024.f);
-    for (int it = 0; it < 64; it++) {
-        const double n = ceil((double)ex[0] / cell + 1e-3) * ceil((double)ex[1] / cell + 1e-3) * ceil((double)ex[2] / cell + 1e-3);
-        if (n <= (double)max_cells) break;
-        cell *= 1.26f;
-    }
-    g->minx = mn[0]; g->miny = mn[1]; g->minz = mn[2];
-    g->cell = cell; g->inv_cell = 1.0f / cell;
-    g->gx = max(1, (int)ceilf(ex[0] / cell + 1e-3f)); g->gy = max(1, (int)ceilf(ex[1] / cell + 1e-3f));
-    g->gz = max(1, (int)ceilf(ex[2] / cell + 1e-3f));
+    // the last workgroup to arrive derives the grid (bb[6]: ticket, zeroed by knn_init_kernel)
+    __shared__ int s_last;
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = atomicAdd(&bb[6], 1) == (int)gridDim.x - 1;
+    __syncthreads();
+    if (s_last && threadIdx.x == 0) { __threadfence(); grid_setup(kb, ks); }
 }
 
 __global__ __launch_bounds__(kT) void cell_count_kernel(KnnBatch kb) {
@@ -363,7 +371,6 @@ extern "C" int sgr_knn_dist2_batched(int32_t n_sets, int32_t P, const float *poi
     const int init_blocks = (int)(init_want < 1024 ? init_want : 1024);
     hipLaunchKernelGGL(knn_init_kernel, dim3(init_blocks, n_sets), dim3(kT), 0, stream, kb);
     hipLaunchKernelGGL(bbox_kernel, dim3(min(nb, 64), n_sets), dim3(kT), 0, stream, kb);
-    hipLaunchKernelGGL(grid_setup_kernel, dim3(1, n_sets), dim3(64), 0, stream, kb);
     hipLaunchKernelGGL(cell_count_kernel, dim3(nb, n_sets), dim3(kT), 0, stream, kb);
     hipLaunchKernelGGL(cell_blocksum_kernel, dim3(scan_blocks, n_sets), dim3(kT), 0, stream, kb);
     hipLaunchKernelGGL(cell_scan_kernel, dim3(scan_blocks, n_sets), dim3(kT), 0, stream, kb);
