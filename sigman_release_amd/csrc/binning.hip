@@ -1220,6 +1220,16 @@ __global__ __launch_bounds__(kThreads) void vseg_upsweep_kernel(const uint64_t *
     const uint32_t c = blockIdx.x;
     if (c >= plan->n_chunks) return;
     const uint4 cm = chunk_map[c];
+    // the chunk's tile ids first, ALL in flight at once (indices past the end re-read the last key): with
+    // the load inside the guarded loop below every one of the 32 was a branch, a load and a wait of its own -- 32 round trips per thread
+    uint32_t tl[ITEMS];
+    {
+        const uint32_t last = cm.z ? cm.z - 1u : 0u;
+        if (cm.z) {                                                // (workgroup-uniform)
+#pragma unroll
+            for (int it = 0; it < ITEMS; it++) tl[it] = (uint32_t)(keys[cm.y + min((uint32_t)it * kThreads + threadIdx.x, last)] >> 32);
+        }
+    }
     const bool vec = (tiles_per_view & 3u) == 0u;                 // rows of the histogram are 16-byte aligned: 16-byte LDS and global accesses
     if (vec) for (uint32_t d = threadIdx.x; d < tiles_per_view / 4u; d += kThreads) reinterpret_cast<uint4 *>(h)[d] = make_uint4(0u, 0u, 0u, 0u);
     else for (uint32_t d = threadIdx.x; d < tiles_per_view; d += kThreads) h[d] = 0;
@@ -1228,7 +1238,7 @@ __global__ __launch_bounds__(kThreads) void vseg_upsweep_kernel(const uint64_t *
 #pragma unroll
     for (int it = 0; it < ITEMS; it++) {
         const uint32_t k = it * kThreads + threadIdx.x;
-        if (k < cm.z) atomicAdd(&h[(uint32_t)(keys[cm.y + k] >> 32) - tbase], 1u);
+        if (k < cm.z) atomicAdd(&h[tl[it] - tbase], 1u);
     }
     __syncthreads();
     uint32_t *out = hist + (size_t)c * tiles_per_view;
