@@ -337,9 +337,19 @@ __global__ __launch_bounds__(kThreads) void wide_downsweep_kernel(const uint64_t
     if (t < 8) s_wl[t] = 0u;
     constexpr int PER = kWide / kThreads;                        // 8 consecutive digits per thread
     {   // exclusive scan of the 2048 digit totals + this workgroup's offset inside each digit; wave_cnt starts zeroed
-        uint32_t v[PER], sum = 0;
+        // the thread's 8 digit totals and its workgroup's 8 offsets: four 16-byte loads up front (one by one inside the loop below they
+        // were eight waits)
+        static_assert(PER == 8, "two uint4 per thread");
+        uint32_t v[PER], hb[PER], sum = 0;
+        {
+            const uint4 t0 = reinterpret_cast<const uint4 *>(totals)[t * 2], t1 = reinterpret_cast<const uint4 *>(totals)[t * 2 + 1];
+            const uint4 *hr = reinterpret_cast<const uint4 *>(hist + (size_t)blockIdx.x * kWide);
+            const uint4 h0 = hr[t * 2], h1 = hr[t * 2 + 1];
+            v[0] = t0.x; v[1] = t0.y; v[2] = t0.z; v[3] = t0.w; v[4] = t1.x; v[5] = t1.y; v[6] = t1.z; v[7] = t1.w;
+            hb[0] = h0.x; hb[1] = h0.y; hb[2] = h0.z; hb[3] = h0.w; hb[4] = h1.x; hb[5] = h1.y; hb[6] = h1.z; hb[7] = h1.w;
+        }
 #pragma unroll
-        for (int j = 0; j < PER; j++) { v[j] = totals[t * PER + j]; sum += v[j]; }
+        for (int j = 0; j < PER; j++) sum += v[j];
         uint32_t inc = sum;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
@@ -353,7 +363,7 @@ __global__ __launch_bounds__(kThreads) void wide_downsweep_kernel(const uint64_t
 #pragma unroll
         for (int j = 0; j < PER; j++) {
             const uint32_t d = t * PER + j;
-            digit_base[d] = run + hist[(size_t)blockIdx.x * kWide + d];
+            digit_base[d] = run + hb[j];
             // F5 for free: the digit IS the tile id, so the scanned totals are the tile ranges (and the occupied tiles the
             // per-tile sort's worklist, whose counter the duplicate kernel cleared)
             if (ranges && blockIdx.x == 0 && d < tiles_total) {
