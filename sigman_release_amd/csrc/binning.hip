@@ -25,6 +25,7 @@ constexpr int kRadix = 1 << kRadixBits;
 // large batches want fewer, longer ones (less histogram traffic)
 constexpr int kItemsSmall = 4, kItemsLarge = 16;
 
+constexpr int kTileBins = 2048;                    // tiles of a launch whose emission kernel writes the tile pass's histogram rows (== kWide)
 struct DupExtra {
     const uint32_t *self_sums;          // un-scanned per-workgroup tile counts (NULL: block_offsets already holds the scan)
     uint64_t *num_rendered;             // [2] device counter + overflow flag (self-scan mode)
@@ -33,6 +34,8 @@ struct DupExtra {
     uint32_t *zero_ptr[3];              // optional buffers to clear on the side: tile ranges, backward flags, a caller buffer
     uint32_t zero_words[3];
     uint32_t *zero_small; uint32_t zero_small_n;      // optional few words (<= 256) to clear: the tile-sort worklist counter(s)
+    uint32_t *hist_rows;                // optional [workgroups][kTileBins]: this workgroup's keys per tile, the block-major histogram row of the
+    uint2 *blk_runs;                    // small-launch tile pass (which then needs no histogram kernel), and its key run (first key, keys written)
     uint32_t write_first;               // store every Gaussian's first tile-instance index into rect[q].w (only the bucket backward's gathers read it;
                                         // a forward-only launch skips the 4-byte stores that dirty every line of the rect array: 0.29 GB of
                                         // write-back for the 90 views of C4)
@@ -50,6 +53,8 @@ __global__ __launch_bounds__(kThreads) void duplicate_keys_kernel(int P, int Tx,
                                                                   DupExtra ex) {
     __shared__ uint32_t wave_tot[4];
     __shared__ unsigned long long red64[4];
+    __shared__ __attribute__((aligned(16))) uint32_t s_th[kTileBins];      // this workgroup's keys per tile (only with ex.hist_rows)
+    if (ex.hist_rows) for (int d = threadIdx.x; d < kTileBins / 4; d += kThreads) reinterpret_cast<uint4 *>(s_th)[d] = make_uint4(0u, 0u, 0u, 0u);
     const int view = blockIdx.y;
     // piggy-backed clear of a small buffer the later kernels expect zeroed (the tile ranges): replaces a memset launch
 #pragma unroll
@@ -136,9 +141,18 @@ __global__ __launch_bounds__(kThreads) void duplicate_keys_kernel(int P, int Tx,
         const uint32_t x = local - y * w;
         const uint32_t dst = block_base + j;
         if (dst < cap) {                                       // capacity mode: never write past the caller's buffers
-            keys[dst] = ((uint64_t)(tbase + ((g >> 16) + y) * (uint32_t)Tx + (g & 0xFFFFu) + x) << 32) | s_dep[lo];
+            const uint32_t tile_id = tbase + ((g >> 16) + y) * (uint32_t)Tx + (g & 0xFFFFu) + x;
+            keys[dst] = ((uint64_t)tile_id << 32) | s_dep[lo];
             vals[dst] = q0 + lo;
+            if (ex.hist_rows) atomicAdd(&s_th[tile_id], 1u);
         }
+    }
+    if (ex.hist_rows) {                                        // (workgroup-uniform) the tile pass's histogram row of this key run
+        __syncthreads();
+        const uint32_t b = blockIdx.y * gridDim.x + blockIdx.x;
+        uint4 *row = reinterpret_cast<uint4 *>(ex.hist_rows + (size_t)b * kTileBins);
+        for (int d = threadIdx.x; d < kTileBins / 4; d += kThreads) row[d] = reinterpret_cast<const uint4 *>(s_th)[d];
+        if (threadIdx.x == 0) ex.blk_runs[b] = make_uint2(block_base, block_base < cap ? min(total, cap - block_base) : 0u);
     }
 }
 
@@ -433,6 +447,78 @@ __global__ __launch_bounds__(kThreads) void wide_downsweep_kernel(const uint64_t
         __syncthreads();
         if (leader) { atomicAdd(&digit_base[d], grp); wave_cnt[wave][d] = 0; }
         __syncthreads();
+    }
+}
+
+// The order-free scatter of the tile pass for key RUNS: workgroup b places the keys the emission workgroup b wrote (blk_runs[b]: first
+// key, count), whose histogram row that workgroup also wrote -- so the small-launch tile pass needs no histogram kernel of its own.
+// Same slots as wide_downsweep_kernel<ITEMS, false>: one returning LDS atomic per key, (depth bits << 32 | value) composites;
+// workgroup 0 writes the tile ranges (F5) and the class worklists.
+template <int ITEMS>
+__global__ __launch_bounds__(kThreads) void wide_downsweep_runs_kernel(const uint64_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
+                                                                       uint64_t *__restrict__ keys_out, const uint2 *__restrict__ blk_runs,
+                                                                       const uint32_t *__restrict__ hist, const uint32_t *__restrict__ totals,
+                                                                       uint2 *__restrict__ ranges, uint32_t tiles_total, uint32_t *__restrict__ worklist) {
+    __shared__ uint32_t digit_base[kWide];
+    __shared__ uint32_t wtot[4];
+    __shared__ uint32_t s_wl[8];
+    const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    if (t < 8) s_wl[t] = 0u;
+    constexpr int PER = kWide / kThreads;
+    static_assert(PER == 8, "two uint4 per thread");
+    const uint2 my = blk_runs[blockIdx.x];
+    {
+        uint32_t v[PER], hb[PER], sum = 0;
+        {
+            const uint4 t0 = reinterpret_cast<const uint4 *>(totals)[t * 2], t1 = reinterpret_cast<const uint4 *>(totals)[t * 2 + 1];
+            const uint4 *hr = reinterpret_cast<const uint4 *>(hist + (size_t)blockIdx.x * kWide);
+            const uint4 h0 = hr[t * 2], h1 = hr[t * 2 + 1];
+            v[0] = t0.x; v[1] = t0.y; v[2] = t0.z; v[3] = t0.w; v[4] = t1.x; v[5] = t1.y; v[6] = t1.z; v[7] = t1.w;
+            hb[0] = h0.x; hb[1] = h0.y; hb[2] = h0.z; hb[3] = h0.w; hb[4] = h1.x; hb[5] = h1.y; hb[6] = h1.z; hb[7] = h1.w;
+        }
+#pragma unroll
+        for (int j = 0; j < PER; j++) sum += v[j];
+        uint32_t inc = sum;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t nb = __shfl_up(inc, off, 64);
+            if (lane >= (uint32_t)off) inc += nb;
+        }
+        if (lane == 63) wtot[wave] = inc;
+        __syncthreads();
+        uint32_t run = inc - sum;
+        for (uint32_t w = 0; w < wave; w++) run += wtot[w];
+#pragma unroll
+        for (int j = 0; j < PER; j++) {
+            const uint32_t d = t * PER + j;
+            digit_base[d] = run + hb[j];
+            if (blockIdx.x == 0 && d < tiles_total) {
+                ranges[d] = v[j] ? make_uint2(run, run + v[j]) : make_uint2(0u, 0u);
+                if (v[j]) {
+                    const uint32_t m = v[j] <= 1024u ? 0u : (v[j] <= 2048u ? 1u : (v[j] <= 4096u ? 2u : (v[j] <= 8192u ? 3u : (v[j] <= 16384u ? 4u : 5u))));
+                    worklist[16u + m * tiles_total + atomicAdd(&s_wl[m], 1u)] = d;
+                }
+            }
+            run += v[j];
+        }
+    }
+    __syncthreads();
+    if (blockIdx.x == 0 && t < 6u) worklist[t] = s_wl[t];
+    for (uint32_t c0 = 0; c0 < my.y; c0 += kThreads * ITEMS) {
+        uint64_t keys_r[ITEMS];
+        uint32_t vals_r[ITEMS];
+        const uint32_t lastk = my.y - 1u;
+#pragma unroll
+        for (int it = 0; it < ITEMS; it++) {                     // (indices past the run re-read its last key: no guarded loads)
+            const uint32_t k = my.x + min(c0 + (uint32_t)it * kThreads + t, lastk);
+            keys_r[it] = keys_in[k]; vals_r[it] = vals_in[k];
+        }
+#pragma unroll
+        for (int it = 0; it < ITEMS; it++)
+            if (c0 + (uint32_t)it * kThreads + t < my.y) {
+                const uint32_t d = (uint32_t)(keys_r[it] >> 32) & (kWide - 1);
+                keys_out[atomicAdd(&digit_base[d], 1u)] = (keys_r[it] << 32) | vals_r[it];
+            }
     }
 }
 
@@ -1448,7 +1534,8 @@ extern "C" size_t sgr_bin_workspace_bytes(uint64_t R, uint64_t tiles_total) {
     // onesweep: [ghist 8x256][tickets 8][err][pad] + status [8 passes][tiles][256]; three-kernel path: [hist tiles x 256][totals 256]
     // + [worklist 64 + tiles] of the segmented flavour; the view-segmented flavour lays its plan / chunk map / histograms / two worklists
     // over the whole area from the start (<= 2 R + R / 256 + 80 B per tile + 64 KB: see vseg_layout)
-    return (size_t)((kMaxPasses * (nblocks > 0 ? nblocks : 1) + kMaxPasses + 2) * kRadix * sizeof(uint32_t) + 1024 +
+    // (+ 4 MB: room for one 8-KB histogram row per emission workgroup of a small launch, see sgr_bin_ex)
+    return (size_t)((kMaxPasses * (nblocks > 0 ? nblocks : 1) + kMaxPasses + 2) * kRadix * sizeof(uint32_t) + 1024 + ((size_t)4 << 20) +
                     (tiles_total ? (tiles_total + 64) * sizeof(uint32_t) + tiles_total * 128 + 65536 : 0));
 }
 
@@ -1478,24 +1565,6 @@ int sgr_bin_ex(const SgrProblem *pb, const int32_t *radii, uint32_t *rect,
     // few tiles + segmented sort: every occupied tile goes on the large-class worklist (counter cleared by the duplicate kernel,
     // filled by tile_ranges)
     const bool all_large = tiles_total <= 2048;
-    { SgrProfScope _p(SGR_K_DUPLICATE, stream);
-    DupExtra ex;
-    ex.write_first = first_index ? 1u : 0u;
-    const uint32_t nblk = (uint32_t)nbx * (uint32_t)pb->n_views;
-    ex.self_sums = self_scan ? block_offsets + (nblk + 1) : nullptr;
-    ex.num_rendered = const_cast<uint64_t *>(num_rendered_dev); ex.nr_host = self_scan ? nr_host : nullptr; ex.capacity = R;
-    ex.zero_ptr[0] = fold_clear ? ranges : nullptr; ex.zero_words[0] = fold_clear ? (uint32_t)(tiles_total * 2) : 0u;
-    for (int c = 0; c < 2; c++) {
-        const bool ok = clear_ptr && clear_ptr[c] && clear_words && clear_words[c] <= (1ull << 26);
-        ex.zero_ptr[1 + c] = ok ? clear_ptr[c] : nullptr; ex.zero_words[1 + c] = ok ? (uint32_t)clear_words[c] : 0u;
-        if (clear_done) clear_done[c] = ok ? 1 : 0;
-    }
-    ex.zero_small = all_large ? (uint32_t *)((char *)workspace + sgr_bin_workspace_bytes(R, 0)) : nullptr; ex.zero_small_n = 16u;   // [0] worklist counter / class counts + tickets
-    if (self_scan && !num_rendered_dev) { sgr_set_error("sgr_bin: self-scan needs the device counter"); return 1; }
-    hipLaunchKernelGGL(duplicate_keys_kernel, dim3(nbx, pb->n_views), dim3(kThreads), 0, stream, pb->P, Tx, Tx * Ty,
-                       radii, (uint4 *)rect, block_offsets, n, keys_a, vals_a, ex);
-    SGR_CHECK_LAUNCH("duplicate_keys_kernel");
-    }
     const bool small = n <= (1u << 19);
     const uint32_t tile_keys = kThreads * (small ? kItemsSmall : kItemsLarge);
     const uint32_t nblocks = (n + tile_keys - 1) / tile_keys;
@@ -1523,6 +1592,31 @@ int sgr_bin_ex(const SgrProblem *pb, const int32_t *radii, uint32_t *rect,
     // class worklists in the area the duplicate kernel cleared (all_large); otherwise the LDS flavour
     const bool wide_regs = mode == 5 && all_large && small && bits_for(tiles_total) > kRadixBits && bits_for(tiles_total) <= kWideBits;
     if (mode == 5) mode = 2;
+    // flavour 5, up to 512 emission workgroups: the emission kernel writes the tile pass's block-major histogram rows for its own key runs
+    // (one 8-KB row per workgroup at the head of the workspace, then the 2048 digit totals, then the runs) -- no histogram kernel
+    const uint32_t nblk_e = (uint32_t)nbx * (uint32_t)pb->n_views;
+    const bool emit_hist = wide_regs && nblk_e <= 512u &&
+                           ((size_t)(nblk_e + 1u) * kWide + 2u * (size_t)nblk_e) * sizeof(uint32_t) <= sgr_bin_workspace_bytes(R, 0);
+    uint2 *blk_runs = (uint2 *)(hist + (size_t)(nblk_e + 1u) * kWide);
+    { SgrProfScope _p(SGR_K_DUPLICATE, stream);
+    DupExtra ex;
+    ex.hist_rows = emit_hist ? hist : nullptr; ex.blk_runs = emit_hist ? blk_runs : nullptr;
+    ex.write_first = first_index ? 1u : 0u;
+    const uint32_t nblk = (uint32_t)nbx * (uint32_t)pb->n_views;
+    ex.self_sums = self_scan ? block_offsets + (nblk + 1) : nullptr;
+    ex.num_rendered = const_cast<uint64_t *>(num_rendered_dev); ex.nr_host = self_scan ? nr_host : nullptr; ex.capacity = R;
+    ex.zero_ptr[0] = fold_clear ? ranges : nullptr; ex.zero_words[0] = fold_clear ? (uint32_t)(tiles_total * 2) : 0u;
+    for (int c = 0; c < 2; c++) {
+        const bool ok = clear_ptr && clear_ptr[c] && clear_words && clear_words[c] <= (1ull << 26);
+        ex.zero_ptr[1 + c] = ok ? clear_ptr[c] : nullptr; ex.zero_words[1 + c] = ok ? (uint32_t)clear_words[c] : 0u;
+        if (clear_done) clear_done[c] = ok ? 1 : 0;
+    }
+    ex.zero_small = all_large ? (uint32_t *)((char *)workspace + sgr_bin_workspace_bytes(R, 0)) : nullptr; ex.zero_small_n = 16u;   // [0] worklist counter / class counts + tickets
+    if (self_scan && !num_rendered_dev) { sgr_set_error("sgr_bin: self-scan needs the device counter"); return 1; }
+    hipLaunchKernelGGL(duplicate_keys_kernel, dim3(nbx, pb->n_views), dim3(kThreads), 0, stream, pb->P, Tx, Tx * Ty,
+                       radii, (uint4 *)rect, block_offsets, n, keys_a, vals_a, ex);
+    SGR_CHECK_LAUNCH("duplicate_keys_kernel");
+    }
     if (mode == 4) {
         char *ws = (char *)workspace;
         VsegPlan *plan = (VsegPlan *)(ws + VL.plan);
@@ -1566,11 +1660,18 @@ int sgr_bin_ex(const SgrProblem *pb, const int32_t *radii, uint32_t *rect,
     if (segmented && wide_regs) {
         uint32_t *wl = (uint32_t *)((char *)workspace + sgr_bin_workspace_bytes(R, 0));     // [16 counters][6][tiles_total]
         { SgrProfScope _ps(SGR_K_SORT, stream);
+        if (emit_hist) {
+        hipLaunchKernelGGL(wide_rowscan_kernel, dim3(kWide / 64), dim3(1024), 0, stream, hist, nblk_e, hist + (size_t)nblk_e * kWide);
+        hipLaunchKernelGGL(wide_downsweep_runs_kernel<kItemsSmall>, dim3(nblk_e), dim3(kThreads), 0, stream, kin, vin, kout, blk_runs, hist,
+                           hist + (size_t)nblk_e * kWide, (uint2 *)ranges, (uint32_t)tiles_total, wl);
+        SGR_CHECK_LAUNCH("wide tile-bit pass (emitted rows)");
+        } else {
         hipLaunchKernelGGL(wide_upsweep_kernel<kItemsSmall>, dim3(nblocks), dim3(kThreads), 0, stream, kin, n, num_rendered_dev, 32, nblocks, hist);
         hipLaunchKernelGGL(wide_rowscan_kernel, dim3(kWide / 64), dim3(1024), 0, stream, hist, nblocks, hist + (size_t)nblocks * kWide);
         hipLaunchKernelGGL((wide_downsweep_kernel<kItemsSmall, false>), dim3(nblocks), dim3(kThreads), 0, stream, kin, vin, kout, vout, n, num_rendered_dev, 32,
                            nblocks, hist, hist + (size_t)nblocks * kWide, (uint2 *)ranges, (uint32_t)tiles_total, wl);
         SGR_CHECK_LAUNCH("wide tile-bit pass");
+        }
         // composites sit tile-bucketed in kout (vout is scratch); the sorted list goes back into (kin, vin)
         TileWork4 tw4;
         for (int c = 0; c < 6; c++) { TileWork w = {wl + 16 + (size_t)c * tiles_total, wl + 8 + c, wl + c}; tw4.w[c] = w; }
