@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Randomised cross-check of the sort flavours on the GPU box (dev): random humanoid scenes (1-2 views, 256..512 px, 2k..130k Gaussians, exact and
 sync-free mode) through forward_debug with the automatic flavour and with the three-kernel whole-key passes: sorted keys, point list, tile ranges
-and images must be identical bit for bit.     usage: python tools/fuzz_bin_modes.py [seconds]"""
-import sys, time
+and images must be identical bit for bit.     usage: [FUZZ_VIEWS=3,5,8] python tools/fuzz_bin_modes.py [seconds]"""
+import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, ".")
 from sigman_release_amd import _cabi, cameras, synthetic
@@ -16,7 +16,7 @@ n = 0
 while time.time() < t_end:
     P = int(rng.choice([2000, 9000, 33000, 70001, 100000, 130000]))
     H = int(rng.choice([256, 272, 400, 512])); W = int(rng.choice([256, 304, 512]))
-    nv = int(rng.choice([1, 1, 2]))
+    nv = int(rng.choice([int(x) for x in os.environ.get("FUZZ_VIEWS", "1,1,2").split(",")]))
     views = [int(v) for v in rng.choice(90, nv, replace=False)]
     g = synthetic.humanoid(P, int(rng.integers(1, 1 << 30)))
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
