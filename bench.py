@@ -39,8 +39,6 @@ import subprocess
 import sys
 import time
 
-os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")   # before torch/HIP initialise: lets the graphs_on variant (SIGMAN_GRAPHS=1) replay safely
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 
 
@@ -57,7 +55,7 @@ def parse_args(argv=None):
                     help="N>1: 'loss' = north_star's protocol (replicated attributes, loss all-reduce overlapped with the backward); "
                          "'full' = attribute broadcast + all-reduce of gradients and loss (sigman_release_amd/parallel.py)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-variants", action="store_true", help="skip the unpinned / graphs-off / per-view-loop re-runs (N=1, c2/c3)")
+    ap.add_argument("--no-variants", action="store_true", help="skip the unpinned / exact-sync / per-view-loop re-runs (N=1, c2/c3)")
     ap.add_argument("--exact-sync", action="store_true", help="read num_rendered back every step (upstream behaviour) instead of the sync-free capacity mode")
     return ap.parse_args(argv)
 
@@ -437,7 +435,8 @@ def variants(args, subj, st, gt, norm, S, P, H, W, mine, dev):
     """The same workload under the conditions the headline does NOT assume (N=1 only):
       per_view_loop_*      the reference's own call pattern (gs.py:62-109): Python loop over subjects and views through the
                            upstream-signature GaussianRasterizer (one launch chain + one autograd node per view), then clamp/stack/L1
-      unpinned_*, graphs_on_*    the batched step re-run in a subprocess without host-thread pinning / with hipGraph replay of the forward chain on"""
+      unpinned_*, exact_sync_*   the batched step re-run in a subprocess without host-thread pinning / with upstream's blocking read of
+                           num_rendered in every forward (--exact-sync) instead of the pre-sized sync-free buffers"""
     from sigman_release_amd.losses import clamped_l1_loss
     out = {}
     leaves = {k: v.clone().requires_grad_(True) for k, v in subj.items()}
@@ -469,11 +468,11 @@ def variants(args, subj, st, gt, norm, S, P, H, W, mine, dev):
     out["per_view_loop_ms_per_step"] = round(dt * 1e3, 4)
     out["per_view_loop_views_per_s"] = round(S * V / dt, 1)
     base = [sys.executable, os.path.abspath(__file__), "--config", args.config, "--no-cpu-baseline", "--no-variants"]
-    for key, env in (("unpinned", {"SIGMAN_NO_PIN": "1"}), ("graphs_on", {"SIGMAN_GRAPHS": "1"})):
+    for key, env, extra in (("unpinned", {"SIGMAN_NO_PIN": "1"}, []), ("exact_sync", {}, ["--exact-sync"])):
         try:
             if _ORIG_AFFINITY is not None:
                 os.sched_setaffinity(0, _ORIG_AFFINITY)
-            r = subprocess.run(base, capture_output=True, text=True, timeout=600, env={**os.environ, **env})
+            r = subprocess.run(base + extra, capture_output=True, text=True, timeout=600, env={**os.environ, **env})
             line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
             out[f"{key}_ms_per_step"] = json.loads(line)["ms_per_step"]
         except Exception as e:      # noqa: BLE001  (a variant that cannot run is reported, not fatal)

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SGR_ABI_VERSION 3
+#define SGR_ABI_VERSION 4
 #define SGR_TILE 16                 /* 16x16 pixel tiles, as the published algorithm */
 #define SGR_REC_FLOATS 12           /* floats of a gradient record (grec, pixel-parallel backward) */
 #define SGR_PART_FLOATS 10          /* floats of a partial gradient record (bucket-parallel backward): 40 B, 8-byte aligned */
@@ -158,22 +158,10 @@ int sgr_rasterize_backward(const SgrProblem *pb, const SgrForwardState *state, c
                            float *dL_dopacity, float *dL_dcolors, float *dL_dsh, float *dL_dcov3D, float *dL_dscales,
                            float *dL_drotations, void *stream);
 
-/*
- * hipGraph replay of the forward launch chain (sync-free mode only): the chain is captured once per distinct argument set (problem +
- * pointers) and replayed with one hipGraphLaunch.  OPT-IN:
- *   0 = plain launches (default: on ROCm 7.2 replay is no faster than the 8 plain launches of a forward, and the instance count of the
- *       sync-free modes reaches the host earlier without it);
- *   1 = replay only if DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 is in the process environment -- ROCm 7.2's pre-recorded graph packets fault after
- *       large host<->device copies in the same process, so that runtime feature has to be off (set the variable before the HIP runtime
- *       initialises);
- *   2 = force replay (caller guarantees the runtime is safe).
- */
-int sgr_set_graphs(int enable);
 /* upstream's `debug=True` (error conventions): while enabled, every kernel launch of the calling thread is followed by a
  * device synchronise, and a fault is reported as a failure of the entry point with the name of the kernel in sgr_last_error();
- * graph replay is bypassed.  Thread-local; returns the previous value. */
+ * Thread-local; returns the previous value. */
 int sgr_set_debug(int enable);
-int sgr_graph_stats(uint64_t *hits, uint64_t *misses);
 
 /* ---- staged, batched API -------------------------------------------------------------------- */
 

@@ -67,10 +67,8 @@ _SIGNATURES = {
     "sgr_set_backward_gather": (C.c_int, [C.c_int]),
     "sgr_set_preprocess_view_group": (C.c_int, [C.c_int]),
     "sgr_set_keep_sorted_keys": (C.c_int, [C.c_int]),
-    "sgr_set_graphs": (C.c_int, [C.c_int]),
     "sgr_set_debug": (C.c_int, [C.c_int]),
     "sgr_set_sort_mode": (C.c_int, [C.c_int]),
-    "sgr_graph_stats": (C.c_int, [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "sgr_render_forward": (C.c_int, [C.POINTER(SgrProblem)] + [C.c_void_p] * 8 + [C.c_uint64] + [C.c_void_p] * 6),
     "sgr_render_backward": (C.c_int, [C.POINTER(SgrProblem)] + [C.c_void_p] * 13 + [C.c_uint64] + [C.c_void_p] * 8),
     "sgr_preprocess_backward": (C.c_int, [C.POINTER(SgrProblem)] + [C.c_void_p] * 15),
@@ -102,10 +100,8 @@ def lib():
             fn = getattr(L, name)          # AttributeError if a declared symbol is not exported
             fn.restype = res
             fn.argtypes = args
-        if L.sgr_abi_version() != 3:
-            raise RuntimeError(f"ABI version mismatch: library reports {L.sgr_abi_version()}, binding expects 3")
-        if os.environ.get("SIGMAN_GRAPHS", "0") in ("1", "2"):    # opt-in hipGraph replay of the forward chain (include/sigman_gsplat.h, sgr_set_graphs)
-            L.sgr_set_graphs(int(os.environ["SIGMAN_GRAPHS"]))
+        if L.sgr_abi_version() != 4:
+            raise RuntimeError(f"ABI version mismatch: library reports {L.sgr_abi_version()}, binding expects 4")
         if os.environ.get("SIGMAN_SORT_MODE", "") in ("0", "1", "2", "4", "5"):  # A/B knob: sort flavour (sgr_set_sort_mode)
             L.sgr_set_sort_mode(int(os.environ["SIGMAN_SORT_MODE"]))
         if os.environ.get("SIGMAN_FWD_MODE", "") in ("1", "2", "3"):      # A/B knob: forward compositing kernel (sgr_set_forward_mode)
@@ -130,7 +126,7 @@ def torch_node():
             spec = importlib.util.spec_from_file_location("sgr_torch_node", path)
             mod = importlib.util.module_from_spec(spec)
             spec.loader.exec_module(mod)
-            if mod.abi_version() != 3:
+            if mod.abi_version() != 4:
                 raise RuntimeError("sgr_torch_node.so was built against another ABI version of libsigman_gsplat.so: rebuild (make -C sigman_release_amd/csrc)")
             _node = mod
     return _node

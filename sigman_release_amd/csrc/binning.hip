@@ -1500,7 +1500,7 @@ __global__ __launch_bounds__(kThreads) void tile_ranges_kernel(const uint64_t *_
 
 // 3 = automatic (default), 4 = view-segmented (per-view tile pass + per-tile depth sort), 2 = segmented (global passes over the tile bits,
 // depth bits per tile in LDS), 0 = onesweep, 1 = three kernels per pass
-int sgr_sort_mode = 3;
+thread_local int sgr_sort_mode = 3;
 
 struct VsegLayout { size_t plan, totals, key_start, chunk_start, chunk_map, hist, tile_total, lists, end; uint32_t chunk_keys, max_chunks; };
 inline VsegLayout vseg_layout(uint64_t R, uint64_t tiles_total, uint32_t n_views, uint32_t tiles_per_view) {

@@ -12,6 +12,7 @@
 // are bit-exact against the CPU oracle.  These kernels are HBM-streaming (~76 B read+written per
 // Gaussian per view forward, ~150 B backward); one thread per Gaussian, view index on blockIdx.y so
 // the camera matrices are wave-uniform scalar loads.
+#include <atomic>
 #include "common.h"
 
 namespace {
@@ -710,7 +711,7 @@ int validate_problem(const SgrProblem *pb) {
 
 int sgr_validate_problem(const SgrProblem *pb) { return validate_problem(pb); }
 
-static int g_view_group = 0;
+static thread_local int g_view_group = 0;
 extern "C" int sgr_set_preprocess_view_group(int n) { g_view_group = n > 0 ? n : 0; return 0; }
 
 extern "C" int32_t sgr_preprocess_blocks_per_view(int32_t P) { return P <= 0 ? 1 : (P + kPreThreads - 1) / kPreThreads; }
@@ -753,8 +754,8 @@ extern "C" int sgr_preprocess_forward(const SgrProblem *pb, float *rec, int32_t 
 
 // 0 = automatic (lanes over views on the colors_precomp path when views_per_subject is a power of two in 2..256), 1 = always the
 // one-thread-per-Gaussian kernel (A/B, and the bit-identity test of the two kernels)
-static int g_bwd_view_loop = 0;
-extern "C" int sgr_set_backward_gather(int mode) { g_bwd_view_loop = mode == 1 ? 1 : 0; return 0; }
+static std::atomic<int> g_bwd_view_loop{0};     // read by the backward, i.e. on the autograd thread: process-wide, but an atomic
+extern "C" int sgr_set_backward_gather(int mode) { g_bwd_view_loop.store(mode == 1 ? 1 : 0); return 0; }
 
 // n_inst: number of tile instances part / flags were sized for (the gather never reads beyond it)
 int sgr_preprocess_backward_ex(const SgrProblem *pb, const int32_t *radii, const uint8_t *clamped, const float *grec,
@@ -774,7 +775,7 @@ int sgr_preprocess_backward_ex(const SgrProblem *pb, const int32_t *radii, const
     if (pb->shs)
         hipLaunchKernelGGL(preprocess_bwd_kernel<true>, grid, dim3(kPreThreads), 0, stream, *pb, radii, clamped, (const float4 *)grec,
                            (const uint4 *)rect, (const float4 *)part, flags, (uint32_t)(n_inst > 0xFFFFFFFFull ? 0xFFFFFFFFull : n_inst), dL_dmeans3D, dL_dmeans2D, dL_dopacity, dL_dcolors, dL_dsh, dL_dcov3D, dL_dscales, dL_drotations);
-    else if (pb->views_per_subject > 1 && pb->views_per_subject <= kPreThreads && kPreThreads % pb->views_per_subject == 0 && !g_bwd_view_loop) {
+    else if (pb->views_per_subject > 1 && pb->views_per_subject <= kPreThreads && kPreThreads % pb->views_per_subject == 0 && !g_bwd_view_loop.load()) {
         const int gpb = kPreThreads / pb->views_per_subject;
         hipLaunchKernelGGL(preprocess_bwd_lanes_kernel, dim3((pb->P + gpb - 1) / gpb, pb->n_views / pb->views_per_subject), dim3(kPreThreads), 0, stream, *pb,
                            radii, clamped, (const float4 *)grec, (const uint4 *)rect, (const float4 *)part, flags,

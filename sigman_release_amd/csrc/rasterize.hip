@@ -9,42 +9,15 @@
 #include <string.h>
 
 #include <cstdlib>
-#include <mutex>
 #include "common.h"
 
 namespace {
 inline uint64_t align_up(uint64_t v, uint64_t a = 256) { return (v + a - 1) / a * a; }
 }
 
-// ---------------------------------------------------------------------------------------------
-// hipGraph cache (sync-free mode only).  With every buffer size known up front, the whole forward chain is a
-// static sequence of ~27 launches whose arguments are the problem description and a handful of pointers.  A
-// training loop presents the SAME pointers step after step (PyTorch's caching allocator replays its
-// allocation sequence), so the chain is captured once per distinct argument set and replayed with a single
-// hipGraphLaunch: one host call instead of ~27, and back-to-back kernel dispatch on the GPU.  Any capture
-// failure, a profiling request, or too many distinct argument sets falls back to plain launches.
-// ---------------------------------------------------------------------------------------------
-namespace {
-struct FwdKey {
-    SgrProblem pb;
-    uint64_t capacity;
-    int32_t with_aux, fwd_mode;
-    void *color, *depth, *alpha, *radii, *nr_host, *geom, *binning, *image, *stream, *clear;
-    uint64_t clear_bytes;
-};
-struct FwdEntry { FwdKey key; hipGraphExec_t exec; SgrForwardState st; uint64_t stamp; };
-constexpr int kGraphSlots = 16;
-FwdEntry g_fwd[kGraphSlots];
-int g_fwd_n = 0;
-uint64_t g_stamp = 0, g_graph_misses = 0, g_graph_hits = 0, g_miss_streak = 0;
-int g_graphs_enabled = 0;        // 0 = plain launches (default); -1 = automatic, not decided yet (see graphs_allowed); > 0 = replay
-std::mutex g_graph_mu;           // the cache below is process-global: forwards issued from several host threads take turns
-}  // namespace
-
-int sgr_prof_active();
 // 0 (default): a fused forward whose binning ends in the register per-tile sort stores only the point list -- the sorted keys have no
 // reader behind that sort (the tile ranges come from the tile pass); 1: keep them (forward_debug / the parity tests look at them)
-static int g_keep_sorted_keys = 0;
+static thread_local int g_keep_sorted_keys = 0;     // thread-local like sgr_set_debug: forward_debug() toggles it around ONE call
 extern "C" int sgr_set_keep_sorted_keys(int keep) { const int old = g_keep_sorted_keys; g_keep_sorted_keys = keep ? 1 : 0; return old; }
 int sgr_preprocess_forward_ex(const SgrProblem *pb, float *rec, int32_t *radii, uint32_t *rect, uint8_t *clamped, uint32_t *block_offsets,
                               uint64_t *num_rendered, uint64_t capacity, bool skip_scan, void *stream_);
@@ -67,24 +40,6 @@ int sgr_render_forward_ex(const SgrProblem *pb, const uint32_t *ranges, const ui
                           void *aux_ckpt_tc, void *aux_ckpt_da, void *aux_desc, uint32_t *aux_order, bool prepared, int aux_layout, void *stream_);
 int sgr_get_forward_mode();
 int sgr_aux_layout_for(uint64_t NS);
-
-// ROCm 7.2's hipGraph "packet capture" (pre-recorded AQL packets, on by default) is not safe next to large host<->device
-// copies issued by the same process: a few replays after e.g. a 5 MB pageable D2H copy the command processor faults
-// ("write access to a read-only page", no wave involved; reproduced with tests/test_gpu_parity.py::test_graph_replay_survives_
-// host_copies).  With DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 in the environment BEFORE the HIP runtime initialises, replay is
-// stable.  Graph replay is therefore OPT-IN (sgr_set_graphs / SIGMAN_GRAPHS): mode 1 replays only when that variable is visibly "0",
-// mode 2 forces it.  The default is plain launches -- on this runtime replay no longer pays anyway (C2 step 0.188 ms with replay,
-// 0.176 ms without, BENCH r02a), and in automatic-capacity mode the instance count then reaches the host while the rest of the chain
-// is still being queued instead of behind the whole graph (per-view path of gs.py:62-109: 318 -> 235 us per view).
-static bool graphs_allowed() {
-    if (g_graphs_enabled < 0) {
-        const char *e = getenv("DEBUG_CLR_GRAPH_PACKET_CAPTURE");
-        g_graphs_enabled = (e && e[0] == '0' && e[1] == 0) ? 1 : 0;
-    }
-    return g_graphs_enabled > 0;
-}
-extern "C" int sgr_set_graphs(int enable) { g_graphs_enabled = enable == 1 ? -1 : enable; return 0; }   // 0 off, 1 auto, 2 force
-extern "C" int sgr_graph_stats(uint64_t *hits, uint64_t *misses) { if (hits) *hits = g_graph_hits; if (misses) *misses = g_graph_misses; return 0; }
 
 static int forward_launches(const SgrProblem *pb, uint64_t capacity, uint64_t R, SgrForwardState *st, float *out_color, float *out_depth,
                             float *out_alpha, int32_t *out_radii, uint64_t *nr_pinned_host, bool preprocess_done, void *caller_clear,
@@ -222,65 +177,6 @@ extern "C" int sgr_rasterize_forward(const SgrProblem *pb, uint64_t capacity, in
     if (!image) { sgr_set_error(alloc ? "image allocator returned NULL" : "pre-allocated image blob too small"); return alloc ? 1 : 2; }
     st->image = image;
 
-    const bool try_graph = graphs_allowed() && capacity > 0 && pb->P > 0 && !sgr_prof_active() && !sgr_debug_enabled();
-    if (try_graph) {
-        std::lock_guard<std::mutex> graph_lock(g_graph_mu);
-        FwdKey key;
-        memset(&key, 0, sizeof(key));
-        key.pb = *pb; key.capacity = capacity; key.with_aux = st->with_aux; key.fwd_mode = sgr_get_forward_mode() | (g_keep_sorted_keys << 8);
-        key.color = out_color; key.depth = out_depth; key.alpha = out_alpha; key.radii = out_radii; key.nr_host = nullptr;
-        key.geom = geom; key.binning = binning; key.image = image; key.stream = nullptr;
-        key.clear = caller_clear; key.clear_bytes = caller_clear_bytes;
-        int found = -1;
-        for (int i = 0; i < g_fwd_n; i++)
-            if (memcmp(&g_fwd[i].key, &key, sizeof(key)) == 0) { found = i; break; }
-        if (found >= 0 && g_fwd[found].exec) {
-            g_fwd[found].stamp = ++g_stamp; g_graph_hits++; g_miss_streak = 0;
-            *st = g_fwd[found].st;
-            st->nr_by_copy = 1;
-            SGR_CHECK_HIP(hipGraphLaunch(g_fwd[found].exec, stream));
-            if (nr_pinned_host) SGR_CHECK_HIP(hipMemcpyAsync(nr_pinned_host, num_rendered + 2, 8, hipMemcpyDeviceToHost, stream));
-            if (nr_event) SGR_CHECK_HIP(hipEventRecord((hipEvent_t)nr_event, stream));
-            return 0;
-        }
-        g_graph_misses++;
-        if (++g_miss_streak > 256) g_graphs_enabled = 0;          // 256 forwards in a row without one repeat: pointers are not stable here, stop trying
-        if (found < 0) {
-            // first sighting of this argument set: run it with plain launches (this also makes sure every kernel's code object is
-            // loaded before anything is captured) and only remember the key; it is captured when it shows up again
-            int slot = g_fwd_n < kGraphSlots ? g_fwd_n++ : -1;
-            if (slot < 0) {                                            // evict the least recently used entry
-                slot = 0;
-                for (int i = 1; i < kGraphSlots; i++) if (g_fwd[i].stamp < g_fwd[slot].stamp) slot = i;
-                if (g_fwd[slot].exec) { (void)hipDeviceSynchronize(); (void)hipGraphExecDestroy(g_fwd[slot].exec); }
-            }
-            g_fwd[slot].key = key; g_fwd[slot].exec = nullptr; g_fwd[slot].stamp = ++g_stamp;
-        } else if (g_graphs_enabled > 0) {
-            // capture on a library-owned stream (the caller's stream may be the legacy default stream, which cannot be captured);
-            // the instantiated graph is then launched into the caller's stream
-            static hipStream_t cap_stream = nullptr;
-            if (!cap_stream && hipStreamCreateWithFlags(&cap_stream, hipStreamNonBlocking) != hipSuccess) { cap_stream = nullptr; g_graphs_enabled = 0; }
-            hipGraph_t graph = nullptr;
-            hipGraphExec_t exec = nullptr;
-            if (g_graphs_enabled > 0 && hipStreamBeginCapture(cap_stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-                const int rc = forward_launches(pb, capacity, R, st, out_color, out_depth, out_alpha, out_radii, nullptr, false, caller_clear,
-                                                caller_clear_bytes, cap_stream);
-                const hipError_t e1 = hipStreamEndCapture(cap_stream, &graph);
-                if (rc == 0 && e1 == hipSuccess && graph && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess) {
-                    (void)hipGraphDestroy(graph);
-                    g_fwd[found].exec = exec; g_fwd[found].st = *st; g_fwd[found].stamp = ++g_stamp;
-                    st->nr_by_copy = 1;
-                    SGR_CHECK_HIP(hipGraphLaunch(exec, stream));
-                    if (nr_pinned_host) SGR_CHECK_HIP(hipMemcpyAsync(nr_pinned_host, num_rendered + 2, 8, hipMemcpyDeviceToHost, stream));
-                    if (nr_event) SGR_CHECK_HIP(hipEventRecord((hipEvent_t)nr_event, stream));
-                    return 0;
-                }
-                if (graph) (void)hipGraphDestroy(graph);
-                (void)hipGetLastError();
-                g_graphs_enabled = 0;                              // capture is not usable in this process: plain launches from now on
-            }
-        }
-    }
     if (forward_launches(pb, capacity, R, st, out_color, out_depth, out_alpha, out_radii, capacity > 0 ? nr_pinned_host : nullptr,
                          preprocess_done, caller_clear, caller_clear_bytes, stream)) return 1;
     // (the event is only needed when the count travels by an asynchronous copy; a kernel's own 8-byte store is polled, and an event

@@ -1050,6 +1050,15 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64) void render_bwd_bucket_kernel(int
     // skips it -- adding its zeros would change nothing
     const bool nonzero = (S1 != 0.f) | (Sx != 0.f) | (Sy != 0.f) | (Sxx != 0.f) | (Sxy != 0.f) | (Syy != 0.f) | (aD != 0.f) | (a7 != 0.f) |
                          (a8 != 0.f) | (a9 != 0.f);
+    // The flag of EVERY survivor this launch looked at is rewritten (1 = record present, 0 = none): the flags live in the forward's image
+    // blob and are cleared only by the forward chain, so a second backward on the same forward state (retain_graph, autograd.grad twice
+    // with another upstream gradient -- the reference's calculate_adaptive_weight does that) must not see the first one's flags next to
+    // its own freshly allocated, partly unwritten record buffer.  (Instance, quadrant) pairs that are in no live bucket are never set.
+    if (has_g) {
+        const uint32_t off = rd.w, rmin = rd.x, rmax = rd.y;
+        const uint32_t inst = off + (ty - (rmin >> 16)) * ((rmax & 0xFFFFu) - (rmin & 0xFFFFu)) + (tx - (rmin & 0xFFFFu));
+        flags[(size_t)inst * 4 + q] = nonzero ? 1 : 0;
+    }
     if (has_g && nonzero) {
         // one NON-atomic 40-byte partial record per (tile instance, quadrant); preprocess_bwd gathers them in a fixed order
         const uint32_t off = rd.w, rmin = rd.x, rmax = rd.y;
@@ -1065,7 +1074,6 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64) void render_bwd_bucket_kernel(int
         rr.v[3] = make_float2(aD, a7);
         rr.v[4] = make_float2(a8, a9);
         *(reinterpret_cast<Rec40 *>(part) + ((size_t)inst * 4 + q)) = rr;
-        flags[(size_t)inst * 4 + q] = 1;
     }
 }
 
@@ -1075,7 +1083,7 @@ int sgr_validate_problem(const SgrProblem *pb);
 
 // 0 = automatic (segment-parallel for <= 2048 tiles, else one wave per quadrant), 1 = serial per-tile kernel (round 1), 2 = segment-parallel
 // kernel, 3 = one wave per (tile, quadrant) (dev/test override: sgr_set_forward_mode)
-static int sgr_fwd_mode = 0;
+static thread_local int sgr_fwd_mode = 0;          // (dev/test switch, thread-local like sgr_set_debug: the forward runs on the caller's thread)
 extern "C" int sgr_set_forward_mode(int mode) { sgr_fwd_mode = mode; return 0; }
 int sgr_get_forward_mode() { return sgr_fwd_mode; }
 
@@ -1084,7 +1092,7 @@ int sgr_get_forward_mode() { return sgr_fwd_mode; }
 extern "C" uint64_t sgr_bucket_slots(uint64_t R, uint64_t tiles_total) { return (R >> 6) + tiles_total + 1; }
 
 // checkpoint layout: 0 = automatic (rows unless their allocation would exceed SIGMAN_AUX_ROWS_MAX_BYTES, default 8 GiB), 1 = compact, 2 = rows
-static int sgr_aux_layout_mode = 0;
+static thread_local int sgr_aux_layout_mode = 0;
 extern "C" int sgr_set_aux_layout(int mode) { sgr_aux_layout_mode = mode; return 0; }
 // -> 2 (rows) or 1 (compact) for a launch with NS bucket slots per quadrant
 int sgr_aux_layout_for(uint64_t NS) {

@@ -10,16 +10,16 @@
 // emission kernel stores, transparent exact re-run on overflow), PyTorch-owned output / workspace tensors handed to the library
 // through the allocator callback of include/sigman_gsplat.h, saved state for the backward.
 //
-// Count check policy (the point of this node).  The automatic mode has to know whether the forward fitted its pre-sized buffers.  Waiting
-// for the count inside the call -- what the Python node does -- stops the host from running ahead of the GPU: the count of view v+1 is
-// queued behind view v's sort and compositing kernels, so every view pays its launch latencies in the open (measured: 160 us of
-// forward pipeline per view for 114 us of kernels).  Here a shape's capacity is LEARNED with inline checks (exact first call, then
-// inline until it has been stable for 8 calls), then raised to 2x the largest count seen and the check is DEFERRED: the count of a
-// forward is looked at by the next forwards of the thread (it has long arrived) or by its own backward, whichever comes first.  A
-// deferred overflow cannot be repaired (the truncated image has been handed out), so it raises RuntimeError from that later call,
-// re-enters the learning phase and names the numbers; the reference's caller swallows exceptions of the render call
-// (core/modules/autoencoder.py:349-361), upstream's own failure mode for exhausted buffers.  SIGMAN_COUNT_CHECK=inline keeps the
-// inline check forever.
+// Count check policy.  The automatic mode has to know whether the forward fitted its pre-sized buffers.  DEFAULT = INLINE: the count is
+// looked at inside the call, after every kernel of the chain has been queued (the emission kernel publishes it early in the chain, so the
+// wait is short), and a forward that did not fit is re-run exactly before anything is returned: the caller NEVER receives a truncated
+// image and never sees an error for it.  The price: the host cannot run further ahead of the GPU than one view.
+// OPT-IN SIGMAN_COUNT_CHECK=deferred (or set_count_check("deferred")): once a shape's capacity has been stable for 8 inline-checked calls
+// it is raised to 2x the largest count seen and the check is DEFERRED -- the host runs ahead; the count of a forward is looked at without
+// blocking before the call returns (already visible and too large -> exact re-run, transparent), else by the thread's next forwards or
+// by its own backward.  An overflow found that late cannot be repaired (the truncated image has been handed out): the forward's own
+// backward and check_pending() raise RuntimeError for it, an unrelated later forward only warns (the reference's caller swallows
+// exceptions of the render call, core/modules/autoencoder.py:349-361, and would zero the wrong batch item); the capacity is re-learned.
 //
 // PyTorch is plumbing here (tensors, streams, autograd graph); every kernel launch happens inside sgr_rasterize_forward /
 // sgr_rasterize_backward.  Built by csrc/Makefile with g++ against the installed torch headers (no device code in this file).
@@ -30,6 +30,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <array>
+#include <atomic>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -49,23 +50,39 @@ using torch::autograd::variable_list;
 
 // ---- pinned words + events for the asynchronous instance count: one per forward whose count nobody has looked at yet
 struct CountSlot { uint64_t *host = nullptr; hipEvent_t ev = nullptr; int dev = 0; };
-struct Pending { CountSlot slot; std::tuple<int, int64_t, int64_t, int64_t> key; uint64_t capacity; bool by_copy; bool checked = false; uint64_t count = 0; bool overflow = false, reported = false; int64_t id = 0; };
+struct Pending { CountSlot slot; std::tuple<int, int64_t, int64_t, int64_t> key; uint64_t capacity; bool by_copy; bool checked = false; uint64_t count = 0; bool overflow = false, reported = false, warned = false; int64_t id = 0; };
 struct ThreadState {
-    std::vector<CountSlot> free_slots;
     std::vector<std::shared_ptr<Pending>> pending;       // deferred checks of this thread, oldest first
 };
 ThreadState &tstate() { thread_local ThreadState t; return t; }
+// The slot pool is PROCESS-global (one mutex): a slot acquired by the forward thread is usually released by the autograd thread (the
+// backward resolves the count), so per-thread free lists never saw their slots again and every step allocated fresh pinned memory.
+// Bounded: at most kMaxFreeSlots idle slots are kept, the rest is handed back to the runtime.
+constexpr size_t kMaxFreeSlots = 512;
+std::mutex g_slot_mu;
+std::vector<CountSlot> g_free_slots;
+uint64_t g_slots_created = 0;
 CountSlot acquire_slot(int dev) {
-    ThreadState &t = tstate();
-    for (size_t i = 0; i < t.free_slots.size(); i++)
-        if (t.free_slots[i].dev == dev) { CountSlot s = t.free_slots[i]; t.free_slots.erase(t.free_slots.begin() + (long)i); return s; }
+    {
+        std::lock_guard<std::mutex> l(g_slot_mu);
+        for (size_t i = g_free_slots.size(); i-- > 0;)
+            if (g_free_slots[i].dev == dev) { CountSlot s = g_free_slots[i]; g_free_slots.erase(g_free_slots.begin() + (long)i); return s; }
+    }
     CountSlot s;
     s.dev = dev;
     SGR_TORCH_CHECK_HIP(hipHostMalloc((void **)&s.host, 16, hipHostMallocDefault));
     SGR_TORCH_CHECK_HIP(hipEventCreateWithFlags(&s.ev, hipEventDisableTiming));
+    { std::lock_guard<std::mutex> l(g_slot_mu); g_slots_created++; }
     return s;
 }
-void release_slot(const CountSlot &s) { tstate().free_slots.push_back(s); }
+void release_slot(const CountSlot &s) {
+    {
+        std::lock_guard<std::mutex> l(g_slot_mu);
+        if (g_free_slots.size() < kMaxFreeSlots) { g_free_slots.push_back(s); return; }
+    }
+    (void)hipEventDestroy(s.ev);
+    (void)hipHostFree(s.host);
+}
 
 struct KeyState { uint64_t capacity = 0, max_count = 0; int stable = 0; bool deferred = false; };
 std::mutex g_mu, g_pend_mu;            // g_pend_mu: a Pending is shared by the issuing thread's list and the autograd thread's backward
@@ -84,7 +101,13 @@ char *alloc_cb(void *user, int32_t which, size_t bytes) {
 inline Tensor f32c(const Tensor &t) { return (t.scalar_type() == at::kFloat && t.is_contiguous()) ? t : t.to(at::kFloat).contiguous(); }
 inline const float *fptr(const Tensor &t) { return (t.defined() && t.numel() > 0) ? t.data_ptr<float>() : nullptr; }
 
-bool inline_forever() { static const bool v = [] { const char *e = getenv("SIGMAN_COUNT_CHECK"); return e && std::string(e) == "inline"; }(); return v; }
+// 0 = inline (default), 1 = deferred once stable (opt-in)
+std::atomic<int> g_count_check{-1};
+bool deferral_allowed() {
+    int v = g_count_check.load();
+    if (v < 0) { const char *e = getenv("SIGMAN_COUNT_CHECK"); v = (e && std::string(e) == "deferred") ? 1 : 0; g_count_check.store(v); }
+    return v == 1;
+}
 
 // reads a slot's word if it is there (block: wait for it); true = resolved
 bool resolve(Pending &p, bool block) {
@@ -103,7 +126,9 @@ bool resolve(Pending &p, bool block) {
     const uint64_t word = *w;
     p.count = word & ~(1ull << 63); p.overflow = (word >> 63) != 0; p.checked = true;
     release_slot(p.slot);
-    g_by_id.erase(p.id);
+    // (an overflowed forward stays findable by its own backward, which is the call that raises for it; bounded)
+    if (!p.overflow) g_by_id.erase(p.id);
+    else while (g_by_id.size() > 4096) g_by_id.erase(g_by_id.begin());
     std::lock_guard<std::mutex> l(g_mu);
     KeyState &k = g_keys[p.key];
     if (p.overflow) { k = KeyState(); return true; }            // back to the learning phase (exact next call)
@@ -115,20 +140,28 @@ bool resolve(Pending &p, bool block) {
     return true;
 }
 [[noreturn]] void raise_deferred(Pending &p) {
-    p.reported = true;
+    { std::lock_guard<std::mutex> pl(g_pend_mu); p.reported = true; g_by_id.erase(p.id); }
     TORCH_CHECK(false, "num_rendered ", p.count, " exceeded the automatic capacity ", p.capacity, " of an EARLIER forward of this thread, whose image is "
-                "therefore truncated (its count is checked after the fact once a shape's capacity has been stable; the capacity is being re-learned now; "
-                "SIGMAN_COUNT_CHECK=inline keeps the check inside every call)");
+                "therefore truncated (SIGMAN_COUNT_CHECK=deferred: the count is checked after the fact once a shape's capacity has been stable; the "
+                "capacity is being re-learned now; the default inline check re-renders such a forward before it returns)");
 }
-// deferred checks of earlier forwards: non-blocking unless too many are outstanding
-void poll_pending() {
+// deferred checks of earlier forwards: non-blocking unless too many are outstanding.  raise_now: check_pending() -- an unrelated forward
+// only warns about an earlier forward's overflow (that forward's own backward raises)
+void poll_pending(bool raise_now) {
     ThreadState &t = tstate();
     std::shared_ptr<Pending> bad;
     size_t keep = 0;
     for (size_t i = 0; i < t.pending.size(); i++) {
         Pending &p = *t.pending[i];
         const bool done = p.checked || resolve(p, t.pending.size() - i > 128);
-        if (done && p.overflow && !p.reported && !bad) bad = t.pending[i];
+        if (done && p.overflow && !p.reported) {
+            if (raise_now) { if (!bad) bad = t.pending[i]; }
+            else if (!p.warned) {
+                p.warned = true;
+                TORCH_WARN("sigman rasterizer: an earlier deferred forward needed ", p.count, " tile instances but its automatic capacity was ", p.capacity,
+                           ": its image is truncated (its backward will raise; the capacity is being re-learned)");
+            }
+        }
         if (!done) t.pending[keep++] = t.pending[i];
     }
     t.pending.resize(keep);
@@ -175,7 +208,7 @@ struct RasterizeGaussiansNode : public torch::autograd::Function<RasterizeGaussi
         hipStream_t stream = c10::hip::getCurrentHIPStream((c10::DeviceIndex)didx).stream();
         const int with_aux = wants_grad ? 1 : 0;
         const auto cap_key = std::make_tuple(didx, P, H, W);
-        poll_pending();                                                      // earlier forwards whose count nobody has looked at yet
+        poll_pending(false);                                                 // earlier forwards whose count nobody has looked at yet
         SgrForwardState st;
         AllocCtx ac;
         ac.dev = dev;
@@ -216,7 +249,19 @@ struct RasterizeGaussiansNode : public torch::autograd::Function<RasterizeGaussi
             check_status(status, "sgr_rasterize_forward");
             if (P == 0) { release_slot(slot); break; }
             if (capacity > 0 && deferred) {
-                // steady state: the host does not wait; this forward's backward or the thread's next forwards look at the count
+                // opt-in steady state: the host does not wait.  One look without blocking: a count that is already visible and does not fit
+                // is repaired right here (exact re-run, nothing has been handed out yet); else this forward's backward or the thread's next
+                // forwards look at it
+                {
+                    volatile uint64_t *w = slot.host;
+                    const bool there = st.nr_by_copy ? hipEventQuery(slot.ev) == hipSuccess : *w != ~0ull;
+                    if (there && (*w >> 63) && attempt == 0) {
+                        release_slot(slot);
+                        std::lock_guard<std::mutex> l(g_mu);
+                        g_keys[cap_key] = KeyState();
+                        continue;
+                    }
+                }
                 mine = std::make_shared<Pending>();
                 mine->slot = slot; mine->key = cap_key; mine->capacity = capacity; mine->by_copy = st.nr_by_copy != 0;
                 { std::lock_guard<std::mutex> pl(g_pend_mu); mine->id = g_next_id++; g_by_id[mine->id] = mine; }
@@ -249,7 +294,7 @@ struct RasterizeGaussiansNode : public torch::autograd::Function<RasterizeGaussi
                     uint64_t c = count + count * 3 / 10 + 4096;
                     k.capacity = c > 0xFFFFFFE0ull ? 0xFFFFFFE0ull : c;
                     k.stable = 0;
-                } else if (++k.stable >= 8 && !inline_forever()) {            // stable: 2x the largest count seen, checks deferred from now on
+                } else if (++k.stable >= 8 && deferral_allowed()) {            // stable: 2x the largest count seen, checks deferred from now on
                     uint64_t c = 2 * k.max_count + 4096;
                     k.capacity = c > 0xFFFFFFE0ull ? 0xFFFFFFE0ull : c;
                     k.deferred = true;
@@ -331,9 +376,17 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.doc() = "C++ autograd node of the single-view upstream-signature rasterizer op above the C ABI of libsigman_gsplat.so";
     m.def("rasterize_gaussians", &rasterize_gaussians, "== diff_gaussian_rasterization.rasterize_gaussians for one view (automatic sync-free capacity)");
     m.def("abi_version", []() { return sgr_abi_version(); });
-    m.def("check_pending", []() { ThreadState &t = tstate(); for (auto &p : t.pending) resolve(*p, true); poll_pending(); },
+    m.def("check_pending", []() { ThreadState &t = tstate(); for (auto &p : t.pending) resolve(*p, true); poll_pending(true); },
           "wait for and check the deferred instance counts of this thread's earlier forwards (raises if one overflowed)");
     m.def("reset", []() { std::lock_guard<std::mutex> l(g_mu); g_keys.clear(); }, "forget the learned capacities (tests)");
+    m.def("set_count_check", [](const std::string &mode) {
+              TORCH_CHECK(mode == "inline" || mode == "deferred", "set_count_check: 'inline' or 'deferred'");
+              g_count_check.store(mode == "deferred" ? 1 : 0);
+              if (mode == "inline") { std::lock_guard<std::mutex> l(g_mu); for (auto &kv : g_keys) kv.second.deferred = false; }
+          }, "'inline' (default): the instance count is checked inside every call, a forward that does not fit is re-rendered exactly before it "
+             "returns; 'deferred': the check moves behind the call once a shape's capacity has been stable (== SIGMAN_COUNT_CHECK=deferred)");
+    m.def("slot_stats", []() { std::lock_guard<std::mutex> l(g_slot_mu); return std::make_tuple((uint64_t)g_slots_created, (uint64_t)g_free_slots.size()); },
+          "(pinned count slots ever created, idle slots in the pool)");
     m.def("key_state", [](int dev, int64_t P, int64_t H, int64_t W) { std::lock_guard<std::mutex> l(g_mu); const KeyState &k = g_keys[std::make_tuple(dev, P, H, W)];
                                                                      return std::make_tuple(k.capacity, k.max_count, k.stable, k.deferred); });
 }

@@ -119,10 +119,13 @@ class _Slot:
                 # the word is stored by the emission kernel itself (no event is recorded for it: an event between two kernels of the
                 # chain costs a ~5 us bubble on the GPU): poll, and drain the device if it takes unusually long
                 spins = 0
-                while int(self.np[0]) == -1:
+                while int(self.np[0]) == -1 and spins < 200000:
                     spins += 1
-                    if spins == 200000:
-                        torch.cuda.synchronize()
+                if int(self.np[0]) == -1:
+                    torch.cuda.synchronize()            # everything queued has run now: the word is there, or it never will be
+                    if int(self.np[0]) == -1:
+                        raise RuntimeError("the forward's instance count never reached its pinned host slot (a launch of the forward chain "
+                                           "failed or was aborted, or the library and this binding disagree about SgrForwardState.nr_by_copy)")
         w = int(self.np[0]) & 0xFFFFFFFFFFFFFFFF
         return w & (_OVF_BIT - 1), 1 if (w & _OVF_BIT) else 0
 
@@ -353,7 +356,7 @@ def _forward_impl(means3D, opacities, colors_precomp, shs, cov3D_precomp, scales
     if pending and (auto_key is not None or not use_aux):
         # automatic mode, and explicit sync-free forwards that will never see a backward (no input needs a gradient: torch.no_grad(),
         # eval, a ground-truth render): look at the count now.  Everything is queued; the count was published right after the
-        # duplicate kernel (or by the copy behind the scan kernel / the replayed graph), so this wait is short and the GPU stays busy.
+        # duplicate kernel (or by the copy behind the scan kernel), so this wait is short and the GPU stays busy.
         spins = 0
         while not slot.arrived() and spins < 20000:
             spins += 1

@@ -1,8 +1,6 @@
 import os
 import sys
 
-os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")   # before torch/HIP initialise: the tests that opt into hipGraph replay need it (csrc/rasterize.hip)
-
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -50,7 +50,6 @@ def _render_loss_factory(dev, gt, cameras):
 
 
 def _worker(rank, world, port, q):
-    os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
@@ -64,14 +63,11 @@ def _worker(rank, world, port, q):
         out = {}
         for exchange in ("full", "loss"):
             src = packed.clone() if rank == 0 or exchange == "loss" else torch.zeros_like(packed)    # "full": only rank 0 holds the attributes
-            for rep in range(3):                                              # repeated: buffers are re-used, graphs replayed
+            for rep in range(3):                                              # repeated: buffers are re-used
                 loss, grad = parallel.view_parallel_step(src, list(VIEWS), render_loss, exchange=exchange)
             torch.cuda.synchronize()
             out[exchange] = (float(loss), grad.cpu().numpy())
-        import ctypes as C
-        h, m = C.c_uint64(0), C.c_uint64(0)
-        _cabi.lib().sgr_graph_stats(C.byref(h), C.byref(m))
-        q.put((rank, out, int(h.value)))
+        q.put((rank, out, 0))
     finally:
         dist.barrier()
         dist.destroy_process_group()

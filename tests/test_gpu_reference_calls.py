@@ -239,7 +239,7 @@ def test_overflow_is_reported_without_a_backward():
 
 
 def test_debug_and_prefiltered_flags(tmp_path, monkeypatch):
-    """debug=True: sync after every kernel, same results, no graph replay, and a failing call leaves snapshot_fw.dump behind
+    """debug=True: sync after every kernel, same results, and a failing call leaves snapshot_fw.dump behind
     (upstream's behaviour); prefiltered=True with a point behind the near plane is an error (upstream traps)."""
     from sigman_release_amd import _cabi
     from sigman_release_amd import rasterizer as R
@@ -264,18 +264,9 @@ def test_debug_and_prefiltered_flags(tmp_path, monkeypatch):
         return color.detach(), d["cov3D_precomp"].grad
 
     c0, g0 = run(False)
-    h0, m0 = C.c_uint64(0), C.c_uint64(0)
-    _cabi.lib().sgr_graph_stats(C.byref(h0), C.byref(m0))
-    _cabi.lib().sgr_set_graphs(2)                                           # even with replay forced on ...
-    try:
-        for _ in range(4):
-            c1, g1 = run(True)
-            assert torch.equal(c0, c1) and torch.equal(g0, g1)
-    finally:
-        _cabi.lib().sgr_set_graphs(0)
-    h1, m1 = C.c_uint64(0), C.c_uint64(0)
-    _cabi.lib().sgr_graph_stats(C.byref(h1), C.byref(m1))
-    assert h1.value == h0.value, "debug mode must not replay launch graphs"
+    for _ in range(4):
+        c1, g1 = run(True)
+        assert torch.equal(c0, c1) and torch.equal(g0, g1)
     assert _cabi.lib().sgr_set_debug(0) == 0, "the debug flag leaked out of the call"
     with pytest.raises(RuntimeError, match="prefiltered"):
         run(False, prefiltered=True)
@@ -366,16 +357,8 @@ def test_cpp_autograd_node_equals_python_node(name):
             assert torch.equal(u, v)
 
 
-def test_cpp_node_deferred_count_check():
-    """Steady state of the C++ node: once a shape's capacity has been stable for 8 calls the instance count is no longer waited for inside
-    the call (the host runs ahead of the GPU like in the batched path); results stay identical; a forward that does not fit is reported by
-    the NEXT call (or its own backward) as RuntimeError, after which the capacity is re-learned."""
-    from sigman_release_amd import _cabi
+def _cpp_node_case(dev):
     from sigman_release_amd import rasterizer as R
-    dev = _dev()
-    node = _cabi.torch_node()
-    assert node is not None
-    node.reset()
     inp, st = cases.humanoid(P=7000, H=144, W=144, seed=41)
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     sv = cases.single_view(st)
@@ -390,30 +373,114 @@ def test_cpp_node_deferred_count_check():
         out = R.GaussianRasterizer(rs)(means3D=mm, means2D=torch.zeros_like(m), opacities=o, colors_precomp=c, cov3D_precomp=cov_)
         return out, mm
 
+    def exact(cov_):
+        bst = R.BatchedRasterizationSettings(144, 144, st["tanfovx"], st["tanfovy"], t(st["bg"]), 1.0, t(sv["viewmatrix"])[None], t(sv["projmatrix"])[None], 0,
+                                             t(sv["campos"])[None], 1)
+        with torch.no_grad():
+            return R.rasterize_gaussians_batched(m[None], None, None, c[None], o[None], None, None, cov_[None], bst)[0][0]
+    return fwd, exact, cov, P
+
+
+def test_cpp_node_default_never_returns_a_truncated_image():
+    """Default policy of the C++ node (the zero-change drop-in path): the instance count is checked inside every call and a forward that does
+    not fit its automatic capacity is re-rendered exactly before anything is returned -- however long the shape has been stable, and however
+    much larger the subject suddenly gets.  No error, no warning, the exact image and finite gradients."""
+    import warnings
+    from sigman_release_amd import _cabi
+    dev = _dev()
+    node = _cabi.torch_node()
+    assert node is not None
+    node.reset()
+    node.set_count_check("inline")
+    fwd, exact, cov, P = _cpp_node_case(dev)
     first = fwd(cov)[0][0].clone()
+    assert torch.equal(first, exact(cov))
     for i in range(14):
         assert torch.equal(fwd(cov)[0][0], first)
-    node.check_pending()
-    capacity, max_count, stable, deferred = node.key_state(0, P, 144, 144)
-    assert deferred and capacity >= 2 * max_count, (capacity, max_count, stable, deferred)
-    # gradients through a deferred forward
-    (out, mm) = fwd(cov, grad=True)
-    out[0].sum().backward()
-    assert torch.isfinite(mm.grad).all()
-    # a forward that needs > 2x the largest count seen: reported by the next call
-    big = cov * 25.0
-    fwd(big)
+    assert not node.key_state(0, P, 144, 144)[3], "the default policy must never defer the count check"
+    big = cov * 25.0                                                          # > 2x the tile instances of everything seen so far
+    want = exact(big)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        torch.cuda._sleep(20_000_000)                                         # the GPU is busy: the count is NOT there when the launches are queued
+        got, mm = fwd(big, grad=True)
+        assert torch.equal(got[0], want)
+        got[0].sum().backward()
+        assert torch.isfinite(mm.grad).all()
+        assert torch.equal(fwd(cov)[0][0], first)
+    # the pinned count slots are pooled process-wide: many forwards before one backward, repeated, do not keep creating slots
+    created0 = node.slot_stats()[0]
+    for step in range(4):
+        outs = [fwd(cov, grad=True) for _ in range(24)]
+        sum(o[0][0].sum() for o in outs).backward()
     torch.cuda.synchronize()
-    with pytest.raises(RuntimeError, match="EARLIER forward"):
-        fwd(cov)
-    # ... or by its own backward, whichever comes first
-    assert torch.equal(fwd(cov)[0][0], first)                                # re-learning: exact again, same image
-    for i in range(12):
-        fwd(cov)
-    node.check_pending()
-    assert node.key_state(0, P, 144, 144)[3]
-    (out, mm) = fwd(big, grad=True)
-    with pytest.raises(RuntimeError, match="EARLIER forward"):
-        out[0].sum().backward()
-    torch.cuda.synchronize()
+    assert node.slot_stats()[0] - created0 <= 1, node.slot_stats()
     node.reset()
+
+
+def test_cpp_node_deferred_count_check():
+    """OPT-IN steady state of the C++ node (SIGMAN_COUNT_CHECK=deferred / set_count_check("deferred")): once a shape's capacity has been stable
+    for 8 calls the instance count is no longer waited for inside the call (the host runs ahead of the GPU like in the batched path); results
+    stay identical; a forward that does not fit and whose count is already visible when its launches are queued is re-rendered exactly on
+    the spot; one whose count arrives later is reported by its own backward (RuntimeError) or check_pending(), an unrelated next forward only
+    warns; the capacity is re-learned."""
+    from sigman_release_amd import _cabi
+    dev = _dev()
+    node = _cabi.torch_node()
+    assert node is not None
+    node.reset()
+    node.set_count_check("deferred")
+    try:
+        fwd, exact, cov, P = _cpp_node_case(dev)
+        first = fwd(cov)[0][0].clone()
+        for i in range(14):
+            assert torch.equal(fwd(cov)[0][0], first)
+        node.check_pending()
+        capacity, max_count, stable, deferred = node.key_state(0, P, 144, 144)
+        assert deferred and capacity >= 2 * max_count, (capacity, max_count, stable, deferred)
+        # gradients through a deferred forward
+        (out, mm) = fwd(cov, grad=True)
+        out[0].sum().backward()
+        assert torch.isfinite(mm.grad).all()
+        big = cov * 25.0
+        # the count is visible when the call ends (idle GPU, everything drained first): repaired on the spot, exact image
+        torch.cuda.synchronize()
+        got = fwd(big)[0][0]
+        torch.cuda.synchronize()
+        if node.key_state(0, P, 144, 144)[3]:                                # (only if the count did not make it in time: then it is a late one)
+            with pytest.warns(UserWarning, match="earlier deferred forward"):
+                fwd(cov)
+        else:
+            assert torch.equal(got, exact(big))
+        # a forward that needs > 2x the largest count seen while the GPU is busy (count NOT visible in time): the next call only warns ...
+        for i in range(12):
+            fwd(cov)
+        node.check_pending()
+        assert node.key_state(0, P, 144, 144)[3]
+        torch.cuda._sleep(20_000_000)
+        fwd(big)
+        torch.cuda.synchronize()
+        with pytest.warns(UserWarning, match="earlier deferred forward"):
+            fwd(cov)
+        assert torch.equal(fwd(cov)[0][0], first)                                # re-learning: exact again, same image
+        for i in range(12):
+            fwd(cov)
+        node.check_pending()
+        assert node.key_state(0, P, 144, 144)[3]
+        # ... its own backward raises
+        torch.cuda._sleep(20_000_000)
+        (out, mm) = fwd(big, grad=True)
+        with pytest.raises(RuntimeError, match="EARLIER forward"):
+            out[0].sum().backward()
+        torch.cuda.synchronize()
+        # ... and so does check_pending()
+        for i in range(12):
+            fwd(cov)
+        node.check_pending()
+        torch.cuda._sleep(20_000_000)
+        fwd(big)
+        with pytest.raises(RuntimeError, match="EARLIER forward"):
+            node.check_pending()
+    finally:
+        node.set_count_check("inline")
+        node.reset()

@@ -1,7 +1,6 @@
 """All five BASELINE.json configs on one MI355X (evidence for DESIGN.md / README; bench.py stays the driver's contract = C2).
 Prints one JSON line per config."""
 import json, os, sys, time
-os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
 from types import SimpleNamespace
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -2,7 +2,6 @@
 upstream-signature GaussianRasterizer, clamp, stack, L1, backward.  Prints issue time (host only) and drained time per phase.
 env: GRAPHS=0|1|2, V (views, default 8), PROF=1 (cProfile of the forward loop)."""
 import cProfile, pstats, os, sys, time
-os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
 import numpy as np
 if os.environ.get("AFF"):
     os.sched_setaffinity(0, set(int(x) for x in os.environ["AFF"].split(",")))
@@ -20,9 +19,6 @@ cv, cvp, cp = [t(x) for x in cameras.make_cameras([VIEWS[i % 8] for i in range(V
 m, c, o, rgb = [t(x).requires_grad_(True) for x in (g["position"], cov, g["opacity"], g["rgb"])]
 gt = torch.rand(V, 3, H, H, device=dev)
 bg = torch.ones(3, device=dev)
-if "GRAPHS" in os.environ:
-    _cabi.lib().sgr_set_graphs(int(os.environ["GRAPHS"]))
-
 NS = int(os.environ.get("STREAMS", "0"))
 streams = [torch.cuda.Stream() for _ in range(NS)]
 
