@@ -187,6 +187,12 @@ int sgr_preprocess_forward(const SgrProblem *pb, float *rec, int32_t *radii, uin
  * order-free 11-bit tile pass; one or two 512^2 views, else like 2); 0 = onesweep over the whole key (one kernel per digit, decoupled
  * look-back); 1 = three kernels per digit.  All give bit-identical sorted keys, values and ranges (for finite depths). */
 int sgr_set_sort_mode(int mode);
+/* deep tile lists in the view-segmented flavour: instead of the register comparison network, a long tile is sorted by DISTRIBUTION in LDS
+ * by one workgroup (per window of 15 232 entries): adaptive depth bins from the tile's own histogram, bin-ordered placement, rank inside
+ * the (tiny) bin -- O(n).  mode 0 = automatic (launches with more than 1024 instances per tile on average, e.g. 1M Gaussians at 512^2:
+ * they used to fall back to six whole-key radix passes), 1 = whenever flavour 4 runs, 2 = never.  Same bits out; a tile with massive
+ * exact depth ties (> 128 in one bin) takes the generic path. */
+int sgr_set_sort_deep(int mode);
 
 /* bytes of scratch sgr_bin needs for R tile instances */
 size_t sgr_bin_workspace_bytes(uint64_t R, uint64_t tiles_total /* n_views * tiles per view */);

@@ -69,6 +69,7 @@ _SIGNATURES = {
     "sgr_set_keep_sorted_keys": (C.c_int, [C.c_int]),
     "sgr_set_debug": (C.c_int, [C.c_int]),
     "sgr_set_sort_mode": (C.c_int, [C.c_int]),
+    "sgr_set_sort_deep": (C.c_int, [C.c_int]),
     "sgr_render_forward": (C.c_int, [C.POINTER(SgrProblem)] + [C.c_void_p] * 8 + [C.c_uint64] + [C.c_void_p] * 6),
     "sgr_render_backward": (C.c_int, [C.POINTER(SgrProblem)] + [C.c_void_p] * 13 + [C.c_uint64] + [C.c_void_p] * 8),
     "sgr_preprocess_backward": (C.c_int, [C.POINTER(SgrProblem)] + [C.c_void_p] * 15),
@@ -104,6 +105,8 @@ def lib():
             raise RuntimeError(f"ABI version mismatch: library reports {L.sgr_abi_version()}, binding expects 4")
         if os.environ.get("SIGMAN_SORT_MODE", "") in ("0", "1", "2", "4", "5"):  # A/B knob: sort flavour (sgr_set_sort_mode)
             L.sgr_set_sort_mode(int(os.environ["SIGMAN_SORT_MODE"]))
+        if os.environ.get("SIGMAN_SORT_DEEP", "") in ("1", "2"):              # A/B knob: LDS distribution sort of long tiles (sgr_set_sort_deep)
+            L.sgr_set_sort_deep(int(os.environ["SIGMAN_SORT_DEEP"]))
         if os.environ.get("SIGMAN_FWD_MODE", "") in ("1", "2", "3"):      # A/B knob: forward compositing kernel (sgr_set_forward_mode)
             L.sgr_set_forward_mode(int(os.environ["SIGMAN_FWD_MODE"]))
         _lib = L

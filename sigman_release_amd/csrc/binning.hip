@@ -14,6 +14,7 @@
 // and writes 12 B per instance; only ceil((32 + bits(n_views*tiles)) / 8) passes are run.
 // No inter-workgroup communication inside a launch (upsweep / scan / downsweep are separate launches),
 // so there is nothing placement- or dispatch-order-dependent here.
+#include <algorithm>
 #include "common.h"
 
 namespace {
@@ -25,6 +26,9 @@ constexpr int kRadix = 1 << kRadixBits;
 // large batches want fewer, longer ones (less histogram traffic)
 constexpr int kItemsSmall = 4, kItemsLarge = 16;
 
+// the LDS distribution sort of long tile lists (deep_tile_kernel): a fine bin holds at most kDeepBinMax composites; LDS composites per
+// workgroup of the 1024-thread / 256-thread instantiation; worklist entry = tile id | window << 26
+constexpr uint32_t kDeepBinMax = 128, kDeepBigCap = 15360, kDeepSmallCap = 4096, kDeepTileMask = 0x03FFFFFFu;
 constexpr int kTileBins = 2048;                    // tiles of a launch whose emission kernel writes the tile pass's histogram rows (== kWide)
 struct DupExtra {
     const uint32_t *self_sums;          // un-scanned per-workgroup tile counts (NULL: block_offsets already holds the scan)
@@ -1232,7 +1236,8 @@ __global__ __launch_bounds__(64 * NW) void tile_sort_regs_kernel(const uint2 *__
 //   vseg_scatter                    every key claims the next slot of its tile with one returning LDS atomic (no stability needed: the
 //                                   per-tile sort orders (depth, value) composites, and the value grows with the emission order)
 // All sizes come from device memory (sync-free mode: the host only knows the capacity).
-struct VsegPlan { uint32_t n_chunks, pad[7], count[8], ticket[8]; };      // worklists by tile size: <= 1024, <= 2048, <= 4096, <= 8192, <= 16384, longer
+struct VsegPlan { uint32_t n_chunks, pad[7], count[8], ticket[8]; };      // worklists by tile size: <= 1024, <= 2048, <= 4096, <= 8192, <= 16384, longer; [6], [7]: the deep kernels' lists
+constexpr uint32_t kDeepMaxN = 1u << 19;                          // longer tiles (a pathological half a million entries in one 16 x 16 tile) keep the generic path
 constexpr int kVsegMaxViews = 4096, kVsegMaxBins = 4096;
 
 __global__ __launch_bounds__(kThreads) void vseg_view_totals_kernel(const uint32_t *__restrict__ sums, uint32_t nbx,
@@ -1252,16 +1257,32 @@ __global__ __launch_bounds__(kThreads) void vseg_view_totals_kernel(const uint32
 __global__ __launch_bounds__(1024) void vseg_plan_kernel(const unsigned long long *__restrict__ view_total, uint32_t n_views, uint32_t cap,
                                                          const uint64_t *__restrict__ n_dev, uint32_t chunk_keys, uint32_t max_chunks,
                                                          VsegPlan *__restrict__ plan, uint32_t *__restrict__ view_key_start,
-                                                         uint32_t *__restrict__ view_chunk_start, uint4 *__restrict__ chunk_map) {
+                                                         uint32_t *__restrict__ view_chunk_start, uint4 *__restrict__ chunk_map,
+                                                         const uint32_t *__restrict__ sums /* NULL, or the per-block emission counts [n_views][nbx] of
+                                                         a launch with <= 16 views: the view totals are then summed here (one launch fewer) */,
+                                                         uint32_t nbx) {
     __shared__ uint32_t s_key[kVsegMaxViews + 1], s_chunk[kVsegMaxViews + 1];
-    __shared__ unsigned long long s_wave[16];
+    __shared__ unsigned long long s_wave[16], s_vtot[16];
     __shared__ uint32_t s_wave32[16];
     const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    if (sums) {
+        for (uint32_t v = 0; v < n_views; v++) {
+            const uint32_t *row = sums + (size_t)v * nbx;
+            unsigned long long acc = 0;
+            for (uint32_t k = t; k < nbx; k += 1024) acc += row[k];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+            if (lane == 0) s_wave[wave] = acc;
+            __syncthreads();
+            if (t == 0) { unsigned long long a = 0; for (int w = 0; w < 16; w++) a += s_wave[w]; s_vtot[v] = a; }
+            __syncthreads();
+        }
+    }
     const unsigned long long n_true = n_dev ? min((unsigned long long)cap, (unsigned long long)*n_dev) : (unsigned long long)cap;
     // ---- exclusive scan of the view totals (4 consecutive views per thread), clamped to the keys that exist in the buffers
     unsigned long long tot[4], sum = 0;
 #pragma unroll
-    for (int j = 0; j < 4; j++) { const uint32_t v = t * 4 + j; tot[j] = v < n_views ? view_total[v] : 0ull; sum += tot[j]; }
+    for (int j = 0; j < 4; j++) { const uint32_t v = t * 4 + j; tot[j] = v < n_views ? (sums ? s_vtot[v] : view_total[v]) : 0ull; sum += tot[j]; }
     unsigned long long inc = sum;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) { const unsigned long long nb = __shfl_up(inc, off, 64); if (lane >= (uint32_t)off) inc += nb; }
@@ -1366,7 +1387,9 @@ __global__ __launch_bounds__(kThreads) void vseg_colscan_kernel(uint32_t *__rest
 // tiles by size class for the per-tile depth sort
 __global__ __launch_bounds__(1024) void vseg_scan_kernel(const uint32_t *__restrict__ tile_total, const uint32_t *__restrict__ view_key_start,
                                                          uint32_t tiles_per_view, uint2 *__restrict__ ranges, VsegPlan *__restrict__ plan,
-                                                         uint32_t *__restrict__ lists /*[6][tiles_total]: one worklist per size class*/, uint32_t tiles_total) {
+                                                         uint32_t *__restrict__ lists /*[8][list_stride]: one worklist per size class + the deep kernels' two*/,
+                                                         uint32_t list_stride, uint32_t deep_min /* tiles of more entries go to the deep kernels' lists (6, 7); 0xFFFFFFFF: none */,
+                                                         uint32_t small_max /* ... of which those up to this many to the small instantiation's (7) */) {
     __shared__ uint32_t s_wave[16];
     __shared__ uint32_t s_carry, s_cnt[8], s_base[8];
     const uint32_t v = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -1392,13 +1415,23 @@ __global__ __launch_bounds__(1024) void vseg_scan_kernel(const uint32_t *__restr
             ranges[v * tiles_per_view + d] = run ? make_uint2(start, start + run) : make_uint2(0u, 0u);
             if (run) {                                                   // (single-key tiles too: the sort kernel moves them to the destination buffer)
                 cls = run <= 1024u ? 0u : (run <= 2048u ? 1u : (run <= 4096u ? 2u : (run <= 8192u ? 3u : (run <= 16384u ? 4u : 5u))));
-                local = atomicAdd(&s_cnt[cls], 1u);
+                uint32_t take = 1u;
+                if (run > deep_min && run <= kDeepMaxN) {                            // -> the deep kernels: small tiles on list 7, big ones on list 6,
+                    if (run <= small_max) cls = 7u;
+                    else { cls = 6u; take = (run + (kDeepBigCap - kDeepBinMax) - 1u) / (kDeepBigCap - kDeepBinMax); }
+                }
+                local = atomicAdd(&s_cnt[cls], take);
             }
         }
         __syncthreads();
         if (t < 8 && s_cnt[t]) s_base[t] = atomicAdd(&plan->count[t], s_cnt[t]);
         __syncthreads();
-        if (cls < 8) lists[(size_t)cls * tiles_total + s_base[cls] + local] = v * tiles_per_view + d;
+        if (cls < 8) {
+            const uint32_t id = v * tiles_per_view + d;
+            uint32_t *dst = lists + (size_t)cls * list_stride + s_base[cls] + local;
+            dst[0] = id;
+            if (cls == 6u) { const uint32_t nw = (run + (kDeepBigCap - kDeepBinMax) - 1u) / (kDeepBigCap - kDeepBinMax); for (uint32_t w = 1; w < nw; w++) dst[w] = id | (w << 26); }
+        }
         __syncthreads();
         if (t == 0) s_carry += all;
         __syncthreads();
@@ -1477,6 +1510,242 @@ __global__ __launch_bounds__(1024) void vseg_scatter_staged_kernel(const uint64_
     for (uint32_t j = t; j < cm.z; j += NT) keys_out[j + delta[tl[j]]] = comp[j];
 }
 
+// column scan for views with MANY chunks (one view of a million Gaussians = 540 chunks: the kernel above walks them one thread per tile,
+// 70 dependent round trips): workgroup (view, slab of 64 tiles), lane = tile (a chunk's 64 counts are one 256-byte run), wave w owns the
+// chunks [w * per, (w + 1) * per) of the view: sums them, the 16 partial sums per tile meet in LDS, then it rewrites its chunks with the
+// running prefix.  Two reads + one write per count, ~2 x (per / 8) dependent round trips.
+__global__ __launch_bounds__(1024) void vseg_colscan_par_kernel(uint32_t *__restrict__ hist, const uint32_t *__restrict__ view_chunk_start,
+                                                                uint32_t tiles_per_view, uint32_t *__restrict__ tile_total) {
+    __shared__ uint32_t part[16][64];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, v = blockIdx.y;
+    const uint32_t d = min(blockIdx.x * 64u + lane, tiles_per_view - 1u);       // (clamped: lanes past the last tile redo it and store nothing)
+    const bool live = blockIdx.x * 64u + lane < tiles_per_view;
+    const uint32_t c0 = view_chunk_start[v], c1 = view_chunk_start[v + 1], nc = c1 - c0;
+    const uint32_t per = (nc + 15u) / 16u, a = c0 + min(nc, wave * per), b = min(c1, a + per);
+    uint32_t *col = hist + (size_t)a * tiles_per_view + d;
+    uint32_t sum = 0, c = a;
+    for (; c + 8 <= b; c += 8) {
+        uint32_t x[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) x[j] = col[(size_t)(c - a + j) * tiles_per_view];
+#pragma unroll
+        for (int j = 0; j < 8; j++) sum += x[j];
+    }
+    for (; c < b; c++) sum += col[(size_t)(c - a) * tiles_per_view];
+    part[wave][lane] = sum;
+    __syncthreads();
+    uint32_t run = 0, all = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < 16; w++) { const uint32_t x = part[w][lane]; if (w < wave) run += x; all += x; }
+    if (live) {
+        for (c = a; c + 8 <= b; c += 8) {
+            uint32_t x[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) x[j] = col[(size_t)(c - a + j) * tiles_per_view];
+#pragma unroll
+            for (int j = 0; j < 8; j++) { col[(size_t)(c - a + j) * tiles_per_view] = run; run += x[j]; }
+        }
+        for (; c < b; c++) { const uint32_t x = col[(size_t)(c - a) * tiles_per_view]; col[(size_t)(c - a) * tiles_per_view] = run; run += x; }
+        if (wave == 0) tile_total[(size_t)v * tiles_per_view + d] = all;
+    }
+}
+
+// ---- deep tiles: an O(n) bucket sort of a whole tile in LDS, one workgroup per tile (window) ------------------------------------------
+// The composites of a tile are (depth bits << 32 | value) with depths of ONE 16 x 16-pixel tile: a few surfaces, i.e. a smooth density
+// over a narrow range.  So instead of a comparison network (n log^2 n compare-exchanges: a 16 384-entry tile keeps sixteen waves busy
+// for ~80 us) the tile is sorted by DISTRIBUTION, entirely in LDS:
+//   1. range [lo, hi] of the tile's depth bits, a coarse 256-bin histogram over it (every 4th composite: a density estimate);
+//   2. the fine bins (4096) are dealt to the coarse bins in proportion to their share of the samples, so the fine bins are narrow where
+//      the tile is dense (a depth outlier that stretches the range, or thin surfaces, cost resolution only where nothing is);
+//      fine bin = monotone function of the depth bits (fp32 arithmetic, monotone by construction);
+//   3. fine histogram, exclusive scan, every composite stored at its bin's cursor in LDS (one returning LDS atomic): ordered by bin;
+//   4. a bin holds a handful of composites: each counts the smaller ones of its own bin (broadcast reads of neighbouring LDS words) and
+//      that rank is its final place -- the point list (and keys) leave in nearly contiguous runs.
+// Exactly the order of every other flavour: bins are ordered by depth, ranks by the full composite, composites are unique.
+// Tiles of more than CAP - 128 entries are walked in windows of whole bins (re-reading the segment, L2-warm).  A tile in which some fine
+// bin holds more than 128 composites (massive exact depth ties) goes to the generic per-tile sort's worklists instead.
+#ifdef SGR_DEEP_TIMING          /* tools/micro/bench_tile_sort.hip: phase stamps of the first tile of every workgroup (100 MHz clock) */
+__device__ unsigned long long sgr_deep_dbg[1024 * 16];
+#define SGR_STAMP(P) if (t == 0 && i == blockIdx.x && blockIdx.x < 1024u) sgr_deep_dbg[blockIdx.x * 16 + (P)] = __builtin_amdgcn_s_memrealtime();
+#else
+#define SGR_STAMP(P)
+#endif
+// worklist entry of the deep kernels: tile id | window << 26 (one workgroup per WINDOW of a tile: a tile of more than CAP - 128 entries
+// is shared by several workgroups, each of which builds the tile's histogram for itself and then places / ranks its own window)
+// A tile the distribution sort declines goes to the register sort's worklists (lists / plan).
+template <int NT, int CAP, int NBF>
+__global__ __launch_bounds__(NT) void deep_tile_kernel(const uint64_t *__restrict__ comp, uint64_t *__restrict__ dst_keys, uint32_t *__restrict__ dst_vals,
+                                                       const uint32_t *__restrict__ count_ptr, const uint32_t *__restrict__ deep_list,
+                                                       const uint2 *__restrict__ ranges, int keep_keys, VsegPlan *__restrict__ plan,
+                                                       uint32_t *__restrict__ lists, uint32_t list_stride) {
+    constexpr uint32_t RI = 16, REG = NT * RI;            // the first REG composites of a tile live in registers (RI per thread) for all passes
+    constexpr uint32_t ITEMS = 8, ROUND = NT * ITEMS;     // the rest (tiles beyond REG entries) is re-read from the segment in every pass
+    constexpr uint32_t NW = NT / 64, NBC = 256, WIN = CAP - kDeepBinMax, PER = NBF / NT;
+    static_assert(NBF % NT == 0 && NT >= (int)NBC && NT % 64 == 0 && (NBF & (NBF - 1)) == 0, "layout");
+    __shared__ uint64_t s_comp[CAP];
+    __shared__ uint32_t s_pre[NBF], s_cur[NBF];
+    __shared__ uint32_t s_ccnt[NBC], s_fstart[NBC], s_fcnt[NBC];
+    __shared__ uint32_t s_wave[NW], s_wave2[NW], s_lo, s_hi, s_bad;
+    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+    const uint32_t ndeep = *count_ptr;
+#define SGR_UNIFORM(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
+    for (uint32_t i = blockIdx.x; i < ndeep; i += gridDim.x) {
+        __syncthreads();                                                        // (LDS reuse between tiles)
+        SGR_STAMP(0)
+        const uint32_t entry = SGR_UNIFORM(deep_list[i]);
+        const uint32_t tile = entry & kDeepTileMask, w0 = (entry >> 26) * WIN;  // this workgroup's window: sorted positions of bins starting in [w0, w0 + WIN)
+        const uint2 range_v = ranges[tile];
+        const uint2 range = make_uint2(SGR_UNIFORM(range_v.x), SGR_UNIFORM(range_v.y));
+        const uint32_t n = range.y - range.x, last = n - 1u;
+        const uint64_t *seg = comp + range.x;
+        uint64_t c[RI];
+#pragma unroll
+        for (uint32_t it = 0; it < RI; it++) c[it] = seg[min(it * NT + t, last)];
+        // f(composite) for the composites beyond the registers
+        auto for_each_rest = [&](auto f) {
+            for (uint32_t r0 = REG; r0 < n; r0 += ROUND) {
+                uint64_t d[ITEMS];
+#pragma unroll
+                for (uint32_t it = 0; it < ITEMS; it++) d[it] = seg[min(r0 + it * NT + t, last)];
+#pragma unroll
+                for (uint32_t it = 0; it < ITEMS; it++) if (r0 + it * NT + t < n) f(d[it]);
+            }
+        };
+        // ---- 1. depth range, coarse histogram
+        uint32_t lo = 0xFFFFFFFFu, hi = 0u;
+#pragma unroll
+        for (uint32_t it = 0; it < RI; it++) { const uint32_t z = (uint32_t)(c[it] >> 32); lo = min(lo, z); hi = max(hi, z); }      // (indices past the end repeat the last entry)
+        for_each_rest([&](uint64_t v) { const uint32_t z = (uint32_t)(v >> 32); lo = min(lo, z); hi = max(hi, z); });
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { lo = min(lo, (uint32_t)__shfl_xor((int)lo, off, 64)); hi = max(hi, (uint32_t)__shfl_xor((int)hi, off, 64)); }
+        if (lane == 0) { s_wave[wave] = lo; s_wave2[wave] = hi; }
+        if (t < NBC) s_ccnt[t] = 0u;
+        __syncthreads();
+        if (t == 0) {
+            uint32_t a = s_wave[0], z = s_wave2[0];
+            for (uint32_t w = 1; w < NW; w++) { a = min(a, s_wave[w]); z = max(z, s_wave2[w]); }
+            s_lo = a; s_hi = z; s_bad = 0u;
+        }
+        __syncthreads();
+        SGR_STAMP(1)
+        lo = SGR_UNIFORM(s_lo);
+        // coarse position of depth bits z: (z - lo) * 256 / (range + 1) in fp32 -- monotone in z; its integer part is the coarse bin
+        const float scc = __builtin_bit_cast(float, SGR_UNIFORM(__builtin_bit_cast(uint32_t, (float)NBC / ((float)(SGR_UNIFORM(s_hi) - lo) + 1.0f))));
+        // a density estimate is all the coarse histogram is: a quarter of the composites (every 4th register / every 4th of the rest)
+        uint32_t n_samples = 0;
+#pragma unroll
+        for (uint32_t it = 0; it < RI; it += 4)
+            if (it * NT + t < n) atomicAdd(&s_ccnt[min(NBC - 1u, (uint32_t)((float)((uint32_t)(c[it] >> 32) - lo) * scc))], 1u);
+        for (uint32_t k = REG + t * 4u; k < n; k += NT * 4u) atomicAdd(&s_ccnt[min(NBC - 1u, (uint32_t)((float)((uint32_t)(seg[k] >> 32) - lo) * scc))], 1u);
+        {   // number of samples (uniform arithmetic): registers it = 0, 4, 8, 12 with it * NT + t < n, plus every 4th of the rest
+            const uint32_t nr = min(n, REG);
+#pragma unroll
+            for (uint32_t it = 0; it < RI; it += 4) n_samples += nr > it * NT ? min((uint32_t)NT, nr - it * NT) : 0u;
+            if (n > REG) n_samples += (n - REG + 3u) / 4u;
+        }
+        __syncthreads();
+        SGR_STAMP(2)
+        // ---- 2. fine bins per coarse bin: one for every occupied coarse bin + the rest in proportion to the samples
+        if (t < NBC) {
+            const uint32_t cnt = s_ccnt[t];
+            const uint32_t fc = cnt ? 1u + (uint32_t)(((uint64_t)cnt * (uint64_t)(NBF - NBC)) / n_samples) : 0u;
+            uint32_t inc = fc;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) { const uint32_t nbv = __shfl_up(inc, off, 64); if (lane >= (uint32_t)off) inc += nbv; }
+            if (lane == 63u) s_wave[wave] = inc;
+            s_fcnt[t] = fc; s_fstart[t] = inc - fc;
+        }
+        __syncthreads();
+        if (t < NBC) { uint32_t add = 0; for (uint32_t w = 0; w < wave; w++) add += s_wave[w]; s_fstart[t] += add; }
+        for (uint32_t b = t; b < (uint32_t)NBF; b += NT) s_cur[b] = 0u;
+        __syncthreads();
+        SGR_STAMP(3)
+        // fine bin of a composite: coarse bin cb + the fraction of the way through it, scaled to cb's share of the fine bins (a coarse bin
+        // that the sampling missed has no fine bins of its own: its composites join the last bin of the nearest occupied one below)
+        auto fine_bin = [&](uint64_t v) -> uint32_t {
+            const float cf = (float)((uint32_t)(v >> 32) - lo) * scc;
+            const uint32_t cb = min(NBC - 1u, (uint32_t)cf);
+            const uint32_t fs = s_fstart[cb], fn = s_fcnt[cb];
+            const float fr = cf - (float)cb;
+            return fn ? fs + min(fn - 1u, (uint32_t)(fr * (float)fn)) : (fs ? fs - 1u : 0u);
+        };
+        // ---- 3. fine histogram.  The bins of the register composites are kept (2 x 16 bits per register); all table reads of a stage are
+        // issued before the first atomic of the next (LDS operations complete in order: read, atomic, read, atomic.. would wait 16 times)
+        uint32_t fbr[RI / 2];
+        {
+            uint32_t fb[RI];
+#pragma unroll
+            for (uint32_t it = 0; it < RI; it++) fb[it] = fine_bin(c[it]);
+#pragma unroll
+            for (uint32_t it = 0; it < RI; it += 2) fbr[it / 2] = fb[it] | (fb[it + 1] << 16);
+#pragma unroll
+            for (uint32_t it = 0; it < RI; it++) if (it * NT + t < n) atomicAdd(&s_cur[fb[it]], 1u);
+        }
+        for_each_rest([&](uint64_t v) { atomicAdd(&s_cur[fine_bin(v)], 1u); });
+        __syncthreads();
+        SGR_STAMP(4)
+        {   // exclusive scan (PER consecutive bins per thread) -> s_pre; cursors = s_cur; fat bins -> generic path
+            uint32_t h[PER], sum = 0, fat = 0;
+#pragma unroll
+            for (uint32_t j = 0; j < PER; j++) { h[j] = s_cur[t * PER + j]; sum += h[j]; fat |= h[j] > kDeepBinMax ? 1u : 0u; }
+            uint32_t inc = sum;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) { const uint32_t nbv = __shfl_up(inc, off, 64); if (lane >= (uint32_t)off) inc += nbv; }
+            if (lane == 63u) s_wave[wave] = inc;
+            if (fat) s_bad = 1u;
+            __syncthreads();
+            uint32_t p = inc - sum;
+            for (uint32_t w = 0; w < wave; w++) p += s_wave[w];
+#pragma unroll
+            for (uint32_t j = 0; j < PER; j++) { s_pre[t * PER + j] = p; s_cur[t * PER + j] = p; p += h[j]; }
+        }
+        __syncthreads();
+        SGR_STAMP(5)
+        if (s_bad) {
+            if (t == 0 && w0 == 0u) {       // -> the generic per-tile sort (register classes up to 16 384 entries, global-memory passes beyond); once per tile
+                const uint32_t cls = n <= 1024u ? 0u : (n <= 2048u ? 1u : (n <= 4096u ? 2u : (n <= 8192u ? 3u : (n <= 16384u ? 4u : 5u))));
+                lists[(size_t)cls * list_stride + atomicAdd(&plan->count[cls], 1u)] = tile;
+            }
+            continue;
+        }
+        // ---- 4. my window: the bins that start in [w0, w0 + WIN) cover the sorted positions [wbeg, wend) (s_pre is monotone: first bin at
+        // or beyond a position by binary search, the same for every thread)
+        auto first_at = [&](uint32_t x) -> uint32_t {
+            uint32_t b = 0;
+            for (uint32_t step = NBF / 2; step > 0; step >>= 1) if (s_pre[b + step - 1u] < x) b += step;       // b = number of bins with s_pre < x (<= NBF - 1 probed)
+            return (b == (uint32_t)NBF - 1u && s_pre[b] < x) ? n : s_pre[b];
+        };
+        const uint32_t wbeg = SGR_UNIFORM(first_at(w0)), wend = SGR_UNIFORM(first_at(w0 + WIN));
+        {   // placement in LDS, bin-ordered (rank inside the bin = one returning LDS atomic; the order inside a bin is settled below)
+            uint32_t pp[RI];
+#pragma unroll
+            for (uint32_t it = 0; it < RI; it++) pp[it] = s_pre[(fbr[it / 2] >> (16u * (it & 1u))) & 0xFFFFu];
+#pragma unroll
+            for (uint32_t it = 0; it < RI; it++)
+                if (it * NT + t < n && pp[it] >= w0 && pp[it] < w0 + WIN) s_comp[atomicAdd(&s_cur[(fbr[it / 2] >> (16u * (it & 1u))) & 0xFFFFu], 1u) - w0] = c[it];
+            for_each_rest([&](uint64_t v) { const uint32_t fb = fine_bin(v), p = s_pre[fb]; if (p >= w0 && p < w0 + WIN) s_comp[atomicAdd(&s_cur[fb], 1u) - w0] = v; });
+        }
+        __syncthreads();
+        SGR_STAMP(6)
+        // every composite counts the smaller ones of its own bin: its final place
+        for (uint32_t q = wbeg + t; q < wend; q += NT) {
+            const uint64_t v = s_comp[q - w0];
+            const uint32_t fb = fine_bin(v);
+            const uint32_t st = s_pre[fb] - w0, en = s_cur[fb] - w0, el = en - 1u;
+            uint32_t rank = 0;
+            for (uint32_t k = st; k < en; k += 4u) {                           // four neighbours per trip (reads clamped to the bin, the surplus not counted)
+                const uint64_t x0 = s_comp[k], x1 = s_comp[min(k + 1u, el)], x2 = s_comp[min(k + 2u, el)], x3 = s_comp[min(k + 3u, el)];
+                rank += (x0 < v ? 1u : 0u) + ((k + 1u < en && x1 < v) ? 1u : 0u) + ((k + 2u < en && x2 < v) ? 1u : 0u) + ((k + 3u < en && x3 < v) ? 1u : 0u);
+            }
+            const uint32_t g = range.x + s_pre[fb] + rank;
+            if (keep_keys) dst_keys[g] = ((uint64_t)tile << 32) | (v >> 32);
+            dst_vals[g] = (uint32_t)v;
+        }
+        SGR_STAMP(7)
+    }
+#undef SGR_UNIFORM
+}
+
 // ---- F5 -------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kThreads) void tile_ranges_kernel(const uint64_t *__restrict__ keys, uint32_t n_host,
                                                                const uint64_t *__restrict__ n_dev, uint2 *__restrict__ ranges,
@@ -1502,8 +1771,11 @@ __global__ __launch_bounds__(kThreads) void tile_ranges_kernel(const uint64_t *_
 // depth bits per tile in LDS), 0 = onesweep, 1 = three kernels per pass
 thread_local int sgr_sort_mode = 3;
 
-struct VsegLayout { size_t plan, totals, key_start, chunk_start, chunk_map, hist, tile_total, lists, end; uint32_t chunk_keys, max_chunks; };
-inline VsegLayout vseg_layout(uint64_t R, uint64_t tiles_total, uint32_t n_views, uint32_t tiles_per_view) {
+struct VsegLayout {
+    size_t plan, totals, key_start, chunk_start, chunk_map, hist, tile_total, lists, end; uint32_t chunk_keys, max_chunks;
+    uint32_t list_stride;
+};
+inline VsegLayout vseg_layout(uint64_t R, uint64_t tiles_total, uint32_t n_views, uint32_t tiles_per_view, bool split = false) {
     auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
     VsegLayout L;
     L.chunk_keys = tiles_per_view > 1024 ? 8192u : 4096u;                    // = 256 * ITEMS of the kernels instantiated below
@@ -1516,7 +1788,9 @@ inline VsegLayout vseg_layout(uint64_t R, uint64_t tiles_total, uint32_t n_views
     L.chunk_map = o; o = al(o + (size_t)L.max_chunks * 16);
     L.hist = o; o = al(o + (size_t)L.max_chunks * tiles_per_view * 4);
     L.tile_total = o; o = al(o + (size_t)tiles_total * 4);
-    L.lists = o; o = al(o + (size_t)tiles_total * 4 * 6);
+    // deep mode: list 6 holds one entry per window of a big tile (<= R / (kDeepBigCap - kDeepBinMax) + tiles_total entries)
+    L.list_stride = (uint32_t)tiles_total + (split ? (uint32_t)(R / (kDeepBigCap - kDeepBinMax)) + 1u : 0u);
+    L.lists = o; o = al(o + (size_t)L.list_stride * 4 * 8);
     L.end = o;
     return L;
 }
@@ -1528,12 +1802,16 @@ inline int bits_for(uint64_t v) { int b = 0; while ((1ull << b) < v) b++; return
 int sgr_validate_problem(const SgrProblem *pb);
 
 extern "C" int sgr_set_sort_mode(int mode) { sgr_sort_mode = mode; return 0; }
+// deep tile lists in the view-segmented flavour (the LDS distribution sort, deep_tile_kernel): 0 = automatic (launches whose tile lists are
+// deep on average), 1 = whenever that flavour runs, 2 = never (deep launches then keep the whole-key passes)
+static thread_local int g_deep_mode = 0;
+extern "C" int sgr_set_sort_deep(int mode) { g_deep_mode = (mode >= 0 && mode <= 2) ? mode : 0; return 0; }
 
 extern "C" size_t sgr_bin_workspace_bytes(uint64_t R, uint64_t tiles_total) {
     const uint64_t nblocks = (R + kThreads * kItemsSmall - 1) / (kThreads * kItemsSmall);
     // onesweep: [ghist 8x256][tickets 8][err][pad] + status [8 passes][tiles][256]; three-kernel path: [hist tiles x 256][totals 256]
-    // + [worklist 64 + tiles] of the segmented flavour; the view-segmented flavour lays its plan / chunk map / histograms / two worklists
-    // over the whole area from the start (<= 2 R + R / 256 + 80 B per tile + 64 KB: see vseg_layout)
+    // + [worklist 64 + tiles] of the segmented flavour; the view-segmented flavour lays its plan / chunk map / histograms / worklists
+    // over the whole area from the start (<= 2 R + R / 256 + 100 B per tile + 64 KB: see vseg_layout)
     // (+ 4 MB: room for one 8-KB histogram row per emission workgroup of a small launch, see sgr_bin_ex)
     return (size_t)((kMaxPasses * (nblocks > 0 ? nblocks : 1) + kMaxPasses + 2) * kRadix * sizeof(uint32_t) + 1024 + ((size_t)4 << 20) +
                     (tiles_total ? (tiles_total + 64) * sizeof(uint32_t) + tiles_total * 128 + 65536 : 0));
@@ -1580,13 +1858,16 @@ int sgr_bin_ex(const SgrProblem *pb, const int32_t *radii, uint32_t *rect,
     // automatic: one or two 512^2 views (<= 2048 tiles, <= 2^19 instances): segmented with the single wide tile pass (74 vs 82 vs 100 us
     // at C2); everything else with <= 4096 tiles per view: view-segmented; beyond that the whole-key passes
     const uint32_t tpv = (uint32_t)Tx * (uint32_t)Ty;
-    const VsegLayout VL = vseg_layout(R, tiles_total, (uint32_t)pb->n_views, tpv);
+    // launches whose tile lists are deep on average (C5: 1M Gaussians on 1024 tiles): the view-segmented flavour hands its long tiles to the
+    // LDS distribution sort (deep_tile_kernel) instead of the register network; without room for its worklists they keep the whole-key passes
+    const bool deep = R > tiles_total * 1024ull;
+    const bool want_deep = g_deep_mode == 1 || (g_deep_mode == 0 && deep);
+    VsegLayout VL = vseg_layout(R, tiles_total, (uint32_t)pb->n_views, tpv, want_deep);
+    bool split = want_deep;
+    if (split && VL.end > workspace_bytes) { split = false; VL = vseg_layout(R, tiles_total, (uint32_t)pb->n_views, tpv, false); }
     const bool vseg_ok = tpv <= (uint32_t)kVsegMaxBins && pb->n_views <= kVsegMaxViews && VL.end <= workspace_bytes;
     int mode = sgr_sort_mode;
-    // (launches whose tile lists are deep on average -- C5: 1M Gaussians on 1024 tiles -- would sort most tiles through global memory in
-    // the per-tile step: those keep the whole-key passes)
-    const bool deep = R > tiles_total * 1024ull;
-    if (mode == 3) mode = (R <= (1ull << 19) && tiles_total <= 2048) ? 5 : ((vseg_ok && !deep) ? 4 : (R <= (1ull << 23) ? 1 : 0));
+    if (mode == 3) mode = (R <= (1ull << 19) && tiles_total <= 2048) ? 5 : ((vseg_ok && (!deep || split)) ? 4 : (R <= (1ull << 23) ? 1 : 0));
     if (mode == 4 && !vseg_ok) mode = R <= (1ull << 23) ? 1 : 0;
     // 5 = segmented with the register per-tile sort: needs the single wide tile pass (256 < tiles <= 2048, <= 2^19 instances) and the
     // class worklists in the area the duplicate kernel cleared (all_large); otherwise the LDS flavour
@@ -1627,14 +1908,22 @@ int sgr_bin_ex(const SgrProblem *pb, const int32_t *radii, uint32_t *rect,
         const uint32_t nblk = (uint32_t)nbx * (uint32_t)pb->n_views;
         const uint32_t *sums = block_offsets + (nblk + 1);                   // un-scanned per-block emission counts, [view][block]
         { SgrProfScope _ps(SGR_K_SORT, stream);
-        hipLaunchKernelGGL(vseg_view_totals_kernel, dim3(pb->n_views), dim3(kThreads), 0, stream, sums, (uint32_t)nbx, totals);
+        const bool fold_totals = pb->n_views <= 16;
+        if (!fold_totals) hipLaunchKernelGGL(vseg_view_totals_kernel, dim3(pb->n_views), dim3(kThreads), 0, stream, sums, (uint32_t)nbx, totals);
         hipLaunchKernelGGL(vseg_plan_kernel, dim3(1), dim3(1024), 0, stream, totals, (uint32_t)pb->n_views, n, num_rendered_dev, VL.chunk_keys,
-                           VL.max_chunks, plan, key_start, chunk_start, chunk_map);
+                           VL.max_chunks, plan, key_start, chunk_start, chunk_map, fold_totals ? sums : (const uint32_t *)nullptr, (uint32_t)nbx);
         if (VL.chunk_keys == 4096u) hipLaunchKernelGGL(vseg_upsweep_kernel<16>, dim3(VL.max_chunks), dim3(kThreads), 0, stream, kin, plan, chunk_map, tpv, vhist);
         else hipLaunchKernelGGL(vseg_upsweep_kernel<32>, dim3(VL.max_chunks), dim3(kThreads), 0, stream, kin, plan, chunk_map, tpv, vhist);
+        // views with many chunks (one or a few views of a deep launch): the chunk-parallel column scan
+        if ((uint64_t)VL.max_chunks >= 64ull * (uint64_t)pb->n_views)
+            hipLaunchKernelGGL(vseg_colscan_par_kernel, dim3((tpv + 63u) / 64u, pb->n_views), dim3(1024), 0, stream, vhist, chunk_start, tpv, tile_total);
+        else
         hipLaunchKernelGGL(vseg_colscan_kernel, dim3((tpv + kThreads - 1) / kThreads, pb->n_views), dim3(kThreads), 0, stream, vhist, chunk_start, tpv, tile_total);
+        // deep mode: one or two views -> EVERY tile goes through the LDS distribution sort (the register sort's floor is one wave's
+        // 1024-entry network, ~15 us, whatever the launch holds); more views -> the tiles beyond the single-wave class
+        const uint32_t deep_min = !split ? 0xFFFFFFFFu : (tiles_total <= 2048 ? 0u : 1024u);                  // 0xFFFFFFFF: no tile
         hipLaunchKernelGGL(vseg_scan_kernel, dim3(pb->n_views), dim3(1024), 0, stream, tile_total, key_start, tpv, (uint2 *)ranges, plan, lists,
-                           (uint32_t)tiles_total);
+                           VL.list_stride, deep_min, kDeepSmallCap - kDeepBinMax);
         if (VL.chunk_keys == 4096u)
             hipLaunchKernelGGL((vseg_scatter_staged_kernel<1024, 4>), dim3(VL.max_chunks + 8), dim3(1024), 0, stream, kin, vin, kout, plan, chunk_map, tpv, vhist,
                                (const uint2 *)ranges);
@@ -1642,16 +1931,33 @@ int sgr_bin_ex(const SgrProblem *pb, const int32_t *radii, uint32_t *rect,
             hipLaunchKernelGGL((vseg_scatter_staged_kernel<4096, 8>), dim3(VL.max_chunks + 8), dim3(1024), 0, stream, kin, vin, kout, plan, chunk_map, tpv, vhist,
                                (const uint2 *)ranges);
         SGR_CHECK_LAUNCH("view-segmented tile pass");
+        SortPrep none; none.desc = nullptr; none.n_desc = 0; none.order = nullptr; none.tiles_total = 0; none.enabled = 0;
+        if (split) {
+            // one workgroup per (window of a) deep tile sorts it by distribution in LDS; the final list goes straight to (kin, vin)
+            // (grids of resident workgroups that stride over their lists: the counts are only known on the device, and a 1024-thread workgroup
+            // with 155 KB of LDS that starts only to find nothing to do still holds a CU for microseconds)
+            const uint32_t gbig = std::max(1u, (uint32_t)std::min<uint64_t>(R / (kDeepSmallCap - kDeepBinMax) + 1, 256u));
+            const uint32_t gsmall = std::max(1u, (uint32_t)std::min<uint64_t>(std::min<uint64_t>(tiles_total, R / 64 + 1), 768u));
+            hipLaunchKernelGGL((deep_tile_kernel<1024, kDeepBigCap, 4096>), dim3(gbig), dim3(1024), 0, stream, kout, kin, vin, &plan->count[6],
+                               lists + (size_t)6 * VL.list_stride, (const uint2 *)ranges, sorted_keys ? 1 : 0, plan, lists, VL.list_stride);
+            hipLaunchKernelGGL((deep_tile_kernel<256, kDeepSmallCap, 1024>), dim3(gsmall), dim3(256), 0, stream, kout, kin, vin, &plan->count[7],
+                               lists + (size_t)7 * VL.list_stride, (const uint2 *)ranges, sorted_keys ? 1 : 0, plan, lists, VL.list_stride);
+            SGR_CHECK_LAUNCH("deep_tile_kernel");
+        }
+        {
         // depth bits per tile: keys now sit tile-bucketed in (kout, vout); the sorted list goes back into (kin, vin)
-        auto work = [&](int cls) { TileWork w = {lists + (size_t)cls * tiles_total, &plan->ticket[cls], &plan->count[cls]}; return w; };
+        auto work = [&](int cls) { TileWork w = {lists + (size_t)cls * VL.list_stride, &plan->ticket[cls], &plan->count[cls]}; return w; };
         auto grid = [&](uint32_t per_cu) { const uint64_t g = (uint64_t)per_cu * 256u; return (uint32_t)(tiles_total < g ? tiles_total : g); };
         // longest tiles first; tiles beyond the LDS capacity go through the global ping-pong buffers, a whole workgroup per tile
         const uint2 *rg = (const uint2 *)ranges;
         TileWork4 tw4;
         for (int c = 0; c < 6; c++) tw4.w[c] = work(c);
-        SortPrep none; none.desc = nullptr; none.n_desc = 0; none.order = nullptr; none.tiles_total = 0; none.enabled = 0;
-        hipLaunchKernelGGL(tile_sort_regs_kernel<16>, dim3(grid(1)), dim3(1024), 0, stream, rg, kout, vout, kin, vin, tw4, 4, 0, none, sorted_keys ? 1 : 0);
+        // (deep mode with every tile on the deep lists: only the tiles those kernels declined -- massive depth ties -- are left: a small grid,
+        // it usually just exits)
+        hipLaunchKernelGGL(tile_sort_regs_kernel<16>, dim3(deep_min == 0u ? std::min(grid(1), 64u) : grid(1)), dim3(1024), 0, stream, rg, kout, vout, kin, vin, tw4, 4, 0,
+                           none, sorted_keys ? 1 : 0);
         SGR_CHECK_LAUNCH("tile_sort_regs_kernel");
+        }
         }
         if (result_in_b_host) *result_in_b_host = (kin == keys_b) ? 1 : 0;
         return 0;

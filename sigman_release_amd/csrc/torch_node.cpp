@@ -158,8 +158,11 @@ void poll_pending(bool raise_now) {
             if (raise_now) { if (!bad) bad = t.pending[i]; }
             else if (!p.warned) {
                 p.warned = true;
-                TORCH_WARN("sigman rasterizer: an earlier deferred forward needed ", p.count, " tile instances but its automatic capacity was ", p.capacity,
-                           ": its image is truncated (its backward will raise; the capacity is being re-learned)");
+                const std::string msg = "sigman rasterizer: an earlier deferred forward needed " + std::to_string(p.count) + " tile instances but its automatic "
+                                        "capacity was " + std::to_string(p.capacity) + ": its image is truncated (its backward will raise; the capacity is being re-learned)";
+                // a real Python UserWarning when this runs on a Python thread (a forward always does); c10's handler otherwise
+                if (PyGILState_Check()) { if (PyErr_WarnEx(PyExc_UserWarning, msg.c_str(), 1) < 0) throw pybind11::error_already_set(); }
+                else TORCH_WARN(msg);
             }
         }
         if (!done) t.pending[keep++] = t.pending[i];

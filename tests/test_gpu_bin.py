@@ -25,7 +25,13 @@ def _build(n_views, P, size, seed, depth_kind, big_rects):
         h = np.where(big, rng.integers(8, T + 1, (n_views, P)), h)
     minx = (rng.random((n_views, P)) * (T - w + 1)).astype(np.int64)
     miny = (rng.random((n_views, P)) * (T - h + 1)).astype(np.int64)
-    if big_rects:                                                                # a hot 6x6-tile window: tile lists of several thousand entries
+    if big_rects == "hot1":                                                      # ONE tile receives 3/4 of everything: > 131 072 entries (64 buckets of > 2048)
+        big = np.zeros((n_views, P), bool)
+        hot = rng.random((n_views, P)) < 0.75
+        w = np.where(hot, 1, w); h = np.where(hot, 1, h)
+        minx = np.where(hot, 5, (rng.random((n_views, P)) * (T - w + 1)).astype(np.int64))
+        miny = np.where(hot, 3, (rng.random((n_views, P)) * (T - h + 1)).astype(np.int64))
+    elif big_rects:                                                              # a hot 6x6-tile window: tile lists of several thousand entries
         hot = rng.random((n_views, P)) < 0.3
         minx = np.where(hot & ~big, 10 + rng.integers(0, 3, (n_views, P)), minx)
         miny = np.where(hot & ~big, 7 + rng.integers(0, 3, (n_views, P)), miny)
@@ -72,6 +78,10 @@ def _build(n_views, P, size, seed, depth_kind, big_rects):
     (4, 60000, 512, "extreme", True),
     (2, 6000, 1024, "extreme", False),
     (2, 50000, 1024, "ties", True),            # 4096 tiles per view, many 8192-key chunks per view: the staged tile pass at full width
+    (1, 230000, 256, "ties", "hot1"),          # one tile of > 131 072 entries with five distinct depths: the deep kernels must decline it
+    (1, 230000, 256, "extreme", "hot1"),
+    (1, 230000, 256, "normal", "hot1"),        # ... and with spread-out depths: nine windows of one tile, nine workgroups
+    (3, 90000, 512, "normal", True),           # three views with long tiles, depths without ties: both deep instantiations next to the register classes
 ])
 def test_sgr_bin_direct_all_flavours(n_views, P, size, depth_kind, big_rects):
     from sigman_release_amd import _cabi
@@ -79,6 +89,8 @@ def test_sgr_bin_direct_all_flavours(n_views, P, size, depth_kind, big_rects):
     dev = torch.device("cuda", 0)
     case = _build(n_views, P, size, 11 + n_views, depth_kind, big_rects)
     R = int(case["cnt"].sum())
+    if big_rects == "hot1":
+        assert case["longest"] > 131072, case["longest"]
     if big_rects and P >= 40000:
         assert case["longest"] > 4096, case["longest"]                           # the multi-wave classes of the register sort are exercised
     nbx = int(L.sgr_preprocess_blocks_per_view(P))
@@ -99,7 +111,9 @@ def test_sgr_bin_direct_all_flavours(n_views, P, size, depth_kind, big_rects):
     tiles_total = n_views * case["T"] ** 2
     ws_bytes = int(L.sgr_bin_workspace_bytes(R, tiles_total))
     try:
-        for mode in (1, 4, 0, 2, 5, 3):
+        # (flavour, deep mode): 4 with the deep mode forced on = the long tiles (all tiles, for one or two views) go through the LDS
+        # distribution sort; tiles with massive exact depth ties must come back through the generic path
+        for mode, deep in ((1, 0), (4, 2), (4, 1), (0, 0), (2, 0), (5, 0), (3, 0)):
             radii, rect, boff = t(case["radii"]), t(case["rect"]), t(offs)
             ka, kb = (torch.zeros(R, dtype=torch.int64, device=dev) for _ in range(2))
             va, vb = (torch.zeros(R, dtype=torch.int32, device=dev) for _ in range(2))
@@ -107,14 +121,15 @@ def test_sgr_bin_direct_all_flavours(n_views, P, size, depth_kind, big_rects):
             rg = torch.full((tiles_total, 2), 0x7FFFFFFF, dtype=torch.int32, device=dev)
             in_b = C.c_int32(-1)
             L.sgr_set_sort_mode(mode)
+            L.sgr_set_sort_deep(deep)
             rc = L.sgr_bin(C.byref(pb), radii.data_ptr(), rect.data_ptr(), boff.data_ptr(), R, None, ka.data_ptr(), kb.data_ptr(),
                            va.data_ptr(), vb.data_ptr(), ws.data_ptr(), ws_bytes, rg.data_ptr(), C.byref(in_b), None)
             assert rc == 0, L.sgr_last_error()
             torch.cuda.synchronize()
             k = (kb if in_b.value else ka).cpu().numpy().view(np.uint64)
             v = (vb if in_b.value else va).cpu().numpy().view(np.uint32)
-            np.testing.assert_array_equal(k, case["keys"], err_msg=f"sorted keys, flavour {mode}")
-            np.testing.assert_array_equal(v, case["vals"], err_msg=f"point list, flavour {mode}")
+            np.testing.assert_array_equal(k, case["keys"], err_msg=f"sorted keys, flavour {mode} deep {deep}")
+            np.testing.assert_array_equal(v, case["vals"], err_msg=f"point list, flavour {mode} deep {deep}")
             got = rg.cpu().numpy().view(np.uint32)
             occ = case["ranges"][:, 1] > case["ranges"][:, 0]
             np.testing.assert_array_equal(got[occ], case["ranges"][occ], err_msg=f"tile ranges, flavour {mode}")
@@ -124,3 +139,4 @@ def test_sgr_bin_direct_all_flavours(n_views, P, size, depth_kind, big_rects):
                                           err_msg=f"first tile-instance index per Gaussian, flavour {mode}")
     finally:
         L.sgr_set_sort_mode(3)
+        L.sgr_set_sort_deep(0)

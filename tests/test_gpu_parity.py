@@ -526,15 +526,20 @@ def test_view_segmented_sort_with_oversize_tiles(oracle):
     d = _to_dev(inp, dev)
     _cabi.lib().sgr_set_sort_mode(4)
     try:
-        for cap in (0, off + 1000):
-            out = R.forward_debug(d["means3D"][None], d["opacities"][None], colors_precomp=d["colors_precomp"][None],
-                                  cov3D_precomp=d["cov3D_precomp"][None], settings=_batched_settings(st, dev, len(views))._replace(max_rendered=cap))
-            torch.cuda.synchronize()
-            np.testing.assert_array_equal(out["keys"].cpu().numpy().view(np.uint64), keys)
-            np.testing.assert_array_equal(out["point_list"].cpu().numpy().astype(np.uint32), plist)
-            np.testing.assert_array_equal(out["ranges"].cpu().numpy().astype(np.uint32), ranges)
+        # deep 2: the long tiles stay with the register sort (16-wave class / global-memory fallback); deep 1: they go to the LDS distribution
+        # sort first (the default for launches that are deep on average), which must decline the tiles with massive depth ties
+        for split, target in ((2, 0), (1, 0)):
+            _cabi.lib().sgr_set_sort_deep(split)
+            for cap in (0, off + 1000):
+                out = R.forward_debug(d["means3D"][None], d["opacities"][None], colors_precomp=d["colors_precomp"][None],
+                                      cov3D_precomp=d["cov3D_precomp"][None], settings=_batched_settings(st, dev, len(views))._replace(max_rendered=cap))
+                torch.cuda.synchronize()
+                np.testing.assert_array_equal(out["keys"].cpu().numpy().view(np.uint64), keys, err_msg=f"split {split} target {target} cap {cap}")
+                np.testing.assert_array_equal(out["point_list"].cpu().numpy().astype(np.uint32), plist, err_msg=f"split {split} target {target} cap {cap}")
+                np.testing.assert_array_equal(out["ranges"].cpu().numpy().astype(np.uint32), ranges)
     finally:
         _cabi.lib().sgr_set_sort_mode(3)
+        _cabi.lib().sgr_set_sort_deep(0)
 
 
 def _check_against_observed(name, stats):
@@ -688,6 +693,13 @@ def test_side_stream(oracle):
     side.synchronize()
     assert all(same), same
     assert np.abs(img[0].cpu().numpy() - ref.color).max() <= IMG_TOL
+
+
+def _humanoid_inputs(P, seed, dev):
+    from sigman_release_amd import synthetic
+    g = synthetic.humanoid(P, seed)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    return t(g["position"]), t(g["opacity"].reshape(P, 1)), t(g["rgb"]), t(synthetic.covariance_from_gaussians(g))
 
 
 def test_full_size_c3_batch_8x8_views_512(oracle):

@@ -357,6 +357,18 @@ def test_cpp_autograd_node_equals_python_node(name):
             assert torch.equal(u, v)
 
 
+_BUSY = {}
+
+
+def _busy(dev):
+    """Queue ~50 ms of GPU work on the current stream (fp32 matmuls): whatever is queued behind it has NOT run when the host gets its next turn."""
+    x = _BUSY.get("x")
+    if x is None:
+        x = _BUSY["x"] = torch.randn(8192, 8192, device=dev)
+    for _ in range(6):
+        _BUSY["y"] = x @ x
+
+
 def _cpp_node_case(dev):
     from sigman_release_amd import rasterizer as R
     inp, st = cases.humanoid(P=7000, H=144, W=144, seed=41)
@@ -402,7 +414,7 @@ def test_cpp_node_default_never_returns_a_truncated_image():
     want = exact(big)
     with warnings.catch_warnings():
         warnings.simplefilter("error")
-        torch.cuda._sleep(20_000_000)                                         # the GPU is busy: the count is NOT there when the launches are queued
+        _busy(dev)                                         # the GPU is busy: the count is NOT there when the launches are queued
         got, mm = fwd(big, grad=True)
         assert torch.equal(got[0], want)
         got[0].sum().backward()
@@ -453,11 +465,12 @@ def test_cpp_node_deferred_count_check():
         else:
             assert torch.equal(got, exact(big))
         # a forward that needs > 2x the largest count seen while the GPU is busy (count NOT visible in time): the next call only warns ...
-        for i in range(12):
+        node.reset()                                                            # (the repaired forward above taught the capacity the big count)
+        for i in range(14):
             fwd(cov)
         node.check_pending()
         assert node.key_state(0, P, 144, 144)[3]
-        torch.cuda._sleep(20_000_000)
+        _busy(dev)
         fwd(big)
         torch.cuda.synchronize()
         with pytest.warns(UserWarning, match="earlier deferred forward"):
@@ -468,7 +481,7 @@ def test_cpp_node_deferred_count_check():
         node.check_pending()
         assert node.key_state(0, P, 144, 144)[3]
         # ... its own backward raises
-        torch.cuda._sleep(20_000_000)
+        _busy(dev)
         (out, mm) = fwd(big, grad=True)
         with pytest.raises(RuntimeError, match="EARLIER forward"):
             out[0].sum().backward()
@@ -477,7 +490,7 @@ def test_cpp_node_deferred_count_check():
         for i in range(12):
             fwd(cov)
         node.check_pending()
-        torch.cuda._sleep(20_000_000)
+        _busy(dev)
         fwd(big)
         with pytest.raises(RuntimeError, match="EARLIER forward"):
             node.check_pending()
