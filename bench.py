@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py -- rasterizer hot-path benchmark (contract in the task brief; metric from BASELINE.json).
 
-    python bench.py [--gpus N] [--config c2|c3|c4|c5] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--config c1|c2|c3|c4|c5] [--steps K] [--warmup W]
 
 `--gpus N` with N > 1 LAUNCHES ITS OWN N RANKS (one process per GPU, `python -m torch.distributed.run --nnodes=1
 --nproc-per-node N --master-addr 127.0.0.1 ...` re-executing this file) when it is not already running under a launcher
@@ -11,6 +11,8 @@ than ranks on the RCCL backend, ends with a non-zero exit code.  (`SIGMAN_BENCH_
 N > 1 code path with all ranks on cuda:0 -- a plumbing check, not a measurement.)
 
 Configs (BASELINE.json `configs`; subjects are procedural humanoids, sigman_release_amd.synthetic):
+  c1  10 000 random Gaussians (U([-0.8,0.8]^3), isotropic log-uniform scales), 1 view 256x256, fwd+bwd: the reference's CPU-runnable case
+      (its CPU time next to C2's); weak scaling like c2.
   c2 (default, the configuration the metric is quoted on): 100 000 Gaussians, 1 view 512x512 per GPU per step, fwd+bwd,
       clamp+L1 loss.  Weak scaling: rank r renders view VIEWS[r] of the same subject.
   c3  VAE render-loss step: 8 subjects x 8 views [30,37,45,53,65,85,0,8] at 512x512, 100 000 Gaussians each, fwd+bwd.
@@ -19,11 +21,15 @@ Configs (BASELINE.json `configs`; subjects are procedural humanoids, sigman_rele
   c5  1M-Gaussian stress (10 jittered layers), 512x512, depth + alpha gradients on, fwd+bwd.  Weak scaling (1 view per GPU).
 For N > 1 the exchange is sigman_release_amd/parallel.py: by default what BASELINE.json's north_star names -- replicated
 attributes, RCCL all-reduce of the image-space loss, overlapped with the backward; `--exchange full` adds the attribute
-broadcast and the all-reduce of the attribute gradients (c2/c5 only).  c4 is forward-only and needs no collective.
+broadcast and the all-reduce of the attribute gradients -- for c3 ONE broadcast of the [8 * 13 * P] pack (42 MB) and ONE all-reduce of the
+packed gradients + loss per step.  c4 is forward-only and needs no collective.
 
 One "step" = one pass of the hot path over one batch (all view slots of this rank in ONE launch chain).  `value` = views/s
 of the whole job with inputs resident in HBM.  The timed step is the rasterizer (+ fused loss): distCUDA2 + get_covariance
-(gs.py:70-73) run once per subject outside it; their cost is reported as `frontend_ms_per_subject`.
+(gs.py:70-73) run once per subject outside it; their cost is reported as `frontend_ms_per_subject`, and `variants.renderer_render_ms_per_step`
+times what the reference's render() really pays: GaussianRenderer.render (3-NN + covariance + rasterizer + clamp) forward and backward.
+A timed region shorter than 20 ms is not a measurement: when `--steps K` would give one, max(K, 100) steps are timed instead and the line
+says so (`steps` = what was timed, `steps_requested` = K).
 `roofline` is for the dominant kernel, timed with HIP events recorded by the library on the launch stream inside the
 timed region; `roofline.traffic` comes from the committed rocprofv3 PMC summary of this same command
 (profiles/r02_pmc_<config>.json; null when there is none for the workload).  `cpu_baseline` is the CPU oracle
@@ -45,7 +51,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--config", choices=("c2", "c3", "c4", "c5"), default="c2")
+    ap.add_argument("--config", choices=("c1", "c2", "c3", "c4", "c5"), default="c2")
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--gaussians", type=int, default=None, help="override the config's Gaussians per subject")
@@ -118,6 +124,8 @@ HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8
 
 # name -> (Gaussians per subject, image size, subjects, backward?, depth+alpha grads?, scaling, steps, warmup)
 CONFIGS = {
+    "c1": dict(P=10_000, size=256, subjects=1, bwd=True, da=False, scaling="weak", steps=200, warmup=20,
+               label="C1: 10k random Gaussians (the reference's CPU-runnable plumbing case)"),
     "c2": dict(P=100_000, size=512, subjects=1, bwd=True, da=False, scaling="weak", steps=200, warmup=20,
                label="C2: procedural humanoid (SMPL-X stand-in)"),
     "c3": dict(P=100_000, size=512, subjects=8, bwd=True, da=False, scaling="strong", steps=40, warmup=6,
@@ -136,7 +144,10 @@ def algorithmic_bytes(kid: int, P: int, Rn: int, HW: int, tiles: int, bwd_da: bo
 
 
 def build_subject(cfg_name: str, P: int, seed: int, dev):
-    g = synthetic.humanoid_layers(P, seed, layers=10) if cfg_name == "c5" else synthetic.humanoid(P, seed)
+    if cfg_name == "c1":
+        g = synthetic.random_cloud(P, seed)             # world_scale: isotropic, log-uniform in [5e-3, 5e-2]
+    else:
+        g = synthetic.humanoid_layers(P, seed, layers=10) if cfg_name == "c5" else synthetic.humanoid(P, seed)
     if cfg_name == "c4":
         g["position"] = np.clip(g["position"], -1.0, 1.0)      # decode-path positions are clamped to [-1,1]^3
     cov = synthetic.covariance_from_gaussians(g)       # host stand-in for distCUDA2 + get_covariance (gs.py:70-73), untimed
@@ -188,7 +199,7 @@ def main(args):
     S = cfg["subjects"]
     bwd, da = cfg["bwd"], cfg["da"]
     # ---- the view slots of this rank
-    if args.config in ("c2", "c5"):
+    if args.config in ("c1", "c2", "c5"):
         vps = args.views_per_step
         all_views = [VIEWS[i % len(VIEWS)] for i in range(world * vps)]            # weak: one more view per extra GPU
     elif args.config == "c3":
@@ -198,7 +209,7 @@ def main(args):
     mine = [all_views[i] for i in parallel.shard_views(len(all_views), rank, world)]
     n_total_views = S * len(all_views)
     n_local = S * len(mine)
-    seeds = {"c2": [1], "c3": [100 + b for b in range(S)], "c4": [3], "c5": [4]}[args.config]
+    seeds = {"c1": [0], "c2": [1], "c3": [100 + b for b in range(S)], "c4": [3], "c5": [4]}[args.config]
     subs = [build_subject(args.config, P, s, dev) for s in seeds]
     subj = {k: torch.stack([x[0][k] for x in subs]) for k in ("means3D", "cov3D", "opacity", "rgb")}      # [S,P,...]
     g_host, cov_host = subs[0][1], subs[0][2]
@@ -262,7 +273,7 @@ def main(args):
         def rl(m, c, o, r, mv):
             out = render_loss(m, c, o, r, mv)
             return (out[0], [out[4], out[5]], [gD, gA]) if da else out     # C5: dL/ddepth, dL/dalpha seeded with the loss in one backward
-        ex = args.exchange if args.config in ("c2", "c5") else "loss"
+        ex = args.exchange
         if ex == "loss":
             # the loss value is only read after the timed region: its all-reduce is waited for one step later (it overlaps the backward AND the
             # next forward; the 4-byte collective's latency never sits between two steps)
@@ -321,6 +332,10 @@ def main(args):
         t3 = float(tr.item())
     for _ in range(min(2000, int(0.05 / max(t3 / 3.0, 1e-5)))):
         step()
+    # a timed region under 20 ms is noise, not a measurement (20 steps of C2 are 3 ms): time at least 100 steps then, and say so
+    steps_requested = steps
+    if steps * (t3 / 3.0) < 0.020:
+        steps = max(steps, 100)
 
     # ---- timed region (no per-kernel events here)
     sync_all()
@@ -374,7 +389,7 @@ def main(args):
 
     out = {
         "metric": f"rendered views/sec ({'fwd+bwd' if bwd else 'fwd'}) at {H}x{W}, {P} Gaussians/view",
-        "value": round(views_per_s, 3), "unit": "views/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+        "value": round(views_per_s, 3), "unit": "views/s", "n_gpus": world, "steps": steps, "steps_requested": steps_requested, "warmup": warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": cfg["scaling"], "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{cfg['label']}, {P} Gaussians/subject, {S} subject(s) x {len(mine)} view(s) on this GPU per step, "
@@ -398,7 +413,7 @@ def main(args):
     if rank == 0 and world == 1:
         out["frontend_ms_per_subject"] = frontend_ms(g_host, dev)
         if not args.no_variants and args.config in ("c2", "c3"):
-            out["variants"] = variants(args, subj, st, gt, norm, S, P, H, W, mine, dev)
+            out["variants"] = variants(args, subj, st, gt, norm, S, P, H, W, mine, dev, subs)
         if not args.no_cpu_baseline:
             if _ORIG_AFFINITY is not None:
                 os.sched_setaffinity(0, _ORIG_AFFINITY)      # the OpenMP oracle gets every host core
@@ -431,8 +446,10 @@ def frontend_ms(g_host, dev):
     return round((time.perf_counter() - t0) / 10 * 1e3, 4)
 
 
-def variants(args, subj, st, gt, norm, S, P, H, W, mine, dev):
+def variants(args, subj, st, gt, norm, S, P, H, W, mine, dev, subs):
     """The same workload under the conditions the headline does NOT assume (N=1 only):
+      renderer_render_*    GaussianRenderer.render (gs.py:49-117: distCUDA2 + get_covariance + all B*V views + clamp) forward and backward from
+                           the `gaussians` dict (position / scale / rotation / opacity / rgb leaves), then the same clamp+L1 loss
       per_view_loop_*      the reference's own call pattern (gs.py:62-109): Python loop over subjects and views through the
                            upstream-signature GaussianRasterizer (one launch chain + one autograd node per view), then clamp/stack/L1
       unpinned_*, exact_sync_*   the batched step re-run in a subprocess without host-thread pinning / with upstream's blocking read of
@@ -442,6 +459,28 @@ def variants(args, subj, st, gt, norm, S, P, H, W, mine, dev):
     leaves = {k: v.clone().requires_grad_(True) for k, v in subj.items()}
     vm, pm, cp = st.viewmatrix, st.projmatrix, st.campos
     V = len(mine)
+    # ---- what the reference's render() pays: the front end (3-NN, covariance) inside the step, leaves = the decoder's outputs
+    from types import SimpleNamespace
+    from sigman_release_amd.renderer import GaussianRenderer
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    gd = {k: torch.stack([t(x[1][k]) for x in subs]).requires_grad_(True) for k in ("position", "opacity", "scale", "cov3d", "rgb")}
+    rend = GaussianRenderer(SimpleNamespace(FoVy=2.0 * float(np.arctan(cameras.TAN_HALF_FOV)), output_size_h=H, output_size_w=W), device=dev)
+    cvw, cvp_, cps = vm.reshape(S, V, 4, 4), pm.reshape(S, V, 4, 4), cp.reshape(S, V, 3)
+
+    def renderer_step():
+        for v in gd.values():
+            v.grad = None
+        img = rend.render(gd, cvw, cvp_, cps, bg_color=st.bg)["image"].reshape(S * V, 3, H, W)
+        ((img - gt).abs().sum() * norm).backward()
+    n = 50 if S * V == 1 else 8
+    for _ in range(3):
+        renderer_step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        renderer_step()
+    torch.cuda.synchronize()
+    out["renderer_render_ms_per_step"] = round((time.perf_counter() - t0) / n * 1e3, 4)
 
     def per_view():
         for v in leaves.values():

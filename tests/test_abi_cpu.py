@@ -141,3 +141,18 @@ int main(void) {
                            "-L", libdir, "-lsigman_gsplat", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
     out = subprocess.check_output([str(exe)], text=True).split()
     assert int(out[0]) == 4 and int(out[1]) == (1000 >> 6) + 16 + 1 and int(out[2]) > 0
+
+
+def test_full_size_record_matches_kernel_sources():
+    """tests/golden/full_size_observed.json (the recorded decision-flip counts the full-size GPU tests use as a ceiling) is bound to the
+    kernel sources it was taken from: after any change of csrc/*.hip / common.h it must be re-recorded on the GPU
+    (SIGMAN_RECORD_OBSERVED=1 pytest -m gpu -k full_size; tools/record_full_size_observed.py) -- this catches a stale record here, without a GPU."""
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location("tgp", os.path.join(os.path.dirname(os.path.abspath(__file__)), "test_gpu_parity.py"))
+    tgp = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tgp)
+    rec = json.load(open(tgp._OBSERVED_PATH))
+    assert rec.get("_csrc_sha16") == tgp.kernel_sources_sha16(), "full_size_observed.json is stale: re-record it on the GPU box"
+    for cfg in ("c2", "c3", "c4", "c5"):
+        assert cfg in rec, cfg

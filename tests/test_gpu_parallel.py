@@ -5,7 +5,7 @@ one subject {v : v mod 2 = r} exactly like BASELINE.json configs[2] shards them 
 `parallel.view_parallel_step` with the fused rasterize + clamp/L1 node as `render_loss`, in both exchange protocols, and
 must reproduce the single-process batched result:
     loss                                  equal to 1e-6 relative (per-view partial sums are added in a different order)
-    exchange="full": gradient on each rank == the single-process gradient
+    exchange="full": gradient on each rank == the single-process gradient (1e-5 of its maximum: fp32 sums over the views in another order)
     exchange="loss": rank 0's partial + rank 1's partial == the single-process gradient; each partial == the single-process
                      gradient of that rank's views alone, BITWISE (same kernels, same inputs)
 Matches /root/reference/core/gaussians/gs.py:62-117 (the views of a subject) + core/loss/whole_loss.py:126-131 (per-view separable L1).
@@ -22,30 +22,33 @@ import torch.multiprocessing as mp
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-VIEWS = (30, 37, 45, 53, 65)          # odd count: the two ranks get 3 and 2 views
-P, H, W, SEED = 20_000, 256, 256, 7
+VIEWS = (30, 37, 45, 53, 65)          # odd count: the two ranks get 3 and 2 views (of every subject)
+S, P, H, W, SEED = 2, 12_000, 256, 256, 7    # S subjects in one packed set, like the 8 subjects of a C3 step (bench.py --config c3)
 
 
 def _problem(dev):
     from sigman_release_amd import cameras, parallel, synthetic
-    g = synthetic.humanoid(P, SEED)
+    gs = [synthetic.humanoid(P, SEED + s) for s in range(S)]
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-    packed = parallel.pack_attributes(t(g["position"]), t(synthetic.covariance_from_gaussians(g)), t(g["opacity"].reshape(P)), t(g["rgb"]))
-    gt = torch.rand(len(VIEWS), 3, H, W, generator=torch.Generator().manual_seed(11)).to(dev)
+    cat = lambda f: t(np.concatenate([f(g) for g in gs]))
+    packed = parallel.pack_attributes(cat(lambda g: g["position"]), cat(synthetic.covariance_from_gaussians), cat(lambda g: g["opacity"].reshape(P)),
+                                      cat(lambda g: g["rgb"]))                                         # [13 * S * P]: one broadcast / one all-reduce
+    gt = torch.rand(S * len(VIEWS), 3, H, W, generator=torch.Generator().manual_seed(11)).to(dev)
     return packed, gt, cameras
 
 
 def _render_loss_factory(dev, gt, cameras):
     from sigman_release_amd import rasterizer as R
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-    norm = 1.0 / (len(VIEWS) * 3 * H * W)
+    norm = 1.0 / (S * len(VIEWS) * 3 * H * W)
 
     def render_loss(means3D, cov3D, opacity, rgb, view_ids):
-        cv, cvp, cp = cameras.make_cameras(view_ids)
+        cv, cvp, cp = cameras.make_cameras(list(view_ids) * S)                # view slot v of the batch renders subject v // len(view_ids)
         st = R.BatchedRasterizationSettings(H, W, cameras.TAN_HALF_FOV, cameras.TAN_HALF_FOV, torch.ones(3, device=dev), 1.0, t(cv), t(cvp), 0,
                                             t(cp), len(view_ids), False, -1)
-        idx = [VIEWS.index(v) for v in view_ids]
-        return R.rasterize_l1_loss_batched(means3D[None], None, None, rgb[None], opacity[None], None, None, cov3D[None], st, gt[idx], None, norm)[0]
+        idx = [s * len(VIEWS) + VIEWS.index(v) for s in range(S) for v in view_ids]
+        sp = lambda x, k: x.reshape(S, P, k)
+        return R.rasterize_l1_loss_batched(sp(means3D, 3), None, None, sp(rgb, 3), sp(opacity, 1), None, None, sp(cov3D, 6), st, gt[idx], None, norm)[0]
     return render_loss
 
 
@@ -109,12 +112,12 @@ def test_two_ranks_hip_view_parallel_matches_single_process():
     for r in range(2):
         loss_f, grad_f = res[r]["full"]
         assert abs(loss_f - loss_all) <= 1e-6 * abs(loss_all), (loss_f, loss_all)
-        assert np.abs(grad_f - grad_all).max() <= 1e-6 * gmax
+        assert np.abs(grad_f - grad_all).max() <= 1e-5 * gmax          # (fp32 sums over the views in another order: observed 3e-6)
         loss_l, grad_l = res[r]["loss"]
         assert abs(loss_l - loss_all) <= 1e-6 * abs(loss_all)
         np.testing.assert_array_equal(grad_l, parts[r][1])                   # the rank's partial == single-process run of its views, bitwise
     np.testing.assert_array_equal(res[0]["full"][1], res[1]["full"][1])      # all-reduced: identical on both ranks
-    assert np.abs(res[0]["loss"][1] + res[1]["loss"][1] - grad_all).max() <= 1e-6 * gmax
+    assert np.abs(res[0]["loss"][1] + res[1]["loss"][1] - grad_all).max() <= 1e-5 * gmax
 
 
 def test_bench_rccl_path_with_one_rank():
@@ -123,7 +126,7 @@ def test_bench_rccl_path_with_one_rank():
     test box cannot hold two RCCL ranks, but every call the 8-GPU run makes is made here."""
     import json
     import subprocess
-    for exchange in ("loss", "full"):
+    for config, exchange, steps in (("c2", "loss", 20), ("c2", "full", 20), ("c3", "full", 3), ("c3", "loss", 3), ("c5", "full", 5), ("c4", "loss", 2)):
         s = socket.socket()
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -131,7 +134,7 @@ def test_bench_rccl_path_with_one_rank():
         env = dict(os.environ, SIGMAN_BENCH_FORCE_PG="1")
         env.pop("SIGMAN_BENCH_BACKEND", None)
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
-               "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5",
+               "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--config", config, "--steps", str(steps), "--warmup", "2",
                "--exchange", exchange, "--no-cpu-baseline", "--no-variants"]
         r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
@@ -139,5 +142,7 @@ def test_bench_rccl_path_with_one_rank():
         assert len(lines) == 1, r.stdout                                   # stdout carries exactly the JSON line
         out = json.loads(lines[0])
         assert out["n_gpus"] == 1 and out["config"]["ranks_seen"] == 1
-        assert out["config"]["parallelism"] == f"view-parallel x1 (nccl), exchange={exchange}"
+        want = "none (forward only)" if config == "c4" else exchange
+        assert out["config"]["parallelism"] == f"view-parallel x1 (nccl), exchange={want}", out["config"]["parallelism"]
+        assert out["config"]["name"] == config
         assert out["value"] > 0 and out["roofline"]["frac"] > 0
