@@ -345,7 +345,7 @@ __global__ __launch_bounds__(kThreads) void wide_downsweep_kernel(const uint64_t
                                                                   const uint64_t *__restrict__ n_dev, int shift, uint32_t nblocks,
                                                                   const uint32_t *__restrict__ hist, const uint32_t *__restrict__ totals,
                                                                   uint2 *__restrict__ ranges, uint32_t tiles_total,
-                                                                  uint32_t *__restrict__ worklist) {
+                                                                  uint32_t *__restrict__ worklist, uint32_t deep_all) {
     const uint32_t n = n_dev ? (uint32_t)min((uint64_t)n_host, *n_dev) : n_host;
     __shared__ uint32_t digit_base[kWide];
     __shared__ uint32_t wave_cnt[4][kWide];
@@ -388,6 +388,11 @@ __global__ __launch_bounds__(kThreads) void wide_downsweep_kernel(const uint64_t
                 ranges[d] = v[j] ? make_uint2(run, run + v[j]) : make_uint2(0u, 0u);
                 if (ORDERED) {
                     if (v[j] && worklist) worklist[1 + atomicAdd(&worklist[0], 1u)] = d;
+                } else if (v[j] && deep_all) {
+                    // every occupied tile -> the LDS distribution sort (256-thread instantiation): one entry per window of 3968 entries; list 0
+                    // runs on into the other lists' room
+                    const uint32_t nw = (v[j] + (kDeepSmallCap - kDeepBinMax) - 1u) / (kDeepSmallCap - kDeepBinMax), at = atomicAdd(&s_wl[0], nw);
+                    for (uint32_t w = 0; w < nw; w++) worklist[16u + at + w] = d | (w << 26);
                 } else if (v[j]) {
                     const uint32_t m = v[j] <= 1024u ? 0u : (v[j] <= 2048u ? 1u : (v[j] <= 4096u ? 2u : (v[j] <= 8192u ? 3u : (v[j] <= 16384u ? 4u : 5u))));
                     // (LDS counters: the ~200 returning device-scope atomics on six words of one line were a serial chain on this
@@ -462,7 +467,7 @@ template <int ITEMS>
 __global__ __launch_bounds__(kThreads) void wide_downsweep_runs_kernel(const uint64_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
                                                                        uint64_t *__restrict__ keys_out, const uint2 *__restrict__ blk_runs,
                                                                        const uint32_t *__restrict__ hist, const uint32_t *__restrict__ totals,
-                                                                       uint2 *__restrict__ ranges, uint32_t tiles_total, uint32_t *__restrict__ worklist) {
+                                                                       uint2 *__restrict__ ranges, uint32_t tiles_total, uint32_t *__restrict__ worklist, uint32_t deep_all) {
     __shared__ uint32_t digit_base[kWide];
     __shared__ uint32_t wtot[4];
     __shared__ uint32_t s_wl[8];
@@ -498,7 +503,10 @@ __global__ __launch_bounds__(kThreads) void wide_downsweep_runs_kernel(const uin
             digit_base[d] = run + hb[j];
             if (blockIdx.x == 0 && d < tiles_total) {
                 ranges[d] = v[j] ? make_uint2(run, run + v[j]) : make_uint2(0u, 0u);
-                if (v[j]) {
+                if (v[j] && deep_all) {
+                    const uint32_t nw = (v[j] + (kDeepSmallCap - kDeepBinMax) - 1u) / (kDeepSmallCap - kDeepBinMax), at = atomicAdd(&s_wl[0], nw);
+                    for (uint32_t w = 0; w < nw; w++) worklist[16u + at + w] = d | (w << 26);
+                } else if (v[j]) {
                     const uint32_t m = v[j] <= 1024u ? 0u : (v[j] <= 2048u ? 1u : (v[j] <= 4096u ? 2u : (v[j] <= 8192u ? 3u : (v[j] <= 16384u ? 4u : 5u))));
                     worklist[16u + m * tiles_total + atomicAdd(&s_wl[m], 1u)] = d;
                 }
@@ -1572,12 +1580,15 @@ __device__ unsigned long long sgr_deep_dbg[1024 * 16];
 #endif
 // worklist entry of the deep kernels: tile id | window << 26 (one workgroup per WINDOW of a tile: a tile of more than CAP - 128 entries
 // is shared by several workgroups, each of which builds the tile's histogram for itself and then places / ranks its own window)
-// A tile the distribution sort declines goes to the register sort's worklists (lists / plan).
-template <int NT, int CAP, int NBF>
-__global__ __launch_bounds__(NT) void deep_tile_kernel(const uint64_t *__restrict__ comp, uint64_t *__restrict__ dst_keys, uint32_t *__restrict__ dst_vals,
+// FB = false: a tile the distribution sort declines goes to the register sort's worklists (lists / plan).
+// FB = true (the single wide tile pass of one or two views: every occupied tile is on the list and this launch sorts everything): a declined
+// tile is sorted on the spot by stable radix passes through the global ping-pong pair (comp / scratch <-> dst), and the spare last
+// workgroup does the compositing kernel's prepare step (tile order + descriptor clear).
+template <int NT, int CAP, int NBF, bool FB = false>
+__global__ __launch_bounds__(NT) void deep_tile_kernel(uint64_t *comp, uint32_t *scratch, uint64_t *__restrict__ dst_keys, uint32_t *__restrict__ dst_vals,
                                                        const uint32_t *__restrict__ count_ptr, const uint32_t *__restrict__ deep_list,
                                                        const uint2 *__restrict__ ranges, int keep_keys, VsegPlan *__restrict__ plan,
-                                                       uint32_t *__restrict__ lists, uint32_t list_stride) {
+                                                       uint32_t *__restrict__ lists, uint32_t list_stride, SortPrep prep) {
     constexpr uint32_t RI = 16, REG = NT * RI;            // the first REG composites of a tile live in registers (RI per thread) for all passes
     constexpr uint32_t ITEMS = 8, ROUND = NT * ITEMS;     // the rest (tiles beyond REG entries) is re-read from the segment in every pass
     constexpr uint32_t NW = NT / 64, NBC = 256, WIN = CAP - kDeepBinMax, PER = NBF / NT;
@@ -1587,9 +1598,14 @@ __global__ __launch_bounds__(NT) void deep_tile_kernel(const uint64_t *__restric
     __shared__ uint32_t s_ccnt[NBC], s_fstart[NBC], s_fcnt[NBC];
     __shared__ uint32_t s_wave[NW], s_wave2[NW], s_lo, s_hi, s_bad;
     const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+    uint32_t nsort = gridDim.x;
+    if (FB && prep.enabled) {                                                     // the spare last workgroup orders the tiles for the forward
+        nsort = gridDim.x - 1;
+        if (blockIdx.x == nsort) { sgr_fwd_prepare(ranges, prep.tiles_total, prep.desc, prep.n_desc, prep.order, s_pre); return; }
+    }
     const uint32_t ndeep = *count_ptr;
 #define SGR_UNIFORM(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
-    for (uint32_t i = blockIdx.x; i < ndeep; i += gridDim.x) {
+    for (uint32_t i = blockIdx.x; i < ndeep; i += nsort) {
         __syncthreads();                                                        // (LDS reuse between tiles)
         SGR_STAMP(0)
         const uint32_t entry = SGR_UNIFORM(deep_list[i]);
@@ -1702,7 +1718,15 @@ __global__ __launch_bounds__(NT) void deep_tile_kernel(const uint64_t *__restric
         __syncthreads();
         SGR_STAMP(5)
         if (s_bad) {
-            if (t == 0 && w0 == 0u) {       // -> the generic per-tile sort (register classes up to 16 384 entries, global-memory passes beyond); once per tile
+            if constexpr (FB) {
+                if (w0 == 0u) {             // once per tile: stable LSD passes over the value bits, then the depth bits, through global memory
+                    uint32_t *l32 = (uint32_t *)s_comp;
+                    uint32_t *hist = l32, *digit_base = l32 + kRadix, *wtot = l32 + 2 * kRadix;
+                    uint32_t (*wave_cnt)[kRadix] = (uint32_t (*)[kRadix])(l32 + 2 * kRadix + 64);
+                    __syncthreads();
+                    sort_one_tile<NT, 1, true>(range, comp, scratch, dst_keys, dst_vals, nullptr, nullptr, nullptr, nullptr, hist, digit_base, wave_cnt, wtot, tile);
+                }
+            } else if (t == 0 && w0 == 0u) {       // -> the generic per-tile sort (register classes up to 16 384 entries, global-memory passes beyond); once per tile
                 const uint32_t cls = n <= 1024u ? 0u : (n <= 2048u ? 1u : (n <= 4096u ? 2u : (n <= 8192u ? 3u : (n <= 16384u ? 4u : 5u))));
                 lists[(size_t)cls * list_stride + atomicAdd(&plan->count[cls], 1u)] = tile;
             }
@@ -1938,10 +1962,10 @@ int sgr_bin_ex(const SgrProblem *pb, const int32_t *radii, uint32_t *rect,
             // with 155 KB of LDS that starts only to find nothing to do still holds a CU for microseconds)
             const uint32_t gbig = std::max(1u, (uint32_t)std::min<uint64_t>(R / (kDeepSmallCap - kDeepBinMax) + 1, 256u));
             const uint32_t gsmall = std::max(1u, (uint32_t)std::min<uint64_t>(std::min<uint64_t>(tiles_total, R / 64 + 1), 768u));
-            hipLaunchKernelGGL((deep_tile_kernel<1024, kDeepBigCap, 4096>), dim3(gbig), dim3(1024), 0, stream, kout, kin, vin, &plan->count[6],
-                               lists + (size_t)6 * VL.list_stride, (const uint2 *)ranges, sorted_keys ? 1 : 0, plan, lists, VL.list_stride);
-            hipLaunchKernelGGL((deep_tile_kernel<256, kDeepSmallCap, 1024>), dim3(gsmall), dim3(256), 0, stream, kout, kin, vin, &plan->count[7],
-                               lists + (size_t)7 * VL.list_stride, (const uint2 *)ranges, sorted_keys ? 1 : 0, plan, lists, VL.list_stride);
+            hipLaunchKernelGGL((deep_tile_kernel<1024, kDeepBigCap, 4096>), dim3(gbig), dim3(1024), 0, stream, kout, vout, kin, vin, &plan->count[6],
+                               lists + (size_t)6 * VL.list_stride, (const uint2 *)ranges, sorted_keys ? 1 : 0, plan, lists, VL.list_stride, none);
+            hipLaunchKernelGGL((deep_tile_kernel<256, kDeepSmallCap, 1024>), dim3(gsmall), dim3(256), 0, stream, kout, vout, kin, vin, &plan->count[7],
+                               lists + (size_t)7 * VL.list_stride, (const uint2 *)ranges, sorted_keys ? 1 : 0, plan, lists, VL.list_stride, none);
             SGR_CHECK_LAUNCH("deep_tile_kernel");
         }
         {
@@ -1965,17 +1989,20 @@ int sgr_bin_ex(const SgrProblem *pb, const int32_t *radii, uint32_t *rect,
     const bool segmented = mode == 2;
     if (segmented && wide_regs) {
         uint32_t *wl = (uint32_t *)((char *)workspace + sgr_bin_workspace_bytes(R, 0));     // [16 counters][6][tiles_total]
+        // per-tile step: the LDS distribution sort (O(n), one 256-thread workgroup per window of 3968 entries, ONE launch for everything) or
+        // -- sgr_set_sort_deep(2) -- the register network, whose launch lasts as long as its longest tile's 4- or 8-wave network
+        const bool wide_deep = g_deep_mode != 2;
         { SgrProfScope _ps(SGR_K_SORT, stream);
         if (emit_hist) {
         hipLaunchKernelGGL(wide_rowscan_kernel, dim3(kWide / 64), dim3(1024), 0, stream, hist, nblk_e, hist + (size_t)nblk_e * kWide);
         hipLaunchKernelGGL(wide_downsweep_runs_kernel<kItemsSmall>, dim3(nblk_e), dim3(kThreads), 0, stream, kin, vin, kout, blk_runs, hist,
-                           hist + (size_t)nblk_e * kWide, (uint2 *)ranges, (uint32_t)tiles_total, wl);
+                           hist + (size_t)nblk_e * kWide, (uint2 *)ranges, (uint32_t)tiles_total, wl, wide_deep ? 1u : 0u);
         SGR_CHECK_LAUNCH("wide tile-bit pass (emitted rows)");
         } else {
         hipLaunchKernelGGL(wide_upsweep_kernel<kItemsSmall>, dim3(nblocks), dim3(kThreads), 0, stream, kin, n, num_rendered_dev, 32, nblocks, hist);
         hipLaunchKernelGGL(wide_rowscan_kernel, dim3(kWide / 64), dim3(1024), 0, stream, hist, nblocks, hist + (size_t)nblocks * kWide);
         hipLaunchKernelGGL((wide_downsweep_kernel<kItemsSmall, false>), dim3(nblocks), dim3(kThreads), 0, stream, kin, vin, kout, vout, n, num_rendered_dev, 32,
-                           nblocks, hist, hist + (size_t)nblocks * kWide, (uint2 *)ranges, (uint32_t)tiles_total, wl);
+                           nblocks, hist, hist + (size_t)nblocks * kWide, (uint2 *)ranges, (uint32_t)tiles_total, wl, wide_deep ? 1u : 0u);
         SGR_CHECK_LAUNCH("wide tile-bit pass");
         }
         // composites sit tile-bucketed in kout (vout is scratch); the sorted list goes back into (kin, vin)
@@ -1985,6 +2012,10 @@ int sgr_bin_ex(const SgrProblem *pb, const int32_t *radii, uint32_t *rect,
         sp.desc = (uint2 *)prep_desc; sp.n_desc = prep_n_desc; sp.order = prep_order; sp.tiles_total = (uint32_t)tiles_total;
         sp.enabled = (prep_order || prep_desc) ? 1 : 0;
         const uint32_t g = (uint32_t)(tiles_total < 256 ? tiles_total : 256);
+        if (wide_deep)      // (up to 3 resident workgroups per CU stride over the window list)
+            hipLaunchKernelGGL((deep_tile_kernel<256, kDeepSmallCap, 1024, true>), dim3((uint32_t)std::min<uint64_t>(tiles_total + R / (kDeepSmallCap - kDeepBinMax) + 1, 768u) + (sp.enabled ? 1u : 0u)),
+                               dim3(256), 0, stream, kout, vout, kin, vin, wl, wl + 16, (const uint2 *)ranges, sorted_keys ? 1 : 0, (VsegPlan *)nullptr, (uint32_t *)nullptr, 0u, sp);
+        else
         hipLaunchKernelGGL(tile_sort_regs_kernel<16>, dim3(g + (sp.enabled ? 1u : 0u)), dim3(1024), 0, stream, (const uint2 *)ranges, kout, vout, kin, vin,
                            tw4, 4, 0, sp, sorted_keys ? 1 : 0);
         if (sp.enabled && prep_done) *prep_done = 1;
@@ -2003,7 +2034,7 @@ int sgr_bin_ex(const SgrProblem *pb, const int32_t *radii, uint32_t *rect,
             hipLaunchKernelGGL(wide_upsweep_kernel<kItemsSmall>, dim3(nblocks), dim3(kThreads), 0, stream, kin, n, num_rendered_dev, 32, nblocks, hist);
             hipLaunchKernelGGL(wide_rowscan_kernel, dim3(kWide / 64), dim3(1024), 0, stream, hist, nblocks, hist + (size_t)nblocks * kWide);
             hipLaunchKernelGGL((wide_downsweep_kernel<kItemsSmall, true>), dim3(nblocks), dim3(kThreads), 0, stream, kin, vin, kout, vout, n, num_rendered_dev, 32, nblocks, hist, hist + (size_t)nblocks * kWide,
-                               (uint2 *)ranges, (uint32_t)tiles_total, worklist);
+                               (uint2 *)ranges, (uint32_t)tiles_total, worklist, 0u);
             SGR_CHECK_LAUNCH("wide tile-bit pass");
             uint64_t *tk = kin; kin = kout; kout = tk;
             uint32_t *tv = vin; vin = vout; vout = tv;

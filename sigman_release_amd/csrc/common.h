@@ -99,18 +99,18 @@ __device__ __forceinline__ uint32_t sgr_lane_id() { return __builtin_amdgcn_mbcn
 __device__ __forceinline__ void sgr_atomic_add(float *p, float v) { unsafeAtomicAdd(p, v); }
 
 
-// Work order for the segment-parallel forward + clear of the bucket descriptors, executed by ONE 1024-thread workgroup (its own
+// Work order for the segment-parallel forward + clear of the bucket descriptors, executed by ONE workgroup of any size (its own
 // tiny kernel in render.hip, or the spare last workgroup of the tile-sort launch in binning.hip).  tmp: 66 words of LDS.
 // order[0] = number of tiles, order[1..] = tile ids, longest list first (32 classes by n >> 7), empty tiles last.
 __device__ __forceinline__ void sgr_fwd_prepare(const uint2 *__restrict__ ranges, uint32_t tiles_total, uint2 *__restrict__ desc, size_t n_desc,
                                                 uint32_t *__restrict__ order, uint32_t *tmp) {
     uint32_t *sHist = tmp, *sCur = tmp + 33;
-    const uint32_t t = threadIdx.x;
-    if (desc) for (size_t i = t; i < n_desc; i += 1024) desc[i] = make_uint2(0u, 0u);
+    const uint32_t t = threadIdx.x, nt = blockDim.x;
+    if (desc) for (size_t i = t; i < n_desc; i += nt) desc[i] = make_uint2(0u, 0u);
     if (!order) return;
     if (t < 33) sHist[t] = 0;
     __syncthreads();
-    for (uint32_t tile = t; tile < tiles_total; tile += 1024) {
+    for (uint32_t tile = t; tile < tiles_total; tile += nt) {
         const uint2 r = ranges[tile];
         atomicAdd(&sHist[r.y > r.x ? 31u - min(31u, (r.y - r.x) >> 7) : 32u], 1u);
     }
@@ -121,7 +121,7 @@ __device__ __forceinline__ void sgr_fwd_prepare(const uint2 *__restrict__ ranges
         order[0] = run;                                          // == tiles_total
     }
     __syncthreads();
-    for (uint32_t tile = t; tile < tiles_total; tile += 1024) {
+    for (uint32_t tile = t; tile < tiles_total; tile += nt) {
         const uint2 r = ranges[tile];
         order[1u + atomicAdd(&sCur[r.y > r.x ? 31u - min(31u, (r.y - r.x) >> 7) : 32u], 1u)] = tile;
     }

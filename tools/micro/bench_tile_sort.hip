@@ -129,8 +129,8 @@ static void run_deep_case(const std::string &name, std::vector<uint32_t> len, ui
     }
     auto reset = [&]() { CK(hipMemcpyAsync(plan, &hp, sizeof(hp), hipMemcpyHostToDevice, 0)); };
     auto deep = [&]() {
-        hipLaunchKernelGGL((deep_tile_kernel<1024, kDeepBigCap, 4096>), dim3(std::max(1u, std::min((uint32_t)lists[6].size(), 256u))), dim3(1024), 0, 0, ka, kb, vb, &plan->count[6], list + (size_t)6 * stride, ranges, 1, plan, list, stride);
-        hipLaunchKernelGGL((deep_tile_kernel<256, kDeepSmallCap, 1024>), dim3(std::max(1u, std::min((uint32_t)lists[7].size(), 768u))), dim3(256), 0, 0, ka, kb, vb, &plan->count[7], list + (size_t)7 * stride, ranges, 1, plan, list, stride); };
+        hipLaunchKernelGGL((deep_tile_kernel<1024, kDeepBigCap, 4096>), dim3(std::max(1u, std::min((uint32_t)lists[6].size(), 256u))), dim3(1024), 0, 0, ka, va, kb, vb, &plan->count[6], list + (size_t)6 * stride, ranges, 1, plan, list, stride, SortPrep{nullptr, 0, nullptr, 0, 0});
+        hipLaunchKernelGGL((deep_tile_kernel<256, kDeepSmallCap, 1024>), dim3(std::max(1u, std::min((uint32_t)lists[7].size(), 768u))), dim3(256), 0, 0, ka, va, kb, vb, &plan->count[7], list + (size_t)7 * stride, ranges, 1, plan, list, stride, SortPrep{nullptr, 0, nullptr, 0, 0}); };
     auto sort = [&]() { hipLaunchKernelGGL(tile_sort_regs_kernel<16>, dim3(getenv("BTS_SORTGRID") ? atoi(getenv("BTS_SORTGRID")) : 256), dim3(1024), 0, 0, ranges, ka, va, kb, vb, tw4, 4, 0, SortPrep{nullptr, 0, nullptr, 0, 0}, 1); };
     // events around each stage only (the counter reset is a host-to-device copy)
     hipEvent_t e0, e1, e2; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1)); CK(hipEventCreate(&e2));
