@@ -32,7 +32,7 @@ A timed region shorter than 20 ms is not a measurement: when `--steps K` would g
 says so (`steps` = what was timed, `steps_requested` = K).
 `roofline` is for the dominant kernel, timed with HIP events recorded by the library on the launch stream inside the
 timed region; `roofline.traffic` comes from the committed rocprofv3 PMC summary of this same command
-(profiles/r02_pmc_<config>.json; null when there is none for the workload).  `cpu_baseline` is the CPU oracle
+(profiles/r03_pmc_<config>.json; null when there is none for the workload).  `cpu_baseline` is the CPU oracle
 (oracle/gsplat_ref.c, OpenMP) on a bounded sample of the same inputs, rank 0 at N=1 only.
 """
 from __future__ import annotations
@@ -219,6 +219,8 @@ def main(args):
     if n_local:
         cv, cvp, cp = cameras.make_cameras(mine * S)                               # slot v -> subject v // len(mine)
         st = R.BatchedRasterizationSettings(H, W, cameras.TAN_HALF_FOV, cameras.TAN_HALF_FOV, bg, 0.5, t(cv), t(cvp), 0, t(cp), len(mine))
+        if da:
+            st = st._replace(depth_alpha_grads=True)       # C5 differentiates depth and alpha: their checkpoints are written by the forward
         if not args.exact_sync:
             # sync-free mode: size the binning buffers from one exact (untimed) forward, +25 % head-room; an overflow would raise
             with torch.no_grad():
@@ -378,14 +380,16 @@ def main(args):
     # HBM traffic of the dominant kernel from the committed rocprofv3 PMC summary of this same command (separate --pmc passes,
     # gfx950 FETCH_SIZE correction applied as MI355X_MICROARCH.md prescribes); null when no summary matches this workload
     traffic, traffic_src = None, None
-    try:
-        path = os.path.join(ROOT, "profiles", f"r02_pmc_{args.config}.json")
-        pmc = json.load(open(path))
-        if pmc.get("P") == P and pmc.get("size") == H and pmc.get("view_slots") == n_local:
-            traffic = pmc["kernels"].get(KERNELS.get(dominant, ""), {}).get("hbm_bytes_corrected")
-            traffic_src = f"profiles/r02_pmc_{args.config}.json (kernels of commit {pmc.get('commit', '?')})"
-    except Exception:
-        traffic = None
+    for rnd in ("r03", "r02"):                      # the newest committed summary for this config
+        try:
+            path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_{args.config}.json")
+            pmc = json.load(open(path))
+            if pmc.get("P") == P and pmc.get("size") == H and pmc.get("view_slots") == n_local:
+                traffic = pmc["kernels"].get(KERNELS.get(dominant, ""), {}).get("hbm_bytes_corrected")
+                traffic_src = f"profiles/{rnd}_pmc_{args.config}.json (kernels of commit {pmc.get('commit', '?')})"
+                break
+        except Exception:
+            traffic = None
 
     out = {
         "metric": f"rendered views/sec ({'fwd+bwd' if bwd else 'fwd'}) at {H}x{W}, {P} Gaussians/view",

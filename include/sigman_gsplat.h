@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SGR_ABI_VERSION 4
+#define SGR_ABI_VERSION 5
 #define SGR_TILE 16                 /* 16x16 pixel tiles, as the published algorithm */
 #define SGR_REC_FLOATS 12           /* floats of a gradient record (grec, pixel-parallel backward) */
 #define SGR_PART_FLOATS 10          /* floats of a partial gradient record (bucket-parallel backward): 40 B, 8-byte aligned */
@@ -98,6 +98,8 @@ typedef struct SgrForwardState {
     uint64_t true_rendered;      /* exact mode: num_rendered; sync-free mode: ~0 (read nr_pinned_host after nr_event) */
     uint64_t NS;                 /* bucket slots per quadrant */
     int32_t with_aux /* 0 none, 1 compact checkpoints, 2 row checkpoints */, result_in_b, flags_cleared;
+    int32_t aux_no_da;           /* 1: the forward left the (depth, alpha) checkpoints out (with_aux & 2); sgr_rasterize_backward adds them on demand */
+    int32_t fwd_kind;            /* the compositing kernel the forward used (1 serial per tile, 2 segment-parallel, 3 one wave per quadrant) */
     int32_t nr_by_copy;          /* sync-free mode: 1 = the count reaches nr_pinned_host through an async device-to-host COPY (not byte-atomic: wait for
                                     nr_event before reading it); 0 = through one 8-byte store of a kernel (the word may be polled) */
     void *geom, *binning, *image;
@@ -116,7 +118,9 @@ typedef struct SgrForwardState {
  *               recorded), 1 = an async copy (a copy engine may write it piecewise: `nr_event`, a hipEvent_t, may be NULL, is recorded
  *               behind the launch chain: wait for it before reading).
  *               (exact mode fills nr_pinned_host[0] = count, [1] = overflow flag before it returns.)
- * with_aux != 0 also records what the bucket-parallel backward needs.
+ * with_aux != 0 also records what the bucket-parallel backward needs; with_aux = 3 (bit 1) leaves the per-pixel (depth, alpha) checkpoints --
+ *               a third of the checkpoint stream, read only by a backward that is handed dL/ddepth or dL/dalpha -- to that backward, which
+ *               then produces them with a second compositing pass (never needed on the reference's call paths).
  * alloc may be NULL if state->geom / binning / image and their *_bytes capacities are pre-filled by the caller (sizes as reported in
  * the state of an earlier call with the same shapes): no callbacks; returns 2 (nothing useful launched) if a blob is too small.
  * caller_clear / caller_clear_bytes: optional device buffer (multiple of 4 bytes) that the call zeroes on the side of its own

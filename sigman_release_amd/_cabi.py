@@ -29,7 +29,7 @@ class SgrProblem(C.Structure):
 
 class SgrForwardState(C.Structure):
     _fields_ = [("R_alloc", C.c_uint64), ("true_rendered", C.c_uint64), ("NS", C.c_uint64), ("with_aux", C.c_int32), ("result_in_b", C.c_int32),
-                ("flags_cleared", C.c_int32), ("nr_by_copy", C.c_int32),
+                ("flags_cleared", C.c_int32), ("aux_no_da", C.c_int32), ("fwd_kind", C.c_int32), ("nr_by_copy", C.c_int32),
                 ("geom", C.c_void_p), ("binning", C.c_void_p), ("image", C.c_void_p),
                 ("geom_bytes", C.c_uint64), ("binning_bytes", C.c_uint64), ("image_bytes", C.c_uint64)] + \
                [(n, C.c_uint64) for n in ("off_rec", "off_rect", "off_clamped", "off_block_offsets", "off_num_rendered", "off_keys_a",
@@ -101,8 +101,8 @@ def lib():
             fn = getattr(L, name)          # AttributeError if a declared symbol is not exported
             fn.restype = res
             fn.argtypes = args
-        if L.sgr_abi_version() != 4:
-            raise RuntimeError(f"ABI version mismatch: library reports {L.sgr_abi_version()}, binding expects 4")
+        if L.sgr_abi_version() != 5:
+            raise RuntimeError(f"ABI version mismatch: library reports {L.sgr_abi_version()}, binding expects 5")
         if os.environ.get("SIGMAN_SORT_MODE", "") in ("0", "1", "2", "4", "5"):  # A/B knob: sort flavour (sgr_set_sort_mode)
             L.sgr_set_sort_mode(int(os.environ["SIGMAN_SORT_MODE"]))
         if os.environ.get("SIGMAN_SORT_DEEP", "") in ("1", "2"):              # A/B knob: LDS distribution sort of long tiles (sgr_set_sort_deep)
@@ -129,7 +129,7 @@ def torch_node():
             spec = importlib.util.spec_from_file_location("sgr_torch_node", path)
             mod = importlib.util.module_from_spec(spec)
             spec.loader.exec_module(mod)
-            if mod.abi_version() != 4:
+            if mod.abi_version() != 5:
                 raise RuntimeError("sgr_torch_node.so was built against another ABI version of libsigman_gsplat.so: rebuild (make -C sigman_release_amd/csrc)")
             _node = mod
     return _node

@@ -37,7 +37,8 @@ int sgr_preprocess_backward_ex(const SgrProblem *pb, const int32_t *radii, const
 int sgr_render_forward_wants_prepare(const SgrProblem *pb, uint64_t R, bool use_aux, size_t *n_desc_out);
 int sgr_render_forward_ex(const SgrProblem *pb, const uint32_t *ranges, const uint32_t *point_list, const float *rec, float *out_color,
                           float *out_depth, float *out_alpha, float *final_T, uint32_t *n_contrib, uint64_t R, void *aux_compact,
-                          void *aux_ckpt_tc, void *aux_ckpt_da, void *aux_desc, uint32_t *aux_order, bool prepared, int aux_layout, void *stream_);
+                          void *aux_ckpt_tc, void *aux_ckpt_da, void *aux_desc, uint32_t *aux_order, bool prepared, int aux_layout, int kind, void *stream_);
+int sgr_render_forward_kind(const SgrProblem *pb);
 int sgr_get_forward_mode();
 int sgr_aux_layout_for(uint64_t NS);
 
@@ -80,11 +81,12 @@ static int forward_launches(const SgrProblem *pb, uint64_t capacity, uint64_t R,
     if (caller_clear && caller_clear_bytes && !clear_done[1]) SGR_CHECK_HIP(hipMemsetAsync(caller_clear, 0, (size_t)caller_clear_bytes, stream));
     st->result_in_b = in_b;
     const uint32_t *point_list = (const uint32_t *)(binning + (in_b ? st->off_vals_b : st->off_vals_a));
+    st->fwd_kind = sgr_render_forward_kind(pb);
     return sgr_render_forward_ex(pb, (const uint32_t *)(image + st->off_ranges), point_list, rec, out_color, out_depth, out_alpha,
                               (float *)(image + st->off_final_T), (uint32_t *)(image + st->off_n_contrib), R,
                               aux_on ? image + st->off_compact : nullptr, aux_on ? image + st->off_ckpt_tc : nullptr,
-                              aux_on ? image + st->off_ckpt_da : nullptr, aux_on ? image + st->off_desc : nullptr,
-                              (uint32_t *)(image + st->off_order), prep_done != 0, st->with_aux, stream);
+                              (aux_on && !st->aux_no_da) ? image + st->off_ckpt_da : nullptr, aux_on ? image + st->off_desc : nullptr,
+                              (uint32_t *)(image + st->off_order), prep_done != 0, st->with_aux, st->fwd_kind, stream);
 }
 
 extern "C" int sgr_rasterize_forward(const SgrProblem *pb, uint64_t capacity, int32_t with_aux, sgr_alloc_fn alloc, void *user,
@@ -159,6 +161,9 @@ extern "C" int sgr_rasterize_forward(const SgrProblem *pb, uint64_t capacity, in
     const bool aux_on = with_aux && R > 0;
     const uint64_t NS = sgr_bucket_slots(R, tiles_total);
     st->NS = NS; st->with_aux = aux_on ? sgr_aux_layout_for(NS) : 0;       // 0 none, 1 compact checkpoints, 2 one checkpoint per 16-survivor row
+    // with_aux & 2: the (depth, alpha) checkpoints -- a third of the checkpoint stream -- are not written now: only a backward that is
+    // handed dL/ddepth or dL/dalpha reads them (no call path of the reference does), and it then produces them with a second compositing pass
+    st->aux_no_da = (aux_on && (with_aux & 2)) ? 1 : 0;
     o = 0;
     st->off_ranges = o; o = align_up(o + tiles_total * 8);
     st->off_final_T = o; o = align_up(o + hw * 4);
@@ -169,7 +174,7 @@ extern "C" int sgr_rasterize_forward(const SgrProblem *pb, uint64_t capacity, in
         st->off_compact = o; o = align_up(o + 4 * R * 8);
         const uint64_t rows = st->with_aux == 2 ? 4 : 1;                    // checkpoint records per pixel and 64-survivor bucket
         st->off_ckpt_tc = o; o = align_up(o + 4 * NS * rows * 64 * 16);
-        st->off_ckpt_da = o; o = align_up(o + 4 * NS * rows * 64 * 8);
+        st->off_ckpt_da = o; o = align_up(o + (st->aux_no_da ? 0 : 4 * NS * rows * 64 * 8));
         st->off_desc = o; o = align_up(o + 4 * NS * 8);
     }
     st->image_bytes = o;
@@ -212,7 +217,11 @@ extern "C" int sgr_rasterize_backward(const SgrProblem *pb, const SgrForwardStat
     const bool aux_on = st->with_aux != 0;
     // scratch: bucket-parallel path = partial records [4*R][10] f32 + flags [R] u32; pixel-parallel path = grec [nq][12] f32
     const uint64_t part_bytes = align_up(st->R_alloc * 4 * SGR_PART_FLOATS * 4);
-    const uint64_t scratch_bytes = aux_on ? part_bytes : nq * SGR_REC_FLOATS * 4;
+    // depth / alpha gradients on a forward that left their checkpoints out: room for them in the scratch blob, filled by a second
+    // compositing pass below (same kernels, same lists: the same values the forward would have stored)
+    const bool da_refill = aux_on && st->aux_no_da && (grad_depth || grad_alpha);
+    const uint64_t da_bytes = da_refill ? align_up(4 * st->NS * (st->with_aux == 2 ? 4 : 1) * 64 * 8) : 0;
+    const uint64_t scratch_bytes = aux_on ? part_bytes + da_bytes : nq * SGR_REC_FLOATS * 4;
     char *scratch = alloc(user, 3, (size_t)scratch_bytes);
     if (!scratch) { sgr_set_error("scratch allocator returned NULL"); return 1; }
     float *part = aux_on ? (float *)scratch : nullptr;
@@ -222,10 +231,19 @@ extern "C" int sgr_rasterize_backward(const SgrProblem *pb, const SgrForwardStat
     const float *rec = (const float *)(geom + st->off_rec);
     const uint32_t *rect = (const uint32_t *)(geom + st->off_rect);
     const uint32_t *point_list = (const uint32_t *)(binning + (st->result_in_b ? st->off_vals_b : st->off_vals_a));
+    const void *ckpt_da = (aux_on && !st->aux_no_da) ? image + st->off_ckpt_da : nullptr;
+    if (da_refill) {
+        char *im = (char *)st->image;
+        void *da = scratch + part_bytes;
+        if (sgr_render_forward_ex(pb, (const uint32_t *)(image + st->off_ranges), point_list, rec, (float *)out_color, (float *)out_depth, (float *)out_alpha,
+                                  (float *)(im + st->off_final_T), (uint32_t *)(im + st->off_n_contrib), st->R_alloc, im + st->off_compact, nullptr, da,
+                                  im + st->off_desc, (uint32_t *)(im + st->off_order), /*prepared=*/true, st->with_aux, st->fwd_kind, stream_)) return 1;
+        ckpt_da = da;
+    }
     if (sgr_render_backward_ex(pb, (const uint32_t *)(image + st->off_ranges), point_list, rec, rect, (const float *)(image + st->off_final_T),
                             (const uint32_t *)(image + st->off_n_contrib), out_color, out_depth, out_alpha, grad_color, grad_depth,
                             grad_alpha, grad_color_scale, st->R_alloc, aux_on ? image + st->off_compact : nullptr, aux_on ? image + st->off_ckpt_tc : nullptr,
-                            aux_on ? image + st->off_ckpt_da : nullptr, aux_on ? image + st->off_desc : nullptr, grec, part, flags, st->flags_cleared != 0, st->with_aux, stream_))
+                            ckpt_da, aux_on ? image + st->off_desc : nullptr, grec, part, flags, st->flags_cleared != 0, st->with_aux, stream_))
         return 1;
     return sgr_preprocess_backward_ex(pb, radii, pb->shs ? (const uint8_t *)(geom + st->off_clamped) : nullptr, grec, rect, part, flags, st->R_alloc,
                                    dL_dmeans3D, dL_dmeans2D, dL_dopacity, dL_dcolors, dL_dsh, dL_dcov3D, dL_dscales, dL_drotations,

@@ -62,8 +62,9 @@ struct FwdAux {
     //           rebuilds the states in front of rows 1..3 with a 48-step walk.  4x less checkpoint footprint and traffic, backward +55 %
     //           (measured at C3: 1.33 -> 2.06 ms for a forward gain of 0.12 ms; selected when the row layout would not fit, rasterize.hip).
     //   The row / bucket at ordinal 0 of a list is never stored (T = 1, sums = 0).
-    float4 *ckpt_tc;
-    float2 *ckpt_da;      // same for (D, A)
+    float4 *ckpt_tc;      // NULL: "depth/alpha only" pass (see ckpt_da): nothing but ckpt_da is written, no outputs either
+    float2 *ckpt_da;      // same for (D, A).  NULL: not stored -- only a backward with dL/ddepth or dL/dalpha reads them (never on the reference's
+                          // call paths), so by default they are produced on demand by a second compositing pass with ckpt_tc = NULL
     uint2 *desc;          // [4*NS]  (global tile id | (rps - 1) << 30, (start << 7) | count): `count` (<= 64) survivors starting at ordinal `start`
                           //          (a multiple of 64) of the (tile, quadrant) list; count == 0 -> slot unused
     uint32_t R, NS;
@@ -135,7 +136,7 @@ __global__ __launch_bounds__(kBlock) void render_fwd_kernel(int W, int H, int Tx
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         uint64_t active = __ballot(!done);
-        if (AUX && active) {
+        if (AUX && active && aux.ckpt_tc) {
             uint2 *dst = aux.compact + (size_t)wave * aux.R + range.x + kbase;
             for (uint32_t g = lane; g < cnt; g += 64) {
                 const uint32_t j = sList[wave][g];
@@ -168,14 +169,14 @@ __global__ __launch_bounds__(kBlock) void render_fwd_kernel(int W, int H, int Tx
                         const uint32_t row = (ord >> 4) & 3u;
                         const size_t s = ((slot0 + (ord >> 6)) * 4 + row) * 64 + lane;
                         if (row == 0u) { B0 = C0; B1 = C1; B2 = C2; BD = D; BA = A; }       // bucket start: absolute state
-                        aux.ckpt_tc[s] = row ? make_float4(T, C0 - B0, C1 - B1, C2 - B2) : make_float4(T, C0, C1, C2);
-                        aux.ckpt_da[s] = row ? make_float2(D - BD, A - BA) : make_float2(D, A);
+                        if (aux.ckpt_tc) aux.ckpt_tc[s] = row ? make_float4(T, C0 - B0, C1 - B1, C2 - B2) : make_float4(T, C0, C1, C2);
+                        if (aux.ckpt_da) aux.ckpt_da[s] = row ? make_float2(D - BD, A - BA) : make_float2(D, A);
                     }
                 } else if constexpr (AUX == 1) {
                     if ((ord & 63u) == 0u && ord != 0u && g + u < cnt) {                    // bucket start: absolute state
                         const size_t s = (slot0 + (ord >> 6)) * 64 + lane;
-                        aux.ckpt_tc[s] = make_float4(T, C0, C1, C2);
-                        aux.ckpt_da[s] = make_float2(D, A);
+                        if (aux.ckpt_tc) aux.ckpt_tc[s] = make_float4(T, C0, C1, C2);
+                        if (aux.ckpt_da) aux.ckpt_da[s] = make_float2(D, A);
                     }
                 }
                 const float test_T = T * (1.f - al[u]);
@@ -193,7 +194,7 @@ __global__ __launch_bounds__(kBlock) void render_fwd_kernel(int W, int H, int Tx
         }
         kbase += cnt;
     }
-    if (inside) {
+    if (inside && !(AUX && !aux.ckpt_tc)) {
         const size_t hw = (size_t)H * W;
         const size_t pix = (size_t)py * W + px;
         const size_t vb = (size_t)view * hw;
@@ -210,7 +211,7 @@ __global__ __launch_bounds__(kBlock) void render_fwd_kernel(int W, int H, int Tx
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, off, 64));
         const uint32_t nb = (kmax + 63u) >> 6;
-        for (uint32_t bk = lane; bk < nb; bk += 64)
+        for (uint32_t bk = lane; bk < nb && aux.ckpt_tc; bk += 64)
             aux.desc[slot0 + bk] = make_uint2(bid | (3u << 30), (bk << 13) | min(64u, kmax - (bk << 6)));   // rps = 4: rows 1-3 relative to row 0
     }
 }
@@ -274,7 +275,7 @@ __global__ __launch_bounds__(64) void render_fwd_wave_kernel(int W, int H, int T
             sB[pos] = make_float4(kHalfLog2e * rb.x, rb.y, rb.z, rb.w);
             sC[pos] = rc;
             sJ[pos] = (uint16_t)lane;
-            if (AUX) aux.compact[(size_t)q * aux.R + range.x + kbase + pos] = make_uint2(rid, (uint32_t)(base + lane));
+            if (AUX && aux.ckpt_tc) aux.compact[(size_t)q * aux.R + range.x + kbase + pos] = make_uint2(rid, (uint32_t)(base + lane));
         }
         if (lane == 0) { sA[cnt] = make_float4(0.f, 0.f, 0.f, 0.f); sB[cnt] = sA[cnt]; sC[cnt] = sA[cnt]; }      // null Gaussian behind an odd count
         // ---- next batch: records now, ids of the batch after it
@@ -313,14 +314,14 @@ __global__ __launch_bounds__(64) void render_fwd_wave_kernel(int W, int H, int T
                         const uint32_t row = (ord >> 4) & 3u;
                         const size_t s = ((slot0 + (ord >> 6)) * 4 + row) * 64 + lane;
                         if (row == 0u) { B0 = C0; B1 = C1; B2 = C2; BD = D; BA = A; }       // bucket start: absolute state
-                        aux.ckpt_tc[s] = row ? make_float4(T, C0 - B0, C1 - B1, C2 - B2) : make_float4(T, C0, C1, C2);
-                        aux.ckpt_da[s] = row ? make_float2(D - BD, A - BA) : make_float2(D, A);
+                        if (aux.ckpt_tc) aux.ckpt_tc[s] = row ? make_float4(T, C0 - B0, C1 - B1, C2 - B2) : make_float4(T, C0, C1, C2);
+                        if (aux.ckpt_da) aux.ckpt_da[s] = row ? make_float2(D - BD, A - BA) : make_float2(D, A);
                     }
                 } else if constexpr (AUX == 1) {
                     if ((ord & 63u) == 0u && ord != 0u && g + u < cnt) {                    // bucket start: absolute state
                         const size_t s = (slot0 + (ord >> 6)) * 64 + lane;
-                        aux.ckpt_tc[s] = make_float4(T, C0, C1, C2);
-                        aux.ckpt_da[s] = make_float2(D, A);
+                        if (aux.ckpt_tc) aux.ckpt_tc[s] = make_float4(T, C0, C1, C2);
+                        if (aux.ckpt_da) aux.ckpt_da[s] = make_float2(D, A);
                     }
                 }
                 const float test_T = T * (1.f - al[u]);
@@ -342,7 +343,7 @@ __global__ __launch_bounds__(64) void render_fwd_wave_kernel(int W, int H, int T
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
-    if (inside) {
+    if (inside && !(AUX && !aux.ckpt_tc)) {
         const size_t hw = (size_t)H * W;
         const size_t pix = (size_t)py * W + px;
         const size_t vb = (size_t)view * hw;
@@ -359,7 +360,7 @@ __global__ __launch_bounds__(64) void render_fwd_wave_kernel(int W, int H, int T
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, off, 64));
         const uint32_t nb = (kmax + 63u) >> 6;
-        for (uint32_t bk = lane; bk < nb; bk += 64)
+        for (uint32_t bk = lane; bk < nb && aux.ckpt_tc; bk += 64)
             aux.desc[slot0 + bk] = make_uint2(bid | (3u << 30), (bk << 13) | min(64u, kmax - (bk << 6)));   // rps = 4: rows 1-3 relative to row 0
     }
 }
@@ -466,7 +467,7 @@ __global__ __launch_bounds__(kSegThreads, 4) void render_fwd_seg_kernel(int W, i
                 fd[2 * h] = rb.w; fd[2 * h + 1] = rc.x;
                 fe[2 * h] = rc.y; fe[2 * h + 1] = rb.z;
                 ((uint32_t *)&pI[pr])[h] = (uint32_t)idx + 1u;
-                if (AUX) aux.compact[(size_t)q * aux.R + range.x + kbase + ord] = make_uint2(rid, (uint32_t)idx);
+                if (AUX && aux.ckpt_tc) aux.compact[(size_t)q * aux.R + range.x + kbase + ord] = make_uint2(rid, (uint32_t)idx);
             }
             qcount += m;
             commit += kSegThreads;
@@ -539,8 +540,8 @@ __global__ __launch_bounds__(kSegThreads, 4) void render_fwd_seg_kernel(int W, i
                     // state at survivor 16 / 32 / 48 of my segment, relative to the segment start (the start's absolute sums are only
                     // known after the cross-wave prefix below; the backward adds the two)
                     const size_t sl = ((slot_next + (s0 >> 6)) * 4 + brow0 + ((s - s0) >> 4)) * 64 + lane;
-                    aux.ckpt_tc[sl] = make_float4(T, d01.x, d01.y, d2D.x);
-                    aux.ckpt_da[sl] = make_float2(d2D.y, dA);
+                    if (aux.ckpt_tc) aux.ckpt_tc[sl] = make_float4(T, d01.x, d01.y, d2D.x);
+                    if (aux.ckpt_da) aux.ckpt_da[sl] = make_float2(d2D.y, dA);
                 }
             }
             float al[4];
@@ -603,16 +604,16 @@ __global__ __launch_bounds__(kSegThreads, 4) void render_fwd_seg_kernel(int W, i
                     const size_t slot = slot_next + (s0 >> 6);
                     if constexpr (AUX == 2) {
                         if (kbase + s0 != 0u) {
-                            aux.ckpt_tc[(slot * 4 + brow0) * 64 + lane] = make_float4(Tin, p0, p1, p2);
-                            aux.ckpt_da[(slot * 4 + brow0) * 64 + lane] = make_float2(pD, pA);
+                            if (aux.ckpt_tc) aux.ckpt_tc[(slot * 4 + brow0) * 64 + lane] = make_float4(Tin, p0, p1, p2);
+                            if (aux.ckpt_da) aux.ckpt_da[(slot * 4 + brow0) * 64 + lane] = make_float2(pD, pA);
                         }
                     } else {
                         if ((s0 & 63u) == 0u && kbase + s0 != 0u) {                // my segment starts a bucket: its absolute start state
-                            aux.ckpt_tc[slot * 64 + lane] = make_float4(Tin, p0, p1, p2);
-                            aux.ckpt_da[slot * 64 + lane] = make_float2(pD, pA);
+                            if (aux.ckpt_tc) aux.ckpt_tc[slot * 64 + lane] = make_float4(Tin, p0, p1, p2);
+                            if (aux.ckpt_da) aux.ckpt_da[slot * 64 + lane] = make_float2(pD, pA);
                         }
                     }
-                    if (lane == 0 && (s0 & 63u) == 0u)
+                    if (lane == 0 && (s0 & 63u) == 0u && aux.ckpt_tc)
                         aux.desc[slot] = make_uint2(bid | (((per >> 4) - 1u) << 30), ((kbase + s0) << 7) | min(64u, m - s0));
                 }
             }
@@ -630,7 +631,7 @@ __global__ __launch_bounds__(kSegThreads, 4) void render_fwd_seg_kernel(int W, i
     sAcc[wave][0][lane] = C0; sAcc[wave][1][lane] = C1; sAcc[wave][2][lane] = C2; sAcc[wave][3][lane] = D; sAcc[wave][4][lane] = A;
     sLast[wave][lane] = last;
     __syncthreads();
-    if (wave == 0 && inside) {
+    if (wave == 0 && inside && !(AUX && !aux.ckpt_tc)) {
         float r0 = 0.f, r1 = 0.f, r2 = 0.f, rD = 0.f, rA = 0.f;
         uint32_t lmax = 0;
 #pragma unroll
@@ -1080,6 +1081,7 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64) void render_bwd_bucket_kernel(int
 }  // namespace
 
 int sgr_validate_problem(const SgrProblem *pb);
+int sgr_render_forward_kind(const SgrProblem *pb);
 
 // 0 = automatic (segment-parallel for <= 2048 tiles, else one wave per quadrant), 1 = serial per-tile kernel (round 1), 2 = segment-parallel
 // kernel, 3 = one wave per (tile, quadrant) (dev/test override: sgr_set_forward_mode)
@@ -1110,6 +1112,13 @@ static FwdAux make_aux(void *compact, void *ckpt_tc, void *ckpt_da, void *desc, 
 }
 
 // does this launch want the one-workgroup prepare step (tile order + descriptor clear), and how many descriptors are there?
+// the compositing kernel a forward of this problem uses on the calling thread: 1 = serial per tile, 2 = segment-parallel, 3 = one wave per quadrant
+int sgr_render_forward_kind(const SgrProblem *pb) {
+    const uint64_t tiles_total = (uint64_t)((pb->W + SGR_TILE - 1) / SGR_TILE) * ((pb->H + SGR_TILE - 1) / SGR_TILE) * pb->n_views;
+    if (sgr_fwd_mode == 2 || (sgr_fwd_mode == 0 && tiles_total <= 2048)) return 2;
+    return sgr_fwd_mode == 1 ? 1 : 3;
+}
+
 int sgr_render_forward_wants_prepare(const SgrProblem *pb, uint64_t R, bool use_aux, size_t *n_desc_out) {
     const uint64_t tiles_total = (uint64_t)((pb->W + SGR_TILE - 1) / SGR_TILE) * ((pb->H + SGR_TILE - 1) / SGR_TILE) * pb->n_views;
     const size_t n_desc = use_aux ? (size_t)4 * sgr_bucket_slots(R, tiles_total) : 0;
@@ -1121,19 +1130,24 @@ int sgr_render_forward_wants_prepare(const SgrProblem *pb, uint64_t R, bool use_
 int sgr_render_forward_ex(const SgrProblem *pb, const uint32_t *ranges, const uint32_t *point_list, const float *rec,
                           float *out_color, float *out_depth, float *out_alpha, float *final_T, uint32_t *n_contrib,
                           uint64_t R, void *aux_compact, void *aux_ckpt_tc, void *aux_ckpt_da, void *aux_desc,
-                          uint32_t *aux_order, bool prepared, int aux_layout /* 1 compact, 2 rows */, void *stream_) {
+                          uint32_t *aux_order, bool prepared, int aux_layout /* 1 compact, 2 rows */, int kind /* 0: choose (sgr_render_forward_kind);
+                          else the compositing kernel to use: the depth/alpha checkpoint pass must repeat its forward's */, void *stream_) {
     if (sgr_validate_problem(pb)) return 1;
+    if (kind == 0) kind = sgr_render_forward_kind(pb);
     const int Tx = (pb->W + SGR_TILE - 1) / SGR_TILE, Ty = (pb->H + SGR_TILE - 1) / SGR_TILE;
     const uint32_t tiles = (uint32_t)Tx * Ty;
     hipStream_t stream = (hipStream_t)stream_;
-    const bool use_aux = aux_compact && aux_ckpt_tc && aux_ckpt_da && aux_desc;
+    // aux_ckpt_da == NULL: no depth/alpha checkpoints; aux_ckpt_tc == NULL (and aux_ckpt_da given): the pass that adds them later
+    const bool use_aux = aux_compact && (aux_ckpt_tc || aux_ckpt_da) && aux_desc;
+    const bool da_pass = use_aux && !aux_ckpt_tc;
     FwdAux aux = make_aux(aux_compact, aux_ckpt_tc, aux_ckpt_da, aux_desc, R, (uint64_t)tiles * pb->n_views);
     const uint64_t tiles_total = (uint64_t)tiles * pb->n_views;
     if (use_aux && tiles_total >= (1ull << 30)) { sgr_set_error("too many tiles (%llu) for the bucket descriptors", (unsigned long long)tiles_total); return 1; }
     // few workgroups (one or two 512^2 views): trade 1.5x arithmetic for an 8x shorter dependency chain
-    const bool seg = sgr_fwd_mode == 2 || (sgr_fwd_mode == 0 && tiles_total <= 2048);
+    const bool seg = kind == 2;
     const size_t n_desc = use_aux ? (size_t)4 * aux.NS : 0;
     const bool prep = seg && (aux_order || (use_aux && n_desc <= (1u << 17)));     // one workgroup orders the tiles and clears the descriptors
+    if (da_pass && !prepared) { sgr_set_error("sgr_render_forward: the depth/alpha checkpoint pass must run on a prepared forward"); return 1; }
     if (use_aux && !(prep && n_desc <= (1u << 17)) && !prepared) SGR_CHECK_HIP(hipMemsetAsync(aux_desc, 0, n_desc * sizeof(uint2), stream));
     SgrProfScope _p(SGR_K_RENDER_FWD, stream);
     if (prep && !prepared) {                                    // (prepared: the tile-sort launch's spare workgroup already did it)
@@ -1154,7 +1168,7 @@ int sgr_render_forward_ex(const SgrProblem *pb, const uint32_t *ranges, const ui
         SGR_CHECK_LAUNCH("render_fwd_seg_kernel");
         return 0;
     }
-    if (sgr_fwd_mode != 1) {
+    if (kind != 1) {
         const uint32_t wgrid = (uint32_t)((tiles_total + 7) / 8) * 32u;          // 8 tiles x 4 quadrants per group of 32 ids
 #define SGR_LAUNCH_WAVE(A)                                                                                                  \
         hipLaunchKernelGGL(render_fwd_wave_kernel<A>, dim3(wgrid), dim3(64), 0, stream, pb->W, pb->H, Tx, tiles, (uint32_t)tiles_total,   \
@@ -1185,7 +1199,7 @@ extern "C" int sgr_render_forward(const SgrProblem *pb, const uint32_t *ranges, 
                                   uint32_t *aux_order, void *stream_) {
     const uint64_t tiles_total = (uint64_t)((pb->W + SGR_TILE - 1) / SGR_TILE) * ((pb->H + SGR_TILE - 1) / SGR_TILE) * pb->n_views;
     return sgr_render_forward_ex(pb, ranges, point_list, rec, out_color, out_depth, out_alpha, final_T, n_contrib, R, aux_compact,
-                                 aux_ckpt_tc, aux_ckpt_da, aux_desc, aux_order, false, sgr_aux_layout_for(sgr_bucket_slots(R, tiles_total)), stream_);
+                                 aux_ckpt_tc, aux_ckpt_da, aux_desc, aux_order, false, sgr_aux_layout_for(sgr_bucket_slots(R, tiles_total)), 0, stream_);
 }
 
 int sgr_render_backward_ex(const SgrProblem *pb, const uint32_t *ranges, const uint32_t *point_list, const float *rec, const uint32_t *rect,
@@ -1198,7 +1212,8 @@ int sgr_render_backward_ex(const SgrProblem *pb, const uint32_t *ranges, const u
     hipStream_t stream = (hipStream_t)stream_;
     const int Tx = (pb->W + SGR_TILE - 1) / SGR_TILE, Ty = (pb->H + SGR_TILE - 1) / SGR_TILE;
     const uint32_t tiles = (uint32_t)Tx * Ty;
-    const bool use_aux = aux_compact && aux_ckpt_tc && aux_ckpt_da && aux_desc && out_color && out_depth && out_alpha && part && flags && rect;
+    const bool use_aux = aux_compact && aux_ckpt_tc && aux_desc && out_color && out_depth && out_alpha && part && flags && rect;
+    if (use_aux && (grad_depth || grad_alpha) && !aux_ckpt_da) { sgr_set_error("sgr_render_backward: dL/ddepth or dL/dalpha given but the forward left no depth/alpha checkpoints"); return 1; }
     if (use_aux) {
         if (R > 0 && !flags_cleared) SGR_CHECK_HIP(hipMemsetAsync(flags, 0, (size_t)R * 4, stream));   // (else: cleared by the forward chain)
     } else {

@@ -209,7 +209,7 @@ struct RasterizeGaussiansNode : public torch::autograd::Function<RasterizeGaussi
         Tensor radii = at::empty({P}, f32.dtype(at::kInt));
         const SgrProblem pb = make_problem(P, H, W, sh_degree, M, tfx, tfy, smod, means3D, opac, colors, sh, cov, scales, rot, vm, pm, campos, bg);
         hipStream_t stream = c10::hip::getCurrentHIPStream((c10::DeviceIndex)didx).stream();
-        const int with_aux = wants_grad ? 1 : 0;
+        const int with_aux = wants_grad ? 3 : 0;          // 3: the (depth, alpha) checkpoints are produced by the backward if it is ever handed such gradients
         const auto cap_key = std::make_tuple(didx, P, H, W);
         poll_pending(false);                                                 // earlier forwards whose count nobody has looked at yet
         SgrForwardState st;

@@ -61,6 +61,11 @@ class BatchedRasterizationSettings(NamedTuple):
     #     host is still queueing the rest of the forward: it is checked once everything is queued, and an overflow silently re-runs
     #     the forward in exact mode (and raises the remembered capacity) -- no blocking read, no user-visible failure mode.
     max_rendered: int = 0
+    # Will the backward be handed dL/ddepth or dL/dalpha?  True: the forward stores their checkpoints (a third of its checkpoint stream).
+    # None / False (default): it does not -- no call path of the reference differentiates depth or alpha (gs.py:99,107-109 drops depth,
+    # SURVEY 8a A6b) -- and a backward that does get such gradients transparently produces the checkpoints with a second compositing
+    # pass first: same results either way, this is a performance hint only.
+    depth_alpha_grads: Optional[bool] = None
 
 
 # SIGMAN_BWD_V1=1 selects the pixel-parallel backward (no auxiliary forward outputs) for A/B comparisons
@@ -318,7 +323,7 @@ def _forward_impl(means3D, opacities, colors_precomp, shs, cov3D_precomp, scales
     nr_host, nr_event, nr_ptr, nr_handle = slot.np, slot.ev, slot.ptr, slot.handle
     state = _cabi.SgrForwardState()
     blobs = [None, None, None, None]
-    use_aux = 1 if (need_ctx and with_aux and not _USE_BWD_V1) else 0
+    use_aux = (1 if getattr(st, "depth_alpha_grads", None) else 3) if (need_ctx and with_aux and not _USE_BWD_V1) else 0    # 3: (depth, alpha) checkpoints on demand
     clear_ptr, clear_bytes = (None, 0) if clear is None else (clear.data_ptr(), clear.numel() * clear.element_size())
     args = (C.byref(pb), capacity, use_aux)
     outs = (color.data_ptr(), depth.data_ptr(), alpha.data_ptr(), radii.data_ptr(), nr_ptr, nr_handle if capacity > 0 else None,

@@ -391,6 +391,37 @@ def test_second_backward_on_the_same_forward(node, oracle):
         assert err <= GRAD_TOL, f"{node}: second backward, grad {k} rel-to-max err {err:.3e}"
 
 
+@pytest.mark.parametrize("fwd_kind", [1, 2, 3], ids=["serial", "segment_parallel", "wave_per_quadrant"])
+def test_depth_alpha_checkpoints_on_demand(fwd_kind):
+    """By default the forward leaves the per-pixel (depth, alpha) checkpoints out (a third of its checkpoint stream; no call path of the
+    reference differentiates depth or alpha) and a backward that IS handed dL/ddepth / dL/dalpha produces them with a second compositing
+    pass of the same kernel.  `depth_alpha_grads=True` stores them in the forward.  Both must give bit-identical gradients, with every
+    compositing kernel, also when the backward runs on the autograd thread (whose forward-mode switch is not the caller's)."""
+    from sigman_release_amd import _cabi
+    from sigman_release_amd import rasterizer as R
+    dev = _dev()
+    H = W = 192
+    inp, st = cases.humanoid(P=9000, H=H, W=W, seed=5, views=(30, 65))
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    gs = [cases.grads_for(H, W, seed=20 + i) for i in range(2)]
+    res = []
+    _cabi.lib().sgr_set_forward_mode(fwd_kind)
+    try:
+        for eager in (None, True):
+            d = {k: t(v)[None].requires_grad_(True) for k, v in inp.items()}
+            bst = _batched_settings(st, dev, 2)._replace(depth_alpha_grads=eager)
+            color, radii, depth, alpha = R.rasterize_gaussians_batched(d["means3D"], None, None, d["colors_precomp"], d["opacities"][..., None], None, None,
+                                                                       d["cov3D_precomp"], bst)
+            sum((color[i] * t(g[0])).sum() + (depth[i] * t(g[1])).sum() + (alpha[i] * t(g[2])).sum() for i, g in enumerate(gs)).backward()
+            torch.cuda.synchronize()
+            res.append([d[k].grad.clone() for k in ("means3D", "colors_precomp", "opacities", "cov3D_precomp")])
+    finally:
+        _cabi.lib().sgr_set_forward_mode(0)
+    for a, b in zip(*res):
+        assert torch.isfinite(a).all() and float(a.abs().max()) > 0
+        assert torch.equal(a, b)
+
+
 def test_no_buffer_leak_across_steps():
     """Forward buffers must be released by reference counting (no ctx <-> output cycle): device memory stays flat over steps."""
     import gc

@@ -13,4 +13,4 @@ find $O -name "*kernel_trace.csv" -delete; find $O -name "*agent_info.csv" -dele
 du -sh $O
 cd $GRAFT_REPO_ROOT
 $B > $O/bench_plain.json 2>/dev/null
-python tools/pmc_summary.py $c $O/pmc_fetch $O/pmc_write $O/kernel_stats.csv $O/bench_plain.json $O/r02_pmc_$c.json | tee $O/table.md
+python tools/pmc_summary.py $c $O/pmc_fetch $O/pmc_write $O/kernel_stats.csv $O/bench_plain.json $O/pmc_$c.json | tee $O/table.md

@@ -1,5 +1,5 @@
 """Dev tool: turn two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) + a --kernel-trace --stats pass of `bench.py --config <c>` into
-profiles/r02_pmc_<c>.json (what bench.py reads `roofline.traffic` from) and print a per-kernel table (markdown) with the algorithmic
+profiles/r0N_pmc_<c>.json (what bench.py reads `roofline.traffic` from) and print a per-kernel table (markdown) with the algorithmic
 bytes of SURVEY.md 8(d) next to the counters.
 usage: python tools/pmc_summary.py <config> <dir_fetch> <dir_write> <kernel_stats.csv> <bench.json> <out.json>
 Correction (MI355X_MICROARCH.md, HBM section): on gfx950 FETCH_SIZE counts 64 B per 128-B request for wide coalesced reads, so read bytes
@@ -9,7 +9,7 @@ import csv, glob, json, re, statistics, subprocess, sys
 
 GROUPS = [  # (bench kernel id name, regex over rocprof kernel names)
     ("preprocess_fwd", r"preprocess_fwd_kernel"), ("scan_block_sums", r"scan_block_sums_kernel"), ("duplicate_keys", r"duplicate_keys_kernel"),
-    ("radix_sort(all passes)", r"(wide_|radix_|vseg_|tile_sort)"), ("tile_ranges", r"tile_ranges_kernel"),
+    ("radix_sort(all passes)", r"(wide_|radix_|vseg_|tile_sort|deep_tile)"), ("tile_ranges", r"tile_ranges_kernel"),
     ("render_fwd", r"(render_fwd|fwd_prepare)"), ("render_bwd", r"render_bwd"), ("preprocess_bwd", r"preprocess_bwd(_lanes)?_kernel"),
     ("clamped_l1", r"clamped_l1_kernel"),
 ]
