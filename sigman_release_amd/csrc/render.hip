@@ -262,7 +262,7 @@ __global__ __launch_bounds__(64) void render_fwd_wave_kernel(int W, int H, int T
     if (lane < n) { rid = point_list[range.x + lane]; ra = rec[(size_t)rid * 4 + 0]; rb = rec[(size_t)rid * 4 + 1]; rc = rec[(size_t)rid * 4 + 2]; }
     if (lane + kWaveBatch < n) id_nx = point_list[range.x + lane + kWaveBatch];
     for (int base = 0; base < n; base += kWaveBatch) {
-        if (!__ballot(!done)) break;
+        if (!__builtin_amdgcn_ballot_w64(!done)) break;
         // ---- stage the current batch (conic pre-scaled into the exp2 domain: exp(power) = exp2(kxx dx^2 + kyy dy^2 + kxy dx dy)) and
         // cull it for this quadrant
         // -- only the survivors go to LDS, compacted: survivor g of the batch sits at index g (no index list to read back)
@@ -290,8 +290,22 @@ __global__ __launch_bounds__(64) void render_fwd_wave_kernel(int W, int H, int T
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         uint32_t lastg = 0xFFFFFFFFu;                                   // survivor of this batch that contributed last to my pixel
-        uint64_t active = __ballot(!done);
-        for (uint32_t g = 0; g < cnt && active; g += SGR_FWD_G) {
+        uint64_t active = __builtin_amdgcn_ballot_w64(!done);
+        // AUX: bit g = a checkpoint is due in front of survivor g of this batch -- its ordinal kbase + g is a multiple of 16 (rows) / 64
+        // (compact) and not 0.  One scalar mask per batch instead of three scalar compares per survivor (the walk is a serial chain per
+        // wave: every instruction in it is latency; the checkpoint bookkeeping was 8 of its 22 scalar instructions per survivor).
+        uint64_t ck = 0;
+        if constexpr (AUX == 2) ck = 0x0001000100010001ull << ((0u - kbase) & 15u);
+        else if constexpr (AUX == 1) ck = 1ull << ((0u - kbase) & 63u);
+        if constexpr (AUX != 0) {
+            if (kbase == 0u) ck &= ~1ull;
+            if (cnt < 64u) ck &= (1ull << cnt) - 1ull;
+        }
+        // "every pixel is done" is looked at every fourth group only: turning the compiler's lane mask of `done` into a loop condition costs two
+        // vector and five scalar instructions; the (at most three) groups composited after the last pixel stopped change nothing (w = 0)
+        for (uint32_t g = 0; g < cnt && active;) {
+          const uint32_t g_end = min(cnt, g + 4u * SGR_FWD_G);
+          for (; g < g_end; g += SGR_FWD_G) {
             float4 a[SGR_FWD_G], b[SGR_FWD_G], c[SGR_FWD_G];
             float al[SGR_FWD_G];
             bool valid[SGR_FWD_G];
@@ -306,11 +320,12 @@ __global__ __launch_bounds__(64) void render_fwd_wave_kernel(int W, int H, int T
                 al[u] = valid[u] ? alpha : 0.f;
             }
             // sequential part, branch-free: the only loop-carried chain is T -> test_T -> (stop) -> T
+            const uint32_t due = AUX ? (uint32_t)(ck >> g) & ((1u << SGR_FWD_G) - 1u) : 0u;
 #pragma unroll
             for (int u = 0; u < SGR_FWD_G; u++) {
                 const uint32_t ord = kbase + g + u;                       // ordinal of this survivor in the quadrant list
                 if constexpr (AUX == 2) {
-                    if ((ord & 15u) == 0u && ord != 0u && g + u < cnt) {
+                    if (__builtin_expect((due >> u) & 1u, 0u)) {
                         const uint32_t row = (ord >> 4) & 3u;
                         const size_t s = ((slot0 + (ord >> 6)) * 4 + row) * 64 + lane;
                         if (row == 0u) { B0 = C0; B1 = C1; B2 = C2; BD = D; BA = A; }       // bucket start: absolute state
@@ -318,26 +333,30 @@ __global__ __launch_bounds__(64) void render_fwd_wave_kernel(int W, int H, int T
                         if (aux.ckpt_da) aux.ckpt_da[s] = row ? make_float2(D - BD, A - BA) : make_float2(D, A);
                     }
                 } else if constexpr (AUX == 1) {
-                    if ((ord & 63u) == 0u && ord != 0u && g + u < cnt) {                    // bucket start: absolute state
+                    if (__builtin_expect((due >> u) & 1u, 0u)) {                                                  // bucket start: absolute state
                         const size_t s = (slot0 + (ord >> 6)) * 64 + lane;
                         if (aux.ckpt_tc) aux.ckpt_tc[s] = make_float4(T, C0, C1, C2);
                         if (aux.ckpt_da) aux.ckpt_da[s] = make_float2(D, A);
                     }
                 }
+                // al = 0 for a Gaussian that is not valid here: its test_T is T itself (>= 1e-4 while the pixel is not done), its weight 0 and
+                // its new T the old one -- only `done` has to gate the updates, `valid` only the index of the last contributor
                 const float test_T = T * (1.f - al[u]);
-                done = done | (valid[u] & (test_T < 0.0001f));            // the crossing Gaussian is NOT composited
-                const bool contrib = valid[u] & !done;
-                const float w = contrib ? al[u] * T : 0.f;
+                done = done | (test_T < 0.0001f);                         // the crossing Gaussian is NOT composited
+                const float w = done ? 0.f : al[u] * T;
                 C0 = fmaf(b[u].w, w, C0); C1 = fmaf(c[u].x, w, C1); C2 = fmaf(c[u].y, w, C2);
                 D = fmaf(b[u].z, w, D);
                 A += w;
-                T = contrib ? test_T : T;
-                lastg = contrib ? g + u : lastg;
-                if (AUX) lastk = contrib ? ord + 1 : lastk;
+                T = done ? T : test_T;
+                lastg = (valid[u] & !done) ? g + u : lastg;
             }
-            active = __ballot(!done);
+          }
+          active = __builtin_amdgcn_ballot_w64(!done);
         }
-        if (lastg != 0xFFFFFFFFu) last = (uint32_t)base + sJ[lastg] + 1u;
+        if (lastg != 0xFFFFFFFFu) {
+            last = (uint32_t)base + sJ[lastg] + 1u;
+            if (AUX) lastk = kbase + lastg + 1u;                          // ordinal + 1 of the last survivor that blended into my pixel
+        }
         kbase += cnt;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");              // the next batch overwrites the staging arrays
         __builtin_amdgcn_wave_barrier();

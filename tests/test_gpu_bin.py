@@ -39,6 +39,16 @@ def _build(n_views, P, size, seed, depth_kind, big_rects):
         depth = rng.uniform(0.2, 50.0, (n_views, P)).astype(np.float32).view(np.uint32)
     elif depth_kind == "ties":
         depth = rng.choice(np.array([0.25, 1.0, 1.0000001, 2.5, 7.0], np.float32), (n_views, P)).view(np.uint32)
+    elif depth_kind == "band_outlier":
+        # nearly everything inside a band of a few thousand ulps, 0.2 % outliers a hundred times farther away: the depth range of a tile is
+        # stretched 1e5-fold beyond where its entries are (the distribution sort's bins adapt to the density, or the tile is declined)
+        depth = rng.uniform(2.5, 2.5005, (n_views, P)).astype(np.float32)
+        far = rng.random((n_views, P)) < 0.002
+        depth = np.where(far, rng.uniform(50.0, 300.0, (n_views, P)).astype(np.float32), depth).view(np.uint32)
+    elif depth_kind == "two_planes":
+        # two thin surfaces (front / back of a body part), each a few hundred distinct depth values wide: thousands of small tie groups
+        depth = np.where(rng.random((n_views, P)) < 0.5, 2.3, 2.7).astype(np.float32) + (rng.integers(0, 300, (n_views, P)) * np.float32(2.4e-7)).astype(np.float32)
+        depth = depth.astype(np.float32).view(np.uint32)
     else:
         pool = np.array([1, 2, 0x7FFFF, 0xFFFFF, 0x00100000, 0x00800000, 0x3F800000, 0x3F800001, 0x7F7FFFFF, 0x7F7FFFFE, 0x7EFFFFFF], np.uint32)
         depth = np.where(rng.random((n_views, P)) < 0.5, rng.choice(pool, (n_views, P)),
@@ -82,6 +92,10 @@ def _build(n_views, P, size, seed, depth_kind, big_rects):
     (1, 230000, 256, "extreme", "hot1"),
     (1, 230000, 256, "normal", "hot1"),        # ... and with spread-out depths: nine windows of one tile, nine workgroups
     (3, 90000, 512, "normal", True),           # three views with long tiles, depths without ties: both deep instantiations next to the register classes
+    (1, 230000, 256, "band_outlier", "hot1"),  # a 140 000-entry tile whose depth range is 1e5 times wider than the band its entries sit in
+    (2, 60000, 512, "band_outlier", True),
+    (1, 230000, 256, "two_planes", "hot1"),    # ... and one made of two thin surfaces with small tie groups everywhere
+    (3, 90000, 512, "two_planes", True),
 ])
 def test_sgr_bin_direct_all_flavours(n_views, P, size, depth_kind, big_rects):
     from sigman_release_amd import _cabi
