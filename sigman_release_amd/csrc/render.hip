@@ -73,6 +73,18 @@ struct FwdAux {
 // -------------------------------------------------------------------------------------------------
 // F6.  AUX=true additionally records what the bucket-parallel backward needs: the per-quadrant culled
 // lists, a per-pixel state checkpoint every 64 surviving Gaussians, and one descriptor per bucket.
+
+// Sums of products are written with their fused multiply-adds spelled out.  `a*b + c*d` may be contracted with either product inside
+// the fma, the compiler picks by operand arrival, and the pick differed between kernels (round 3: the wave forward fused the kyy term
+// of the exponent, the segment-parallel forward and the backward the kxy term; the backward's colour dot changed its order when its LDS
+// reads moved).  Written out, every forward kernel and the backward agree TO THE BIT on a Gaussian's exponent -- hence on which Gaussians
+// pass the alpha test at a pixel -- and a kernel's results do not depend on its instantiation or on the compiler's schedule.
+__device__ __forceinline__ float sgr_power2(float kxx, float kyy, float kxy, float dx, float dy) {   // (exp2 domain: conic pre-scaled)
+    return fmaf(dx, kxx * dx, fmaf(kxy * dx, dy, (kyy * dy) * dy));
+}
+__device__ __forceinline__ float sgr_dot3(float a0, float b0, float a1, float b1, float a2, float b2) {
+    return fmaf(a2, b2, fmaf(a1, b1, a0 * b0));
+}
 // -------------------------------------------------------------------------------------------------
 template <int AUX>
 __global__ __launch_bounds__(kBlock) void render_fwd_kernel(int W, int H, int Tx, uint32_t tiles_per_view,
@@ -155,7 +167,7 @@ __global__ __launch_bounds__(kBlock) void render_fwd_kernel(int W, int H, int Tx
 #pragma unroll
             for (int u = 0; u < SGR_FWD_G; u++) {
                 const float dx = a[u].x - pxf, dy = a[u].y - pyf;
-                const float power = (a[u].z * dx) * dx + ((b[u].x * dy) * dy + (a[u].w * dx) * dy);
+                const float power = sgr_power2(a[u].z, b[u].x, a[u].w, dx, dy);
                 const float alpha = fminf(0.99f, b[u].y * __builtin_amdgcn_exp2f(power));
                 valid[u] = (power <= 0.f) & (alpha >= (1.0f / 255.0f));
                 al[u] = valid[u] ? alpha : 0.f;
@@ -314,7 +326,7 @@ __global__ __launch_bounds__(64) void render_fwd_wave_kernel(int W, int H, int T
 #pragma unroll
             for (int u = 0; u < SGR_FWD_G; u++) {
                 const float dx = a[u].x - pxf, dy = a[u].y - pyf;
-                const float power = (a[u].z * dx) * dx + ((b[u].x * dy) * dy + (a[u].w * dx) * dy);
+                const float power = sgr_power2(a[u].z, b[u].x, a[u].w, dx, dy);
                 const float alpha = fminf(0.99f, b[u].y * __builtin_amdgcn_exp2f(power));
                 valid[u] = (power <= 0.f) & (alpha >= (1.0f / 255.0f));
                 al[u] = valid[u] ? alpha : 0.f;
@@ -529,7 +541,7 @@ __global__ __launch_bounds__(kSegThreads, 4) void render_fwd_seg_kernel(int W, i
                 const float4 qa = pA[pb + u], qb = pB[pb + u], qc = pC[pb + u];
                 const v2f gx = {qa.x, qa.y}, gy = {qa.z, qa.w}, kxx = {qb.x, qb.y}, kxy = {qb.z, qb.w}, kyy = {qc.x, qc.y}, op = {qc.z, qc.w};
                 const v2f dx = gx - px2, dy = gy - py2;
-                const v2f power = (kxx * dx) * dx + ((kyy * dy) * dy + (kxy * dx) * dy);
+                const v2f power = __builtin_elementwise_fma(dx, kxx * dx, __builtin_elementwise_fma(kxy * dx, dy, (kyy * dy) * dy));   // == sgr_power2 per element
                 const v2f G = {__builtin_amdgcn_exp2f(power.x), __builtin_amdgcn_exp2f(power.y)};
                 const v2f og = op * G;
                 const float a0 = fminf(0.99f, og.x), a1 = fminf(0.99f, og.y);
@@ -573,7 +585,7 @@ __global__ __launch_bounds__(kSegThreads, 4) void render_fwd_seg_kernel(int W, i
                 const uint2 qi = pI[pb + u];
                 const v2f gx = {qa.x, qa.y}, gy = {qa.z, qa.w}, kxx = {qb.x, qb.y}, kxy = {qb.z, qb.w}, kyy = {qc.x, qc.y}, op = {qc.z, qc.w};
                 const v2f dx = gx - px2, dy = gy - py2;
-                const v2f power = (kxx * dx) * dx + ((kyy * dy) * dy + (kxy * dx) * dy);
+                const v2f power = __builtin_elementwise_fma(dx, kxx * dx, __builtin_elementwise_fma(kxy * dx, dy, (kyy * dy) * dy));   // == sgr_power2 per element
                 const v2f G = {__builtin_amdgcn_exp2f(power.x), __builtin_amdgcn_exp2f(power.y)};
                 const v2f og = op * G;
                 const float a0 = fminf(0.99f, og.x), a1 = fminf(0.99f, og.y);
@@ -940,11 +952,11 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64) void render_bwd_bucket_kernel(int
             const float gs = gscale ? *gscale : 1.f;          // optional device scalar on dL/dcolor
             g0 = gs * gC[vb * 3 + pix]; g1 = gs * gC[vb * 3 + hw + pix]; g2 = gs * gC[vb * 3 + 2 * hw + pix];
             // O = out . g: everything the pixel composited (incl. the T_final*bg term), dotted with the upstream gradient
-            O = out_color[vb * 3 + pix] * g0 + out_color[vb * 3 + hw + pix] * g1 + out_color[vb * 3 + 2 * hw + pix] * g2;
+            O = sgr_dot3(out_color[vb * 3 + pix], g0, out_color[vb * 3 + hw + pix], g1, out_color[vb * 3 + 2 * hw + pix], g2);
             if (HAS_DA) {
                 if (gD) gd = gD[vb + pix];
                 if (gA) ga = gA[vb + pix];
-                O += out_depth[vb + pix] * gd + out_alpha[vb + pix] * ga;
+                O += fmaf(out_alpha[vb + pix], ga, out_depth[vb + pix] * gd);
             }
         }
         sPixA[wv][16 + pos] = make_float4((float)px, (float)py, __uint_as_float(last), g0);
@@ -953,8 +965,8 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64) void render_bwd_bucket_kernel(int
         if (start) {
             const float4 tc = aux.ckpt_tc[ROWS ? slot * 256 + p : slot * 64 + p];
             T0 = tc.x;
-            Pre0 = tc.y * g0 + tc.z * g1 + tc.w * g2;
-            if (HAS_DA) { const float2 da = aux.ckpt_da[ROWS ? slot * 256 + p : slot * 64 + p]; Pre0 += da.x * gd + da.y * ga; }
+            Pre0 = sgr_dot3(tc.y, g0, tc.z, g1, tc.w, g2);
+            if (HAS_DA) { const float2 da = aux.ckpt_da[ROWS ? slot * 256 + p : slot * 64 + p]; Pre0 += fmaf(da.y, ga, da.x * gd); }
         }
         sDyn[wv][0][pos] = make_float2(T0, O - Pre0);
         if constexpr (ROWS) {
@@ -965,8 +977,8 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64) void render_bwd_bucket_kernel(int
                 if ((uint32_t)(16 * r) < count) {
                     const float4 tc = aux.ckpt_tc[(slot * 4 + r) * 64 + p];
                     Tr = tc.x;
-                    float dotv = tc.y * g0 + tc.z * g1 + tc.w * g2;
-                    if (HAS_DA) { const float2 da = aux.ckpt_da[(slot * 4 + r) * 64 + p]; dotv += da.x * gd + da.y * ga; }
+                    float dotv = sgr_dot3(tc.y, g0, tc.z, g1, tc.w, g2);
+                    if (HAS_DA) { const float2 da = aux.ckpt_da[(slot * 4 + r) * 64 + p]; dotv += fmaf(da.y, ga, da.x * gd); }
                     if (((uint32_t)r & (rps - 1u)) == 0u) PreSeg = dotv;      // rps is 1, 2 or 4
                     Prer = (((uint32_t)r & (rps - 1u)) == 0u) ? dotv : PreSeg + dotv;
                 }
@@ -988,14 +1000,14 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64) void render_bwd_bucket_kernel(int
                 const float jop = SGR_BCAST(op), jcr = SGR_BCAST(cr), jcg = SGR_BCAST(cg), jcb = SGR_BCAST(cb);
                 const uint32_t jidx = (uint32_t)__builtin_amdgcn_readlane((int)gidx, (int)j);
                 const float dx = jx - wpx, dy = jy - wpy;
-                const float p2 = (jkxx * dx) * dx + ((jkyy * dy) * dy + (jkxy * dx) * dy);
+                const float p2 = sgr_power2(jkxx, jkyy, jkxy, dx, dy);
                 const float G = __builtin_amdgcn_exp2f(p2);
                 const float alpha = fminf(0.99f, jop * G);
                 if (jidx < wlast && p2 <= 0.f && alpha >= (1.0f / 255.0f)) {
                     const float w = alpha * wT;
-                    float qj = jcr * wg0 + jcg * wg1 + jcb * wg2;
-                    if (HAS_DA) qj += SGR_BCAST(gdep) * wgd + wga;
-                    wRem -= w * qj;
+                    float qj = sgr_dot3(jcr, wg0, jcg, wg1, jcb, wg2);
+                    if (HAS_DA) qj += fmaf(SGR_BCAST(gdep), wgd, wga);
+                    wRem = fmaf(-w, qj, wRem);
                     wT *= 1.f - alpha;
                 }
 #undef SGR_BCAST
@@ -1017,27 +1029,33 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64) void render_bwd_bucket_kernel(int
     float S1 = 0.f, Sx = 0.f, Sy = 0.f, Sxx = 0.f, Sxy = 0.f, Syy = 0.f, aD = 0.f, a7 = 0.f, a8 = 0.f, a9 = 0.f;
     const int nsteps = n_alive ? n_alive + (int)min(count, 16u) - 1 : 0;
     const int rl = lane & 15;
+    // The three LDS reads of a step are issued one step AHEAD (two register sets) and pinned there by a compiler barrier: left to itself
+    // the compiler sinks them into the regions that use them -- feed -> wait -> shift, position -> wait -> Gaussian, gradient -> wait ->
+    // sums: three exposed LDS round trips per step on a kernel whose waves spend most of their time waiting.  (Volatile loads are no
+    // alternative: each is followed by a wait for its completion.)
     const float4 *pa = &sPixA[wv][16 - rl], *pb = &sPixB[wv][16 - rl];          // [S] = stream entry S - rl
     const float2 *pd = &sDyn[wv][row][0];
-#define SGR_BWD_STEP(IN, OUT, S)                                                                                        \
+#define SGR_BWD_LOAD(S, FA, FB, FD) { FA = pa[(S)]; FB = pb[(S)]; FD = pd[min((S), n_alive - 1)]; asm volatile("" ::: "memory"); }
+#define SGR_BWD_STEP(IN, OUT, S, fa, fb, fd, NFA, NFB, NFD)                                                             \
     {                                                                                                                   \
-        const float4 fa = pa[(S)];                                                                                      \
-        const float4 fb = pb[(S)];                                                                                      \
-        const float2 fd = pd[min((S), n_alive - 1)];                                                                    \
         const bool has = (uint32_t)((S) - rl) < (uint32_t)n_alive;      /* a stream entry sits in this lane */           \
+        /* the shift is the first use of this step's reads (one wait, nothing else in flight: the compiler's wait counts do not   \
+           survive the loop's back edge, a wait with the next reads already issued would be a wait for them too); THEN the next   \
+           step's reads go out and travel while this step computes */                                                             \
         OUT.T = row_shift_in(IN.T, fd.x); OUT.Rem = row_shift_in(IN.Rem, fd.y);                                         \
+        SGR_BWD_LOAD((S) + 1, NFA, NFB, NFD)                                                                            \
         const float dx = gx - fa.x, dy = gy - fa.y;                                                                     \
-        const float p2 = (kxx * dx) * dx + ((kyy * dy) * dy + (kxy * dx) * dy);                                         \
+        const float p2 = sgr_power2(kxx, kyy, kxy, dx, dy);                                                             \
         const float G = __builtin_amdgcn_exp2f(p2);                                                                     \
         const float alpha = fminf(0.99f, op * G);                                                                       \
         const bool valid = has && gidx < __float_as_uint(fa.z) && p2 <= 0.f && alpha >= (1.0f / 255.0f);                \
         if (valid) {                                                                                                    \
             const float w = alpha * OUT.T;                                                                              \
-            float qj = cr * fa.w + cg * fb.x + cb * fb.y;                                                               \
-            if (HAS_DA) qj += gdep * fb.z + fb.w;                                                                       \
+            float qj = sgr_dot3(cr, fa.w, cg, fb.x, cb, fb.y);                                                          \
+            if (HAS_DA) qj += fmaf(gdep, fb.z, fb.w);                                                                   \
             const float oma = 1.f - alpha;                                                                              \
-            OUT.Rem -= w * qj;                                                                                          \
-            const float dL_dalpha = OUT.T * qj - OUT.Rem * __builtin_amdgcn_rcpf(oma);                                  \
+            OUT.Rem = fmaf(-w, qj, OUT.Rem);                                                                            \
+            const float dL_dalpha = fmaf(OUT.T, qj, -(OUT.Rem * __builtin_amdgcn_rcpf(oma)));                           \
             OUT.T *= oma;                                                                                               \
             const float v = G * dL_dalpha; /* upstream differentiates through op*G even when alpha is capped */         \
             const float vx = v * dx, vy = v * dy;                                                                       \
@@ -1048,12 +1066,16 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64) void render_bwd_bucket_kernel(int
         }                                                                                                               \
     }
     int s = 0;
+    float4 fa0, fb0, fa1, fb1;
+    float2 fd0, fd1;
+    SGR_BWD_LOAD(0, fa0, fb0, fd0)               // (entries beyond the stream are addressable and unused: has == false)
     for (; s + 1 < nsteps; s += 2) {
-        SGR_BWD_STEP(A, B, s)
-        SGR_BWD_STEP(B, A, s + 1)
+        SGR_BWD_STEP(A, B, s, fa0, fb0, fd0, fa1, fb1, fd1)
+        SGR_BWD_STEP(B, A, s + 1, fa1, fb1, fd1, fa0, fb0, fd0)
     }
-    if (s < nsteps) SGR_BWD_STEP(A, B, s)
+    if (s < nsteps) SGR_BWD_STEP(A, B, s, fa0, fb0, fd0, fa1, fb1, fd1)
 #undef SGR_BWD_STEP
+#undef SGR_BWD_LOAD
     if (SPLIT) {
         // the odd wave hands its sums to the even wave of the same bucket
         __shared__ float sComb[1][10][64];
@@ -1083,8 +1105,8 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64) void render_bwd_bucket_kernel(int
         // one NON-atomic 40-byte partial record per (tile instance, quadrant); preprocess_bwd gathers them in a fixed order
         const uint32_t off = rd.w, rmin = rd.x, rmax = rd.y;
         const uint32_t inst = off + (ty - (rmin >> 16)) * ((rmax & 0xFFFFu) - (rmin & 0xFFFFu)) + (tx - (rmin & 0xFFFFu));
-        const float a0 = -0.5f * (float)W * op * (cxx * Sx + cxy * Sy);       // dL/dNDC x (includes 0.5*W like upstream)
-        const float a1 = -0.5f * (float)H * op * (cyy * Sy + cxy * Sx);
+        const float a0 = -0.5f * (float)W * op * fmaf(cxy, Sy, cxx * Sx);       // dL/dNDC x (includes 0.5*W like upstream)
+        const float a1 = -0.5f * (float)H * op * fmaf(cxy, Sx, cyy * Sy);
         // 40 B, 8-byte aligned: 16 + 16 + 8-byte stores (three write requests per record instead of five)
         struct __attribute__((packed, aligned(8))) Rec40 { float2 v[5]; };
         Rec40 rr;
