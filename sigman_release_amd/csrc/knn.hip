@@ -54,24 +54,46 @@ __device__ __forceinline__ KnnSet knn_set(const KnnBatch &kb, int set) {
 __device__ __forceinline__ int f2ord(float f) { int i = __float_as_int(f); return i >= 0 ? i : i ^ 0x7FFFFFFF; }
 __device__ __forceinline__ float ord2f(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7FFFFFFF); }
 
-// per set: bbox words (min = +max ordered, max = -max ordered) and zeroed cell counters / fill cursors, in ONE launch for all sets
-// (no pageable host->device copies: nothing here blocks the host or dangles under stream capture)
-__global__ __launch_bounds__(kT) void knn_init_kernel(KnnBatch kb) {
+constexpr int kBoxBlocks = 64;       // workgroups of the prepare kernel that also reduce the bounding box (one partial each)
+
+// One launch for everything the grid build needs before it can count: the cell counters / fill cursors are
+// cleared, and the first kBoxBlocks workgroups leave one bounding-box partial each (6 floats at the head of the not-yet-used `sorted`
+// array).  No atomics, no ticket: nothing here needs initialised memory (the workspace is whatever the caller's allocator returned).
+__global__ __launch_bounds__(kT) void knn_prep_kernel(KnnBatch kb, int box_blocks) {
     const KnnSet ks = knn_set(kb, blockIdx.y);
-    if (blockIdx.x == 0 && threadIdx.x < 8) ks.bb[threadIdx.x] = threadIdx.x < 3 ? 0x7F7FFFFF : (threadIdx.x < 6 ? (int)0x80800000 : 0);
     const size_t n = (size_t)2 * kb.max_cells + 1;            // cell_start [max_cells + 1] and cell_fill [max_cells] are adjacent
     for (size_t i = (size_t)blockIdx.x * kT + threadIdx.x; i < n; i += (size_t)gridDim.x * kT) ks.cell_start[i] = 0u;
+    if ((int)blockIdx.x >= box_blocks) return;
+    const int P = kb.P; const float *pts = ks.pts;
+    __shared__ float red[4][6];
+    float mn[3] = {3.0e38f, 3.0e38f, 3.0e38f}, mx[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+    for (int i = blockIdx.x * kT + threadIdx.x; i < P; i += box_blocks * kT)
+#pragma unroll
+        for (int k = 0; k < 3; k++) { const float v = pts[3 * (size_t)i + k]; mn[k] = fminf(mn[k], v); mx[k] = fmaxf(mx[k], v); }
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { mn[k] = fminf(mn[k], __shfl_xor(mn[k], off, 64)); mx[k] = fmaxf(mx[k], __shfl_xor(mx[k], off, 64)); }
+    }
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) { red[wave][k] = mn[k]; red[wave][3 + k] = mx[k]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const int k = threadIdx.x;
+        const float a = red[0][k], b = red[1][k], c = red[2][k], d = red[3][k];
+        reinterpret_cast<float *>(ks.sorted)[blockIdx.x * 6 + k] = k < 3 ? fminf(fminf(a, b), fminf(c, d)) : fmaxf(fmaxf(a, b), fmaxf(c, d));
+    }
 }
 
-// derive the grid from the bbox on device (no host round trip): cell = cbrt(volume * 2 / P), clamped so the
+// derive the grid from the bounding box on device (no host round trip): cell = cbrt(volume * 2 / P), clamped so the
 // grid has at most max_cells cells; degenerate extents are padded.
-// (one thread: the last workgroup of bbox_kernel to finish, so no launch of its own)
-__device__ void grid_setup(const KnnBatch &kb, const KnnSet &ks) {
-    const int P = kb.P, max_cells = kb.max_cells; int *bb = ks.bb; Grid *g = ks.grid;
-    float mn[3], ex[3];
-    int bv[6];
-    for (int k = 0; k < 6; k++) bv[k] = __hip_atomic_load(&bb[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // the other workgroups' atomics
-    for (int k = 0; k < 3; k++) { mn[k] = ord2f(bv[k]); ex[k] = fmaxf(ord2f(bv[3 + k]) - mn[k], 1e-6f); }
+__device__ void grid_setup(const KnnBatch &kb, const float (&mn)[3], const float (&mxv)[3], Grid *g) {
+    const int P = kb.P, max_cells = kb.max_cells;
+    float ex[3];
+    for (int k = 0; k < 3; k++) ex[k] = fmaxf(mxv[k] - mn[k], 1e-6f);
     // ~1 point per cell if the cloud fills its bounding volume, ~5 per occupied cell if it is a surface (the reference's
     // inputs are points on the SMPL-X surface): take the finer of the two estimates.  (The search is bound by its per-lane candidate
     // loads -- one lane per cycle and CU through the texture addresser -- so the cells are as fine as the stop test allows: with
@@ -93,46 +115,33 @@ __device__ void grid_setup(const KnnBatch &kb, const KnnSet &ks) {
     g->gz = max(1, (int)ceilf(ex[2] / cell + 1e-3f));
 }
 
-__global__ __launch_bounds__(kT) void bbox_kernel(KnnBatch kb) {
+__global__ __launch_bounds__(kT) void cell_count_kernel(KnnBatch kb, int box_blocks) {
     const KnnSet ks = knn_set(kb, blockIdx.y);
-    const int P = kb.P; const float *pts = ks.pts; int *bb = ks.bb;
-    __shared__ float red[4][6];
-    float mn[3] = {3.0e38f, 3.0e38f, 3.0e38f}, mx[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
-    for (int i = blockIdx.x * kT + threadIdx.x; i < P; i += gridDim.x * kT)
+    const int P = kb.P; const float *pts = ks.pts; uint32_t *cell_cnt = ks.cell_start, *pt_cell = ks.pt_cell;
+    // every workgroup reduces the (<= 64) bounding-box partials and derives the grid for itself (the same few hundred bytes out of L2,
+    // the same arithmetic: the same grid in every workgroup); workgroup 0 also stores it for the kernels that follow.  Replaces the
+    // bounding-box kernel's atomics + last-workgroup ticket and the launch that initialised them.
+    __shared__ Grid s_grid;
+    if (threadIdx.x < 64) {
+        const float *part = reinterpret_cast<const float *>(ks.sorted);
+        const int b = min((int)threadIdx.x, box_blocks - 1);                 // (lanes beyond the partials repeat the last one)
+        float mn[3], mx[3];
 #pragma unroll
-        for (int k = 0; k < 3; k++) { const float v = pts[3 * (size_t)i + k]; mn[k] = fminf(mn[k], v); mx[k] = fmaxf(mx[k], v); }
+        for (int k = 0; k < 3; k++) { mn[k] = part[b * 6 + k]; mx[k] = part[b * 6 + 3 + k]; }
 #pragma unroll
-    for (int k = 0; k < 3; k++) {
+        for (int k = 0; k < 3; k++) {
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) { mn[k] = fminf(mn[k], __shfl_xor(mn[k], off, 64)); mx[k] = fmaxf(mx[k], __shfl_xor(mx[k], off, 64)); }
-    }
-    const int wave = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) {
-#pragma unroll
-        for (int k = 0; k < 3; k++) { red[wave][k] = mn[k]; red[wave][3 + k] = mx[k]; }
+            for (int off = 32; off > 0; off >>= 1) { mn[k] = fminf(mn[k], __shfl_xor(mn[k], off, 64)); mx[k] = fmaxf(mx[k], __shfl_xor(mx[k], off, 64)); }
+        }
+        if (threadIdx.x == 0) {
+            grid_setup(kb, mn, mx, &s_grid);
+            if (blockIdx.x == 0) *ks.grid = s_grid;
+        }
     }
     __syncthreads();
-    if (threadIdx.x < 6) {                                   // one atomic per block and component (the grid is at most 64 blocks)
-        const int k = threadIdx.x;
-        const float a = red[0][k], b = red[1][k], c = red[2][k], d = red[3][k];
-        if (k < 3) atomicMin(&bb[k], f2ord(fminf(fminf(a, b), fminf(c, d))));
-        else atomicMax(&bb[k], f2ord(fmaxf(fmaxf(a, b), fmaxf(c, d))));
-        __threadfence();                                       // performed before this workgroup's ticket below
-    }
-    // the last workgroup to arrive derives the grid (bb[6]: ticket, zeroed by knn_init_kernel)
-    __shared__ int s_last;
-    __syncthreads();
-    if (threadIdx.x == 0) s_last = atomicAdd(&bb[6], 1) == (int)gridDim.x - 1;
-    __syncthreads();
-    if (s_last && threadIdx.x == 0) { __threadfence(); grid_setup(kb, ks); }
-}
-
-__global__ __launch_bounds__(kT) void cell_count_kernel(KnnBatch kb) {
-    const KnnSet ks = knn_set(kb, blockIdx.y);
-    const int P = kb.P; const float *pts = ks.pts; const Grid *gp = ks.grid; uint32_t *cell_cnt = ks.cell_start, *pt_cell = ks.pt_cell;
     const int i = blockIdx.x * kT + threadIdx.x;
     if (i >= P) return;
-    const Grid g = *gp;
+    const Grid g = s_grid;
     int cx, cy, cz;
     const int c = cell_of(g, pts[3 * (size_t)i], pts[3 * (size_t)i + 1], pts[3 * (size_t)i + 2], cx, cy, cz);
     pt_cell[i] = (uint32_t)c;
@@ -369,9 +378,9 @@ extern "C" int sgr_knn_dist2_batched(int32_t n_sets, int32_t P, const float *poi
     const int scan_blocks = (max_cells + 1 + kScanTile - 1) / kScanTile;
     const size_t init_want = ((size_t)2 * max_cells + 1 + kT * 4 - 1) / (kT * 4);
     const int init_blocks = (int)(init_want < 1024 ? init_want : 1024);
-    hipLaunchKernelGGL(knn_init_kernel, dim3(init_blocks, n_sets), dim3(kT), 0, stream, kb);
-    hipLaunchKernelGGL(bbox_kernel, dim3(min(nb, 64), n_sets), dim3(kT), 0, stream, kb);
-    hipLaunchKernelGGL(cell_count_kernel, dim3(nb, n_sets), dim3(kT), 0, stream, kb);
+    const int box_blocks = min(nb, kBoxBlocks);                       // (6 floats each at the head of `sorted`: P float4 >= 6 * box_blocks floats)
+    hipLaunchKernelGGL(knn_prep_kernel, dim3(max(init_blocks, box_blocks), n_sets), dim3(kT), 0, stream, kb, box_blocks);
+    hipLaunchKernelGGL(cell_count_kernel, dim3(nb, n_sets), dim3(kT), 0, stream, kb, box_blocks);
     hipLaunchKernelGGL(cell_blocksum_kernel, dim3(scan_blocks, n_sets), dim3(kT), 0, stream, kb);
     hipLaunchKernelGGL(cell_scan_kernel, dim3(scan_blocks, n_sets), dim3(kT), 0, stream, kb);
     hipLaunchKernelGGL(cell_scatter_kernel, dim3(nb, n_sets), dim3(kT), 0, stream, kb);
