@@ -722,7 +722,9 @@ __device__ __forceinline__ void seg_sort_passes(uint32_t n, uint32_t *ka, uint32
         // 4 waves) and touch only the counters a round used: the first version had three 16-deep LDS loops per round (clear,
         // prefix, digit-base update) -- worth 1 us of the 24 us the 2 900-entry tiles of C2 take
         constexpr bool TWO_LEVEL = NW > 4;
-        __shared__ uint32_t gsum[TWO_LEVEL ? 4 : 1][kRadix];
+        constexpr int NG = TWO_LEVEL ? NW / 4 : 1;                  // groups of 4 waves (8- and 16-wave workgroups)
+        static_assert(!TWO_LEVEL || NW % 4 == 0, "two-level prefix: whole groups of 4 waves");
+        __shared__ uint32_t gsum[NG][kRadix];
         const uint32_t pg = t >> 8, pd = t & (kRadix - 1);           // TWO_LEVEL: my (group of 4 waves, digit) in the prefix step
         if (TWO_LEVEL) {
 #pragma unroll
@@ -777,7 +779,12 @@ __device__ __forceinline__ void seg_sort_passes(uint32_t n, uint32_t *ka, uint32
             if (TWO_LEVEL) {
 #pragma unroll
                 for (int k = 0; k < 4; k++) wave_cnt[4 * pg + k][pd] = 0;
-                if (pg == 0) digit_base[pd] += (gsum[0][pd] + gsum[1][pd]) + (gsum[2][pd] + gsum[3][pd]);
+                if (pg == 0) {
+                    uint32_t add = 0;
+#pragma unroll
+                    for (int g = 0; g < NG; g++) add += gsum[g][pd];
+                    digit_base[pd] += add;
+                }
             } else if (t < kRadix) {
                 uint32_t add = 0;
 #pragma unroll
@@ -1589,7 +1596,7 @@ __global__ __launch_bounds__(NT) void deep_tile_kernel(uint64_t *comp, uint32_t 
                                                        const uint32_t *__restrict__ count_ptr, const uint32_t *__restrict__ deep_list,
                                                        const uint2 *__restrict__ ranges, int keep_keys, VsegPlan *__restrict__ plan,
                                                        uint32_t *__restrict__ lists, uint32_t list_stride, SortPrep prep) {
-    constexpr uint32_t RI = 16, REG = NT * RI;            // the first REG composites of a tile live in registers (RI per thread) for all passes
+    constexpr uint32_t RI = (CAP + NT - 1) / NT <= 4 ? 4 : ((CAP + NT - 1) / NT <= 8 ? 8 : 16), REG = NT * RI;   // the first REG composites of a tile live in registers (RI per thread) for all passes
     constexpr uint32_t ITEMS = 8, ROUND = NT * ITEMS;     // the rest (tiles beyond REG entries) is re-read from the segment in every pass
     constexpr uint32_t NW = NT / 64, NBC = 256, WIN = CAP - kDeepBinMax, PER = NBF / NT;
     static_assert(NBF % NT == 0 && NT >= (int)NBC && NT % 64 == 0 && (NBF & (NBF - 1)) == 0, "layout");
@@ -1964,7 +1971,7 @@ int sgr_bin_ex(const SgrProblem *pb, const int32_t *radii, uint32_t *rect,
             const uint32_t gsmall = std::max(1u, (uint32_t)std::min<uint64_t>(std::min<uint64_t>(tiles_total, R / 64 + 1), 768u));
             hipLaunchKernelGGL((deep_tile_kernel<1024, kDeepBigCap, 4096>), dim3(gbig), dim3(1024), 0, stream, kout, vout, kin, vin, &plan->count[6],
                                lists + (size_t)6 * VL.list_stride, (const uint2 *)ranges, sorted_keys ? 1 : 0, plan, lists, VL.list_stride, none);
-            hipLaunchKernelGGL((deep_tile_kernel<256, kDeepSmallCap, 1024>), dim3(gsmall), dim3(256), 0, stream, kout, vout, kin, vin, &plan->count[7],
+            hipLaunchKernelGGL((deep_tile_kernel<512, kDeepSmallCap, 1024>), dim3(gsmall), dim3(512), 0, stream, kout, vout, kin, vin, &plan->count[7],
                                lists + (size_t)7 * VL.list_stride, (const uint2 *)ranges, sorted_keys ? 1 : 0, plan, lists, VL.list_stride, none);
             SGR_CHECK_LAUNCH("deep_tile_kernel");
         }
@@ -2012,9 +2019,11 @@ int sgr_bin_ex(const SgrProblem *pb, const int32_t *radii, uint32_t *rect,
         sp.desc = (uint2 *)prep_desc; sp.n_desc = prep_n_desc; sp.order = prep_order; sp.tiles_total = (uint32_t)tiles_total;
         sp.enabled = (prep_order || prep_desc) ? 1 : 0;
         const uint32_t g = (uint32_t)(tiles_total < 256 ? tiles_total : 256);
-        if (wide_deep)      // (up to 3 resident workgroups per CU stride over the window list)
-            hipLaunchKernelGGL((deep_tile_kernel<256, kDeepSmallCap, 1024, true>), dim3((uint32_t)std::min<uint64_t>(tiles_total + R / (kDeepSmallCap - kDeepBinMax) + 1, 768u) + (sp.enabled ? 1u : 0u)),
-                               dim3(256), 0, stream, kout, vout, kin, vin, wl, wl + 16, (const uint2 *)ranges, sorted_keys ? 1 : 0, (VsegPlan *)nullptr, (uint32_t *)nullptr, 0u, sp);
+        if (wide_deep)      // (resident workgroups stride over the window list.  1024 threads per tile: a single view has fewer tiles than the chip has
+                            // CUs, so a tile's workgroup has its CU to itself and the phases are latency chains -- 256 threads: 15.5 us at C2, 512: 11.5,
+                            // 1024: 10.5; the batch instantiation for lists of <= 4096 entries runs 512 threads: C5 38 -> 33 us, 1024 is slower there)
+            hipLaunchKernelGGL((deep_tile_kernel<1024, kDeepSmallCap, 1024, true>), dim3((uint32_t)std::min<uint64_t>(tiles_total + R / (kDeepSmallCap - kDeepBinMax) + 1, 768u) + (sp.enabled ? 1u : 0u)),
+                               dim3(1024), 0, stream, kout, vout, kin, vin, wl, wl + 16, (const uint2 *)ranges, sorted_keys ? 1 : 0, (VsegPlan *)nullptr, (uint32_t *)nullptr, 0u, sp);
         else
         hipLaunchKernelGGL(tile_sort_regs_kernel<16>, dim3(g + (sp.enabled ? 1u : 0u)), dim3(1024), 0, stream, (const uint2 *)ranges, kout, vout, kin, vin,
                            tw4, 4, 0, sp, sorted_keys ? 1 : 0);
