@@ -30,6 +30,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <array>
+#include <chrono>
 #include <atomic>
 #include <map>
 #include <memory>
@@ -98,6 +99,19 @@ char *alloc_cb(void *user, int32_t which, size_t bytes) {
     return (char *)a->blob[which].data_ptr();
 }
 
+// Waits for the pinned count word: polls for up to 2 s of wall time (the store comes from a kernel early in a chain that is already queued,
+// possibly behind a step's worth of earlier work), so that the callers' fallback -- a device synchronise, which drains everything queued
+// and costs the host its run-ahead -- only ever runs when something is wrong.  (A fixed 200 000 polls were over in ~60 us: with the GPU a
+// step behind, every wait ended in that synchronise: C2 0.154 ms per step instead of 0.138.)
+inline void spin_for_count(volatile uint64_t *w) {
+    if (*w != ~0ull) return;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        for (int k = 0; k < 2048; k++) { if (*w != ~0ull) return; __builtin_ia32_pause(); }
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) return;
+    }
+}
+
 inline Tensor f32c(const Tensor &t) { return (t.scalar_type() == at::kFloat && t.is_contiguous()) ? t : t.to(at::kFloat).contiguous(); }
 inline const float *fptr(const Tensor &t) { return (t.defined() && t.numel() > 0) ? t.data_ptr<float>() : nullptr; }
 
@@ -119,7 +133,7 @@ bool resolve(Pending &p, bool block) {
         if (!block) return false;
         if (p.by_copy) SGR_TORCH_CHECK_HIP(hipEventSynchronize(p.slot.ev));
         else {                                                     // stored by the emission kernel itself, no event recorded: poll, then drain
-            for (int spins = 0; *w == ~0ull && spins < 200000; spins++) {}
+            spin_for_count(w);
             if (*w == ~0ull) SGR_TORCH_CHECK_HIP(hipDeviceSynchronize());
         }
     }
@@ -276,7 +290,7 @@ struct RasterizeGaussiansNode : public torch::autograd::Function<RasterizeGaussi
                 // learning phase: everything is queued; the emission kernel stores the count into the pinned word right after it has summed the
                 // block counts (large launches: an async copy behind the scan kernel -- then only the event says "complete")
                 volatile uint64_t *w = slot.host;
-                if (!st.nr_by_copy) for (int spins = 0; *w == ~0ull && spins < 200000; spins++) {}
+                if (!st.nr_by_copy) spin_for_count(w);
                 if (st.nr_by_copy) SGR_TORCH_CHECK_HIP(hipEventSynchronize(slot.ev));
                 else if (*w == ~0ull) SGR_TORCH_CHECK_HIP(hipDeviceSynchronize());
                 const uint64_t word = *w;
@@ -367,6 +381,188 @@ struct RasterizeGaussiansNode : public torch::autograd::Function<RasterizeGaussi
     }
 };
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Batched rasterizer + fused clamp/L1 image loss (rasterizer.py: _RasterizeL1Batched, what a training step of the batched path and
+// bench.py's step call) as a C++ node, for the reference's input flavour (colors_precomp + cov3D_precomp, no mask) in the explicit
+// sync-free mode (max_rendered > 0).  Why: at one view the Python node needs 110-135 us of host time per step (depending on the boost
+// state of the CPU core) against 137 us of kernels -- the host was co-limiting the step (tools/long_run.py, tools/trace_vs_time.sh:
+// constant kernel durations, step period 137.6 -> 153 us in discrete levels).  Same semantics as the Python node: the count is looked
+// at by the forward's own backward after its kernels are queued (or by a later forward / check_pending() if no backward ever runs),
+// and a forward that did not fit its capacity raises -- the caller chose the capacity.
+struct BPending { CountSlot slot; uint64_t capacity = 0; bool by_copy = false, checked = false, overflow = false, reported = false; uint64_t count = 0; int64_t id = 0; };
+std::map<int64_t, std::shared_ptr<BPending>> g_b_by_id;
+std::map<std::tuple<int, int64_t, int64_t, int64_t, int64_t, uint64_t, int>, std::array<uint64_t, 3>> g_b_blob_sizes;
+std::vector<std::shared_ptr<BPending>> &b_pending() { thread_local std::vector<std::shared_ptr<BPending>> v; return v; }
+
+bool b_resolve(BPending &p, bool block) {
+    std::lock_guard<std::mutex> pl(g_pend_mu);
+    if (p.checked) return true;
+    volatile uint64_t *w = p.slot.host;
+    bool there = p.by_copy ? hipEventQuery(p.slot.ev) == hipSuccess : *w != ~0ull;
+    if (!there) {
+        if (!block) return false;
+        if (p.by_copy) SGR_TORCH_CHECK_HIP(hipEventSynchronize(p.slot.ev));
+        else {
+            spin_for_count(w);
+            if (*w == ~0ull) SGR_TORCH_CHECK_HIP(hipDeviceSynchronize());
+        }
+    }
+    const uint64_t word = *w;
+    p.count = word & ~(1ull << 63); p.overflow = (word >> 63) != 0; p.checked = true;
+    release_slot(p.slot);
+    g_b_by_id.erase(p.id);
+    return true;
+}
+[[noreturn]] void b_raise(BPending &p, bool earlier) {
+    p.reported = true;
+    TORCH_CHECK(false, "num_rendered ", p.count, " exceeds max_rendered ", p.capacity, ": results of ",
+                earlier ? "an EARLIER forward of this thread (reported now: nobody had looked at its count yet) are" : "this forward are",
+                " truncated; raise BatchedRasterizationSettings.max_rendered (or use 0 = exact mode)");
+}
+void b_poll(bool block) {            // forwards of this thread whose backward never ran
+    auto &v = b_pending();
+    std::shared_ptr<BPending> bad;
+    size_t keep = 0;
+    for (size_t i = 0; i < v.size(); i++) {
+        BPending &p = *v[i];
+        const bool done = p.checked || b_resolve(p, block || v.size() - i > 128);
+        if (done && p.overflow && !p.reported && !bad) bad = v[i];
+        if (!done) v[keep++] = v[i];
+    }
+    v.resize(keep);
+    if (bad) b_raise(*bad, true);
+}
+
+struct RasterizeL1BatchedNode : public torch::autograd::Function<RasterizeL1BatchedNode> {
+    static variable_list forward(AutogradContext *ctx, Tensor means3D_, Tensor colors_, Tensor opac_, Tensor cov_, Tensor vm_, Tensor pm_, Tensor campos_,
+                                 Tensor bg_, Tensor target_, int64_t H, int64_t W, double tfx, double tfy, double smod, int64_t vps, int64_t capacity_,
+                                 double weight, bool da_grads) {
+        TORCH_CHECK(means3D_.dim() == 3 && means3D_.size(2) == 3, "means3D must have dimensions (subjects, num_points, 3)");
+        TORCH_CHECK(means3D_.is_cuda(), "sigman_release_amd rasterizer needs tensors on a ROCm device (there is no CPU fallback)");
+        TORCH_CHECK(capacity_ > 0, "the C++ batched node handles the explicit sync-free mode (max_rendered > 0) only");
+        const c10::Device dev = means3D_.device();
+        c10::DeviceGuard guard(dev);
+        const int didx = dev.index();
+        const int64_t S = means3D_.size(0), P = means3D_.size(1);
+        const Tensor means3D = f32c(means3D_), opac = f32c(opac_).reshape({S, P}), colors = f32c(colors_), cov = f32c(cov_);
+        const Tensor vm = f32c(vm_), pm = f32c(pm_), campos = f32c(campos_), bg = f32c(bg_), target = f32c(target_);
+        const int64_t nv = vm.size(0);
+        TORCH_CHECK(nv == S * vps, "viewmatrix has ", nv, " views but inputs describe ", S, " subjects x ", vps, " views");
+        const bool wants_grad = means3D_.requires_grad() || opac_.requires_grad() || colors_.requires_grad() || cov_.requires_grad();
+        const auto f32 = at::TensorOptions().dtype(at::kFloat).device(dev);
+        Tensor color = at::empty({nv, 3, H, W}, f32), depth = at::empty({nv, 1, H, W}, f32), alpha = at::empty({nv, 1, H, W}, f32);
+        Tensor radii = at::empty({nv, P}, f32.dtype(at::kInt));
+        Tensor sums = at::empty({nv + 1}, f32), gimg = at::empty({nv, 3, H, W}, f32);      // [per-view partial sums | total]: cleared by the rasterizer's own kernels
+        SgrProblem pb = make_problem(P, H, W, 0, 0, tfx, tfy, smod, means3D, opac, colors, Tensor(), cov, Tensor(), Tensor(), vm, pm, campos, bg);
+        pb.n_views = (int32_t)nv; pb.views_per_subject = (int32_t)vps;
+        hipStream_t stream = c10::hip::getCurrentHIPStream((c10::DeviceIndex)didx).stream();
+        const int with_aux = wants_grad ? (da_grads ? 1 : 3) : 0;
+        const uint64_t capacity = (uint64_t)capacity_;
+        b_poll(false);
+        SgrL1Epilogue ep;
+        ep.target = target.data_ptr<float>(); ep.mask = nullptr; ep.grad_color = gimg.data_ptr<float>(); ep.loss_per_view = sums.data_ptr<float>();
+        ep.loss_total = sums.data_ptr<float>() + nv; ep.weight = (float)weight; ep.sums_already_zero = 1;
+        SgrForwardState st;
+        memset(&st, 0, sizeof(st));
+        AllocCtx ac;
+        ac.dev = dev;
+        CountSlot slot = acquire_slot(didx);
+        slot.host[0] = ~0ull; slot.host[1] = 0;
+        const auto size_key = std::make_tuple(didx, P, nv, H, W, capacity, with_aux);
+        std::array<uint64_t, 3> sizes{0, 0, 0};
+        bool have = false;
+        { std::lock_guard<std::mutex> l(g_mu); auto it = g_b_blob_sizes.find(size_key); if (it != g_b_blob_sizes.end()) { sizes = it->second; have = true; } }
+        int status = 2;
+        if (have) {
+            for (int k = 0; k < 3; k++) ac.blob[k] = at::empty({(int64_t)sizes[k]}, f32.dtype(at::kByte));
+            st.geom = ac.blob[0].data_ptr(); st.binning = ac.blob[1].data_ptr(); st.image = ac.blob[2].data_ptr();
+            st.geom_bytes = sizes[0]; st.binning_bytes = sizes[1]; st.image_bytes = sizes[2];
+            status = sgr_rasterize_forward_l1(&pb, capacity, with_aux, nullptr, nullptr, color.data_ptr<float>(), depth.data_ptr<float>(), alpha.data_ptr<float>(),
+                                              radii.data_ptr<int32_t>(), slot.host, slot.ev, sums.data_ptr(), (uint64_t)(nv + 1) * 4, &st, &ep, stream);
+        }
+        if (status == 2) {
+            memset(&st, 0, sizeof(st));
+            status = sgr_rasterize_forward_l1(&pb, capacity, with_aux, alloc_cb, &ac, color.data_ptr<float>(), depth.data_ptr<float>(), alpha.data_ptr<float>(),
+                                              radii.data_ptr<int32_t>(), slot.host, slot.ev, sums.data_ptr(), (uint64_t)(nv + 1) * 4, &st, &ep, stream);
+            if (status == 0) {
+                std::lock_guard<std::mutex> l(g_mu);
+                g_b_blob_sizes[size_key] = {st.geom_bytes < 256 ? 256 : st.geom_bytes, st.binning_bytes < 256 ? 256 : st.binning_bytes,
+                                            st.image_bytes < 256 ? 256 : st.image_bytes};
+            }
+        }
+        if (status != 0) release_slot(slot);
+        check_status(status, "sgr_rasterize_forward_l1");
+        auto mine = std::make_shared<BPending>();
+        mine->slot = slot; mine->capacity = capacity; mine->by_copy = st.nr_by_copy != 0;
+        { std::lock_guard<std::mutex> pl(g_pend_mu); mine->id = g_next_id++; g_b_by_id[mine->id] = mine; }
+        if (wants_grad) b_pending().push_back(mine);              // found again by the backward, or by a later forward if no backward ever runs
+        else {                                                     // nobody will come back for it: look now (everything is queued, the count is published early)
+            b_resolve(*mine, true);
+            if (mine->overflow) b_raise(*mine, false);
+        }
+        ctx->set_materialize_grads(false);
+        Tensor per_view = sums.narrow(0, 0, nv), loss = sums.select(0, nv);
+        ctx->mark_non_differentiable({radii, per_view});
+        Tensor st_bytes = at::empty({(int64_t)sizeof(SgrForwardState)}, at::TensorOptions().dtype(at::kByte));
+        memcpy(st_bytes.data_ptr(), &st, sizeof(st));
+        ctx->save_for_backward({means3D, opac, colors, cov, color, depth, alpha, radii, ac.blob[0], ac.blob[1], ac.blob[2], vm, pm, campos, bg, gimg});
+        ctx->saved_data["st"] = st_bytes;
+        ctx->saved_data["pending"] = mine->id;
+        ctx->saved_data["dims"] = std::vector<int64_t>{S, P, nv, H, W, vps, opac_.dim()};
+        ctx->saved_data["scal"] = std::vector<double>{tfx, tfy, smod};
+        return {loss, per_view, color, radii, depth, alpha};
+    }
+
+    static variable_list backward(AutogradContext *ctx, variable_list grads) {
+        const auto saved = ctx->get_saved_variables();
+        const Tensor &means3D = saved[0], &opac = saved[1], &colors = saved[2], &cov = saved[3], &color = saved[4], &depth = saved[5], &alpha = saved[6],
+                     &radii = saved[7], &vm = saved[11], &pm = saved[12], &campos = saved[13], &bg = saved[14], &gimg = saved[15];
+        const auto dims = ctx->saved_data["dims"].toIntVector();
+        const auto scal = ctx->saved_data["scal"].toDoubleVector();
+        const int64_t S = dims[0], P = dims[1], nv = dims[2], H = dims[3], W = dims[4], vps = dims[5];
+        const c10::Device dev = means3D.device();
+        c10::DeviceGuard guard(dev);
+        SgrForwardState st;
+        memcpy(&st, ctx->saved_data["st"].toTensor().data_ptr(), sizeof(st));
+        const auto f32 = at::TensorOptions().dtype(at::kFloat).device(dev);
+        const Tensor &g_loss = grads[0], &g_color = grads[2];
+        Tensor gC, scale;
+        if (!g_loss.defined() && !g_color.defined()) gC = at::zeros_like(gimg);
+        else if (!g_color.defined()) { gC = gimg; scale = g_loss.reshape({1}).to(at::kFloat); }        // the common case: only the loss is used
+        else gC = g_loss.defined() ? f32c(g_color) + gimg * g_loss : f32c(g_color);
+        Tensor gD = grads[4].defined() ? f32c(grads[4]) : Tensor(), gA = grads[5].defined() ? f32c(grads[5]) : Tensor();
+        Tensor d_means3D = at::empty({S, P, 3}, f32), d_op = at::empty({S, P}, f32), d_cov = at::empty({S, P, 6}, f32), d_col = at::empty({S, P, 3}, f32);
+        SgrProblem pb = make_problem(P, H, W, 0, 0, scal[0], scal[1], scal[2], means3D, opac, colors, Tensor(), cov, Tensor(), Tensor(), vm, pm, campos, bg);
+        pb.n_views = (int32_t)nv; pb.views_per_subject = (int32_t)vps;
+        hipStream_t stream = c10::hip::getCurrentHIPStream(dev.index()).stream();
+        AllocCtx ac;
+        ac.dev = dev;
+        auto mp = [](const Tensor &t) -> float * { return (t.defined() && t.numel() > 0) ? t.data_ptr<float>() : nullptr; };
+        check_status(sgr_rasterize_backward(&pb, &st, radii.data_ptr<int32_t>(), color.data_ptr<float>(), depth.data_ptr<float>(), alpha.data_ptr<float>(),
+                                            gC.data_ptr<float>(), mp(gD), mp(gA), mp(scale), alloc_cb, &ac, mp(d_means3D), nullptr, mp(d_op), mp(d_col), nullptr,
+                                            mp(d_cov), nullptr, nullptr, stream),
+                     "sgr_rasterize_backward");
+        std::shared_ptr<BPending> mine;
+        {
+            std::lock_guard<std::mutex> pl(g_pend_mu);
+            auto it = g_b_by_id.find(ctx->saved_data["pending"].toInt());
+            if (it != g_b_by_id.end()) mine = it->second;
+        }
+        if (mine) {                    // after the backward is queued: the host never idles the GPU while it waits for the forward's counter
+            b_resolve(*mine, true);
+            if (mine->overflow && !mine->reported) b_raise(*mine, false);
+        }
+        variable_list out = {d_means3D, d_col, dims[6] == 3 ? d_op.unsqueeze(-1) : d_op, d_cov};
+        for (int k = 0; k < 14; k++) out.push_back(Tensor());
+        return out;
+    }
+};
+
+std::vector<Tensor> rasterize_l1_batched(Tensor means3D, Tensor colors, Tensor opac, Tensor cov, Tensor vm, Tensor pm, Tensor campos, Tensor bg, Tensor target,
+                                         int64_t H, int64_t W, double tfx, double tfy, double smod, int64_t vps, int64_t capacity, double weight, bool da_grads) {
+    return RasterizeL1BatchedNode::apply(means3D, colors, opac, cov, vm, pm, campos, bg, target, H, W, tfx, tfy, smod, vps, capacity, weight, da_grads);
+}
+
 std::vector<Tensor> rasterize_gaussians(Tensor means3D, Tensor means2D, Tensor sh, Tensor colors, Tensor opac, Tensor scales, Tensor rot, Tensor cov,
                                         int64_t H, int64_t W, double tfx, double tfy, Tensor bg, double smod, Tensor vm, Tensor pm, int64_t sh_degree,
                                         Tensor campos) {
@@ -378,6 +574,8 @@ std::vector<Tensor> rasterize_gaussians(Tensor means3D, Tensor means2D, Tensor s
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.doc() = "C++ autograd node of the single-view upstream-signature rasterizer op above the C ABI of libsigman_gsplat.so";
     m.def("rasterize_gaussians", &rasterize_gaussians, "== diff_gaussian_rasterization.rasterize_gaussians for one view (automatic sync-free capacity)");
+    m.def("rasterize_l1_batched", &rasterize_l1_batched, "batched rasterizer + fused clamp/L1 loss, explicit sync-free capacity (== rasterizer.rasterize_l1_loss_batched)");
+    m.def("check_pending_batched", []() { b_poll(true); }, "look at the counts of this thread's batched forwards whose backward never ran; raises if one was truncated");
     m.def("abi_version", []() { return sgr_abi_version(); });
     m.def("check_pending", []() { ThreadState &t = tstate(); for (auto &p : t.pending) resolve(*p, true); poll_pending(true); },
           "wait for and check the deferred instance counts of this thread's earlier forwards (raises if one overflowed)");

@@ -497,3 +497,81 @@ def test_cpp_node_deferred_count_check():
     finally:
         node.set_count_check("inline")
         node.reset()
+
+
+def _batched_l1_inputs(dev, S, V, P=5000, H=128, W=144, seed=5):
+    from sigman_release_amd import rasterizer as R
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    hosts = [synthetic.humanoid(P, seed + s) for s in range(S)]
+    base = {"means3D": torch.stack([t(g["position"]) for g in hosts]), "rgb": torch.stack([t(g["rgb"]) for g in hosts]),
+            "opacity": torch.stack([t(g["opacity"].reshape(P, 1)) for g in hosts]),
+            "cov3D": torch.stack([t(synthetic.covariance_from_gaussians(g)) for g in hosts])}
+    cv, cvp, cp = cameras.make_cameras([int(v) for v in np.random.default_rng(seed).choice(90, V, replace=False)] * S)
+    mk = lambda cap, da=None: R.BatchedRasterizationSettings(H, W, cameras.TAN_HALF_FOV, cameras.TAN_HALF_FOV, torch.ones(3, device=dev), 1.0, t(cv), t(cvp), 0,
+                                                             t(cp), V, False, cap, da)
+    target = torch.rand(S * V, 3, H, W, device=dev, generator=torch.Generator(device=dev).manual_seed(seed))
+    return base, mk, target
+
+
+@pytest.mark.parametrize("S,V,mode", [(1, 1, "loss"), (1, 2, "loss+color"), (2, 4, "loss"), (1, 2, "depth+alpha")])
+def test_cpp_batched_l1_node_equals_python_node(S, V, mode):
+    """rasterize_l1_loss_batched routes the reference's input flavour in the explicit sync-free mode to the C++ node (csrc/torch_node.cpp):
+    same loss, per-view losses, images and gradients as the Python node, bit for bit."""
+    from sigman_release_amd import _cabi, rasterizer as R
+    if _cabi.torch_node() is None:
+        pytest.skip("sgr_torch_node.so not built / SIGMAN_PY_NODE=1")
+    dev = _dev()
+    base, mk, target = _batched_l1_inputs(dev, S, V)
+    st = mk(400000, True if mode == "depth+alpha" else None)
+    res = []
+    for impl in ("python", "cpp"):
+        d = {k: v.clone().requires_grad_(True) for k, v in base.items()}
+        args = (d["means3D"], None, None, d["rgb"], d["opacity"], None, None, d["cov3D"], st, target, None, 0.37)
+        out = R._RasterizeL1Batched.apply(*args) if impl == "python" else R.rasterize_l1_loss_batched(*args)
+        if impl == "cpp":
+            assert type(out[0].grad_fn).__name__ != "_RasterizeL1BatchedBackward", "the call did not reach the C++ node"
+        loss, per_view, color, radii, depth, alpha = out
+        total = loss * 1.7
+        if mode == "loss+color":
+            total = total + (color * color).sum() * 0.01
+        if mode == "depth+alpha":
+            total = total + (depth * 0.3).sum() + (alpha * alpha).sum() * 0.2
+        total.backward()
+        torch.cuda.synchronize()
+        res.append([x.detach().clone() for x in (loss, per_view, color, radii, depth, alpha)] + [d[k].grad.clone() for k in ("means3D", "rgb", "opacity", "cov3D")])
+    for i, (a, b) in enumerate(zip(*res)):
+        assert a.shape == b.shape
+        if i < 2:       # loss / per-view losses: float atomics over the pixels, equal up to the order of the additions
+            assert torch.allclose(a, b, rtol=1e-5, atol=0.0)
+        else:
+            assert torch.equal(a, b), i
+    R.check_pending_overflows(True)
+
+
+def test_cpp_batched_l1_node_overflow_and_no_grad():
+    """A forward that does not fit its explicit capacity raises from its own backward; without a backward, from check_pending_overflows();
+    under torch.no_grad() from the forward itself -- the Python node's behaviour."""
+    from sigman_release_amd import _cabi, rasterizer as R
+    if _cabi.torch_node() is None:
+        pytest.skip("sgr_torch_node.so not built / SIGMAN_PY_NODE=1")
+    dev = _dev()
+    base, mk, target = _batched_l1_inputs(dev, 1, 2)
+    call = lambda d, st: R.rasterize_l1_loss_batched(d["means3D"], None, None, d["rgb"], d["opacity"], None, None, d["cov3D"], st, target, None, 1.0)
+    small = mk(1000)
+    d = {k: v.clone().requires_grad_(True) for k, v in base.items()}
+    loss = call(d, small)[0]
+    with pytest.raises(RuntimeError, match="exceeds max_rendered 1000"):
+        loss.backward()
+    d = {k: v.clone().requires_grad_(True) for k, v in base.items()}
+    call(d, small)                                          # no backward
+    with pytest.raises(RuntimeError, match="EARLIER forward"):
+        R.check_pending_overflows(True)
+    with torch.no_grad(), pytest.raises(RuntimeError, match="exceeds max_rendered 1000"):
+        call(base, small)
+    # and a fitting capacity keeps working afterwards, many forwards deep
+    ok = mk(400000)
+    for _ in range(300):
+        d = {k: v.clone().requires_grad_(True) for k, v in base.items()}
+        call(d, ok)[0].backward()
+    R.check_pending_overflows(True)
+    assert np.isfinite(float(d["means3D"].grad.abs().sum()))
