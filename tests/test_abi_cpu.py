@@ -156,3 +156,17 @@ def test_full_size_record_matches_kernel_sources():
     assert rec.get("_csrc_sha16") == tgp.kernel_sources_sha16(), "full_size_observed.json is stale: re-record it on the GPU box"
     for cfg in ("c2", "c3", "c4", "c5"):
         assert cfg in rec, cfg
+
+
+def test_torch_node_module_loads_and_exports_both_ops():
+    """lib/sgr_torch_node.so (csrc/torch_node.cpp): importable without a GPU, built against this ABI, exports the single-view op and the
+    batched op with the fused L1 loss."""
+    import os
+    from sigman_release_amd import _cabi
+    if os.environ.get("SIGMAN_PY_NODE", "0") == "1":
+        pytest.skip("SIGMAN_PY_NODE=1")
+    node = _cabi.torch_node()
+    assert node is not None, "sgr_torch_node.so is not built (make -C sigman_release_amd/csrc)"
+    assert node.abi_version() == _cabi.lib().sgr_abi_version()
+    for name in ("rasterize_gaussians", "rasterize_l1_batched", "check_pending", "check_pending_batched", "set_count_check", "slot_stats"):
+        assert callable(getattr(node, name)), name
