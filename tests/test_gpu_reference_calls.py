@@ -575,3 +575,46 @@ def test_cpp_batched_l1_node_overflow_and_no_grad():
         call(d, ok)[0].backward()
     R.check_pending_overflows(True)
     assert np.isfinite(float(d["means3D"].grad.abs().sum()))
+
+
+def test_cpp_batched_l1_node_two_threads_two_streams():
+    """Two Python threads drive the batched node on their own streams at the same time (forward on the caller's thread, backward on the
+    autograd engine's): every step of each thread reproduces that thread's single-threaded result bit for bit."""
+    import threading
+    from sigman_release_amd import _cabi, rasterizer as R
+    if _cabi.torch_node() is None:
+        pytest.skip("sgr_torch_node.so not built / SIGMAN_PY_NODE=1")
+    dev = _dev()
+    cases_ = [_batched_l1_inputs(dev, 1, 2, P=20000, H=192, W=192, seed=3), _batched_l1_inputs(dev, 1, 1, P=50000, H=256, W=256, seed=9)]
+
+    def run(case, n, out, stream):
+        base, mk, target = case
+        st = mk(600000)
+        try:
+            with torch.cuda.stream(stream):
+                res = None
+                for _ in range(n):
+                    d = {k: v.clone().requires_grad_(True) for k, v in base.items()}
+                    o = R.rasterize_l1_loss_batched(d["means3D"], None, None, d["rgb"], d["opacity"], None, None, d["cov3D"], st, target, None, 1e-3)
+                    o[0].backward()
+                    cur = [o[2].detach().clone()] + [d[k].grad.clone() for k in ("means3D", "rgb", "opacity", "cov3D")]
+                    if res is not None:
+                        assert all(torch.equal(a, b) for a, b in zip(res, cur))
+                    res = cur
+                stream.synchronize()
+            out.append(res)
+        except BaseException as e:          # (an assertion in a thread would otherwise vanish)
+            out.append(e)
+
+    ref = [[], []]
+    for i, c in enumerate(cases_):
+        run(c, 2, ref[i], torch.cuda.current_stream())
+    outs = [[], []]
+    ths = [threading.Thread(target=run, args=(cases_[i], 60, outs[i], torch.cuda.Stream())) for i in range(2)]
+    [th.start() for th in ths]
+    [th.join() for th in ths]
+    torch.cuda.synchronize()
+    for i in range(2):
+        assert not isinstance(outs[i][0], BaseException), outs[i][0]
+        assert all(torch.equal(a, b) for a, b in zip(ref[i][0], outs[i][0]))
+    R.check_pending_overflows(True)
