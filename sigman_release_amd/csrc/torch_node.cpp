@@ -201,7 +201,7 @@ SgrProblem make_problem(int64_t P, int64_t H, int64_t W, int64_t sh_degree, int6
 struct RasterizeGaussiansNode : public torch::autograd::Function<RasterizeGaussiansNode> {
     static variable_list forward(AutogradContext *ctx, Tensor means3D_, Tensor means2D, Tensor sh_, Tensor colors_, Tensor opac_, Tensor scales_,
                                  Tensor rot_, Tensor cov_, int64_t H, int64_t W, double tfx, double tfy, Tensor bg_, double smod, Tensor vm_,
-                                 Tensor pm_, int64_t sh_degree, Tensor campos_) {
+                                 Tensor pm_, int64_t sh_degree, Tensor campos_, bool grad_mode) {
         TORCH_CHECK(means3D_.dim() == 2 && means3D_.size(1) == 3, "means3D must have dimensions (num_points, 3)");
         TORCH_CHECK(means3D_.is_cuda(), "sigman_release_amd rasterizer needs tensors on a ROCm device (there is no CPU fallback)");
         const c10::Device dev = means3D_.device();
@@ -214,10 +214,11 @@ struct RasterizeGaussiansNode : public torch::autograd::Function<RasterizeGaussi
                      rot = opt(rot_), cov = opt(cov_);
         const Tensor vm = f32c(vm_), pm = f32c(pm_), campos = f32c(campos_), bg = f32c(bg_);
         const int64_t M = sh.defined() ? sh.size(1) : 0;
-        const bool wants_grad = means3D_.requires_grad() || opac_.requires_grad() || (sh_.defined() && sh_.requires_grad()) ||
+        // (grad_mode: torch.is_grad_enabled() of the CALLER -- inside a Function's forward it is always off)
+        const bool wants_grad = grad_mode && (means3D_.requires_grad() || opac_.requires_grad() || (sh_.defined() && sh_.requires_grad()) ||
                                 (colors_.defined() && colors_.requires_grad()) || (scales_.defined() && scales_.requires_grad()) ||
                                 (rot_.defined() && rot_.requires_grad()) || (cov_.defined() && cov_.requires_grad()) ||
-                                (means2D.defined() && means2D.requires_grad());
+                                (means2D.defined() && means2D.requires_grad()));
         const auto f32 = at::TensorOptions().dtype(at::kFloat).device(dev);
         Tensor color = at::empty({3, H, W}, f32), depth = at::empty({1, H, W}, f32), alpha = at::empty({1, H, W}, f32);
         Tensor radii = at::empty({P}, f32.dtype(at::kInt));
@@ -376,7 +377,7 @@ struct RasterizeGaussiansNode : public torch::autograd::Function<RasterizeGaussi
         }
         // gradients in forward-argument order: means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, then the 10 settings
         variable_list out = {d_means3D, d_means2D, d_sh, colors.defined() ? d_col : Tensor(), d_op, d_sc, d_rot, cov.defined() ? d_cov : Tensor()};
-        for (int k = 0; k < 10; k++) out.push_back(Tensor());
+        for (int k = 0; k < 11; k++) out.push_back(Tensor());
         return out;
     }
 };
@@ -436,7 +437,7 @@ void b_poll(bool block) {            // forwards of this thread whose backward n
 struct RasterizeL1BatchedNode : public torch::autograd::Function<RasterizeL1BatchedNode> {
     static variable_list forward(AutogradContext *ctx, Tensor means3D_, Tensor colors_, Tensor opac_, Tensor cov_, Tensor vm_, Tensor pm_, Tensor campos_,
                                  Tensor bg_, Tensor target_, int64_t H, int64_t W, double tfx, double tfy, double smod, int64_t vps, int64_t capacity_,
-                                 double weight, bool da_grads) {
+                                 double weight, bool da_grads, bool grad_mode) {
         TORCH_CHECK(means3D_.dim() == 3 && means3D_.size(2) == 3, "means3D must have dimensions (subjects, num_points, 3)");
         TORCH_CHECK(means3D_.is_cuda(), "sigman_release_amd rasterizer needs tensors on a ROCm device (there is no CPU fallback)");
         TORCH_CHECK(capacity_ > 0, "the C++ batched node handles the explicit sync-free mode (max_rendered > 0) only");
@@ -448,7 +449,9 @@ struct RasterizeL1BatchedNode : public torch::autograd::Function<RasterizeL1Batc
         const Tensor vm = f32c(vm_), pm = f32c(pm_), campos = f32c(campos_), bg = f32c(bg_), target = f32c(target_);
         const int64_t nv = vm.size(0);
         TORCH_CHECK(nv == S * vps, "viewmatrix has ", nv, " views but inputs describe ", S, " subjects x ", vps, " views");
-        const bool wants_grad = means3D_.requires_grad() || opac_.requires_grad() || colors_.requires_grad() || cov_.requires_grad();
+        // (under torch.no_grad() nothing will ever come back for a gradient, whatever the leaves say: the lighter forward, the count looked at now)
+        // (grad_mode: torch.is_grad_enabled() of the CALLER -- inside a Function's forward it is always off)
+        const bool wants_grad = grad_mode && (means3D_.requires_grad() || opac_.requires_grad() || colors_.requires_grad() || cov_.requires_grad());
         const auto f32 = at::TensorOptions().dtype(at::kFloat).device(dev);
         Tensor color = at::empty({nv, 3, H, W}, f32), depth = at::empty({nv, 1, H, W}, f32), alpha = at::empty({nv, 1, H, W}, f32);
         Tensor radii = at::empty({nv, P}, f32.dtype(at::kInt));
@@ -553,20 +556,22 @@ struct RasterizeL1BatchedNode : public torch::autograd::Function<RasterizeL1Batc
             if (mine->overflow && !mine->reported) b_raise(*mine, false);
         }
         variable_list out = {d_means3D, d_col, dims[6] == 3 ? d_op.unsqueeze(-1) : d_op, d_cov};
-        for (int k = 0; k < 14; k++) out.push_back(Tensor());
+        for (int k = 0; k < 15; k++) out.push_back(Tensor());
         return out;
     }
 };
 
 std::vector<Tensor> rasterize_l1_batched(Tensor means3D, Tensor colors, Tensor opac, Tensor cov, Tensor vm, Tensor pm, Tensor campos, Tensor bg, Tensor target,
                                          int64_t H, int64_t W, double tfx, double tfy, double smod, int64_t vps, int64_t capacity, double weight, bool da_grads) {
-    return RasterizeL1BatchedNode::apply(means3D, colors, opac, cov, vm, pm, campos, bg, target, H, W, tfx, tfy, smod, vps, capacity, weight, da_grads);
+    return RasterizeL1BatchedNode::apply(means3D, colors, opac, cov, vm, pm, campos, bg, target, H, W, tfx, tfy, smod, vps, capacity, weight, da_grads,
+                                         at::GradMode::is_enabled());
 }
 
 std::vector<Tensor> rasterize_gaussians(Tensor means3D, Tensor means2D, Tensor sh, Tensor colors, Tensor opac, Tensor scales, Tensor rot, Tensor cov,
                                         int64_t H, int64_t W, double tfx, double tfy, Tensor bg, double smod, Tensor vm, Tensor pm, int64_t sh_degree,
                                         Tensor campos) {
-    return RasterizeGaussiansNode::apply(means3D, means2D, sh, colors, opac, scales, rot, cov, H, W, tfx, tfy, bg, smod, vm, pm, sh_degree, campos);
+    return RasterizeGaussiansNode::apply(means3D, means2D, sh, colors, opac, scales, rot, cov, H, W, tfx, tfy, bg, smod, vm, pm, sh_degree, campos,
+                                         at::GradMode::is_enabled());
 }
 
 }  // namespace

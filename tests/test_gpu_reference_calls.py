@@ -568,6 +568,9 @@ def test_cpp_batched_l1_node_overflow_and_no_grad():
         R.check_pending_overflows(True)
     with torch.no_grad(), pytest.raises(RuntimeError, match="exceeds max_rendered 1000"):
         call(base, small)
+    d = {k: v.clone().requires_grad_(True) for k, v in base.items()}          # leaves that require grad, but under no_grad: still "now"
+    with torch.no_grad(), pytest.raises(RuntimeError, match="this forward"):
+        call(d, small)
     # and a fitting capacity keeps working afterwards, many forwards deep
     ok = mk(400000)
     for _ in range(300):
