@@ -27,7 +27,7 @@ constexpr int kRadix = 1 << kRadixBits;
 constexpr int kItemsSmall = 4, kItemsLarge = 16;
 
 // the LDS distribution sort of long tile lists (deep_tile_kernel): a fine bin holds at most kDeepBinMax composites; LDS composites per
-// workgroup of the 1024-thread / 256-thread instantiation; worklist entry = tile id | window << 26
+// workgroup of the big (15 360-composite) / small (4 096-composite) instantiation; worklist entry = tile id | window << 26
 constexpr uint32_t kDeepBinMax = 128, kDeepBigCap = 15360, kDeepSmallCap = 4096, kDeepTileMask = 0x03FFFFFFu;
 constexpr int kTileBins = 2048;                    // tiles of a launch whose emission kernel writes the tile pass's histogram rows (== kWide)
 struct DupExtra {
@@ -389,7 +389,7 @@ __global__ __launch_bounds__(kThreads) void wide_downsweep_kernel(const uint64_t
                 if (ORDERED) {
                     if (v[j] && worklist) worklist[1 + atomicAdd(&worklist[0], 1u)] = d;
                 } else if (v[j] && deep_all) {
-                    // every occupied tile -> the LDS distribution sort (256-thread instantiation): one entry per window of 3968 entries; list 0
+                    // every occupied tile -> the LDS distribution sort (small instantiation): one entry per window of 3968 entries; list 0
                     // runs on into the other lists' room
                     const uint32_t nw = (v[j] + (kDeepSmallCap - kDeepBinMax) - 1u) / (kDeepSmallCap - kDeepBinMax), at = atomicAdd(&s_wl[0], nw);
                     for (uint32_t w = 0; w < nw; w++) worklist[16u + at + w] = d | (w << 26);
@@ -1996,7 +1996,7 @@ int sgr_bin_ex(const SgrProblem *pb, const int32_t *radii, uint32_t *rect,
     const bool segmented = mode == 2;
     if (segmented && wide_regs) {
         uint32_t *wl = (uint32_t *)((char *)workspace + sgr_bin_workspace_bytes(R, 0));     // [16 counters][6][tiles_total]
-        // per-tile step: the LDS distribution sort (O(n), one 256-thread workgroup per window of 3968 entries, ONE launch for everything) or
+        // per-tile step: the LDS distribution sort (O(n), one workgroup per window of 3968 entries, ONE launch for everything) or
         // -- sgr_set_sort_deep(2) -- the register network, whose launch lasts as long as its longest tile's 4- or 8-wave network
         const bool wide_deep = g_deep_mode != 2;
         { SgrProfScope _ps(SGR_K_SORT, stream);
