@@ -443,6 +443,7 @@ def _fwd_common(ctx, means3D, sh, colors_precomp, opacities, scales, rotations, 
     # fp32-only op: inputs are cast here, so an enclosing autocast region (gs.py:98) cannot downcast them
     opt = lambda t: None if t is None or t.numel() == 0 else _f32c(t)
     means3D = _f32c(means3D)
+    ctx.op_shape = tuple(opacities.shape)            # [S,P,1] (upstream's form) or [S,P]: the gradient goes back in the same shape
     opacities = _f32c(opacities).reshape(means3D.shape[0], means3D.shape[1])
     sh, colors_precomp, scales, rotations, cov3Ds_precomp = map(opt, (sh, colors_precomp, scales, rotations, cov3Ds_precomp))
     f32 = torch.float32
@@ -473,7 +474,7 @@ def _bwd_common(ctx, grad_color, grad_depth, grad_alpha, grad_color_scale=None):
         ctx.sgr, means3D, opacities, colors_precomp, sh, cov3Ds_precomp, scales, rotations, ctx.st, grad_color, grad_depth,
         grad_alpha, (color, depth, alpha), grad_color_scale, want_means2D=ctx.has_means2D)
     has_sh, has_col, has_sr, has_cov = ctx.has
-    return (d_means3D, d_means2D if ctx.has_means2D else None, d_sh if has_sh else None, d_col if has_col else None, d_op.unsqueeze(-1),
+    return (d_means3D, d_means2D if ctx.has_means2D else None, d_sh if has_sh else None, d_col if has_col else None, d_op.reshape(ctx.op_shape),
             d_sc if has_sr else None, d_rot if has_sr else None, d_cov if has_cov else None)
 
 

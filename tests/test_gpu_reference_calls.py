@@ -621,3 +621,37 @@ def test_cpp_batched_l1_node_two_threads_two_streams():
         assert not isinstance(outs[i][0], BaseException), outs[i][0]
         assert all(torch.equal(a, b) for a, b in zip(ref[i][0], outs[i][0]))
     R.check_pending_overflows(True)
+
+
+def test_cpp_batched_l1_node_input_forms():
+    """Input forms the Python node accepts, through the C++ node: opacities as [S,P] (no trailing 1), non-contiguous colours, half-precision
+    leaves (cast to fp32 inside, gradients come back in the leaf's dtype) -- same numbers as the Python node."""
+    from sigman_release_amd import _cabi, rasterizer as R
+    if _cabi.torch_node() is None:
+        pytest.skip("sgr_torch_node.so not built / SIGMAN_PY_NODE=1")
+    dev = _dev()
+    base, mk, target = _batched_l1_inputs(dev, 2, 2)
+    st = mk(400000)
+    S, P = base["means3D"].shape[:2]
+    wide = torch.zeros(S, P, 6, device=dev)
+    wide[..., ::2] = base["rgb"]
+    forms = {
+        "opacity_2d": lambda: dict(base, opacity=base["opacity"].reshape(S, P)),
+        "non_contiguous_rgb": lambda: dict(base, rgb=wide[..., ::2]),
+        "bf16_leaves": lambda: {k: v.to(torch.bfloat16) for k, v in base.items()},
+    }
+    for name, make in forms.items():
+        res = []
+        for impl in ("python", "cpp"):
+            src = make()
+            d = {k: v.detach().clone().requires_grad_(True) if k != "rgb" or name != "non_contiguous_rgb" else v.detach().requires_grad_(True) for k, v in src.items()}
+            args = (d["means3D"], None, None, d["rgb"], d["opacity"], None, None, d["cov3D"], st, target, None, 0.5)
+            out = R._RasterizeL1Batched.apply(*args) if impl == "python" else R.rasterize_l1_loss_batched(*args)
+            out[0].backward()
+            torch.cuda.synchronize()
+            res.append([out[2].detach().clone()] + [d[k].grad.clone() for k in ("means3D", "rgb", "opacity", "cov3D")])
+            for k in ("means3D", "rgb", "opacity", "cov3D"):
+                assert d[k].grad.shape == d[k].shape and d[k].grad.dtype == d[k].dtype, (name, impl, k)
+        for a, b in zip(*res):
+            assert torch.equal(a, b), name
+    R.check_pending_overflows(True)
