@@ -195,7 +195,9 @@ int sgr_set_sort_mode(int mode);
  * by one workgroup (per window of 15 232 entries): adaptive depth bins from the tile's own histogram, bin-ordered placement, rank inside
  * the (tiny) bin -- O(n).  mode 0 = automatic (launches with more than 1024 instances per tile on average, e.g. 1M Gaussians at 512^2:
  * they used to fall back to six whole-key radix passes), 1 = whenever flavour 4 runs, 2 = never.  Same bits out; a tile with massive
- * exact depth ties (> 128 in one bin) takes the generic path. */
+ * exact depth ties (> 128 in one bin) takes the generic path.  Bits 8..15 of `mode` (tests; 0 = default 64): behind the single wide tile pass
+ * (one or two 512^2 views) a tile with more windows of 3968 entries than this is listed once and sorted whole by one workgroup -- what a tile
+ * beyond 64 windows (the window field of a list entry) gets in production. */
 int sgr_set_sort_deep(int mode);
 
 /* bytes of scratch sgr_bin needs for R tile instances */

@@ -29,6 +29,15 @@ constexpr int kItemsSmall = 4, kItemsLarge = 16;
 // the LDS distribution sort of long tile lists (deep_tile_kernel): a fine bin holds at most kDeepBinMax composites; LDS composites per
 // workgroup of the big (15 360-composite) / small (4 096-composite) instantiation; worklist entry = tile id | window << 26
 constexpr uint32_t kDeepBinMax = 128, kDeepBigCap = 15360, kDeepSmallCap = 4096, kDeepTileMask = 0x03FFFFFFu;
+constexpr uint32_t kDeepMaxWindows = 64;           // 6-bit window field
+// FB instantiation of deep_tile_kernel (behind the single wide tile pass: <= 2048 tiles, so bits 11..25 of an entry are free):
+//   kDeepWhole     set by the tile pass in the ONE entry of a tile with more windows than the window field can number (> 64 x 3968 entries;
+//                  sgr_set_sort_deep can lower the cap for tests): that workgroup sorts the whole tile on the spot with the stable radix
+//                  passes, alone (windows 64, 128.. of such a tile used to wrap to window 0: several workgroups re-sorting one segment in place)
+//   kDeepDeclined  set in a tile's window-0 entry by that window's workgroup when it declines the tile (massive depth ties), BEFORE it starts
+//                  to re-sort the tile's segment in place; the other windows' workgroups look at it once their own histogram reads of the
+//                  segment are over
+constexpr uint32_t kDeepWhole = 1u << 24, kDeepDeclined = 1u << 25, kDeepFbTileMask = kDeepWhole - 1u;
 constexpr int kTileBins = 2048;                    // tiles of a launch whose emission kernel writes the tile pass's histogram rows (== kWide)
 struct DupExtra {
     const uint32_t *self_sums;          // un-scanned per-workgroup tile counts (NULL: block_offsets already holds the scan)
@@ -391,8 +400,13 @@ __global__ __launch_bounds__(kThreads) void wide_downsweep_kernel(const uint64_t
                 } else if (v[j] && deep_all) {
                     // every occupied tile -> the LDS distribution sort (small instantiation): one entry per window of 3968 entries; list 0
                     // runs on into the other lists' room
-                    const uint32_t nw = (v[j] + (kDeepSmallCap - kDeepBinMax) - 1u) / (kDeepSmallCap - kDeepBinMax), at = atomicAdd(&s_wl[0], nw);
-                    for (uint32_t w = 0; w < nw; w++) worklist[16u + at + w] = d | (w << 26);
+                    // (deep_all = the most windows a tile may have, <= 64: the window field of an entry has 6 bits.  A longer tile is listed
+                    // once, marked kDeepWhole)
+                    uint32_t nw = (v[j] + (kDeepSmallCap - kDeepBinMax) - 1u) / (kDeepSmallCap - kDeepBinMax);
+                    const uint32_t whole = nw > deep_all ? kDeepWhole : 0u;
+                    if (whole) nw = 1u;
+                    const uint32_t at = atomicAdd(&s_wl[0], nw);
+                    for (uint32_t w = 0; w < nw; w++) worklist[16u + at + w] = d | whole | (w << 26);
                 } else if (v[j]) {
                     const uint32_t m = v[j] <= 1024u ? 0u : (v[j] <= 2048u ? 1u : (v[j] <= 4096u ? 2u : (v[j] <= 8192u ? 3u : (v[j] <= 16384u ? 4u : 5u))));
                     // (LDS counters: the ~200 returning device-scope atomics on six words of one line were a serial chain on this
@@ -504,8 +518,13 @@ __global__ __launch_bounds__(kThreads) void wide_downsweep_runs_kernel(const uin
             if (blockIdx.x == 0 && d < tiles_total) {
                 ranges[d] = v[j] ? make_uint2(run, run + v[j]) : make_uint2(0u, 0u);
                 if (v[j] && deep_all) {
-                    const uint32_t nw = (v[j] + (kDeepSmallCap - kDeepBinMax) - 1u) / (kDeepSmallCap - kDeepBinMax), at = atomicAdd(&s_wl[0], nw);
-                    for (uint32_t w = 0; w < nw; w++) worklist[16u + at + w] = d | (w << 26);
+                    // (deep_all = the most windows a tile may have, <= 64: the window field of an entry has 6 bits.  A longer tile is listed
+                    // once, marked kDeepWhole)
+                    uint32_t nw = (v[j] + (kDeepSmallCap - kDeepBinMax) - 1u) / (kDeepSmallCap - kDeepBinMax);
+                    const uint32_t whole = nw > deep_all ? kDeepWhole : 0u;
+                    if (whole) nw = 1u;
+                    const uint32_t at = atomicAdd(&s_wl[0], nw);
+                    for (uint32_t w = 0; w < nw; w++) worklist[16u + at + w] = d | whole | (w << 26);
                 } else if (v[j]) {
                     const uint32_t m = v[j] <= 1024u ? 0u : (v[j] <= 2048u ? 1u : (v[j] <= 4096u ? 2u : (v[j] <= 8192u ? 3u : (v[j] <= 16384u ? 4u : 5u))));
                     worklist[16u + m * tiles_total + atomicAdd(&s_wl[m], 1u)] = d;
@@ -1593,7 +1612,7 @@ __device__ unsigned long long sgr_deep_dbg[1024 * 16];
 // workgroup does the compositing kernel's prepare step (tile order + descriptor clear).
 template <int NT, int CAP, int NBF, bool FB = false>
 __global__ __launch_bounds__(NT) void deep_tile_kernel(uint64_t *comp, uint32_t *scratch, uint64_t *__restrict__ dst_keys, uint32_t *__restrict__ dst_vals,
-                                                       const uint32_t *__restrict__ count_ptr, const uint32_t *__restrict__ deep_list,
+                                                       const uint32_t *__restrict__ count_ptr, uint32_t *deep_list,
                                                        const uint2 *__restrict__ ranges, int keep_keys, VsegPlan *__restrict__ plan,
                                                        uint32_t *__restrict__ lists, uint32_t list_stride, SortPrep prep) {
     constexpr uint32_t RI = (CAP + NT - 1) / NT <= 4 ? 4 : ((CAP + NT - 1) / NT <= 8 ? 8 : 16), REG = NT * RI;   // the first REG composites of a tile live in registers (RI per thread) for all passes
@@ -1616,10 +1635,20 @@ __global__ __launch_bounds__(NT) void deep_tile_kernel(uint64_t *comp, uint32_t 
         __syncthreads();                                                        // (LDS reuse between tiles)
         SGR_STAMP(0)
         const uint32_t entry = SGR_UNIFORM(deep_list[i]);
-        const uint32_t tile = entry & kDeepTileMask, w0 = (entry >> 26) * WIN;  // this workgroup's window: sorted positions of bins starting in [w0, w0 + WIN)
+        const uint32_t tile = entry & (FB ? kDeepFbTileMask : kDeepTileMask), w0 = (entry >> 26) * WIN;  // this workgroup's window: sorted positions of bins starting in [w0, w0 + WIN)
         const uint2 range_v = ranges[tile];
         const uint2 range = make_uint2(SGR_UNIFORM(range_v.x), SGR_UNIFORM(range_v.y));
         const uint32_t n = range.y - range.x, last = n - 1u;
+        // FB: stable LSD passes over the value bits, then the depth bits, through global memory (comp / scratch <-> dst): the whole tile, by
+        // this workgroup alone
+        auto sort_here = [&]() {
+            uint32_t *l32 = (uint32_t *)s_comp;
+            uint32_t *hist = l32, *digit_base = l32 + kRadix, *wtot = l32 + 2 * kRadix;
+            uint32_t (*wave_cnt)[kRadix] = (uint32_t (*)[kRadix])(l32 + 2 * kRadix + 64);
+            __syncthreads();
+            sort_one_tile<NT, 1, true>(range, comp, scratch, dst_keys, dst_vals, nullptr, nullptr, nullptr, nullptr, hist, digit_base, wave_cnt, wtot, tile);
+        };
+        if constexpr (FB) { if (entry & kDeepWhole) { sort_here(); continue; } }
         const uint64_t *seg = comp + range.x;
         uint64_t c[RI];
 #pragma unroll
@@ -1721,17 +1750,19 @@ __global__ __launch_bounds__(NT) void deep_tile_kernel(uint64_t *comp, uint32_t 
             for (uint32_t w = 0; w < wave; w++) p += s_wave[w];
 #pragma unroll
             for (uint32_t j = 0; j < PER; j++) { s_pre[t * PER + j] = p; s_cur[t * PER + j] = p; p += h[j]; }
+            // FB, a later window of a shared tile: has window 0 declined the tile?  Then it is re-sorting the segment in place, and whatever this
+            // workgroup's own histogram said (its reads may have met half-rewritten data) it must stay away.  Flag clear: window 0 had not
+            // started when every read above was already over -- this histogram is the tile's, and window 0 will decide the same.
+            if (FB && w0 != 0u && t == 0 &&
+                (__hip_atomic_load(&deep_list[i - (entry >> 26)], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) & kDeepDeclined)) s_bad = 1u;
         }
         __syncthreads();
         SGR_STAMP(5)
         if (s_bad) {
             if constexpr (FB) {
-                if (w0 == 0u) {             // once per tile: stable LSD passes over the value bits, then the depth bits, through global memory
-                    uint32_t *l32 = (uint32_t *)s_comp;
-                    uint32_t *hist = l32, *digit_base = l32 + kRadix, *wtot = l32 + 2 * kRadix;
-                    uint32_t (*wave_cnt)[kRadix] = (uint32_t (*)[kRadix])(l32 + 2 * kRadix + 64);
-                    __syncthreads();
-                    sort_one_tile<NT, 1, true>(range, comp, scratch, dst_keys, dst_vals, nullptr, nullptr, nullptr, nullptr, hist, digit_base, wave_cnt, wtot, tile);
+                if (w0 == 0u) {             // once per tile
+                    if (t == 0) { __hip_atomic_fetch_or(&deep_list[i], kDeepDeclined, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); __threadfence(); }
+                    sort_here();
                 }
             } else if (t == 0 && w0 == 0u) {       // -> the generic per-tile sort (register classes up to 16 384 entries, global-memory passes beyond); once per tile
                 const uint32_t cls = n <= 1024u ? 0u : (n <= 2048u ? 1u : (n <= 4096u ? 2u : (n <= 8192u ? 3u : (n <= 16384u ? 4u : 5u))));
@@ -1836,7 +1867,15 @@ extern "C" int sgr_set_sort_mode(int mode) { sgr_sort_mode = mode; return 0; }
 // deep tile lists in the view-segmented flavour (the LDS distribution sort, deep_tile_kernel): 0 = automatic (launches whose tile lists are
 // deep on average), 1 = whenever that flavour runs, 2 = never (deep launches then keep the whole-key passes)
 static thread_local int g_deep_mode = 0;
-extern "C" int sgr_set_sort_deep(int mode) { g_deep_mode = (mode >= 0 && mode <= 2) ? mode : 0; return 0; }
+// bits 8..15 of `mode` (tests): the most windows a tile may have behind the single wide tile pass before it is listed once and sorted whole
+// (0 = the window field's 64)
+static thread_local uint32_t g_deep_max_windows = kDeepMaxWindows;
+extern "C" int sgr_set_sort_deep(int mode) {
+    const int m = mode & 0xFF, cap = (mode >> 8) & 0xFF;
+    g_deep_mode = (m >= 0 && m <= 2) ? m : 0;
+    g_deep_max_windows = (cap >= 1 && cap <= (int)kDeepMaxWindows) ? (uint32_t)cap : kDeepMaxWindows;
+    return 0;
+}
 
 extern "C" size_t sgr_bin_workspace_bytes(uint64_t R, uint64_t tiles_total) {
     const uint64_t nblocks = (R + kThreads * kItemsSmall - 1) / (kThreads * kItemsSmall);
@@ -2003,13 +2042,13 @@ int sgr_bin_ex(const SgrProblem *pb, const int32_t *radii, uint32_t *rect,
         if (emit_hist) {
         hipLaunchKernelGGL(wide_rowscan_kernel, dim3(kWide / 64), dim3(1024), 0, stream, hist, nblk_e, hist + (size_t)nblk_e * kWide);
         hipLaunchKernelGGL(wide_downsweep_runs_kernel<kItemsSmall>, dim3(nblk_e), dim3(kThreads), 0, stream, kin, vin, kout, blk_runs, hist,
-                           hist + (size_t)nblk_e * kWide, (uint2 *)ranges, (uint32_t)tiles_total, wl, wide_deep ? 1u : 0u);
+                           hist + (size_t)nblk_e * kWide, (uint2 *)ranges, (uint32_t)tiles_total, wl, wide_deep ? g_deep_max_windows : 0u);
         SGR_CHECK_LAUNCH("wide tile-bit pass (emitted rows)");
         } else {
         hipLaunchKernelGGL(wide_upsweep_kernel<kItemsSmall>, dim3(nblocks), dim3(kThreads), 0, stream, kin, n, num_rendered_dev, 32, nblocks, hist);
         hipLaunchKernelGGL(wide_rowscan_kernel, dim3(kWide / 64), dim3(1024), 0, stream, hist, nblocks, hist + (size_t)nblocks * kWide);
         hipLaunchKernelGGL((wide_downsweep_kernel<kItemsSmall, false>), dim3(nblocks), dim3(kThreads), 0, stream, kin, vin, kout, vout, n, num_rendered_dev, 32,
-                           nblocks, hist, hist + (size_t)nblocks * kWide, (uint2 *)ranges, (uint32_t)tiles_total, wl, wide_deep ? 1u : 0u);
+                           nblocks, hist, hist + (size_t)nblocks * kWide, (uint2 *)ranges, (uint32_t)tiles_total, wl, wide_deep ? g_deep_max_windows : 0u);
         SGR_CHECK_LAUNCH("wide tile-bit pass");
         }
         // composites sit tile-bucketed in kout (vout is scratch); the sorted list goes back into (kin, vin)

@@ -51,7 +51,7 @@ using torch::autograd::variable_list;
 
 // ---- pinned words + events for the asynchronous instance count: one per forward whose count nobody has looked at yet
 struct CountSlot { uint64_t *host = nullptr; hipEvent_t ev = nullptr; int dev = 0; };
-struct Pending { CountSlot slot; std::tuple<int, int64_t, int64_t, int64_t> key; uint64_t capacity; bool by_copy; bool checked = false; uint64_t count = 0; bool overflow = false, reported = false, warned = false; int64_t id = 0; };
+struct Pending { CountSlot slot; std::tuple<int, int64_t, int64_t, int64_t> key; uint64_t capacity; bool by_copy; std::atomic<bool> checked{false}; uint64_t count = 0; bool overflow = false, reported = false, warned = false; int64_t id = 0; std::mutex mu; };
 struct ThreadState {
     std::vector<std::shared_ptr<Pending>> pending;       // deferred checks of this thread, oldest first
 };
@@ -103,13 +103,29 @@ char *alloc_cb(void *user, int32_t which, size_t bytes) {
 // possibly behind a step's worth of earlier work), so that the callers' fallback -- a device synchronise, which drains everything queued
 // and costs the host its run-ahead -- only ever runs when something is wrong.  (A fixed 200 000 polls were over in ~60 us: with the GPU a
 // step behind, every wait ended in that synchronise: C2 0.154 ms per step instead of 0.138.)
-inline void spin_for_count(volatile uint64_t *w) {
+inline void spin_for_count(volatile uint64_t *w, const std::atomic<bool> &resolved) {
     if (*w != ~0ull) return;
     const auto t0 = std::chrono::steady_clock::now();
     for (;;) {
-        for (int k = 0; k < 2048; k++) { if (*w != ~0ull) return; __builtin_ia32_pause(); }
+        for (int k = 0; k < 2048; k++) { if (*w != ~0ull || resolved.load(std::memory_order_acquire)) return; __builtin_ia32_pause(); }
         if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) return;
     }
+}
+// The wait for a count (poll, event, in the worst case a device synchronise) runs WITHOUT g_pend_mu: the mutex is process-wide, and a thread
+// waiting up to 2 s for its own view's count under it would stall every other thread's forward and backward bookkeeping (other streams, other
+// GPUs).  true = the word is there (or somebody else resolved the entry meanwhile).
+template <class P>
+inline bool wait_for_count(P &p, bool block) {
+    volatile uint64_t *w = p.slot.host;
+    const bool there = p.by_copy ? hipEventQuery(p.slot.ev) == hipSuccess : *w != ~0ull;
+    if (there) return true;
+    if (!block) return false;
+    if (p.by_copy) SGR_TORCH_CHECK_HIP(hipEventSynchronize(p.slot.ev));
+    else {                                                         // stored by the emission kernel itself, no event recorded: poll, then drain
+        spin_for_count(w, p.checked);
+        if (*w == ~0ull && !p.checked.load(std::memory_order_acquire)) SGR_TORCH_CHECK_HIP(hipDeviceSynchronize());
+    }
+    return true;
 }
 
 inline Tensor f32c(const Tensor &t) { return (t.scalar_type() == at::kFloat && t.is_contiguous()) ? t : t.to(at::kFloat).contiguous(); }
@@ -125,20 +141,16 @@ bool deferral_allowed() {
 
 // reads a slot's word if it is there (block: wait for it); true = resolved
 bool resolve(Pending &p, bool block) {
+    if (p.checked.load(std::memory_order_acquire)) return true;
+    // one thread at a time looks at an entry (its own mutex: only a thread that wants THIS count waits here); the slot stays ours meanwhile
+    std::unique_lock<std::mutex> own(p.mu, std::defer_lock);
+    if (block) own.lock(); else if (!own.try_lock()) return false;
+    if (p.checked.load(std::memory_order_acquire)) return true;
+    if (!wait_for_count(p, block)) return false;
     std::lock_guard<std::mutex> pl(g_pend_mu);
-    if (p.checked) return true;
-    volatile uint64_t *w = p.slot.host;
-    bool there = p.by_copy ? hipEventQuery(p.slot.ev) == hipSuccess : *w != ~0ull;
-    if (!there) {
-        if (!block) return false;
-        if (p.by_copy) SGR_TORCH_CHECK_HIP(hipEventSynchronize(p.slot.ev));
-        else {                                                     // stored by the emission kernel itself, no event recorded: poll, then drain
-            spin_for_count(w);
-            if (*w == ~0ull) SGR_TORCH_CHECK_HIP(hipDeviceSynchronize());
-        }
-    }
-    const uint64_t word = *w;
-    p.count = word & ~(1ull << 63); p.overflow = (word >> 63) != 0; p.checked = true;
+    if (p.checked.load(std::memory_order_relaxed)) return true;        // the other thread was first (it also released the slot)
+    const uint64_t word = *(volatile uint64_t *)p.slot.host;
+    p.count = word & ~(1ull << 63); p.overflow = (word >> 63) != 0; p.checked.store(true, std::memory_order_release);
     release_slot(p.slot);
     // (an overflowed forward stays findable by its own backward, which is the call that raises for it; bounded)
     if (!p.overflow) g_by_id.erase(p.id);
@@ -291,7 +303,8 @@ struct RasterizeGaussiansNode : public torch::autograd::Function<RasterizeGaussi
                 // learning phase: everything is queued; the emission kernel stores the count into the pinned word right after it has summed the
                 // block counts (large launches: an async copy behind the scan kernel -- then only the event says "complete")
                 volatile uint64_t *w = slot.host;
-                if (!st.nr_by_copy) spin_for_count(w);
+                static const std::atomic<bool> never{false};
+                if (!st.nr_by_copy) spin_for_count(w, never);
                 if (st.nr_by_copy) SGR_TORCH_CHECK_HIP(hipEventSynchronize(slot.ev));
                 else if (*w == ~0ull) SGR_TORCH_CHECK_HIP(hipDeviceSynchronize());
                 const uint64_t word = *w;
@@ -390,26 +403,22 @@ struct RasterizeGaussiansNode : public torch::autograd::Function<RasterizeGaussi
 // constant kernel durations, step period 137.6 -> 153 us in discrete levels).  Same semantics as the Python node: the count is looked
 // at by the forward's own backward after its kernels are queued (or by a later forward / check_pending() if no backward ever runs),
 // and a forward that did not fit its capacity raises -- the caller chose the capacity.
-struct BPending { CountSlot slot; uint64_t capacity = 0; bool by_copy = false, checked = false, overflow = false, reported = false; uint64_t count = 0; int64_t id = 0; };
+struct BPending { CountSlot slot; uint64_t capacity = 0; bool by_copy = false; std::atomic<bool> checked{false}; bool overflow = false, reported = false; uint64_t count = 0; int64_t id = 0; std::mutex mu; };
 std::map<int64_t, std::shared_ptr<BPending>> g_b_by_id;
 std::map<std::tuple<int, int64_t, int64_t, int64_t, int64_t, uint64_t, int>, std::array<uint64_t, 3>> g_b_blob_sizes;
 std::vector<std::shared_ptr<BPending>> &b_pending() { thread_local std::vector<std::shared_ptr<BPending>> v; return v; }
 
 bool b_resolve(BPending &p, bool block) {
+    if (p.checked.load(std::memory_order_acquire)) return true;
+    // one thread at a time looks at an entry (its own mutex: only a thread that wants THIS count waits here); the slot stays ours meanwhile
+    std::unique_lock<std::mutex> own(p.mu, std::defer_lock);
+    if (block) own.lock(); else if (!own.try_lock()) return false;
+    if (p.checked.load(std::memory_order_acquire)) return true;
+    if (!wait_for_count(p, block)) return false;
     std::lock_guard<std::mutex> pl(g_pend_mu);
-    if (p.checked) return true;
-    volatile uint64_t *w = p.slot.host;
-    bool there = p.by_copy ? hipEventQuery(p.slot.ev) == hipSuccess : *w != ~0ull;
-    if (!there) {
-        if (!block) return false;
-        if (p.by_copy) SGR_TORCH_CHECK_HIP(hipEventSynchronize(p.slot.ev));
-        else {
-            spin_for_count(w);
-            if (*w == ~0ull) SGR_TORCH_CHECK_HIP(hipDeviceSynchronize());
-        }
-    }
-    const uint64_t word = *w;
-    p.count = word & ~(1ull << 63); p.overflow = (word >> 63) != 0; p.checked = true;
+    if (p.checked.load(std::memory_order_relaxed)) return true;
+    const uint64_t word = *(volatile uint64_t *)p.slot.host;
+    p.count = word & ~(1ull << 63); p.overflow = (word >> 63) != 0; p.checked.store(true, std::memory_order_release);
     release_slot(p.slot);
     g_b_by_id.erase(p.id);
     return true;

@@ -127,7 +127,10 @@ def test_sgr_bin_direct_all_flavours(n_views, P, size, depth_kind, big_rects):
     try:
         # (flavour, deep mode): 4 with the deep mode forced on = the long tiles (all tiles, for one or two views) go through the LDS
         # distribution sort; tiles with massive exact depth ties must come back through the generic path
-        for mode, deep in ((1, 0), (4, 2), (4, 1), (0, 0), (2, 0), (5, 0), (3, 0)):
+        # (5, 1 << 8) / (5, 2 << 8): flavour 5 with the window cap of the wide pass's distribution sort lowered to 1 / 2 (bits 8..15 of the deep
+        # mode): tiles of more than 3968 / 7936 entries are listed ONCE, marked "whole", and sorted on the spot by one workgroup -- the path a
+        # tile of more than 64 windows (254 000 entries) takes in production, exercised here at sizes the other flavours are checked at
+        for mode, deep in ((1, 0), (4, 2), (4, 1), (0, 0), (2, 0), (5, 0), (5, 1 << 8), (5, 2 << 8), (3, 0)):
             radii, rect, boff = t(case["radii"]), t(case["rect"]), t(offs)
             ka, kb = (torch.zeros(R, dtype=torch.int64, device=dev) for _ in range(2))
             va, vb = (torch.zeros(R, dtype=torch.int32, device=dev) for _ in range(2))
