@@ -28,8 +28,8 @@ One "step" = one pass of the hot path over one batch (all view slots of this ran
 of the whole job with inputs resident in HBM.  The timed step is the rasterizer (+ fused loss): distCUDA2 + get_covariance
 (gs.py:70-73) run once per subject outside it; their cost is reported as `frontend_ms_per_subject`, and `variants.renderer_render_ms_per_step`
 times what the reference's render() really pays: GaussianRenderer.render (3-NN + covariance + rasterizer + clamp) forward and backward.
-A timed region shorter than 20 ms is not a measurement: when `--steps K` would give one, max(K, 100) steps are timed instead and the line
-says so (`steps` = what was timed, `steps_requested` = K).
+A timed region shorter than 20 ms is not a measurement: when `--steps K` would give one, as many steps as 20 ms hold (at least 100) are
+timed instead and the line says so (`steps` = what was timed, `steps_requested` = K).
 `roofline` is for the dominant kernel, timed with HIP events recorded by the library on the launch stream inside the
 timed region; `roofline.traffic` comes from the committed rocprofv3 PMC summary of this same command
 (profiles/r03_pmc_<config>.json; null when there is none for the workload).  `cpu_baseline` is the CPU oracle
@@ -107,6 +107,49 @@ def _pin_host_threads():
 
 
 _ORIG_AFFINITY = _pin_host_threads()
+
+
+def _set_affinity_all_threads(mask):
+    """sched_setaffinity(0, ..) moves the calling thread only; the autograd engine's thread exists by now."""
+    for tid in os.listdir("/proc/self/task"):
+        try:
+            os.sched_setaffinity(int(tid), mask)
+        except OSError:
+            pass
+
+
+def _choose_host_cores(step, sync_all, t_step):
+    if _ORIG_AFFINITY is None:
+        return "not pinned (SIGMAN_NO_PIN=1)"
+    base = sorted(os.sched_getaffinity(0))
+    cands = [("cores %s" % base, set(base))]
+    for off in (8, 16):                                         # the same quad one / two CCXs further
+        alt = {c + off for c in base}
+        if alt <= _ORIG_AFFINITY:
+            cands.append(("cores %s" % sorted(alt), alt))
+    cands.append(("not pinned", set(_ORIG_AFFINITY)))
+    n = max(10, min(2000, int(0.03 / t_step)))
+    trial = []
+    for name, mask in cands:
+        _set_affinity_all_threads(mask)
+        for _ in range(max(3, n // 10)):
+            step()
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            step()
+        sync_all()
+        trial.append((time.perf_counter() - t0) / n)
+    if dist.is_initialized():                                   # one decision for the job: every rank takes the option that is best for the slowest rank
+        tt = torch.tensor(trial, dtype=torch.float64, device=torch.device("cuda", torch.cuda.current_device()))
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        trial = [float(x) for x in tt.tolist()]
+    best = min(range(len(cands)), key=lambda i: trial[i])
+    if trial[best] > 0.97 * trial[0]:                           # within the noise of a 30-ms trial: keep the start-up choice
+        best = 0
+    _set_affinity_all_threads(cands[best][1])
+    return ("host threads on %s (untimed %d-step trials, ms per step: " % (cands[best][0], n)
+            + ", ".join("%s %.4f" % (c[0], t * 1e3) for c, t in zip(cands, trial)) + ")")
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -334,10 +377,20 @@ def main(args):
         t3 = float(tr.item())
     for _ in range(min(2000, int(0.05 / max(t3 / 3.0, 1e-5)))):
         step()
-    # a timed region under 20 ms is noise, not a measurement (20 steps of C2 are 3 ms): time at least 100 steps then, and say so
+    # a timed region under 20 ms is noise, not a measurement (20 steps of C2 are 3 ms): time as many steps as 20 ms hold then, and say so
     steps_requested = steps
-    if steps * (t3 / 3.0) < 0.020:
-        steps = max(steps, 100)
+    t_step = max(t3 / 3.0, 1e-6)
+    if steps * t_step < 0.020:
+        steps = max(steps, int(np.ceil(0.020 / t_step)), 100)
+        if dist_on:                                   # the same count on every rank
+            ts = torch.tensor([steps], device=dev, dtype=torch.int64)
+            dist.all_reduce(ts, op=dist.ReduceOp.MAX)
+            steps = int(ts.item())
+    # ---- where the two host threads of the step (Python + autograd engine) run: the 4-core set chosen at start-up, a neighbouring set,
+    # or wherever the scheduler puts them -- whichever drives the step fastest on THIS box (a short untimed trial each: on some hosts the
+    # first cores carry the interrupts / the launcher's own threads and the pinned step is 30 % slower than the free one; on most the
+    # free one wanders across CCXs).  The choice and the trial times are in the line (config.host_threads).
+    pin_report = _choose_host_cores(step, sync_all, t_step)
 
     # ---- timed region (no per-kernel events here)
     sync_all()
@@ -413,7 +466,7 @@ def main(args):
         "kernel_ms_per_step": breakdown,
         "loss": None if loss is None else float(loss.detach()),
     }
-    out["config"]["host_threads"] = ("pinned to cores %s" % sorted(os.sched_getaffinity(0))) if _ORIG_AFFINITY is not None else "not pinned"
+    out["config"]["host_threads"] = pin_report
     if rank == 0 and world == 1:
         out["frontend_ms_per_subject"] = frontend_ms(g_host, dev)
         if not args.no_variants and args.config in ("c2", "c3"):
@@ -453,13 +506,15 @@ def frontend_ms(g_host, dev):
 def variants(args, subj, st, gt, norm, S, P, H, W, mine, dev, subs):
     """The same workload under the conditions the headline does NOT assume (N=1 only):
       renderer_render_*    GaussianRenderer.render (gs.py:49-117: distCUDA2 + get_covariance + all B*V views + clamp) forward and backward from
-                           the `gaussians` dict (position / scale / rotation / opacity / rgb leaves), then the same clamp+L1 loss
+                           the `gaussians` dict (position / scale / rotation / opacity / rgb leaves), then the headline's fused clamp+L1 loss kernel
+      auto_capacity_*      the batched rasterizer in automatic capacity mode (max_rendered = -1) + the same loss: no caller-supplied capacity
       per_view_loop_*      the reference's own call pattern (gs.py:62-109): Python loop over subjects and views through the
                            upstream-signature GaussianRasterizer (one launch chain + one autograd node per view), then clamp/stack/L1
       unpinned_*, exact_sync_*   the batched step re-run in a subprocess without host-thread pinning / with upstream's blocking read of
                            num_rendered in every forward (--exact-sync) instead of the pre-sized sync-free buffers"""
     from sigman_release_amd.losses import clamped_l1_loss
     out = {}
+    one = torch.ones((), device=dev)
     leaves = {k: v.clone().requires_grad_(True) for k, v in subj.items()}
     vm, pm, cp = st.viewmatrix, st.projmatrix, st.campos
     V = len(mine)
@@ -475,7 +530,7 @@ def variants(args, subj, st, gt, norm, S, P, H, W, mine, dev, subs):
         for v in gd.values():
             v.grad = None
         img = rend.render(gd, cvw, cvp_, cps, bg_color=st.bg)["image"].reshape(S * V, 3, H, W)
-        ((img - gt).abs().sum() * norm).backward()
+        clamped_l1_loss(img, gt, None, norm).backward(one)          # the headline's loss kernel (clamping the clamped image again changes nothing)
     n = 50 if S * V == 1 else 8
     for _ in range(3):
         renderer_step()
@@ -485,6 +540,24 @@ def variants(args, subj, st, gt, norm, S, P, H, W, mine, dev, subs):
         renderer_step()
     torch.cuda.synchronize()
     out["renderer_render_ms_per_step"] = round((time.perf_counter() - t0) / n * 1e3, 4)
+
+    # ---- the batched step in AUTOMATIC capacity mode (max_rendered = -1: what render() and every caller that does not size the binning
+    # buffers itself gets): sync-free with the capacity learned on the first call, count checked inside the call
+    st_auto = st._replace(max_rendered=-1)
+
+    def auto_step():
+        for v in leaves.values():
+            v.grad = None
+        color = R.rasterize_gaussians_batched(leaves["means3D"], None, None, leaves["rgb"], leaves["opacity"], None, None, leaves["cov3D"], st_auto)[0]
+        clamped_l1_loss(color, gt, None, norm).backward(one)
+    for _ in range(5):
+        auto_step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        auto_step()
+    torch.cuda.synchronize()
+    out["auto_capacity_ms_per_step"] = round((time.perf_counter() - t0) / n * 1e3, 4)
 
     def per_view():
         for v in leaves.values():

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SGR_ABI_VERSION 5
+#define SGR_ABI_VERSION 6
 #define SGR_TILE 16                 /* 16x16 pixel tiles, as the published algorithm */
 #define SGR_REC_FLOATS 12           /* floats of a gradient record (grec, pixel-parallel backward) */
 #define SGR_PART_FLOATS 10          /* floats of a partial gradient record (bucket-parallel backward): 40 B, 8-byte aligned */
@@ -325,6 +325,11 @@ int sgr_cov3d_backward(int32_t n, const float *scale_raw, const float *rotation,
 int sgr_clamped_l1_loss(int32_t n_views, int32_t H, int32_t W, const float *color, const float *target, const float *mask,
                         float weight, float *grad_color, float *loss_per_view, float *loss_total, int32_t sums_already_zero,
                         void *stream);
+
+/* rendered_image.clamp(0, 1) (gs.py:107) and its backward (grad_x = grad_y where 0 <= x <= 1, else 0: torch.clamp's inclusive mask) over n
+ * contiguous floats; the renderer node (csrc/torch_node.cpp, GaussianRenderer.render) keeps the unclamped colours for the rasterizer's backward. */
+int sgr_clamp01_forward(uint64_t n, const float *x, float *y, void *stream);
+int sgr_clamp01_backward(uint64_t n, const float *x, const float *grad_y, float *grad_x, void *stream);
 
 /* ---- optional per-kernel profiler (HIP events on the launch stream; used by bench.py) -------- */
 enum {

@@ -42,6 +42,7 @@ class SgrL1Epilogue(C.Structure):
                 ("loss_total", C.c_void_p), ("weight", C.c_float), ("sums_already_zero", C.c_int32)]
 
 
+ABI_VERSION = 6          # include/sigman_gsplat.h: SGR_ABI_VERSION
 ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_int32, C.c_size_t)
 
 _SIGNATURES = {
@@ -81,6 +82,8 @@ _SIGNATURES = {
     "sgr_cov3d_backward": (C.c_int, [C.c_int32] + [C.c_void_p] * 7),
     "sgr_clamped_l1_loss": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p,
                                       C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
+    "sgr_clamp01_forward": (C.c_int, [C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "sgr_clamp01_backward": (C.c_int, [C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sgr_prof_configure": (C.c_int, [C.c_uint32]),
     "sgr_prof_collect": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_uint32)]),
 }
@@ -101,14 +104,10 @@ def lib():
             fn = getattr(L, name)          # AttributeError if a declared symbol is not exported
             fn.restype = res
             fn.argtypes = args
-        if L.sgr_abi_version() != 5:
-            raise RuntimeError(f"ABI version mismatch: library reports {L.sgr_abi_version()}, binding expects 5")
-        if os.environ.get("SIGMAN_SORT_MODE", "") in ("0", "1", "2", "4", "5"):  # A/B knob: sort flavour (sgr_set_sort_mode)
-            L.sgr_set_sort_mode(int(os.environ["SIGMAN_SORT_MODE"]))
-        if os.environ.get("SIGMAN_SORT_DEEP", "") in ("1", "2"):              # A/B knob: LDS distribution sort of long tiles (sgr_set_sort_deep)
-            L.sgr_set_sort_deep(int(os.environ["SIGMAN_SORT_DEEP"]))
-        if os.environ.get("SIGMAN_FWD_MODE", "") in ("1", "2", "3"):      # A/B knob: forward compositing kernel (sgr_set_forward_mode)
-            L.sgr_set_forward_mode(int(os.environ["SIGMAN_FWD_MODE"]))
+        if L.sgr_abi_version() != ABI_VERSION:
+            raise RuntimeError(f"ABI version mismatch: library reports {L.sgr_abi_version()}, binding expects {ABI_VERSION}")
+        # (the A/B knobs SIGMAN_SORT_MODE / SIGMAN_SORT_DEEP / SIGMAN_FWD_MODE are read by the library itself, by every thread at its first
+        # use: the setters -- sgr_set_sort_mode & co -- are per thread, the environment is the process-wide default)
         _lib = L
     return _lib
 
@@ -129,7 +128,7 @@ def torch_node():
             spec = importlib.util.spec_from_file_location("sgr_torch_node", path)
             mod = importlib.util.module_from_spec(spec)
             spec.loader.exec_module(mod)
-            if mod.abi_version() != 5:
+            if mod.abi_version() != ABI_VERSION:
                 raise RuntimeError("sgr_torch_node.so was built against another ABI version of libsigman_gsplat.so: rebuild (make -C sigman_release_amd/csrc)")
             _node = mod
     return _node

@@ -1831,7 +1831,7 @@ __global__ __launch_bounds__(kThreads) void tile_ranges_kernel(const uint64_t *_
 
 // 3 = automatic (default), 4 = view-segmented (per-view tile pass + per-tile depth sort), 2 = segmented (global passes over the tile bits,
 // depth bits per tile in LDS), 0 = onesweep, 1 = three kernels per pass
-thread_local int sgr_sort_mode = 3;
+thread_local int sgr_sort_mode = sgr_env_knob("SIGMAN_SORT_MODE", 0, 5, 3);        // (per thread; every thread starts from the environment)
 
 struct VsegLayout {
     size_t plan, totals, key_start, chunk_start, chunk_map, hist, tile_total, lists, end; uint32_t chunk_keys, max_chunks;
@@ -1866,7 +1866,7 @@ int sgr_validate_problem(const SgrProblem *pb);
 extern "C" int sgr_set_sort_mode(int mode) { sgr_sort_mode = mode; return 0; }
 // deep tile lists in the view-segmented flavour (the LDS distribution sort, deep_tile_kernel): 0 = automatic (launches whose tile lists are
 // deep on average), 1 = whenever that flavour runs, 2 = never (deep launches then keep the whole-key passes)
-static thread_local int g_deep_mode = 0;
+static thread_local int g_deep_mode = sgr_env_knob("SIGMAN_SORT_DEEP", 0, 2, 0);
 // bits 8..15 of `mode` (tests): the most windows a tile may have behind the single wide tile pass before it is listed once and sorted whole
 // (0 = the window field's 64)
 static thread_local uint32_t g_deep_max_windows = kDeepMaxWindows;
@@ -1984,8 +1984,10 @@ int sgr_bin_ex(const SgrProblem *pb, const int32_t *radii, uint32_t *rect,
                            VL.max_chunks, plan, key_start, chunk_start, chunk_map, fold_totals ? sums : (const uint32_t *)nullptr, (uint32_t)nbx);
         if (VL.chunk_keys == 4096u) hipLaunchKernelGGL(vseg_upsweep_kernel<16>, dim3(VL.max_chunks), dim3(kThreads), 0, stream, kin, plan, chunk_map, tpv, vhist);
         else hipLaunchKernelGGL(vseg_upsweep_kernel<32>, dim3(VL.max_chunks), dim3(kThreads), 0, stream, kin, plan, chunk_map, tpv, vhist);
-        // views with many chunks (one or a few views of a deep launch): the chunk-parallel column scan
-        if ((uint64_t)VL.max_chunks >= 64ull * (uint64_t)pb->n_views)
+        // views with many chunks (one or a few views of a deep launch): the chunk-parallel column scan.  Its cost grows with tiles x views
+        // (C5, 1 view x 1024 tiles, 540 chunks: 7 us against 70 us of dependent round trips), the serial scan's with the chunks per view only:
+        // at 76 chunks per view the serial scan is the faster one (C4, 90 views x 4096 tiles: 31 us against 45 us)
+        if ((uint64_t)VL.max_chunks >= 192ull * (uint64_t)pb->n_views)
             hipLaunchKernelGGL(vseg_colscan_par_kernel, dim3((tpv + 63u) / 64u, pb->n_views), dim3(1024), 0, stream, vhist, chunk_start, tpv, tile_total);
         else
         hipLaunchKernelGGL(vseg_colscan_kernel, dim3((tpv + kThreads - 1) / kThreads, pb->n_views), dim3(kThreads), 0, stream, vhist, chunk_start, tpv, tile_total);

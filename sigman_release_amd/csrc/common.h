@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/sigman_gsplat.h"
 
@@ -36,6 +37,17 @@ int sgr_debug_enabled();        // api.hip: upstream's debug=True (thread-local)
             }                                                                                    \
         }                                                                                        \
     } while (0)
+
+// initial value of a per-thread dev / A-B knob: the environment variable when it holds one of the accepted values, else `dflt`.  The knobs
+// (sgr_set_sort_mode, sgr_set_sort_deep, sgr_set_forward_mode) are thread_local -- a setter changes the CALLING thread's flavour only --
+// and every thread, whenever it is created, starts from the same environment: a profile taken through SIGMAN_SORT_MODE=... measures that
+// flavour on the autograd / DataLoader threads as well, not just on the thread that loaded the library.
+inline int sgr_env_knob(const char *name, int lo, int hi, int dflt) {
+    const char *e = getenv(name);
+    if (!e || !*e) return dflt;
+    const int v = atoi(e);
+    return (v >= lo && v <= hi) ? v : dflt;
+}
 
 // profiler hooks (api.hip): slot = sgr_prof_begin(kernel id, stream); launch...; sgr_prof_end(slot, stream)
 int sgr_prof_begin(int kid, hipStream_t s);

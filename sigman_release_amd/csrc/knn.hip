@@ -358,8 +358,10 @@ __global__ __launch_bounds__(kT) void cov3d_bwd_kernel(int n, const float *__res
 }  // namespace
 
 extern "C" size_t sgr_knn_workspace_bytes(int32_t P, int32_t max_cells) {
-    // [bbox 8 u32][Grid 16 u32][cell_cnt/start max_cells+1][cell_fill max_cells][pt_cell P][sorted P float4]
-    return (size_t)(8 + 16 + 1024 + (size_t)max_cells + 1 + (size_t)max_cells + (size_t)P) * 4 + (size_t)P * 16 + 64;
+    // [bbox 8 u32][Grid 16 u32][cell_cnt/start max_cells+1][cell_fill max_cells][pt_cell P][sorted max(P, 2) float4]
+    // (the head of `sorted` first holds the bounding-box partials: 6 floats per prepare workgroup, min(ceil(P / 256), 64) of them --
+    // 24 * ceil(P / 256) <= 16 * P bytes from P = 2 on; a single point gets the room of two)
+    return (size_t)(8 + 16 + 1024 + (size_t)max_cells + 1 + (size_t)max_cells + (size_t)P) * 4 + (size_t)(P < 2 ? 2 : P) * 16 + 64;
 }
 
 extern "C" int sgr_knn_dist2_batched(int32_t n_sets, int32_t P, const float *points, float *out_dist2, void *workspace,
@@ -378,7 +380,7 @@ extern "C" int sgr_knn_dist2_batched(int32_t n_sets, int32_t P, const float *poi
     const int scan_blocks = (max_cells + 1 + kScanTile - 1) / kScanTile;
     const size_t init_want = ((size_t)2 * max_cells + 1 + kT * 4 - 1) / (kT * 4);
     const int init_blocks = (int)(init_want < 1024 ? init_want : 1024);
-    const int box_blocks = min(nb, kBoxBlocks);                       // (6 floats each at the head of `sorted`: P float4 >= 6 * box_blocks floats)
+    const int box_blocks = min(nb, kBoxBlocks);                       // (6 floats each at the head of `sorted`: sgr_knn_workspace_bytes leaves room for them)
     hipLaunchKernelGGL(knn_prep_kernel, dim3(max(init_blocks, box_blocks), n_sets), dim3(kT), 0, stream, kb, box_blocks);
     hipLaunchKernelGGL(cell_count_kernel, dim3(nb, n_sets), dim3(kT), 0, stream, kb, box_blocks);
     hipLaunchKernelGGL(cell_blocksum_kernel, dim3(scan_blocks, n_sets), dim3(kT), 0, stream, kb);

@@ -1126,7 +1126,7 @@ int sgr_render_forward_kind(const SgrProblem *pb);
 
 // 0 = automatic (segment-parallel for <= 2048 tiles, else one wave per quadrant), 1 = serial per-tile kernel (round 1), 2 = segment-parallel
 // kernel, 3 = one wave per (tile, quadrant) (dev/test override: sgr_set_forward_mode)
-static thread_local int sgr_fwd_mode = 0;          // (dev/test switch, thread-local like sgr_set_debug: the forward runs on the caller's thread)
+static thread_local int sgr_fwd_mode = sgr_env_knob("SIGMAN_FWD_MODE", 0, 3, 0);          // (dev/test switch, thread-local like sgr_set_debug: the forward runs on the caller's thread; every thread starts from the environment)
 extern "C" int sgr_set_forward_mode(int mode) { sgr_fwd_mode = mode; return 0; }
 int sgr_get_forward_mode() { return sgr_fwd_mode; }
 

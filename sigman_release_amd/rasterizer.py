@@ -499,6 +499,17 @@ def rasterize_gaussians_batched(means3D, means2D, sh, colors_precomp, opacities,
     scales [S,P,3] + rotations [S,P,4] | cov3Ds_precomp [S,P,6].  Returns color [n_views,3,H,W], radii [n_views,P],
     depth [n_views,1,H,W], alpha [n_views,1,H,W].
     """
+    st = raster_settings
+    if (sh is None and scales is None and rotations is None and means2D is None and colors_precomp is not None and cov3Ds_precomp is not None
+            and not getattr(st, "debug", False) and means3D.ndim == 3 and means3D.shape[1] > 0 and not _USE_BWD_V1):
+        node = _cabi.torch_node()
+        if node is not None:
+            # the reference's input flavour: the same node in C++ (csrc/torch_node.cpp, RenderBatchedNode) -- same capacity policy
+            # (max_rendered < 0 automatic with the inline check and the transparent exact re-run, > 0 explicit, 0 exact), same results,
+            # a third of the host time per call
+            return tuple(node.rasterize_batched(means3D, colors_precomp, opacities, cov3Ds_precomp, st.viewmatrix, st.projmatrix, st.campos, st.bg,
+                                                int(st.image_height), int(st.image_width), float(st.tanfovx), float(st.tanfovy), float(st.scale_modifier),
+                                                int(st.views_per_subject), int(getattr(st, "max_rendered", 0) or 0), bool(getattr(st, "depth_alpha_grads", None))))
     return _RasterizeGaussiansBatched.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                                             raster_settings)
 

@@ -90,6 +90,17 @@ class GaussianRenderer:
     def render(self, gaussians, cam_view, cam_view_proj, cam_pos, bg_color=None, scale_modifier=0.5):
         B, V = cam_view.shape[:2]
         H, W = self.opt.output_size_h, self.opt.output_size_w
+        node = _cabi.torch_node() if gaussians["position"].device.type == "cuda" and gaussians["position"].shape[1] > 0 else None
+        if node is not None:
+            # everything below as ONE C++ autograd node above the C ABI (csrc/torch_node.cpp, RenderBatchedNode: 3-NN, covariance build,
+            # batched rasterizer with the automatic capacity, clamp; backward: clamp mask, rasterizer, covariance): same numbers, one node
+            # issued from the interpreter instead of four
+            bg = self.bg_color if bg_color is None else bg_color
+            image, _radii, _depth, alpha = node.render_batched(gaussians["position"], gaussians["rgb"], gaussians["opacity"], gaussians["scale"],
+                                                               gaussians["cov3d"], cam_view.reshape(B * V, 4, 4), cam_view_proj.reshape(B * V, 4, 4),
+                                                               cam_pos.reshape(B * V, 3), bg, int(H), int(W), self.tan_half_fov, self.tan_half_fov,
+                                                               float(scale_modifier), int(V), -1)
+            return {"image": image.view(B, V, 3, H, W), "alpha": alpha.view(B, V, 1, H, W)}
         position = gaussians["position"].float()
         P = position.shape[1]
         with torch.no_grad():

@@ -1019,7 +1019,11 @@ def test_automatic_capacity_mode_is_transparent():
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     P, H, W = 6000, 160, 144
     inp, st = cases.humanoid(P=P, H=H, W=W, seed=31)
+    from sigman_release_amd import _cabi
+    node = _cabi.torch_node()                       # (the reference's input flavour goes through the C++ node when it is built: same policy)
     R._auto_capacity.pop((0, P, 1, H, W), None)
+    if node is not None:
+        node.reset_batched()
     results = []
     # splat size multiplier per call: small (learns a small capacity), same, 3x (overflows the remembered capacity), 3x again, small
     for mul in (0.4, 0.4, 3.0, 3.0, 0.4):
@@ -1035,7 +1039,7 @@ def test_automatic_capacity_mode_is_transparent():
         for a, b in zip(*per_mode):
             assert torch.equal(a, b)
         results.append(int((per_mode[0][1] > 0).sum()))
-    cap = R._auto_capacity[(0, P, 1, H, W)]
+    cap = node.batched_capacity(0, P, 1, H, W) if node is not None else R._auto_capacity[(0, P, 1, H, W)]
     assert cap > 0 and results[2] >= results[0]
 
 

@@ -655,3 +655,110 @@ def test_cpp_batched_l1_node_input_forms():
         for a, b in zip(*res):
             assert torch.equal(a, b), name
     R.check_pending_overflows(True)
+
+
+@pytest.mark.parametrize("S,V,cap,mode", [(1, 1, -1, "color"), (2, 3, -1, "color+depth+alpha"), (1, 2, 400000, "color"), (2, 2, 0, "color+depth+alpha")])
+def test_cpp_batched_rasterize_node_equals_python_node(S, V, cap, mode):
+    """rasterize_gaussians_batched routes the reference's input flavour to the C++ node (csrc/torch_node.cpp, RenderBatchedNode) in all three
+    capacity modes (automatic / explicit / exact): images, radii and gradients equal the Python node's bit for bit -- also on the second and
+    third call of the automatic mode, which are the sync-free ones."""
+    from sigman_release_amd import _cabi, rasterizer as R
+    node = _cabi.torch_node()
+    if node is None:
+        pytest.skip("sgr_torch_node.so not built / SIGMAN_PY_NODE=1")
+    dev = _dev()
+    base, mk, _target = _batched_l1_inputs(dev, S, V)
+    st = mk(cap, True if "depth" in mode else None)
+    node.reset_batched()
+    R._auto_capacity.clear()
+    gsum = torch.randn(S * V, 3, st.image_height, st.image_width, device=dev, generator=torch.Generator(device=dev).manual_seed(2))
+    res = {"python": [], "cpp": []}
+    for rep in range(3):
+        for impl in ("python", "cpp"):
+            d = {k: v.clone().requires_grad_(True) for k, v in base.items()}
+            args = (d["means3D"], None, None, d["rgb"], d["opacity"], None, None, d["cov3D"], st)
+            out = R._RasterizeGaussiansBatched.apply(*args) if impl == "python" else R.rasterize_gaussians_batched(*args)
+            if impl == "cpp":
+                assert type(out[0].grad_fn).__name__ != "_RasterizeGaussiansBatchedBackward", "the call did not reach the C++ node"
+            color, radii, depth, alpha = out
+            total = (color * gsum).sum()
+            if "depth" in mode:
+                total = total + (depth * 0.3).sum() + (alpha * alpha).sum() * 0.2
+            total.backward()
+            torch.cuda.synchronize()
+            res[impl].append([x.detach().clone() for x in (color, radii, depth, alpha)] + [d[k].grad.clone() for k in ("means3D", "rgb", "opacity", "cov3D")])
+    for rep in range(3):
+        for i, (a, b) in enumerate(zip(res["python"][rep], res["cpp"][rep])):
+            assert a.shape == b.shape and torch.equal(a, b), (rep, i)
+        for a, b in zip(res["cpp"][0], res["cpp"][rep]):
+            assert torch.equal(a, b), rep
+    R.check_pending_overflows(True)
+
+
+def test_cpp_batched_rasterize_node_capacity_policy():
+    """Automatic mode: a scene that outgrows the remembered capacity is re-rendered exactly inside the call (never a truncated image, never an
+    error); explicit mode: too small a capacity raises from the backward / at once under no_grad, like the Python node."""
+    from sigman_release_amd import _cabi, rasterizer as R
+    node = _cabi.torch_node()
+    if node is None:
+        pytest.skip("sgr_torch_node.so not built / SIGMAN_PY_NODE=1")
+    dev = _dev()
+    base, mk, _t = _batched_l1_inputs(dev, 1, 2)
+    node.reset_batched()
+    call = lambda d, st: R.rasterize_gaussians_batched(d["means3D"], None, None, d["rgb"], d["opacity"], None, None, d["cov3D"], st)
+    auto = mk(-1)
+    small = {k: (v * 0.35 if k == "cov3D" else v) for k, v in base.items()}                 # smaller splats: fewer tile instances
+    with torch.no_grad():
+        call(small, auto)                                                                  # learns the small scene's capacity
+        exact_big = call(base, mk(0))
+        got_big = call(base, auto)                                                         # does not fit: must come back complete
+        again = call(base, auto)                                                           # now sync-free with the re-learned capacity
+    for a, b, c in zip(exact_big, got_big, again):
+        assert torch.equal(a, b) and torch.equal(a, c)
+    tiny = mk(1000)
+    d = {k: v.clone().requires_grad_(True) for k, v in base.items()}
+    color = call(d, tiny)[0]
+    with pytest.raises(RuntimeError, match="exceeds max_rendered 1000"):
+        color.sum().backward()
+    with torch.no_grad(), pytest.raises(RuntimeError, match="exceeds max_rendered 1000"):
+        call(base, tiny)
+    R.check_pending_overflows(True)
+
+
+def test_cpp_render_node_equals_python_render(monkeypatch):
+    """GaussianRenderer.render through the C++ node (3-NN + covariance + rasterizer + clamp in one autograd node) == the Python path
+    (dist_cuda2, _Cov3D, the Python rasterizer node, torch's clamp): image, alpha and the gradients of all five leaves, bit for bit; bf16
+    leaves get their gradients back in bf16."""
+    from types import SimpleNamespace
+    from sigman_release_amd import _cabi
+    from sigman_release_amd.renderer import GaussianRenderer
+    if _cabi.torch_node() is None:
+        pytest.skip("sgr_torch_node.so not built / SIGMAN_PY_NODE=1")
+    dev = _dev()
+    B, V, P, H, W = 2, 3, 6000, 112, 96
+    subj = [synthetic.humanoid(P, 70 + b) for b in range(B)]
+    host = {k: np.stack([s[k] for s in subj]) for k in ("position", "opacity", "scale", "cov3d", "rgb")}
+    host["rgb"] = host["rgb"] * 1.3 - 0.1                                                  # some colours leave [0, 1]: the clamp and its mask matter
+    cams = [cameras.make_cameras(v) for v in [(30, 37, 65), (45, 0, 85)]]
+    cam = [torch.from_numpy(np.stack([c[i] for c in cams])).to(dev) for i in range(3)]
+    rend = GaussianRenderer(SimpleNamespace(FoVy=cameras.FOVY, output_size_h=H, output_size_w=W))
+    gsum = torch.randn(B, V, 3, H, W, device=dev, generator=torch.Generator(device=dev).manual_seed(4))
+    for dtype in (torch.float32, torch.bfloat16):
+        res = []
+        for impl in ("python", "cpp"):
+            if impl == "python":
+                monkeypatch.setattr(_cabi, "_node", None)
+            else:
+                monkeypatch.undo()
+            g = {k: torch.from_numpy(v).to(dev).to(dtype).requires_grad_(True) for k, v in host.items()}
+            out = rend.render(g, *cam)
+            assert out["image"].shape == (B, V, 3, H, W) and out["alpha"].shape == (B, V, 1, H, W)
+            assert float(out["image"].min()) >= 0.0 and float(out["image"].max()) <= 1.0
+            ((out["image"] * gsum).sum() + (out["alpha"] * 0.1).sum()).backward()
+            torch.cuda.synchronize()
+            for k in g:
+                assert g[k].grad is not None and g[k].grad.dtype == dtype and g[k].grad.shape == g[k].shape, (impl, k)
+            res.append([out["image"].detach().clone(), out["alpha"].detach().clone()] + [g[k].grad.clone() for k in ("position", "opacity", "scale", "cov3d", "rgb")])
+        monkeypatch.undo()
+        for i, (a, b) in enumerate(zip(*res)):
+            assert torch.equal(a, b), (str(dtype), i)
