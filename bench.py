@@ -22,7 +22,8 @@ Configs (BASELINE.json `configs`; subjects are procedural humanoids, sigman_rele
 For N > 1 the exchange is sigman_release_amd/parallel.py: by default what BASELINE.json's north_star names -- replicated
 attributes, RCCL all-reduce of the image-space loss, overlapped with the backward; `--exchange full` adds the attribute
 broadcast and the all-reduce of the attribute gradients -- for c3 ONE broadcast of the [8 * 13 * P] pack (42 MB) and ONE all-reduce of the
-packed gradients + loss per step.  c4 is forward-only and needs no collective.
+packed gradients + loss per step; `--exchange full-pipelined [--pipeline-chunks K]` does the same per chunk of subjects (default: per subject)
+with chunk c+1's broadcast and chunk c's all-reduce in flight while the other chunk is rendered.  c4 is forward-only and needs no collective.
 
 One "step" = one pass of the hot path over one batch (all view slots of this rank in ONE launch chain).  `value` = views/s
 of the whole job with inputs resident in HBM.  The timed step is the rasterizer (+ fused loss): distCUDA2 + get_covariance
@@ -57,9 +58,12 @@ def parse_args(argv=None):
     ap.add_argument("--gaussians", type=int, default=None, help="override the config's Gaussians per subject")
     ap.add_argument("--size", type=int, default=None, help="override the config's image size")
     ap.add_argument("--views-per-step", type=int, default=1, help="c2/c5: views per GPU per step")
-    ap.add_argument("--exchange", choices=("loss", "full"), default="loss",
+    ap.add_argument("--exchange", choices=("loss", "full", "full-pipelined"), default="loss",
                     help="N>1: 'loss' = north_star's protocol (replicated attributes, loss all-reduce overlapped with the backward); "
-                         "'full' = attribute broadcast + all-reduce of gradients and loss (sigman_release_amd/parallel.py)")
+                         "'full' = attribute broadcast + all-reduce of gradients and loss (sigman_release_amd/parallel.py); "
+                         "'full-pipelined' = the same per chunk of subjects, chunk c+1's broadcast and chunk c's all-reduce travelling while "
+                         "the other chunk is rendered (parallel.view_parallel_subjects)")
+    ap.add_argument("--pipeline-chunks", type=int, default=0, help="full-pipelined: pipeline stages per step (default: one per subject)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true", help="skip the unpinned / exact-sync / per-view-loop re-runs (N=1, c2/c3)")
     ap.add_argument("--exact-sync", action="store_true", help="read num_rendered back every step (upstream behaviour) instead of the sync-free capacity mode")
@@ -305,6 +309,38 @@ def main(args):
 
     pending = []          # N > 1, exchange="loss": the previous step's loss all-reduce
 
+    # ---- exchange="full-pipelined": one attribute pack, one settings tuple (with its own sync-free capacity) and one loss function per chunk
+    pipe = None
+    if dist_on and bwd and args.exchange == "full-pipelined" and n_local:
+        K = args.pipeline_chunks or S
+        if S % K:
+            fail(f"--pipeline-chunks {K} does not divide the {S} subjects of {args.config}")
+        Sc = S // K
+        cvc, cvpc, cpc = cameras.make_cameras(mine * Sc)
+        chunk_packs, chunk_fns = [], []
+        for c in range(K):
+            sl = slice(c * Sc, (c + 1) * Sc)
+            st_c = R.BatchedRasterizationSettings(H, W, cameras.TAN_HALF_FOV, cameras.TAN_HALF_FOV, bg, 0.5, t(cvc), t(cvpc), 0, t(cpc), len(mine))
+            if da:
+                st_c = st_c._replace(depth_alpha_grads=True)
+            if not args.exact_sync:
+                with torch.no_grad():
+                    probe = R.forward_debug(subj["means3D"][sl], subj["opacity"][sl], colors_precomp=subj["rgb"][sl], cov3D_precomp=subj["cov3D"][sl], settings=st_c)
+                st_c = st_c._replace(max_rendered=int(probe["num_rendered"] * 1.25) + 4096)
+                del probe
+            gt_c = gt[c * Sc * len(mine): (c + 1) * Sc * len(mine)]
+            gD_c = None if gD is None else gD[c * Sc * len(mine): (c + 1) * Sc * len(mine)]
+            gA_c = None if gA is None else gA[c * Sc * len(mine): (c + 1) * Sc * len(mine)]
+            chunk_packs.append(parallel.pack_attributes(subj["means3D"][sl].reshape(Sc * P, 3), subj["cov3D"][sl].reshape(Sc * P, 6),
+                                                        subj["opacity"][sl].reshape(Sc * P), subj["rgb"][sl].reshape(Sc * P, 3)))
+
+            def fn(m, cv_, o, r, _views, st_c=st_c, gt_c=gt_c, gD_c=gD_c, gA_c=gA_c):
+                spc = lambda x, k: x.reshape(Sc, P, k)
+                out = R.rasterize_l1_loss_batched(spc(m, 3), None, None, spc(r, 3), spc(o, 1), None, None, spc(cv_, 6), st_c, gt_c, None, norm)
+                return (out[0], [out[4], out[5]], [gD_c, gA_c]) if da else out[0]
+            chunk_fns.append(fn)
+        pipe = (chunk_packs, chunk_fns)
+
     def step():
         if not bwd:
             with torch.no_grad():
@@ -327,7 +363,10 @@ def main(args):
                 pending[0].wait()
             pending[:] = [work]
             return loss
-        loss, _grad = parallel.view_parallel_step(packed, all_views, rl, exchange=ex, seed_grad=one, pack_grad=False)
+        if ex == "full-pipelined" and pipe is not None:
+            losses, _grads = parallel.view_parallel_subjects(pipe[0], all_views, pipe[1], seed_grad=one, pipeline=True)
+            return losses.sum()
+        loss, _grad = parallel.view_parallel_step(packed, all_views, rl, exchange="full" if ex == "full-pipelined" else ex, seed_grad=one, pack_grad=False)
         return loss
 
     L = _cabi.lib()

@@ -19,6 +19,12 @@ Two exchange protocols (view_parallel_step(exchange=...)):
   "full"  for callers without a replicated producer: steps 1 + 2 + 3 above (global loss AND global attribute gradient on every
           rank).
 
+Several subjects per step (the reference's batch of 8, configs/training.yaml) in the "full" protocol: `view_parallel_subjects` runs the
+subjects (or chunks of subjects) as a PIPELINE -- the broadcast of chunk c+1 travels while chunk c is rendered, the all-reduce of chunk c's
+gradients while chunk c+1 is rendered -- instead of one blocking broadcast, the render, one blocking all-reduce.  Each chunk has
+its own [n + 1] gradient buffer, so the collectives in flight never alias.  `all_gather_images` is the forward-only counterpart (the
+reference's only cross-rank traffic on rendered images: core/loss/eval.py:81-82 gathers images_pred for the metrics).
+
 The render function is injected, so the sharding/collective logic is testable on CPU with gloo (tests/test_parallel_cpu.py).
 """
 from __future__ import annotations
@@ -122,3 +128,86 @@ def view_parallel_step(packed: torch.Tensor, view_ids: Sequence[int], render_los
     if world > 1:
         dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)     # gradients [13*P] + loss scalar: one collective
     return buf[-1], buf[:-1]
+
+
+def view_parallel_subjects(chunks: Sequence[torch.Tensor], view_ids: Sequence[int], render_loss, *, srcs: Sequence[int] = None, group=None,
+                           pipeline: bool = True, seed_grad: torch.Tensor = None):
+    """exchange="full" for a step of several subjects, pipelined over chunks of subjects.
+
+    chunks      flat attribute buffers, one per pipeline stage (one subject's [13*P] pack, or several subjects packed by the caller);
+                chunk c needs valid contents on rank srcs[c] only (default: every chunk comes from rank 0)
+    view_ids    the views of a subject (the same for every chunk); rank r renders {v : index(v) mod world = r} of every chunk
+    render_loss callable (means3D, cov3D, opacity, rgb, my_view_ids) -> loss | (loss, extra_outputs, extra_grads) as in view_parallel_step,
+                or a sequence of one callable per chunk (each with its own targets); the four attribute views are those of
+                unpack_attributes(chunk): a caller that packed several subjects reshapes them itself
+    pipeline    True: chunk c+1's broadcast is issued before chunk c is rendered and waited for after it; chunk c's gradient all-reduce is
+                issued right behind its backward and waited for at the end.  With RCCL the collectives run on the backend's own stream
+                (work.wait() makes the compute stream wait, never the host), i.e. the broadcast overlaps the previous chunk's kernels and the
+                all-reduce the next chunk's; the first broadcast and the last all-reduce of a step stay exposed.
+                False: the same collectives, blocking, in program order -- the same numbers bit for bit (tests).
+    -> (losses [n_chunks] tensor, [global gradient of chunk c, flat like chunk c] list)
+    """
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    n = len(chunks)
+    srcs = [0] * n if srcs is None else list(srcs)
+    fns = list(render_loss) if isinstance(render_loss, (list, tuple)) else [render_loss] * n
+    mine = [view_ids[i] for i in shard_views(len(view_ids), rank, world)]
+    bwork = [None] * n
+    rwork = [None] * n
+    bufs = [None] * n
+
+    def start_broadcast(c):
+        if world > 1:
+            bwork[c] = dist.broadcast(chunks[c], src=srcs[c], group=group, async_op=pipeline)
+
+    if n:
+        start_broadcast(0)
+    for c in range(n):
+        if pipeline and c + 1 < n:
+            start_broadcast(c + 1)                       # travels while chunk c is rendered
+        if bwork[c] is not None:
+            bwork[c].wait()
+        leaves = [x.detach().requires_grad_(True) for x in unpack_attributes(chunks[c])]
+        if mine:
+            loss, extra_out, extra_grad = _split(fns[c](*leaves, mine))
+            _backward(loss, seed_grad, extra_out, extra_grad)
+            bufs[c] = torch.cat([(l.grad if l.grad is not None else torch.zeros_like(l)).reshape(-1) for l in leaves]
+                                + [loss.detach().reshape(1).to(chunks[c].dtype)])
+        else:
+            bufs[c] = torch.zeros(chunks[c].numel() + 1, device=chunks[c].device, dtype=chunks[c].dtype)
+        if world > 1:
+            rwork[c] = dist.all_reduce(bufs[c], op=dist.ReduceOp.SUM, group=group, async_op=pipeline)   # travels while chunk c+1 is rendered
+        if not pipeline and c + 1 < n:
+            start_broadcast(c + 1)
+    for w in rwork:
+        if w is not None:
+            w.wait()
+    if not n:
+        return torch.zeros(0), []
+    return torch.stack([b[-1] for b in bufs]), [b[:-1] for b in bufs]
+
+
+def all_gather_images(local: torch.Tensor, n_views: int, group=None) -> torch.Tensor:
+    """Forward-only / evaluation path: every rank rendered its shard {v : v mod world = rank} of n_views views (`local` [n_mine, ...] in
+    that order); returns all views [n_views, ...] in view order on every rank (core/loss/eval.py:81-82 gathers the predicted images for
+    PSNR / SSIM / LPIPS).  One collective: the shards are padded to ceil(n_views / world) views (90 views on 8 ranks: 11 or 12 each)."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    n_mine = len(shard_views(n_views, rank, world))
+    if local.shape[0] != n_mine:
+        raise ValueError(f"rank {rank} of {world} holds {local.shape[0]} views, its shard of {n_views} views has {n_mine}")
+    if world == 1:
+        return local
+    per = (n_views + world - 1) // world
+    pad = local if n_mine == per else torch.cat([local, local.new_zeros((per - n_mine,) + tuple(local.shape[1:]))])
+    out = local.new_empty((world, per) + tuple(local.shape[1:]))
+    try:
+        dist.all_gather_into_tensor(out.view((world * per,) + tuple(local.shape[1:])), pad.contiguous(), group=group)
+    except (RuntimeError, NotImplementedError):          # a backend without the flat form: the list form, then the same layout
+        parts = [torch.empty_like(pad) for _ in range(world)]
+        dist.all_gather(parts, pad.contiguous(), group=group)
+        out = torch.stack(parts)
+    # view v was rendered by rank v mod world as its (v // world)-th view
+    idx = torch.arange(n_views, device=local.device)
+    return out[idx % world, idx // world]

@@ -126,7 +126,7 @@ def test_bench_rccl_path_with_one_rank():
     test box cannot hold two RCCL ranks, but every call the 8-GPU run makes is made here."""
     import json
     import subprocess
-    for config, exchange, steps in (("c2", "loss", 20), ("c2", "full", 20), ("c3", "full", 3), ("c3", "loss", 3), ("c5", "full", 5), ("c4", "loss", 2)):
+    for config, exchange, steps in (("c2", "loss", 20), ("c2", "full", 20), ("c3", "full", 3), ("c3", "full-pipelined", 3), ("c3", "loss", 3), ("c5", "full", 5), ("c4", "loss", 2)):
         s = socket.socket()
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -146,3 +146,113 @@ def test_bench_rccl_path_with_one_rank():
         assert out["config"]["parallelism"] == f"view-parallel x1 (nccl), exchange={want}", out["config"]["parallelism"]
         assert out["config"]["name"] == config
         assert out["value"] > 0 and out["roofline"]["frac"] > 0
+
+
+# ---- several subjects per step: the pipelined "full" exchange with the real HIP node
+PS, PP, PH = 4, 6_000, 192           # 4 subjects = 4 pipeline stages
+
+
+def _pipe_problem(dev):
+    from sigman_release_amd import cameras, parallel, synthetic
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    chunks = []
+    for s in range(PS):
+        g = synthetic.humanoid(PP, 50 + s)
+        chunks.append(parallel.pack_attributes(t(g["position"]), t(synthetic.covariance_from_gaussians(g)), t(g["opacity"].reshape(PP)), t(g["rgb"])))
+    gt = torch.rand(PS, len(VIEWS), 3, PH, PH, generator=torch.Generator().manual_seed(13)).to(dev)
+    norm = 1.0 / (PS * len(VIEWS) * 3 * PH * PH)
+
+    def make(s):
+        from sigman_release_amd import rasterizer as R
+
+        def render_loss(means3D, cov3D, opacity, rgb, view_ids):
+            cv, cvp, cp = cameras.make_cameras(list(view_ids))
+            st = R.BatchedRasterizationSettings(PH, PH, cameras.TAN_HALF_FOV, cameras.TAN_HALF_FOV, torch.ones(3, device=dev), 1.0, t(cv), t(cvp), 0,
+                                                t(cp), len(view_ids), False, -1)
+            idx = [VIEWS.index(v) for v in view_ids]
+            return R.rasterize_l1_loss_batched(means3D[None], None, None, rgb[None], opacity[None], None, None, cov3D[None], st, gt[s, idx], None, norm)[0]
+        return render_loss
+    return chunks, [make(s) for s in range(PS)]
+
+
+def _pipe_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from sigman_release_amd import parallel
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(0)
+        truth, fns = _pipe_problem(dev)
+        srcs = [0, 1, 0, 1]
+        out = {}
+        for pipeline in (False, True):
+            chunks = [c.clone() if rank == srcs[i] else torch.zeros_like(c) for i, c in enumerate(truth)]
+            for rep in range(2):
+                losses, grads = parallel.view_parallel_subjects(chunks, list(VIEWS), fns, srcs=srcs, pipeline=pipeline)
+            torch.cuda.synchronize()
+            out[pipeline] = (losses.cpu().numpy(), [g.cpu().numpy() for g in grads])
+        # forward-only path: every rank renders its views of subject 0, the images are gathered in view order
+        from sigman_release_amd import cameras, rasterizer as R
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        mine = [VIEWS[i] for i in parallel.shard_views(len(VIEWS), rank, world)]
+        cv, cvp, cp = cameras.make_cameras(mine)
+        st = R.BatchedRasterizationSettings(PH, PH, cameras.TAN_HALF_FOV, cameras.TAN_HALF_FOV, torch.ones(3, device=dev), 1.0, t(cv), t(cvp), 0, t(cp),
+                                            len(mine), False, -1)
+        m, c, o, r = parallel.unpack_attributes(truth[0])
+        with torch.no_grad():
+            local = R.rasterize_gaussians_batched(m[None], None, None, r[None], o[None], None, None, c[None], st)[0]
+            allv = parallel.all_gather_images(local, len(VIEWS))
+        q.put((rank, out, allv.cpu().numpy()))
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_two_ranks_pipelined_subject_exchange_bitwise_equals_blocking():
+    """parallel.view_parallel_subjects with the real fused rasterize + L1 node: 4 subjects (producers alternate between the ranks), 5 views
+    sharded over 2 ranks.  Pipelined (async broadcast of subject s+1 under the render of s, async all-reduce of s under the render of s+1)
+    == blocking: every gradient BITWISE (the loss values to the order of the loss kernel's float atomics), on both ranks; both match the
+    single-process run; the gathered forward-only images equal a single-process render of all views."""
+    from sigman_release_amd import cameras, parallel, rasterizer as R
+    dev = torch.device("cuda", 0)
+    truth, fns = _pipe_problem(dev)
+    want = parallel.view_parallel_subjects([c.clone() for c in truth], list(VIEWS), fns)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    cv, cvp, cp = cameras.make_cameras(list(VIEWS))
+    st = R.BatchedRasterizationSettings(PH, PH, cameras.TAN_HALF_FOV, cameras.TAN_HALF_FOV, torch.ones(3, device=dev), 1.0, t(cv), t(cvp), 0, t(cp),
+                                        len(VIEWS), False, -1)
+    m, c, o, r = parallel.unpack_attributes(truth[0])
+    with torch.no_grad():
+        images = R.rasterize_gaussians_batched(m[None], None, None, r[None], o[None], None, None, c[None], st)[0].cpu().numpy()
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_pipe_worker, args=(r_, 2, port, q)) for r_ in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(2):
+        rank, out, allv = q.get(timeout=600)
+        res[rank] = (out, allv)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank in range(2):
+        out, allv = res[rank]
+        # (the loss VALUE is a sum of float atomics over the pixels in the fused loss kernel: equal up to the order of the additions, run to run;
+        # the gradients have no such freedom)
+        np.testing.assert_allclose(out[True][0], out[False][0], rtol=1e-6)
+        for a, b in zip(out[True][1], out[False][1]):
+            np.testing.assert_array_equal(a, b)
+        np.testing.assert_allclose(out[True][0], want[0].cpu().numpy(), rtol=1e-6)
+        for s_ in range(PS):
+            g = want[1][s_].cpu().numpy()
+            assert np.abs(out[True][1][s_] - g).max() <= 1e-5 * np.abs(g).max()
+        np.testing.assert_array_equal(allv, images)                       # single-view renders of a batch == the batched render, bit for bit
+    for s_ in range(PS):
+        np.testing.assert_array_equal(res[0][0][True][1][s_], res[1][0][True][1][s_])

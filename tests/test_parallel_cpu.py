@@ -134,3 +134,70 @@ def test_bench_refuses_to_report_fewer_ranks_than_asked():
     r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "0"], capture_output=True, text=True,
                         timeout=600, env=env2)
     assert r2.returncode != 0 and '"n_gpus"' not in r2.stdout
+
+
+# ---- several subjects per step: the pipelined "full" exchange and the image gather (world-size-2 gloo, a cheap analytic "renderer")
+_PV = [30, 37, 45, 53, 65]
+
+
+def _toy_render_loss(chunk):
+    """A differentiable stand-in with the renderer's interface: depends on the view ids, on every attribute and on the chunk."""
+    def render_loss(m, c, o, r, my_views):
+        total = 0.0
+        for v in my_views:
+            w = 1.0 + 0.01 * v + 0.1 * chunk
+            total = total + (torch.sin(m * w).sum() + (c * c).sum() * w + (o * r.sum(1, keepdim=True)).sum() * (w - 0.5)) / (len(_PV) * m.shape[0])
+        return total
+    return render_loss
+
+
+def _pipe_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    S, P = 4, 50
+    gen = torch.Generator().manual_seed(11)
+    truth = [torch.randn(13 * P, generator=gen) for _ in range(S)]
+    srcs = [0, 1, 1, 0]                                                        # producers differ per subject
+    fns = [_toy_render_loss(c) for c in range(S)]
+    out = {}
+    for pipeline in (False, True):
+        chunks = [t.clone() if rank == srcs[c] else torch.zeros_like(t) for c, t in enumerate(truth)]
+        for _ in range(2):                                                     # twice: the second step starts from broadcast contents
+            losses, grads = parallel.view_parallel_subjects(chunks, _PV, fns, srcs=srcs, pipeline=pipeline)
+        out[pipeline] = (losses.clone(), [g.clone() for g in grads], [c.clone() for c in chunks])
+    assert torch.equal(out[True][0], out[False][0])
+    assert all(torch.equal(a, b) for a, b in zip(out[True][1], out[False][1]))
+    assert all(torch.equal(a, t) for a, t in zip(out[True][2], truth))          # every rank ends up holding every subject's attributes
+    # image gather: rank r "rendered" views {v : v mod world = r} of 5 views; every rank gets all 5 in view order
+    mine = parallel.shard_views(5, rank, world)
+    local = torch.stack([torch.full((3, 4, 6), float(v)) for v in mine])
+    allv = parallel.all_gather_images(local, 5)
+    assert allv.shape == (5, 3, 4, 6) and all(float(allv[v].mean()) == float(v) for v in range(5))
+    q.put((rank, out[True][0].numpy(), [g.numpy() for g in out[True][1]]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_pipelined_subject_exchange_matches_blocking_and_single_process():
+    """view_parallel_subjects: 4 subjects from different producer ranks, 5 views sharded over 2 ranks; pipelined == blocking bit for bit on
+    every rank, and both equal the single-process loss / gradient of every subject; all_gather_images returns the views in view order."""
+    S, P = 4, 50
+    gen = torch.Generator().manual_seed(11)
+    truth = [torch.randn(13 * P, generator=gen) for _ in range(S)]
+    want = parallel.view_parallel_subjects([t.clone() for t in truth], _PV, [_toy_render_loss(c) for c in range(S)])
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_pipe_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    res = [q.get(timeout=300) for _ in range(2)]
+    [p.join(timeout=60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    for rank, losses, grads in res:
+        np.testing.assert_allclose(losses, want[0].numpy(), rtol=1e-5)
+        for c in range(S):
+            np.testing.assert_allclose(grads[c], want[1][c].numpy(), atol=1e-6 * np.abs(want[1][c].numpy()).max())
+    np.testing.assert_array_equal(res[0][1], res[1][1])
+    for c in range(S):
+        np.testing.assert_array_equal(res[0][2][c], res[1][2][c])              # all-reduced: identical on both ranks
