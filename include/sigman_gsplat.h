@@ -65,6 +65,12 @@ typedef struct SgrProblem {
     const float *projmatrix;        /* [n_views,16] */
     const float *campos;            /* [n_views,3]  */
     const float *bg;                /* [3] */
+    /* optional (ABI v6): the clamp of the reference's caller (rendered_image.clamp(0, 1), gs.py:107) folded into the compositing kernels */
+    float *color_clamped;           /* [n_views,3,H,W] or NULL.  Forward: clamp(colour, 0, 1) is ALSO written here (out_color stays unclamped:
+                                       the backward starts from it) */
+    int32_t clamp_grad;             /* backward: != 0 -> grad_color is dL/d(clamped colour): it passes where 0 <= colour <= 1 (torch.clamp's
+                                       inclusive mask) and is dropped elsewhere; needs the bucket backward (with_aux) */
+    int32_t reserved0;
 } SgrProblem;
 
 /*

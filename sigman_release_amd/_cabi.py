@@ -24,6 +24,7 @@ class SgrProblem(C.Structure):
         ("means3D", C.c_void_p), ("opacities", C.c_void_p), ("colors_precomp", C.c_void_p), ("shs", C.c_void_p),
         ("cov3D_precomp", C.c_void_p), ("scales", C.c_void_p), ("rotations", C.c_void_p),
         ("viewmatrix", C.c_void_p), ("projmatrix", C.c_void_p), ("campos", C.c_void_p), ("bg", C.c_void_p),
+        ("color_clamped", C.c_void_p), ("clamp_grad", C.c_int32), ("reserved0", C.c_int32),      # optional: zero when not given
     ]
 
 

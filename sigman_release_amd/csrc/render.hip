@@ -68,6 +68,7 @@ struct FwdAux {
     uint2 *desc;          // [4*NS]  (global tile id | (rps - 1) << 30, (start << 7) | count): `count` (<= 64) survivors starting at ordinal `start`
                           //          (a multiple of 64) of the (tile, quadrant) list; count == 0 -> slot unused
     uint32_t R, NS;
+    float *clamped;       // optional [n_views,3,H,W]: clamp(colour, 0, 1) next to the unclamped colours (SgrProblem.color_clamped: gs.py:107 folded in)
 };
 
 // -------------------------------------------------------------------------------------------------
@@ -212,9 +213,15 @@ __global__ __launch_bounds__(kBlock) void render_fwd_kernel(int W, int H, int Tx
         const size_t vb = (size_t)view * hw;
         final_T[vb + pix] = T;
         n_contrib[vb + pix] = last;
-        out_color[(vb * 3) + pix] = C0 + T * bg[0];
-        out_color[(vb * 3) + hw + pix] = C1 + T * bg[1];
-        out_color[(vb * 3) + 2 * hw + pix] = C2 + T * bg[2];
+        const float o0 = C0 + T * bg[0], o1 = C1 + T * bg[1], o2 = C2 + T * bg[2];
+        out_color[(vb * 3) + pix] = o0;
+        out_color[(vb * 3) + hw + pix] = o1;
+        out_color[(vb * 3) + 2 * hw + pix] = o2;
+        if (aux.clamped) {
+            aux.clamped[(vb * 3) + pix] = fminf(fmaxf(o0, 0.f), 1.f);
+            aux.clamped[(vb * 3) + hw + pix] = fminf(fmaxf(o1, 0.f), 1.f);
+            aux.clamped[(vb * 3) + 2 * hw + pix] = fminf(fmaxf(o2, 0.f), 1.f);
+        }
         out_depth[vb + pix] = D;
         out_alpha[vb + pix] = A;
     }
@@ -380,9 +387,15 @@ __global__ __launch_bounds__(64) void render_fwd_wave_kernel(int W, int H, int T
         const size_t vb = (size_t)view * hw;
         final_T[vb + pix] = T;
         n_contrib[vb + pix] = last;
-        out_color[(vb * 3) + pix] = C0 + T * bg[0];
-        out_color[(vb * 3) + hw + pix] = C1 + T * bg[1];
-        out_color[(vb * 3) + 2 * hw + pix] = C2 + T * bg[2];
+        const float o0 = C0 + T * bg[0], o1 = C1 + T * bg[1], o2 = C2 + T * bg[2];
+        out_color[(vb * 3) + pix] = o0;
+        out_color[(vb * 3) + hw + pix] = o1;
+        out_color[(vb * 3) + 2 * hw + pix] = o2;
+        if (aux.clamped) {
+            aux.clamped[(vb * 3) + pix] = fminf(fmaxf(o0, 0.f), 1.f);
+            aux.clamped[(vb * 3) + hw + pix] = fminf(fmaxf(o1, 0.f), 1.f);
+            aux.clamped[(vb * 3) + 2 * hw + pix] = fminf(fmaxf(o2, 0.f), 1.f);
+        }
         out_depth[vb + pix] = D;
         out_alpha[vb + pix] = A;
     }
@@ -677,9 +690,15 @@ __global__ __launch_bounds__(kSegThreads, 4) void render_fwd_seg_kernel(int W, i
         const size_t vb = (size_t)view * hw;
         final_T[vb + pix] = Tf;
         n_contrib[vb + pix] = lmax;
-        out_color[(vb * 3) + pix] = r0 + Tf * bg[0];
-        out_color[(vb * 3) + hw + pix] = r1 + Tf * bg[1];
-        out_color[(vb * 3) + 2 * hw + pix] = r2 + Tf * bg[2];
+        const float o0 = r0 + Tf * bg[0], o1 = r1 + Tf * bg[1], o2 = r2 + Tf * bg[2];
+        out_color[(vb * 3) + pix] = o0;
+        out_color[(vb * 3) + hw + pix] = o1;
+        out_color[(vb * 3) + 2 * hw + pix] = o2;
+        if (aux.clamped) {
+            aux.clamped[(vb * 3) + pix] = fminf(fmaxf(o0, 0.f), 1.f);
+            aux.clamped[(vb * 3) + hw + pix] = fminf(fmaxf(o1, 0.f), 1.f);
+            aux.clamped[(vb * 3) + 2 * hw + pix] = fminf(fmaxf(o2, 0.f), 1.f);
+        }
         out_depth[vb + pix] = rD;
         out_alpha[vb + pix] = rA;
     }
@@ -881,7 +900,7 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64) void render_bwd_bucket_kernel(int
                                                                    const float *__restrict__ out_alpha,
                                                                    const float *__restrict__ gC, const float *__restrict__ gD,
                                                                    const float *__restrict__ gA, const float *__restrict__ gscale,
-                                                                   FwdAux aux, float4 *__restrict__ part, uint8_t *__restrict__ flags) {
+                                                                   FwdAux aux, float4 *__restrict__ part, uint8_t *__restrict__ flags, int clamp_grad) {
     // !SPLIT (batches of views): ONE wave = one bucket per workgroup.  Most bucket slots of a launch are unused (the slot count is an upper
     // bound from the list lengths: 78 % empty at C3); with four buckets per workgroup a workgroup usually held one real wave and 16 KB of
     // LDS until it was done, which capped a CU at ~10 working waves.
@@ -951,8 +970,12 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64) void render_bwd_bucket_kernel(int
         {
             const float gs = gscale ? *gscale : 1.f;          // optional device scalar on dL/dcolor
             g0 = gs * gC[vb * 3 + pix]; g1 = gs * gC[vb * 3 + hw + pix]; g2 = gs * gC[vb * 3 + 2 * hw + pix];
+            const float c0 = out_color[vb * 3 + pix], c1 = out_color[vb * 3 + hw + pix], c2 = out_color[vb * 3 + 2 * hw + pix];
+            if (clamp_grad) {        // the upstream gradient is w.r.t. clamp(colour, 0, 1) (gs.py:107): torch.clamp's backward, inclusive mask
+                g0 = (c0 >= 0.f && c0 <= 1.f) ? g0 : 0.f; g1 = (c1 >= 0.f && c1 <= 1.f) ? g1 : 0.f; g2 = (c2 >= 0.f && c2 <= 1.f) ? g2 : 0.f;
+            }
             // O = out . g: everything the pixel composited (incl. the T_final*bg term), dotted with the upstream gradient
-            O = sgr_dot3(out_color[vb * 3 + pix], g0, out_color[vb * 3 + hw + pix], g1, out_color[vb * 3 + 2 * hw + pix], g2);
+            O = sgr_dot3(c0, g0, c1, g1, c2, g2);
             if (HAS_DA) {
                 if (gD) gd = gD[vb + pix];
                 if (gA) ga = gA[vb + pix];
@@ -1145,10 +1168,11 @@ int sgr_aux_layout_for(uint64_t NS) {
     return 4 * NS * 4 * 64 * 24 > limit ? 1 : 2;
 }
 
-static FwdAux make_aux(void *compact, void *ckpt_tc, void *ckpt_da, void *desc, uint64_t R, uint64_t tiles_total) {
+static FwdAux make_aux(void *compact, void *ckpt_tc, void *ckpt_da, void *desc, uint64_t R, uint64_t tiles_total, float *clamped = nullptr) {
     FwdAux a;
     a.compact = (uint2 *)compact; a.ckpt_tc = (float4 *)ckpt_tc; a.ckpt_da = (float2 *)ckpt_da; a.desc = (uint2 *)desc;
     a.R = (uint32_t)R; a.NS = (uint32_t)sgr_bucket_slots(R, tiles_total);
+    a.clamped = clamped;
     return a;
 }
 
@@ -1181,7 +1205,7 @@ int sgr_render_forward_ex(const SgrProblem *pb, const uint32_t *ranges, const ui
     // aux_ckpt_da == NULL: no depth/alpha checkpoints; aux_ckpt_tc == NULL (and aux_ckpt_da given): the pass that adds them later
     const bool use_aux = aux_compact && (aux_ckpt_tc || aux_ckpt_da) && aux_desc;
     const bool da_pass = use_aux && !aux_ckpt_tc;
-    FwdAux aux = make_aux(aux_compact, aux_ckpt_tc, aux_ckpt_da, aux_desc, R, (uint64_t)tiles * pb->n_views);
+    FwdAux aux = make_aux(aux_compact, aux_ckpt_tc, aux_ckpt_da, aux_desc, R, (uint64_t)tiles * pb->n_views, da_pass ? nullptr : pb->color_clamped);
     const uint64_t tiles_total = (uint64_t)tiles * pb->n_views;
     if (use_aux && tiles_total >= (1ull << 30)) { sgr_set_error("too many tiles (%llu) for the bucket descriptors", (unsigned long long)tiles_total); return 1; }
     // few workgroups (one or two 512^2 views): trade 1.5x arithmetic for an 8x shorter dependency chain
@@ -1271,7 +1295,7 @@ int sgr_render_backward_ex(const SgrProblem *pb, const uint32_t *ranges, const u
 #define SGR_LAUNCH_BWD(DA, SP, RW)                                                                                          \
         hipLaunchKernelGGL((render_bwd_bucket_kernel<DA, SP, RW>), dim3(nblocks), dim3(SP ? 128 : 64), 0, stream, pb->W, pb->H, Tx, tiles, \
                            (const uint2 *)ranges, (const float4 *)rec, (const uint4 *)rect, n_contrib, out_color, out_depth, out_alpha, grad_color, \
-                           grad_depth, grad_alpha, grad_color_scale, aux, (float4 *)part, (uint8_t *)flags)
+                           grad_depth, grad_alpha, grad_color_scale, aux, (float4 *)part, (uint8_t *)flags, pb->clamp_grad)
         const bool da = grad_depth || grad_alpha, rows = aux_layout == 2;
         if (rows) {
             if (split && da) SGR_LAUNCH_BWD(true, true, true); else if (split) SGR_LAUNCH_BWD(false, true, true);
@@ -1284,6 +1308,7 @@ int sgr_render_backward_ex(const SgrProblem *pb, const uint32_t *ranges, const u
         SGR_CHECK_LAUNCH("render_bwd_bucket_kernel");
         return 0;
     }
+    if (pb->clamp_grad) { sgr_set_error("sgr_render_backward: SgrProblem.clamp_grad needs the bucket backward (a forward run with auxiliary outputs)"); return 1; }
     hipLaunchKernelGGL(render_bwd_kernel, dim3(tiles * pb->n_views), dim3(kBlock), 0, stream, pb->W, pb->H, Tx, tiles,
                        (const uint2 *)ranges, point_list, (const float4 *)rec, pb->bg, final_T, n_contrib, grad_color, grad_depth,
                        grad_alpha, grad_color_scale, grec);

@@ -203,6 +203,7 @@ SgrProblem make_problem(int64_t P, int64_t H, int64_t W, int64_t sh_degree, int6
                         const Tensor &opac, const Tensor &colors, const Tensor &sh, const Tensor &cov, const Tensor &scales, const Tensor &rot,
                         const Tensor &vm, const Tensor &pm, const Tensor &campos, const Tensor &bg) {
     SgrProblem pb;
+    memset(&pb, 0, sizeof(pb));                                     // (optional fields: color_clamped / clamp_grad off)
     pb.P = (int32_t)P; pb.n_views = 1; pb.views_per_subject = 1; pb.H = (int32_t)H; pb.W = (int32_t)W; pb.sh_degree = (int32_t)sh_degree; pb.M = (int32_t)M;
     pb.tanfovx = (float)tfx; pb.tanfovy = (float)tfy; pb.scale_modifier = (float)smod;
     pb.means3D = fptr(means3D); pb.opacities = fptr(opac); pb.colors_precomp = fptr(colors); pb.shs = fptr(sh); pb.cov3D_precomp = fptr(cov);
@@ -695,7 +696,7 @@ struct RenderBatchedNode : public torch::autograd::Function<RenderBatchedNode> {
             dist2 = at::empty({S, P}, f32);
             cov = at::empty({S, P, 6}, f32);
             if (P > 0) {
-                const int64_t mc = std::min<int64_t>(1 << 21, std::max<int64_t>(16 * P, 4096));
+                const int64_t mc = std::min<int64_t>((1 << 22) - 1, std::max<int64_t>(16 * P, 4096));      // (renderer.py: _KNN_MAX_CELLS)
                 const uint64_t stride = ((uint64_t)sgr_knn_workspace_bytes((int32_t)P, (int32_t)mc) + 255) / 256 * 256;
                 Tensor ws = at::empty({(int64_t)(stride * (uint64_t)S)}, f32.dtype(at::kByte));
                 check_status(sgr_knn_dist2_batched((int32_t)S, (int32_t)P, means3D.data_ptr<float>(), dist2.data_ptr<float>(), ws.data_ptr(), stride * (uint64_t)S,
@@ -714,12 +715,12 @@ struct RenderBatchedNode : public torch::autograd::Function<RenderBatchedNode> {
         pb.n_views = (int32_t)nv; pb.views_per_subject = (int32_t)vps;
         const int with_aux = wants_grad ? (da_grads ? 1 : 3) : 0;
         BatchedFwd fw;
-        batched_forward(pb, dev, P, nv, H, W, with_aux, capacity_req, wants_grad, color, depth, alpha, radii, stream, fw);
         Tensor image = color;
-        if (mode == 1) {                                             // gs.py:107; the unclamped colours stay behind for the backward
+        if (mode == 1) {                 // gs.py:107: the compositing kernel writes clamp(colour, 0, 1) next to the unclamped colours, which stay behind for the backward
             image = at::empty_like(color);
-            check_status(sgr_clamp01_forward((uint64_t)color.numel(), color.data_ptr<float>(), image.data_ptr<float>(), stream), "sgr_clamp01_forward");
+            pb.color_clamped = image.data_ptr<float>();
         }
+        batched_forward(pb, dev, P, nv, H, W, with_aux, capacity_req, wants_grad, color, depth, alpha, radii, stream, fw);
         ctx->set_materialize_grads(false);
         ctx->mark_non_differentiable({radii});
         Tensor st_bytes = at::empty({(int64_t)sizeof(SgrForwardState)}, at::TensorOptions().dtype(at::kByte));
@@ -747,17 +748,12 @@ struct RenderBatchedNode : public torch::autograd::Function<RenderBatchedNode> {
         memcpy(&st, ctx->saved_data["st"].toTensor().data_ptr(), sizeof(st));
         const auto f32 = at::TensorOptions().dtype(at::kFloat).device(dev);
         hipStream_t stream = c10::hip::getCurrentHIPStream(dev.index()).stream();
-        Tensor gC;
-        if (!grads[0].defined()) gC = at::zeros({nv, 3, H, W}, f32);
-        else if (mode == 1) {                                        // clamp's backward: the gradient passes where 0 <= colour <= 1
-            const Tensor g = f32c(grads[0]);
-            gC = at::empty({nv, 3, H, W}, f32);
-            check_status(sgr_clamp01_backward((uint64_t)color.numel(), color.data_ptr<float>(), g.data_ptr<float>(), gC.data_ptr<float>(), stream), "sgr_clamp01_backward");
-        } else gC = f32c(grads[0]);
+        Tensor gC = grads[0].defined() ? f32c(grads[0]) : at::zeros({nv, 3, H, W}, f32);
         Tensor gD = grads[2].defined() ? f32c(grads[2]) : Tensor(), gA = grads[3].defined() ? f32c(grads[3]) : Tensor();
         Tensor d_means3D = at::empty({S, P, 3}, f32), d_op = at::empty({S, P}, f32), d_cov = at::empty({S, P, 6}, f32), d_col = at::empty({S, P, 3}, f32);
         SgrProblem pb = make_problem(P, H, W, 0, 0, scal[0], scal[1], scal[2], means3D, opac, colors, Tensor(), cov, Tensor(), Tensor(), vm, pm, campos, bg);
         pb.n_views = (int32_t)nv; pb.views_per_subject = (int32_t)vps;
+        pb.clamp_grad = mode == 1 ? 1 : 0;     // render(): the upstream gradient is w.r.t. the clamped image; the compositing backward applies clamp's mask itself
         AllocCtx ac;
         ac.dev = dev;
         auto mp = [](const Tensor &t) -> float * { return (t.defined() && t.numel() > 0) ? t.data_ptr<float>() : nullptr; };

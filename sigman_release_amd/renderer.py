@@ -19,7 +19,7 @@ import torch
 from . import _cabi
 from .rasterizer import BatchedRasterizationSettings, _f32c, _ptr, _stream, rasterize_gaussians_batched
 
-_KNN_MAX_CELLS = 1 << 21      # upper bound of the uniform grid; the grid actually used is bounded by 16 cells per point
+_KNN_MAX_CELLS = (1 << 22) - 1      # upper bound of the uniform grid; the grid actually used is bounded by 16 cells per point
 
 
 def dist_cuda2(points: torch.Tensor) -> torch.Tensor:
