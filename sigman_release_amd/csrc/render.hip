@@ -468,6 +468,29 @@ __global__ __launch_bounds__(kSegThreads, 4) void render_fwd_seg_kernel(int W, i
     const float qx0 = (float)(tx * 16 + (q & 1u) * 8), qy0 = (float)(ty * 16 + (q >> 1) * 8);
     const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     const int n = (int)(range.y - range.x);
+    if (n == 0) {
+        // An empty tile (812 of the 1024 tiles of a 512^2 humanoid view) only receives the background.  Its quadrant 0 workgroup writes all
+        // 256 pixels, the other three leave at once: these workgroups are dispatched behind the working ones and each holds a full
+        // workgroup's registers and LDS while it lives -- four of them per empty tile, each walking through the whole kernel with 64 of its
+        // 512 threads writing, were 5 of the kernel's 53 us at C2.  (Workgroup-uniform exit in front of the first barrier.)
+        if (q != 0u || (AUX && !aux.ckpt_tc) || t >= 256) return;
+        const int bx = (int)tx * 16 + (t & 15), by = (int)ty * 16 + (t >> 4);
+        if (bx < W && by < H) {
+            const size_t hw = (size_t)H * W, pix = (size_t)by * W + bx, vb = (size_t)view * hw;
+            const float b0 = bg[0], b1 = bg[1], b2 = bg[2];
+            final_T[vb + pix] = 1.f;
+            n_contrib[vb + pix] = 0u;
+            out_color[(vb * 3) + pix] = b0; out_color[(vb * 3) + hw + pix] = b1; out_color[(vb * 3) + 2 * hw + pix] = b2;
+            if (aux.clamped) {
+                aux.clamped[(vb * 3) + pix] = fminf(fmaxf(b0, 0.f), 1.f);
+                aux.clamped[(vb * 3) + hw + pix] = fminf(fmaxf(b1, 0.f), 1.f);
+                aux.clamped[(vb * 3) + 2 * hw + pix] = fminf(fmaxf(b2, 0.f), 1.f);
+            }
+            out_depth[vb + pix] = 0.f;
+            out_alpha[vb + pix] = 0.f;
+        }
+        return;
+    }
     float C0 = 0.f, C1 = 0.f, C2 = 0.f, D = 0.f, A = 0.f;      // this wave's share of the pixel sums
     float Tcarry = 1.f;                                         // identical in all 8 waves
     float cc0 = 0.f, cc1 = 0.f, cc2 = 0.f, ccD = 0.f, ccA = 0.f;   // composited-so-far (all waves), AUX only
