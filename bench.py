@@ -127,10 +127,11 @@ def _choose_host_cores(step, sync_all, t_step):
         return "not pinned (SIGMAN_NO_PIN=1)"
     base = sorted(os.sched_getaffinity(0))
     cands = [("cores %s" % base, set(base))]
-    for off in (8, 16):                                         # the same quad one / two CCXs further
-        alt = {c + off for c in base}
-        if alt <= _ORIG_AFFINITY:
-            cands.append(("cores %s" % sorted(alt), alt))
+    if not dist.is_initialized():                               # (N > 1: the same two options on every rank -- the trial times are all-reduced)
+        for off in (8, 16):                                     # the same quad one / two CCXs further
+            alt = {c + off for c in base}
+            if alt <= _ORIG_AFFINITY:
+                cands.append(("cores %s" % sorted(alt), alt))
     cands.append(("not pinned", set(_ORIG_AFFINITY)))
     n = max(10, min(2000, int(0.03 / t_step)))
     trial = []
