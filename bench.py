@@ -33,7 +33,7 @@ A timed region shorter than 20 ms is not a measurement: when `--steps K` would g
 timed instead and the line says so (`steps` = what was timed, `steps_requested` = K).
 `roofline` is for the dominant kernel, timed with HIP events recorded by the library on the launch stream inside the
 timed region; `roofline.traffic` comes from the committed rocprofv3 PMC summary of this same command
-(profiles/r03_pmc_<config>.json; null when there is none for the workload).  `cpu_baseline` is the CPU oracle
+(profiles/r04_pmc_<config>.json, else the newest older one; null when there is none for the workload).  `cpu_baseline` is the CPU oracle
 (oracle/gsplat_ref.c, OpenMP) on a bounded sample of the same inputs, rank 0 at N=1 only.
 """
 from __future__ import annotations
@@ -473,7 +473,7 @@ def main(args):
     # HBM traffic of the dominant kernel from the committed rocprofv3 PMC summary of this same command (separate --pmc passes,
     # gfx950 FETCH_SIZE correction applied as MI355X_MICROARCH.md prescribes); null when no summary matches this workload
     traffic, traffic_src = None, None
-    for rnd in ("r03", "r02"):                      # the newest committed summary for this config
+    for rnd in ("r04", "r03", "r02"):                      # the newest committed summary for this config
         try:
             path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_{args.config}.json")
             pmc = json.load(open(path))

@@ -11,3 +11,5 @@ SIGMAN_BENCH_BACKEND=gloo timeout 600 python bench.py --gpus 2 --config c3 --ste
 SIGMAN_BENCH_BACKEND=gloo timeout 600 python bench.py --gpus 2 --config c5 --steps 10 --warmup 3 > $O/bench_c5_n2gloo.json 2> $O/bench_c5_n2gloo.err; tail -c 600 $O/bench_c5_n2gloo.json; tail -3 $O/bench_c5_n2gloo.err
 SIGMAN_BENCH_BACKEND=gloo timeout 600 python bench.py --gpus 2 --config c4 --steps 5 --warmup 2 > $O/bench_c4_n2gloo.json 2> $O/bench_c4_n2gloo.err; tail -c 600 $O/bench_c4_n2gloo.json; tail -3 $O/bench_c4_n2gloo.err
 SIGMAN_BENCH_BACKEND=gloo timeout 600 python bench.py --gpus 2 --config c3 --exchange full --steps 5 --warmup 2 > $O/bench_c3_full_n2gloo.json 2> $O/bench_c3_full_n2gloo.err; tail -c 600 $O/bench_c3_full_n2gloo.json
+SIGMAN_BENCH_BACKEND=gloo timeout 600 python bench.py --gpus 2 --config c3 --exchange full-pipelined --steps 5 --warmup 2 > $O/bench_c3_fullpipe_n2gloo.json 2> $O/bench_c3_fullpipe_n2gloo.err; tail -c 600 $O/bench_c3_fullpipe_n2gloo.json
+SIGMAN_BENCH_BACKEND=gloo timeout 600 python bench.py --gpus 2 --config c3 --exchange full-pipelined --pipeline-chunks 2 --steps 5 --warmup 2 > $O/bench_c3_fullpipe2_n2gloo.json 2> $O/bench_c3_fullpipe2_n2gloo.err; tail -c 600 $O/bench_c3_fullpipe2_n2gloo.json
