@@ -45,7 +45,7 @@ __device__ __forceinline__ KnnSet knn_set(const KnnBatch &kb, int set) {
     k.out = kb.out + (size_t)set * kb.P;
     uint32_t *w = (uint32_t *)(kb.ws + (size_t)set * kb.ws_stride);
     k.bb = (int *)w; k.grid = (Grid *)(w + 8); k.bsum = w + 24; k.cell_start = w + 24 + 1024;
-    k.cell_fill = k.cell_start + (size_t)kb.max_cells + 1; k.pt_cell = k.cell_fill + kb.max_cells;
+    k.cell_fill = k.cell_start + (size_t)kb.max_cells + 1; k.pt_cell = k.cell_fill + max(kb.max_cells, kb.P);      // (cell_fill: one rank per POINT)
     k.sorted = (float4 *)(((uintptr_t)(k.pt_cell + kb.P) + 15) & ~(uintptr_t)15);
     return k;
 }
@@ -61,7 +61,7 @@ constexpr int kBoxBlocks = 64;       // workgroups of the prepare kernel that al
 // array).  No atomics, no ticket: nothing here needs initialised memory (the workspace is whatever the caller's allocator returned).
 __global__ __launch_bounds__(kT) void knn_prep_kernel(KnnBatch kb, int box_blocks) {
     const KnnSet ks = knn_set(kb, blockIdx.y);
-    const size_t n = (size_t)2 * kb.max_cells + 1;            // cell_start [max_cells + 1] and cell_fill [max_cells] are adjacent
+    const size_t n = (size_t)kb.max_cells + 1;                // the cell counters (the array behind them holds every point's rank in its cell: no clear)
     for (size_t i = (size_t)blockIdx.x * kT + threadIdx.x; i < n; i += (size_t)gridDim.x * kT) ks.cell_start[i] = 0u;
     if ((int)blockIdx.x >= box_blocks) return;
     const int P = kb.P; const float *pts = ks.pts;
@@ -145,7 +145,9 @@ __global__ __launch_bounds__(kT) void cell_count_kernel(KnnBatch kb, int box_blo
     int cx, cy, cz;
     const int c = cell_of(g, pts[3 * (size_t)i], pts[3 * (size_t)i + 1], pts[3 * (size_t)i + 2], cx, cy, cz);
     pt_cell[i] = (uint32_t)c;
-    atomicAdd(&cell_cnt[c], 1u);
+    // the point's rank among the points of its cell (arrival order: the result does not depend on it, see the header) -- the scatter kernel
+    // then needs neither cursors nor atomics of its own, and nobody has to clear a second per-cell array
+    ks.cell_fill[i] = atomicAdd(&cell_cnt[c], 1u);
 }
 
 // exclusive scan over the cells in two parallel steps (a fine grid has ~1e6 cells: one workgroup walking them serially
@@ -205,11 +207,11 @@ __global__ __launch_bounds__(kT) void cell_scan_kernel(KnnBatch kb) {
 __global__ __launch_bounds__(kT) void cell_scatter_kernel(KnnBatch kb) {
     const KnnSet ks = knn_set(kb, blockIdx.y);
     const int P = kb.P; const float *pts = ks.pts; const uint32_t *pt_cell = ks.pt_cell, *cell_start = ks.cell_start;
-    uint32_t *cell_fill = ks.cell_fill; float4 *sorted = ks.sorted;      // xyz + bitcast original index
+    const uint32_t *cell_fill = ks.cell_fill; float4 *sorted = ks.sorted;      // xyz + bitcast original index
     const int i = blockIdx.x * kT + threadIdx.x;
     if (i >= P) return;
     const uint32_t c = pt_cell[i];
-    const uint32_t slot = cell_start[c] + atomicAdd(&cell_fill[c], 1u);
+    const uint32_t slot = cell_start[c] + cell_fill[i];           // (rank in the cell, from the count kernel)
     sorted[slot] = make_float4(pts[3 * (size_t)i], pts[3 * (size_t)i + 1], pts[3 * (size_t)i + 2], __uint_as_float((uint32_t)i));
 }
 
@@ -358,10 +360,10 @@ __global__ __launch_bounds__(kT) void cov3d_bwd_kernel(int n, const float *__res
 }  // namespace
 
 extern "C" size_t sgr_knn_workspace_bytes(int32_t P, int32_t max_cells) {
-    // [bbox 8 u32][Grid 16 u32][cell_cnt/start max_cells+1][cell_fill max_cells][pt_cell P][sorted max(P, 2) float4]
+    // [bbox 8 u32][Grid 16 u32][cell_cnt/start max_cells+1][point ranks: max(max_cells, P) words][pt_cell P][sorted max(P, 2) float4]
     // (the head of `sorted` first holds the bounding-box partials: 6 floats per prepare workgroup, min(ceil(P / 256), 64) of them --
     // 24 * ceil(P / 256) <= 16 * P bytes from P = 2 on; a single point gets the room of two)
-    return (size_t)(8 + 16 + 1024 + (size_t)max_cells + 1 + (size_t)max_cells + (size_t)P) * 4 + (size_t)(P < 2 ? 2 : P) * 16 + 64;
+    return (size_t)(8 + 16 + 1024 + (size_t)max_cells + 1 + (size_t)(max_cells > P ? max_cells : P) + (size_t)P) * 4 + (size_t)(P < 2 ? 2 : P) * 16 + 64;
 }
 
 extern "C" int sgr_knn_dist2_batched(int32_t n_sets, int32_t P, const float *points, float *out_dist2, void *workspace,
@@ -378,7 +380,7 @@ extern "C" int sgr_knn_dist2_batched(int32_t n_sets, int32_t P, const float *poi
     SgrProfScope _p(SGR_K_KNN, stream);
     const int nb = (P + kT - 1) / kT;
     const int scan_blocks = (max_cells + 1 + kScanTile - 1) / kScanTile;
-    const size_t init_want = ((size_t)2 * max_cells + 1 + kT * 4 - 1) / (kT * 4);
+    const size_t init_want = ((size_t)max_cells + 1 + kT * 4 - 1) / (kT * 4);
     const int init_blocks = (int)(init_want < 1024 ? init_want : 1024);
     const int box_blocks = min(nb, kBoxBlocks);                       // (6 floats each at the head of `sorted`: sgr_knn_workspace_bytes leaves room for them)
     hipLaunchKernelGGL(knn_prep_kernel, dim3(max(init_blocks, box_blocks), n_sets), dim3(kT), 0, stream, kb, box_blocks);
