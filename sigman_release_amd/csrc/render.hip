@@ -928,8 +928,10 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64) void render_bwd_bucket_kernel(int
     // bound from the list lengths: 78 % empty at C3); with four buckets per workgroup a workgroup usually held one real wave and 16 KB of
     // LDS until it was done, which capped a CU at ~10 working waves.
     constexpr int NWV = SPLIT ? 2 : 1;        // waves per workgroup (SPLIT: the two halves of one bucket)
-    __shared__ float4 sPixA[NWV][96];         // per wave: (x, y, n_contrib bits, g0) of stream entry i at [16 + i] (16 unread-but-addressable
-    __shared__ float4 sPixB[NWV][96];         //           (g1, g2, gD, gA)                  slots on either side: lanes look 15 entries back and ahead)
+    __shared__ float4 sPix[NWV][2][96];       // per wave: [0] (x, y, n_contrib bits, g0) of stream entry i at [16 + i] (16 unread-but-addressable
+                                              //           [1] (g1, g2, gD, gA)                  slots on either side: lanes look 15 entries back and ahead)
+    float4 (*sPixA)[96] = reinterpret_cast<float4 (*)[96]>(&sPix[0][0][0]);        // sPixA[w] = sPix[w][0]: rows 2 w, sPixB[w] = sPix[w][1]: rows 2 w + 1
+    float4 (*sPixB)[96] = reinterpret_cast<float4 (*)[96]>(&sPix[0][1][0]);
     __shared__ float2 sDyn[NWV][4][64];       // per wave, per row: (T, Rem) of pixel p at the start of the row
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     // XCD placement as in the forward: workgroup ids b, b+8, b+16, b+24 (same XCD) take the same stretch of bucket slots in the four
@@ -1005,8 +1007,8 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64) void render_bwd_bucket_kernel(int
                 O += fmaf(out_alpha[vb + pix], ga, out_depth[vb + pix] * gd);
             }
         }
-        sPixA[wv][16 + pos] = make_float4((float)px, (float)py, __uint_as_float(last), g0);
-        sPixB[wv][16 + pos] = make_float4(g1, g2, gd, ga);
+        sPixA[2 * wv][16 + pos] = make_float4((float)px, (float)py, __uint_as_float(last), g0);
+        sPixB[2 * wv][16 + pos] = make_float4(g1, g2, gd, ga);
         float T0 = 1.f, Pre0 = 0.f;
         if (start) {
             const float4 tc = aux.ckpt_tc[ROWS ? slot * 256 + p : slot * 64 + p];
@@ -1079,7 +1081,7 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64) void render_bwd_bucket_kernel(int
     // the compiler sinks them into the regions that use them -- feed -> wait -> shift, position -> wait -> Gaussian, gradient -> wait ->
     // sums: three exposed LDS round trips per step on a kernel whose waves spend most of their time waiting.  (Volatile loads are no
     // alternative: each is followed by a wait for its completion.)
-    const float4 *pa = &sPixA[wv][16 - rl], *pb = &sPixB[wv][16 - rl];          // [S] = stream entry S - rl
+    const float4 *pa = &sPixA[2 * wv][16 - rl], *pb = &sPixB[2 * wv][16 - rl];          // [S] = stream entry S - rl
     const float2 *pd = &sDyn[wv][row][0];
 #define SGR_BWD_LOAD(S, FA, FB, FD) { FA = pa[(S)]; FB = pb[(S)]; FD = pd[min((S), n_alive - 1)]; asm volatile("" ::: "memory"); }
 #define SGR_BWD_STEP(IN, OUT, S, fa, fb, fd, NFA, NFB, NFD)                                                             \
@@ -1124,7 +1126,10 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64) void render_bwd_bucket_kernel(int
 #undef SGR_BWD_LOAD
     if (SPLIT) {
         // the odd wave hands its sums to the even wave of the same bucket
-        __shared__ float sComb[1][10][64];
+        // (the odd wave's own pixel arrays, 3 KB, are free once ITS step loop is over: its ten sums go there -- 10 KB of LDS per workgroup instead of
+        // 12.5: 16 workgroups = eight waves per SIMD on a CU instead of 12 = six, and a one-view launch's 8 200 waves are resident at once)
+        float (*sComb)[10][64] = reinterpret_cast<float (*)[10][64]>(&sPix[NWV - 1][0][0]);
+        static_assert(sizeof(float) * 10 * 64 <= sizeof(float4) * 2 * 96, "the odd wave's pixel arrays hold its ten sums");
         if (half == 1u) {
             float *c = &sComb[sub][0][lane];
             c[0] = S1; c[64] = Sx; c[128] = Sy; c[192] = Sxx; c[256] = Sxy; c[320] = Syy; c[384] = aD; c[448] = a7; c[512] = a8; c[576] = a9;
