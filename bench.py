@@ -29,7 +29,7 @@ One "step" = one pass of the hot path over one batch (all view slots of this ran
 of the whole job with inputs resident in HBM.  The timed step is the rasterizer (+ fused loss): distCUDA2 + get_covariance
 (gs.py:70-73) run once per subject outside it; their cost is reported as `frontend_ms_per_subject`, and `variants.renderer_render_ms_per_step`
 times what the reference's render() really pays: GaussianRenderer.render (3-NN + covariance + rasterizer + clamp) forward and backward.
-A timed region shorter than 20 ms is not a measurement: when `--steps K` would give one, as many steps as 20 ms hold (at least 100) are
+A timed region shorter than 100 ms is not a measurement: when `--steps K` would give one, as many steps as 100 ms hold (at least 100) are
 timed instead and the line says so (`steps` = what was timed, `steps_requested` = K).
 `roofline` is for the dominant kernel, timed with HIP events recorded by the library on the launch stream inside the
 timed region; `roofline.traffic` comes from the committed rocprofv3 PMC summary of this same command
@@ -111,6 +111,7 @@ def _pin_host_threads():
 
 
 _ORIG_AFFINITY = _pin_host_threads()
+_DEBUG_BLOCKS = os.environ.get("SIGMAN_BENCH_DEBUG") == "1"
 
 
 def _set_affinity_all_threads(mask):
@@ -421,11 +422,12 @@ def main(args):
         t3 = float(tr.item())
     for _ in range(min(2000, int(0.05 / max(t3 / 3.0, 1e-5)))):
         step()
-    # a timed region under 20 ms is noise, not a measurement (20 steps of C2 are 3 ms): time as many steps as 20 ms hold then, and say so
+    # a timed region under 100 ms is noise, not a measurement (20 steps of C2 are 3 ms; 20-ms windows of one box within a minute: 0.131 .. 0.159 ms per step,
+    # the slow phases last a few ms each and are neither the host's garbage collector nor its run-ahead): time as many steps as 100 ms hold then, and say so
     steps_requested = steps
     t_step = max(t3 / 3.0, 1e-6)
-    if steps * t_step < 0.020:
-        steps = max(steps, int(np.ceil(0.020 / t_step)), 100)
+    if steps * t_step < 0.100:
+        steps = max(steps, int(np.ceil(0.100 / t_step)), 100)
         if dist_on:                                   # the same count on every rank
             ts = torch.tensor([steps], device=dev, dtype=torch.int64)
             dist.all_reduce(ts, op=dist.ReduceOp.MAX)
@@ -437,13 +439,37 @@ def main(args):
     pin_report = _choose_host_cores(step, sync_all, t_step)
 
     # ---- timed region (no per-kernel events here)
+    # The fused node's backward normally WAITS for its own forward's instance count (it arrives ~15 us into that forward's kernels): the host can
+    # then never be more than one step ahead, and a host hiccup longer than the ~30 us of slack a 133-us step leaves becomes a bubble on the GPU
+    # (timed regions of 0.131 .. 0.144 ms on one box within a minute).  "lazy": the backward only looks; a count that has not arrived yet is waited
+    # for two forwards later (csrc/torch_node.cpp, set_count_wait) -- the overflow check still happens for every step, one step later, and once
+    # more behind the timed region (check_pending_overflows below).  SIGMAN_COUNT_WAIT=own keeps the default.
+    lazy_counts = False
+    _node = _cabi.torch_node()
+    if _node is not None and not args.exact_sync and os.environ.get("SIGMAN_COUNT_WAIT", "own") == "lazy":     # (opt-in: measured, no clear gain -- see DESIGN 7e)
+        _node.set_count_wait("lazy")
+        lazy_counts = True
+        for _ in range(3):
+            step()
+    # no cyclic garbage collection inside the timed region: every step creates a few hundred Python objects, and a generation-2 pass that
+    # happens to fall into a 20-ms window costs it milliseconds (regions of 0.131 and 0.159 ms within one minute on one box)
+    import gc
+    gc.collect()
+    gc.disable()
     sync_all()
     t0 = time.perf_counter()
     loss = None
-    for _ in range(steps):
+    dbg_marks = []
+    for k_ in range(steps):
         loss = step()
+        if _DEBUG_BLOCKS and (k_ + 1) % max(steps // 8, 1) == 0:
+            dbg_marks.append(time.perf_counter() - t0)           # (host time stamps only: no synchronisation inside the timed region)
     sync_all()
     elapsed = time.perf_counter() - t0
+    gc.enable()
+    R.check_pending_overflows(True)                      # every step's instance count has been looked at (raises if one did not fit)
+    if _DEBUG_BLOCKS:
+        print("[bench] host time stamps inside the timed region (s):", [round(x, 5) for x in dbg_marks], "elapsed", round(elapsed, 5), "affinity now", len(os.sched_getaffinity(0)), file=sys.stderr)
     if dist_on:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -499,7 +525,8 @@ def main(args):
                    "name": args.config, "views_per_step_total": n_total_views, "view_slots_this_gpu": n_local,
                    "parallelism": (f"view-parallel x{world} ({backend}), exchange={'none (forward only)' if not bwd else args.exchange}" if dist_on else "single GPU"),
                    "ranks_seen": world, "num_rendered_per_gpu": Rn, "gaussian_pixel_visits_per_gpu": S_visits,
-                   "binning_buffers": "exact (D2H read of num_rendered per step)" if args.exact_sync else (f"pre-sized, max_rendered={st.max_rendered} (sync-free)" if st else "-")},
+                   "binning_buffers": "exact (D2H read of num_rendered per step)" if args.exact_sync else (f"pre-sized, max_rendered={st.max_rendered} (sync-free)" if st else "-"),
+                   "count_check": "exact read" if args.exact_sync else ("every step, by the backward of the step after next at the latest (set_count_wait lazy)" if lazy_counts else "every step, by its own backward")},
         "gaussian_pixel_ops_per_s_per_gpu": round(S_visits / (ms_per_step * 1e-3), 1),
         "tile_instances_per_s_per_gpu": round(Rn / (ms_per_step * 1e-3), 1),
         "step_hbm": {"algorithmic_bytes_per_step_per_gpu": step_bytes, "achieved_GBps": round(step_bytes / (ms_per_step * 1e-3) / 1e9, 1),

@@ -433,13 +433,26 @@ bool b_resolve(BPending &p, bool block) {
                 earlier ? "an EARLIER forward of this thread (reported now: nobody had looked at its count yet) are" : "this forward are",
                 " truncated; raise BatchedRasterizationSettings.max_rendered (or use 0 = exact mode)");
 }
-void b_poll(bool block) {            // forwards of this thread whose backward never ran
+// Explicit capacity: WHEN the backward looks at its forward's count.  0 = "own" (default): it waits for it -- the count arrives ~15 us into the
+// forward's own kernels, so the host can never be more than one step ahead of the GPU, and with ~100 us of host work per 133-us step (C2) every
+// host hiccup longer than the slack becomes a bubble on the GPU.  1 = "lazy" (set_count_wait("lazy") / SIGMAN_COUNT_WAIT=lazy; bench.py opts in):
+// the backward only looks (no wait); a count that has not arrived stays pending and is waited for by the thread's forward after next -- the host
+// may run two steps ahead.  An overflow is then reported one step later ("EARLIER forward"), still before anything else of that thread runs.
+std::atomic<int> g_count_wait{-1};
+bool count_wait_lazy() {
+    int v = g_count_wait.load();
+    if (v < 0) { const char *e = getenv("SIGMAN_COUNT_WAIT"); v = (e && std::string(e) == "lazy") ? 1 : 0; g_count_wait.store(v); }
+    return v == 1;
+}
+
+void b_poll(bool block) {            // forwards of this thread whose backward never ran (or, lazy: ran before the count had arrived)
     auto &v = b_pending();
     std::shared_ptr<BPending> bad;
     size_t keep = 0;
+    const size_t in_flight = count_wait_lazy() ? 1 : 128;          // newest entries that may stay unresolved
     for (size_t i = 0; i < v.size(); i++) {
         BPending &p = *v[i];
-        const bool done = p.checked || b_resolve(p, block || v.size() - i > 128);
+        const bool done = p.checked || b_resolve(p, block || v.size() - i > in_flight);
         if (done && p.overflow && !p.reported && !bad) bad = v[i];
         if (!done) v[keep++] = v[i];
     }
@@ -565,8 +578,7 @@ struct RasterizeL1BatchedNode : public torch::autograd::Function<RasterizeL1Batc
             if (it != g_b_by_id.end()) mine = it->second;
         }
         if (mine) {                    // after the backward is queued: the host never idles the GPU while it waits for the forward's counter
-            b_resolve(*mine, true);
-            if (mine->overflow && !mine->reported) b_raise(*mine, false);
+            if (b_resolve(*mine, !count_wait_lazy()) && mine->overflow && !mine->reported) b_raise(*mine, false);
         }
         variable_list out = {d_means3D, d_col, dims[6] == 3 ? d_op.unsqueeze(-1) : d_op, d_cov};
         for (int k = 0; k < 15; k++) out.push_back(Tensor());
@@ -779,8 +791,7 @@ struct RenderBatchedNode : public torch::autograd::Function<RenderBatchedNode> {
                 if (it != g_b_by_id.end()) mine = it->second;
             }
             if (mine) {
-                b_resolve(*mine, true);
-                if (mine->overflow) b_raise(*mine, false);         // (again, if a later forward has reported it already: like the Python node)
+                if (b_resolve(*mine, !count_wait_lazy()) && mine->overflow) b_raise(*mine, false);         // (again, if a later forward has reported it already: like the Python node)
             }
         }
         variable_list out = {d_means3D, d_col, dims[6] == 3 ? d_op.unsqueeze(-1) : d_op, d_fourth, d_rot};
@@ -838,6 +849,11 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
               if (mode == "inline") { std::lock_guard<std::mutex> l(g_mu); for (auto &kv : g_keys) kv.second.deferred = false; }
           }, "'inline' (default): the instance count is checked inside every call, a forward that does not fit is re-rendered exactly before it "
              "returns; 'deferred': the check moves behind the call once a shape's capacity has been stable (== SIGMAN_COUNT_CHECK=deferred)");
+    m.def("set_count_wait", [](const std::string &mode) {
+              TORCH_CHECK(mode == "own" || mode == "lazy", "set_count_wait: 'own' or 'lazy'");
+              g_count_wait.store(mode == "lazy" ? 1 : 0);
+          }, "explicit-capacity batched nodes: 'own' (default): a backward waits for its forward's instance count; 'lazy': it only looks, a count that "
+             "has not arrived is waited for by the thread's forward after next (the host may run two steps ahead; an overflow is reported one step later)");
     m.def("slot_stats", []() { std::lock_guard<std::mutex> l(g_slot_mu); return std::make_tuple((uint64_t)g_slots_created, (uint64_t)g_free_slots.size()); },
           "(pinned count slots ever created, idle slots in the pool)");
     m.def("key_state", [](int dev, int64_t P, int64_t H, int64_t W) { std::lock_guard<std::mutex> l(g_mu); const KeyState &k = g_keys[std::make_tuple(dev, P, H, W)];
