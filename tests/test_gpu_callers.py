@@ -157,6 +157,52 @@ def test_fused_clamped_l1_loss(H, W, use_mask):
     assert torch.allclose(color.grad.double(), c2.grad, atol=1e-7)
 
 
+@pytest.mark.parametrize("H,W,V,use_mask", [(100, 77, 1, True), (64, 64, 2, False), (33, 130, 3, True), (16, 16, 1, False)])
+@pytest.mark.parametrize("fwd_mode", [2, 3, 1])
+def test_raster_l1_entry_point_behind_every_forward_kernel(H, W, V, use_mask, fwd_mode):
+    """sgr_rasterize_forward_l1 behind every compositing kernel, on ragged sizes, empty tiles and a view with nothing in it: the per-view
+    losses equal clamped_l1_loss(rasterize(...))'s up to summation order, and dL/dcolor -- hence every gradient -- is bit-identical.
+    (Round 4 tried the loss as the segment-parallel kernel's own epilogue; this test is what that variant had to pass.  It did, and lost:
+    DESIGN.md dead ends.)"""
+    from sigman_release_amd import _cabi, rasterizer as R
+    from sigman_release_amd.losses import clamped_l1_loss
+    import cases
+    dev = _dev()
+    views = (30, 65, 10)[:V]
+    inp, st = cases.humanoid(P=1500, H=H, W=W, seed=5, views=views)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    bst = R.BatchedRasterizationSettings(st["image_height"], st["image_width"], st["tanfovx"], st["tanfovy"], t(st["bg"]), 1.0,
+                                         t(st["viewmatrix"]), t(st["projmatrix"]), 0, t(st["campos"]), V)
+    g = torch.Generator(device=dev).manual_seed(H * 1000 + W)
+    target = torch.rand(V, 3, H, W, device=dev, generator=g)
+    mask = (torch.rand(V, 1, H, W, device=dev, generator=g) > 0.2).float() if use_mask else None
+    _cabi.lib().sgr_set_forward_mode(fwd_mode)
+    try:
+        out = []
+        for fused in (False, True):
+            d = {k: t(v)[None].requires_grad_(True) for k, v in inp.items()}
+            args = (d["means3D"], None, None, d["colors_precomp"], d["opacities"][..., None], None, None, d["cov3D_precomp"], bst)
+            if fused:
+                loss, per_view, color, radii, depth, alpha = R._RasterizeL1Batched.apply(*args, target, mask, 0.37)
+            else:
+                color, radii, depth, alpha = R._RasterizeGaussiansBatched.apply(*args)
+                loss = clamped_l1_loss(color, target, mask, 0.37)
+                cl = color.detach().clamp(0, 1)
+                per_view = 0.37 * ((cl - target) * (mask if mask is not None else 1.0)).abs().sum(dim=(1, 2, 3))
+            loss.backward()
+            torch.cuda.synchronize()
+            out.append((loss.detach(), per_view.detach(), color.detach().clone(), {k: v.grad.clone() for k, v in d.items()}))
+    finally:
+        _cabi.lib().sgr_set_forward_mode(0)
+    assert torch.allclose(out[0][0], out[1][0], rtol=2e-5, atol=1e-6)
+    assert torch.allclose(out[0][1], out[1][1], rtol=2e-5, atol=1e-6)
+    assert torch.allclose(out[1][1].sum(), out[1][0], rtol=2e-5, atol=1e-6)
+    assert torch.equal(out[0][2], out[1][2])
+    for k in out[0][3]:
+        a, b = out[0][3][k], out[1][3][k]
+        assert torch.equal(a, b), k
+
+
 @pytest.mark.parametrize("use_color_too", [False, True])
 def test_fused_raster_l1_node_equals_two_nodes(use_color_too):
     """rasterize_l1_loss_batched (one autograd node, upstream scalar passed to the backward kernel as a device pointer)
