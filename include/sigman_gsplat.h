@@ -36,9 +36,8 @@
 extern "C" {
 #endif
 
-#define SGR_ABI_VERSION 6
+#define SGR_ABI_VERSION 7
 #define SGR_TILE 16                 /* 16x16 pixel tiles, as the published algorithm */
-#define SGR_REC_FLOATS 12           /* floats of a gradient record (grec, pixel-parallel backward) */
 #define SGR_PART_FLOATS 10          /* floats of a partial gradient record (bucket-parallel backward): 40 B, 8-byte aligned */
 #define SGR_REC_STRIDE 16           /* floats of the packed per-(view,Gaussian) record `rec` (64 B, one cache line) */
 
@@ -79,11 +78,9 @@ typedef struct SgrProblem {
  *   rec[0..3]   = pixel x, pixel y, conic.xx, conic.xy
  *   rec[4..7]   = conic.yy, opacity, view depth, r
  *   rec[8..11]  = g, b, hx, hy      (hx,hy: half extents of the exact alpha >= 1/255 bound; <0 = never visible)
- *   rec[12..15] = padding (the record is one 64-byte line)
- * The gradient record written by sgr_render_backward has the same shape:
- *   grec[0..3] = dL/dNDCx, dL/dNDCy, dL/dconic.xx, dL/dconic.xy
- *   grec[4..7] = dL/dconic.yy, dL/dopacity, dL/ddepth, dL/dr
- *   grec[8..11]= dL/dg, dL/db, 0, 0
+ *   rec[12..15] = p*, 0, 0, 0       (ABI v7) p*: the published alpha test `min(0.99, opacity * exp(power)) >= 1/255` as a threshold on the
+ *                 exponent in the exp2 domain -- the smallest float power2 <= 0 that passes, computed with a correctly rounded exp2 exactly
+ *                 like the CPU oracle (+inf: never passes); the compositing kernels test p* <= power2 <= 0 (csrc/render.hip, header)
  */
 
 int sgr_abi_version(void);
@@ -103,9 +100,9 @@ typedef struct SgrForwardState {
     uint64_t R_alloc;            /* size of the binning buffers in tile instances: exact num_rendered, or the capacity */
     uint64_t true_rendered;      /* exact mode: num_rendered; sync-free mode: ~0 (read nr_pinned_host after nr_event) */
     uint64_t NS;                 /* bucket slots per quadrant */
-    int32_t with_aux /* 0 none, 1 compact checkpoints, 2 row checkpoints */, result_in_b, flags_cleared;
+    int32_t with_aux /* 0 none, 2 row checkpoints (1 was the compact layout of ABI <= 6) */, result_in_b, flags_cleared;
     int32_t aux_no_da;           /* 1: the forward left the (depth, alpha) checkpoints out (with_aux & 2); sgr_rasterize_backward adds them on demand */
-    int32_t fwd_kind;            /* the compositing kernel the forward used (1 serial per tile, 2 segment-parallel, 3 one wave per quadrant) */
+    int32_t fwd_kind;            /* the compositing kernel the forward used (2 segment-parallel, 3 one wave per quadrant) */
     int32_t nr_by_copy;          /* sync-free mode: 1 = the count reaches nr_pinned_host through an async device-to-host COPY (not byte-atomic: wait for
                                     nr_event before reading it); 0 = through one 8-byte store of a kernel (the word may be polled) */
     void *geom, *binning, *image;
@@ -159,7 +156,8 @@ int sgr_rasterize_forward_l1(const SgrProblem *pb, uint64_t capacity, int32_t wi
 
 /*
  * == upstream _C.rasterize_gaussians_backward (reached from train_vae.py:166).  Gradient outputs as in
- * sgr_preprocess_backward.  out_color/out_depth/out_alpha are the forward's outputs.  grad_color_scale: optional DEVICE scalar
+ * sgr_preprocess_backward.  Needs a forward that ran with with_aux != 0 -- or one that rendered nothing (no visible tile instance:
+ * every gradient is then written as zero).  out_color/out_depth/out_alpha are the forward's outputs.  grad_color_scale: optional DEVICE scalar
  * multiplied onto grad_color (the upstream gradient of a fused image loss; saves the caller an elementwise kernel), or NULL.
  */
 int sgr_rasterize_backward(const SgrProblem *pb, const SgrForwardState *state, const int32_t *radii, const float *out_color,
@@ -226,8 +224,8 @@ int sgr_bin(const SgrProblem *pb, const int32_t *radii, uint32_t *rect /* [3] of
 uint64_t sgr_bucket_slots(uint64_t R, uint64_t tiles_total);
 
 /* forward compositing kernel choice: 0 = automatic (segment-parallel for launches of <= 2048 tiles, one wave per (tile, quadrant)
- * otherwise), 1 = serial per tile (one workgroup per tile), 2 = segment-parallel, 3 = one wave per (tile, quadrant).  All produce the same
- * outputs. */
+ * otherwise), 2 = segment-parallel, 3 = one wave per (tile, quadrant); anything else is refused.  Both produce the same integer
+ * artefacts and the same alpha-test decisions. */
 int sgr_set_forward_mode(int mode);
 
 /* B2 + B3 kernel choice: 0 = automatic (default: on the colors_precomp path with views_per_subject in {2, 4, .., 256} one thread per
@@ -244,19 +242,14 @@ int sgr_set_keep_sorted_keys(int keep);
  * as leave >= 4096 workgroups), n >= 1 = exactly n (dev/test override).  The outputs do not depend on it. */
 int sgr_set_preprocess_view_group(int n);
 
-/* checkpoint layout of the auxiliary forward outputs: 0 = automatic (default: "rows" unless that allocation would exceed
- * SIGMAN_AUX_ROWS_MAX_BYTES, 8 GiB if unset), 1 = compact, 2 = rows.  sgr_rasterize_forward records its choice in state->with_aux. */
-int sgr_set_aux_layout(int mode);
-
 /*
  * F6: per-tile front-to-back compositing.  out_color [n_views,3,H,W], out_depth [n_views,1,H,W],
  * out_alpha [n_views,1,H,W], final_T f32 [n_views,H,W], n_contrib u32 [n_views,H,W].
  * Optional auxiliary outputs for the bucket-parallel backward (pass all four or none; NS = sgr_bucket_slots(R, n_views*tiles)):
  *   aux_compact  u32 [4][R][2]   per (tile, 8x8 quadrant) culled list: (record id, index in the tile list)
- *   aux_ckpt_tc  f32 [4*NS][rows][64][4], aux_ckpt_da f32 [4*NS][rows][64][2]   per-pixel (T,C) / (D,A) checkpoints of each <=64-survivor bucket.
- *                Layout "rows" (rows = 4; default): one record before each 16-survivor row -- T absolute; sums absolute on rows that start a
- *                forward segment, else relative to that row.  Layout "compact" (rows = 1): the absolute state before the bucket's first
- *                survivor only; the backward rebuilds the inner rows (4x smaller, backward ~1.5x slower).  sgr_set_aux_layout chooses.
+ *   aux_ckpt_tc  f32 [4*NS][4][64][4], aux_ckpt_da f32 [4*NS][4][64][2]   per-pixel (T,C) / (D,A) checkpoints of each <=64-survivor bucket:
+ *                one record before each 16-survivor row -- T absolute; sums absolute on rows that start a forward segment, else relative
+ *                to that row
  *   aux_desc     u32 [4*NS][2]   bucket descriptors (tile | (rows per segment - 1) << 30, (start << 7) | count); zeroed by this call
  * aux_order (optional, u32 [1 + n_views*tiles]) receives the work order of the segment-parallel kernel (longest tile lists
  * first, empty tiles last); NULL = tiles in index order.
@@ -267,31 +260,29 @@ int sgr_render_forward(const SgrProblem *pb, const uint32_t *ranges, const uint3
                        void *stream);
 
 /*
- * B1: gradient records from the image gradients.  grad_depth / grad_alpha may be NULL (treated as zero).
- * With the forward's aux buffers (and the forward's output images) the bucket-parallel kernel runs: one wave per
- * <=64-Gaussian bucket, lanes own Gaussians, pixel states rotate through the wave (no reductions, no LDS, NO ATOMICS):
+ * B1: gradients of the compositing from the image gradients.  grad_depth / grad_alpha may be NULL (treated as zero; with either given,
+ * aux_ckpt_da must hold the forward's depth/alpha checkpoints).  Needs the forward's auxiliary outputs and output images: one wave per
+ * <=64-Gaussian bucket, lanes own Gaussians, pixel states move through the lanes (no reductions, no LDS atomics, NO GLOBAL ATOMICS):
  * each lane writes one partial record part[(4*instance + quadrant)*10 .. +10] and sets flags byte [4*instance + quadrant]
  * (part f32 [4*R*SGR_PART_FLOATS] = [4*R*10], flags u32 [R], flags zeroed by this call); sgr_preprocess_backward gathers them in a fixed order,
- * so gradients are bitwise reproducible.  grec may be NULL on this path.
- * Without the aux buffers (NULL) the pixel-parallel reverse walk runs: needs final_T and grec [n_views*P*12], which is
- * zeroed by this call and accumulated with hardware float atomics (one set per tile and Gaussian).
+ * so gradients are bitwise reproducible.  (ABI <= 6 also had the published pixel-parallel reverse walk with float atomics as a second
+ * path -- `grec`, `final_T`, `point_list` arguments; removed in v7.)
  */
-int sgr_render_backward(const SgrProblem *pb, const uint32_t *ranges, const uint32_t *point_list, const float *rec, const uint32_t *rect,
-                        const float *final_T, const uint32_t *n_contrib, const float *out_color, const float *out_depth,
+int sgr_render_backward(const SgrProblem *pb, const uint32_t *ranges, const float *rec, const uint32_t *rect,
+                        const uint32_t *n_contrib, const float *out_color, const float *out_depth,
                         const float *out_alpha, const float *grad_color, const float *grad_depth, const float *grad_alpha,
                         const float *grad_color_scale /* optional device scalar on grad_color, or NULL */,
                         uint64_t R, const void *aux_compact, const void *aux_ckpt_tc, const void *aux_ckpt_da,
-                        const void *aux_desc, float *grec, float *part, uint32_t *flags, void *stream);
+                        const void *aux_desc, float *part, uint32_t *flags, void *stream);
 
 /*
- * B2 + B3: per-(view,Gaussian) gradient records (either `grec`, or `rect` + `part` + `flags` from the bucket-parallel
- * sgr_render_backward) -> per-subject parameter gradients, summed over the
+ * B2 + B3: the bucket backward's partial records (`rect` + `part` + `flags`) -> per-subject parameter gradients, summed over the
  * subject's views in a fixed order (no atomics).  Outputs are fully written (no pre-zeroing needed):
  *   dL_dmeans3D [S,P,3], dL_dmeans2D [n_views,P,3] (NDC units like upstream, z = 0; may be NULL: not written),
  *   dL_dopacity [S,P], dL_dcolors [S,P,3] (or dL_dsh [S,P,M,3] when shs), dL_dcov3D [S,P,6],
  *   dL_dscales [S,P,3] / dL_drotations [S,P,4] (only when scales given; else may be NULL)
  */
-int sgr_preprocess_backward(const SgrProblem *pb, const int32_t *radii, const uint8_t *clamped, const float *grec,
+int sgr_preprocess_backward(const SgrProblem *pb, const int32_t *radii, const uint8_t *clamped,
                             const uint32_t *rect, const float *part, const uint32_t *flags, float *dL_dmeans3D, float *dL_dmeans2D, float *dL_dopacity, float *dL_dcolors,
                             float *dL_dsh, float *dL_dcov3D, float *dL_dscales, float *dL_drotations,
                             void *stream);
@@ -331,11 +322,6 @@ int sgr_cov3d_backward(int32_t n, const float *scale_raw, const float *rotation,
 int sgr_clamped_l1_loss(int32_t n_views, int32_t H, int32_t W, const float *color, const float *target, const float *mask,
                         float weight, float *grad_color, float *loss_per_view, float *loss_total, int32_t sums_already_zero,
                         void *stream);
-
-/* rendered_image.clamp(0, 1) (gs.py:107) and its backward (grad_x = grad_y where 0 <= x <= 1, else 0: torch.clamp's inclusive mask) over n
- * contiguous floats; the renderer node (csrc/torch_node.cpp, GaussianRenderer.render) keeps the unclamped colours for the rasterizer's backward. */
-int sgr_clamp01_forward(uint64_t n, const float *x, float *y, void *stream);
-int sgr_clamp01_backward(uint64_t n, const float *x, const float *grad_y, float *grad_x, void *stream);
 
 /* ---- optional per-kernel profiler (HIP events on the launch stream; used by bench.py) -------- */
 enum {

@@ -23,6 +23,23 @@
  * sorted lists / tile ranges bit-exact between the two.  ndc2Pix is evaluated in double exactly
  * like the published algorithm (its literals are doubles).
  *
+ * The per-visit exponent and the alpha test (F6 / B1) exist in two arithmetic forms, selected by
+ * ref_set_alpha_mode():
+ *   0 "reproducible" (DEFAULT, what the HIP kernels are pinned against): the published
+ *       power = -0.5 (con.x dx^2 + con.z dy^2) - con.y dx dy;  alpha = min(0.99, con.w * exp(power))
+ *     is evaluated as exp(power) = 2^power2 with the conic pre-scaled by -0.5 log2(e) / -log2(e)
+ *     (three fp32 products per Gaussian) and power2 as ONE explicit chain of fused multiply-adds
+ *     (ref_power2), and 2^power2 is rounded to fp32 from an fp64 polynomial (ref_exp2_cr: every
+ *     step one correctly rounded IEEE operation).  Both are reproducible bit for bit on any IEEE
+ *     machine -- the HIP kernels evaluate the same chain (v_fma_f32), and preprocess.hip derives from
+ *     the same ref_exp2_cr steps the per-Gaussian exponent threshold its alpha test uses -- so
+ *     EVERY alpha-test decision (alpha >= 1/255, power > 0) of the HIP path equals this file's.
+ *   1 "published order": the literal expression above, left to right without FMA, libm expf.
+ *     Mathematically the same function; the exponents differ by a few ulp, which moves an alpha
+ *     that sits within ~1e-6 (relative) of 1/255 across the threshold: about 2 pixels per million
+ *     (tests/test_oracle_cpu.py counts them).  Upstream's own build is no better defined: nvcc
+ *     contracts the expression into FMAs of its choosing and exp() is CUDA's 2-ulp expf.
+ *
  * One deliberate deviation from the ashawkey fork, documented in DESIGN.md: the backward pass
  * starts its transmittance walk from a stored final_T (as the original Inria rasterizer does)
  * instead of recomputing 1 - out_alpha; the two differ by fp32 rounding of a sum and the stored
@@ -63,6 +80,81 @@ typedef struct {
 
 static inline float fminf_(float a, float b) { return a < b ? a : b; }
 static inline float fmaxf_(float a, float b) { return a > b ? a : b; }
+
+/* ---- per-visit exponent / alpha (see the header): 0 = reproducible (default), 1 = published order */
+static int g_alpha_mode = 0;
+void ref_set_alpha_mode(int mode) { g_alpha_mode = mode ? 1 : 0; }
+int ref_get_alpha_mode(void) { return g_alpha_mode; }
+
+/* 2^x rounded to fp32 from an fp64 evaluation with ~1e-16 relative error: n = rint(x), e^((x - n) ln 2) as a
+ * degree-13 Taylor polynomial in Horner form.  One correctly rounded IEEE operation per step; the same steps in
+ * the same order as sgr_exp2_cr in sigman_release_amd/csrc/preprocess.hip (restated there, not shared). */
+static inline float ref_exp2_cr(float x) {
+    const double xd = (double)x;
+    const double n = rint(xd);
+    const double t = (xd - n) * 0.693147180559945309417232121458;
+    double p = 1.0 / 6227020800.0;
+    p = fma(p, t, 1.0 / 479001600.0);
+    p = fma(p, t, 1.0 / 39916800.0);
+    p = fma(p, t, 1.0 / 3628800.0);
+    p = fma(p, t, 1.0 / 362880.0);
+    p = fma(p, t, 1.0 / 40320.0);
+    p = fma(p, t, 1.0 / 5040.0);
+    p = fma(p, t, 1.0 / 720.0);
+    p = fma(p, t, 1.0 / 120.0);
+    p = fma(p, t, 1.0 / 24.0);
+    p = fma(p, t, 1.0 / 6.0);
+    p = fma(p, t, 0.5);
+    p = fma(p, t, 1.0);
+    p = fma(p, t, 1.0);
+    return (float)ldexp(p, (int)n);
+}
+void ref_exp2_cr_array(const float *x, float *y, int64_t n) { for (int64_t i = 0; i < n; i++) y[i] = ref_exp2_cr(x[i]); }
+
+/* The alpha test as a threshold on the exponent (what the HIP kernels evaluate): alpha = min(0.99, op * 2^p) is monotone in p, so
+ *     alpha >= 1/255   <=>   p >= p*(op),      p* = the smallest fp32 p <= 0 that passes (+inf: none does).
+ * Restated here so that tests can (a) prove the equivalence on the CPU (tests/test_oracle_cpu.py) and (b) compare the p* the HIP
+ * preprocess kernel stores in every record bit for bit.  Plain bisection over the bit patterns of |p| in [0, 127]. */
+static inline int ref_alpha_passes(float op, uint32_t mag) {
+    union { uint32_t u; float f; } c; c.u = mag;
+    return fminf_(0.99f, op * ref_exp2_cr(-c.f)) >= 1.0f / 255.0f;
+}
+float ref_alpha_threshold(float op) {
+    if (!(op >= 1.0f / 255.0f)) return INFINITY;
+    uint32_t lo = 0u, hi = 0x42FE0000u;                     /* |p| = 0 passes, |p| = 127 does not */
+    while (hi - lo > 1u) {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        if (ref_alpha_passes(op, mid)) lo = mid; else hi = mid;
+    }
+    union { uint32_t u; float f; } c; c.u = lo;
+    return -c.f;
+}
+void ref_alpha_threshold_array(const float *op, float *pstar, int64_t n) {
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; i++) pstar[i] = ref_alpha_threshold(op[i]);
+}
+/* min(0.99, op * 2^p) >= 1/255 with p given by its value (p <= 0): the direct evaluation the renderer below uses */
+void ref_alpha_test_array(const float *op, const float *p, uint8_t *pass, int64_t n) {
+    for (int64_t i = 0; i < n; i++) pass[i] = (p[i] <= 0.0f) && (fminf_(0.99f, op[i] * ref_exp2_cr(p[i])) >= 1.0f / 255.0f);
+}
+
+/* exponent in the exp2 domain: conic pre-scaled (kxx, kyy by -0.5 log2 e, kxy by -log2 e), one FMA chain */
+static const float K_LOG2E = -1.4426950408889634f, K_HALF_LOG2E = -0.7213475204444817f;
+static inline float ref_power2(const float *co, float dx, float dy) {
+    const float kxx = K_HALF_LOG2E * co[0], kxy = K_LOG2E * co[1], kyy = K_HALF_LOG2E * co[2];
+    return fmaf(dx, kxx * dx, fmaf(kxy * dx, dy, (kyy * dy) * dy));
+}
+/* G = exp(power) at one (pixel, Gaussian) pair, or -1 if the published `power > 0 -> continue` rule applies */
+static inline float ref_gauss(const float *co, float dx, float dy) {
+    if (g_alpha_mode == 0) {
+        const float p2 = ref_power2(co, dx, dy);
+        if (p2 > 0.0f) return -1.f;
+        return ref_exp2_cr(p2);
+    }
+    const float power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+    if (power > 0.0f) return -1.f;
+    return expf(power);
+}
 
 /* p_view = w2c * p  (published transformPoint4x3) */
 static inline void xform4x3(const float *m, const float *p, float *o) {
@@ -325,9 +417,9 @@ void ref_render_fwd(int H, int W, const uint32_t *ranges, const uint32_t *point_
                     contributor++;
                     const float dx = xy[2 * g] - pfx, dy = xy[2 * g + 1] - pfy;
                     const float *co = conic_opacity + 4 * g;
-                    const float power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
-                    if (power > 0.0f) continue;
-                    const float alpha = fminf_(0.99f, co[3] * expf(power));
+                    const float G = ref_gauss(co, dx, dy);
+                    if (G < 0.0f) continue;                 /* power > 0 */
+                    const float alpha = fminf_(0.99f, co[3] * G);
                     if (alpha < 1.0f / 255.0f) continue;
                     const float test_T = T * (1.f - alpha);
                     if (test_T < 0.0001f) break;            /* the crossing Gaussian is NOT composited */
@@ -385,9 +477,8 @@ void ref_render_bwd(int P, int H, int W, int64_t R, const uint32_t *ranges, cons
                     const uint32_t g = point_list[r];
                     const float dx = xy[2 * g] - pfx, dy = xy[2 * g + 1] - pfy;
                     const float *co = conic_opacity + 4 * g;
-                    const float power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
-                    if (power > 0.0f) continue;
-                    const float G = expf(power);
+                    const float G = ref_gauss(co, dx, dy);
+                    if (G < 0.0f) continue;                 /* power > 0 */
                     const float alpha = fminf_(0.99f, co[3] * G);
                     if (alpha < 1.0f / 255.0f) continue;
                     T = T / (1.f - alpha);

@@ -50,6 +50,41 @@ def lib():
     return _lib
 
 
+def set_alpha_mode(mode: int) -> int:
+    """0 = reproducible exponent (explicit FMA chain on the pre-scaled conic) + correctly rounded exp2: the default, what the HIP kernels
+    are pinned against; 1 = the published expression left to right without FMA + libm expf (gsplat_ref.c header).  Returns the old mode."""
+    L = lib()
+    old = int(L.ref_get_alpha_mode())
+    L.ref_set_alpha_mode(int(mode))
+    return old
+
+
+def exp2_cr(x) -> np.ndarray:
+    """ref_exp2_cr over an array: 2^x rounded to fp32 from the fp64 polynomial both sides share step for step."""
+    x = np.ascontiguousarray(np.asarray(x, np.float32)).reshape(-1)
+    y = np.empty_like(x)
+    lib().ref_exp2_cr_array(C.c_void_p(x.ctypes.data), C.c_void_p(y.ctypes.data), C.c_int64(x.size))
+    return y
+
+
+def alpha_threshold(opacities) -> np.ndarray:
+    """p*(opacity): the smallest fp32 exponent (exp2 domain, <= 0) that passes the published alpha test, +inf if none does --
+    the value the HIP preprocess kernel stores in float 11 of every record (gsplat_ref.c, ref_alpha_threshold)."""
+    op = np.ascontiguousarray(np.asarray(opacities, np.float32)).reshape(-1)
+    out = np.empty_like(op)
+    lib().ref_alpha_threshold_array(C.c_void_p(op.ctypes.data), C.c_void_p(out.ctypes.data), C.c_int64(op.size))
+    return out
+
+
+def alpha_test(opacities, p) -> np.ndarray:
+    """The alpha test evaluated directly, as the renderer does: p <= 0 and min(0.99, op * 2^p) >= 1/255."""
+    op = np.ascontiguousarray(np.asarray(opacities, np.float32)).reshape(-1)
+    p = np.ascontiguousarray(np.asarray(p, np.float32)).reshape(-1)
+    out = np.empty(op.size, np.uint8)
+    lib().ref_alpha_test_array(C.c_void_p(op.ctypes.data), C.c_void_p(p.ctypes.data), C.c_void_p(out.ctypes.data), C.c_int64(op.size))
+    return out.astype(bool)
+
+
 def _f32(a, shape=None):
     a = np.ascontiguousarray(np.asarray(a, dtype=np.float32))
     if shape is not None:

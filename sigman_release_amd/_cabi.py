@@ -43,7 +43,7 @@ class SgrL1Epilogue(C.Structure):
                 ("loss_total", C.c_void_p), ("weight", C.c_float), ("sums_already_zero", C.c_int32)]
 
 
-ABI_VERSION = 6          # include/sigman_gsplat.h: SGR_ABI_VERSION
+ABI_VERSION = 7          # include/sigman_gsplat.h: SGR_ABI_VERSION
 ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_int32, C.c_size_t)
 
 _SIGNATURES = {
@@ -65,7 +65,6 @@ _SIGNATURES = {
                           C.c_void_p]),
     "sgr_bucket_slots": (C.c_uint64, [C.c_uint64, C.c_uint64]),
     "sgr_set_forward_mode": (C.c_int, [C.c_int]),
-    "sgr_set_aux_layout": (C.c_int, [C.c_int]),
     "sgr_set_backward_gather": (C.c_int, [C.c_int]),
     "sgr_set_preprocess_view_group": (C.c_int, [C.c_int]),
     "sgr_set_keep_sorted_keys": (C.c_int, [C.c_int]),
@@ -73,8 +72,8 @@ _SIGNATURES = {
     "sgr_set_sort_mode": (C.c_int, [C.c_int]),
     "sgr_set_sort_deep": (C.c_int, [C.c_int]),
     "sgr_render_forward": (C.c_int, [C.POINTER(SgrProblem)] + [C.c_void_p] * 8 + [C.c_uint64] + [C.c_void_p] * 6),
-    "sgr_render_backward": (C.c_int, [C.POINTER(SgrProblem)] + [C.c_void_p] * 13 + [C.c_uint64] + [C.c_void_p] * 8),
-    "sgr_preprocess_backward": (C.c_int, [C.POINTER(SgrProblem)] + [C.c_void_p] * 15),
+    "sgr_render_backward": (C.c_int, [C.POINTER(SgrProblem)] + [C.c_void_p] * 11 + [C.c_uint64] + [C.c_void_p] * 7),
+    "sgr_preprocess_backward": (C.c_int, [C.POINTER(SgrProblem)] + [C.c_void_p] * 14),
     "sgr_mark_visible": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sgr_knn_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
     "sgr_knn_dist2": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int32, C.c_void_p]),
@@ -83,8 +82,6 @@ _SIGNATURES = {
     "sgr_cov3d_backward": (C.c_int, [C.c_int32] + [C.c_void_p] * 7),
     "sgr_clamped_l1_loss": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p,
                                       C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
-    "sgr_clamp01_forward": (C.c_int, [C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "sgr_clamp01_backward": (C.c_int, [C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sgr_prof_configure": (C.c_int, [C.c_uint32]),
     "sgr_prof_collect": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_uint32)]),
 }

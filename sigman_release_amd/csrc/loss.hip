@@ -66,58 +66,8 @@ __global__ __launch_bounds__(kT) void clamped_l1_kernel(const float *__restrict_
         if (loss_total) sgr_atomic_add(loss_total, part);
     }
 }
-// rendered_image.clamp(0, 1) (gs.py:107) and its backward for the renderer node (csrc/torch_node.cpp): one thread per element, no loops.
-// The backward mask is torch.clamp's: INCLUSIVE, exactly 0 / 1 pass.
-__global__ __launch_bounds__(256) void clamp01_fwd_kernel(const float *__restrict__ x, float *__restrict__ y, uint64_t n) {
-    const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
-    if (i < n) y[i] = fminf(fmaxf(x[i], 0.f), 1.f);
-}
-__global__ __launch_bounds__(256) void clamp01_fwd4_kernel(const float4 *__restrict__ x, float4 *__restrict__ y, uint64_t n4) {
-    const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
-    if (i < n4) {
-        const float4 v = x[i];
-        y[i] = make_float4(fminf(fmaxf(v.x, 0.f), 1.f), fminf(fmaxf(v.y, 0.f), 1.f), fminf(fmaxf(v.z, 0.f), 1.f), fminf(fmaxf(v.w, 0.f), 1.f));
-    }
-}
-__global__ __launch_bounds__(256) void clamp01_bwd_kernel(const float *__restrict__ x, const float *__restrict__ gy, float *__restrict__ gx, uint64_t n) {
-    const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
-    if (i < n) { const float v = x[i]; gx[i] = (v >= 0.f && v <= 1.f) ? gy[i] : 0.f; }
-}
-__global__ __launch_bounds__(256) void clamp01_bwd4_kernel(const float4 *__restrict__ x, const float4 *__restrict__ gy, float4 *__restrict__ gx, uint64_t n4) {
-    const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
-    if (i < n4) {
-        const float4 v = x[i], g = gy[i];
-        gx[i] = make_float4((v.x >= 0.f && v.x <= 1.f) ? g.x : 0.f, (v.y >= 0.f && v.y <= 1.f) ? g.y : 0.f, (v.z >= 0.f && v.z <= 1.f) ? g.z : 0.f,
-                            (v.w >= 0.f && v.w <= 1.f) ? g.w : 0.f);
-    }
-}
 }  // namespace
 
-extern "C" int sgr_clamp01_forward(uint64_t n, const float *x, float *y, void *stream_) {
-    if (n == 0) return 0;
-    if (!x || !y) { sgr_set_error("sgr_clamp01_forward: NULL pointer"); return 1; }
-    if (n > (1ull << 39)) { sgr_set_error("sgr_clamp01_forward: too many elements"); return 1; }
-    hipStream_t stream = (hipStream_t)stream_;
-    const bool vec = !((((uintptr_t)x | (uintptr_t)y) & 15) || (n & 3));
-    const uint64_t m = vec ? n / 4 : n;
-    if (vec) hipLaunchKernelGGL(clamp01_fwd4_kernel, dim3((uint32_t)((m + 255) / 256)), dim3(256), 0, stream, (const float4 *)x, (float4 *)y, m);
-    else hipLaunchKernelGGL(clamp01_fwd_kernel, dim3((uint32_t)((m + 255) / 256)), dim3(256), 0, stream, x, y, m);
-    SGR_CHECK_LAUNCH("clamp01_fwd_kernel");
-    return 0;
-}
-
-extern "C" int sgr_clamp01_backward(uint64_t n, const float *x, const float *grad_y, float *grad_x, void *stream_) {
-    if (n == 0) return 0;
-    if (!x || !grad_y || !grad_x) { sgr_set_error("sgr_clamp01_backward: NULL pointer"); return 1; }
-    if (n > (1ull << 39)) { sgr_set_error("sgr_clamp01_backward: too many elements"); return 1; }
-    hipStream_t stream = (hipStream_t)stream_;
-    const bool vec = !((((uintptr_t)x | (uintptr_t)grad_y | (uintptr_t)grad_x) & 15) || (n & 3));
-    const uint64_t m = vec ? n / 4 : n;
-    if (vec) hipLaunchKernelGGL(clamp01_bwd4_kernel, dim3((uint32_t)((m + 255) / 256)), dim3(256), 0, stream, (const float4 *)x, (const float4 *)grad_y, (float4 *)grad_x, m);
-    else hipLaunchKernelGGL(clamp01_bwd_kernel, dim3((uint32_t)((m + 255) / 256)), dim3(256), 0, stream, x, grad_y, grad_x, m);
-    SGR_CHECK_LAUNCH("clamp01_bwd_kernel");
-    return 0;
-}
 
 extern "C" int sgr_clamped_l1_loss(int32_t n_views, int32_t H, int32_t W, const float *color, const float *target,
                                    const float *mask, float weight, float *grad_color, float *loss_per_view, float *loss_total,

@@ -42,6 +42,52 @@ __device__ __forceinline__ void xform4x4(const float *m, const float *p, float *
 }
 __device__ __forceinline__ float ndc2pix(float v, int S) { return (float)((((double)v + 1.0) * (double)S - 1.0) * 0.5); }
 
+// -------------------------------------------------------------------------------------------------
+// The alpha test as a threshold on the exponent (render.hip, file header).
+// sgr_exp2_cr: 2^x rounded to fp32 from an fp64 evaluation whose error (~1e-16) is far below half an fp32 ulp: n = rint(x),
+// e^((x - n) ln 2) by a degree-13 Taylor polynomial in Horner form.  Every step is ONE correctly rounded IEEE operation (cvt, rint, sub,
+// mul, fma, ldexp, cvt) and the CPU oracle (its ref_exp2_cr) performs the same steps in the same order: bit-identical on both sides.
+// -------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float sgr_exp2_cr(float x) {
+    const double xd = (double)x;
+    const double n = rint(xd);
+    const double t = (xd - n) * 0.693147180559945309417232121458;
+    double p = 1.0 / 6227020800.0;
+    p = fma(p, t, 1.0 / 479001600.0);
+    p = fma(p, t, 1.0 / 39916800.0);
+    p = fma(p, t, 1.0 / 3628800.0);
+    p = fma(p, t, 1.0 / 362880.0);
+    p = fma(p, t, 1.0 / 40320.0);
+    p = fma(p, t, 1.0 / 5040.0);
+    p = fma(p, t, 1.0 / 720.0);
+    p = fma(p, t, 1.0 / 120.0);
+    p = fma(p, t, 1.0 / 24.0);
+    p = fma(p, t, 1.0 / 6.0);
+    p = fma(p, t, 0.5);
+    p = fma(p, t, 1.0);
+    p = fma(p, t, 1.0);
+    return (float)ldexp(p, (int)n);
+}
+// the published test at exponent -|p| (mag = bits of |p|), evaluated like the CPU oracle does: power2 <= 0 and min(0.99, op * 2^power2) >= 1/255
+__device__ __forceinline__ bool alpha_passes(float op, uint32_t mag) {
+    return fminf(0.99f, op * sgr_exp2_cr(-__uint_as_float(mag))) >= (1.0f / 255.0f);
+}
+// p* = the SMALLEST exponent (exp2 domain, <= 0) at which a Gaussian of opacity `op` passes the alpha test; +inf if it never does.
+// alpha is monotone in the exponent, so  alpha >= 1/255  <=>  power2 >= p*  for every power2 <= 0.  Bisection over the bit patterns of
+// |p| between a bracket around log2(255 op) (hardware log: only an estimate) -- widened to all of [0, 127] if the estimate is off.
+__device__ __forceinline__ float sgr_alpha_threshold(float op) {
+    if (!(op >= (1.0f / 255.0f))) return __builtin_inff();      // (NaN included) op * G <= op < 1/255 for every G <= 1
+    uint32_t lo = 0u, hi = 0x42FE0000u;                         // |p| = 0 passes (alpha = min(0.99, op)); |p| = 127 never does
+    const float est = fminf(fmaxf(__log2f(op * 255.0f), 0.f), 126.f);
+    const uint32_t e = __float_as_uint(est), a = e > 8u ? e - 8u : 0u, b = e + 8u;
+    if (alpha_passes(op, a)) { lo = a; if (!alpha_passes(op, b)) hi = b; else lo = b; } else hi = a;
+    while (hi - lo > 1u) {                                      // invariant: lo passes, hi does not
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        if (alpha_passes(op, mid)) lo = mid; else hi = mid;
+    }
+    return -__uint_as_float(lo);
+}
+
 __device__ __forceinline__ void quat_to_rot(const float *q, float R[3][3]) {
     const float r = q[0], x = q[1], y = q[2], z = q[3];
     R[0][0] = 1.f - 2.f * (y * y + z * z); R[0][1] = 2.f * (x * y - r * z); R[0][2] = 2.f * (x * z + r * y);
@@ -189,12 +235,13 @@ __global__ __launch_bounds__(kPreThreads) void preprocess_fwd_kernel(SgrProblem 
     const bool live = i < pb.P;
     int cur_subj = -1;
     float p[3] = {0.f, 0.f, 0.f}, c6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, op = 0.f, rgb_in[3] = {0.f, 0.f, 0.f};
+    float pstar = __builtin_inff();                           // alpha-test threshold on the exponent: a function of the opacity alone
     for (int view = v0; view < v1; view++) {
     const int subj = view / pb.views_per_subject;
     const float *V = pb.viewmatrix + 16 * (size_t)view;
     const float *M = pb.projmatrix + 16 * (size_t)view;
     uint32_t tiles = 0;
-    float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = make_float4(0.f, 0.f, -1.f, -1.f);
+    float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = make_float4(0.f, 0.f, __uint_as_float(0xBF80BF80u), __builtin_inff());   // (half extents -1 | -1: never visible; p* = +inf: never valid)
     if (live) {
         const size_t q = (size_t)view * pb.P + i, sp = (size_t)subj * pb.P + i;
         if (subj != cur_subj) {                              // uniform: once per subject
@@ -203,6 +250,7 @@ __global__ __launch_bounds__(kPreThreads) void preprocess_fwd_kernel(SgrProblem 
             for (int k = 0; k < 3; k++) p[k] = pb.means3D[sp * 3 + k];
             load_cov3d(pb, sp, c6);
             op = pb.opacities[sp];
+            pstar = sgr_alpha_threshold(op);
             if (pb.colors_precomp) {
 #pragma unroll
                 for (int k = 0; k < 3; k++) rgb_in[k] = pb.colors_precomp[sp * 3 + k];   // untouched, no clamp
@@ -273,7 +321,11 @@ __global__ __launch_bounds__(kPreThreads) void preprocess_fwd_kernel(SgrProblem 
                     }
                     r0 = make_float4(px, py, cx, cy);
                     r1 = make_float4(cz, op, pv[2], rgb[0]);
-                    r2 = make_float4(rgb[1], rgb[2], hx, hy);
+                    // the two half extents travel as bf16 halves of ONE word, rounded UP (a cull bound may only grow: + <= 0.8 %), so that the
+                    // record's twelfth float is free for p*: no fourth 16-byte load per tile instance in the compositing kernels
+                    const uint32_t hxb = hx < 0.f ? 0xBF80u : (uint32_t)min(0x7F80u, (__float_as_uint(hx) + 0xFFFFu) >> 16);
+                    const uint32_t hyb = hy < 0.f ? 0xBF80u : (uint32_t)min(0x7F80u, (__float_as_uint(hy) + 0xFFFFu) >> 16);
+                    r2 = make_float4(rgb[1], rgb[2], __uint_as_float(hxb | (hyb << 16)), pstar);
                     rad_out = rad;
                     rect_out = make_uint2((uint32_t)minx | ((uint32_t)miny << 16), (uint32_t)maxx | ((uint32_t)maxy << 16));
                     tiles = (uint32_t)area;
@@ -413,7 +465,7 @@ struct ViewGrad { float mean[3], cov[6], op, col[3]; };
 // SH=false (the reference's colors_precomp path) compiles without the spherical-harmonics tables: no scratch, half the VGPRs
 template <bool SH>
 __device__ __forceinline__ void bwd_view(const SgrProblem &pb, int view, int i, size_t sp, const float (&p)[3], const float (&c6)[6], float fx, float fy,
-                                         const int32_t *__restrict__ radii, const uint8_t *__restrict__ clamped, const float4 *__restrict__ grec,
+                                         const int32_t *__restrict__ radii, const uint8_t *__restrict__ clamped,
                                          const uint4 *__restrict__ rect, const float4 *__restrict__ part, const uint32_t *__restrict__ flags,
                                          uint32_t n_inst, float *__restrict__ dL_dmeans2D, float *__restrict__ dL_dsh, ViewGrad &out) {
 #pragma unroll
@@ -423,10 +475,10 @@ __device__ __forceinline__ void bwd_view(const SgrProblem &pb, int view, int i, 
     out.op = 0.f;
     const size_t q = (size_t)view * pb.P + i;
     float *g2out = dL_dmeans2D ? dL_dmeans2D + q * 3 : nullptr;      // (NULL: nobody wants dL/dNDC)
-    const uint4 r3 = part ? rect[q] : make_uint4(0u, 0u, 0u, 0u);   // requested beside the radius, not behind it (one round trip less)
+    const uint4 r3 = rect[q];                                        // requested beside the radius, not behind it (one round trip less)
     if (!(radii[q] > 0)) { if (g2out) { g2out[0] = g2out[1] = g2out[2] = 0.f; } return; }
     float4 g0, g1, g2;
-    if (part) {
+    {
         // deterministic gather of the bucket-parallel backward's partial records: one per (tile instance, quadrant),
         // summed in tile order then quadrant order -- no atomics anywhere in the backward
         const uint32_t off = r3.w, rmin = r3.x, rmax = r3.y;
@@ -459,8 +511,6 @@ __device__ __forceinline__ void bwd_view(const SgrProblem &pb, int view, int i, 
             }
             f = fn;
         }
-    } else {
-        g0 = grec[q * 3 + 0]; g1 = grec[q * 3 + 1]; g2 = grec[q * 3 + 2];
     }
     const float *V = pb.viewmatrix + 16 * (size_t)view;
     const float *M = pb.projmatrix + 16 * (size_t)view;
@@ -600,7 +650,7 @@ __device__ __forceinline__ void bwd_finish(const SgrProblem &pb, size_t sp, cons
 }
 
 #define SGR_BWD_ARGS                                                                                                              \
-    SgrProblem pb, const int32_t *__restrict__ radii, const uint8_t *__restrict__ clamped, const float4 *__restrict__ grec,        \
+    SgrProblem pb, const int32_t *__restrict__ radii, const uint8_t *__restrict__ clamped,                                          \
     const uint4 *__restrict__ rect, const float4 *__restrict__ part, const uint32_t *__restrict__ flags, uint32_t n_inst,          \
     float *__restrict__ dL_dmeans3D, float *__restrict__ dL_dmeans2D, float *__restrict__ dL_dopacity,                              \
     float *__restrict__ dL_dcolors, float *__restrict__ dL_dsh, float *__restrict__ dL_dcov3D, float *__restrict__ dL_dscales,      \
@@ -624,7 +674,7 @@ __global__ __launch_bounds__(kPreThreads) void preprocess_bwd_kernel(SGR_BWD_ARG
     const int v0 = subj * pb.views_per_subject;
     for (int vv = 0; vv < pb.views_per_subject; vv++) {
         ViewGrad g;
-        bwd_view<SH>(pb, v0 + vv, i, sp, p, c6, fx, fy, radii, clamped, grec, rect, part, flags, n_inst, dL_dmeans2D, dL_dsh, g);
+        bwd_view<SH>(pb, v0 + vv, i, sp, p, c6, fx, fy, radii, clamped, rect, part, flags, n_inst, dL_dmeans2D, dL_dsh, g);
 #pragma unroll
         for (int k = 0; k < 6; k++) gcov[k] += g.cov[k];
         if (!SH) { gcol[0] += g.col[0]; gcol[1] += g.col[1]; gcol[2] += g.col[2]; }
@@ -649,7 +699,7 @@ __global__ __launch_bounds__(kPreThreads) __attribute__((amdgpu_waves_per_eu(5))
         const float p[3] = {pb.means3D[sp * 3 + 0], pb.means3D[sp * 3 + 1], pb.means3D[sp * 3 + 2]};
         float c6[6];
         load_cov3d(pb, sp, c6);
-        bwd_view<false>(pb, subj * vps + vv, i, sp, p, c6, fx, fy, radii, clamped, grec, rect, part, flags, n_inst, dL_dmeans2D, dL_dsh, g);
+        bwd_view<false>(pb, subj * vps + vv, i, sp, p, c6, fx, fy, radii, clamped, rect, part, flags, n_inst, dL_dmeans2D, dL_dsh, g);
 #pragma unroll
         for (int k = 0; k < 3; k++) { acc[k][t] = g.mean[k]; acc[10 + k][t] = g.col[k]; }
 #pragma unroll
@@ -758,13 +808,13 @@ static std::atomic<int> g_bwd_view_loop{0};     // read by the backward, i.e. on
 extern "C" int sgr_set_backward_gather(int mode) { g_bwd_view_loop.store(mode == 1 ? 1 : 0); return 0; }
 
 // n_inst: number of tile instances part / flags were sized for (the gather never reads beyond it)
-int sgr_preprocess_backward_ex(const SgrProblem *pb, const int32_t *radii, const uint8_t *clamped, const float *grec,
+int sgr_preprocess_backward_ex(const SgrProblem *pb, const int32_t *radii, const uint8_t *clamped,
                                const uint32_t *rect, const float *part, const uint32_t *flags, uint64_t n_inst, float *dL_dmeans3D, float *dL_dmeans2D,
                                float *dL_dopacity, float *dL_dcolors, float *dL_dsh, float *dL_dcov3D, float *dL_dscales, float *dL_drotations,
                                void *stream_) {
     if (validate_problem(pb)) return 1;
     if (pb->P == 0) return 0;
-    if (!grec && !(part && flags && rect)) { sgr_set_error("sgr_preprocess_backward: need grec, or rect + part + flags"); return 1; }
+    if (!(part && flags && rect)) { sgr_set_error("sgr_preprocess_backward: need rect + part + flags"); return 1; }
     if (pb->shs && (!dL_dsh || !clamped)) { sgr_set_error("dL_dsh / clamped required on the SH path"); return 1; }
     if (!pb->shs && !dL_dcolors) { sgr_set_error("dL_dcolors required on the colors_precomp path"); return 1; }
     if (pb->scales && (!dL_dscales || !dL_drotations)) { sgr_set_error("dL_dscales / dL_drotations required"); return 1; }
@@ -773,27 +823,27 @@ int sgr_preprocess_backward_ex(const SgrProblem *pb, const int32_t *radii, const
     dim3 grid(nbx, pb->n_views / pb->views_per_subject);
     { SgrProfScope _p(SGR_K_PREPROCESS_BWD, stream);
     if (pb->shs)
-        hipLaunchKernelGGL(preprocess_bwd_kernel<true>, grid, dim3(kPreThreads), 0, stream, *pb, radii, clamped, (const float4 *)grec,
+        hipLaunchKernelGGL(preprocess_bwd_kernel<true>, grid, dim3(kPreThreads), 0, stream, *pb, radii, clamped,
                            (const uint4 *)rect, (const float4 *)part, flags, (uint32_t)(n_inst > 0xFFFFFFFFull ? 0xFFFFFFFFull : n_inst), dL_dmeans3D, dL_dmeans2D, dL_dopacity, dL_dcolors, dL_dsh, dL_dcov3D, dL_dscales, dL_drotations);
     else if (pb->views_per_subject > 1 && pb->views_per_subject <= kPreThreads && kPreThreads % pb->views_per_subject == 0 && !g_bwd_view_loop.load()) {
         const int gpb = kPreThreads / pb->views_per_subject;
         hipLaunchKernelGGL(preprocess_bwd_lanes_kernel, dim3((pb->P + gpb - 1) / gpb, pb->n_views / pb->views_per_subject), dim3(kPreThreads), 0, stream, *pb,
-                           radii, clamped, (const float4 *)grec, (const uint4 *)rect, (const float4 *)part, flags,
+                           radii, clamped, (const uint4 *)rect, (const float4 *)part, flags,
                            (uint32_t)(n_inst > 0xFFFFFFFFull ? 0xFFFFFFFFull : n_inst), dL_dmeans3D, dL_dmeans2D, dL_dopacity, dL_dcolors, dL_dsh, dL_dcov3D,
                            dL_dscales, dL_drotations);
     } else
-        hipLaunchKernelGGL(preprocess_bwd_kernel<false>, grid, dim3(kPreThreads), 0, stream, *pb, radii, clamped, (const float4 *)grec,
+        hipLaunchKernelGGL(preprocess_bwd_kernel<false>, grid, dim3(kPreThreads), 0, stream, *pb, radii, clamped,
                            (const uint4 *)rect, (const float4 *)part, flags, (uint32_t)(n_inst > 0xFFFFFFFFull ? 0xFFFFFFFFull : n_inst), dL_dmeans3D, dL_dmeans2D, dL_dopacity, dL_dcolors, dL_dsh, dL_dcov3D, dL_dscales, dL_drotations);
     SGR_CHECK_LAUNCH("preprocess_bwd_kernel");
     }
     return 0;
 }
 
-extern "C" int sgr_preprocess_backward(const SgrProblem *pb, const int32_t *radii, const uint8_t *clamped, const float *grec,
+extern "C" int sgr_preprocess_backward(const SgrProblem *pb, const int32_t *radii, const uint8_t *clamped,
                                        const uint32_t *rect, const float *part, const uint32_t *flags, float *dL_dmeans3D, float *dL_dmeans2D, float *dL_dopacity, float *dL_dcolors,
                                        float *dL_dsh, float *dL_dcov3D, float *dL_dscales, float *dL_drotations,
                                        void *stream_) {
-    return sgr_preprocess_backward_ex(pb, radii, clamped, grec, rect, part, flags, ~0ull, dL_dmeans3D, dL_dmeans2D, dL_dopacity, dL_dcolors, dL_dsh,
+    return sgr_preprocess_backward_ex(pb, radii, clamped, rect, part, flags, ~0ull, dL_dmeans3D, dL_dmeans2D, dL_dopacity, dL_dcolors, dL_dsh,
                                       dL_dcov3D, dL_dscales, dL_drotations, stream_);
 }
 

@@ -26,21 +26,20 @@ int sgr_bin_ex(const SgrProblem *pb, const int32_t *radii, uint32_t *rect, const
                size_t workspace_bytes, uint32_t *ranges, int32_t *result_in_b_host, bool self_scan, uint64_t *nr_host, void *prep_desc,
                size_t prep_n_desc, uint32_t *prep_order, int *prep_done, uint32_t *const *clear_ptr, const uint64_t *clear_words,
                int *clear_done, bool first_index, bool sorted_keys, void *stream_);
-int sgr_render_backward_ex(const SgrProblem *pb, const uint32_t *ranges, const uint32_t *point_list, const float *rec, const uint32_t *rect, const float *final_T,
+int sgr_render_backward_ex(const SgrProblem *pb, const uint32_t *ranges, const float *rec, const uint32_t *rect,
                            const uint32_t *n_contrib, const float *out_color, const float *out_depth, const float *out_alpha,
                            const float *grad_color, const float *grad_depth, const float *grad_alpha, const float *grad_color_scale,
                            uint64_t R, const void *aux_compact, const void *aux_ckpt_tc, const void *aux_ckpt_da, const void *aux_desc,
-                           float *grec, float *part, uint32_t *flags, bool flags_cleared, int aux_layout, void *stream_);
-int sgr_preprocess_backward_ex(const SgrProblem *pb, const int32_t *radii, const uint8_t *clamped, const float *grec, const uint32_t *rect,
+                           float *part, uint32_t *flags, bool flags_cleared, void *stream_);
+int sgr_preprocess_backward_ex(const SgrProblem *pb, const int32_t *radii, const uint8_t *clamped, const uint32_t *rect,
                                const float *part, const uint32_t *flags, uint64_t n_inst, float *dL_dmeans3D, float *dL_dmeans2D, float *dL_dopacity,
                                float *dL_dcolors, float *dL_dsh, float *dL_dcov3D, float *dL_dscales, float *dL_drotations, void *stream_);
 int sgr_render_forward_wants_prepare(const SgrProblem *pb, uint64_t R, bool use_aux, size_t *n_desc_out);
 int sgr_render_forward_ex(const SgrProblem *pb, const uint32_t *ranges, const uint32_t *point_list, const float *rec, float *out_color,
                           float *out_depth, float *out_alpha, float *final_T, uint32_t *n_contrib, uint64_t R, void *aux_compact,
-                          void *aux_ckpt_tc, void *aux_ckpt_da, void *aux_desc, uint32_t *aux_order, bool prepared, int aux_layout, int kind, void *stream_);
+                          void *aux_ckpt_tc, void *aux_ckpt_da, void *aux_desc, uint32_t *aux_order, bool prepared, int kind, void *stream_);
 int sgr_render_forward_kind(const SgrProblem *pb);
 int sgr_get_forward_mode();
-int sgr_aux_layout_for(uint64_t NS);
 
 static int forward_launches(const SgrProblem *pb, uint64_t capacity, uint64_t R, SgrForwardState *st, float *out_color, float *out_depth,
                             float *out_alpha, int32_t *out_radii, uint64_t *nr_pinned_host, bool preprocess_done, void *caller_clear,
@@ -86,7 +85,7 @@ static int forward_launches(const SgrProblem *pb, uint64_t capacity, uint64_t R,
                               (float *)(image + st->off_final_T), (uint32_t *)(image + st->off_n_contrib), R,
                               aux_on ? image + st->off_compact : nullptr, aux_on ? image + st->off_ckpt_tc : nullptr,
                               (aux_on && !st->aux_no_da) ? image + st->off_ckpt_da : nullptr, aux_on ? image + st->off_desc : nullptr,
-                              (uint32_t *)(image + st->off_order), prep_done != 0, st->with_aux, st->fwd_kind, stream);
+                              (uint32_t *)(image + st->off_order), prep_done != 0, st->fwd_kind, stream);
 }
 
 extern "C" int sgr_rasterize_forward(const SgrProblem *pb, uint64_t capacity, int32_t with_aux, sgr_alloc_fn alloc, void *user,
@@ -160,7 +159,7 @@ extern "C" int sgr_rasterize_forward(const SgrProblem *pb, uint64_t capacity, in
     // ---- image blob
     const bool aux_on = with_aux && R > 0;
     const uint64_t NS = sgr_bucket_slots(R, tiles_total);
-    st->NS = NS; st->with_aux = aux_on ? sgr_aux_layout_for(NS) : 0;       // 0 none, 1 compact checkpoints, 2 one checkpoint per 16-survivor row
+    st->NS = NS; st->with_aux = aux_on ? 2 : 0;                             // 0 none, 2 one checkpoint per 16-survivor row (1 was round 2's compact layout)
     // with_aux & 2: the (depth, alpha) checkpoints -- a third of the checkpoint stream -- are not written now: only a backward that is
     // handed dL/ddepth or dL/dalpha reads them (no call path of the reference does), and it then produces them with a second compositing pass
     st->aux_no_da = (aux_on && (with_aux & 2)) ? 1 : 0;
@@ -172,7 +171,7 @@ extern "C" int sgr_rasterize_forward(const SgrProblem *pb, uint64_t capacity, in
     if (aux_on) {
         st->off_flags = o; o = align_up(o + R * 4);                // one byte per (tile instance, quadrant): partial record written by the backward
         st->off_compact = o; o = align_up(o + 4 * R * 8);
-        const uint64_t rows = st->with_aux == 2 ? 4 : 1;                    // checkpoint records per pixel and 64-survivor bucket
+        const uint64_t rows = 4;                                            // checkpoint records per pixel and 64-survivor bucket
         st->off_ckpt_tc = o; o = align_up(o + 4 * NS * rows * 64 * 16);
         st->off_ckpt_da = o; o = align_up(o + (st->aux_no_da ? 0 : 4 * NS * rows * 64 * 8));
         st->off_desc = o; o = align_up(o + 4 * NS * 8);
@@ -213,39 +212,53 @@ extern "C" int sgr_rasterize_backward(const SgrProblem *pb, const SgrForwardStat
                                       float *dL_dcov3D, float *dL_dscales, float *dL_drotations, void *stream_) {
     if (!pb || !st || !alloc) { sgr_set_error("sgr_rasterize_backward: NULL argument"); return 1; }
     if (pb->P <= 0) return 0;
+    hipStream_t stream = (hipStream_t)stream_;
     const uint64_t nq = (uint64_t)pb->n_views * (uint64_t)pb->P;
-    const bool aux_on = st->with_aux != 0;
-    // scratch: bucket-parallel path = partial records [4*R][10] f32 + flags [R] u32; pixel-parallel path = grec [nq][12] f32
+    if (st->with_aux == 0) {
+        // A forward without auxiliary outputs: either nothing was rendered (R == 0: every Gaussian culled or off screen -- sgr_rasterize_forward
+        // then records no lists or checkpoints whatever the caller asked for), and every gradient is zero; or the caller said it would not
+        // differentiate (with_aux = 0).  (Until round 4 the published pixel-parallel backward ran here.)
+        if (st->R_alloc != 0) { sgr_set_error("sgr_rasterize_backward: the forward ran without auxiliary outputs (with_aux = 0): nothing to differentiate through"); return 1; }
+        const uint64_t ns = (uint64_t)(pb->n_views / pb->views_per_subject) * (uint64_t)pb->P;
+        if (dL_dmeans3D) SGR_CHECK_HIP(hipMemsetAsync(dL_dmeans3D, 0, ns * 3 * 4, stream));
+        if (dL_dmeans2D) SGR_CHECK_HIP(hipMemsetAsync(dL_dmeans2D, 0, nq * 3 * 4, stream));
+        if (dL_dopacity) SGR_CHECK_HIP(hipMemsetAsync(dL_dopacity, 0, ns * 4, stream));
+        if (dL_dcolors) SGR_CHECK_HIP(hipMemsetAsync(dL_dcolors, 0, ns * 3 * 4, stream));
+        if (dL_dsh && pb->shs) SGR_CHECK_HIP(hipMemsetAsync(dL_dsh, 0, ns * (uint64_t)pb->M * 3 * 4, stream));
+        if (dL_dcov3D) SGR_CHECK_HIP(hipMemsetAsync(dL_dcov3D, 0, ns * 6 * 4, stream));
+        if (dL_dscales && pb->scales) SGR_CHECK_HIP(hipMemsetAsync(dL_dscales, 0, ns * 3 * 4, stream));
+        if (dL_drotations && pb->scales) SGR_CHECK_HIP(hipMemsetAsync(dL_drotations, 0, ns * 4 * 4, stream));
+        return 0;
+    }
+    // scratch: partial records [4*R][10] f32 (the flags [R] u32 live in the forward's image blob)
     const uint64_t part_bytes = align_up(st->R_alloc * 4 * SGR_PART_FLOATS * 4);
     // depth / alpha gradients on a forward that left their checkpoints out: room for them in the scratch blob, filled by a second
     // compositing pass below (same kernels, same lists: the same values the forward would have stored)
-    const bool da_refill = aux_on && st->aux_no_da && (grad_depth || grad_alpha);
-    const uint64_t da_bytes = da_refill ? align_up(4 * st->NS * (st->with_aux == 2 ? 4 : 1) * 64 * 8) : 0;
-    const uint64_t scratch_bytes = aux_on ? part_bytes + da_bytes : nq * SGR_REC_FLOATS * 4;
-    char *scratch = alloc(user, 3, (size_t)scratch_bytes);
+    const bool da_refill = st->aux_no_da && (grad_depth || grad_alpha);
+    const uint64_t da_bytes = da_refill ? align_up(4 * st->NS * 4 * 64 * 8) : 0;
+    char *scratch = alloc(user, 3, (size_t)(part_bytes + da_bytes));
     if (!scratch) { sgr_set_error("scratch allocator returned NULL"); return 1; }
-    float *part = aux_on ? (float *)scratch : nullptr;
-    uint32_t *flags = aux_on ? (uint32_t *)((char *)st->image + st->off_flags) : nullptr;     // lives in the forward's image blob
-    float *grec = aux_on ? nullptr : (float *)scratch;
+    float *part = (float *)scratch;
+    uint32_t *flags = (uint32_t *)((char *)st->image + st->off_flags);
     const char *geom = (const char *)st->geom, *binning = (const char *)st->binning, *image = (const char *)st->image;
     const float *rec = (const float *)(geom + st->off_rec);
     const uint32_t *rect = (const uint32_t *)(geom + st->off_rect);
-    const uint32_t *point_list = (const uint32_t *)(binning + (st->result_in_b ? st->off_vals_b : st->off_vals_a));
-    const void *ckpt_da = (aux_on && !st->aux_no_da) ? image + st->off_ckpt_da : nullptr;
+    const void *ckpt_da = !st->aux_no_da ? image + st->off_ckpt_da : nullptr;
     if (da_refill) {
         char *im = (char *)st->image;
         void *da = scratch + part_bytes;
+        const uint32_t *point_list = (const uint32_t *)(binning + (st->result_in_b ? st->off_vals_b : st->off_vals_a));
         if (sgr_render_forward_ex(pb, (const uint32_t *)(image + st->off_ranges), point_list, rec, (float *)out_color, (float *)out_depth, (float *)out_alpha,
                                   (float *)(im + st->off_final_T), (uint32_t *)(im + st->off_n_contrib), st->R_alloc, im + st->off_compact, nullptr, da,
-                                  im + st->off_desc, (uint32_t *)(im + st->off_order), /*prepared=*/true, st->with_aux, st->fwd_kind, stream_)) return 1;
+                                  im + st->off_desc, (uint32_t *)(im + st->off_order), /*prepared=*/true, st->fwd_kind, stream_)) return 1;
         ckpt_da = da;
     }
-    if (sgr_render_backward_ex(pb, (const uint32_t *)(image + st->off_ranges), point_list, rec, rect, (const float *)(image + st->off_final_T),
-                            (const uint32_t *)(image + st->off_n_contrib), out_color, out_depth, out_alpha, grad_color, grad_depth,
-                            grad_alpha, grad_color_scale, st->R_alloc, aux_on ? image + st->off_compact : nullptr, aux_on ? image + st->off_ckpt_tc : nullptr,
-                            ckpt_da, aux_on ? image + st->off_desc : nullptr, grec, part, flags, st->flags_cleared != 0, st->with_aux, stream_))
+    if (sgr_render_backward_ex(pb, (const uint32_t *)(image + st->off_ranges), rec, rect, (const uint32_t *)(image + st->off_n_contrib),
+                               out_color, out_depth, out_alpha, grad_color, grad_depth, grad_alpha, grad_color_scale, st->R_alloc,
+                               image + st->off_compact, image + st->off_ckpt_tc, ckpt_da, image + st->off_desc, part, flags,
+                               st->flags_cleared != 0, stream_))
         return 1;
-    return sgr_preprocess_backward_ex(pb, radii, pb->shs ? (const uint8_t *)(geom + st->off_clamped) : nullptr, grec, rect, part, flags, st->R_alloc,
-                                   dL_dmeans3D, dL_dmeans2D, dL_dopacity, dL_dcolors, dL_dsh, dL_dcov3D, dL_dscales, dL_drotations,
-                                   stream_);
+    return sgr_preprocess_backward_ex(pb, radii, pb->shs ? (const uint8_t *)(geom + st->off_clamped) : nullptr, rect, part, flags, st->R_alloc,
+                                      dL_dmeans3D, dL_dmeans2D, dL_dopacity, dL_dcolors, dL_dsh, dL_dcov3D, dL_dscales, dL_drotations,
+                                      stream_);
 }

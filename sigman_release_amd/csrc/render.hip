@@ -1,17 +1,25 @@
 // render.hip -- per-tile compositing kernels for gfx950 (CDNA4, wave64):
-//   F6  front-to-back alpha compositing -> color, depth, alpha (+ final_T, n_contrib)   (render_fwd_kernel)
-//   B1  per-pixel reverse walk -> per-(view,Gaussian) gradient records                  (render_bwd_kernel)
+//   F6  front-to-back alpha compositing -> color, depth, alpha (+ final_T, n_contrib)
+//         render_fwd_wave_kernel   one wave per (tile, 8x8 quadrant): batches of views (the chip is full)
+//         render_fwd_seg_kernel    eight waves per (tile, quadrant), segment-parallel: one or two views (the chip is not)
+//   B1  gradients of the compositing -> one partial record per (tile instance, quadrant)   (render_bwd_bucket_kernel)
 // Replaces renderCUDA forward/backward of the third-party rasterizer behind
 // /root/reference/core/gaussians/gs.py:98-106 and train_vae.py:166, for all views of a batch in ONE launch
-// (grid = n_views * tiles; the reference issues B*V separate launch chains, gs.py:62,75).
+// (the reference issues B*V separate launch chains, gs.py:62,75).
 //
-// Mapping: one workgroup = one 16x16 tile = 4 waves; wave w owns the 8x8 quadrant (w&1, w>>1) so that a
-// wave's 64 pixels are spatially compact (early termination and sub-tile culling are decided per wave).
-// Per 256-Gaussian batch the workgroup gathers the packed 48-B records (3 coalesced 16-B loads per thread)
-// into LDS once; each wave then builds, with __ballot over an exact per-Gaussian bounding test, the list of
-// Gaussians that can reach alpha >= 1/255 anywhere in ITS quadrant and walks only those (scalar bit loop,
-// LDS broadcast reads).  Culled Gaussians would have hit the published `alpha < 1/255 -> continue` rule for
-// every pixel of the quadrant, so results (including n_contrib) are unchanged by the cull.
+// A wave owns an 8x8 quadrant of a 16x16 tile, so that its 64 pixels are spatially compact: early termination and
+// sub-tile culling are decided per wave.  The tile list is culled for the quadrant with a ballot over an exact
+// per-Gaussian bounding test (the half extents of the alpha >= 1/255 ellipse, written by preprocess): culled
+// Gaussians would have hit the published `alpha < 1/255 -> continue` rule at every pixel of the quadrant, so results
+// (including n_contrib) are unchanged by the cull.
+//
+// THE ALPHA TEST.  The published rule `alpha = min(0.99, opacity * exp(power)); if (alpha < 1/255) continue` is a
+// threshold on the exponent: alpha is monotone in `power`, so for every Gaussian there is ONE float p* with
+//     alpha >= 1/255   <=>   power >= p*.
+// preprocess.hip computes p* per Gaussian with a correctly rounded exp2 (fp64, the same sequence of IEEE operations as
+// the CPU oracle) and stores it in the record (its twelfth float); the kernels below test `p* <= power <= 0` -- the same instruction count
+// as comparing alpha, but the decision no longer depends on the last bit of v_exp_f32: every forward kernel, the
+// backward and the CPU oracle take the same decision at every (pixel, Gaussian) pair, bit for bit.
 //
 // Roofline: algorithmic HBM bytes are 44 B per tile instance + 24 B (fwd) / 28 B (bwd) per pixel
 // (SURVEY.md 8d); with 3-4 px splats the inner loop is VALU-bound, not HBM-bound -- see DESIGN.md.
@@ -20,48 +28,31 @@
 
 namespace {
 
-constexpr int kBlock = 256;
 #ifndef SGR_FWD_G
-#define SGR_FWD_G 2            // Gaussians per iteration of the serial forward kernel: 2 -> 72 VGPRs (7 waves/SIMD); 4 -> 96 VGPRs is 12% slower at 64 views
+#define SGR_FWD_G 2            // Gaussians per iteration of the wave forward: 2 -> 70 VGPRs (7 waves/SIMD); 4 is 12% slower at 64 views
 #endif
 constexpr float kLog2e = -1.4426950408889634f;          // conic.xy is pre-multiplied by -log2(e)
 constexpr float kHalfLog2e = -0.7213475204444817f;      // conic.xx / conic.yy by -0.5*log2(e)
+constexpr float kNever = __builtin_inff();              // p* of an entry that must never pass the alpha test (null padding)
 
-struct Quad {
-    uint32_t view, tile, tx, ty;
-    int px, py;
-    bool inside;
-};
-
-__device__ __forceinline__ uint32_t cull_mask(const float4 &a, const float4 &c, float x0, float y0) {
-    const float gx = a.x, gy = a.y, hx = c.z, hy = c.w;
-    if (hx < 0.f) return 0u;                       // opacity <= 1/255: can never pass the alpha floor
-    const float lox = gx - hx, hix = gx + hx, loy = gy - hy, hiy = gy + hy;
-    const bool xl = (hix >= x0) && (lox <= x0 + 7.f);
-    const bool xr = (hix >= x0 + 8.f) && (lox <= x0 + 15.f);
-    const bool yt = (hiy >= y0) && (loy <= y0 + 7.f);
-    const bool yb = (hiy >= y0 + 8.f) && (loy <= y0 + 15.f);
-    return (uint32_t)(xl && yt) | ((uint32_t)(xr && yt) << 1) | ((uint32_t)(xl && yb) << 2) | ((uint32_t)(xr && yb) << 3);
-}
-
-// the same test for ONE quadrant whose first pixel is (qx0, qy0)
+// bounding test of the alpha >= 1/255 ellipse against the quadrant whose first pixel is (qx0, qy0)
+// (c.z = the two half extents as bf16 halves of one word, rounded up by preprocess: hx in the low half, hy in the high half; c.w = p*)
 __device__ __forceinline__ bool cull_quadrant(const float4 &a, const float4 &c, float qx0, float qy0) {
-    const float hx = c.z, hy = c.w;
-    if (hx < 0.f) return false;
+    const uint32_t h2 = __float_as_uint(c.z);
+    const float hx = __uint_as_float(h2 << 16), hy = __uint_as_float(h2 & 0xFFFF0000u);
+    if (hx < 0.f) return false;                    // opacity <= 1/255: can never pass the alpha floor
     return (a.x + hx >= qx0) && (a.x - hx <= qx0 + 7.f) && (a.y + hy >= qy0) && (a.y - hy <= qy0 + 7.f);
 }
 
 // auxiliary forward outputs that feed the bucket-parallel backward (all optional; see sgr_render_forward)
 struct FwdAux {
     uint2 *compact;       // [4][R]  per (tile, quadrant) culled list in order: (record id, 0-based index in the tile list)
-    // Checkpoints, two layouts (AUX template argument of the forward kernels / ROWS of the backward):
-    //   AUX = 2 "rows" (default, fastest):  [4*NS][4][64]  per bucket, per 16-survivor row, per pixel: (T, C0, C1, C2) before the row's first
-    //           survivor.  T is absolute.  With rps = rows per forward segment (1..4, in the descriptor): rows with r % rps == 0 start a
-    //           segment and hold ABSOLUTE composited sums, the others hold the sums accumulated since their segment's start (row r - r % rps).
-    //   AUX = 1 "compact":  [4*NS][64]  per bucket, per pixel: the absolute state before the bucket's first survivor only; the backward
-    //           rebuilds the states in front of rows 1..3 with a 48-step walk.  4x less checkpoint footprint and traffic, backward +55 %
-    //           (measured at C3: 1.33 -> 2.06 ms for a forward gain of 0.12 ms; selected when the row layout would not fit, rasterize.hip).
-    //   The row / bucket at ordinal 0 of a list is never stored (T = 1, sums = 0).
+    // Checkpoints [4*NS][4][64]: per bucket of 64 survivors, per 16-survivor row, per pixel: (T, C0, C1, C2) before the row's first
+    // survivor.  T is absolute.  With rps = rows per forward segment (1..4, in the descriptor): rows with r % rps == 0 start a
+    // segment and hold ABSOLUTE composited sums, the others hold the sums accumulated since their segment's start (row r - r % rps).
+    // The row at ordinal 0 of a list is never stored (T = 1, sums = 0).
+    // (Round 2 also had a "compact" layout -- one checkpoint per bucket, the inner rows rebuilt by the backward: 4x smaller, backward
+    // +55 % -- selected when the rows would not fit 8 GiB; no BASELINE config came near that, removed in round 5.)
     float4 *ckpt_tc;      // NULL: "depth/alpha only" pass (see ckpt_da): nothing but ckpt_da is written, no outputs either
     float2 *ckpt_da;      // same for (D, A).  NULL: not stored -- only a backward with dL/ddepth or dL/dalpha reads them (never on the reference's
                           // call paths), so by default they are produced on demand by a second compositing pass with ckpt_tc = NULL
@@ -71,15 +62,11 @@ struct FwdAux {
     float *clamped;       // optional [n_views,3,H,W]: clamp(colour, 0, 1) next to the unclamped colours (SgrProblem.color_clamped: gs.py:107 folded in)
 };
 
-// -------------------------------------------------------------------------------------------------
-// F6.  AUX=true additionally records what the bucket-parallel backward needs: the per-quadrant culled
-// lists, a per-pixel state checkpoint every 64 surviving Gaussians, and one descriptor per bucket.
-
 // Sums of products are written with their fused multiply-adds spelled out.  `a*b + c*d` may be contracted with either product inside
 // the fma, the compiler picks by operand arrival, and the pick differed between kernels (round 3: the wave forward fused the kyy term
 // of the exponent, the segment-parallel forward and the backward the kxy term; the backward's colour dot changed its order when its LDS
-// reads moved).  Written out, every forward kernel and the backward agree TO THE BIT on a Gaussian's exponent -- hence on which Gaussians
-// pass the alpha test at a pixel -- and a kernel's results do not depend on its instantiation or on the compiler's schedule.
+// reads moved).  Written out, every forward kernel, the backward AND the CPU oracle (its ref_power2) agree TO THE BIT
+// on a Gaussian's exponent at a pixel.
 __device__ __forceinline__ float sgr_power2(float kxx, float kyy, float kxy, float dx, float dy) {   // (exp2 domain: conic pre-scaled)
     return fmaf(dx, kxx * dx, fmaf(kxy * dx, dy, (kyy * dy) * dy));
 }
@@ -87,166 +74,18 @@ __device__ __forceinline__ float sgr_dot3(float a0, float b0, float a1, float b1
     return fmaf(a2, b2, fmaf(a1, b1, a0 * b0));
 }
 // -------------------------------------------------------------------------------------------------
-template <int AUX>
-__global__ __launch_bounds__(kBlock) void render_fwd_kernel(int W, int H, int Tx, uint32_t tiles_per_view,
-                                                            const uint2 *__restrict__ ranges,
-                                                            const uint32_t *__restrict__ point_list,
-                                                            const float4 *__restrict__ rec, const float *__restrict__ bg,
-                                                            float *__restrict__ out_color, float *__restrict__ out_depth,
-                                                            float *__restrict__ out_alpha, float *__restrict__ final_T,
-                                                            uint32_t *__restrict__ n_contrib, FwdAux aux) {
-    __shared__ float4 sA[kBlock + 1], sB[kBlock + 1], sC[kBlock + 1];   // entry 256 = null Gaussian (opacity 0)
-    __shared__ uint32_t sMask[kBlock];
-    __shared__ uint32_t sId[kBlock];
-    __shared__ __attribute__((aligned(8))) uint16_t sList[4][kBlock + 8];
-    const uint32_t bid = sgr_xcd_remap(blockIdx.x, gridDim.x);
-    const uint32_t view = bid / tiles_per_view, tile = bid - view * tiles_per_view;
-    const uint32_t tx = tile % Tx, ty = tile / Tx;
-    const uint2 range = ranges[bid];
-    const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
-    const int px = (int)tx * 16 + (wave & 1) * 8 + (lane & 7);
-    const int py = (int)ty * 16 + (wave >> 1) * 8 + (lane >> 3);
-    const bool inside = px < W && py < H;
-    const float pxf = (float)px, pyf = (float)py;
-    const float x0 = (float)(tx * 16), y0 = (float)(ty * 16);
-    const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    bool done = !inside;
-    float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f, D = 0.f, A = 0.f;
-    float B0 = 0.f, B1 = 0.f, B2 = 0.f, BD = 0.f, BA = 0.f;   // AUX = 2: composited sums at the start of the current 64-survivor bucket
-    uint32_t last = 0, lastk = 0;
-    uint32_t kbase = 0;                                  // survivors of this wave's quadrant in earlier batches
-    const int n = (int)(range.y - range.x);
-    const int rounds = (n + kBlock - 1) / kBlock;
-    const size_t slot0 = (size_t)wave * aux.NS + (range.x >> 6) + (size_t)bid;         // first bucket slot of (tile, quadrant)
-    if (t == 0) { sA[kBlock] = make_float4(0.f, 0.f, 0.f, 0.f); sB[kBlock] = sA[kBlock]; sC[kBlock] = sA[kBlock]; }
-    for (int r = 0; r < rounds; r++) {
-        if (__syncthreads_count(done) == kBlock) break;      // also the barrier that protects LDS reuse
-        const int idx = r * kBlock + t;
-        uint32_t m = 0;
-        if (idx < n) {
-            const uint32_t id = point_list[range.x + idx];
-            const float4 a = rec[(size_t)id * 4 + 0], b = rec[(size_t)id * 4 + 1], c = rec[(size_t)id * 4 + 2];
-            // conic pre-scaled into the exp2 domain: exp(power) = exp2(kxx dx^2 + kyy dy^2 + kxy dx dy)
-            sA[t] = make_float4(a.x, a.y, kHalfLog2e * a.z, kLog2e * a.w);
-            sB[t] = make_float4(kHalfLog2e * b.x, b.y, b.z, b.w);
-            sC[t] = c;
-            sId[t] = id;
-            m = cull_mask(a, c, x0, y0);
-        }
-        sMask[t] = m;
-        __syncthreads();
-        // ---- wave-private culled list of this batch (ballot + prefix popcount), padded with the null entry
-        uint32_t cnt = 0;
-#pragma unroll
-        for (int ch = 0; ch < 4; ch++) {
-            const bool bit = (sMask[ch * 64 + lane] >> wave) & 1u;
-            const uint64_t bal = __ballot(bit);
-            if (bit) sList[wave][cnt + (uint32_t)__popcll(bal & lt_mask)] = (uint16_t)(ch * 64 + lane);
-            cnt += (uint32_t)__popcll(bal);
-        }
-        if (lane < 4) sList[wave][cnt + lane] = (uint16_t)kBlock;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        uint64_t active = __ballot(!done);
-        if (AUX && active && aux.ckpt_tc) {
-            uint2 *dst = aux.compact + (size_t)wave * aux.R + range.x + kbase;
-            for (uint32_t g = lane; g < cnt; g += 64) {
-                const uint32_t j = sList[wave][g];
-                dst[g] = make_uint2(sId[j], (uint32_t)(r * kBlock) + j);
-            }
-        }
-        for (uint32_t g = 0; g < cnt && active; g += SGR_FWD_G) {
-            int js[SGR_FWD_G];
-#pragma unroll
-            for (int u = 0; u < SGR_FWD_G; u++) js[u] = sList[wave][g + u];
-            float4 a[SGR_FWD_G], b[SGR_FWD_G], c[SGR_FWD_G];
-            float al[SGR_FWD_G];
-            bool valid[SGR_FWD_G];
-#pragma unroll
-            for (int u = 0; u < SGR_FWD_G; u++) { a[u] = sA[js[u]]; b[u] = sB[js[u]]; c[u] = sC[js[u]]; }
-#pragma unroll
-            for (int u = 0; u < SGR_FWD_G; u++) {
-                const float dx = a[u].x - pxf, dy = a[u].y - pyf;
-                const float power = sgr_power2(a[u].z, b[u].x, a[u].w, dx, dy);
-                const float alpha = fminf(0.99f, b[u].y * __builtin_amdgcn_exp2f(power));
-                valid[u] = (power <= 0.f) & (alpha >= (1.0f / 255.0f));
-                al[u] = valid[u] ? alpha : 0.f;
-            }
-            // sequential part, branch-free: the only loop-carried chain is T -> test_T -> (stop) -> T
-#pragma unroll
-            for (int u = 0; u < SGR_FWD_G; u++) {
-                const uint32_t ord = kbase + g + u;                       // ordinal of this survivor in the quadrant list
-                if constexpr (AUX == 2) {
-                    if ((ord & 15u) == 0u && ord != 0u && g + u < cnt) {
-                        const uint32_t row = (ord >> 4) & 3u;
-                        const size_t s = ((slot0 + (ord >> 6)) * 4 + row) * 64 + lane;
-                        if (row == 0u) { B0 = C0; B1 = C1; B2 = C2; BD = D; BA = A; }       // bucket start: absolute state
-                        if (aux.ckpt_tc) aux.ckpt_tc[s] = row ? make_float4(T, C0 - B0, C1 - B1, C2 - B2) : make_float4(T, C0, C1, C2);
-                        if (aux.ckpt_da) aux.ckpt_da[s] = row ? make_float2(D - BD, A - BA) : make_float2(D, A);
-                    }
-                } else if constexpr (AUX == 1) {
-                    if ((ord & 63u) == 0u && ord != 0u && g + u < cnt) {                    // bucket start: absolute state
-                        const size_t s = (slot0 + (ord >> 6)) * 64 + lane;
-                        if (aux.ckpt_tc) aux.ckpt_tc[s] = make_float4(T, C0, C1, C2);
-                        if (aux.ckpt_da) aux.ckpt_da[s] = make_float2(D, A);
-                    }
-                }
-                const float test_T = T * (1.f - al[u]);
-                done = done | (valid[u] & (test_T < 0.0001f));            // the crossing Gaussian is NOT composited
-                const bool contrib = valid[u] & !done;
-                const float w = contrib ? al[u] * T : 0.f;
-                C0 = fmaf(b[u].w, w, C0); C1 = fmaf(c[u].x, w, C1); C2 = fmaf(c[u].y, w, C2);
-                D = fmaf(b[u].z, w, D);
-                A += w;
-                T = contrib ? test_T : T;
-                last = contrib ? (uint32_t)(r * kBlock + js[u] + 1) : last;
-                if (AUX) lastk = contrib ? ord + 1 : lastk;
-            }
-            active = __ballot(!done);
-        }
-        kbase += cnt;
-    }
-    if (inside && !(AUX && !aux.ckpt_tc)) {
-        const size_t hw = (size_t)H * W;
-        const size_t pix = (size_t)py * W + px;
-        const size_t vb = (size_t)view * hw;
-        final_T[vb + pix] = T;
-        n_contrib[vb + pix] = last;
-        const float o0 = C0 + T * bg[0], o1 = C1 + T * bg[1], o2 = C2 + T * bg[2];
-        out_color[(vb * 3) + pix] = o0;
-        out_color[(vb * 3) + hw + pix] = o1;
-        out_color[(vb * 3) + 2 * hw + pix] = o2;
-        if (aux.clamped) {
-            aux.clamped[(vb * 3) + pix] = fminf(fmaxf(o0, 0.f), 1.f);
-            aux.clamped[(vb * 3) + hw + pix] = fminf(fmaxf(o1, 0.f), 1.f);
-            aux.clamped[(vb * 3) + 2 * hw + pix] = fminf(fmaxf(o2, 0.f), 1.f);
-        }
-        out_depth[vb + pix] = D;
-        out_alpha[vb + pix] = A;
-    }
-    if (AUX) {
-        uint32_t kmax = lastk;                                 // survivors up to the last one that blended anywhere in the quadrant
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, off, 64));
-        const uint32_t nb = (kmax + 63u) >> 6;
-        for (uint32_t bk = lane; bk < nb && aux.ckpt_tc; bk += 64)
-            aux.desc[slot0 + bk] = make_uint2(bid | (3u << 30), (bk << 13) | min(64u, kmax - (bk << 6)));   // rps = 4: rows 1-3 relative to row 0
-    }
-}
-
-// -------------------------------------------------------------------------------------------------
-// F6, one WAVE per (tile, quadrant) -- the default for launches that fill the chip (batches of views).  The per-tile kernel above stages
-// 256 entries per workgroup barrier and keeps all four quadrant waves until the last one is done; here every quadrant is its own
+// F6, one WAVE per (tile, quadrant) -- the default for launches that fill the chip (batches of views).  Every quadrant is its own
 // 64-thread workgroup: it walks the tile list in batches of 64 entries (lane j stages entry j: record prefetched one batch ahead, ids
-// two ahead), culls them for its own 8x8 pixels with one ballot, and composites the survivors with the same arithmetic -- no workgroup
+// two ahead), culls them for its own 8x8 pixels with one ballot, and composites the survivors -- no workgroup
 // barrier anywhere, a quadrant whose pixels have all stopped ends at once and frees its SIMD slot.  The four waves of a tile re-read the
 // tile's records (L2 hits: workgroups b, b+8, b+16, b+24 are the four quadrants of one tile and run on the same XCD).
-// Outputs, auxiliary outputs and bucket layout are identical to render_fwd_kernel's.
 // -------------------------------------------------------------------------------------------------
 constexpr int kWaveBatch = 64;
+#ifndef SGR_WAVE_AUX_WAVES
+#define SGR_WAVE_AUX_WAVES 7   // waves per SIMD asked for the checkpointing instantiation: 7 = 68 VGPRs without spills; 8 = 64 VGPRs + 16 B of scratch
+#endif
 template <int AUX>
-__global__ __launch_bounds__(64) void render_fwd_wave_kernel(int W, int H, int Tx, uint32_t tiles_per_view, uint32_t tiles_total,
+__global__ __launch_bounds__(64, AUX ? SGR_WAVE_AUX_WAVES : 8) void render_fwd_wave_kernel(int W, int H, int Tx, uint32_t tiles_per_view, uint32_t tiles_total,
                                                              const uint2 *__restrict__ ranges,
                                                              const uint32_t *__restrict__ point_list,
                                                              const float4 *__restrict__ rec, const float *__restrict__ bg,
@@ -270,7 +109,6 @@ __global__ __launch_bounds__(64) void render_fwd_wave_kernel(int W, int H, int T
     const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     bool done = !inside;
     float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f, D = 0.f, A = 0.f;
-    float B0 = 0.f, B1 = 0.f, B2 = 0.f, BD = 0.f, BA = 0.f;   // AUX = 2: composited sums at the start of the current 64-survivor bucket
     uint32_t last = 0, lastk = 0;
     uint32_t kbase = 0;                                  // survivors of this quadrant in earlier batches
     const int n = (int)(range.y - range.x);
@@ -292,11 +130,11 @@ __global__ __launch_bounds__(64) void render_fwd_wave_kernel(int W, int H, int T
         if (bit) {
             sA[pos] = make_float4(ra.x, ra.y, kHalfLog2e * ra.z, kLog2e * ra.w);
             sB[pos] = make_float4(kHalfLog2e * rb.x, rb.y, rb.z, rb.w);
-            sC[pos] = rc;
+            sC[pos] = rc;                                               // (g, b, -, p*)
             sJ[pos] = (uint16_t)lane;
             if (AUX && aux.ckpt_tc) aux.compact[(size_t)q * aux.R + range.x + kbase + pos] = make_uint2(rid, (uint32_t)(base + lane));
         }
-        if (lane == 0) { sA[cnt] = make_float4(0.f, 0.f, 0.f, 0.f); sB[cnt] = sA[cnt]; sC[cnt] = sA[cnt]; }      // null Gaussian behind an odd count
+        if (lane == 0) { sA[cnt] = make_float4(0.f, 0.f, 0.f, 0.f); sB[cnt] = sA[cnt]; sC[cnt] = make_float4(0.f, 0.f, 0.f, kNever); }      // null Gaussian behind an odd count: never valid
         // ---- next batch: records now, ids of the batch after it
         {
             const int nx = base + kWaveBatch + lane;
@@ -310,12 +148,10 @@ __global__ __launch_bounds__(64) void render_fwd_wave_kernel(int W, int H, int T
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         uint32_t lastg = 0xFFFFFFFFu;                                   // survivor of this batch that contributed last to my pixel
         uint64_t active = __builtin_amdgcn_ballot_w64(!done);
-        // AUX: bit g = a checkpoint is due in front of survivor g of this batch -- its ordinal kbase + g is a multiple of 16 (rows) / 64
-        // (compact) and not 0.  One scalar mask per batch instead of three scalar compares per survivor (the walk is a serial chain per
+        // AUX: bit g = a checkpoint is due in front of survivor g of this batch -- its ordinal kbase + g is a multiple of 16 and not 0.  One scalar mask per batch instead of three scalar compares per survivor (the walk is a serial chain per
         // wave: every instruction in it is latency; the checkpoint bookkeeping was 8 of its 22 scalar instructions per survivor).
         uint64_t ck = 0;
-        if constexpr (AUX == 2) ck = 0x0001000100010001ull << ((0u - kbase) & 15u);
-        else if constexpr (AUX == 1) ck = 1ull << ((0u - kbase) & 63u);
+        if constexpr (AUX != 0) ck = 0x0001000100010001ull << ((0u - kbase) & 15u);
         if constexpr (AUX != 0) {
             if (kbase == 0u) ck &= ~1ull;
             if (cnt < 64u) ck &= (1ull << cnt) - 1ull;
@@ -335,7 +171,7 @@ __global__ __launch_bounds__(64) void render_fwd_wave_kernel(int W, int H, int T
                 const float dx = a[u].x - pxf, dy = a[u].y - pyf;
                 const float power = sgr_power2(a[u].z, b[u].x, a[u].w, dx, dy);
                 const float alpha = fminf(0.99f, b[u].y * __builtin_amdgcn_exp2f(power));
-                valid[u] = (power <= 0.f) & (alpha >= (1.0f / 255.0f));
+                valid[u] = (power <= 0.f) & (power >= c[u].w);            // p* <= power <= 0  <=>  the published alpha test (see the file header)
                 al[u] = valid[u] ? alpha : 0.f;
             }
             // sequential part, branch-free: the only loop-carried chain is T -> test_T -> (stop) -> T
@@ -343,17 +179,11 @@ __global__ __launch_bounds__(64) void render_fwd_wave_kernel(int W, int H, int T
 #pragma unroll
             for (int u = 0; u < SGR_FWD_G; u++) {
                 const uint32_t ord = kbase + g + u;                       // ordinal of this survivor in the quadrant list
-                if constexpr (AUX == 2) {
+                if constexpr (AUX != 0) {
                     if (__builtin_expect((due >> u) & 1u, 0u)) {
-                        const uint32_t row = (ord >> 4) & 3u;
-                        const size_t s = ((slot0 + (ord >> 6)) * 4 + row) * 64 + lane;
-                        if (row == 0u) { B0 = C0; B1 = C1; B2 = C2; BD = D; BA = A; }       // bucket start: absolute state
-                        if (aux.ckpt_tc) aux.ckpt_tc[s] = row ? make_float4(T, C0 - B0, C1 - B1, C2 - B2) : make_float4(T, C0, C1, C2);
-                        if (aux.ckpt_da) aux.ckpt_da[s] = row ? make_float2(D - BD, A - BA) : make_float2(D, A);
-                    }
-                } else if constexpr (AUX == 1) {
-                    if (__builtin_expect((due >> u) & 1u, 0u)) {                                                  // bucket start: absolute state
-                        const size_t s = (slot0 + (ord >> 6)) * 64 + lane;
+                        // every row holds the ABSOLUTE state (descriptor: one row per segment); the segment-parallel kernel can only give
+                        // its inner rows relative to their segment's start
+                        const size_t s = ((slot0 + (ord >> 6)) * 4 + ((ord >> 4) & 3u)) * 64 + lane;
                         if (aux.ckpt_tc) aux.ckpt_tc[s] = make_float4(T, C0, C1, C2);
                         if (aux.ckpt_da) aux.ckpt_da[s] = make_float2(D, A);
                     }
@@ -405,7 +235,7 @@ __global__ __launch_bounds__(64) void render_fwd_wave_kernel(int W, int H, int T
         for (int off = 32; off > 0; off >>= 1) kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, off, 64));
         const uint32_t nb = (kmax + 63u) >> 6;
         for (uint32_t bk = lane; bk < nb && aux.ckpt_tc; bk += 64)
-            aux.desc[slot0 + bk] = make_uint2(bid | (3u << 30), (bk << 13) | min(64u, kmax - (bk << 6)));   // rps = 4: rows 1-3 relative to row 0
+            aux.desc[slot0 + bk] = make_uint2(bid, (bk << 13) | min(64u, kmax - (bk << 6)));                // rps = 1: every row absolute
     }
 }
 
@@ -442,7 +272,7 @@ __global__ __launch_bounds__(kSegThreads, 4) void render_fwd_seg_kernel(int W, i
     // per-pixel arithmetic of both runs as packed fp32 (v_pk_*: two survivors per instruction) straight out of ds_read_b128:
     __shared__ float4 pA[kSegRing / 2], pB[kSegRing / 2], pC[kSegRing / 2];   // (x0,x1,y0,y1) (kxx0,kxx1,kxy0,kxy1) (kyy0,kyy1,op0,op1)
     __shared__ float4 pD[kSegRing / 2], pE[kSegRing / 2];                     // (r0,g0,r1,g1) (b0,depth0,b1,depth1): per-survivor channel pairs
-    __shared__ uint2 pI[kSegRing / 2];                                        // (list index + 1) of both
+    __shared__ float4 pQ[kSegRing / 2];                                       // (p*0, p*1, bits of (list index + 1) of both): phase 1 reads the first half
     __shared__ float sT[kSegWaves][64];
     __shared__ float sAcc[kSegWaves][5][64];
     __shared__ float sTstop[64];
@@ -528,12 +358,13 @@ __global__ __launch_bounds__(kSegThreads, 4) void render_fwd_seg_kernel(int W, i
                 const uint32_t s = (qhead + ord) & (kSegRing - 1);
                 const uint32_t pr = s >> 1, h = s & 1u;
                 float *fa = (float *)&pA[pr], *fb = (float *)&pB[pr], *fc = (float *)&pC[pr], *fd = (float *)&pD[pr], *fe = (float *)&pE[pr];
+                float *fq = (float *)&pQ[pr];
                 fa[h] = ra.x; fa[2 + h] = ra.y;
                 fb[h] = kHalfLog2e * ra.z; fb[2 + h] = kLog2e * ra.w;
                 fc[h] = kHalfLog2e * rb.x; fc[2 + h] = rb.y;
                 fd[2 * h] = rb.w; fd[2 * h + 1] = rc.x;
                 fe[2 * h] = rc.y; fe[2 * h + 1] = rb.z;
-                ((uint32_t *)&pI[pr])[h] = (uint32_t)idx + 1u;
+                fq[h] = rc.w; fq[2 + h] = __uint_as_float((uint32_t)idx + 1u);       // rc.w = p*
                 if (AUX && aux.ckpt_tc) aux.compact[(size_t)q * aux.R + range.x + kbase + ord] = make_uint2(rid, (uint32_t)idx);
             }
             qcount += m;
@@ -560,9 +391,10 @@ __global__ __launch_bounds__(kSegThreads, 4) void render_fwd_seg_kernel(int W, i
             const uint32_t s = (qhead + m + (uint32_t)t) & (kSegRing - 1);
             const uint32_t pr = s >> 1, h = s & 1u;
             float *fa = (float *)&pA[pr], *fb = (float *)&pB[pr], *fc = (float *)&pC[pr], *fd = (float *)&pD[pr], *fe = (float *)&pE[pr];
-            fa[h] = 0.f; fa[2 + h] = 0.f; fb[h] = 0.f; fb[2 + h] = 0.f; fc[h] = 0.f; fc[2 + h] = 0.f;      // opacity 0: never valid
+            float *fq = (float *)&pQ[pr];
+            fa[h] = 0.f; fa[2 + h] = 0.f; fb[h] = 0.f; fb[2 + h] = 0.f; fc[h] = 0.f; fc[2 + h] = 0.f;      // opacity 0 ...
             fd[2 * h] = 0.f; fd[2 * h + 1] = 0.f; fe[2 * h] = 0.f; fe[2 * h + 1] = 0.f;
-            ((uint32_t *)&pI[pr])[h] = 0u;
+            fq[h] = kNever; fq[2 + h] = 0.f;                                                                  // ... and p* = +inf: never valid
         }
         if (m & 3u) __syncthreads();
 #define SGR_RING(S) ((qhead + (S)) & (kSegRing - 1))
@@ -575,14 +407,15 @@ __global__ __launch_bounds__(kSegThreads, 4) void render_fwd_seg_kernel(int W, i
 #pragma unroll
             for (int u = 0; u < 2; u++) {                                  // two pairs = four survivors
                 const float4 qa = pA[pb + u], qb = pB[pb + u], qc = pC[pb + u];
+                const float2 ps = *reinterpret_cast<const float2 *>(&pQ[pb + u]);      // (p*0, p*1)
                 const v2f gx = {qa.x, qa.y}, gy = {qa.z, qa.w}, kxx = {qb.x, qb.y}, kxy = {qb.z, qb.w}, kyy = {qc.x, qc.y}, op = {qc.z, qc.w};
                 const v2f dx = gx - px2, dy = gy - py2;
                 const v2f power = __builtin_elementwise_fma(dx, kxx * dx, __builtin_elementwise_fma(kxy * dx, dy, (kyy * dy) * dy));   // == sgr_power2 per element
                 const v2f G = {__builtin_amdgcn_exp2f(power.x), __builtin_amdgcn_exp2f(power.y)};
                 const v2f og = op * G;
                 const float a0 = fminf(0.99f, og.x), a1 = fminf(0.99f, og.y);
-                om[2 * u] = ((power.x <= 0.f) & (a0 >= (1.0f / 255.0f))) ? 1.f - a0 : 1.f;
-                om[2 * u + 1] = ((power.y <= 0.f) & (a1 >= (1.0f / 255.0f))) ? 1.f - a1 : 1.f;
+                om[2 * u] = ((power.x <= 0.f) & (power.x >= ps.x)) ? 1.f - a0 : 1.f;          // p* <= power <= 0: the published alpha test
+                om[2 * u + 1] = ((power.y <= 0.f) & (power.y >= ps.y)) ? 1.f - a1 : 1.f;
             }
             Tseg = (((Tseg * om[0]) * om[1]) * om[2]) * om[3];
         }
@@ -602,7 +435,7 @@ __global__ __launch_bounds__(kSegThreads, 4) void render_fwd_seg_kernel(int W, i
         // the full 51 instructions per survivor for nothing -- a third of the evaluated pairs on the opaque C2 subject)
         if (__ballot(!done))
         for (uint32_t s = s0; s < s1; s += 4) {
-            if constexpr (AUX == 2) {
+            if constexpr (AUX != 0) {
                 if (s != s0 && ((s - s0) & 15u) == 0u) {
                     // state at survivor 16 / 32 / 48 of my segment, relative to the segment start (the start's absolute sums are only
                     // known after the cross-wave prefix below; the backward adds the two)
@@ -618,18 +451,18 @@ __global__ __launch_bounds__(kSegThreads, 4) void render_fwd_seg_kernel(int W, i
 #pragma unroll
             for (int u = 0; u < 2; u++) {
                 const float4 qa = pA[pb + u], qb = pB[pb + u], qc = pC[pb + u], qd = pD[pb + u], qe = pE[pb + u];
-                const uint2 qi = pI[pb + u];
+                const float4 qq = pQ[pb + u];
                 const v2f gx = {qa.x, qa.y}, gy = {qa.z, qa.w}, kxx = {qb.x, qb.y}, kxy = {qb.z, qb.w}, kyy = {qc.x, qc.y}, op = {qc.z, qc.w};
                 const v2f dx = gx - px2, dy = gy - py2;
                 const v2f power = __builtin_elementwise_fma(dx, kxx * dx, __builtin_elementwise_fma(kxy * dx, dy, (kyy * dy) * dy));   // == sgr_power2 per element
                 const v2f G = {__builtin_amdgcn_exp2f(power.x), __builtin_amdgcn_exp2f(power.y)};
                 const v2f og = op * G;
                 const float a0 = fminf(0.99f, og.x), a1 = fminf(0.99f, og.y);
-                al[2 * u] = ((power.x <= 0.f) & (a0 >= (1.0f / 255.0f))) ? a0 : 0.f;
-                al[2 * u + 1] = ((power.y <= 0.f) & (a1 >= (1.0f / 255.0f))) ? a1 : 0.f;
+                al[2 * u] = ((power.x <= 0.f) & (power.x >= qq.x)) ? a0 : 0.f;
+                al[2 * u + 1] = ((power.y <= 0.f) & (power.y >= qq.y)) ? a1 : 0.f;
                 rg[2 * u] = (v2f){qd.x, qd.y}; rg[2 * u + 1] = (v2f){qd.z, qd.w};
                 bd[2 * u] = (v2f){qe.x, qe.y}; bd[2 * u + 1] = (v2f){qe.z, qe.w};
-                li[2 * u] = qi.x; li[2 * u + 1] = qi.y;
+                li[2 * u] = __float_as_uint(qq.z); li[2 * u + 1] = __float_as_uint(qq.w);
             }
 #pragma unroll
             for (int u = 0; u < 4; u++) {
@@ -669,16 +502,9 @@ __global__ __launch_bounds__(kSegThreads, 4) void render_fwd_seg_kernel(int W, i
                 for (int w = 0; w < kSegWaves; w++) if ((((uint32_t)w * per) >> 6) == (s0 >> 6)) live |= sContrib[w];
                 if (live) {
                     const size_t slot = slot_next + (s0 >> 6);
-                    if constexpr (AUX == 2) {
-                        if (kbase + s0 != 0u) {
-                            if (aux.ckpt_tc) aux.ckpt_tc[(slot * 4 + brow0) * 64 + lane] = make_float4(Tin, p0, p1, p2);
-                            if (aux.ckpt_da) aux.ckpt_da[(slot * 4 + brow0) * 64 + lane] = make_float2(pD, pA);
-                        }
-                    } else {
-                        if ((s0 & 63u) == 0u && kbase + s0 != 0u) {                // my segment starts a bucket: its absolute start state
-                            if (aux.ckpt_tc) aux.ckpt_tc[slot * 64 + lane] = make_float4(Tin, p0, p1, p2);
-                            if (aux.ckpt_da) aux.ckpt_da[slot * 64 + lane] = make_float2(pD, pA);
-                        }
+                    if (kbase + s0 != 0u) {
+                        if (aux.ckpt_tc) aux.ckpt_tc[(slot * 4 + brow0) * 64 + lane] = make_float4(Tin, p0, p1, p2);
+                        if (aux.ckpt_da) aux.ckpt_da[(slot * 4 + brow0) * 64 + lane] = make_float2(pD, pA);
                     }
                     if (lane == 0 && (s0 & 63u) == 0u && aux.ckpt_tc)
                         aux.desc[slot] = make_uint2(bid | (((per >> 4) - 1u) << 30), ((kbase + s0) << 7) | min(64u, m - s0));
@@ -741,148 +567,6 @@ __global__ __launch_bounds__(1024) void fwd_prepare_kernel(const uint2 *__restri
 }
 
 // -------------------------------------------------------------------------------------------------
-// B1 (v1): pixel-parallel reverse walk; per visited Gaussian the 10 partials are reduced across the wave
-// with DPP adds (no LDS traffic), accumulated per batch in LDS, and flushed with ONE set of hardware float
-// atomics per (tile, Gaussian) instead of one per (pixel, Gaussian) as in the published kernel.
-// -------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void render_bwd_kernel(int W, int H, int Tx, uint32_t tiles_per_view,
-                                                            const uint2 *__restrict__ ranges,
-                                                            const uint32_t *__restrict__ point_list,
-                                                            const float4 *__restrict__ rec, const float *__restrict__ bg,
-                                                            const float *__restrict__ final_T,
-                                                            const uint32_t *__restrict__ n_contrib,
-                                                            const float *__restrict__ gC, const float *__restrict__ gD,
-                                                            const float *__restrict__ gA, const float *__restrict__ gscale,
-                                                            float *__restrict__ grec) {
-    __shared__ float4 sA[kBlock], sB[kBlock], sC[kBlock];
-    __shared__ uint32_t sMask[kBlock];
-    __shared__ uint32_t sId[kBlock];
-    __shared__ float sGrad[10][kBlock];
-    __shared__ uint32_t sMax[4];
-    const uint32_t bid = sgr_xcd_remap(blockIdx.x, gridDim.x);
-    const uint32_t view = bid / tiles_per_view, tile = bid - view * tiles_per_view;
-    const uint32_t tx = tile % Tx, ty = tile / Tx;
-    const uint2 range = ranges[bid];
-    const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
-    const int px = (int)tx * 16 + (wave & 1) * 8 + (lane & 7);
-    const int py = (int)ty * 16 + (wave >> 1) * 8 + (lane >> 3);
-    const bool inside = px < W && py < H;
-    const float pxf = (float)px, pyf = (float)py;
-    const float x0 = (float)(tx * 16), y0 = (float)(ty * 16);
-    const size_t hw = (size_t)H * W;
-    const size_t pix = (size_t)py * W + px;
-    const size_t vb = (size_t)view * hw;
-    const float Tf = inside ? final_T[vb + pix] : 0.f;
-    const uint32_t last = inside ? n_contrib[vb + pix] : 0u;
-    float g0 = 0.f, g1 = 0.f, g2 = 0.f, gd = 0.f, ga = 0.f;
-    if (inside) {
-        const float gs = gscale ? *gscale : 1.f;              // optional device scalar on dL/dcolor (a loss weight / upstream scalar)
-        g0 = gs * gC[vb * 3 + pix]; g1 = gs * gC[vb * 3 + hw + pix]; g2 = gs * gC[vb * 3 + 2 * hw + pix];
-        if (gD) gd = gD[vb + pix];
-        if (gA) ga = gA[vb + pix];
-    }
-    const float bg_dot = (bg[0] * g0 + bg[1] * g1) + bg[2] * g2;
-    const float ddelx_dx = 0.5f * (float)W, ddely_dy = 0.5f * (float)H;
-    // only the first max(n_contrib) entries of the tile list can receive gradient
-    uint32_t wmax = last;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) wmax = max(wmax, (uint32_t)__shfl_xor((int)wmax, off, 64));
-    if (lane == 0) sMax[wave] = wmax;
-    __syncthreads();
-    const uint32_t bmax = max(max(sMax[0], sMax[1]), max(sMax[2], sMax[3]));
-    const int n = (int)min(range.y - range.x, bmax);
-    const int rounds = (n + kBlock - 1) / kBlock;
-    float T = Tf;
-    float accC0 = 0.f, accC1 = 0.f, accC2 = 0.f, accD = 0.f, accA = 0.f;
-    float last_alpha = 0.f, lastC0 = 0.f, lastC1 = 0.f, lastC2 = 0.f, lastD = 0.f;
-    for (int r = rounds - 1; r >= 0; r--) {
-        __syncthreads();
-        const int idx = r * kBlock + t;
-        uint32_t m = 0;
-        if (idx < n) {
-            const uint32_t id = point_list[range.x + idx];
-            const float4 a = rec[(size_t)id * 4 + 0], b = rec[(size_t)id * 4 + 1], c = rec[(size_t)id * 4 + 2];
-            sA[t] = a; sB[t] = b; sC[t] = c;
-            sId[t] = id;
-            m = cull_mask(a, c, x0, y0);
-        }
-        sMask[t] = m;
-#pragma unroll
-        for (int k = 0; k < 10; k++) sGrad[k][t] = 0.f;
-        __syncthreads();
-        for (int ch = 3; ch >= 0; ch--) {
-            if ((uint32_t)(r * kBlock + ch * 64) >= wmax) continue;      // nothing in this chunk precedes any pixel's last contributor
-            uint64_t bal = __ballot((sMask[ch * 64 + lane] >> wave) & 1u);
-            while (bal) {
-                const int bit = 63 - __builtin_clzll(bal);
-                bal &= ~(1ull << bit);
-                const int j = ch * 64 + bit;
-                const uint32_t contributor = (uint32_t)(r * kBlock + j);    // 0-based position in the tile list
-                const float4 a = sA[j], b = sB[j];
-                const float4 c = sC[j];
-                const float dx = a.x - pxf, dy = a.y - pyf;
-                const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
-                const float G = __expf(power);
-                const float alpha = fminf(0.99f, b.y * G);
-                const bool valid = (contributor < last) && power <= 0.f && alpha >= (1.0f / 255.0f);
-                if (!__ballot(valid)) continue;
-                float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f, v4 = 0.f, v5 = 0.f, v6 = 0.f, v7 = 0.f, v8 = 0.f, v9 = 0.f;
-                if (valid) {
-                    T = T / (1.f - alpha);
-                    const float w = alpha * T;
-                    float dL_dalpha;
-                    accC0 = last_alpha * lastC0 + (1.f - last_alpha) * accC0; lastC0 = b.w;
-                    dL_dalpha = (b.w - accC0) * g0;
-                    accC1 = last_alpha * lastC1 + (1.f - last_alpha) * accC1; lastC1 = c.x;
-                    dL_dalpha += (c.x - accC1) * g1;
-                    accC2 = last_alpha * lastC2 + (1.f - last_alpha) * accC2; lastC2 = c.y;
-                    dL_dalpha += (c.y - accC2) * g2;
-                    accD = last_alpha * lastD + (1.f - last_alpha) * accD; lastD = b.z;
-                    dL_dalpha += (b.z - accD) * gd;
-                    accA = last_alpha + (1.f - last_alpha) * accA;
-                    dL_dalpha += (1.f - accA) * ga;
-                    dL_dalpha *= T;
-                    last_alpha = alpha;
-                    dL_dalpha += (-Tf / (1.f - alpha)) * bg_dot;
-                    const float dL_dG = b.y * dL_dalpha;           // differentiates through op*G even when capped (as upstream)
-                    const float gdx = G * dx, gdy = G * dy;
-                    const float dG_ddelx = -gdx * a.z - gdy * a.w;
-                    const float dG_ddely = -gdy * b.x - gdx * a.w;
-                    v0 = dL_dG * dG_ddelx * ddelx_dx;
-                    v1 = dL_dG * dG_ddely * ddely_dy;
-                    v2 = -0.5f * gdx * dx * dL_dG;
-                    v3 = -0.5f * gdx * dy * dL_dG;
-                    v4 = -0.5f * gdy * dy * dL_dG;
-                    v5 = G * dL_dalpha;
-                    v6 = w * gd;
-                    v7 = w * g0; v8 = w * g1; v9 = w * g2;
-                }
-                v0 = sgr_wave_sum_to_lane63(v0); v1 = sgr_wave_sum_to_lane63(v1); v2 = sgr_wave_sum_to_lane63(v2);
-                v3 = sgr_wave_sum_to_lane63(v3); v4 = sgr_wave_sum_to_lane63(v4); v5 = sgr_wave_sum_to_lane63(v5);
-                v6 = sgr_wave_sum_to_lane63(v6); v7 = sgr_wave_sum_to_lane63(v7); v8 = sgr_wave_sum_to_lane63(v8);
-                v9 = sgr_wave_sum_to_lane63(v9);
-                if (lane == 63) {
-                    sgr_atomic_add(&sGrad[0][j], v0); sgr_atomic_add(&sGrad[1][j], v1); sgr_atomic_add(&sGrad[2][j], v2);
-                    sgr_atomic_add(&sGrad[3][j], v3); sgr_atomic_add(&sGrad[4][j], v4); sgr_atomic_add(&sGrad[5][j], v5);
-                    sgr_atomic_add(&sGrad[6][j], v6); sgr_atomic_add(&sGrad[7][j], v7); sgr_atomic_add(&sGrad[8][j], v8);
-                    sgr_atomic_add(&sGrad[9][j], v9);
-                }
-            }
-        }
-        __syncthreads();
-        if (idx < n && sMask[t]) {
-            float *g = grec + (size_t)sId[t] * SGR_REC_FLOATS;
-#pragma unroll
-            for (int k = 0; k < 10; k++) {
-                const float v = sGrad[k][t];
-                if (v != 0.f) sgr_atomic_add(g + k, v);
-            }
-        }
-    }
-}
-
-
-// -------------------------------------------------------------------------------------------------
 // B1 (v2): bucket-parallel "systolic" backward.  One wave = one bucket of <= 64 consecutive surviving
 // Gaussians of one (tile, quadrant) against that quadrant's 64 pixels.  LANES OWN GAUSSIANS: each lane keeps
 // its Gaussian's record and its 10 gradient accumulators in registers for the whole kernel, so there is
@@ -912,7 +596,7 @@ __device__ __forceinline__ float row_shift_in(float v, float feed) {
 // SPLIT (launches with few buckets, i.e. one or two views): TWO waves per bucket, each streaming one half of the quadrant's pixels
 // -- more wave-steps but twice the waves, which is what a 4 000-bucket launch on 1 024 SIMDs lacks; the second wave's per-Gaussian
 // sums are added to the first's through LDS before the single partial record is written.
-template <bool HAS_DA, bool SPLIT, bool ROWS>
+template <bool HAS_DA, bool SPLIT>
 __global__ __launch_bounds__(SPLIT ? 128 : 64) void render_bwd_bucket_kernel(int W, int H, int Tx, uint32_t tiles_per_view,
                                                                    const uint2 *__restrict__ ranges,
                                                                    const float4 *__restrict__ rec,
@@ -947,7 +631,7 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64) void render_bwd_bucket_kernel(int
     const uint32_t desc_y = (uint32_t)__builtin_amdgcn_readfirstlane((int)desc_v.y);
     const uint32_t desc_x = (uint32_t)__builtin_amdgcn_readfirstlane((int)desc_v.x);
     const uint32_t bid = desc_x & 0x3FFFFFFFu;
-    const uint32_t rps = (desc_x >> 30) + 1u;                  // ROWS: rows per forward segment; rows with r % rps == 0 hold absolute sums
+    const uint32_t rps = (desc_x >> 30) + 1u;                  // rows per forward segment; rows with r % rps == 0 hold absolute sums
     const uint32_t count = desc_y & 127u;
     if (count == 0) return;                                   // unused bucket slot (both waves of a SPLIT pair leave together; ended waves do not count at barriers)
     const uint32_t start = desc_y >> 7;                        // ordinal of this bucket's first survivor in the quadrant list
@@ -966,6 +650,7 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64) void render_bwd_bucket_kernel(int
     float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra, rc = ra;
     uint4 rd = make_uint4(0u, 0u, 0u, 0u);                     // (rect min, rect max, depth bits, first tile-instance index)
     if (has_g) { ra = rec[(size_t)e.x * 4 + 0]; rb = rec[(size_t)e.x * 4 + 1]; rc = rec[(size_t)e.x * 4 + 2]; rd = rect[e.x]; }
+    const float pstar = has_g ? rc.w : kNever;                 // alpha test: p* <= power <= 0 (file header)
     const float gx = ra.x, gy = ra.y, cxx = ra.z, cxy = ra.w, cyy = rb.x, op = rb.y, gdep = rb.z, cr = rb.w, cg = rc.x, cb = rc.y;
     // conic pre-scaled into the exp2 domain: G = exp(power) = exp2(kxx dx^2 + kyy dy^2 + kxy dx dy)
     const float kL2e = 1.4426950408889634f;
@@ -974,8 +659,6 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64) void render_bwd_bucket_kernel(int
     // receive a contribution from this bucket are streamed: a pixel whose last contributor lies in front of the bucket's first survivor
     // (n_contrib <= its list index) is valid for none of the bucket's Gaussians.  The stream keeps the pixel order, so the sums of the
     // step loop add the same terms in the same order: bit-identical to streaming all 64, in (alive pixels + 15) steps instead of 79.
-    float wT = 1.f, wRem = 0.f, wpx = 0.f, wpy = 0.f, wg0 = 0.f, wg1 = 0.f, wg2 = 0.f, wgd = 0.f, wga = 0.f;
-    uint32_t wlast = 0;
     const uint32_t gidx0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)gidx);        // list index of the bucket's first survivor (count >= 1)
     const int p = lane + (int)half * NPIX;
     const int px = (int)tx * 16 + (int)(q & 1u) * 8 + (p & 7);
@@ -1011,13 +694,13 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64) void render_bwd_bucket_kernel(int
         sPixB[2 * wv][16 + pos] = make_float4(g1, g2, gd, ga);
         float T0 = 1.f, Pre0 = 0.f;
         if (start) {
-            const float4 tc = aux.ckpt_tc[ROWS ? slot * 256 + p : slot * 64 + p];
+            const float4 tc = aux.ckpt_tc[slot * 256 + p];
             T0 = tc.x;
             Pre0 = sgr_dot3(tc.y, g0, tc.z, g1, tc.w, g2);
-            if (HAS_DA) { const float2 da = aux.ckpt_da[ROWS ? slot * 256 + p : slot * 64 + p]; Pre0 += fmaf(da.y, ga, da.x * gd); }
+            if (HAS_DA) { const float2 da = aux.ckpt_da[slot * 256 + p]; Pre0 += fmaf(da.y, ga, da.x * gd); }
         }
         sDyn[wv][0][pos] = make_float2(T0, O - Pre0);
-        if constexpr (ROWS) {
+        {
             float PreSeg = Pre0;                               // composited-so-far at the start of the forward segment the row is in
 #pragma unroll
             for (int r = 1; r < 4; r++) {
@@ -1032,35 +715,6 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64) void render_bwd_bucket_kernel(int
                 }
                 sDyn[wv][r][pos] = make_float2(Tr, O - Prer);
             }
-        }
-        wT = T0; wRem = O - Pre0; wpx = (float)px; wpy = (float)py; wlast = last; wg0 = g0; wg1 = g1; wg2 = g2; wgd = gd; wga = ga;
-    }
-    if constexpr (!ROWS) {
-        // compact checkpoints: the forward stored the pixel state at the bucket's start only; the states in front of rows 1..3 are rebuilt by
-        // walking the bucket's first 48 survivors with the same arithmetic as the step loop below (lanes = pixels, the survivor's record
-        // broadcast from its owner lane)
-#pragma unroll
-        for (int r = 1; r < 4; r++) {
-            const uint32_t j1 = min(count, (uint32_t)(16 * r));
-            for (uint32_t j = (uint32_t)(16 * (r - 1)); j < j1; j++) {                  // wave-uniform trip count
-#define SGR_BCAST(v) __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), (int)j))
-                const float jx = SGR_BCAST(gx), jy = SGR_BCAST(gy), jkxx = SGR_BCAST(kxx), jkyy = SGR_BCAST(kyy), jkxy = SGR_BCAST(kxy);
-                const float jop = SGR_BCAST(op), jcr = SGR_BCAST(cr), jcg = SGR_BCAST(cg), jcb = SGR_BCAST(cb);
-                const uint32_t jidx = (uint32_t)__builtin_amdgcn_readlane((int)gidx, (int)j);
-                const float dx = jx - wpx, dy = jy - wpy;
-                const float p2 = sgr_power2(jkxx, jkyy, jkxy, dx, dy);
-                const float G = __builtin_amdgcn_exp2f(p2);
-                const float alpha = fminf(0.99f, jop * G);
-                if (jidx < wlast && p2 <= 0.f && alpha >= (1.0f / 255.0f)) {
-                    const float w = alpha * wT;
-                    float qj = sgr_dot3(jcr, wg0, jcg, wg1, jcb, wg2);
-                    if (HAS_DA) qj += fmaf(SGR_BCAST(gdep), wgd, wga);
-                    wRem = fmaf(-w, qj, wRem);
-                    wT *= 1.f - alpha;
-                }
-#undef SGR_BCAST
-            }
-            if (alive) sDyn[wv][r][pos] = make_float2(wT, wRem);
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1096,7 +750,7 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64) void render_bwd_bucket_kernel(int
         const float p2 = sgr_power2(kxx, kyy, kxy, dx, dy);                                                             \
         const float G = __builtin_amdgcn_exp2f(p2);                                                                     \
         const float alpha = fminf(0.99f, op * G);                                                                       \
-        const bool valid = has && gidx < __float_as_uint(fa.z) && p2 <= 0.f && alpha >= (1.0f / 255.0f);                \
+        const bool valid = has && gidx < __float_as_uint(fa.z) && p2 <= 0.f && p2 >= pstar;                              \
         if (valid) {                                                                                                    \
             const float w = alpha * OUT.T;                                                                              \
             float qj = sgr_dot3(cr, fa.w, cg, fb.x, cb, fb.y);                                                          \
@@ -1175,26 +829,19 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64) void render_bwd_bucket_kernel(int
 int sgr_validate_problem(const SgrProblem *pb);
 int sgr_render_forward_kind(const SgrProblem *pb);
 
-// 0 = automatic (segment-parallel for <= 2048 tiles, else one wave per quadrant), 1 = serial per-tile kernel (round 1), 2 = segment-parallel
-// kernel, 3 = one wave per (tile, quadrant) (dev/test override: sgr_set_forward_mode)
+// 0 = automatic (segment-parallel for <= 2048 tiles, else one wave per quadrant), 2 = segment-parallel kernel, 3 = one wave per
+// (tile, quadrant) (dev/test override: sgr_set_forward_mode).  (1 was round 1's serial per-tile kernel: removed in round 5.)
 static thread_local int sgr_fwd_mode = sgr_env_knob("SIGMAN_FWD_MODE", 0, 3, 0);          // (dev/test switch, thread-local like sgr_set_debug: the forward runs on the caller's thread; every thread starts from the environment)
-extern "C" int sgr_set_forward_mode(int mode) { sgr_fwd_mode = mode; return 0; }
+extern "C" int sgr_set_forward_mode(int mode) {
+    if (mode != 0 && mode != 2 && mode != 3) { sgr_set_error("sgr_set_forward_mode: %d is not a forward kernel (0 automatic, 2 segment-parallel, 3 one wave per quadrant)", mode); return 1; }
+    sgr_fwd_mode = mode;
+    return 0;
+}
 int sgr_get_forward_mode() { return sgr_fwd_mode; }
 
 // a (tile, quadrant) list of n entries has <= n survivors in <= floor(n / 64) + 1 buckets, and floor(a/64) + floor(n/64) <= floor((a+n)/64):
 // slot base (range.x >> 6) + tile id leaves exactly that room
 extern "C" uint64_t sgr_bucket_slots(uint64_t R, uint64_t tiles_total) { return (R >> 6) + tiles_total + 1; }
-
-// checkpoint layout: 0 = automatic (rows unless their allocation would exceed SIGMAN_AUX_ROWS_MAX_BYTES, default 8 GiB), 1 = compact, 2 = rows
-static thread_local int sgr_aux_layout_mode = 0;
-extern "C" int sgr_set_aux_layout(int mode) { sgr_aux_layout_mode = mode; return 0; }
-// -> 2 (rows) or 1 (compact) for a launch with NS bucket slots per quadrant
-int sgr_aux_layout_for(uint64_t NS) {
-    if (sgr_aux_layout_mode == 1 || sgr_aux_layout_mode == 2) return sgr_aux_layout_mode;
-    static uint64_t limit = 0;
-    if (!limit) { const char *e = getenv("SIGMAN_AUX_ROWS_MAX_BYTES"); limit = e ? strtoull(e, nullptr, 10) : (8ull << 30); if (!limit) limit = 1; }
-    return 4 * NS * 4 * 64 * 24 > limit ? 1 : 2;
-}
 
 static FwdAux make_aux(void *compact, void *ckpt_tc, void *ckpt_da, void *desc, uint64_t R, uint64_t tiles_total, float *clamped = nullptr) {
     FwdAux a;
@@ -1204,27 +851,27 @@ static FwdAux make_aux(void *compact, void *ckpt_tc, void *ckpt_da, void *desc, 
     return a;
 }
 
-// does this launch want the one-workgroup prepare step (tile order + descriptor clear), and how many descriptors are there?
-// the compositing kernel a forward of this problem uses on the calling thread: 1 = serial per tile, 2 = segment-parallel, 3 = one wave per quadrant
+static bool fwd_is_seg(uint64_t tiles_total) { return sgr_fwd_mode == 2 || (sgr_fwd_mode != 3 && tiles_total <= 2048); }
+
+// the compositing kernel a forward of this problem uses on the calling thread: 2 = segment-parallel, 3 = one wave per quadrant
 int sgr_render_forward_kind(const SgrProblem *pb) {
     const uint64_t tiles_total = (uint64_t)((pb->W + SGR_TILE - 1) / SGR_TILE) * ((pb->H + SGR_TILE - 1) / SGR_TILE) * pb->n_views;
-    if (sgr_fwd_mode == 2 || (sgr_fwd_mode == 0 && tiles_total <= 2048)) return 2;
-    return sgr_fwd_mode == 1 ? 1 : 3;
+    return fwd_is_seg(tiles_total) ? 2 : 3;
 }
 
+// does this launch want the one-workgroup prepare step (tile order + descriptor clear), and how many descriptors are there?
 int sgr_render_forward_wants_prepare(const SgrProblem *pb, uint64_t R, bool use_aux, size_t *n_desc_out) {
     const uint64_t tiles_total = (uint64_t)((pb->W + SGR_TILE - 1) / SGR_TILE) * ((pb->H + SGR_TILE - 1) / SGR_TILE) * pb->n_views;
     const size_t n_desc = use_aux ? (size_t)4 * sgr_bucket_slots(R, tiles_total) : 0;
     if (n_desc_out) *n_desc_out = n_desc;
-    const bool seg = sgr_fwd_mode == 2 || (sgr_fwd_mode == 0 && tiles_total <= 2048);
-    return seg && n_desc <= (1u << 17) ? 1 : 0;
+    return fwd_is_seg(tiles_total) && n_desc <= (1u << 17) ? 1 : 0;
 }
 
 int sgr_render_forward_ex(const SgrProblem *pb, const uint32_t *ranges, const uint32_t *point_list, const float *rec,
                           float *out_color, float *out_depth, float *out_alpha, float *final_T, uint32_t *n_contrib,
                           uint64_t R, void *aux_compact, void *aux_ckpt_tc, void *aux_ckpt_da, void *aux_desc,
-                          uint32_t *aux_order, bool prepared, int aux_layout /* 1 compact, 2 rows */, int kind /* 0: choose (sgr_render_forward_kind);
-                          else the compositing kernel to use: the depth/alpha checkpoint pass must repeat its forward's */, void *stream_) {
+                          uint32_t *aux_order, bool prepared, int kind /* 0: choose (sgr_render_forward_kind); else the compositing kernel to
+                          use: the depth/alpha checkpoint pass must repeat its forward's */, void *stream_) {
     if (sgr_validate_problem(pb)) return 1;
     if (kind == 0) kind = sgr_render_forward_kind(pb);
     const int Tx = (pb->W + SGR_TILE - 1) / SGR_TILE, Ty = (pb->H + SGR_TILE - 1) / SGR_TILE;
@@ -1254,35 +901,19 @@ int sgr_render_forward_ex(const SgrProblem *pb, const uint32_t *ranges, const ui
         hipLaunchKernelGGL(render_fwd_seg_kernel<A>, dim3(seg_grid), dim3(kSegThreads), 0, stream, pb->W, pb->H, Tx, tiles,        \
                            (const uint2 *)ranges, point_list, (const float4 *)rec, pb->bg, out_color, out_depth, out_alpha, final_T,  \
                            n_contrib, aux, (const uint32_t *)aux_order, (uint32_t)tiles_total)
-        if (!use_aux) SGR_LAUNCH_SEG(0);
-        else if (aux_layout == 2) SGR_LAUNCH_SEG(2);
-        else SGR_LAUNCH_SEG(1);
+        if (!use_aux) SGR_LAUNCH_SEG(0); else SGR_LAUNCH_SEG(2);
 #undef SGR_LAUNCH_SEG
         SGR_CHECK_LAUNCH("render_fwd_seg_kernel");
         return 0;
     }
-    if (kind != 1) {
-        const uint32_t wgrid = (uint32_t)((tiles_total + 7) / 8) * 32u;          // 8 tiles x 4 quadrants per group of 32 ids
+    const uint32_t wgrid = (uint32_t)((tiles_total + 7) / 8) * 32u;          // 8 tiles x 4 quadrants per group of 32 ids
 #define SGR_LAUNCH_WAVE(A)                                                                                                  \
-        hipLaunchKernelGGL(render_fwd_wave_kernel<A>, dim3(wgrid), dim3(64), 0, stream, pb->W, pb->H, Tx, tiles, (uint32_t)tiles_total,   \
-                           (const uint2 *)ranges, point_list, (const float4 *)rec, pb->bg, out_color, out_depth, out_alpha, final_T,  \
-                           n_contrib, aux)
-        if (!use_aux) SGR_LAUNCH_WAVE(0);
-        else if (aux_layout == 2) SGR_LAUNCH_WAVE(2);
-        else SGR_LAUNCH_WAVE(1);
-#undef SGR_LAUNCH_WAVE
-        SGR_CHECK_LAUNCH("render_fwd_wave_kernel");
-        return 0;
-    }
-#define SGR_LAUNCH_FWD(A)                                                                                                   \
-    hipLaunchKernelGGL(render_fwd_kernel<A>, dim3(tiles * pb->n_views), dim3(kBlock), 0, stream, pb->W, pb->H, Tx, tiles,          \
-                       (const uint2 *)ranges, point_list, (const float4 *)rec, pb->bg, out_color, out_depth, out_alpha, final_T,      \
+    hipLaunchKernelGGL(render_fwd_wave_kernel<A>, dim3(wgrid), dim3(64), 0, stream, pb->W, pb->H, Tx, tiles, (uint32_t)tiles_total,   \
+                       (const uint2 *)ranges, point_list, (const float4 *)rec, pb->bg, out_color, out_depth, out_alpha, final_T,  \
                        n_contrib, aux)
-    if (!use_aux) SGR_LAUNCH_FWD(0);
-    else if (aux_layout == 2) SGR_LAUNCH_FWD(2);
-    else SGR_LAUNCH_FWD(1);
-#undef SGR_LAUNCH_FWD
-    SGR_CHECK_LAUNCH("render_fwd_kernel");
+    if (!use_aux) SGR_LAUNCH_WAVE(0); else SGR_LAUNCH_WAVE(2);
+#undef SGR_LAUNCH_WAVE
+    SGR_CHECK_LAUNCH("render_fwd_wave_kernel");
     return 0;
 }
 
@@ -1290,68 +921,47 @@ extern "C" int sgr_render_forward(const SgrProblem *pb, const uint32_t *ranges, 
                                   float *out_color, float *out_depth, float *out_alpha, float *final_T, uint32_t *n_contrib,
                                   uint64_t R, void *aux_compact, void *aux_ckpt_tc, void *aux_ckpt_da, void *aux_desc,
                                   uint32_t *aux_order, void *stream_) {
-    const uint64_t tiles_total = (uint64_t)((pb->W + SGR_TILE - 1) / SGR_TILE) * ((pb->H + SGR_TILE - 1) / SGR_TILE) * pb->n_views;
     return sgr_render_forward_ex(pb, ranges, point_list, rec, out_color, out_depth, out_alpha, final_T, n_contrib, R, aux_compact,
-                                 aux_ckpt_tc, aux_ckpt_da, aux_desc, aux_order, false, sgr_aux_layout_for(sgr_bucket_slots(R, tiles_total)), 0, stream_);
+                                 aux_ckpt_tc, aux_ckpt_da, aux_desc, aux_order, false, 0, stream_);
 }
 
-int sgr_render_backward_ex(const SgrProblem *pb, const uint32_t *ranges, const uint32_t *point_list, const float *rec, const uint32_t *rect,
-                           const float *final_T, const uint32_t *n_contrib, const float *out_color,
-                           const float *out_depth, const float *out_alpha, const float *grad_color,
-                           const float *grad_depth, const float *grad_alpha, const float *grad_color_scale, uint64_t R,
+int sgr_render_backward_ex(const SgrProblem *pb, const uint32_t *ranges, const float *rec, const uint32_t *rect,
+                           const uint32_t *n_contrib, const float *out_color, const float *out_depth, const float *out_alpha,
+                           const float *grad_color, const float *grad_depth, const float *grad_alpha, const float *grad_color_scale, uint64_t R,
                            const void *aux_compact, const void *aux_ckpt_tc, const void *aux_ckpt_da, const void *aux_desc,
-                           float *grec, float *part, uint32_t *flags, bool flags_cleared, int aux_layout /* 1 compact, 2 rows */, void *stream_) {
+                           float *part, uint32_t *flags, bool flags_cleared, void *stream_) {
     if (sgr_validate_problem(pb)) return 1;
     hipStream_t stream = (hipStream_t)stream_;
     const int Tx = (pb->W + SGR_TILE - 1) / SGR_TILE, Ty = (pb->H + SGR_TILE - 1) / SGR_TILE;
     const uint32_t tiles = (uint32_t)Tx * Ty;
-    const bool use_aux = aux_compact && aux_ckpt_tc && aux_desc && out_color && out_depth && out_alpha && part && flags && rect;
-    if (use_aux && (grad_depth || grad_alpha) && !aux_ckpt_da) { sgr_set_error("sgr_render_backward: dL/ddepth or dL/dalpha given but the forward left no depth/alpha checkpoints"); return 1; }
-    if (use_aux) {
-        if (R > 0 && !flags_cleared) SGR_CHECK_HIP(hipMemsetAsync(flags, 0, (size_t)R * 4, stream));   // (else: cleared by the forward chain)
-    } else {
-        if (!grec) { sgr_set_error("sgr_render_backward: grec required for the pixel-parallel kernel"); return 1; }
-        if (pb->P > 0) SGR_CHECK_HIP(hipMemsetAsync(grec, 0, (size_t)pb->n_views * pb->P * SGR_REC_FLOATS * sizeof(float), stream));
+    if (!(aux_compact && aux_ckpt_tc && aux_desc && out_color && out_depth && out_alpha && part && flags && rect && n_contrib && grad_color)) {
+        sgr_set_error("sgr_render_backward: needs the forward's auxiliary outputs (compact lists, checkpoints, descriptors), its output images, rect, part and flags");
+        return 1;
     }
+    if ((grad_depth || grad_alpha) && !aux_ckpt_da) { sgr_set_error("sgr_render_backward: dL/ddepth or dL/dalpha given but the forward left no depth/alpha checkpoints"); return 1; }
+    if (R > 0 && !flags_cleared) SGR_CHECK_HIP(hipMemsetAsync(flags, 0, (size_t)R * 4, stream));   // (else: cleared by the forward chain)
     SgrProfScope _p(SGR_K_RENDER_BWD, stream);
-    if (use_aux) {
-        FwdAux aux = make_aux((void *)aux_compact, (void *)aux_ckpt_tc, (void *)aux_ckpt_da, (void *)aux_desc, R,
-                              (uint64_t)tiles * pb->n_views);
-        // few buckets (one or two views): two waves per bucket (SPLIT) to give the SIMDs enough waves to hide latencies
-        const bool split = (uint64_t)tiles * pb->n_views <= 2048;
-        const uint32_t nblocks = (aux.NS + 7u) / 8u * 32u;               // one workgroup per (bucket slot, quadrant), in groups of 8 slots x 4 quadrants
-#define SGR_LAUNCH_BWD(DA, SP, RW)                                                                                          \
-        hipLaunchKernelGGL((render_bwd_bucket_kernel<DA, SP, RW>), dim3(nblocks), dim3(SP ? 128 : 64), 0, stream, pb->W, pb->H, Tx, tiles, \
-                           (const uint2 *)ranges, (const float4 *)rec, (const uint4 *)rect, n_contrib, out_color, out_depth, out_alpha, grad_color, \
-                           grad_depth, grad_alpha, grad_color_scale, aux, (float4 *)part, (uint8_t *)flags, pb->clamp_grad)
-        const bool da = grad_depth || grad_alpha, rows = aux_layout == 2;
-        if (rows) {
-            if (split && da) SGR_LAUNCH_BWD(true, true, true); else if (split) SGR_LAUNCH_BWD(false, true, true);
-            else if (da) SGR_LAUNCH_BWD(true, false, true); else SGR_LAUNCH_BWD(false, false, true);
-        } else {
-            if (split && da) SGR_LAUNCH_BWD(true, true, false); else if (split) SGR_LAUNCH_BWD(false, true, false);
-            else if (da) SGR_LAUNCH_BWD(true, false, false); else SGR_LAUNCH_BWD(false, false, false);
-        }
+    FwdAux aux = make_aux((void *)aux_compact, (void *)aux_ckpt_tc, (void *)aux_ckpt_da, (void *)aux_desc, R, (uint64_t)tiles * pb->n_views);
+    // few buckets (one or two views): two waves per bucket (SPLIT) to give the SIMDs enough waves to hide latencies
+    const bool split = (uint64_t)tiles * pb->n_views <= 2048;
+    const uint32_t nblocks = (aux.NS + 7u) / 8u * 32u;               // one workgroup per (bucket slot, quadrant), in groups of 8 slots x 4 quadrants
+#define SGR_LAUNCH_BWD(DA, SP)                                                                                              \
+    hipLaunchKernelGGL((render_bwd_bucket_kernel<DA, SP>), dim3(nblocks), dim3(SP ? 128 : 64), 0, stream, pb->W, pb->H, Tx, tiles, \
+                       (const uint2 *)ranges, (const float4 *)rec, (const uint4 *)rect, n_contrib, out_color, out_depth, out_alpha, grad_color, \
+                       grad_depth, grad_alpha, grad_color_scale, aux, (float4 *)part, (uint8_t *)flags, pb->clamp_grad)
+    const bool da = grad_depth || grad_alpha;
+    if (split && da) SGR_LAUNCH_BWD(true, true); else if (split) SGR_LAUNCH_BWD(false, true);
+    else if (da) SGR_LAUNCH_BWD(true, false); else SGR_LAUNCH_BWD(false, false);
 #undef SGR_LAUNCH_BWD
-        SGR_CHECK_LAUNCH("render_bwd_bucket_kernel");
-        return 0;
-    }
-    if (pb->clamp_grad) { sgr_set_error("sgr_render_backward: SgrProblem.clamp_grad needs the bucket backward (a forward run with auxiliary outputs)"); return 1; }
-    hipLaunchKernelGGL(render_bwd_kernel, dim3(tiles * pb->n_views), dim3(kBlock), 0, stream, pb->W, pb->H, Tx, tiles,
-                       (const uint2 *)ranges, point_list, (const float4 *)rec, pb->bg, final_T, n_contrib, grad_color, grad_depth,
-                       grad_alpha, grad_color_scale, grec);
-    SGR_CHECK_LAUNCH("render_bwd_kernel");
+    SGR_CHECK_LAUNCH("render_bwd_bucket_kernel");
     return 0;
 }
 
-extern "C" int sgr_render_backward(const SgrProblem *pb, const uint32_t *ranges, const uint32_t *point_list, const float *rec, const uint32_t *rect,
-                                   const float *final_T, const uint32_t *n_contrib, const float *out_color,
-                                   const float *out_depth, const float *out_alpha, const float *grad_color,
-                                   const float *grad_depth, const float *grad_alpha, const float *grad_color_scale, uint64_t R,
-                                   const void *aux_compact, const void *aux_ckpt_tc, const void *aux_ckpt_da, const void *aux_desc,
-                                   float *grec, float *part, uint32_t *flags, void *stream_) {
-    const uint64_t tiles_total = (uint64_t)((pb->W + SGR_TILE - 1) / SGR_TILE) * ((pb->H + SGR_TILE - 1) / SGR_TILE) * pb->n_views;
-    return sgr_render_backward_ex(pb, ranges, point_list, rec, rect, final_T, n_contrib, out_color, out_depth, out_alpha, grad_color, grad_depth,
-                                  grad_alpha, grad_color_scale, R, aux_compact, aux_ckpt_tc, aux_ckpt_da, aux_desc, grec, part, flags, false,
-                                  sgr_aux_layout_for(sgr_bucket_slots(R, tiles_total)), stream_);
+extern "C" int sgr_render_backward(const SgrProblem *pb, const uint32_t *ranges, const float *rec, const uint32_t *rect,
+                                   const uint32_t *n_contrib, const float *out_color, const float *out_depth, const float *out_alpha,
+                                   const float *grad_color, const float *grad_depth, const float *grad_alpha, const float *grad_color_scale,
+                                   uint64_t R, const void *aux_compact, const void *aux_ckpt_tc, const void *aux_ckpt_da, const void *aux_desc,
+                                   float *part, uint32_t *flags, void *stream_) {
+    return sgr_render_backward_ex(pb, ranges, rec, rect, n_contrib, out_color, out_depth, out_alpha, grad_color, grad_depth, grad_alpha,
+                                  grad_color_scale, R, aux_compact, aux_ckpt_tc, aux_ckpt_da, aux_desc, part, flags, false, stream_);
 }

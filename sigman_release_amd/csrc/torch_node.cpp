@@ -123,7 +123,18 @@ inline bool wait_for_count(P &p, bool block) {
     if (p.by_copy) SGR_TORCH_CHECK_HIP(hipEventSynchronize(p.slot.ev));
     else {                                                         // stored by the emission kernel itself, no event recorded: poll, then drain
         spin_for_count(w, p.checked);
-        if (*w == ~0ull && !p.checked.load(std::memory_order_acquire)) SGR_TORCH_CHECK_HIP(hipDeviceSynchronize());
+        if (*w == ~0ull && !p.checked.load(std::memory_order_acquire)) {
+            // drain the device the entry belongs to -- the calling thread may sit on another one (a thread driving two GPUs polls its
+            // older entries under the new forward's guard)
+            int cur = 0;
+            SGR_TORCH_CHECK_HIP(hipGetDevice(&cur));
+            if (cur != p.slot.dev) SGR_TORCH_CHECK_HIP(hipSetDevice(p.slot.dev));
+            const hipError_t e = hipDeviceSynchronize();
+            if (cur != p.slot.dev) SGR_TORCH_CHECK_HIP(hipSetDevice(cur));
+            SGR_TORCH_CHECK_HIP(e);
+            TORCH_CHECK(*w != ~0ull || p.checked.load(std::memory_order_acquire),
+                        "sigman_release_amd: the forward's instance count never arrived (device ", p.slot.dev, ")");
+        }
     }
     return true;
 }
@@ -611,7 +622,9 @@ void batched_forward(const SgrProblem &pb, const c10::Device &dev, int64_t P, in
     b_poll(false);
     for (int attempt = 0;; attempt++) {
         uint64_t capacity = capacity_req > 0 ? (uint64_t)capacity_req : 0;
-        if (capacity_req < 0) { std::lock_guard<std::mutex> l(g_mu); capacity = g_bkeys[cap_key].capacity; }
+        // automatic mode: the remembered capacity -- but the re-run after an overflow is exact whatever another thread rendering the same
+        // shape has re-learned in between (a second sync-free attempt could overflow again and surface as an error instead of a re-run)
+        if (capacity_req < 0 && attempt == 0) { std::lock_guard<std::mutex> l(g_mu); capacity = g_bkeys[cap_key].capacity; }
         CountSlot slot = acquire_slot(didx);
         slot.host[0] = ~0ull; slot.host[1] = 0;
         SgrForwardState &st = out.st;
@@ -659,8 +672,9 @@ void batched_forward(const SgrProblem &pb, const c10::Device &dev, int64_t P, in
             static const std::atomic<bool> never{false};
             if (!st.nr_by_copy) spin_for_count(w, never);
             if (st.nr_by_copy) SGR_TORCH_CHECK_HIP(hipEventSynchronize(slot.ev));
-            else if (*w == ~0ull) SGR_TORCH_CHECK_HIP(hipDeviceSynchronize());
+            else if (*w == ~0ull) SGR_TORCH_CHECK_HIP(hipDeviceSynchronize());      // (the caller's DeviceGuard is on slot.dev)
             const uint64_t word = *w;
+            if (word == ~0ull) { release_slot(slot); TORCH_CHECK(false, "sigman_release_amd: the forward's instance count never arrived (device ", didx, ")"); }
             count = word & ~(1ull << 63); overflow = word >> 63;
         }
         release_slot(slot);
@@ -669,7 +683,7 @@ void batched_forward(const SgrProblem &pb, const c10::Device &dev, int64_t P, in
             g_bkeys[cap_key] = BKeyState();
             continue;
         }
-        TORCH_CHECK(!overflow, "num_rendered ", count, " exceeds the 32-bit instance index");
+        TORCH_CHECK(!overflow, "num_rendered ", count, " exceeds the 32-bit instance index");      // (only an exact run gets here with the flag set)
         if (capacity_req < 0) {
             std::lock_guard<std::mutex> l(g_mu);
             BKeyState &k = g_bkeys[cap_key];

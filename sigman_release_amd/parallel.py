@@ -202,9 +202,11 @@ def all_gather_images(local: torch.Tensor, n_views: int, group=None) -> torch.Te
     per = (n_views + world - 1) // world
     pad = local if n_mine == per else torch.cat([local, local.new_zeros((per - n_mine,) + tuple(local.shape[1:]))])
     out = local.new_empty((world, per) + tuple(local.shape[1:]))
-    try:
+    # The collective is chosen UP FRONT from the backend -- every rank takes the same branch -- never by catching an error: a real failure
+    # (an RCCL error, a shape mismatch on one rank) must surface, and ranks that caught different errors would issue different collectives.
+    if dist.get_backend(group) == "nccl":               # RCCL: the flat form, one kernel
         dist.all_gather_into_tensor(out.view((world * per,) + tuple(local.shape[1:])), pad.contiguous(), group=group)
-    except (RuntimeError, NotImplementedError):          # a backend without the flat form: the list form, then the same layout
+    else:                                               # gloo (CPU tests, host-staged): the list form, then the same layout
         parts = [torch.empty_like(pad) for _ in range(world)]
         dist.all_gather(parts, pad.contiguous(), group=group)
         out = torch.stack(parts)

@@ -68,8 +68,6 @@ class BatchedRasterizationSettings(NamedTuple):
     depth_alpha_grads: Optional[bool] = None
 
 
-# SIGMAN_BWD_V1=1 selects the pixel-parallel backward (no auxiliary forward outputs) for A/B comparisons
-_USE_BWD_V1 = os.environ.get("SIGMAN_BWD_V1", "0") == "1"
 
 
 _EMPTY = torch.Tensor([])          # upstream passes torch.Tensor([]) for every missing optional; one shared instance (never written)
@@ -325,7 +323,7 @@ def _forward_impl(means3D, opacities, colors_precomp, shs, cov3D_precomp, scales
     nr_host, nr_event, nr_ptr, nr_handle = slot.np, slot.ev, slot.ptr, slot.handle
     state = _cabi.SgrForwardState()
     blobs = [None, None, None, None]
-    use_aux = (1 if getattr(st, "depth_alpha_grads", None) else 3) if (need_ctx and with_aux and not _USE_BWD_V1) else 0    # 3: (depth, alpha) checkpoints on demand
+    use_aux = (1 if getattr(st, "depth_alpha_grads", None) else 3) if (need_ctx and with_aux) else 0    # 3: (depth, alpha) checkpoints on demand
     clear_ptr, clear_bytes = (None, 0) if clear is None else (clear.data_ptr(), clear.numel() * clear.element_size())
     args = (C.byref(pb), capacity, use_aux)
     outs = (color.data_ptr(), depth.data_ptr(), alpha.data_ptr(), radii.data_ptr(), nr_ptr, nr_handle if capacity > 0 else None,
@@ -501,7 +499,7 @@ def rasterize_gaussians_batched(means3D, means2D, sh, colors_precomp, opacities,
     """
     st = raster_settings
     if (sh is None and scales is None and rotations is None and means2D is None and colors_precomp is not None and cov3Ds_precomp is not None
-            and not getattr(st, "debug", False) and means3D.ndim == 3 and means3D.shape[1] > 0 and not _USE_BWD_V1):
+            and not getattr(st, "debug", False) and means3D.ndim == 3 and means3D.shape[1] > 0):
         node = _cabi.torch_node()
         if node is not None:
             # the reference's input flavour: the same node in C++ (csrc/torch_node.cpp, RenderBatchedNode) -- same capacity policy
@@ -562,7 +560,7 @@ def rasterize_l1_loss_batched(means3D, means2D, sh, colors_precomp, opacities, s
     st = raster_settings
     cap = getattr(st, "max_rendered", 0) or 0
     if (cap > 0 and sh is None and scales is None and rotations is None and mask is None and means2D is None and colors_precomp is not None
-            and cov3Ds_precomp is not None and not getattr(st, "debug", False) and means3D.ndim == 3 and means3D.shape[1] > 0 and not _USE_BWD_V1):
+            and cov3Ds_precomp is not None and not getattr(st, "debug", False) and means3D.ndim == 3 and means3D.shape[1] > 0):
         node = _cabi.torch_node()
         if node is not None:
             # the reference's input flavour in the explicit sync-free mode: the same node in C++ (csrc/torch_node.cpp) -- half the host time per

@@ -1,8 +1,9 @@
 """-m gpu: HIP path (through the C ABI) against the CPU oracle on identical seeded inputs.
 
-Bars: integer artefacts (radii, tile rects, sorted keys, point lists, tile ranges) BIT-EXACT; images within
-1e-4 abs (north_star tolerance; observed ~1e-6); n_contrib equal except on ulp-borderline alpha tests;
-gradients within 1e-4 * max|g| per tensor (float atomics make the summation order free).
+Bars: integer artefacts (radii, tile rects, sorted keys, point lists, tile ranges, the per-Gaussian alpha-test thresholds p*) BIT-EXACT;
+images within 1e-4 abs (north_star tolerance; observed ~1e-6); n_contrib EQUAL (since round 5 every alpha-test decision of the HIP path
+is the oracle's, bit for bit: csrc/render.hip header; what can still differ is a `T < 1e-4` stop decision whose T sits within rounding of
+1e-4 -- counted where it happens); gradients within 1e-4 * max|g| per tensor.
 """
 import os
 
@@ -23,9 +24,9 @@ def _dev():
     return torch.device("cuda:0")
 
 
-@pytest.fixture(params=[1, 2, 3], ids=["fwd_serial", "fwd_segment_parallel", "fwd_wave_per_quadrant"])
+@pytest.fixture(params=[2, 3], ids=["fwd_segment_parallel", "fwd_wave_per_quadrant"])
 def fwd_mode(request):
-    """Run the test once per forward compositing kernel (serial per-tile / segment-parallel / one wave per quadrant); all must match the oracle."""
+    """Run the test once per forward compositing kernel (segment-parallel / one wave per quadrant); both must match the oracle."""
     from sigman_release_amd import _cabi
     _cabi.lib().sgr_set_forward_mode(request.param)
     yield request.param
@@ -73,13 +74,15 @@ def test_forward_artefacts_and_images(name, oracle, fwd_mode):
     np.testing.assert_array_equal(rec[vis, 6].view(np.uint32), ref.depths[vis].view(np.uint32))       # depth bits
     np.testing.assert_array_equal(rec[vis, 0:2].view(np.uint32), ref.xy[vis].view(np.uint32))         # pixel centre bits
     np.testing.assert_allclose(rec[vis][:, [2, 3, 4]], ref.conic_opacity[vis][:, :3], rtol=1e-6, atol=0)
+    # the alpha test as a per-Gaussian threshold on the exponent (record float 11): the oracle's restatement of the search, bit for bit
+    np.testing.assert_array_equal(rec[vis, 11].view(np.uint32), oracle.alpha_threshold(np.asarray(inp["opacities"]).reshape(-1)[vis]).view(np.uint32))
     # ---- images
     for k, r in (("color", ref.color), ("depth", ref.depth), ("alpha", ref.alpha)):
         err = np.abs(out[k][0].cpu().numpy() - r).max() if r.size else 0.0
         assert err <= IMG_TOL, f"{name}: {k} max abs err {err}"
     nc = out["n_contrib"][0].cpu().numpy().astype(np.uint32)
-    frac_bad = float((nc != ref.n_contrib).mean())
-    assert frac_bad <= 1e-3, f"{name}: n_contrib differs on {frac_bad:.2%} of pixels"
+    n_bad = int((nc != ref.n_contrib).sum())
+    assert n_bad == 0, f"{name}: n_contrib differs on {n_bad} pixels (alpha-test decisions are bit-exact: only a T < 1e-4 stop within rounding of the threshold may differ, and none does in these cases)"
     assert np.abs(out["final_T"][0].cpu().numpy() - ref.final_T).max() <= IMG_TOL
 
 
@@ -122,43 +125,6 @@ def test_backward_gradients(name, oracle, fwd_mode):
         err = float(np.abs(got - want).max()) / scale
         assert np.isfinite(got).all(), f"{name}: {nm} has non-finite gradients"
         assert err <= GRAD_TOL, f"{name}: grad {nm} rel-to-max err {err:.3e} (max|g| {scale:.3e})"
-
-
-@pytest.mark.parametrize("name", ["humanoid_20k_256", "deep_tiles", "opaque_stack", "cloud_sh3"])
-def test_compact_checkpoint_layout(name, oracle, fwd_mode):
-    """The forward's checkpoints for the bucket-parallel backward exist in two layouts (include/sigman_gsplat.h, sgr_set_aux_layout):
-    one record per 16-survivor row (default) or one per 64-survivor bucket with the inner rows rebuilt by the backward (4x smaller;
-    chosen automatically when the row layout would not fit).  Both must give the oracle's gradients."""
-    from sigman_release_amd import _cabi
-    from sigman_release_amd import rasterizer as R
-    dev = _dev()
-    inp, st = cases.CASES[name]()
-    H, W = st["image_height"], st["image_width"]
-    gC, gD, gA = cases.grads_for(H, W)
-    ref = oracle.forward(**inp, **cases.single_view(st))
-    gref = oracle.backward(ref, gC, gD, gA)
-    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-    res = {}
-    try:
-        for layout in (2, 1):
-            _cabi.lib().sgr_set_aux_layout(layout)
-            d = {k: t(v)[None].requires_grad_(True) for k, v in inp.items()}
-            color, radii, depth, alpha = R.rasterize_gaussians_batched(
-                d["means3D"], None, d.get("shs"), d.get("colors_precomp"), d["opacities"][..., None], d.get("scales"), d.get("rotations"),
-                d.get("cov3D_precomp"), _batched_settings(st, dev, 1))
-            ((color[0] * t(gC)).sum() + (depth[0] * t(gD)).sum() + (alpha[0] * t(gA)).sum()).backward()
-            torch.cuda.synchronize()
-            res[layout] = {k: v.grad[0].cpu().numpy() for k, v in d.items()}
-    finally:
-        _cabi.lib().sgr_set_aux_layout(0)
-    names = {"means3D": "means3D", "opacities": "opacities", "colors_precomp": "colors_precomp", "cov3D_precomp": "cov3D_precomp", "shs": "sh",
-             "scales": "scales", "rotations": "rotations"}
-    for k in res[1]:
-        want = gref[names[k]].reshape(res[1][k].shape)
-        scale = max(np.abs(want).max(), 1e-20)
-        for layout in (1, 2):
-            assert np.abs(res[layout][k] - want).max() / scale <= GRAD_TOL, (k, layout)
-        assert np.abs(res[1][k] - res[2][k]).max() / scale <= 2e-5, k
 
 
 def test_empty_and_degenerate():
@@ -244,20 +210,42 @@ def test_mark_visible(oracle):
 
 
 @pytest.mark.parametrize("name", ["cloud_precomp", "cloud_precomp_ragged", "cloud_sh3", "cull_and_clamp", "opaque_stack",
-                                  "single_gaussian"])
+                                  "single_gaussian", "c1_10k_256"])
 def test_against_committed_golden_vectors(name):
-    """HIP path vs tests/golden/*.npz (inputs + expected outputs committed; no oracle code involved at run time)."""
+    """HIP path vs tests/golden/*.npz (expected outputs committed; no oracle code involved at run time): every integer artefact the file holds
+    -- radii, tile rects, tiles touched, sorted keys, point list, tile ranges, n_contrib -- bit for bit, images and gradients within the
+    north_star tolerance.  `c1_10k_256` is BASELINE.json's config 1 at full size (its inputs and upstream gradients are seeded, not stored)."""
     import os
     from sigman_release_amd import rasterizer as R
     dev = _dev()
     z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"{name}.npz"))
-    _, st = cases.CASES[name]()
-    inp = {k[3:]: z[k] for k in z.files if k.startswith("in_")}
-    d = {k: torch.from_numpy(v).to(dev).requires_grad_(True) for k, v in inp.items()}
+    inp_seeded, st = cases.CASES[name]()
+    inp = {k[3:]: z[k] for k in z.files if k.startswith("in_")} or inp_seeded
+    d = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev).requires_grad_(True) for k, v in inp.items()}
     P = inp["means3D"].shape[0]
     H, W = st["image_height"], st["image_width"]
+    gC, gD, gA = (z["grad_color"], z["grad_depth"], z["grad_alpha"]) if "grad_color" in z.files else cases.grads_for(H, W)
     sv = cases.single_view(st)
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    # ---- the integer artefacts, from the debug forward (same kernels; it keeps the sorted keys and hands the intermediate buffers out)
+    with torch.no_grad():
+        o = {k: (v.detach()[None] if k != "opacities" else v.detach()[None]) for k, v in d.items()}
+        dbg = R.forward_debug(o["means3D"], o["opacities"], colors_precomp=o.get("colors_precomp"), shs=o.get("shs"), cov3D_precomp=o.get("cov3D_precomp"),
+                              scales=o.get("scales"), rotations=o.get("rotations"), settings=_batched_settings(st, dev, 1))
+    torch.cuda.synchronize()
+    assert dbg["num_rendered"] == z["keys"].shape[0]
+    np.testing.assert_array_equal(dbg["radii"][0].cpu().numpy(), z["radii"])
+    rect = dbg["rect"][0].cpu().numpy().astype(np.uint32)
+    rect4 = np.stack([rect[:, 0] & 0xFFFF, rect[:, 0] >> 16, rect[:, 1] & 0xFFFF, rect[:, 1] >> 16], 1).astype(np.int32)
+    vis = z["radii"] > 0
+    np.testing.assert_array_equal(rect4[vis], z["rect"][vis])
+    np.testing.assert_array_equal(((rect4[:, 2] - rect4[:, 0]) * (rect4[:, 3] - rect4[:, 1]))[vis], z["tiles_touched"][vis])
+    np.testing.assert_array_equal(dbg["keys"].cpu().numpy().view(np.uint64), z["keys"])
+    np.testing.assert_array_equal(dbg["point_list"].cpu().numpy().astype(np.uint32), z["point_list"])
+    np.testing.assert_array_equal(dbg["ranges"][0].cpu().numpy().astype(np.uint32), z["ranges"])
+    np.testing.assert_array_equal(dbg["n_contrib"][0].cpu().numpy().astype(np.uint32), z["n_contrib"])
+    assert np.abs(dbg["final_T"][0].cpu().numpy() - z["final_T"]).max() <= IMG_TOL
+    # ---- images and gradients through the upstream-signature module
     rs = R.GaussianRasterizationSettings(H, W, st["tanfovx"], st["tanfovy"], t(st["bg"]), st["scale_modifier"],
                                          t(sv["viewmatrix"]), t(sv["projmatrix"]), st["sh_degree"], t(sv["campos"]), False, False)
     means2D = torch.zeros(P, 3, device=dev, requires_grad=True)
@@ -265,7 +253,7 @@ def test_against_committed_golden_vectors(name):
         means3D=d["means3D"], means2D=means2D, opacities=d["opacities"].reshape(P, 1), shs=d.get("shs"),
         colors_precomp=d.get("colors_precomp"), scales=d.get("scales"), rotations=d.get("rotations"),
         cov3D_precomp=d.get("cov3D_precomp"))
-    ((color * t(z["grad_color"])).sum() + (depth * t(z["grad_depth"])).sum() + (alpha * t(z["grad_alpha"])).sum()).backward()
+    ((color * t(gC)).sum() + (depth * t(gD)).sum() + (alpha * t(gA)).sum()).backward()
     torch.cuda.synchronize()
     np.testing.assert_array_equal(radii.cpu().numpy(), z["radii"])
     assert np.abs(color.detach().cpu().numpy() - z["color"]).max() <= IMG_TOL
@@ -391,7 +379,7 @@ def test_second_backward_on_the_same_forward(node, oracle):
         assert err <= GRAD_TOL, f"{node}: second backward, grad {k} rel-to-max err {err:.3e}"
 
 
-@pytest.mark.parametrize("fwd_kind", [1, 2, 3], ids=["serial", "segment_parallel", "wave_per_quadrant"])
+@pytest.mark.parametrize("fwd_kind", [2, 3], ids=["segment_parallel", "wave_per_quadrant"])
 def test_depth_alpha_checkpoints_on_demand(fwd_kind):
     """By default the forward leaves the per-pixel (depth, alpha) checkpoints out (a third of its checkpoint stream; no call path of the
     reference differentiates depth or alpha) and a backward that IS handed dL/ddepth / dL/dalpha produces them with a second compositing
@@ -1091,7 +1079,7 @@ def test_backward_gather_kernels_bit_identical(views_per_subject, use_scales):
 def test_randomised_parity_slice(oracle):
     """A bounded slice of tools/fuzz_parity.py under the driver: 600 seeded random configurations (seeds 3000..3599 --
     ragged image sizes, P around the 64-lane boundaries, faint to saturating opacities, tiny to huge splats, colours + covariances or SH
-    degree 0-3 + scales / rotations, 1-3 views per batch, a random forward kernel and checkpoint layout each) against the CPU oracle, view by
+    degree 0-3 + scales / rotations, 1-3 views per batch, a random forward kernel each) against the CPU oracle, view by
     view.  Integer artefacts (instance count, radii, tile ranges; sorted keys and point list for single views) must be IDENTICAL in every
     configuration.  Images / gradients beyond the north_star tolerance are counted -- a Gaussian whose alpha sits within an ulp of 1/255 at
     a pixel is resolved differently by the oracle's expf and the kernels' v_exp_f32 -- and checked against the committed record like the
@@ -1113,9 +1101,8 @@ def test_randomised_parity_slice(oracle):
             views = [int(v) for v in rng.choice(90, V, replace=False)]
             st["viewmatrix"], st["projmatrix"], st["campos"] = cameras.make_cameras(views)
             H, W = st["image_height"], st["image_width"]
-            mode, layout = int(rng.choice([1, 2, 3])), int(rng.choice([1, 2]))
+            mode = int(rng.choice([2, 3]))
             L.sgr_set_forward_mode(mode)
-            L.sgr_set_aux_layout(layout)
             d = {k: t(v)[None].requires_grad_(True) for k, v in inp.items()}
             bst = _batched_settings(st, dev, V)
             with torch.no_grad():
@@ -1127,7 +1114,7 @@ def test_randomised_parity_slice(oracle):
             sum((color[v] * t(g[v][0])).sum() + (depth[v] * t(g[v][1])).sum() + (alpha[v] * t(g[v][2])).sum() for v in range(V)).backward()
             torch.cuda.synchronize()
             acc, total = None, 0
-            what = f"seed {seed} ({V} view(s), forward kernel {mode}, checkpoint layout {layout})"
+            what = f"seed {seed} ({V} view(s), forward kernel {mode})"
             for v in range(V):
                 r = oracle.forward(**inp, **cases.single_view(st, v))
                 assert np.array_equal(dbg["radii"][v].cpu().numpy(), r.radii), f"{what}: radii"
@@ -1162,7 +1149,6 @@ def test_randomised_parity_slice(oracle):
                     assert e <= 5e-2, f"{what}: grad {k} rel-to-max err {e:.3e}"
     finally:
         L.sgr_set_forward_mode(0)
-        L.sgr_set_aux_layout(0)
     assert n_views >= 600
     _check_against_observed("fuzz_slice", {"views_with_a_pixel_off": (n_bad_views, worst_img), "gradient_tensors_off": (n_bad_grads, worst_grad)})
 

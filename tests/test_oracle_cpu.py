@@ -15,18 +15,88 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 @pytest.mark.parametrize("name", make_golden.GOLDEN_CASES)
 def test_oracle_reproduces_golden(name, oracle):
-    """Bit-exact for integers; floats to 1e-6 (libm expf may differ by an ulp between hosts)."""
+    """Bit-exact for the integer artefacts AND the forward images: in its default (reproducible) mode the forward uses no libm function whose
+    last bit could differ between hosts -- sqrt and division are correctly rounded, the exponent is an explicit FMA chain, 2^x an fp64
+    polynomial of correctly rounded steps (gsplat_ref.c header).  Gradients (fp64 sums over OpenMP-scheduled tiles) to 1e-5 of their largest entry."""
     want = np.load(os.path.join(HERE, "golden", f"{name}.npz"))
     got = make_golden.make(name)
-    for k in ("radii", "rect", "tiles_touched", "keys", "point_list", "ranges"):
+    assert sorted(got) == sorted(want.files), name
+    for k in ("radii", "rect", "tiles_touched", "keys", "point_list", "ranges", "n_contrib"):
         np.testing.assert_array_equal(got[k], want[k], err_msg=f"{name}:{k}")
-    assert (got["n_contrib"] != want["n_contrib"]).mean() <= 1e-3
     for k in ("color", "depth", "alpha", "final_T"):
-        np.testing.assert_allclose(got[k], want[k], atol=1e-6, rtol=0, err_msg=f"{name}:{k}")
+        np.testing.assert_array_equal(got[k].view(np.uint32), want[k].view(np.uint32), err_msg=f"{name}:{k}")
     for k in want.files:
         if k.startswith("g_"):
             scale = max(np.abs(want[k]).max(), 1e-20)
             assert np.abs(got[k] - want[k]).max() / scale <= 1e-5, f"{name}:{k}"
+
+
+def test_exp2_cr_is_correctly_rounded(oracle):
+    """ref_exp2_cr (the fp64 polynomial whose steps preprocess.hip repeats) against numpy's exp2 in double, rounded to fp32: identical on
+    two million exponents over the range the alpha test can reach and beyond, plus exact powers of two."""
+    rng = np.random.default_rng(5)
+    x = np.concatenate([-rng.random(1_000_000, np.float32) * 9.0, -rng.random(1_000_000, np.float32) * 40.0,
+                        -np.arange(0, 127, dtype=np.float32), -np.float32(2.0) ** -np.arange(1, 60, dtype=np.float32)]).astype(np.float32)
+    got = oracle.exp2_cr(x)
+    want = np.exp2(x.astype(np.float64)).astype(np.float32)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), int((got != want).sum())
+    assert np.array_equal(oracle.exp2_cr(-np.arange(0, 20, dtype=np.float32)), (0.5 ** np.arange(0, 20)).astype(np.float32))
+
+
+def test_alpha_test_is_a_threshold_on_the_exponent(oracle):
+    """What the HIP kernels rely on: for every opacity there is ONE fp32 p* <= 0 with  (alpha test passes at p)  <=>  (p >= p*)  for all
+    p <= 0.  ref_alpha_threshold finds it by bisection; here the equivalence is checked against the DIRECT evaluation of the test (the one
+    the oracle's renderer uses) at p*, at its neighbours, and at random exponents -- for opacities from below 1/255 to above 1, the
+    threshold itself, 0.99 and its neighbours."""
+    rng = np.random.default_rng(11)
+    c = np.float32(1.0) / np.float32(255.0)
+    op = np.concatenate([rng.random(200_000, np.float32), np.float32(10.0) ** -(rng.random(50_000, np.float32) * 2.5).astype(np.float32),
+                         np.nextafter(c, np.float32(0), dtype=np.float32)[None], c[None], np.nextafter(c, np.float32(1), dtype=np.float32)[None],
+                         np.array([0.0, 1.0, 0.99, np.nextafter(np.float32(0.99), np.float32(1)), np.nextafter(np.float32(0.99), np.float32(0)), 1.5, 250.0, np.nan, -0.3], np.float32)]).astype(np.float32)
+    ps = oracle.alpha_threshold(op)
+    never = ~(op >= c)                                     # (NaN included)
+    assert np.isposinf(ps[never]).all() and np.isfinite(ps[~never]).all() and (ps[~never] <= 0).all()
+    o, p = op[~never], ps[~never]
+    assert oracle.alpha_test(o, p).all()                                                        # p* passes
+    below = np.nextafter(p, np.float32(-np.inf), dtype=np.float32)
+    assert not oracle.alpha_test(o, below).any()                                                # its lower neighbour does not
+    for k in range(4):                                                                          # monotone: random exponents on either side
+        q = (-rng.random(o.size, np.float32) * 9.0).astype(np.float32)
+        np.testing.assert_array_equal(oracle.alpha_test(o, q), q >= p)
+    assert not oracle.alpha_test(op[never], np.zeros(int(never.sum()), np.float32)).any()       # never-passing opacities fail even at p = 0
+
+
+@pytest.mark.parametrize("name", ["cloud_precomp", "opaque_stack", "humanoid_20k_256"])
+def test_reproducible_and_published_exponent_agree_up_to_threshold_decisions(name, oracle):
+    """The oracle's two arithmetic forms of the per-visit exponent (gsplat_ref.c header: 0 = explicit FMA chain on the pre-scaled conic +
+    correctly rounded exp2, the default the HIP kernels are pinned against; 1 = the published expression left to right + libm expf) are the
+    same function up to a few ulp: identical integer artefacts, images equal to 1e-5 except where an alpha within ~1e-6 of 1/255 (or a T
+    within rounding of 1e-4) falls on the other side -- at most a handful of pixels, each moved by less than one alpha step."""
+    inp, st = cases.CASES[name]()
+    sv = cases.single_view(st)
+    H, W = st["image_height"], st["image_width"]
+    gC, gD, gA = cases.grads_for(H, W)
+    res = []
+    try:
+        for mode in (0, 1):
+            oracle.set_alpha_mode(mode)
+            r = oracle.forward(**inp, **sv)
+            res.append((r, oracle.backward(r, gC, gD, gA)))
+    finally:
+        oracle.set_alpha_mode(0)
+    (r0, g0), (r1, g1) = res
+    np.testing.assert_array_equal(r0.keys, r1.keys)
+    np.testing.assert_array_equal(r0.ranges, r1.ranges)
+    off = np.zeros((H, W), bool)
+    for a, b in ((r0.color, r1.color), (r0.depth, r1.depth), (r0.alpha, r1.alpha)):
+        e = np.abs(a - b)
+        off |= (e > 1e-5).reshape(-1, H, W).any(0)
+        assert e.max() <= 4.0 / 255.0
+    flips = int((r0.n_contrib != r1.n_contrib).sum())
+    assert off.sum() <= 4 and flips <= 4, (int(off.sum()), flips)
+    for k in g0:
+        scale = max(np.abs(g0[k]).max(), 1e-20)
+        assert np.abs(g0[k] - g1[k]).max() / scale <= (1e-5 if off.sum() == 0 else 2e-2), k
 
 
 def _dense_vs_c(oracle, inp, st, H, W):

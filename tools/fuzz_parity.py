@@ -38,8 +38,8 @@ try:
         views = [int(v) for v in rng.choice(90, V, replace=False)]
         st["viewmatrix"], st["projmatrix"], st["campos"] = cameras.make_cameras(views)
         H, W = st["image_height"], st["image_width"]
-        mode, layout = int(rng.choice([1, 2, 3])), int(rng.choice([1, 2]))
-        L.sgr_set_forward_mode(mode); L.sgr_set_aux_layout(layout)
+        mode, layout = int(rng.choice([2, 3])), 2
+        L.sgr_set_forward_mode(mode)
         d = {k: t(v)[None].requires_grad_(True) for k, v in inp.items()}
         bst = T._batched_settings(st, dev, V)
         with torch.no_grad():
@@ -81,7 +81,7 @@ try:
             if e > 1e-4: bad_grad.append((seed, k, V, mode, layout, e))
         n += 1; n_views += V; seed += 1
 finally:
-    L.sgr_set_forward_mode(0); L.sgr_set_aux_layout(0)
+    L.sgr_set_forward_mode(0)
 print(f"fuzz_parity: {n} configurations, {n_views} views (seeds up to {seed - 1}): integer artefacts differ in {len(bad_int)}; "
       f"views with a pixel beyond 1e-4: {len(bad_img)} (largest error {worst_img:.3e}; at most {most_pixels} pixel(s) of a view are off: single decisions at the 1/255 alpha threshold, tools/fuzz_parity_explain.py); gradients beyond 1e-4 of max|g| in {len(bad_grad)} (largest {worst_grad:.3e})")
 for name, lst in (("integer", bad_int), ("image", bad_img), ("gradient", bad_grad)):
