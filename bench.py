@@ -30,7 +30,12 @@ of the whole job with inputs resident in HBM.  The timed step is the rasterizer 
 (gs.py:70-73) run once per subject outside it; their cost is reported as `frontend_ms_per_subject`, and `variants.renderer_render_ms_per_step`
 times what the reference's render() really pays: GaussianRenderer.render (3-NN + covariance + rasterizer + clamp) forward and backward.
 A timed region shorter than 100 ms is not a measurement: when `--steps K` would give one, as many steps as 100 ms hold (at least 100) are
-timed instead and the line says so (`steps` = what was timed, `steps_requested` = K).
+timed instead and the line says so (`steps` = what was timed, `steps_requested` = K).  `gpu_ms_per_step` is the same region between two HIP
+events on the launch stream (first kernel to last kernel: it excludes the host's final synchronise, not the gaps the host may leave between
+steps); `windows` repeats the K steps `--windows` more times and reports min / median / max per step of wall and event time, so that a slow
+phase of the box or of its clocks shows up as spread instead of being folded into one number; `sclk_mhz` = the GPU's shader clock sampled
+from sysfs by a side process during the timed region.  The loss of the timed step is the reference's MASKED L1 (whole_loss.py:126-131:
+gt_masks multiplies prediction and target; mask = ground-truth alpha > 0.5) unless `--no-mask`.
 `roofline` is for the dominant kernel, timed with HIP events recorded by the library on the launch stream inside the
 timed region; `roofline.traffic` comes from the committed rocprofv3 PMC summary of this same command
 (profiles/r04_pmc_<config>.json, else the newest older one; null when there is none for the workload).  `cpu_baseline` is the CPU oracle
@@ -65,6 +70,8 @@ def parse_args(argv=None):
                          "the other chunk is rendered (parallel.view_parallel_subjects)")
     ap.add_argument("--pipeline-chunks", type=int, default=0, help="full-pipelined: pipeline stages per step (default: one per subject)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-mask", action="store_true", help="plain L1 instead of the reference's masked L1 (whole_loss.py:126-131: gt_masks = ground-truth alpha > 0.5)")
+    ap.add_argument("--windows", type=int, default=8, help="untimed-for-the-headline repeat windows of the same K steps behind the timed region (spread report)")
     ap.add_argument("--no-variants", action="store_true", help="skip the unpinned / exact-sync / per-view-loop re-runs (N=1, c2/c3)")
     ap.add_argument("--exact-sync", action="store_true", help="read num_rendered back every step (upstream behaviour) instead of the sync-free capacity mode")
     return ap.parse_args(argv)
@@ -208,6 +215,54 @@ def build_subject(cfg_name: str, P: int, seed: int, dev):
     return dict(means3D=t(g["position"]), cov3D=t(cov), opacity=t(g["opacity"].reshape(P, 1)), rgb=t(g["rgb"])), g, cov
 
 
+class _SclkSampler:
+    """Shader clock of the GPU during the timed region, sampled by a side process (pinned off the step's cores) that reads the amdgpu sysfs
+    node every 10 ms -- no HIP call, no GIL shared with the step.  stop() -> {"min", "median", "max", "samples", "source"} in MHz, or a note."""
+    _SRC = r'''
+import glob, os, re, sys, time
+idx = int(sys.argv[1])
+try:
+    os.sched_setaffinity(0, set(os.sched_getaffinity(0)) - set(range(0, 4)) or os.sched_getaffinity(0))
+except Exception:
+    pass
+cards = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"), key=lambda p: int(re.search(r"card(\d+)", p).group(1)))
+path = cards[idx] if idx < len(cards) else (cards[0] if cards else None)
+print(path or "none", flush=True)
+while path:
+    try:
+        for ln in open(path):
+            if "*" in ln:
+                m = re.search(r"(\d+)\s*[Mm][Hh]z", ln)
+                if m: print(m.group(1), flush=True)
+    except Exception as e:
+        print("err", e, flush=True); break
+    time.sleep(0.01)
+'''
+
+    def __init__(self, local_rank):
+        self.p = None
+        try:
+            self.p = subprocess.Popen([sys.executable, "-c", self._SRC, str(local_rank)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True,
+                                      preexec_fn=(lambda: os.sched_setaffinity(0, _ORIG_AFFINITY)) if _ORIG_AFFINITY else None)
+            self.src = self.p.stdout.readline().strip()          # the sampler is up (first line: the node it reads)
+        except Exception as e:      # noqa: BLE001
+            self.src = f"unavailable ({e})"
+
+    def stop(self):
+        if self.p is None:
+            return {"note": self.src}
+        self.p.terminate()
+        try:
+            out, _ = self.p.communicate(timeout=5)
+        except Exception:      # noqa: BLE001
+            self.p.kill()
+            out = ""
+        v = [int(x) for x in out.split() if x.isdigit()]
+        if not v:
+            return {"note": f"no samples from {self.src}"}
+        return {"min": int(np.min(v)), "median": int(np.median(v)), "max": int(np.max(v)), "samples": len(v), "source": self.src}
+
+
 def fail(msg: str, code: int = 2):
     print(f"[bench] ERROR: {msg}", file=sys.stderr, flush=True)
     sys.exit(code)
@@ -282,14 +337,18 @@ def main(args):
             del probe
     norm = 1.0 / (n_total_views * 3 * H * W)
 
-    gt = gD = gA = None
+    gt = gD = gA = gt_mask = None
     if bwd and n_local:
         # ground truth: render of a perturbed copy (untimed); stand-in for the dataset image of whole_loss.py:126-131
         with torch.no_grad():
             rng = torch.Generator(device="cpu").manual_seed(1234)
             pert = lambda x, s: x + s * torch.randn(x.shape, generator=rng).to(dev)
-            gt = R.rasterize_gaussians_batched(pert(subj["means3D"], 2e-3), None, None, subj["rgb"] * 0.9, subj["opacity"], None, None,
-                                               subj["cov3D"], st)[0].clamp(0, 1)
+            gt_all = R.rasterize_gaussians_batched(pert(subj["means3D"], 2e-3), None, None, subj["rgb"] * 0.9, subj["opacity"], None, None,
+                                                   subj["cov3D"], st)
+            gt = gt_all[0].clamp(0, 1)
+            # the reference's loss mask (the subject's matte; whole_loss.py:126-131 multiplies prediction AND target by it)
+            gt_mask = None if args.no_mask else (gt_all[3] > 0.5).to(torch.float32).contiguous()
+            del gt_all
         if da:
             gen = torch.Generator(device="cpu").manual_seed(77)
             gD = (torch.randn(n_local, 1, H, W, generator=gen) * norm).to(dev)
@@ -299,7 +358,7 @@ def main(args):
     def render_loss(means3D, cov3D, opacity, rgb, _views=None):
         # gs.py:98-107 rasterize + clamp, whole_loss.py:126-131 L1: one autograd node, loss kernel right behind the compositing kernel
         sp = lambda x, k: x.reshape(S, P, k)
-        out = R.rasterize_l1_loss_batched(sp(means3D, 3), None, None, sp(rgb, 3), sp(opacity, 1), None, None, sp(cov3D, 6), st, gt, None, norm)
+        out = R.rasterize_l1_loss_batched(sp(means3D, 3), None, None, sp(rgb, 3), sp(opacity, 1), None, None, sp(cov3D, 6), st, gt, gt_mask, norm)
         return out if da else out[0]
 
     leaves = {k: v.clone().requires_grad_(True) for k, v in subj.items()}
@@ -337,12 +396,13 @@ def main(args):
             gt_c = gt[c * Sc * len(mine): (c + 1) * Sc * len(mine)]
             gD_c = None if gD is None else gD[c * Sc * len(mine): (c + 1) * Sc * len(mine)]
             gA_c = None if gA is None else gA[c * Sc * len(mine): (c + 1) * Sc * len(mine)]
+            gm_c = None if gt_mask is None else gt_mask[c * Sc * len(mine): (c + 1) * Sc * len(mine)]
             chunk_packs.append(parallel.pack_attributes(subj["means3D"][sl].reshape(Sc * P, 3), subj["cov3D"][sl].reshape(Sc * P, 6),
                                                         subj["opacity"][sl].reshape(Sc * P), subj["rgb"][sl].reshape(Sc * P, 3)))
 
-            def fn(m, cv_, o, r, _views, st_c=st_c, gt_c=gt_c, gD_c=gD_c, gA_c=gA_c):
+            def fn(m, cv_, o, r, _views, st_c=st_c, gt_c=gt_c, gD_c=gD_c, gA_c=gA_c, gm_c=gm_c):
                 spc = lambda x, k: x.reshape(Sc, P, k)
-                out = R.rasterize_l1_loss_batched(spc(m, 3), None, None, spc(r, 3), spc(o, 1), None, None, spc(cv_, 6), st_c, gt_c, None, norm)
+                out = R.rasterize_l1_loss_batched(spc(m, 3), None, None, spc(r, 3), spc(o, 1), None, None, spc(cv_, 6), st_c, gt_c, gm_c, norm)
                 return (out[0], [out[4], out[5]], [gD_c, gA_c]) if da else out[0]
             chunk_fns.append(fn)
         pipe = (chunk_packs, chunk_fns)
@@ -456,16 +516,34 @@ def main(args):
     import gc
     gc.collect()
     gc.disable()
+    sclk = _SclkSampler(local_rank) if rank == 0 else None       # a side PROCESS on another core (no GIL, no HIP): reads one sysfs file every 10 ms
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)   # (the library launches on torch's current stream)
     sync_all()
     t0 = time.perf_counter()
+    ev0.record()
     loss = None
     dbg_marks = []
     for k_ in range(steps):
         loss = step()
         if _DEBUG_BLOCKS and (k_ + 1) % max(steps // 8, 1) == 0:
             dbg_marks.append(time.perf_counter() - t0)           # (host time stamps only: no synchronisation inside the timed region)
+    ev1.record()
     sync_all()
     elapsed = time.perf_counter() - t0
+    gpu_elapsed = ev0.elapsed_time(ev1) * 1e-3
+    sclk_report = sclk.stop() if sclk is not None else None
+    # ---- the same K steps `--windows` more times: spread of wall and event time per step (not the headline: that is the region above)
+    win_wall, win_gpu = [], []
+    for _w in range(max(args.windows, 0)):
+        sync_all()
+        tw = time.perf_counter()
+        ev0.record()
+        for _ in range(steps):
+            step()
+        ev1.record()
+        sync_all()
+        win_wall.append((time.perf_counter() - tw) / steps * 1e3)
+        win_gpu.append(ev0.elapsed_time(ev1) / steps)
     gc.enable()
     R.check_pending_overflows(True)                      # every step's instance count has been looked at (raises if one did not fit)
     if _DEBUG_BLOCKS:
@@ -517,11 +595,11 @@ def main(args):
     out = {
         "metric": f"rendered views/sec ({'fwd+bwd' if bwd else 'fwd'}) at {H}x{W}, {P} Gaussians/view",
         "value": round(views_per_s, 3), "unit": "views/s", "n_gpus": world, "steps": steps, "steps_requested": steps_requested, "warmup": warmup,
-        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": cfg["scaling"], "vs_baseline": None,
+        "ms_per_step": round(ms_per_step, 4), "gpu_ms_per_step": round(gpu_elapsed / steps * 1e3, 4), "higher_is_better": True, "scaling": cfg["scaling"], "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{cfg['label']}, {P} Gaussians/subject, {S} subject(s) x {len(mine)} view(s) on this GPU per step, "
                                f"{H}x{W}, {'fwd+bwd' if bwd else 'forward only'}, colors_precomp+cov3D_precomp"
-                               + (", clamp+L1 loss" if bwd else "") + (", dL/ddepth and dL/dalpha non-zero" if da else ""),
+                               + ((", clamp + masked L1 loss (mask = ground-truth alpha > 0.5)" if gt_mask is not None else ", clamp+L1 loss") if bwd else "") + (", dL/ddepth and dL/dalpha non-zero" if da else ""),
                    "name": args.config, "views_per_step_total": n_total_views, "view_slots_this_gpu": n_local,
                    "parallelism": (f"view-parallel x{world} ({backend}), exchange={'none (forward only)' if not bwd else args.exchange}" if dist_on else "single GPU"),
                    "ranks_seen": world, "num_rendered_per_gpu": Rn, "gaussian_pixel_visits_per_gpu": S_visits,
@@ -538,6 +616,12 @@ def main(args):
         "loss": None if loss is None else float(loss.detach()),
     }
     out["config"]["host_threads"] = pin_report
+    if win_wall:
+        q = lambda v: [round(float(x), 4) for x in (np.min(v), np.median(v), np.max(v))]
+        out["windows"] = {"n": len(win_wall), "steps_each": steps, "wall_ms_per_step_min_median_max": q(win_wall), "gpu_ms_per_step_min_median_max": q(win_gpu),
+                          "note": "repeats of the timed region behind it (this rank); the headline is the first region, not their minimum"}
+    if sclk_report is not None:
+        out["sclk_mhz"] = sclk_report
     if rank == 0 and world == 1:
         out["frontend_ms_per_subject"] = frontend_ms(g_host, dev)
         if not args.no_variants and args.config in ("c2", "c3"):

@@ -473,7 +473,7 @@ void b_poll(bool block) {            // forwards of this thread whose backward n
 
 struct RasterizeL1BatchedNode : public torch::autograd::Function<RasterizeL1BatchedNode> {
     static variable_list forward(AutogradContext *ctx, Tensor means3D_, Tensor colors_, Tensor opac_, Tensor cov_, Tensor vm_, Tensor pm_, Tensor campos_,
-                                 Tensor bg_, Tensor target_, int64_t H, int64_t W, double tfx, double tfy, double smod, int64_t vps, int64_t capacity_,
+                                 Tensor bg_, Tensor target_, Tensor mask_, int64_t H, int64_t W, double tfx, double tfy, double smod, int64_t vps, int64_t capacity_,
                                  double weight, bool da_grads, bool grad_mode) {
         TORCH_CHECK(means3D_.dim() == 3 && means3D_.size(2) == 3, "means3D must have dimensions (subjects, num_points, 3)");
         TORCH_CHECK(means3D_.is_cuda(), "sigman_release_amd rasterizer needs tensors on a ROCm device (there is no CPU fallback)");
@@ -486,6 +486,11 @@ struct RasterizeL1BatchedNode : public torch::autograd::Function<RasterizeL1Batc
         const Tensor vm = f32c(vm_), pm = f32c(pm_), campos = f32c(campos_), bg = f32c(bg_), target = f32c(target_);
         const int64_t nv = vm.size(0);
         TORCH_CHECK(nv == S * vps, "viewmatrix has ", nv, " views but inputs describe ", S, " subjects x ", vps, " views");
+        // the loss mask of the reference (whole_loss.py:126-131: gt_masks multiplies prediction and target alike), [n_views,1,H,W]; an empty tensor = none
+        const bool has_mask = mask_.defined() && mask_.numel() > 0;
+        const Tensor mask = has_mask ? f32c(mask_.device() == dev ? mask_ : mask_.to(dev)) : Tensor();
+        TORCH_CHECK(!has_mask || mask.numel() == nv * H * W, "mask must have ", nv * H * W, " elements ([n_views,1,H,W]), got ", mask.numel());
+        TORCH_CHECK(target.numel() == nv * 3 * H * W, "target must have ", nv * 3 * H * W, " elements ([n_views,3,H,W]), got ", target.numel());
         // (under torch.no_grad() nothing will ever come back for a gradient, whatever the leaves say: the lighter forward, the count looked at now)
         // (grad_mode: torch.is_grad_enabled() of the CALLER -- inside a Function's forward it is always off)
         const bool wants_grad = grad_mode && (means3D_.requires_grad() || opac_.requires_grad() || colors_.requires_grad() || cov_.requires_grad());
@@ -500,7 +505,7 @@ struct RasterizeL1BatchedNode : public torch::autograd::Function<RasterizeL1Batc
         const uint64_t capacity = (uint64_t)capacity_;
         b_poll(false);
         SgrL1Epilogue ep;
-        ep.target = target.data_ptr<float>(); ep.mask = nullptr; ep.grad_color = gimg.data_ptr<float>(); ep.loss_per_view = sums.data_ptr<float>();
+        ep.target = target.data_ptr<float>(); ep.mask = has_mask ? mask.data_ptr<float>() : nullptr; ep.grad_color = gimg.data_ptr<float>(); ep.loss_per_view = sums.data_ptr<float>();
         ep.loss_total = sums.data_ptr<float>() + nv; ep.weight = (float)weight; ep.sums_already_zero = 1;
         SgrForwardState st;
         memset(&st, 0, sizeof(st));
@@ -592,7 +597,7 @@ struct RasterizeL1BatchedNode : public torch::autograd::Function<RasterizeL1Batc
             if (b_resolve(*mine, !count_wait_lazy()) && mine->overflow && !mine->reported) b_raise(*mine, false);
         }
         variable_list out = {d_means3D, d_col, dims[6] == 3 ? d_op.unsqueeze(-1) : d_op, d_cov};
-        for (int k = 0; k < 15; k++) out.push_back(Tensor());
+        for (int k = 0; k < 16; k++) out.push_back(Tensor());
         return out;
     }
 };
@@ -828,8 +833,9 @@ std::vector<Tensor> render_batched(Tensor position, Tensor rgb, Tensor opacity, 
 }
 
 std::vector<Tensor> rasterize_l1_batched(Tensor means3D, Tensor colors, Tensor opac, Tensor cov, Tensor vm, Tensor pm, Tensor campos, Tensor bg, Tensor target,
-                                         int64_t H, int64_t W, double tfx, double tfy, double smod, int64_t vps, int64_t capacity, double weight, bool da_grads) {
-    return RasterizeL1BatchedNode::apply(means3D, colors, opac, cov, vm, pm, campos, bg, target, H, W, tfx, tfy, smod, vps, capacity, weight, da_grads,
+                                         Tensor mask /* [n_views,1,H,W], or an empty tensor */, int64_t H, int64_t W, double tfx, double tfy, double smod, int64_t vps,
+                                         int64_t capacity, double weight, bool da_grads) {
+    return RasterizeL1BatchedNode::apply(means3D, colors, opac, cov, vm, pm, campos, bg, target, mask, H, W, tfx, tfy, smod, vps, capacity, weight, da_grads,
                                          at::GradMode::is_enabled());
 }
 

@@ -559,14 +559,16 @@ def rasterize_l1_loss_batched(means3D, means2D, sh, colors_precomp, opacities, s
     """-> (loss, per_view_loss [n_views], color, radii, depth, alpha);  loss = weight * sum(mask * |clamp(color, 0, 1) - target|)."""
     st = raster_settings
     cap = getattr(st, "max_rendered", 0) or 0
-    if (cap > 0 and sh is None and scales is None and rotations is None and mask is None and means2D is None and colors_precomp is not None
+    if (cap > 0 and sh is None and scales is None and rotations is None and means2D is None and colors_precomp is not None
             and cov3Ds_precomp is not None and not getattr(st, "debug", False) and means3D.ndim == 3 and means3D.shape[1] > 0):
         node = _cabi.torch_node()
         if node is not None:
             # the reference's input flavour in the explicit sync-free mode: the same node in C++ (csrc/torch_node.cpp) -- half the host time per
             # step, which at one view is what decides whether the host keeps up with 137 us of kernels
+            # (with or without the reference's loss mask, whole_loss.py:126-131; an upstream gradient into the colour output -- LPIPS next to
+            # the L1 -- is added to the L1's inside the node's backward)
             return tuple(node.rasterize_l1_batched(means3D, colors_precomp, opacities, cov3Ds_precomp, st.viewmatrix, st.projmatrix, st.campos, st.bg, target,
-                                                   int(st.image_height), int(st.image_width), float(st.tanfovx), float(st.tanfovy), float(st.scale_modifier),
+                                                   _EMPTY if mask is None else mask, int(st.image_height), int(st.image_width), float(st.tanfovx), float(st.tanfovy), float(st.scale_modifier),
                                                    int(st.views_per_subject), int(cap), float(weight), bool(getattr(st, "depth_alpha_grads", None))))
     return _RasterizeL1Batched.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                                      raster_settings, target, mask, weight)
