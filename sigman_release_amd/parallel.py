@@ -31,11 +31,20 @@ from __future__ import annotations
 
 from typing import Callable, Sequence
 
+import os
+
 import torch
 import torch.distributed as dist
 
 ATTR = 13  # mean 3 | cov3D 6 | opacity 1 | rgb 3
 
+
+
+def _collectives(world: int) -> bool:
+    """Are collectives issued?  Always for more than one rank; for ONE rank only when a process group exists and SIGMAN_FORCE_COLLECTIVES=1
+    asks for them -- a 1-rank broadcast / all-reduce / all-gather is a valid RCCL operation on the backend's own stream, which is how the
+    1-GPU test box runs every call (and every stream-ordering wait) of the N > 1 paths."""
+    return world > 1 or (dist.is_initialized() and os.environ.get("SIGMAN_FORCE_COLLECTIVES") == "1")
 
 def shard_views(n_views: int, rank: int, world: int) -> list[int]:
     """Views rendered by `rank`: {v : v mod world == rank} (C3: 8 views <-> 8 GPUs; C4: 90 views -> 11-12 per GPU)."""
@@ -100,7 +109,7 @@ def view_parallel_step(packed: torch.Tensor, view_ids: Sequence[int], render_los
             loss_val = loss.detach().reshape(1).clone()
         else:
             loss, loss_val = None, torch.zeros(1, device=packed.device, dtype=packed.dtype)
-        if world > 1:
+        if _collectives(world):
             work = dist.all_reduce(loss_val, op=dist.ReduceOp.SUM, group=group, async_op=True)   # travels while the backward runs
         if loss is not None:
             _backward(loss, seed_grad, extra_out, extra_grad)
@@ -113,7 +122,7 @@ def view_parallel_step(packed: torch.Tensor, view_ids: Sequence[int], render_los
         if work is not None:
             work.wait()
         return loss_val[0], grad
-    if world > 1 and broadcast:
+    if _collectives(world) and broadcast:
         dist.broadcast(packed, src=src, group=group)
     # the four attributes are contiguous views of the flat buffer: separate autograd leaves without any copy
     leaves = [x.detach().requires_grad_(True) for x in unpack_attributes(packed)]
@@ -125,7 +134,7 @@ def view_parallel_step(packed: torch.Tensor, view_ids: Sequence[int], render_los
                         + [loss.detach().reshape(1).to(packed.dtype)])
     else:
         buf = torch.zeros(packed.numel() + 1, device=packed.device, dtype=packed.dtype)
-    if world > 1:
+    if _collectives(world):
         dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)     # gradients [13*P] + loss scalar: one collective
     return buf[-1], buf[:-1]
 
@@ -158,7 +167,7 @@ def view_parallel_subjects(chunks: Sequence[torch.Tensor], view_ids: Sequence[in
     bufs = [None] * n
 
     def start_broadcast(c):
-        if world > 1:
+        if _collectives(world):
             bwork[c] = dist.broadcast(chunks[c], src=srcs[c], group=group, async_op=pipeline)
 
     if n:
@@ -176,7 +185,7 @@ def view_parallel_subjects(chunks: Sequence[torch.Tensor], view_ids: Sequence[in
                                 + [loss.detach().reshape(1).to(chunks[c].dtype)])
         else:
             bufs[c] = torch.zeros(chunks[c].numel() + 1, device=chunks[c].device, dtype=chunks[c].dtype)
-        if world > 1:
+        if _collectives(world):
             rwork[c] = dist.all_reduce(bufs[c], op=dist.ReduceOp.SUM, group=group, async_op=pipeline)   # travels while chunk c+1 is rendered
         if not pipeline and c + 1 < n:
             start_broadcast(c + 1)
@@ -197,7 +206,7 @@ def all_gather_images(local: torch.Tensor, n_views: int, group=None) -> torch.Te
     n_mine = len(shard_views(n_views, rank, world))
     if local.shape[0] != n_mine:
         raise ValueError(f"rank {rank} of {world} holds {local.shape[0]} views, its shard of {n_views} views has {n_mine}")
-    if world == 1:
+    if not _collectives(world):
         return local
     per = (n_views + world - 1) // world
     pad = local if n_mine == per else torch.cat([local, local.new_zeros((per - n_mine,) + tuple(local.shape[1:]))])

@@ -131,11 +131,11 @@ def test_bench_rccl_path_with_one_rank():
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
         s.close()
-        env = dict(os.environ, SIGMAN_BENCH_FORCE_PG="1")
+        env = dict(os.environ, SIGMAN_BENCH_FORCE_PG="1", SIGMAN_FORCE_COLLECTIVES="1")     # one rank, but every collective of the N > 1 step is issued
         env.pop("SIGMAN_BENCH_BACKEND", None)
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
                "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--config", config, "--steps", str(steps), "--warmup", "2",
-               "--exchange", exchange, "--no-cpu-baseline", "--no-variants"]
+               "--exchange", exchange, "--no-cpu-baseline", "--no-variants", "--windows", "0"]
         r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         lines = [l for l in r.stdout.splitlines() if l.strip()]
@@ -175,17 +175,19 @@ def _pipe_problem(dev):
     return chunks, [make(s) for s in range(PS)]
 
 
-def _pipe_worker(rank, world, port, q):
+def _pipe_worker(rank, world, port, q, backend="gloo"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    if world == 1:
+        os.environ["SIGMAN_FORCE_COLLECTIVES"] = "1"          # the 1-rank RCCL run issues every broadcast / all-reduce / all-gather
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
     from sigman_release_amd import parallel
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    dist.init_process_group(backend, rank=rank, world_size=world, **({"device_id": dev} if backend == "nccl" else {}))
     try:
-        dev = torch.device("cuda", 0)
-        torch.cuda.set_device(0)
         truth, fns = _pipe_problem(dev)
-        srcs = [0, 1, 0, 1]
+        srcs = [i % world for i in range(PS)]
         out = {}
         for pipeline in (False, True):
             chunks = [c.clone() if rank == srcs[i] else torch.zeros_like(c) for i, c in enumerate(truth)]
@@ -256,3 +258,32 @@ def test_two_ranks_pipelined_subject_exchange_bitwise_equals_blocking():
         np.testing.assert_array_equal(allv, images)                       # single-view renders of a batch == the batched render, bit for bit
     for s_ in range(PS):
         np.testing.assert_array_equal(res[0][0][True][1][s_], res[1][0][True][1][s_])
+
+
+def test_rccl_one_rank_pipelined_exchange_bitwise_equals_blocking():
+    """The pipelined "full" exchange over RCCL itself (backend "nccl"): collectives on the backend's own stream, `work.wait()` ordering the
+    compute stream behind them, chunk c + 1's broadcast issued before chunk c is rendered, chunk c's all-reduce behind its backward -- with
+    ONE rank under the process group (the 1-GPU box cannot hold two RCCL ranks; every call an 8-GPU step makes is made, and a missing
+    wait would let the render read a pack the broadcast has not delivered).  Gradients bitwise equal to the blocking protocol and to the
+    group-less single-process run; `all_gather_images` takes its RCCL branch.  UNMEASURED ON HARDWARE beyond this: no multi-GPU node so far."""
+    from sigman_release_amd import parallel
+    dev = torch.device("cuda", 0)
+    truth, fns = _pipe_problem(dev)
+    want = parallel.view_parallel_subjects([c.clone() for c in truth], list(VIEWS), fns)
+    torch.cuda.synchronize()
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_pipe_worker, args=(0, 1, port, q, "nccl"))
+    p.start()
+    rank, out, allv = q.get(timeout=600)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    np.testing.assert_allclose(out[True][0], out[False][0], rtol=1e-6)
+    for a, b, w in zip(out[True][1], out[False][1], want[1]):
+        np.testing.assert_array_equal(a, b)                                  # pipelined == blocking, bit for bit
+        np.testing.assert_array_equal(a, w.cpu().numpy())                    # == no process group at all
+    assert allv.shape[0] == len(VIEWS)
