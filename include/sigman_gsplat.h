@@ -189,16 +189,17 @@ int32_t sgr_preprocess_blocks_per_view(int32_t P);
 int sgr_preprocess_forward(const SgrProblem *pb, float *rec, int32_t *radii, uint32_t *rect, uint8_t *clamped,
                            uint32_t *block_offsets, uint64_t *num_rendered, uint64_t capacity, void *stream);
 
-/* sort flavour: 3 = automatic (default); 4 = view-segmented: the emission is view-major, so ONE order-free counting pass per view over the
- * tile id (<= 4096 tiles per view) + a register sort of (depth bits, value) composites per tile; 2 = segmented: global LSD passes over
- * the tile-id bits only, then a stable LDS radix sort of the depth bits per tile; 5 = segmented with the register sort per tile (one
- * order-free 11-bit tile pass; one or two 512^2 views, else like 2); 0 = onesweep over the whole key (one kernel per digit, decoupled
- * look-back); 1 = three kernels per digit.  All give bit-identical sorted keys, values and ranges (for finite depths). */
+/* sort flavour: 3 = automatic (default); 5 = one order-free 11-bit pass over the tile id (its histogram rows written by the emission
+ * kernel) + an LDS distribution sort of (depth bits, value) composites per tile: one or two 512^2 views (<= 2048 tiles, <= 2^19 instances),
+ * else like 3; 4 = view-segmented: the emission is view-major, so ONE order-free counting pass per view over the tile id (<= 4096 tiles per
+ * view) + a register sort of the composites per tile; 1 = three kernels per 8-bit digit over the whole key (the fallback beyond 4096 tiles
+ * per view).  All give bit-identical sorted keys, values and ranges (for finite depths).  Anything else is refused.  (ABI <= 6 also had
+ * 0 = onesweep and 2 = LDS-segmented.) */
 int sgr_set_sort_mode(int mode);
 /* deep tile lists in the view-segmented flavour: instead of the register comparison network, a long tile is sorted by DISTRIBUTION in LDS
  * by one workgroup (per window of 15 232 entries): adaptive depth bins from the tile's own histogram, bin-ordered placement, rank inside
  * the (tiny) bin -- O(n).  mode 0 = automatic (launches with more than 1024 instances per tile on average, e.g. 1M Gaussians at 512^2:
- * they used to fall back to six whole-key radix passes), 1 = whenever flavour 4 runs, 2 = never.  Same bits out; a tile with massive
+ * they used to fall back to six whole-key radix passes), 1 = whenever flavour 4 runs, 2 = never (flavour 4 only: flavour 5 always uses it).  Same bits out; a tile with massive
  * exact depth ties (> 128 in one bin) takes the generic path.  Bits 8..15 of `mode` (tests; 0 = default 64): behind the single wide tile pass
  * (one or two 512^2 views) a tile with more windows of 3968 entries than this is listed once and sorted whole by one workgroup -- what a tile
  * beyond 64 windows (the window field of a list entry) gets in production. */

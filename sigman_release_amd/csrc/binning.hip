@@ -301,25 +301,6 @@ __global__ __launch_bounds__(kThreads) void radix_downsweep_kernel(const uint64_
 // digits that occur in the round (leaders of each wave's match-any groups), never the whole 2048-entry tables.
 constexpr int kWideBits = 11, kWide = 1 << kWideBits;
 
-template <int ITEMS>
-__global__ __launch_bounds__(kThreads) void wide_upsweep_kernel(const uint64_t *__restrict__ keys, uint32_t n_host, const uint64_t *__restrict__ n_dev,
-                                                                int shift, uint32_t nblocks, uint32_t *__restrict__ hist) {
-    __shared__ __attribute__((aligned(16))) uint32_t h[kWide];
-    const uint32_t n = n_dev ? (uint32_t)min((uint64_t)n_host, *n_dev) : n_host;
-    for (int d = threadIdx.x; d < kWide; d += kThreads) h[d] = 0;
-    __syncthreads();
-    const uint32_t base = blockIdx.x * (kThreads * ITEMS);
-#pragma unroll
-    for (int it = 0; it < ITEMS; it++) {
-        const uint32_t k = base + it * kThreads + threadIdx.x;
-        if (k < n) atomicAdd(&h[(uint32_t)(keys[k] >> shift) & (kWide - 1)], 1u);
-    }
-    __syncthreads();
-    // block-major rows: one coalesced 8-KB store per workgroup (digit-major columns were 2048 scattered 4-byte stores each)
-    uint4 *row = reinterpret_cast<uint4 *>(hist + (size_t)blockIdx.x * kWide);
-    for (int d = threadIdx.x; d < kWide / 4; d += kThreads) row[d] = reinterpret_cast<const uint4 *>(h)[d];
-}
-
 // hist is block-major [nblocks][2048].  One workgroup of 1024 threads per group of 64 consecutive digits: lane = digit (a row's 64
 // counts are one 256-byte run), wave w walks the blocks w, w + 16, ..: per digit an exclusive prefix over the blocks in place + the
 // digit total.  Every wave first sums its blocks, the 16 partial sums per digit meet in LDS, then it rewrites its blocks with the
@@ -342,135 +323,6 @@ __global__ __launch_bounds__(1024) void wide_rowscan_kernel(uint32_t *__restrict
 #pragma unroll
     for (int i = 0; i < kMaxPer; i++) { const uint32_t b = b0 + (uint32_t)i; if (b < b1) col[(size_t)b * kWide] = run; run += v[i]; }
     if (wave == 0) totals[d] = all;
-}
-
-// ORDERED: stable (match-any ballots, three barriers per item), writes keys and values, one worklist of occupied tiles.
-// !ORDERED (register per-tile sort behind it): every key claims the next slot of its tile with one returning LDS atomic and leaves a
-// (depth bits << 32 | value) composite there; worklist = [16 counters: count[m] at [m], tickets at [8 + m]] [6][tiles_total] tile ids by
-// length class (<= 1024 << m entries for m = 0..4, longer ones in class 5).
-template <int ITEMS, bool ORDERED>
-__global__ __launch_bounds__(kThreads) void wide_downsweep_kernel(const uint64_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
-                                                                  uint64_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, uint32_t n_host,
-                                                                  const uint64_t *__restrict__ n_dev, int shift, uint32_t nblocks,
-                                                                  const uint32_t *__restrict__ hist, const uint32_t *__restrict__ totals,
-                                                                  uint2 *__restrict__ ranges, uint32_t tiles_total,
-                                                                  uint32_t *__restrict__ worklist, uint32_t deep_all) {
-    const uint32_t n = n_dev ? (uint32_t)min((uint64_t)n_host, *n_dev) : n_host;
-    __shared__ uint32_t digit_base[kWide];
-    __shared__ uint32_t wave_cnt[4][kWide];
-    __shared__ uint32_t wtot[4];
-    __shared__ uint32_t s_wl[8];                                  // class worklist fill levels (workgroup 0 is the only one that appends)
-    const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    if (t < 8) s_wl[t] = 0u;
-    constexpr int PER = kWide / kThreads;                        // 8 consecutive digits per thread
-    {   // exclusive scan of the 2048 digit totals + this workgroup's offset inside each digit; wave_cnt starts zeroed
-        // the thread's 8 digit totals and its workgroup's 8 offsets: four 16-byte loads up front (one by one inside the loop below they
-        // were eight waits)
-        static_assert(PER == 8, "two uint4 per thread");
-        uint32_t v[PER], hb[PER], sum = 0;
-        {
-            const uint4 t0 = reinterpret_cast<const uint4 *>(totals)[t * 2], t1 = reinterpret_cast<const uint4 *>(totals)[t * 2 + 1];
-            const uint4 *hr = reinterpret_cast<const uint4 *>(hist + (size_t)blockIdx.x * kWide);
-            const uint4 h0 = hr[t * 2], h1 = hr[t * 2 + 1];
-            v[0] = t0.x; v[1] = t0.y; v[2] = t0.z; v[3] = t0.w; v[4] = t1.x; v[5] = t1.y; v[6] = t1.z; v[7] = t1.w;
-            hb[0] = h0.x; hb[1] = h0.y; hb[2] = h0.z; hb[3] = h0.w; hb[4] = h1.x; hb[5] = h1.y; hb[6] = h1.z; hb[7] = h1.w;
-        }
-#pragma unroll
-        for (int j = 0; j < PER; j++) sum += v[j];
-        uint32_t inc = sum;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t nb = __shfl_up(inc, off, 64);
-            if (lane >= (uint32_t)off) inc += nb;
-        }
-        if (lane == 63) wtot[wave] = inc;
-        __syncthreads();
-        uint32_t run = inc - sum;
-        for (uint32_t w = 0; w < wave; w++) run += wtot[w];
-#pragma unroll
-        for (int j = 0; j < PER; j++) {
-            const uint32_t d = t * PER + j;
-            digit_base[d] = run + hb[j];
-            // F5 for free: the digit IS the tile id, so the scanned totals are the tile ranges (and the occupied tiles the
-            // per-tile sort's worklist, whose counter the duplicate kernel cleared)
-            if (ranges && blockIdx.x == 0 && d < tiles_total) {
-                ranges[d] = v[j] ? make_uint2(run, run + v[j]) : make_uint2(0u, 0u);
-                if (ORDERED) {
-                    if (v[j] && worklist) worklist[1 + atomicAdd(&worklist[0], 1u)] = d;
-                } else if (v[j] && deep_all) {
-                    // every occupied tile -> the LDS distribution sort (small instantiation): one entry per window of 3968 entries; list 0
-                    // runs on into the other lists' room
-                    // (deep_all = the most windows a tile may have, <= 64: the window field of an entry has 6 bits.  A longer tile is listed
-                    // once, marked kDeepWhole)
-                    uint32_t nw = (v[j] + (kDeepSmallCap - kDeepBinMax) - 1u) / (kDeepSmallCap - kDeepBinMax);
-                    const uint32_t whole = nw > deep_all ? kDeepWhole : 0u;
-                    if (whole) nw = 1u;
-                    const uint32_t at = atomicAdd(&s_wl[0], nw);
-                    for (uint32_t w = 0; w < nw; w++) worklist[16u + at + w] = d | whole | (w << 26);
-                } else if (v[j]) {
-                    const uint32_t m = v[j] <= 1024u ? 0u : (v[j] <= 2048u ? 1u : (v[j] <= 4096u ? 2u : (v[j] <= 8192u ? 3u : (v[j] <= 16384u ? 4u : 5u))));
-                    // (LDS counters: the ~200 returning device-scope atomics on six words of one line were a serial chain on this
-                    // workgroup's way to its scatter)
-                    worklist[16u + m * tiles_total + atomicAdd(&s_wl[m], 1u)] = d;
-                }
-            }
-            run += v[j];
-#pragma unroll
-            for (int w = 0; w < 4; w++) wave_cnt[w][d] = 0;
-        }
-    }
-    const uint32_t base = blockIdx.x * (kThreads * ITEMS);
-    const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    uint64_t keys_r[ITEMS];
-    uint32_t vals_r[ITEMS];
-#pragma unroll
-    for (int it = 0; it < ITEMS; it++) {
-        const uint32_t k = base + it * kThreads + t;
-        keys_r[it] = 0; vals_r[it] = 0;
-        if (k < n) { keys_r[it] = keys_in[k]; vals_r[it] = vals_in[k]; }
-    }
-    __syncthreads();
-    if (!ORDERED) {
-        if (ranges && blockIdx.x == 0 && t < 6u) worklist[t] = s_wl[t];
-#pragma unroll
-        for (int it = 0; it < ITEMS; it++) {
-            const uint32_t k = base + it * kThreads + t;
-            if (k < n) {
-                const uint32_t d = (uint32_t)(keys_r[it] >> shift) & (kWide - 1);
-                keys_out[atomicAdd(&digit_base[d], 1u)] = (keys_r[it] << 32) | vals_r[it];
-            }
-        }
-        return;
-    }
-#pragma unroll
-    for (int it = 0; it < ITEMS; it++) {
-        const uint32_t k = base + it * kThreads + t;
-        const bool valid = k < n;
-        const uint64_t key = keys_r[it];
-        const uint32_t val = vals_r[it];
-        const uint32_t d = (uint32_t)(key >> shift) & (kWide - 1);
-        uint64_t peers = __ballot(valid);
-#pragma unroll
-        for (int b = 0; b < kWideBits; b++) {
-            const bool bit = (d >> b) & 1;
-            const uint64_t m = __ballot(bit);
-            peers &= bit ? m : ~m;
-        }
-        const uint32_t rank = (uint32_t)__popcll(peers & lt_mask);
-        const uint32_t grp = (uint32_t)__popcll(peers);
-        const bool leader = valid && rank == 0;
-        if (leader) wave_cnt[wave][d] = grp;
-        __syncthreads();
-        if (valid) {
-            uint32_t pos = digit_base[d] + rank;
-            for (uint32_t w = 0; w < wave; w++) pos += wave_cnt[w][d];
-            keys_out[pos] = key;
-            vals_out[pos] = val;
-        }
-        __syncthreads();
-        if (leader) { atomicAdd(&digit_base[d], grp); wave_cnt[wave][d] = 0; }
-        __syncthreads();
-    }
 }
 
 // The order-free scatter of the tile pass for key RUNS: workgroup b places the keys the emission workgroup b wrote (blk_runs[b]: first
@@ -553,161 +405,17 @@ __global__ __launch_bounds__(kThreads) void wide_downsweep_runs_kernel(const uin
     }
 }
 
-// ---- F4, onesweep variant: ONE kernel per digit instead of three --------------------------------------
-// (a) radix_hist_all_kernel reads the keys once and builds the global histograms of every pass (the multiset of keys
-//     does not change between passes, so all digit histograms can be taken up front);
-// (b) per pass, radix_onesweep_kernel's workgroups draw tile ids from an atomic ticket (so every lower-numbered tile is
-//     owned by a workgroup that is already running), publish their per-digit counts in a status word
-//     (2 flag bits | 30-bit value) and resolve their exclusive prefix by decoupled look-back over the earlier tiles.
-// The status word carries its own payload and only moves 0 -> AGGREGATE -> INCLUSIVE, so a stale read is merely an
-// older valid state: relaxed agent-scope atomics suffice, no fences, no placement assumptions (guide G16).  Spins are
-// bounded: if a status never shows up the kernel raises an error flag and returns instead of hanging.
-constexpr uint32_t kFlagAgg = 1u << 30, kFlagInc = 2u << 30, kValMask = (1u << 30) - 1u;
-constexpr int kMaxPasses = 8;
+// ---- stable LSD radix passes over ONE tile's segment, through the global ping-pong pair ------------------------------
+// The generic path of the per-tile sorts below: tiles beyond the register network's 16 384 entries, and tiles the LDS distribution
+// sort declines (massive exact depth ties).  Digits on which a whole segment agrees are skipped -- the exponent byte of the depths
+// inside one tile almost always is.  (Rounds 1-4 also ran these passes in LDS as a sort flavour of its own -- global passes over the
+// tile bits, then one workgroup per tile over the depth bits -- next to a whole-key onesweep with decoupled look-back; both were
+// removed in round 5: the automatic choice reached them only for <= 256 tiles / > 2^23 instances beyond 4096 tiles per view.)
 
-__global__ __launch_bounds__(kThreads) void radix_hist_all_kernel(const uint64_t *__restrict__ keys, uint32_t n_host,
-                                                                  const uint64_t *__restrict__ n_dev, int passes,
-                                                                  uint32_t *__restrict__ ghist /*[passes][256]*/) {
-    __shared__ uint32_t h[kMaxPasses][kRadix];
-    const uint32_t n = n_dev ? (uint32_t)min((uint64_t)n_host, *n_dev) : n_host;
-    for (int p = 0; p < passes; p++) h[p][threadIdx.x] = 0;
-    __syncthreads();
-    const uint32_t lane = threadIdx.x & 63;
-    // (uniform trip count per wave, so the ballots below are well defined)
-    for (uint32_t k0 = blockIdx.x * kThreads + (threadIdx.x & ~63u); k0 < n; k0 += gridDim.x * kThreads) {
-        const uint32_t k = k0 + lane;
-        const bool valid = k < n;
-        const uint64_t key = valid ? keys[k] : 0ull;
-        const uint64_t vmask = __ballot(valid);
-        for (int p = 0; p < passes; p++) {
-            const uint32_t d = (uint32_t)(key >> (p * kRadixBits)) & (kRadix - 1);
-            // keys arrive grouped by view and tile row, so in the upper digits a whole wave usually agrees: one atomic instead of a
-            // 64-way same-address LDS conflict
-            const uint32_t d0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)d);
-            if (__ballot(valid && d != d0) == 0ull) {
-                if (lane == (uint32_t)__builtin_ctzll(vmask | (1ull << 63)) && vmask) atomicAdd(&h[p][d0], (uint32_t)__popcll(vmask));
-            } else if (valid) {
-                atomicAdd(&h[p][d], 1u);
-            }
-        }
-    }
-    __syncthreads();
-    for (int p = 0; p < passes; p++) {
-        const uint32_t c = h[p][threadIdx.x];
-        if (c) atomicAdd(&ghist[p * kRadix + threadIdx.x], c);
-    }
-}
-
-template <int ITEMS>
-__global__ __launch_bounds__(kThreads) void radix_onesweep_kernel(const uint64_t *__restrict__ keys_in,
-                                                                  const uint32_t *__restrict__ vals_in,
-                                                                  uint64_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out,
-                                                                  uint32_t n_host, const uint64_t *__restrict__ n_dev, int shift,
-                                                                  const uint32_t *__restrict__ ghist /*[256] of this pass*/,
-                                                                  uint32_t *__restrict__ status /*[tiles][256] of this pass*/,
-                                                                  uint32_t *__restrict__ ticket, uint32_t *__restrict__ err) {
-    __shared__ uint32_t digit_base[kRadix];
-    __shared__ uint32_t hist[kRadix];
-    __shared__ uint32_t wave_cnt[4][kRadix];
-    __shared__ uint32_t wtot[4];
-    __shared__ uint32_t s_tile;
-    const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const uint32_t n = n_dev ? (uint32_t)min((uint64_t)n_host, *n_dev) : n_host;
-    if (t == 0) s_tile = atomicAdd(ticket, 1u);
-    hist[t] = 0;
-    __syncthreads();
-    const uint32_t tile = s_tile;
-    const uint32_t base = tile * (kThreads * ITEMS);
-    if (base >= n) return;                                     // workgroup-uniform
-    uint64_t key[ITEMS];
-    uint32_t val[ITEMS];
-#pragma unroll
-    for (int it = 0; it < ITEMS; it++) {
-        const uint32_t k = base + it * kThreads + t;
-        key[it] = 0; val[it] = 0;
-        if (k < n) { key[it] = keys_in[k]; val[it] = vals_in[k]; atomicAdd(&hist[(uint32_t)(key[it] >> shift) & (kRadix - 1)], 1u); }
-    }
-    __syncthreads();
-    {   // thread t owns digit t: global start of the digit (scan of the pass histogram) + tiles before mine (look-back)
-        const uint32_t g = ghist[t];
-        uint32_t inc = g;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t nb = __shfl_up(inc, off, 64);
-            if (lane >= (uint32_t)off) inc += nb;
-        }
-        if (lane == 63) wtot[wave] = inc;
-        __syncthreads();
-        uint32_t gstart = inc - g;
-        for (uint32_t w = 0; w < wave; w++) gstart += wtot[w];
-        const uint32_t cnt = hist[t];
-        uint32_t excl = 0;
-        uint32_t *mine = status + (size_t)tile * kRadix + t;
-        if (tile == 0) {
-            __hip_atomic_store(mine, cnt | kFlagInc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else {
-            __hip_atomic_store(mine, cnt | kFlagAgg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            for (int tt = (int)tile - 1; tt >= 0; --tt) {
-                const uint32_t *p = status + (size_t)tt * kRadix + t;
-                uint32_t v = 0;
-                uint32_t spins = 0;
-                do {
-                    v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                } while ((v >> 30) == 0u && ++spins < (1u << 22));
-                if ((v >> 30) == 0u) { atomicOr(err, 1u); break; }          // bounded spin: report instead of hanging
-                excl += v & kValMask;
-                if ((v >> 30) == 2u) break;
-            }
-            __hip_atomic_store(mine, ((excl + cnt) & kValMask) | kFlagInc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        digit_base[t] = gstart + excl;
-    }
-    const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-#pragma unroll
-    for (int it = 0; it < ITEMS; it++) {
-        const uint32_t k = base + it * kThreads + t;
-        const bool valid = k < n;
-        const uint32_t d = (uint32_t)(key[it] >> shift) & (kRadix - 1);
-#pragma unroll
-        for (int w = 0; w < 4; w++) wave_cnt[w][t] = 0;
-        __syncthreads();
-        uint64_t peers = __ballot(valid);
-#pragma unroll
-        for (int b = 0; b < kRadixBits; b++) {
-            const bool bit = (d >> b) & 1;
-            const uint64_t m = __ballot(bit);
-            peers &= bit ? m : ~m;
-        }
-        const uint32_t rank = (uint32_t)__popcll(peers & lt_mask);
-        if (valid && rank == 0) wave_cnt[wave][d] = (uint32_t)__popcll(peers);
-        __syncthreads();
-        if (valid) {
-            uint32_t pos = digit_base[d] + rank;
-            for (uint32_t w = 0; w < wave; w++) pos += wave_cnt[w][d];
-            keys_out[pos] = key[it];
-            vals_out[pos] = val[it];
-        }
-        __syncthreads();
-        digit_base[t] += wave_cnt[0][t] + wave_cnt[1][t] + wave_cnt[2][t] + wave_cnt[3][t];
-        __syncthreads();
-    }
-}
-
-// ---- F4, segmented variant: the key is (tile, depth), so sort the TILE bits globally and the DEPTH bits per tile ----
-// Global LSD passes are run over the tile-id bits only (2 passes for up to 65536 tiles instead of 6-7 over the
-// whole key); they are stable, so afterwards every tile owns a contiguous segment whose entries are still in
-// emission order (ascending Gaussian index).  tile_ranges then finds the segments and tile_sort_kernel sorts each
-// one by its 32 depth bits with a stable LSD radix sort that lives entirely in LDS (160 KB/CU on MI355X: a 4096-entry
-// segment needs 64 KB for two key/value ping-pong pairs).  Digits on which a whole segment agrees are skipped -- the
-// exponent byte of the depths inside one tile almost always is.  Segments longer than the LDS capacity are sorted by
-// the same code through the global ping-pong buffers.  The result is bit-identical to one stable sort of the full key.
-constexpr int kSegCapSmall = 1024, kSegCapLarge = 4096;
-
-// BY_VAL (global path only): the digits are taken from the VALUE instead of the depth bits -- the first half of a sort by the
-// (depth, value) composite for segments whose entries arrive in arbitrary order (view-segmented flavour, tiles beyond 16384 entries)
-template <int NT, bool IN_LDS, bool BY_VAL = false>
-__device__ __forceinline__ void seg_sort_passes(uint32_t n, uint32_t *ka, uint32_t *va, uint32_t *kb, uint32_t *vb,
-                                                uint64_t *gka, uint32_t *gva, uint64_t *gkb, uint32_t *gvb, bool &in_b,
+// BY_VAL: the digits are taken from the VALUE instead of the depth bits -- the first half of a sort by the (depth, value) composite
+// for segments whose entries arrive in arbitrary order
+template <int NT, bool BY_VAL = false>
+__device__ __forceinline__ void seg_sort_passes(uint32_t n, uint64_t *gka, uint32_t *gva, uint64_t *gkb, uint32_t *gvb, bool &in_b,
                                                 uint32_t *hist, uint32_t *digit_base, uint32_t (*wave_cnt)[kRadix], uint32_t *wtot) {
     constexpr int NW = NT / 64;
     const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -717,7 +425,7 @@ __device__ __forceinline__ void seg_sort_passes(uint32_t n, uint32_t *ka, uint32
         if (t < kRadix) hist[t] = 0;
         __syncthreads();
         for (uint32_t k = t; k < n; k += NT) {
-            const uint32_t key = IN_LDS ? (in_b ? kb[k] : ka[k]) : (BY_VAL ? (in_b ? gvb[k] : gva[k]) : (uint32_t)(in_b ? gkb[k] : gka[k]));
+            const uint32_t key = BY_VAL ? (in_b ? gvb[k] : gva[k]) : (uint32_t)(in_b ? gkb[k] : gka[k]);
             atomicAdd(&hist[(key >> shift) & (kRadix - 1)], 1u);
         }
         __syncthreads();
@@ -756,8 +464,7 @@ __device__ __forceinline__ void seg_sort_passes(uint32_t n, uint32_t *ka, uint32
             uint32_t key = 0, val = 0;
             uint64_t key64 = 0;
             if (valid) {
-                if (IN_LDS) { key = in_b ? kb[k] : ka[k]; val = in_b ? vb[k] : va[k]; }
-                else { key64 = in_b ? gkb[k] : gka[k]; key = (uint32_t)key64; val = in_b ? gvb[k] : gva[k]; }
+                key64 = in_b ? gkb[k] : gka[k]; key = (uint32_t)key64; val = in_b ? gvb[k] : gva[k];
             }
             const uint32_t d = ((BY_VAL ? val : key) >> shift) & (kRadix - 1);
             if (!TWO_LEVEL) {
@@ -791,8 +498,7 @@ __device__ __forceinline__ void seg_sort_passes(uint32_t n, uint32_t *ka, uint32
                 } else {
                     for (uint32_t w = 0; w < wave; w++) pos += wave_cnt[w][d];
                 }
-                if (IN_LDS) { (in_b ? ka : kb)[pos] = key; (in_b ? va : vb)[pos] = val; }
-                else { (in_b ? gka : gkb)[pos] = key64; (in_b ? gva : gvb)[pos] = val; }
+                (in_b ? gka : gkb)[pos] = key64; (in_b ? gva : gvb)[pos] = val;
             }
             __syncthreads();
             if (TWO_LEVEL) {
@@ -813,93 +519,37 @@ __device__ __forceinline__ void seg_sort_passes(uint32_t n, uint32_t *ka, uint32
             __syncthreads();
         }
         in_b = !in_b;
-        if (!IN_LDS) { __threadfence_block(); __syncthreads(); }
+        __threadfence_block(); __syncthreads();
     }
 }
 
-// src = buffers holding the tile-bucketed data, dst = the other pair; the sorted segment always ends up in dst.
-// Two size classes share the code: CAP=1024 / 256 threads (16 KB of LDS: full occupancy for the many short lists) handles
-// segments of <= 1024 entries, CAP=4096 / 1024 threads handles the rest (and oversize segments through global memory).
-// (launching a 1024-thread / 80-KB-LDS workgroup per tile just to have it exit costs ~10 us per CU slot, so the small-class
-// launch, one workgroup per tile, appends the long tiles to a worklist that a fixed-size large-class grid then drains)
-// (a launch with few tiles -- one 512^2 view -- skips the small class: tile_ranges_kernel puts every occupied tile on the worklist
-// and the large-class workgroups take one each, all resident at once, so the two classes no longer run back to back)
-struct SortPrep {               // optional piggy-back job of the large-class launch's spare last workgroup (sgr_fwd_prepare)
+struct SortPrep {               // optional piggy-back job of the per-tile sort launch's spare last workgroup (sgr_fwd_prepare)
     uint2 *desc; size_t n_desc; uint32_t *order; uint32_t tiles_total; int enabled;
 };
 
-// sorts ONE tile's segment by its depth bits (stable), src -> dst; all NT threads of the workgroup take part.
-// UNORDERED: the entries do not arrive in emission order (view-segmented flavour): stable passes over the value bits first, then over
-// the depth bits = order by the (depth, value) composite, through the global ping-pong pair whatever the length.
-template <int NT, int CAP, bool UNORDERED = false>
+// sorts ONE tile's segment of (depth bits << 32 | value) composites by that composite (stable passes over the value bits first, then over
+// the depth bits), src -> dst as (tile | depth) keys and values; all NT threads of the workgroup take part.
+template <int NT>
 __device__ __forceinline__ void sort_one_tile(const uint2 range, uint64_t *__restrict__ src_keys, uint32_t *__restrict__ src_vals,
-                                              uint64_t *__restrict__ dst_keys, uint32_t *__restrict__ dst_vals, uint32_t *ka, uint32_t *va,
-                                              uint32_t *kb, uint32_t *vb, uint32_t *hist, uint32_t *digit_base,
-                                              uint32_t (*wave_cnt)[kRadix], uint32_t *wtot, uint32_t tile = 0u) {
+                                              uint64_t *__restrict__ dst_keys, uint32_t *__restrict__ dst_vals, uint32_t *hist, uint32_t *digit_base,
+                                              uint32_t (*wave_cnt)[kRadix], uint32_t *wtot, uint32_t tile) {
     const uint32_t t = threadIdx.x;
     const uint32_t n = range.y - range.x;
     uint64_t *gsrc_k = src_keys + range.x, *gdst_k = dst_keys + range.x;
     uint32_t *gsrc_v = src_vals + range.x, *gdst_v = dst_vals + range.x;
     bool in_b = false;
-    if (UNORDERED) {
-        // the scatter pass left (depth bits << 32 | value) composites in src_keys: back to (tile | depth) keys and values first
-        for (uint32_t k = t; k < n; k += NT) { const uint64_t c = gsrc_k[k]; gsrc_k[k] = ((uint64_t)tile << 32) | (c >> 32); gsrc_v[k] = (uint32_t)c; }
-        __threadfence_block();
-        __syncthreads();
-        seg_sort_passes<NT, false, true>(n, nullptr, nullptr, nullptr, nullptr, gsrc_k, gsrc_v, gdst_k, gdst_v, in_b, hist, digit_base, wave_cnt, wtot);
-        seg_sort_passes<NT, false, false>(n, nullptr, nullptr, nullptr, nullptr, gsrc_k, gsrc_v, gdst_k, gdst_v, in_b, hist, digit_base, wave_cnt, wtot);
-        __threadfence_block();
-        __syncthreads();
-        if (!in_b)
-            for (uint32_t k = t; k < n; k += NT) { gdst_k[k] = gsrc_k[k]; gdst_v[k] = gsrc_v[k]; }
-    } else if (n <= (uint32_t)CAP) {
-        const uint32_t hi = (uint32_t)(gsrc_k[0] >> 32);                      // tile id, identical for the whole segment
-        for (uint32_t k = t; k < n; k += NT) { ka[k] = (uint32_t)gsrc_k[k]; va[k] = gsrc_v[k]; }
-        __syncthreads();
-        if (n > 1) seg_sort_passes<NT, true>(n, ka, va, kb, vb, nullptr, nullptr, nullptr, nullptr, in_b, hist, digit_base, wave_cnt, wtot);
-        __syncthreads();
-        const uint32_t *fk = in_b ? kb : ka, *fv = in_b ? vb : va;
-        for (uint32_t k = t; k < n; k += NT) { gdst_k[k] = ((uint64_t)hi << 32) | fk[k]; gdst_v[k] = fv[k]; }
-    } else {
-        // oversize segment: same algorithm through the global ping-pong pair (a = src, b = dst)
-        seg_sort_passes<NT, false>(n, nullptr, nullptr, nullptr, nullptr, gsrc_k, gsrc_v, gdst_k, gdst_v, in_b, hist, digit_base, wave_cnt, wtot);
-        __threadfence_block();
-        __syncthreads();
-        if (!in_b)                                               // result sits in src: move it to dst
-            for (uint32_t k = t; k < n; k += NT) { gdst_k[k] = gsrc_k[k]; gdst_v[k] = gsrc_v[k]; }
-    }
+    // the scatter pass left (depth bits << 32 | value) composites in src_keys: back to (tile | depth) keys and values first
+    for (uint32_t k = t; k < n; k += NT) { const uint64_t c = gsrc_k[k]; gsrc_k[k] = ((uint64_t)tile << 32) | (c >> 32); gsrc_v[k] = (uint32_t)c; }
+    __threadfence_block();
+    __syncthreads();
+    seg_sort_passes<NT, true>(n, gsrc_k, gsrc_v, gdst_k, gdst_v, in_b, hist, digit_base, wave_cnt, wtot);
+    seg_sort_passes<NT, false>(n, gsrc_k, gsrc_v, gdst_k, gdst_v, in_b, hist, digit_base, wave_cnt, wtot);
+    __threadfence_block();
+    __syncthreads();
+    if (!in_b)
+        for (uint32_t k = t; k < n; k += NT) { gdst_k[k] = gsrc_k[k]; gdst_v[k] = gsrc_v[k]; }
 }
 
-template <int NT, int CAP, bool SMALL_CLASS>
-__global__ __launch_bounds__(NT) void tile_sort_kernel(const uint2 *__restrict__ ranges, uint64_t *__restrict__ src_keys,
-                                                       uint32_t *__restrict__ src_vals, uint64_t *__restrict__ dst_keys,
-                                                       uint32_t *__restrict__ dst_vals, uint32_t *__restrict__ worklist /*[0]=count, [1..]=tiles*/,
-                                                       SortPrep prep) {
-    __shared__ uint32_t ka[CAP], va[CAP], kb[CAP], vb[CAP];
-    __shared__ uint32_t hist[kRadix], digit_base[kRadix], wave_cnt[NT / 64][kRadix], wtot[4];
-    const uint32_t t = threadIdx.x;
-    uint32_t nsort = gridDim.x;
-    if (!SMALL_CLASS && NT == 1024 && prep.enabled) {
-        nsort = gridDim.x - 1;
-        if (blockIdx.x == nsort) { sgr_fwd_prepare(ranges, prep.tiles_total, prep.desc, prep.n_desc, prep.order, hist); return; }
-    }
-    const uint32_t nwork = SMALL_CLASS ? 1u : worklist[0];
-    for (uint32_t wi = SMALL_CLASS ? 0u : blockIdx.x; wi < nwork; wi += nsort) {
-        const uint32_t tile_id = SMALL_CLASS ? blockIdx.x : worklist[1 + wi];
-        const uint2 range = ranges[tile_id];
-        const uint32_t n = range.y - range.x;
-        if (n == 0) return;
-        if (SMALL_CLASS && n > (uint32_t)kSegCapSmall) {
-            if (t == 0) worklist[1 + atomicAdd(&worklist[0], 1u)] = tile_id;
-            return;
-        }
-        __syncthreads();                                               // (large class: LDS reuse between worklist items)
-        sort_one_tile<NT, CAP>(range, src_keys, src_vals, dst_keys, dst_vals, ka, va, kb, vb, hist, digit_base, wave_cnt, wtot);
-    }
-}
-
-// worklists of occupied tiles (by length class) drained by a fixed grid of workgroups: tile lists differ 100x in length, so a static
-// round-robin alone would leave most of the grid idle behind the long ones
 struct TileWork { const uint32_t *list; uint32_t *ticket; const uint32_t *count; };
 
 // ---- per-tile depth sort IN REGISTERS ----------------------------------------------------------------------------------
@@ -1168,7 +818,7 @@ __global__ __launch_bounds__(64 * NW) void tile_sort_regs_kernel(const uint2 *__
             const uint32_t tile = w.list[wi];
             const uint2 range = ranges[tile];
             if (range.y > range.x)
-                sort_one_tile<64 * NW, 1, true>(range, src_comp, src_scratch, dst_keys, dst_vals, nullptr, nullptr, nullptr, nullptr, hist, digit_base,
+                sort_one_tile<64 * NW>(range, src_comp, src_scratch, dst_keys, dst_vals, hist, digit_base,
                                                 wave_cnt, wtot, tile);
         }
         __syncthreads();
@@ -1646,7 +1296,7 @@ __global__ __launch_bounds__(NT) void deep_tile_kernel(uint64_t *comp, uint32_t 
             uint32_t *hist = l32, *digit_base = l32 + kRadix, *wtot = l32 + 2 * kRadix;
             uint32_t (*wave_cnt)[kRadix] = (uint32_t (*)[kRadix])(l32 + 2 * kRadix + 64);
             __syncthreads();
-            sort_one_tile<NT, 1, true>(range, comp, scratch, dst_keys, dst_vals, nullptr, nullptr, nullptr, nullptr, hist, digit_base, wave_cnt, wtot, tile);
+            sort_one_tile<NT>(range, comp, scratch, dst_keys, dst_vals, hist, digit_base, wave_cnt, wtot, tile);
         };
         if constexpr (FB) { if (entry & kDeepWhole) { sort_here(); continue; } }
         const uint64_t *seg = comp + range.x;
@@ -1810,28 +1460,22 @@ __global__ __launch_bounds__(NT) void deep_tile_kernel(uint64_t *comp, uint32_t 
 
 // ---- F5 -------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kThreads) void tile_ranges_kernel(const uint64_t *__restrict__ keys, uint32_t n_host,
-                                                               const uint64_t *__restrict__ n_dev, uint2 *__restrict__ ranges,
-                                                               uint32_t *__restrict__ worklist, int append_all) {
-    // worklist[0] = counter: append_all == 0 -> reset here for the small-class tile sort that fills it afterwards;
-    // append_all != 0 -> (already cleared by the duplicate kernel) every occupied tile is appended by the thread at its segment start
+                                                               const uint64_t *__restrict__ n_dev, uint2 *__restrict__ ranges) {
     const uint32_t n = n_dev ? (uint32_t)min((uint64_t)n_host, *n_dev) : n_host;
-    if (worklist && !append_all && blockIdx.x == 0 && threadIdx.x == 0) worklist[0] = 0;
     const uint32_t r = blockIdx.x * kThreads + threadIdx.x;
     if (r >= n) return;
     const uint32_t tile = (uint32_t)(keys[r] >> 32);
-    bool first = r == 0;
     if (r == 0) ranges[tile].x = 0;
     else {
         const uint32_t prev = (uint32_t)(keys[r - 1] >> 32);
-        if (tile != prev) { ranges[prev].y = r; ranges[tile].x = r; first = true; }
+        if (tile != prev) { ranges[prev].y = r; ranges[tile].x = r; }
     }
     if (r == n - 1) ranges[tile].y = n;
-    if (append_all && first) worklist[1 + atomicAdd(&worklist[0], 1u)] = tile;
 }
 
-// 3 = automatic (default), 4 = view-segmented (per-view tile pass + per-tile depth sort), 2 = segmented (global passes over the tile bits,
-// depth bits per tile in LDS), 0 = onesweep, 1 = three kernels per pass
-thread_local int sgr_sort_mode = sgr_env_knob("SIGMAN_SORT_MODE", 0, 5, 3);        // (per thread; every thread starts from the environment)
+// 3 = automatic (default), 5 = single wide tile pass + LDS distribution sort per tile (one or two 512^2 views; else like 3),
+// 4 = view-segmented (per-view tile pass + per-tile depth sort), 1 = three kernels per 8-bit digit over the whole key (the fallback)
+thread_local int sgr_sort_mode = sgr_env_knob("SIGMAN_SORT_MODE", 1, 5, 3);        // (per thread; every thread starts from the environment)
 
 struct VsegLayout {
     size_t plan, totals, key_start, chunk_start, chunk_map, hist, tile_total, lists, end; uint32_t chunk_keys, max_chunks;
@@ -1863,7 +1507,11 @@ inline int bits_for(uint64_t v) { int b = 0; while ((1ull << b) < v) b++; return
 
 int sgr_validate_problem(const SgrProblem *pb);
 
-extern "C" int sgr_set_sort_mode(int mode) { sgr_sort_mode = mode; return 0; }
+extern "C" int sgr_set_sort_mode(int mode) {
+    if (mode != 1 && mode != 3 && mode != 4 && mode != 5) { sgr_set_error("sgr_set_sort_mode: %d is not a sort flavour (3 automatic, 5 wide pass, 4 view-segmented, 1 whole-key passes)", mode); return 1; }
+    sgr_sort_mode = mode;
+    return 0;
+}
 // deep tile lists in the view-segmented flavour (the LDS distribution sort, deep_tile_kernel): 0 = automatic (launches whose tile lists are
 // deep on average), 1 = whenever that flavour runs, 2 = never (deep launches then keep the whole-key passes)
 static thread_local int g_deep_mode = sgr_env_knob("SIGMAN_SORT_DEEP", 0, 2, 0);
@@ -1879,11 +1527,10 @@ extern "C" int sgr_set_sort_deep(int mode) {
 
 extern "C" size_t sgr_bin_workspace_bytes(uint64_t R, uint64_t tiles_total) {
     const uint64_t nblocks = (R + kThreads * kItemsSmall - 1) / (kThreads * kItemsSmall);
-    // onesweep: [ghist 8x256][tickets 8][err][pad] + status [8 passes][tiles][256]; three-kernel path: [hist tiles x 256][totals 256]
-    // + [worklist 64 + tiles] of the segmented flavour; the view-segmented flavour lays its plan / chunk map / histograms / worklists
+    // whole-key passes: [hist blocks x 256][totals 256]; the view-segmented flavour lays its plan / chunk map / histograms / worklists
     // over the whole area from the start (<= 2 R + R / 256 + 100 B per tile + 64 KB: see vseg_layout)
-    // (+ 4 MB: room for one 8-KB histogram row per emission workgroup of a small launch, see sgr_bin_ex)
-    return (size_t)((kMaxPasses * (nblocks > 0 ? nblocks : 1) + kMaxPasses + 2) * kRadix * sizeof(uint32_t) + 1024 + ((size_t)4 << 20) +
+    // (+ 4 MB: room for one 8-KB histogram row per emission workgroup of a small launch, see sgr_bin_ex; the size formula is round 1's)
+    return (size_t)((8 * (nblocks > 0 ? nblocks : 1) + 8 + 2) * kRadix * sizeof(uint32_t) + 1024 + ((size_t)4 << 20) +
                     (tiles_total ? (tiles_total + 64) * sizeof(uint32_t) + tiles_total * 128 + 65536 : 0));
 }
 
@@ -1910,9 +1557,7 @@ int sgr_bin_ex(const SgrProblem *pb, const int32_t *radii, uint32_t *rect,
     if (workspace_bytes < sgr_bin_workspace_bytes(R, tiles_total)) { sgr_set_error("sgr_bin: workspace too small"); return 1; }
     const uint32_t n = (uint32_t)R;
     const int nbx = sgr_preprocess_blocks_per_view(pb->P);
-    // few tiles + segmented sort: every occupied tile goes on the large-class worklist (counter cleared by the duplicate kernel,
-    // filled by tile_ranges)
-    const bool all_large = tiles_total <= 2048;
+    const bool all_large = tiles_total <= 2048;                  // the wide tile pass's worklist area sits behind the radix scratch: cleared by the emission kernel
     const bool small = n <= (1u << 19);
     const uint32_t tile_keys = kThreads * (small ? kItemsSmall : kItemsLarge);
     const uint32_t nblocks = (n + tile_keys - 1) / tile_keys;
@@ -1922,11 +1567,9 @@ int sgr_bin_ex(const SgrProblem *pb, const int32_t *radii, uint32_t *rect,
     const int passes = (total_bits + kRadixBits - 1) / kRadixBits;
     uint64_t *kin = keys_a, *kout = keys_b;
     uint32_t *vin = vals_a, *vout = vals_b;
-    // sort flavour: 2 (default) = tile bits globally + depth bits per tile in LDS; 0 = onesweep over the whole key; 1 = three kernels
-    // automatic: segmented up to 2^19 instances (one 512^2 view: 74 vs 82 vs 100 us), three-kernel up to 2^23 (16 views: 285 vs
-    // 323 vs 360 us), onesweep beyond (64 views: 1041 vs 1176 vs 1186 us; 90 views at 1024^2: 3.57 vs 3.82 vs 3.87 ms)
-    // automatic: one or two 512^2 views (<= 2048 tiles, <= 2^19 instances): segmented with the single wide tile pass (74 vs 82 vs 100 us
-    // at C2); everything else with <= 4096 tiles per view: view-segmented; beyond that the whole-key passes
+    // automatic: one or two 512^2 views (<= 2048 tiles, <= 2^19 instances, <= 512 emission workgroups): ONE order-free 11-bit pass over
+    // the tile id whose histogram rows the emission kernel writes itself, then the LDS distribution sort per tile; everything else with
+    // <= 4096 tiles per view: view-segmented; beyond that the whole-key passes
     const uint32_t tpv = (uint32_t)Tx * (uint32_t)Ty;
     // launches whose tile lists are deep on average (C5: 1M Gaussians on 1024 tiles): the view-segmented flavour hands its long tiles to the
     // LDS distribution sort (deep_tile_kernel) instead of the register network; without room for its worklists they keep the whole-key passes
@@ -1936,18 +1579,16 @@ int sgr_bin_ex(const SgrProblem *pb, const int32_t *radii, uint32_t *rect,
     bool split = want_deep;
     if (split && VL.end > workspace_bytes) { split = false; VL = vseg_layout(R, tiles_total, (uint32_t)pb->n_views, tpv, false); }
     const bool vseg_ok = tpv <= (uint32_t)kVsegMaxBins && pb->n_views <= kVsegMaxViews && VL.end <= workspace_bytes;
-    int mode = sgr_sort_mode;
-    if (mode == 3) mode = (R <= (1ull << 19) && tiles_total <= 2048) ? 5 : ((vseg_ok && (!deep || split)) ? 4 : (R <= (1ull << 23) ? 1 : 0));
-    if (mode == 4 && !vseg_ok) mode = R <= (1ull << 23) ? 1 : 0;
-    // 5 = segmented with the register per-tile sort: needs the single wide tile pass (256 < tiles <= 2048, <= 2^19 instances) and the
-    // class worklists in the area the duplicate kernel cleared (all_large); otherwise the LDS flavour
-    const bool wide_regs = mode == 5 && all_large && small && bits_for(tiles_total) > kRadixBits && bits_for(tiles_total) <= kWideBits;
-    if (mode == 5) mode = 2;
-    // flavour 5, up to 512 emission workgroups: the emission kernel writes the tile pass's block-major histogram rows for its own key runs
-    // (one 8-KB row per workgroup at the head of the workspace, then the 2048 digit totals, then the runs) -- no histogram kernel
+    // the wide pass: the emission kernel writes the tile pass's block-major histogram rows for its own key runs (one 8-KB row per
+    // workgroup at the head of the workspace, then the 2048 digit totals, then the runs) -- no histogram kernel
     const uint32_t nblk_e = (uint32_t)nbx * (uint32_t)pb->n_views;
-    const bool emit_hist = wide_regs && nblk_e <= 512u &&
-                           ((size_t)(nblk_e + 1u) * kWide + 2u * (size_t)nblk_e) * sizeof(uint32_t) <= sgr_bin_workspace_bytes(R, 0);
+    const bool wide_ok = all_large && small && nblk_e <= 512u &&
+                         ((size_t)(nblk_e + 1u) * kWide + 2u * (size_t)nblk_e) * sizeof(uint32_t) <= sgr_bin_workspace_bytes(R, 0);
+    int mode = sgr_sort_mode;
+    if (mode == 3 || mode == 5) mode = wide_ok ? 5 : 4;
+    if (mode == 4 && !(vseg_ok && (!deep || split || sgr_sort_mode == 4))) mode = 1;
+    if (mode == 4 && !vseg_ok) mode = 1;
+    const bool emit_hist = mode == 5;
     uint2 *blk_runs = (uint2 *)(hist + (size_t)(nblk_e + 1u) * kWide);
     { SgrProfScope _p(SGR_K_DUPLICATE, stream);
     DupExtra ex;
@@ -2034,124 +1675,31 @@ int sgr_bin_ex(const SgrProblem *pb, const int32_t *radii, uint32_t *rect,
         if (result_in_b_host) *result_in_b_host = (kin == keys_b) ? 1 : 0;
         return 0;
     }
-    const bool segmented = mode == 2;
-    if (segmented && wide_regs) {
+    if (mode == 5) {
         uint32_t *wl = (uint32_t *)((char *)workspace + sgr_bin_workspace_bytes(R, 0));     // [16 counters][6][tiles_total]
-        // per-tile step: the LDS distribution sort (O(n), one workgroup per window of 3968 entries, ONE launch for everything) or
-        // -- sgr_set_sort_deep(2) -- the register network, whose launch lasts as long as its longest tile's 4- or 8-wave network
-        const bool wide_deep = g_deep_mode != 2;
         { SgrProfScope _ps(SGR_K_SORT, stream);
-        if (emit_hist) {
         hipLaunchKernelGGL(wide_rowscan_kernel, dim3(kWide / 64), dim3(1024), 0, stream, hist, nblk_e, hist + (size_t)nblk_e * kWide);
         hipLaunchKernelGGL(wide_downsweep_runs_kernel<kItemsSmall>, dim3(nblk_e), dim3(kThreads), 0, stream, kin, vin, kout, blk_runs, hist,
-                           hist + (size_t)nblk_e * kWide, (uint2 *)ranges, (uint32_t)tiles_total, wl, wide_deep ? g_deep_max_windows : 0u);
+                           hist + (size_t)nblk_e * kWide, (uint2 *)ranges, (uint32_t)tiles_total, wl, g_deep_max_windows);
         SGR_CHECK_LAUNCH("wide tile-bit pass (emitted rows)");
-        } else {
-        hipLaunchKernelGGL(wide_upsweep_kernel<kItemsSmall>, dim3(nblocks), dim3(kThreads), 0, stream, kin, n, num_rendered_dev, 32, nblocks, hist);
-        hipLaunchKernelGGL(wide_rowscan_kernel, dim3(kWide / 64), dim3(1024), 0, stream, hist, nblocks, hist + (size_t)nblocks * kWide);
-        hipLaunchKernelGGL((wide_downsweep_kernel<kItemsSmall, false>), dim3(nblocks), dim3(kThreads), 0, stream, kin, vin, kout, vout, n, num_rendered_dev, 32,
-                           nblocks, hist, hist + (size_t)nblocks * kWide, (uint2 *)ranges, (uint32_t)tiles_total, wl, wide_deep ? g_deep_max_windows : 0u);
-        SGR_CHECK_LAUNCH("wide tile-bit pass");
-        }
-        // composites sit tile-bucketed in kout (vout is scratch); the sorted list goes back into (kin, vin)
-        TileWork4 tw4;
-        for (int c = 0; c < 6; c++) { TileWork w = {wl + 16 + (size_t)c * tiles_total, wl + 8 + c, wl + c}; tw4.w[c] = w; }
+        // composites sit tile-bucketed in kout (vout is scratch); the sorted list goes back into (kin, vin).  Per-tile step: the LDS
+        // distribution sort (O(n), one workgroup per window of 3968 entries, ONE launch for everything; its spare last workgroup runs the
+        // forward's prepare step).  Resident workgroups stride over the window list.  1024 threads per tile: a single view has fewer
+        // tiles than the chip has CUs, so a tile's workgroup has its CU to itself and the phases are latency chains -- 256 threads: 15.5 us
+        // at C2, 512: 11.5, 1024: 10.5
         SortPrep sp;
         sp.desc = (uint2 *)prep_desc; sp.n_desc = prep_n_desc; sp.order = prep_order; sp.tiles_total = (uint32_t)tiles_total;
         sp.enabled = (prep_order || prep_desc) ? 1 : 0;
-        const uint32_t g = (uint32_t)(tiles_total < 256 ? tiles_total : 256);
-        if (wide_deep)      // (resident workgroups stride over the window list.  1024 threads per tile: a single view has fewer tiles than the chip has
-                            // CUs, so a tile's workgroup has its CU to itself and the phases are latency chains -- 256 threads: 15.5 us at C2, 512: 11.5,
-                            // 1024: 10.5; the batch instantiation for lists of <= 4096 entries runs 512 threads: C5 38 -> 33 us, 1024 is slower there)
-            hipLaunchKernelGGL((deep_tile_kernel<1024, kDeepSmallCap, 1024, true>), dim3((uint32_t)std::min<uint64_t>(tiles_total + R / (kDeepSmallCap - kDeepBinMax) + 1, 768u) + (sp.enabled ? 1u : 0u)),
-                               dim3(1024), 0, stream, kout, vout, kin, vin, wl, wl + 16, (const uint2 *)ranges, sorted_keys ? 1 : 0, (VsegPlan *)nullptr, (uint32_t *)nullptr, 0u, sp);
-        else
-        hipLaunchKernelGGL(tile_sort_regs_kernel<16>, dim3(g + (sp.enabled ? 1u : 0u)), dim3(1024), 0, stream, (const uint2 *)ranges, kout, vout, kin, vin,
-                           tw4, 4, 0, sp, sorted_keys ? 1 : 0);
+        hipLaunchKernelGGL((deep_tile_kernel<1024, kDeepSmallCap, 1024, true>), dim3((uint32_t)std::min<uint64_t>(tiles_total + R / (kDeepSmallCap - kDeepBinMax) + 1, 768u) + (sp.enabled ? 1u : 0u)),
+                           dim3(1024), 0, stream, kout, vout, kin, vin, wl, wl + 16, (const uint2 *)ranges, sorted_keys ? 1 : 0, (VsegPlan *)nullptr, (uint32_t *)nullptr, 0u, sp);
         if (sp.enabled && prep_done) *prep_done = 1;
-        SGR_CHECK_LAUNCH("tile_sort_regs_kernel");
+        SGR_CHECK_LAUNCH("deep_tile_kernel");
         }
         if (result_in_b_host) *result_in_b_host = (kin == keys_b) ? 1 : 0;
         return 0;
     }
-    if (segmented) {
-        uint32_t *worklist = (uint32_t *)((char *)workspace + sgr_bin_workspace_bytes(R, 0));   // [1 + tiles_total] behind the radix scratch
-        const int tile_bits = bits_for(tiles_total);
-        const int tpasses = (tile_bits + kRadixBits - 1) / kRadixBits;
-        const bool wide = small && tile_bits > kRadixBits && tile_bits <= kWideBits;      // one 11-bit pass instead of two 8-bit passes
-        { SgrProfScope _ps(SGR_K_SORT, stream);
-        if (wide) {
-            hipLaunchKernelGGL(wide_upsweep_kernel<kItemsSmall>, dim3(nblocks), dim3(kThreads), 0, stream, kin, n, num_rendered_dev, 32, nblocks, hist);
-            hipLaunchKernelGGL(wide_rowscan_kernel, dim3(kWide / 64), dim3(1024), 0, stream, hist, nblocks, hist + (size_t)nblocks * kWide);
-            hipLaunchKernelGGL((wide_downsweep_kernel<kItemsSmall, true>), dim3(nblocks), dim3(kThreads), 0, stream, kin, vin, kout, vout, n, num_rendered_dev, 32, nblocks, hist, hist + (size_t)nblocks * kWide,
-                               (uint2 *)ranges, (uint32_t)tiles_total, worklist, 0u);
-            SGR_CHECK_LAUNCH("wide tile-bit pass");
-            uint64_t *tk = kin; kin = kout; kout = tk;
-            uint32_t *tv = vin; vin = vout; vout = tv;
-        } else
-        for (int p = 0; p < tpasses; p++) {
-            const int shift = 32 + p * kRadixBits;
-            if (small) hipLaunchKernelGGL(radix_upsweep_kernel<kItemsSmall>, dim3(nblocks), dim3(kThreads), 0, stream, kin, n, num_rendered_dev, shift, nblocks, hist);
-            else hipLaunchKernelGGL(radix_upsweep_kernel<kItemsLarge>, dim3(nblocks), dim3(kThreads), 0, stream, kin, n, num_rendered_dev, shift, nblocks, hist);
-            hipLaunchKernelGGL(radix_rowscan_kernel, dim3(kRadix), dim3(kThreads), 0, stream, hist, nblocks, totals);
-            if (small) hipLaunchKernelGGL(radix_downsweep_kernel<kItemsSmall>, dim3(nblocks), dim3(kThreads), 0, stream, kin, vin, kout, vout, n, num_rendered_dev, shift, nblocks, hist, totals);
-            else hipLaunchKernelGGL(radix_downsweep_kernel<kItemsLarge>, dim3(nblocks), dim3(kThreads), 0, stream, kin, vin, kout, vout, n, num_rendered_dev, shift, nblocks, hist, totals);
-            SGR_CHECK_LAUNCH("radix tile-bit pass");
-            uint64_t *tk = kin; kin = kout; kout = tk;
-            uint32_t *tv = vin; vin = vout; vout = tv;
-        }
-        }
-        if (!wide) {                                            // (the wide pass wrote the ranges and the worklist itself)
-        SgrProfScope _pr(SGR_K_RANGES, stream);
-        hipLaunchKernelGGL(tile_ranges_kernel, dim3((n + kThreads - 1) / kThreads), dim3(kThreads), 0, stream, kin, n, num_rendered_dev, (uint2 *)ranges, worklist, all_large ? 1 : 0);
-        SGR_CHECK_LAUNCH("tile_ranges_kernel");
-        }
-        { SgrProfScope _ps(SGR_K_SORT, stream);
-        const uint32_t big_grid = (uint32_t)(tiles_total < 512 ? tiles_total : 512);
-        SortPrep sp;
-        sp.desc = (uint2 *)prep_desc; sp.n_desc = prep_n_desc; sp.order = prep_order; sp.tiles_total = (uint32_t)tiles_total;
-        sp.enabled = (prep_order || prep_desc) ? 1 : 0;
-        SortPrep none = sp; none.enabled = 0;
-        if (!all_large)
-            hipLaunchKernelGGL((tile_sort_kernel<256, kSegCapSmall, true>), dim3((uint32_t)tiles_total), dim3(256), 0, stream,
-                               (const uint2 *)ranges, kin, vin, kout, vout, worklist, none);
-        // one or two views: every occupied tile is a workgroup of this launch, at most one per CU is resident anyway -- so give it 150 KB of
-        // LDS and keep tiles of up to 8192 entries out of the global-memory fallback (side views of the humanoid have 6000-entry tiles:
-        // 66 -> ~45 us for the launch, whose duration is its heaviest tile's)
-        if (all_large)
-            hipLaunchKernelGGL((tile_sort_kernel<1024, 2 * kSegCapLarge, false>), dim3(big_grid + (sp.enabled ? 1u : 0u)), dim3(1024), 0, stream,
-                               (const uint2 *)ranges, kin, vin, kout, vout, worklist, sp);
-        else
-        hipLaunchKernelGGL((tile_sort_kernel<1024, kSegCapLarge, false>), dim3(big_grid + (sp.enabled ? 1u : 0u)), dim3(1024), 0, stream,
-                           (const uint2 *)ranges, kin, vin, kout, vout, worklist, sp);
-        if (sp.enabled && prep_done) *prep_done = 1;
-        SGR_CHECK_LAUNCH("tile_sort_kernel");
-        }
-        if (result_in_b_host) *result_in_b_host = (kout == keys_b) ? 1 : 0;
-        return 0;
-    }
-    const bool onesweep = mode == 0 && passes <= kMaxPasses && R < (1ull << 30);
+    // ---- the fallback: three kernels per 8-bit digit over the whole key (> 4096 tiles per view, or no room for the view-segmented plan)
     { SgrProfScope _ps(SGR_K_SORT, stream);
-    if (onesweep) {
-        uint32_t *ws32 = (uint32_t *)workspace;
-        uint32_t *ghist = ws32;                                   // [kMaxPasses][256]
-        uint32_t *tickets = ghist + kMaxPasses * kRadix;          // [kMaxPasses]
-        uint32_t *err = tickets + kMaxPasses;                     // [1] (+ padding to 256 entries)
-        uint32_t *status = tickets + kRadix;                      // [passes][nblocks][256]
-        SGR_CHECK_HIP(hipMemsetAsync(ws32, 0, ((size_t)(kMaxPasses + 1) * kRadix + (size_t)passes * nblocks * kRadix) * sizeof(uint32_t), stream));
-        const uint32_t hist_blocks = nblocks < 1024u ? (nblocks ? nblocks : 1u) : 1024u;
-        hipLaunchKernelGGL(radix_hist_all_kernel, dim3(hist_blocks), dim3(kThreads), 0, stream, kin, n, num_rendered_dev, passes, ghist);
-        SGR_CHECK_LAUNCH("radix_hist_all_kernel");
-        for (int p = 0; p < passes; p++) {
-            const int shift = p * kRadixBits;
-            uint32_t *st_p = status + (size_t)p * nblocks * kRadix;
-            if (small) hipLaunchKernelGGL(radix_onesweep_kernel<kItemsSmall>, dim3(nblocks), dim3(kThreads), 0, stream, kin, vin, kout, vout, n, num_rendered_dev, shift, ghist + p * kRadix, st_p, tickets + p, err);
-            else hipLaunchKernelGGL(radix_onesweep_kernel<kItemsLarge>, dim3(nblocks), dim3(kThreads), 0, stream, kin, vin, kout, vout, n, num_rendered_dev, shift, ghist + p * kRadix, st_p, tickets + p, err);
-            SGR_CHECK_LAUNCH("radix_onesweep_kernel");
-            uint64_t *tk = kin; kin = kout; kout = tk;
-            uint32_t *tv = vin; vin = vout; vout = tv;
-        }
-    } else
     for (int p = 0; p < passes; p++) {
         const int shift = p * kRadixBits;
         if (small) hipLaunchKernelGGL(radix_upsweep_kernel<kItemsSmall>, dim3(nblocks), dim3(kThreads), 0, stream, kin, n, num_rendered_dev, shift, nblocks, hist);
@@ -2168,8 +1716,7 @@ int sgr_bin_ex(const SgrProblem *pb, const int32_t *radii, uint32_t *rect,
     }
     if (result_in_b_host) *result_in_b_host = (kin == keys_b) ? 1 : 0;
     { SgrProfScope _p(SGR_K_RANGES, stream);
-    hipLaunchKernelGGL(tile_ranges_kernel, dim3((n + kThreads - 1) / kThreads), dim3(kThreads), 0, stream, kin, n,
-                       num_rendered_dev, (uint2 *)ranges, (uint32_t *)nullptr, 0);
+    hipLaunchKernelGGL(tile_ranges_kernel, dim3((n + kThreads - 1) / kThreads), dim3(kThreads), 0, stream, kin, n, num_rendered_dev, (uint2 *)ranges);
     SGR_CHECK_LAUNCH("tile_ranges_kernel");
     }
     return 0;

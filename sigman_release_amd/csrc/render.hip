@@ -567,15 +567,13 @@ __global__ __launch_bounds__(1024) void fwd_prepare_kernel(const uint2 *__restri
 }
 
 // -------------------------------------------------------------------------------------------------
-// B1 (v2): bucket-parallel "systolic" backward.  One wave = one bucket of <= 64 consecutive surviving
-// Gaussians of one (tile, quadrant) against that quadrant's 64 pixels.  LANES OWN GAUSSIANS: each lane keeps
-// its Gaussian's record and its 10 gradient accumulators in registers for the whole kernel, so there is
-// no cross-lane reduction and no LDS at all.  The 64 pixel states (position, n_contrib, upstream grads, and
-// the running transmittance / composited-so-far dot product) travel through the lanes by a full-wave DPP
-// rotate (wave_ror:1, available on the gfx9 family) -- pixel p enters lane 0 at step p and reaches lane i at
-// step p+i, i.e. in front-to-back order, starting from the forward pass's checkpoint for this bucket.
-// All buckets of a frame run concurrently (thousands of independent waves instead of one serial walk per tile),
-// and each (tile-quadrant, Gaussian) pair costs ONE set of hardware float atomics.
+// B1: bucket-parallel "systolic" backward.  One wave = one bucket of <= 64 consecutive surviving Gaussians of one (tile, quadrant)
+// against that quadrant's pixels.  LANES OWN GAUSSIANS: each lane keeps its Gaussian's record and its ten gradient accumulators in
+// registers for the whole kernel, so there is no cross-lane reduction; the pixel states (the running transmittance and the
+// composited-so-far dot product) travel through the lanes of a 16-lane row by DPP shifts, front to back, starting from the forward
+// pass's checkpoint for that row; the static pixel data is read from LDS.  All buckets of a frame run concurrently (thousands of
+// independent waves instead of one serial walk per tile), and each (tile instance, quadrant) pair leaves ONE non-atomic 40-byte partial
+// record that preprocess_bwd gathers in a fixed order: NO ATOMICS anywhere in the backward, gradients are bitwise reproducible.
 //
 // Math (front-to-back form of the published reverse walk), per pixel with g = upstream gradient vector over
 // (r,g,b,depth,alpha), f_j = (r_j,g_j,b_j,depth_j,1), q_j = f_j . g, w_j = alpha_j T_j:

@@ -16,7 +16,7 @@ def _dev():
     return torch.device("cuda:0")
 
 
-@pytest.mark.parametrize("kind,P", [("humanoid", 20000), ("humanoid", 100_003), ("cloud", 5000), ("dups", 600), ("tiny", 5), ("line", 3000),
+@pytest.mark.parametrize("kind,P", [("humanoid", 20000), ("humanoid", 100_003), ("cloud", 5000), ("cloud", 300_000), ("thin_shell", 50_000), ("dups", 600), ("tiny", 5), ("line", 3000),
                                     ("outliers", 4001)])
 def test_dist_cuda2_exact_knn(kind, P):
     from scipy.spatial import cKDTree
@@ -24,8 +24,11 @@ def test_dist_cuda2_exact_knn(kind, P):
     rng = np.random.default_rng(4)
     if kind == "humanoid":
         pts = synthetic.humanoid(P, 2)["position"]
-    elif kind == "cloud":
+    elif kind == "cloud":          # (300 000 points: beyond the brick table every scatter workgroup scans for itself -> the separate scan kernels)
         pts = rng.uniform(-0.8, 0.8, size=(P, 3)).astype(np.float32)
+    elif kind == "thin_shell":     # a sphere surface far from the origin: coordinates ~100x the extent of a brick neighbourhood (rounding allowance)
+        v = rng.normal(size=(P, 3)); v /= np.linalg.norm(v, axis=1, keepdims=True)
+        pts = (v * 0.5 + np.array([40.0, -25.0, 10.0])).astype(np.float32)
     elif kind == "dups":
         pts = np.repeat(rng.normal(size=(P // 4, 3)).astype(np.float32), 4, 0)       # every point has 3 exact duplicates
     elif kind == "tiny":
