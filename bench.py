@@ -197,10 +197,11 @@ CONFIGS = {
 }
 
 
-def algorithmic_bytes(kid: int, P: int, Rn: int, HW: int, tiles: int, bwd_da: bool = True) -> float:
-    """SURVEY.md 8(d) per-view figures; P, Rn, HW, tiles are totals over the view slots of one launch."""
+def algorithmic_bytes(kid: int, P: int, Rn: int, HW: int, tiles: int, masked: bool = False) -> float:
+    """SURVEY.md 8(d) per-view figures; P, Rn, HW, tiles are totals over the view slots of one launch (loss kernel: colour + target + gradient,
+    12 B per pixel each, + 4 B of mask)."""
     return float({0: 76 * P, 1: 8 * P, 2: 20 * P + 12 * Rn, 3: 24 * Rn, 4: 8 * Rn + 8 * tiles, 5: 44 * Rn + 24 * HW,
-                  6: 88 * Rn + 28 * HW, 7: 108 * P, 10: 36 * HW}[kid])
+                  6: 88 * Rn + 28 * HW, 7: 108 * P, 10: (40 if masked else 36) * HW}[kid])
 
 
 def build_subject(cfg_name: str, P: int, seed: int, dev):
@@ -574,14 +575,14 @@ def main(args):
     tiles = ((W + 15) // 16) * ((H + 15) // 16)
     dom_ms, dom_n = dom.get(dominant, (0.0, 0))
     dom_avg_ms = dom_ms / max(dom_n, 1)
-    abytes = algorithmic_bytes(dominant, P * n_local, Rn, H * W * n_local, tiles * n_local)
+    abytes = algorithmic_bytes(dominant, P * n_local, Rn, H * W * n_local, tiles * n_local, gt_mask is not None)
     achieved = abytes / (dom_avg_ms * 1e-3) / 1e9 if dom_avg_ms > 0 else 0.0
     step_bytes = ((212 if bwd else 104) * P * n_local + (176 if bwd else 88) * Rn + (52 if bwd else 24) * H * W * n_local + 8 * tiles * n_local)
 
     # HBM traffic of the dominant kernel from the committed rocprofv3 PMC summary of this same command (separate --pmc passes,
     # gfx950 FETCH_SIZE correction applied as MI355X_MICROARCH.md prescribes); null when no summary matches this workload
     traffic, traffic_src = None, None
-    for rnd in ("r04", "r03", "r02"):                      # the newest committed summary for this config
+    for rnd in ("r05", "r04", "r03", "r02"):               # the newest committed summary for this config
         try:
             path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_{args.config}.json")
             pmc = json.load(open(path))
@@ -615,6 +616,19 @@ def main(args):
         "kernel_ms_per_step": breakdown,
         "loss": None if loss is None else float(loss.detach()),
     }
+    # The compositing kernels are instruction-bound, not byte-bound: next to the HBM figure the contract asks for, the roof
+    # they really approach -- plain wave64 VALU instructions issued per second against the rate measured on this part with
+    # tools/micro/valu_rate.hip (8.55e11/s) -- from the committed SQ-counter summary of this same command (tools/pmc_sq.sh), if there is one
+    try:
+        sq = json.load(open(os.path.join(ROOT, "profiles", f"r05_sq_{args.config}.json")))
+        kname = KERNELS.get(dominant, "")
+        ent = next((v for k, v in sq["kernels"].items() if k.startswith(kname) and "SQ_INSTS_VALU" in v and v.get("avg_us")), None)
+        if ent:
+            rate = ent["SQ_INSTS_VALU"] / (ent["avg_us"] * 1e-6)
+            out["roofline_valu_issue"] = {"bound": "valu_issue", "kernel": kname, "achieved": round(rate / 1e9, 1), "peak": 855.0, "unit": "G wave-instr/s",
+                                          "frac": round(rate / 8.55e11, 4), "source": f"profiles/r05_sq_{args.config}.json (SQ_INSTS_VALU / kernel duration of that run)"}
+    except Exception:      # noqa: BLE001
+        pass
     out["config"]["host_threads"] = pin_report
     if win_wall:
         q = lambda v: [round(float(x), 4) for x in (np.min(v), np.median(v), np.max(v))]

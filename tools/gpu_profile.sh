@@ -9,8 +9,10 @@ rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks_$c -o $c -- $B >
 cp $(find /tmp/ks_$c -name "*kernel_stats.csv" | head -1) $O/kernel_stats.csv
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o f -- $B > /dev/null 2> $O/pmc_fetch.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o w -- $B > /dev/null 2> $O/pmc_write.err
+# what leaves the L2 for the memory side (round 5; there is no Infinity-Cache hit counter in rocprofv3's list on this stack: gpurun_out/counters_avail.txt)
+rocprofv3 --pmc TCC_EA0_RDREQ_DRAM_sum TCC_EA0_RDREQ_DRAM_32B_sum TCC_EA0_WRREQ_DRAM_sum TCC_EA0_WRREQ_64B_sum --kernel-trace --output-format csv -d $O/pmc_dram -o d -- $B > /dev/null 2> $O/pmc_dram.err
 find $O -name "*kernel_trace.csv" -delete; find $O -name "*agent_info.csv" -delete
 du -sh $O
 cd $GRAFT_REPO_ROOT
 $B > $O/bench_plain.json 2>/dev/null
-python tools/pmc_summary.py $c $O/pmc_fetch $O/pmc_write $O/kernel_stats.csv $O/bench_plain.json $O/pmc_$c.json | tee $O/table.md
+python tools/pmc_summary.py $c $O/pmc_fetch $O/pmc_write $O/kernel_stats.csv $O/bench_plain.json $O/pmc_$c.json $O/pmc_dram | tee $O/table.md
