@@ -16,3 +16,5 @@ du -sh $O
 cd $GRAFT_REPO_ROOT
 $B > $O/bench_plain.json 2>/dev/null
 python tools/pmc_summary.py $c $O/pmc_fetch $O/pmc_write $O/kernel_stats.csv $O/bench_plain.json $O/pmc_$c.json $O/pmc_dram | tee $O/table.md
+# (the per-dispatch counter tables are tens of MB per config: gpurun copies gpurun_out/ back only below 64 MiB)
+rm -rf $O/pmc_fetch $O/pmc_write $O/pmc_dram /tmp/ks_$c
