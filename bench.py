@@ -38,7 +38,7 @@ from sysfs by a side process during the timed region.  The loss of the timed ste
 gt_masks multiplies prediction and target; mask = ground-truth alpha > 0.5) unless `--no-mask`.
 `roofline` is for the dominant kernel, timed with HIP events recorded by the library on the launch stream inside the
 timed region; `roofline.traffic` comes from the committed rocprofv3 PMC summary of this same command
-(profiles/r04_pmc_<config>.json, else the newest older one; null when there is none for the workload).  `cpu_baseline` is the CPU oracle
+(profiles/r05_pmc_<config>.json, else the newest older one; null when there is none for the workload).  `cpu_baseline` is the CPU oracle
 (oracle/gsplat_ref.c, OpenMP) on a bounded sample of the same inputs, rank 0 at N=1 only.
 """
 from __future__ import annotations
