@@ -55,6 +55,9 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 #define TILE 16
 
@@ -80,6 +83,16 @@ typedef struct {
 
 static inline float fminf_(float a, float b) { return a < b ? a : b; }
 static inline float fmaxf_(float a, float b) { return a > b ? a : b; }
+
+/* Threads of the CALLING thread's later parallel regions (OpenMP's nthreads-var is per thread): lets a test harness run several oracle
+ * calls side by side from a thread pool, each with a small team, instead of one call at a time on every core. */
+void ref_set_num_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
 
 /* ---- per-visit exponent / alpha (see the header): 0 = reproducible (default), 1 = published order */
 static int g_alpha_mode = 0;

@@ -50,6 +50,11 @@ def lib():
     return _lib
 
 
+def set_threads(n: int) -> None:
+    """OpenMP team size of the CALLING Python thread's later oracle calls (test harnesses that run several calls side by side)."""
+    lib().ref_set_num_threads(int(n))
+
+
 def set_alpha_mode(mode: int) -> int:
     """0 = reproducible exponent (explicit FMA chain on the pre-scaled conic) + correctly rounded exp2: the default, what the HIP kernels
     are pinned against; 1 = the published expression left to right without FMA + libm expf (gsplat_ref.c header).  Returns the old mode."""

@@ -255,7 +255,12 @@ __global__ __launch_bounds__(64, AUX ? SGR_WAVE_AUX_WAVES : 8) void render_fwd_w
 // the bucket-parallel backward with its checkpoint (T_in, composited-so-far); cutting segments at exactly 64
 // survivors (only the last one of a list is shorter) keeps all four 16-lane rows of the backward's waves busy.
 // -------------------------------------------------------------------------------------------------
-constexpr int kSegThreads = 512, kSegWaves = 8, kSegRing = 1024, kSegPer = 64;
+// (waves per workgroup, measured in round 5 on one box: 4 -> C2 forward 48.8 -> 61.8 us, C1 26.5 -> 23.5; 16 -> one workgroup per CU and
+// spills, C2 87 us.  The heaviest tile's chain of rounds is the critical path at C2, the number of resident workgroups at C1.)
+#ifndef SGR_SEG_WAVES
+#define SGR_SEG_WAVES 8
+#endif
+constexpr int kSegWaves = SGR_SEG_WAVES, kSegThreads = 64 * kSegWaves, kSegRing = 2 * kSegThreads, kSegPer = 64;
 typedef float v2f __attribute__((ext_vector_type(2)));      // <2 x float>: the backend selects v_pk_{add,mul,fma}_f32 for it
 
 
@@ -382,7 +387,7 @@ __global__ __launch_bounds__(kSegThreads, 4) void render_fwd_seg_kernel(int W, i
         // one round: m survivors in up to 8 segments of 16, 32 or 64 (1, 2 or 4 backward rows; segments never straddle a
         // 64-survivor bucket).  Only the last round of a list is shorter than 512, and then spreads over all waves.
         const uint32_t m = min(qcount, (uint32_t)(kSegWaves * kSegPer));
-        const uint32_t per = m <= 128u ? 16u : (m <= 256u ? 32u : 64u);
+        const uint32_t per = m <= 16u * kSegWaves ? 16u : (m <= 32u * kSegWaves ? 32u : 64u);
         const uint32_t s0 = min(m, (uint32_t)wave * per), s1 = min(m, s0 + per);
         const uint32_t brow0 = (s0 & 63u) >> 4;                     // my segment's first row inside its 64-survivor bucket
         // the loops below take survivors four at a time without bounds checks: pad the (last) round with null entries (opacity 0).

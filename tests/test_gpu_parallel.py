@@ -126,7 +126,8 @@ def test_bench_rccl_path_with_one_rank():
     test box cannot hold two RCCL ranks, but every call the 8-GPU run makes is made here."""
     import json
     import subprocess
-    for config, exchange, steps in (("c2", "loss", 20), ("c3", "full", 3), ("c3", "full-pipelined", 3), ("c5", "full", 5), ("c4", "loss", 2)):
+    # (three launches, ~7 s each: the loss-only exchange, the blocking gradient all-reduce, the pipelined per-subject exchange)
+    for config, exchange, steps in (("c2", "loss", 20), ("c5", "full", 5), ("c3", "full-pipelined", 3)):
         s = socket.socket()
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]

@@ -1081,9 +1081,9 @@ def test_randomised_parity_slice(oracle):
     ragged image sizes, P around the 64-lane boundaries, faint to saturating opacities, tiny to huge splats, colours + covariances or SH
     degree 0-3 + scales / rotations, 1-3 views per batch, a random forward kernel each) against the CPU oracle, view by
     view.  Integer artefacts (instance count, radii, tile ranges; sorted keys and point list for single views) must be IDENTICAL in every
-    configuration.  Images / gradients beyond the north_star tolerance are counted -- a Gaussian whose alpha sits within an ulp of 1/255 at
-    a pixel is resolved differently by the oracle's expf and the kernels' v_exp_f32 -- and checked against the committed record like the
-    full-size tests: no view may have more than two such pixels, and the counts may not double."""
+    configuration.  Images / gradients beyond the north_star tolerance are counted and checked against the committed record like the
+    full-size tests (round 5: the record is all zeros -- every alpha-test decision is made identically on both sides); no view may have
+    more than two such pixels, and the counts may not double."""
     from sigman_release_amd import _cabi, cameras
     from sigman_release_amd import rasterizer as R
     L = _cabi.lib()
@@ -1093,60 +1093,80 @@ def test_randomised_parity_slice(oracle):
              "scales": "scales", "rotations": "rotations"}
     n_views = n_bad_views = n_bad_grads = 0
     worst_img = worst_grad = 0.0
+
+    # The CPU side of a configuration (inputs, cameras, the oracle's forward + backward per view) does not depend on the GPU: a pool of
+    # host threads works ahead of the GPU loop, each oracle call with a small OpenMP team (one call at a time on every core of the box spent
+    # its time starting 256-thread teams for 500-Gaussian scenes: 47 s of the suite)
+    def cpu_side(seed):
+        oracle.set_threads(4)
+        rng = np.random.default_rng(7000 + seed)
+        inp, st = _random_config(seed)
+        V = int(rng.choice([1, 1, 2, 3]))
+        views = [int(v) for v in rng.choice(90, V, replace=False)]
+        st["viewmatrix"], st["projmatrix"], st["campos"] = cameras.make_cameras(views)
+        mode = int(rng.choice([2, 3]))
+        g = [cases.grads_for(st["image_height"], st["image_width"], seed=seed * 7 + v) for v in range(V)]
+        refs, acc = [], None
+        for v in range(V):
+            r = oracle.forward(**inp, **cases.single_view(st, v))
+            gr = oracle.backward(r, *g[v])
+            acc = gr if acc is None else {k: acc[k] + gr[k] for k in acc}
+            refs.append(r)
+        return inp, st, V, mode, g, refs, acc
+
+    from concurrent.futures import ThreadPoolExecutor
+    seeds = list(range(3000, 3600))
+    ahead = 48
     try:
-        for seed in range(3000, 3600):
-            rng = np.random.default_rng(7000 + seed)
-            inp, st = _random_config(seed)
-            V = int(rng.choice([1, 1, 2, 3]))
-            views = [int(v) for v in rng.choice(90, V, replace=False)]
-            st["viewmatrix"], st["projmatrix"], st["campos"] = cameras.make_cameras(views)
-            H, W = st["image_height"], st["image_width"]
-            mode = int(rng.choice([2, 3]))
-            L.sgr_set_forward_mode(mode)
-            d = {k: t(v)[None].requires_grad_(True) for k, v in inp.items()}
-            bst = _batched_settings(st, dev, V)
-            with torch.no_grad():
-                dbg = R.forward_debug(d["means3D"], d["opacities"], colors_precomp=d.get("colors_precomp"), shs=d.get("shs"),
-                                      cov3D_precomp=d.get("cov3D_precomp"), scales=d.get("scales"), rotations=d.get("rotations"), settings=bst)
-            color, radii, depth, alpha = R.rasterize_gaussians_batched(d["means3D"], None, d.get("shs"), d.get("colors_precomp"), d["opacities"][..., None],
-                                                                       d.get("scales"), d.get("rotations"), d.get("cov3D_precomp"), bst)
-            g = [cases.grads_for(H, W, seed=seed * 7 + v) for v in range(V)]
-            sum((color[v] * t(g[v][0])).sum() + (depth[v] * t(g[v][1])).sum() + (alpha[v] * t(g[v][2])).sum() for v in range(V)).backward()
-            torch.cuda.synchronize()
-            acc, total = None, 0
-            what = f"seed {seed} ({V} view(s), forward kernel {mode})"
-            for v in range(V):
-                r = oracle.forward(**inp, **cases.single_view(st, v))
-                assert np.array_equal(dbg["radii"][v].cpu().numpy(), r.radii), f"{what}: radii"
-                hr, orr = dbg["ranges"][v].cpu().numpy().astype(np.int64), np.asarray(r.ranges).astype(np.int64)
-                ne = (orr[:, 1] - orr[:, 0]) > 0
-                assert np.array_equal(hr[:, 1] - hr[:, 0], orr[:, 1] - orr[:, 0]) and np.array_equal(hr[ne, 0] - total, orr[ne, 0]), f"{what}: tile ranges"
-                total += r.R
-                off, e = np.zeros((H, W), bool), 0.0
-                for got, want in ((color[v], r.color), (depth[v], r.depth), (alpha[v], r.alpha)):
-                    ea = np.abs(got.detach().cpu().numpy() - want)
-                    e = max(e, float(ea.max()))
-                    off |= (ea > IMG_TOL).any(0)
-                worst_img = max(worst_img, e)
-                n_views += 1
-                if off.any():
-                    n_bad_views += 1
-                    assert int(off.sum()) <= 2 and e <= 1.0 / 255.0 + 1e-4, f"{what}, view {v}: {int(off.sum())} pixels beyond 1e-4 (max {e:.3e}): more than single threshold decisions"
-                gr = oracle.backward(r, *g[v])
-                acc = gr if acc is None else {k: acc[k] + gr[k] for k in acc}
-            assert dbg["num_rendered"] == total, f"{what}: instance count"
-            if V == 1:
-                assert np.array_equal(dbg["keys"].cpu().numpy().view(np.uint64), r.keys), f"{what}: sorted keys"
-                assert np.array_equal(dbg["point_list"].cpu().numpy().astype(np.uint32), r.point_list), f"{what}: point list"
-            for k, x in d.items():
-                want = acc[names[k]].reshape(x.grad[0].shape)
-                got = x.grad[0].cpu().numpy()
-                assert np.isfinite(got).all(), f"{what}: grad {k}"
-                e = float(np.abs(got - want).max()) / max(float(np.abs(want).max()), 1e-20)
-                worst_grad = max(worst_grad, e)
-                if e > GRAD_TOL:
-                    n_bad_grads += 1
-                    assert e <= 5e-2, f"{what}: grad {k} rel-to-max err {e:.3e}"
+        with ThreadPoolExecutor(max_workers=max(2, min(16, (os.cpu_count() or 8) // 4))) as pool:
+            futs = {sd: pool.submit(cpu_side, sd) for sd in seeds[:ahead]}
+            for n_done, seed in enumerate(seeds):
+                if n_done + ahead < len(seeds):
+                    futs[seeds[n_done + ahead]] = pool.submit(cpu_side, seeds[n_done + ahead])
+                inp, st, V, mode, g, refs, acc = futs.pop(seed).result()
+                H, W = st["image_height"], st["image_width"]
+                L.sgr_set_forward_mode(mode)
+                d = {k: t(v)[None].requires_grad_(True) for k, v in inp.items()}
+                bst = _batched_settings(st, dev, V)
+                with torch.no_grad():
+                    dbg = R.forward_debug(d["means3D"], d["opacities"], colors_precomp=d.get("colors_precomp"), shs=d.get("shs"),
+                                          cov3D_precomp=d.get("cov3D_precomp"), scales=d.get("scales"), rotations=d.get("rotations"), settings=bst)
+                color, radii, depth, alpha = R.rasterize_gaussians_batched(d["means3D"], None, d.get("shs"), d.get("colors_precomp"), d["opacities"][..., None],
+                                                                           d.get("scales"), d.get("rotations"), d.get("cov3D_precomp"), bst)
+                sum((color[v] * t(g[v][0])).sum() + (depth[v] * t(g[v][1])).sum() + (alpha[v] * t(g[v][2])).sum() for v in range(V)).backward()
+                torch.cuda.synchronize()
+                total = 0
+                what = f"seed {seed} ({V} view(s), forward kernel {mode})"
+                for v in range(V):
+                    r = refs[v]
+                    assert np.array_equal(dbg["radii"][v].cpu().numpy(), r.radii), f"{what}: radii"
+                    hr, orr = dbg["ranges"][v].cpu().numpy().astype(np.int64), np.asarray(r.ranges).astype(np.int64)
+                    ne = (orr[:, 1] - orr[:, 0]) > 0
+                    assert np.array_equal(hr[:, 1] - hr[:, 0], orr[:, 1] - orr[:, 0]) and np.array_equal(hr[ne, 0] - total, orr[ne, 0]), f"{what}: tile ranges"
+                    total += r.R
+                    off, e = np.zeros((H, W), bool), 0.0
+                    for got, want in ((color[v], r.color), (depth[v], r.depth), (alpha[v], r.alpha)):
+                        ea = np.abs(got.detach().cpu().numpy() - want)
+                        e = max(e, float(ea.max()))
+                        off |= (ea > IMG_TOL).any(0)
+                    worst_img = max(worst_img, e)
+                    n_views += 1
+                    if off.any():
+                        n_bad_views += 1
+                        assert int(off.sum()) <= 2 and e <= 1.0 / 255.0 + 1e-4, f"{what}, view {v}: {int(off.sum())} pixels beyond 1e-4 (max {e:.3e}): more than single threshold decisions"
+                assert dbg["num_rendered"] == total, f"{what}: instance count"
+                if V == 1:
+                    assert np.array_equal(dbg["keys"].cpu().numpy().view(np.uint64), refs[0].keys), f"{what}: sorted keys"
+                    assert np.array_equal(dbg["point_list"].cpu().numpy().astype(np.uint32), refs[0].point_list), f"{what}: point list"
+                for k, x in d.items():
+                    want = acc[names[k]].reshape(x.grad[0].shape)
+                    got = x.grad[0].cpu().numpy()
+                    assert np.isfinite(got).all(), f"{what}: grad {k}"
+                    e = float(np.abs(got - want).max()) / max(float(np.abs(want).max()), 1e-20)
+                    worst_grad = max(worst_grad, e)
+                    if e > GRAD_TOL:
+                        n_bad_grads += 1
+                        assert e <= 5e-2, f"{what}: grad {k} rel-to-max err {e:.3e}"
     finally:
         L.sgr_set_forward_mode(0)
     assert n_views >= 600
