@@ -264,6 +264,17 @@ constexpr int kSegWaves = SGR_SEG_WAVES, kSegThreads = 64 * kSegWaves, kSegRing 
 typedef float v2f __attribute__((ext_vector_type(2)));      // <2 x float>: the backend selects v_pk_{add,mul,fma}_f32 for it
 
 
+#ifdef SGR_SEG_TRACE
+// Dev instrumentation (tools/seg_trace.py, built by tools/build_ab.sh with -DSGR_SEG_TRACE): wave 0 of the workgroups of the first
+// kSegTraceSlots work-order slots records (s_memtime << 8 | event id) at every phase boundary.  Not compiled into the product library.
+constexpr int kSegTraceSlots = 8, kSegTraceEvents = 512, kSegTraceSched = kSegTraceSlots * 4 * kSegTraceEvents;   // schedule records start here: 4 words per (slot, q)
+__device__ unsigned long long *g_seg_trace = nullptr;
+extern "C" int sgr_debug_seg_trace(void *buf) { return hipMemcpyToSymbol(HIP_SYMBOL(g_seg_trace), &buf, sizeof(buf)) == hipSuccess ? 0 : 1; }
+#define SGR_TR(ID) do { if (tr_buf && tr_n < kSegTraceEvents) { tr_buf[tr_n++] = ((unsigned long long)__builtin_readcyclecounter() << 8) | (unsigned)(ID); } } while (0)
+#else
+#define SGR_TR(ID) do { } while (0)
+#endif
+
 template <int AUX>
 __global__ __launch_bounds__(kSegThreads, 4) void render_fwd_seg_kernel(int W, int H, int Tx, uint32_t tiles_per_view,
                                                                      const uint2 *__restrict__ ranges,
@@ -296,6 +307,19 @@ __global__ __launch_bounds__(kSegThreads, 4) void render_fwd_seg_kernel(int W, i
     const uint32_t tx = tile % Tx, ty = tile / Tx;
     const uint2 range = ranges[bid];
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+#ifdef SGR_SEG_TRACE
+    unsigned long long *tr_buf = (g_seg_trace && slot < (uint32_t)kSegTraceSlots && t == 0) ? g_seg_trace + ((size_t)slot * 4 + q) * kSegTraceEvents : nullptr;
+    int tr_n = 2;
+    if (tr_buf) { tr_buf[1] = ((unsigned long long)(uint32_t)(range.y - range.x) << 32) | bid; }
+    SGR_TR(1);
+    unsigned long long *sch = (g_seg_trace && t == 0) ? g_seg_trace + kSegTraceSched + ((size_t)slot * 4 + q) * 4 : nullptr;
+    if (sch) {
+        sch[0] = wall_clock64();
+        sch[2] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 20) << 32) | (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);
+        sch[3] = ((unsigned long long)(uint32_t)(range.y - range.x) << 32) | bid;
+        sch[1] = sch[0];
+    }
+#endif
     const int px = (int)tx * 16 + (int)(q & 1u) * 8 + (lane & 7);
     const int py = (int)ty * 16 + (int)(q >> 1) * 8 + (lane >> 3);
     const bool inside = px < W && py < H;
@@ -348,6 +372,7 @@ __global__ __launch_bounds__(kSegThreads, 4) void render_fwd_seg_kernel(int W, i
     if (t + kSegThreads < n) id_nx = point_list[range.x + t + kSegThreads];
     for (;;) {
         if (__syncthreads_count(pix_done) == kSegThreads) break;     // also: every wave is done reading the previous round's ring entries
+        SGR_TR(2);
         // ---- fill: cull + append sub-chunks until a full round is available
         while (qcount < (uint32_t)(kSegWaves * kSegPer) && commit < n) {
             const int idx = commit + t;
@@ -384,6 +409,7 @@ __global__ __launch_bounds__(kSegThreads, 4) void render_fwd_seg_kernel(int W, i
             __syncthreads();                                     // ring entries visible; sWaveCnt reusable
         }
         if (qcount == 0) break;
+        SGR_TR(3);
         // one round: m survivors in up to 8 segments of 16, 32 or 64 (1, 2 or 4 backward rows; segments never straddle a
         // 64-survivor bucket).  Only the last round of a list is shorter than 512, and then spreads over all waves.
         const uint32_t m = min(qcount, (uint32_t)(kSegWaves * kSegPer));
@@ -424,8 +450,10 @@ __global__ __launch_bounds__(kSegThreads, 4) void render_fwd_seg_kernel(int W, i
             }
             Tseg = (((Tseg * om[0]) * om[1]) * om[2]) * om[3];
         }
+        SGR_TR(4);
         sT[wave][lane] = Tseg;
         __syncthreads();
+        SGR_TR(5);
         float Tin = Tcarry, Tall = Tcarry;
 #pragma unroll
         for (int w = 0; w < kSegWaves; w++) { const float tw = sT[w][lane]; if (w < wave) Tin *= tw; Tall *= tw; }
@@ -486,6 +514,7 @@ __global__ __launch_bounds__(kSegThreads, 4) void render_fwd_seg_kernel(int W, i
         }
         const float d0 = d01.x, d1 = d01.y, d2 = d2D.x, dD = d2D.y;
 #undef SGR_RING
+        SGR_TR(6);
         if (done && !done_at_start) Tstop = T;                   // I am the segment in which this pixel stopped
         C0 += d0; C1 += d1; C2 += d2; D += dD; A += dA;
         if (AUX) {
@@ -517,12 +546,14 @@ __global__ __launch_bounds__(kSegThreads, 4) void render_fwd_seg_kernel(int W, i
             }
             slot_next += (m + 63u) >> 6;
         }
+        SGR_TR(7);
         kbase += m;
         qhead = (qhead + m) & (kSegRing - 1);
         qcount -= m;
         Tcarry = Tall;
         pix_done = !inside | (Tcarry < 0.0001f);
     }
+    SGR_TR(8);
     // ---- combine the 8 partial sums
     __syncthreads();
     if (Tstop >= 0.f) sTstop[lane] = Tstop;
@@ -556,6 +587,11 @@ __global__ __launch_bounds__(kSegThreads, 4) void render_fwd_seg_kernel(int W, i
         out_depth[vb + pix] = rD;
         out_alpha[vb + pix] = rA;
     }
+#ifdef SGR_SEG_TRACE
+    SGR_TR(9);
+    if (tr_buf) tr_buf[0] = (unsigned long long)tr_n;
+    if (sch) sch[1] = wall_clock64();
+#endif
 }
 
 // -------------------------------------------------------------------------------------------------

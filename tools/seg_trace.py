@@ -1,0 +1,80 @@
+"""Dev tool (GPU): phase timeline of the segment-parallel forward's heaviest workgroups at a bench config.  Needs a library built with
+-DSGR_SEG_TRACE:   tools/build_ab.sh trace render.hip -DSGR_SEG_TRACE;  SIGMAN_PY_NODE=1 SIGMAN_GSPLAT_LIB=$PWD/tools/ab/trace.so python tools/seg_trace.py c2
+Events (wave 0 of the workgroup): 1 start, 2 loop top, 3 fill done, 4 phase 1 done, 5 prefix barrier passed, 6 phase 2 done, 7 round bookkeeping done,
+8 list done, 9 outputs written.  Prints, per traced workgroup, the time spent between consecutive event kinds (us, s_memtime at 100 MHz)."""
+import ctypes as C, os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+from sigman_release_amd import _cabi, cameras, rasterizer as R
+
+name = sys.argv[1] if len(sys.argv) > 1 else "c2"
+cfg = bench.CONFIGS[name]
+dev = torch.device("cuda", 0)
+P, H = cfg["P"], cfg["size"]
+sub = bench.build_subject(name, P, {"c1": 0, "c2": 1, "c5": 4}.get(name, 1), dev)[0]
+subj = {k: sub[k][None] for k in ("means3D", "cov3D", "opacity", "rgb")}
+t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+cv, cvp, cp = cameras.make_cameras([bench.VIEWS[0]])
+st = R.BatchedRasterizationSettings(H, H, cameras.TAN_HALF_FOV, cameras.TAN_HALF_FOV, torch.ones(3, device=dev), 0.5, t(cv), t(cvp), 0, t(cp), 1)
+L = _cabi.lib()
+L.sgr_debug_seg_trace.restype = C.c_int; L.sgr_debug_seg_trace.argtypes = [C.c_void_p]
+NS, NE = 8, 512
+TILES = (H // 16) ** 2
+buf = torch.zeros(NS * 4 * NE + TILES * 16, dtype=torch.int64, device=dev)
+leaves = [subj[k].clone().requires_grad_(True) for k in ("means3D", "rgb", "opacity", "cov3D")]
+def fwd():
+    return R.rasterize_gaussians_batched(leaves[0], None, None, leaves[1], leaves[2][..., None] if leaves[2].dim() == 2 else leaves[2], None, None, leaves[3], st)
+for _ in range(5): fwd()
+torch.cuda.synchronize()
+assert L.sgr_debug_seg_trace(C.c_void_p(buf.data_ptr())) == 0
+ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+fwd(); torch.cuda.synchronize()
+raw = buf.cpu().numpy().astype(np.uint64)
+b = raw[:NS * 4 * NE].reshape(NS, 4, NE)
+sch = raw[NS * 4 * NE:].reshape(TILES, 4, 4)
+names = {1: "start", 2: "loop", 3: "fill", 4: "phase1", 5: "prefix", 6: "phase2", 7: "book", 8: "done", 9: "written"}
+t00 = None
+for s in range(NS):
+    for q in range(4):
+        n = int(b[s, q, 0])
+        if n < 3: continue
+        info = int(b[s, q, 1]); length, bid = info >> 32, info & 0xFFFFFFFF
+        ev = [(int(x) >> 8, int(x) & 255) for x in b[s, q, 2:n]]
+        if t00 is None: t00 = ev[0][0]
+        tot = {}
+        for (ta, _), (tb, ib) in zip(ev[:-1], ev[1:]):
+            tot[ib] = tot.get(ib, 0) + (tb - ta)
+        rounds = sum(1 for _, i in ev if i == 6)
+        fills = sum(1 for _, i in ev if i == 3)
+        dur = (ev[-1][0] - ev[0][0]) / 100.0
+        print(f"slot {s} q{q} tile {bid:5d} n {length:5d} rounds {rounds:2d}  start +{(ev[0][0] - t00) / 100.0:6.2f} us  total {dur:6.2f} us | " +
+              "  ".join(f"{names[i]} {v / 100.0:5.2f}" for i, v in sorted(tot.items())))
+
+# ---- schedule of ALL workgroups (s_memrealtime, 100 MHz): start / end relative to the first start, XCD / SE / CU from HW_ID
+rows = []
+for sl in range(TILES):
+    for q in range(4):
+        w0, w1, hw, info = (int(x) for x in sch[sl, q])
+        if w0 == 0: continue
+        xcc = (hw >> 32) & 0xF; hwid = hw & 0xFFFFFFFF
+        cu = (hwid >> 8) & 0xF; sh = (hwid >> 12) & 1; se = (hwid >> 13) & 7
+        rows.append((w0, w1, sl, q, info >> 32, xcc, se, sh, cu))
+t0 = min(r[0] for r in rows)
+work = [r for r in rows if r[4] > 0]
+tend = max(r[1] for r in work)
+print(f"workgroups recorded {len(rows)}, working {len(work)}, span of the working ones {(tend - t0) / 100.0:.2f} us")
+print("running working-workgroups over time (2-us bins):", [sum(1 for r in work if r[0] - t0 <= 100 * k * 2 < r[1] - t0) for k in range(0, int((tend - t0) / 200) + 2)])
+import collections
+per_cu = collections.defaultdict(list)
+for r in work: per_cu[(r[5], r[6], r[7], r[8])].append(r)
+print("CUs with working workgroups:", len(per_cu))
+ends = sorted(((max(x[1] for x in v) - t0) / 100.0, k) for k, v in per_cu.items())
+print("last end per CU: min %.1f median %.1f max %.1f us" % (ends[0][0], ends[len(ends) // 2][0], ends[-1][0]))
+for e, k in ends[-4:] + ends[:2]:
+    v = sorted(per_cu[k])
+    print(f"  CU xcc{k[0]} se{k[1]} sh{k[2]} cu{k[3]}: " + "  ".join(f"[slot {x[2]} q{x[3]} n {x[4]} {(x[0] - t0) / 100.0:.1f}-{(x[1] - t0) / 100.0:.1f}]" for x in v))
+starts = sorted((r[0] - t0) / 100.0 for r in work)
+print("start times of working workgroups (us), every 53rd:", [round(x, 1) for x in starts[::53]])
+durs = sorted(((r[1] - r[0]) / 100.0, r[4]) for r in work)
+print("durations (us, n): shortest", durs[:3], "median", durs[len(durs) // 2], "longest", durs[-3:])
