@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SGR_ABI_VERSION 7
+#define SGR_ABI_VERSION 8
 #define SGR_TILE 16                 /* 16x16 pixel tiles, as the published algorithm */
 #define SGR_PART_FLOATS 10          /* floats of a partial gradient record (bucket-parallel backward): 40 B, 8-byte aligned */
 #define SGR_REC_STRIDE 16           /* floats of the packed per-(view,Gaussian) record `rec` (64 B, one cache line) */
@@ -110,6 +110,12 @@ typedef struct SgrForwardState {
     uint64_t off_rec, off_rect, off_clamped, off_block_offsets, off_num_rendered;               /* in geom   */
     uint64_t off_keys_a, off_keys_b, off_vals_a, off_vals_b, off_sort_ws;                        /* in binning */
     uint64_t off_ranges, off_final_T, off_n_contrib, off_compact, off_ckpt_tc, off_ckpt_da, off_desc, off_order, off_flags;   /* in image */
+    /* ABI v8: the single-view fused step (sgr_rasterize_forward_l1 with SgrL1Epilogue.fuse_backward) */
+    uint64_t off_part, off_loss_part;   /* in image: the backward's partial records [4*R_alloc*10] f32, the per-(tile, quadrant) loss shares */
+    int32_t fused_bwd;           /* != 0: the forward call also produced the loss, dL/dcolor and the partial records of the loss's own backward
+                                    (1: bucket backward queued behind the compositing kernel, 2: inside it): sgr_rasterize_backward may be called
+                                    with grad_color = NULL */
+    int32_t reserved1;
 } SgrForwardState;
 
 /*
@@ -139,6 +145,15 @@ int sgr_rasterize_forward(const SgrProblem *pb, uint64_t capacity, int32_t with_
  * gs.py:98-107 + whole_loss.py:126-131): the loss kernel is queued right behind the compositing kernel instead of after a trip back
  * through the caller (at one 512^2 view the host, not the GPU, paces the step).  Return codes as sgr_rasterize_forward; on 2 nothing of
  * the epilogue ran.
+ *
+ * fuse_backward != 0 (ABI v8) allows the FUSED single-view step: when the launch composites with the segment-parallel kernel (<= 2048
+ * tiles: one or two 512^2 views) and records auxiliary outputs (with_aux = 3: no depth/alpha checkpoints), the clamp + masked L1 and its
+ * gradient are evaluated by the compositing workgroups themselves (the loss is pixel-local) -- no loss launch -- and the bucket backward
+ * of dL/dloss = 1 is queued right behind by the same call (or, sgr_set_fused_step(2), run inside the compositing kernel): the forward call
+ * leaves the partial records behind (state->fused_bwd != 0, state->off_part).  sgr_rasterize_backward with grad_color = NULL then only
+ * gathers them, multiplied by *grad_color_scale.  grad_color (dL/dcolor) is still written, so a backward that is handed another upstream
+ * gradient (grad_color != NULL) works as after any forward.  Results: dL/dcolor and (default flavour) the partial records are bit-identical
+ * to the unfused path's; the loss sums are added in a fixed order (no atomics) and so differ from the unfused path's in the last bits only.
  */
 typedef struct SgrL1Epilogue {
     const float *target;          /* [n_views,3,H,W] */
@@ -148,6 +163,8 @@ typedef struct SgrL1Epilogue {
     float *loss_total;            /* [1] or NULL */
     float weight;
     int32_t sums_already_zero;    /* 1: the accumulators are cleared by this very call (caller_clear) or were cleared by the caller */
+    int32_t fuse_backward;        /* see above; 0 = never */
+    int32_t reserved0;
 } SgrL1Epilogue;
 int sgr_rasterize_forward_l1(const SgrProblem *pb, uint64_t capacity, int32_t with_aux, sgr_alloc_fn alloc, void *user,
                              float *out_color, float *out_depth, float *out_alpha, int32_t *out_radii, uint64_t *nr_pinned_host,
@@ -159,6 +176,8 @@ int sgr_rasterize_forward_l1(const SgrProblem *pb, uint64_t capacity, int32_t wi
  * sgr_preprocess_backward.  Needs a forward that ran with with_aux != 0 -- or one that rendered nothing (no visible tile instance:
  * every gradient is then written as zero).  out_color/out_depth/out_alpha are the forward's outputs.  grad_color_scale: optional DEVICE scalar
  * multiplied onto grad_color (the upstream gradient of a fused image loss; saves the caller an elementwise kernel), or NULL.
+ * grad_color = NULL (ABI v8): only after a forward with state->fused_bwd = 1 -- the gradient of that forward's own loss, times
+ * *grad_color_scale (grad_depth / grad_alpha must be NULL).
  */
 int sgr_rasterize_backward(const SgrProblem *pb, const SgrForwardState *state, const int32_t *radii, const float *out_color,
                            const float *out_depth, const float *out_alpha, const float *grad_color, const float *grad_depth,
@@ -233,6 +252,13 @@ int sgr_set_forward_mode(int mode);
  * (view, Gaussian), the per-view contributions added in view order by one thread per Gaussian; otherwise one thread per Gaussian that
  * loops over the views), 1 = always the loop.  Both give bit-identical gradients. */
 int sgr_set_backward_gather(int mode);
+
+/* the fused single-view step of sgr_rasterize_forward_l1 when the epilogue allows it and the launch qualifies (environment SIGMAN_FUSED_STEP):
+ * 1 (default) = loss shares + dL/dcolor inside the compositing kernel, the bucket backward queued right behind it by the forward call (one
+ * launch fewer: no loss kernel; its spare workgroup sums the loss shares); 2 = the bucket backward inside the compositing kernel as well (two
+ * launches fewer; measured slower at C1 / C2: a switch for measurements); 0 = never (A/B, parity tests against the unfused chain).
+ * Thread-local; returns the previous value. */
+int sgr_set_fused_step(int mode);
 
 /* sgr_rasterize_forward*: 0 (default) = when the binning ends in the register per-tile sort, only the point list is stored -- the sorted keys
  * have no reader behind that sort (the tile ranges come from the tile pass); 1 = keep the sorted keys in the binning blob as well

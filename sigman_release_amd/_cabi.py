@@ -35,15 +35,17 @@ class SgrForwardState(C.Structure):
                 ("geom_bytes", C.c_uint64), ("binning_bytes", C.c_uint64), ("image_bytes", C.c_uint64)] + \
                [(n, C.c_uint64) for n in ("off_rec", "off_rect", "off_clamped", "off_block_offsets", "off_num_rendered", "off_keys_a",
                                           "off_keys_b", "off_vals_a", "off_vals_b", "off_sort_ws", "off_ranges", "off_final_T",
-                                          "off_n_contrib", "off_compact", "off_ckpt_tc", "off_ckpt_da", "off_desc", "off_order", "off_flags")]
+                                          "off_n_contrib", "off_compact", "off_ckpt_tc", "off_ckpt_da", "off_desc", "off_order", "off_flags",
+                                          "off_part", "off_loss_part")] + \
+               [("fused_bwd", C.c_int32), ("reserved1", C.c_int32)]
 
 
 class SgrL1Epilogue(C.Structure):
     _fields_ = [("target", C.c_void_p), ("mask", C.c_void_p), ("grad_color", C.c_void_p), ("loss_per_view", C.c_void_p),
-                ("loss_total", C.c_void_p), ("weight", C.c_float), ("sums_already_zero", C.c_int32)]
+                ("loss_total", C.c_void_p), ("weight", C.c_float), ("sums_already_zero", C.c_int32), ("fuse_backward", C.c_int32), ("reserved0", C.c_int32)]
 
 
-ABI_VERSION = 7          # include/sigman_gsplat.h: SGR_ABI_VERSION
+ABI_VERSION = 8          # include/sigman_gsplat.h: SGR_ABI_VERSION
 ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_int32, C.c_size_t)
 
 _SIGNATURES = {
@@ -68,6 +70,7 @@ _SIGNATURES = {
     "sgr_set_backward_gather": (C.c_int, [C.c_int]),
     "sgr_set_preprocess_view_group": (C.c_int, [C.c_int]),
     "sgr_set_keep_sorted_keys": (C.c_int, [C.c_int]),
+    "sgr_set_fused_step": (C.c_int, [C.c_int]),
     "sgr_set_debug": (C.c_int, [C.c_int]),
     "sgr_set_sort_mode": (C.c_int, [C.c_int]),
     "sgr_set_sort_deep": (C.c_int, [C.c_int]),

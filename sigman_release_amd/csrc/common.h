@@ -58,6 +58,36 @@ struct SgrProfScope {
     ~SgrProfScope() { sgr_prof_end(slot, s); }
 };
 
+// the single-view fused step (render.hip: FusedL1; rasterize.hip fills it from SgrL1Epilogue + the image blob)
+struct SgrFusedL1Args {
+    const float *target, *mask;
+    float weight;
+    float *gimg, *loss_part, *loss_per_view, *loss_total;
+    const uint32_t *rect;
+    float *part;
+    uint32_t *flags;
+    int backward_inside;        // 1: the compositing kernel also runs its workgroups' own bucket backward (AUX == 4); 0: loss shares + dL/dcolor only
+};
+
+// The EMPTY tiles of a one- or two-view launch (812 of the 1024 tiles of a 512^2 humanoid view) only receive the background -- and, in the
+// fused step, contribute the background's loss share and dL/dcolor.  None of that depends on the Gaussians, so in the fused step EVERY tile
+// is pre-filled with it by extra workgroups of an early launch that leaves the chip idle (the row scan of the single wide tile pass: 32
+// workgroups, 5 us); the compositing kernel overwrites the occupied tiles and its empty-tile workgroups leave at once -- instead of 812 of
+// them trickling through its tail, each living through a load round trip (C2: 3.8 us).  Measured alternatives: idle workgroups of the
+// per-tile sort launch (knows the ranges, fills only the empty tiles): that launch 10.3 -> 13.7 us; extra workgroups of the preprocess
+// launch: 7.4 -> 8.5 us (the fill's 14 MB compete with its streams); without the loss the compositing kernel's own empty-tile path costs 0.2 us.
+struct SgrBgJob {
+    int enabled, W, H, Tx;
+    uint32_t tiles_per_view, tiles_total;
+    const float *bg;
+    float *out_color, *out_depth, *out_alpha, *final_T;
+    uint32_t *n_contrib;
+    float *clamped;                 // optional (SgrProblem.color_clamped)
+    const float *target, *mask;     // target == NULL: no loss
+    float weight;
+    float *gimg, *loss_part;
+};
+
 // ---------------------------------------------------------------------------------------------
 // device helpers
 // ---------------------------------------------------------------------------------------------
@@ -136,6 +166,43 @@ __device__ __forceinline__ void sgr_fwd_prepare(const uint2 *__restrict__ ranges
     for (uint32_t tile = t; tile < tiles_total; tile += nt) {
         const uint2 r = ranges[tile];
         order[1u + atomicAdd(&sCur[r.y > r.x ? 31u - min(31u, (r.y - r.x) >> 7) : 32u], 1u)] = tile;
+    }
+}
+
+// Background (and, fused step, loss share + dL/dcolor) of the tiles bid = group, group + n_groups, ...; called by whole groups of 256
+// threads (4 waves; a tile's 256 pixels; wave w's loss sum goes to the loss slot of quadrant w -- render.hip's own empty-tile path writes the same).
+__device__ __forceinline__ void sgr_bg_fill(const SgrBgJob &j, uint32_t group, uint32_t n_groups) {
+    const uint32_t t = threadIdx.x & 255u, wv = t >> 6;
+    const size_t hw = (size_t)j.H * j.W;
+    for (uint32_t bid = group; bid < j.tiles_total; bid += n_groups) {
+        const uint32_t view = bid / j.tiles_per_view, tile = bid - view * j.tiles_per_view;
+        const int bx = (int)(tile % (uint32_t)j.Tx) * 16 + (int)(t & 15u), by = (int)(tile / (uint32_t)j.Tx) * 16 + (int)(t >> 4);
+        const bool in = bx < j.W && by < j.H;
+        const size_t pix = (size_t)by * j.W + bx, vb = (size_t)view * hw;
+        float lsum = 0.f;
+        if (in) {
+            const float b[3] = {j.bg[0], j.bg[1], j.bg[2]};
+            j.final_T[vb + pix] = 1.f;
+            j.n_contrib[vb + pix] = 0u;
+            j.out_depth[vb + pix] = 0.f;
+            j.out_alpha[vb + pix] = 0.f;
+            const float m = (j.target && j.mask) ? j.mask[vb + pix] : 1.f;
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                j.out_color[vb * 3 + (size_t)c * hw + pix] = b[c];
+                if (j.clamped) j.clamped[vb * 3 + (size_t)c * hw + pix] = fminf(fmaxf(b[c], 0.f), 1.f);
+                if (j.target) {
+                    const float d = (fminf(fmaxf(b[c], 0.f), 1.f) - j.target[vb * 3 + (size_t)c * hw + pix]) * m;
+                    lsum += fabsf(d);
+                    const float sg = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+                    j.gimg[vb * 3 + (size_t)c * hw + pix] = (b[c] >= 0.f && b[c] <= 1.f) ? j.weight * m * sg : 0.f;
+                }
+            }
+        }
+        if (j.target) {
+            lsum = sgr_wave_sum(lsum);
+            if ((t & 63u) == 0u) j.loss_part[(size_t)bid * 4 + wv] = j.weight * lsum;
+        }
     }
 }
 

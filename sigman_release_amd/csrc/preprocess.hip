@@ -13,6 +13,7 @@
 // Gaussian per view forward, ~150 B backward); one thread per Gaussian, view index on blockIdx.y so
 // the camera matrices are wave-uniform scalar loads.
 #include <atomic>
+#include <string.h>
 #include "common.h"
 
 namespace {
@@ -467,7 +468,8 @@ template <bool SH>
 __device__ __forceinline__ void bwd_view(const SgrProblem &pb, int view, int i, size_t sp, const float (&p)[3], const float (&c6)[6], float fx, float fy,
                                          const int32_t *__restrict__ radii, const uint8_t *__restrict__ clamped,
                                          const uint4 *__restrict__ rect, const float4 *__restrict__ part, const uint32_t *__restrict__ flags,
-                                         uint32_t n_inst, float *__restrict__ dL_dmeans2D, float *__restrict__ dL_dsh, ViewGrad &out) {
+                                         uint32_t n_inst, const float *__restrict__ part_scale, float *__restrict__ dL_dmeans2D, float *__restrict__ dL_dsh,
+                                         ViewGrad &out) {
 #pragma unroll
     for (int k = 0; k < 3; k++) { out.mean[k] = 0.f; out.col[k] = 0.f; }
 #pragma unroll
@@ -510,6 +512,11 @@ __device__ __forceinline__ void bwd_view(const SgrProblem &pb, int view, int i, 
                 }
             }
             f = fn;
+        }
+        if (part_scale) {
+            // the partial records of a fused rasterize + loss step are for dL/dloss = 1: everything below is linear in the ten sums
+            const float sc = *part_scale;
+            g0.x *= sc; g0.y *= sc; g0.z *= sc; g0.w *= sc; g1.x *= sc; g1.y *= sc; g1.z *= sc; g1.w *= sc; g2.x *= sc; g2.y *= sc;
         }
     }
     const float *V = pb.viewmatrix + 16 * (size_t)view;
@@ -652,6 +659,7 @@ __device__ __forceinline__ void bwd_finish(const SgrProblem &pb, size_t sp, cons
 #define SGR_BWD_ARGS                                                                                                              \
     SgrProblem pb, const int32_t *__restrict__ radii, const uint8_t *__restrict__ clamped,                                          \
     const uint4 *__restrict__ rect, const float4 *__restrict__ part, const uint32_t *__restrict__ flags, uint32_t n_inst,          \
+    const float *__restrict__ part_scale,                                                                                           \
     float *__restrict__ dL_dmeans3D, float *__restrict__ dL_dmeans2D, float *__restrict__ dL_dopacity,                              \
     float *__restrict__ dL_dcolors, float *__restrict__ dL_dsh, float *__restrict__ dL_dcov3D, float *__restrict__ dL_dscales,      \
     float *__restrict__ dL_drot
@@ -674,7 +682,7 @@ __global__ __launch_bounds__(kPreThreads) void preprocess_bwd_kernel(SGR_BWD_ARG
     const int v0 = subj * pb.views_per_subject;
     for (int vv = 0; vv < pb.views_per_subject; vv++) {
         ViewGrad g;
-        bwd_view<SH>(pb, v0 + vv, i, sp, p, c6, fx, fy, radii, clamped, rect, part, flags, n_inst, dL_dmeans2D, dL_dsh, g);
+        bwd_view<SH>(pb, v0 + vv, i, sp, p, c6, fx, fy, radii, clamped, rect, part, flags, n_inst, part_scale, dL_dmeans2D, dL_dsh, g);
 #pragma unroll
         for (int k = 0; k < 6; k++) gcov[k] += g.cov[k];
         if (!SH) { gcol[0] += g.col[0]; gcol[1] += g.col[1]; gcol[2] += g.col[2]; }
@@ -699,7 +707,7 @@ __global__ __launch_bounds__(kPreThreads) __attribute__((amdgpu_waves_per_eu(5))
         const float p[3] = {pb.means3D[sp * 3 + 0], pb.means3D[sp * 3 + 1], pb.means3D[sp * 3 + 2]};
         float c6[6];
         load_cov3d(pb, sp, c6);
-        bwd_view<false>(pb, subj * vps + vv, i, sp, p, c6, fx, fy, radii, clamped, rect, part, flags, n_inst, dL_dmeans2D, dL_dsh, g);
+        bwd_view<false>(pb, subj * vps + vv, i, sp, p, c6, fx, fy, radii, clamped, rect, part, flags, n_inst, part_scale, dL_dmeans2D, dL_dsh, g);
 #pragma unroll
         for (int k = 0; k < 3; k++) { acc[k][t] = g.mean[k]; acc[10 + k][t] = g.col[k]; }
 #pragma unroll
@@ -811,7 +819,7 @@ extern "C" int sgr_set_backward_gather(int mode) { g_bwd_view_loop.store(mode ==
 int sgr_preprocess_backward_ex(const SgrProblem *pb, const int32_t *radii, const uint8_t *clamped,
                                const uint32_t *rect, const float *part, const uint32_t *flags, uint64_t n_inst, float *dL_dmeans3D, float *dL_dmeans2D,
                                float *dL_dopacity, float *dL_dcolors, float *dL_dsh, float *dL_dcov3D, float *dL_dscales, float *dL_drotations,
-                               void *stream_) {
+                               const float *part_scale /* optional device scalar on the gathered sums (the fused step's upstream dL/dloss) */, void *stream_) {
     if (validate_problem(pb)) return 1;
     if (pb->P == 0) return 0;
     if (!(part && flags && rect)) { sgr_set_error("sgr_preprocess_backward: need rect + part + flags"); return 1; }
@@ -824,16 +832,16 @@ int sgr_preprocess_backward_ex(const SgrProblem *pb, const int32_t *radii, const
     { SgrProfScope _p(SGR_K_PREPROCESS_BWD, stream);
     if (pb->shs)
         hipLaunchKernelGGL(preprocess_bwd_kernel<true>, grid, dim3(kPreThreads), 0, stream, *pb, radii, clamped,
-                           (const uint4 *)rect, (const float4 *)part, flags, (uint32_t)(n_inst > 0xFFFFFFFFull ? 0xFFFFFFFFull : n_inst), dL_dmeans3D, dL_dmeans2D, dL_dopacity, dL_dcolors, dL_dsh, dL_dcov3D, dL_dscales, dL_drotations);
+                           (const uint4 *)rect, (const float4 *)part, flags, (uint32_t)(n_inst > 0xFFFFFFFFull ? 0xFFFFFFFFull : n_inst), part_scale, dL_dmeans3D, dL_dmeans2D, dL_dopacity, dL_dcolors, dL_dsh, dL_dcov3D, dL_dscales, dL_drotations);
     else if (pb->views_per_subject > 1 && pb->views_per_subject <= kPreThreads && kPreThreads % pb->views_per_subject == 0 && !g_bwd_view_loop.load()) {
         const int gpb = kPreThreads / pb->views_per_subject;
         hipLaunchKernelGGL(preprocess_bwd_lanes_kernel, dim3((pb->P + gpb - 1) / gpb, pb->n_views / pb->views_per_subject), dim3(kPreThreads), 0, stream, *pb,
                            radii, clamped, (const uint4 *)rect, (const float4 *)part, flags,
-                           (uint32_t)(n_inst > 0xFFFFFFFFull ? 0xFFFFFFFFull : n_inst), dL_dmeans3D, dL_dmeans2D, dL_dopacity, dL_dcolors, dL_dsh, dL_dcov3D,
+                           (uint32_t)(n_inst > 0xFFFFFFFFull ? 0xFFFFFFFFull : n_inst), part_scale, dL_dmeans3D, dL_dmeans2D, dL_dopacity, dL_dcolors, dL_dsh, dL_dcov3D,
                            dL_dscales, dL_drotations);
     } else
         hipLaunchKernelGGL(preprocess_bwd_kernel<false>, grid, dim3(kPreThreads), 0, stream, *pb, radii, clamped,
-                           (const uint4 *)rect, (const float4 *)part, flags, (uint32_t)(n_inst > 0xFFFFFFFFull ? 0xFFFFFFFFull : n_inst), dL_dmeans3D, dL_dmeans2D, dL_dopacity, dL_dcolors, dL_dsh, dL_dcov3D, dL_dscales, dL_drotations);
+                           (const uint4 *)rect, (const float4 *)part, flags, (uint32_t)(n_inst > 0xFFFFFFFFull ? 0xFFFFFFFFull : n_inst), part_scale, dL_dmeans3D, dL_dmeans2D, dL_dopacity, dL_dcolors, dL_dsh, dL_dcov3D, dL_dscales, dL_drotations);
     SGR_CHECK_LAUNCH("preprocess_bwd_kernel");
     }
     return 0;
@@ -844,7 +852,7 @@ extern "C" int sgr_preprocess_backward(const SgrProblem *pb, const int32_t *radi
                                        float *dL_dsh, float *dL_dcov3D, float *dL_dscales, float *dL_drotations,
                                        void *stream_) {
     return sgr_preprocess_backward_ex(pb, radii, clamped, rect, part, flags, ~0ull, dL_dmeans3D, dL_dmeans2D, dL_dopacity, dL_dcolors, dL_dsh,
-                                      dL_dcov3D, dL_dscales, dL_drotations, stream_);
+                                      dL_dcov3D, dL_dscales, dL_drotations, nullptr, stream_);
 }
 
 extern "C" int sgr_mark_visible(int32_t P, const float *means3D, const float *viewmatrix, uint8_t *present, void *stream_) {

@@ -17,6 +17,11 @@ inline uint64_t align_up(uint64_t v, uint64_t a = 256) { return (v + a - 1) / a 
 
 // 0 (default): a fused forward whose binning ends in the register per-tile sort stores only the point list -- the sorted keys have no
 // reader behind that sort (the tile ranges come from the tile pass); 1: keep them (forward_debug / the parity tests look at them)
+// the single-view fused step (SgrL1Epilogue.fuse_backward) when the launch qualifies: 0 = never (A/B, tests), 1 (default) = loss + dL/dcolor inside the
+// compositing kernel and the bucket backward queued behind it by the forward call, 2 = that backward inside the compositing kernel too: SIGMAN_FUSED_STEP
+static thread_local int g_fused_step = sgr_env_knob("SIGMAN_FUSED_STEP", 0, 2, 1);
+extern "C" int sgr_set_fused_step(int mode) { const int old = g_fused_step; g_fused_step = (mode >= 0 && mode <= 2) ? mode : 1; return old; }
+static int sgr_fused_step_enabled() { return g_fused_step; }
 static thread_local int g_keep_sorted_keys = 0;     // thread-local like sgr_set_debug: forward_debug() toggles it around ONE call
 extern "C" int sgr_set_keep_sorted_keys(int keep) { const int old = g_keep_sorted_keys; g_keep_sorted_keys = keep ? 1 : 0; return old; }
 int sgr_preprocess_forward_ex(const SgrProblem *pb, float *rec, int32_t *radii, uint32_t *rect, uint8_t *clamped, uint32_t *block_offsets,
@@ -25,25 +30,28 @@ int sgr_bin_ex(const SgrProblem *pb, const int32_t *radii, uint32_t *rect, const
                const uint64_t *num_rendered_dev, uint64_t *keys_a, uint64_t *keys_b, uint32_t *vals_a, uint32_t *vals_b, void *workspace,
                size_t workspace_bytes, uint32_t *ranges, int32_t *result_in_b_host, bool self_scan, uint64_t *nr_host, void *prep_desc,
                size_t prep_n_desc, uint32_t *prep_order, int *prep_done, uint32_t *const *clear_ptr, const uint64_t *clear_words,
-               int *clear_done, bool first_index, bool sorted_keys, void *stream_);
+               int *clear_done, bool first_index, bool sorted_keys, const SgrBgJob *bg_job, int *bg_done, void *stream_);
 int sgr_render_backward_ex(const SgrProblem *pb, const uint32_t *ranges, const float *rec, const uint32_t *rect,
                            const uint32_t *n_contrib, const float *out_color, const float *out_depth, const float *out_alpha,
                            const float *grad_color, const float *grad_depth, const float *grad_alpha, const float *grad_color_scale,
                            uint64_t R, const void *aux_compact, const void *aux_ckpt_tc, const void *aux_ckpt_da, const void *aux_desc,
-                           float *part, uint32_t *flags, bool flags_cleared, void *stream_);
+                           float *part, uint32_t *flags, bool flags_cleared, const SgrFusedL1Args *loss_reduce, void *stream_);
 int sgr_preprocess_backward_ex(const SgrProblem *pb, const int32_t *radii, const uint8_t *clamped, const uint32_t *rect,
                                const float *part, const uint32_t *flags, uint64_t n_inst, float *dL_dmeans3D, float *dL_dmeans2D, float *dL_dopacity,
-                               float *dL_dcolors, float *dL_dsh, float *dL_dcov3D, float *dL_dscales, float *dL_drotations, void *stream_);
+                               float *dL_dcolors, float *dL_dsh, float *dL_dcov3D, float *dL_dscales, float *dL_drotations,
+                               const float *part_scale, void *stream_);
 int sgr_render_forward_wants_prepare(const SgrProblem *pb, uint64_t R, bool use_aux, size_t *n_desc_out);
 int sgr_render_forward_ex(const SgrProblem *pb, const uint32_t *ranges, const uint32_t *point_list, const float *rec, float *out_color,
                           float *out_depth, float *out_alpha, float *final_T, uint32_t *n_contrib, uint64_t R, void *aux_compact,
-                          void *aux_ckpt_tc, void *aux_ckpt_da, void *aux_desc, uint32_t *aux_order, bool prepared, int kind, void *stream_);
+                          void *aux_ckpt_tc, void *aux_ckpt_da, void *aux_desc, uint32_t *aux_order, bool prepared, int kind,
+                          const SgrFusedL1Args *fused, bool bg_done, void *stream_);
 int sgr_render_forward_kind(const SgrProblem *pb);
 int sgr_get_forward_mode();
 
 static int forward_launches(const SgrProblem *pb, uint64_t capacity, uint64_t R, SgrForwardState *st, float *out_color, float *out_depth,
                             float *out_alpha, int32_t *out_radii, uint64_t *nr_pinned_host, bool preprocess_done, void *caller_clear,
-                            uint64_t caller_clear_bytes, hipStream_t stream) {
+                            uint64_t caller_clear_bytes, const SgrL1Epilogue *l1 /* st->fused_bwd: the epilogue the compositing kernel absorbs */,
+                            hipStream_t stream) {
     char *geom = (char *)st->geom, *binning = (char *)st->binning, *image = (char *)st->image;
     float *rec = (float *)(geom + st->off_rec);
     uint32_t *rect = (uint32_t *)(geom + st->off_rect);
@@ -54,6 +62,20 @@ static int forward_launches(const SgrProblem *pb, uint64_t capacity, uint64_t R,
     // caller's pinned slot are folded into the duplicate kernel (three launches fewer)
     const uint64_t nblk = (uint64_t)sgr_preprocess_blocks_per_view(pb->P) * pb->n_views;
     const bool self_scan = !preprocess_done && capacity > 0 && nblk <= 2048;
+    // the fused step: every tile is pre-filled with the background, its loss shares and dL/dcolor by extra workgroups of an early launch of the
+    // binning (bg_done says whether the flavour had room for it; common.h SgrBgJob); the compositing kernel's empty tiles then have nothing to do
+    SgrBgJob bgj;
+    memset(&bgj, 0, sizeof(bgj));
+    int bg_done = 0;
+    if (st->fused_bwd) {
+        bgj.enabled = 1; bgj.W = pb->W; bgj.H = pb->H; bgj.Tx = (pb->W + SGR_TILE - 1) / SGR_TILE;
+        bgj.tiles_per_view = (uint32_t)bgj.Tx * (uint32_t)((pb->H + SGR_TILE - 1) / SGR_TILE);
+        bgj.tiles_total = bgj.tiles_per_view * (uint32_t)pb->n_views;
+        bgj.bg = pb->bg; bgj.out_color = out_color; bgj.out_depth = out_depth; bgj.out_alpha = out_alpha;
+        bgj.final_T = (float *)(image + st->off_final_T); bgj.n_contrib = (uint32_t *)(image + st->off_n_contrib); bgj.clamped = pb->color_clamped;
+        if (st->fused_bwd) { bgj.target = l1->target; bgj.mask = l1->mask; bgj.weight = l1->weight; bgj.gimg = l1->grad_color;
+                             bgj.loss_part = (float *)(image + st->off_loss_part); }
+    }
     if (!preprocess_done) {
         if (sgr_preprocess_forward_ex(pb, rec, out_radii, rect, clamped, block_offsets, num_rendered, capacity, self_scan, stream)) return 1;
         if (nr_pinned_host && !self_scan) SGR_CHECK_HIP(hipMemcpyAsync(nr_pinned_host, num_rendered + 2, 8, hipMemcpyDeviceToHost, stream));   // count | overflow << 63
@@ -75,23 +97,42 @@ static int forward_launches(const SgrProblem *pb, uint64_t capacity, uint64_t R,
                    binning + st->off_sort_ws, (size_t)sgr_bin_workspace_bytes(R, (uint64_t)((pb->W + SGR_TILE - 1) / SGR_TILE) * ((pb->H + SGR_TILE - 1) / SGR_TILE) * pb->n_views),
                    (uint32_t *)(image + st->off_ranges), &in_b, self_scan, self_scan ? nr_pinned_host : nullptr,
                    want_prep && aux_on ? image + st->off_desc : nullptr, n_desc, want_prep ? (uint32_t *)(image + st->off_order) : nullptr,
-                   &prep_done, clear_ptr, clear_words, clear_done, /*first_index=*/aux_on, /*sorted_keys=*/g_keep_sorted_keys != 0, stream)) return 1;
+                   &prep_done, clear_ptr, clear_words, clear_done, /*first_index=*/aux_on, /*sorted_keys=*/g_keep_sorted_keys != 0, bgj.enabled ? &bgj : nullptr, &bg_done, stream)) return 1;
     st->flags_cleared = clear_done[0];
     if (caller_clear && caller_clear_bytes && !clear_done[1]) SGR_CHECK_HIP(hipMemsetAsync(caller_clear, 0, (size_t)caller_clear_bytes, stream));
     st->result_in_b = in_b;
     const uint32_t *point_list = (const uint32_t *)(binning + (in_b ? st->off_vals_b : st->off_vals_a));
     st->fwd_kind = sgr_render_forward_kind(pb);
-    return sgr_render_forward_ex(pb, (const uint32_t *)(image + st->off_ranges), point_list, rec, out_color, out_depth, out_alpha,
+    SgrFusedL1Args fa;
+    if (st->fused_bwd) {
+        // the fused kernel's backward writes the flags of the survivors it looks at: the rest must be clear before it starts
+        if (!st->flags_cleared) { SGR_CHECK_HIP(hipMemsetAsync(image + st->off_flags, 0, (size_t)R * 4, stream)); st->flags_cleared = 1; }
+        fa.target = l1->target; fa.mask = l1->mask; fa.weight = l1->weight; fa.gimg = l1->grad_color;
+        fa.loss_part = (float *)(image + st->off_loss_part); fa.loss_per_view = l1->loss_per_view; fa.loss_total = l1->loss_total;
+        fa.rect = rect; fa.part = (float *)(image + st->off_part); fa.flags = (uint32_t *)(image + st->off_flags);
+        fa.backward_inside = st->fused_bwd == 2 ? 1 : 0;
+    }
+    const int rc = sgr_render_forward_ex(pb, (const uint32_t *)(image + st->off_ranges), point_list, rec, out_color, out_depth, out_alpha,
                               (float *)(image + st->off_final_T), (uint32_t *)(image + st->off_n_contrib), R,
                               aux_on ? image + st->off_compact : nullptr, aux_on ? image + st->off_ckpt_tc : nullptr,
                               (aux_on && !st->aux_no_da) ? image + st->off_ckpt_da : nullptr, aux_on ? image + st->off_desc : nullptr,
-                              (uint32_t *)(image + st->off_order), prep_done != 0, st->fwd_kind, stream);
+                              (uint32_t *)(image + st->off_order), prep_done != 0, st->fwd_kind, st->fused_bwd ? &fa : nullptr, bg_done != 0, stream);
+    if (rc || st->fused_bwd != 1) return rc;
+    // fused step, flavour 1: the compositing kernel left the loss shares and dL/dcolor; the bucket backward of dL/dloss = 1 follows at once
+    // (its spare workgroup sums the loss shares), so that the caller's backward only gathers
+    SgrProblem pbb = *pb;
+    pbb.clamp_grad = 0;                    // (the loss has its own clamp; dL/dcolor is w.r.t. the unclamped colour)
+    return sgr_render_backward_ex(&pbb, (const uint32_t *)(image + st->off_ranges), rec, rect, (const uint32_t *)(image + st->off_n_contrib), out_color,
+                                  out_depth, out_alpha, l1->grad_color, nullptr, nullptr, nullptr, R, image + st->off_compact, image + st->off_ckpt_tc, nullptr,
+                                  image + st->off_desc, fa.part, fa.flags, /*flags_cleared=*/true, &fa, stream);
 }
 
-extern "C" int sgr_rasterize_forward(const SgrProblem *pb, uint64_t capacity, int32_t with_aux, sgr_alloc_fn alloc, void *user,
-                                     float *out_color, float *out_depth, float *out_alpha, int32_t *out_radii,
-                                     uint64_t *nr_pinned_host, void *nr_event, void *caller_clear, uint64_t caller_clear_bytes,
-                                     SgrForwardState *st, void *stream_) {
+// l1 != NULL with l1->fuse_backward: the caller is sgr_rasterize_forward_l1 and allows the single-view FUSED step (render.hip, FusedL1) --
+// taken when the launch uses the segment-parallel kernel and records auxiliary outputs without depth/alpha checkpoints; st->fused_bwd tells
+static int rasterize_forward_impl(const SgrProblem *pb, uint64_t capacity, int32_t with_aux, sgr_alloc_fn alloc, void *user,
+                                  float *out_color, float *out_depth, float *out_alpha, int32_t *out_radii,
+                                  uint64_t *nr_pinned_host, void *nr_event, void *caller_clear, uint64_t caller_clear_bytes,
+                                  SgrForwardState *st, const SgrL1Epilogue *l1, void *stream_) {
     if (!pb || !st || !out_color || !out_depth || !out_alpha || (!out_radii && pb->P > 0)) { sgr_set_error("sgr_rasterize_forward: NULL argument"); return 1; }
     // alloc == NULL: the caller pre-allocated the three blobs (state->geom / binning / image with their *_bytes capacities, e.g. from the
     // sizes a previous call with the same shapes reported): no callbacks.  A blob that is too small -> return 2 with the needed sizes in
@@ -175,6 +216,11 @@ extern "C" int sgr_rasterize_forward(const SgrProblem *pb, uint64_t capacity, in
         st->off_ckpt_tc = o; o = align_up(o + 4 * NS * rows * 64 * 16);
         st->off_ckpt_da = o; o = align_up(o + (st->aux_no_da ? 0 : 4 * NS * rows * 64 * 8));
         st->off_desc = o; o = align_up(o + 4 * NS * 8);
+        if (l1 && l1->fuse_backward && st->aux_no_da && sgr_render_forward_kind(pb) == 2 && sgr_fused_step_enabled()) {
+            st->fused_bwd = sgr_fused_step_enabled();     // 1: loss inside the compositing kernel, bucket backward queued behind; 2: that backward inside as well
+            st->off_part = o; o = align_up(o + R * 4 * SGR_PART_FLOATS * 4);        // the backward's partial records are written by the forward's launch
+            st->off_loss_part = o; o = align_up(o + tiles_total * 4 * 4);
+        }
     }
     st->image_bytes = o;
     char *image = get_blob(2, o);
@@ -182,11 +228,19 @@ extern "C" int sgr_rasterize_forward(const SgrProblem *pb, uint64_t capacity, in
     st->image = image;
 
     if (forward_launches(pb, capacity, R, st, out_color, out_depth, out_alpha, out_radii, capacity > 0 ? nr_pinned_host : nullptr,
-                         preprocess_done, caller_clear, caller_clear_bytes, stream)) return 1;
+                         preprocess_done, caller_clear, caller_clear_bytes, l1, stream)) return 1;
     // (the event is only needed when the count travels by an asynchronous copy; a kernel's own 8-byte store is polled, and an event
     // record between the compositing kernel and whatever the caller queues next is a ~5 us bubble on the GPU)
     if (capacity > 0 && nr_event && st->nr_by_copy) SGR_CHECK_HIP(hipEventRecord((hipEvent_t)nr_event, stream));
     return 0;
+}
+
+extern "C" int sgr_rasterize_forward(const SgrProblem *pb, uint64_t capacity, int32_t with_aux, sgr_alloc_fn alloc, void *user,
+                                     float *out_color, float *out_depth, float *out_alpha, int32_t *out_radii,
+                                     uint64_t *nr_pinned_host, void *nr_event, void *caller_clear, uint64_t caller_clear_bytes,
+                                     SgrForwardState *st, void *stream_) {
+    return rasterize_forward_impl(pb, capacity, with_aux, alloc, user, out_color, out_depth, out_alpha, out_radii, nr_pinned_host, nr_event,
+                                  caller_clear, caller_clear_bytes, st, nullptr, stream_);
 }
 
 extern "C" int sgr_clamped_l1_loss(int32_t n_views, int32_t H, int32_t W, const float *color, const float *target, const float *mask, float weight,
@@ -197,9 +251,10 @@ extern "C" int sgr_rasterize_forward_l1(const SgrProblem *pb, uint64_t capacity,
                                         uint64_t *nr_pinned_host, void *nr_event, void *caller_clear, uint64_t caller_clear_bytes,
                                         SgrForwardState *st, const SgrL1Epilogue *l1, void *stream_) {
     if (!l1 || !l1->target || !l1->grad_color || !l1->loss_per_view) { sgr_set_error("sgr_rasterize_forward_l1: NULL epilogue argument"); return 1; }
-    const int rc = sgr_rasterize_forward(pb, capacity, with_aux, alloc, user, out_color, out_depth, out_alpha, out_radii, nr_pinned_host, nr_event,
-                                         caller_clear, caller_clear_bytes, st, stream_);
+    const int rc = rasterize_forward_impl(pb, capacity, with_aux, alloc, user, out_color, out_depth, out_alpha, out_radii, nr_pinned_host, nr_event,
+                                          caller_clear, caller_clear_bytes, st, l1, stream_);
     if (rc) return rc;
+    if (st->fused_bwd) return 0;               // loss, dL/dcolor and the compositing backward ran inside the compositing kernel
     return sgr_clamped_l1_loss(pb->n_views, pb->H, pb->W, out_color, l1->target, l1->mask, l1->weight, l1->grad_color, l1->loss_per_view,
                                l1->loss_total, l1->sums_already_zero, stream_);
 }
@@ -230,6 +285,18 @@ extern "C" int sgr_rasterize_backward(const SgrProblem *pb, const SgrForwardStat
         if (dL_drotations && pb->scales) SGR_CHECK_HIP(hipMemsetAsync(dL_drotations, 0, ns * 4 * 4, stream));
         return 0;
     }
+    const char *geom = (const char *)st->geom, *binning = (const char *)st->binning, *image = (const char *)st->image;
+    const float *rec = (const float *)(geom + st->off_rec);
+    const uint32_t *rect = (const uint32_t *)(geom + st->off_rect);
+    if (!grad_color) {
+        // a FUSED forward (st->fused_bwd) already ran the compositing backward for ITS OWN loss: what is left is the gather, with the upstream
+        // scalar dL/dloss (grad_color_scale, NULL = 1) multiplied onto the gathered sums -- every gradient is linear in them
+        if (!st->fused_bwd) { sgr_set_error("sgr_rasterize_backward: grad_color is NULL but the forward was not a fused rasterize + L1 step"); return 1; }
+        if (grad_depth || grad_alpha) { sgr_set_error("sgr_rasterize_backward: the fused step's own backward has no dL/ddepth / dL/dalpha: pass grad_color"); return 1; }
+        return sgr_preprocess_backward_ex(pb, radii, pb->shs ? (const uint8_t *)(geom + st->off_clamped) : nullptr, rect, (const float *)(image + st->off_part),
+                                          (const uint32_t *)(image + st->off_flags), st->R_alloc, dL_dmeans3D, dL_dmeans2D, dL_dopacity, dL_dcolors, dL_dsh,
+                                          dL_dcov3D, dL_dscales, dL_drotations, grad_color_scale, stream_);
+    }
     // scratch: partial records [4*R][10] f32 (the flags [R] u32 live in the forward's image blob)
     const uint64_t part_bytes = align_up(st->R_alloc * 4 * SGR_PART_FLOATS * 4);
     // depth / alpha gradients on a forward that left their checkpoints out: room for them in the scratch blob, filled by a second
@@ -240,9 +307,6 @@ extern "C" int sgr_rasterize_backward(const SgrProblem *pb, const SgrForwardStat
     if (!scratch) { sgr_set_error("scratch allocator returned NULL"); return 1; }
     float *part = (float *)scratch;
     uint32_t *flags = (uint32_t *)((char *)st->image + st->off_flags);
-    const char *geom = (const char *)st->geom, *binning = (const char *)st->binning, *image = (const char *)st->image;
-    const float *rec = (const float *)(geom + st->off_rec);
-    const uint32_t *rect = (const uint32_t *)(geom + st->off_rect);
     const void *ckpt_da = !st->aux_no_da ? image + st->off_ckpt_da : nullptr;
     if (da_refill) {
         char *im = (char *)st->image;
@@ -250,15 +314,15 @@ extern "C" int sgr_rasterize_backward(const SgrProblem *pb, const SgrForwardStat
         const uint32_t *point_list = (const uint32_t *)(binning + (st->result_in_b ? st->off_vals_b : st->off_vals_a));
         if (sgr_render_forward_ex(pb, (const uint32_t *)(image + st->off_ranges), point_list, rec, (float *)out_color, (float *)out_depth, (float *)out_alpha,
                                   (float *)(im + st->off_final_T), (uint32_t *)(im + st->off_n_contrib), st->R_alloc, im + st->off_compact, nullptr, da,
-                                  im + st->off_desc, (uint32_t *)(im + st->off_order), /*prepared=*/true, st->fwd_kind, stream_)) return 1;
+                                  im + st->off_desc, (uint32_t *)(im + st->off_order), /*prepared=*/true, st->fwd_kind, nullptr, false, stream_)) return 1;
         ckpt_da = da;
     }
     if (sgr_render_backward_ex(pb, (const uint32_t *)(image + st->off_ranges), rec, rect, (const uint32_t *)(image + st->off_n_contrib),
                                out_color, out_depth, out_alpha, grad_color, grad_depth, grad_alpha, grad_color_scale, st->R_alloc,
                                image + st->off_compact, image + st->off_ckpt_tc, ckpt_da, image + st->off_desc, part, flags,
-                               st->flags_cleared != 0, stream_))
+                               st->flags_cleared != 0, nullptr, stream_))
         return 1;
     return sgr_preprocess_backward_ex(pb, radii, pb->shs ? (const uint8_t *)(geom + st->off_clamped) : nullptr, rect, part, flags, st->R_alloc,
                                       dL_dmeans3D, dL_dmeans2D, dL_dopacity, dL_dcolors, dL_dsh, dL_dcov3D, dL_dscales, dL_drotations,
-                                      stream_);
+                                      nullptr, stream_);
 }

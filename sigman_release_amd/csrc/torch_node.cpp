@@ -507,6 +507,9 @@ struct RasterizeL1BatchedNode : public torch::autograd::Function<RasterizeL1Batc
         SgrL1Epilogue ep;
         ep.target = target.data_ptr<float>(); ep.mask = has_mask ? mask.data_ptr<float>() : nullptr; ep.grad_color = gimg.data_ptr<float>(); ep.loss_per_view = sums.data_ptr<float>();
         ep.loss_total = sums.data_ptr<float>() + nv; ep.weight = (float)weight; ep.sums_already_zero = 1;
+        // one or two views: loss, dL/dcolor and the compositing backward of the loss run inside the compositing kernel (st.fused_bwd tells whether
+        // the launch qualified); the backward below then only gathers
+        ep.fuse_backward = (wants_grad && !da_grads) ? 1 : 0; ep.reserved0 = 0;
         SgrForwardState st;
         memset(&st, 0, sizeof(st));
         AllocCtx ac;
@@ -572,10 +575,12 @@ struct RasterizeL1BatchedNode : public torch::autograd::Function<RasterizeL1Batc
         const auto f32 = at::TensorOptions().dtype(at::kFloat).device(dev);
         const Tensor &g_loss = grads[0], &g_color = grads[2];
         Tensor gC, scale;
+        Tensor gD = grads[4].defined() ? f32c(grads[4]) : Tensor(), gA = grads[5].defined() ? f32c(grads[5]) : Tensor();
+        // a fused forward has run the compositing backward of its own loss already: with nothing but dL/dloss coming back, gather and scale
+        const bool gather_only = st.fused_bwd && g_loss.defined() && !g_color.defined() && !gD.defined() && !gA.defined();
         if (!g_loss.defined() && !g_color.defined()) gC = at::zeros_like(gimg);
         else if (!g_color.defined()) { gC = gimg; scale = g_loss.reshape({1}).to(at::kFloat); }        // the common case: only the loss is used
         else gC = g_loss.defined() ? f32c(g_color) + gimg * g_loss : f32c(g_color);
-        Tensor gD = grads[4].defined() ? f32c(grads[4]) : Tensor(), gA = grads[5].defined() ? f32c(grads[5]) : Tensor();
         Tensor d_means3D = at::empty({S, P, 3}, f32), d_op = at::empty({S, P}, f32), d_cov = at::empty({S, P, 6}, f32), d_col = at::empty({S, P, 3}, f32);
         SgrProblem pb = make_problem(P, H, W, 0, 0, scal[0], scal[1], scal[2], means3D, opac, colors, Tensor(), cov, Tensor(), Tensor(), vm, pm, campos, bg);
         pb.n_views = (int32_t)nv; pb.views_per_subject = (int32_t)vps;
@@ -584,7 +589,7 @@ struct RasterizeL1BatchedNode : public torch::autograd::Function<RasterizeL1Batc
         ac.dev = dev;
         auto mp = [](const Tensor &t) -> float * { return (t.defined() && t.numel() > 0) ? t.data_ptr<float>() : nullptr; };
         check_status(sgr_rasterize_backward(&pb, &st, radii.data_ptr<int32_t>(), color.data_ptr<float>(), depth.data_ptr<float>(), alpha.data_ptr<float>(),
-                                            gC.data_ptr<float>(), mp(gD), mp(gA), mp(scale), alloc_cb, &ac, mp(d_means3D), nullptr, mp(d_op), mp(d_col), nullptr,
+                                            gather_only ? nullptr : gC.data_ptr<float>(), mp(gD), mp(gA), mp(scale), alloc_cb, &ac, mp(d_means3D), nullptr, mp(d_op), mp(d_col), nullptr,
                                             mp(d_cov), nullptr, nullptr, stream),
                      "sgr_rasterize_backward");
         std::shared_ptr<BPending> mine;

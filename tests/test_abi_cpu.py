@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 10
     for n in names:
         assert hasattr(L, n), f"{n} declared in include/sigman_gsplat.h but not exported"
-    assert _cabi.lib().sgr_abi_version() == _cabi.ABI_VERSION == 7
+    assert _cabi.lib().sgr_abi_version() == _cabi.ABI_VERSION == 8
     assert _cabi.lib().sgr_preprocess_blocks_per_view(1000) == 4
     assert _cabi.lib().sgr_bin_workspace_bytes(10_000, 1024) >= 3 * 256 * 4
 
@@ -93,13 +93,14 @@ def test_ply_roundtrip_and_checkpoint_loader(tmp_path):
 
 
 def test_ctypes_structs_match_the_c_header(tmp_path):
-    """The ctypes mirror of SgrProblem / SgrForwardState must have the C compiler's size and field offsets (no GPU needed)."""
+    """The ctypes mirror of SgrProblem / SgrForwardState / SgrL1Epilogue must have the C compiler's size and field offsets (no GPU needed)."""
     import ctypes as C
     import os
     import subprocess
     from sigman_release_amd import _cabi
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    fields = {"SgrProblem": [n for n, _ in _cabi.SgrProblem._fields_], "SgrForwardState": [n for n, _ in _cabi.SgrForwardState._fields_]}
+    fields = {"SgrProblem": [n for n, _ in _cabi.SgrProblem._fields_], "SgrForwardState": [n for n, _ in _cabi.SgrForwardState._fields_],
+              "SgrL1Epilogue": [n for n, _ in _cabi.SgrL1Epilogue._fields_]}
     src = ['#include <stdio.h>', '#include <stddef.h>', '#include "sigman_gsplat.h"', 'int main(void) {']
     for st, names in fields.items():
         src.append(f'printf("{st} %zu\\n", sizeof({st}));')
@@ -140,7 +141,7 @@ int main(void) {
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(root, "include"), str(c_file), "-o", str(exe),
                            "-L", libdir, "-lsigman_gsplat", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
     out = subprocess.check_output([str(exe)], text=True).split()
-    assert int(out[0]) == 7 and int(out[1]) == (1000 >> 6) + 16 + 1 and int(out[2]) > 0
+    assert int(out[0]) == 8 and int(out[1]) == (1000 >> 6) + 16 + 1 and int(out[2]) > 0
 
 
 def test_full_size_record_matches_kernel_sources():

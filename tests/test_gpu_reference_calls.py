@@ -513,10 +513,14 @@ def _batched_l1_inputs(dev, S, V, P=5000, H=128, W=144, seed=5):
     return base, mk, target
 
 
-@pytest.mark.parametrize("S,V,mode", [(1, 1, "loss"), (1, 2, "loss+color"), (2, 4, "loss"), (1, 2, "depth+alpha")])
+@pytest.mark.parametrize("S,V,mode", [(1, 1, "loss"), (1, 1, "loss*1.7"), (1, 2, "loss+color"), (2, 4, "loss"), (2, 4, "loss*1.7"), (1, 2, "depth+alpha")])
 def test_cpp_batched_l1_node_equals_python_node(S, V, mode):
     """rasterize_l1_loss_batched routes the reference's input flavour in the explicit sync-free mode to the C++ node (csrc/torch_node.cpp):
-    same loss, per-view losses, images and gradients as the Python node, bit for bit."""
+    same loss, per-view losses, images and gradients as the Python node, bit for bit.  The Python node always runs the UNFUSED chain
+    (compositing, loss kernel, compositing backward, gather); at these sizes (<= 2048 tiles) the C++ node takes the FUSED single-view step
+    (loss + dL/dcolor + the compositing backward inside the compositing kernel, csrc/render.hip FusedL1): its partial records are for
+    dL/dloss = 1 and the gather multiplies the upstream scalar in, so gradients are bit-identical for an upstream gradient of 1 and equal
+    to the last bits otherwise; with a second gradient into the colour (or depth / alpha) the node falls back to the unfused backward."""
     from sigman_release_amd import _cabi, rasterizer as R
     if _cabi.torch_node() is None:
         pytest.skip("sgr_torch_node.so not built / SIGMAN_PY_NODE=1")
@@ -531,7 +535,7 @@ def test_cpp_batched_l1_node_equals_python_node(S, V, mode):
         if impl == "cpp":
             assert type(out[0].grad_fn).__name__ != "_RasterizeL1BatchedBackward", "the call did not reach the C++ node"
         loss, per_view, color, radii, depth, alpha = out
-        total = loss * 1.7
+        total = loss * (1.0 if mode == "loss" else 1.7)
         if mode == "loss+color":
             total = total + (color * color).sum() * 0.01
         if mode == "depth+alpha":
@@ -543,8 +547,61 @@ def test_cpp_batched_l1_node_equals_python_node(S, V, mode):
         assert a.shape == b.shape
         if i < 2:       # loss / per-view losses: float atomics over the pixels, equal up to the order of the additions
             assert torch.allclose(a, b, rtol=1e-5, atol=0.0)
+        elif i >= 6 and mode == "loss*1.7":     # the fused step scales the gathered sums, the unfused chain dL/dcolor
+            assert torch.allclose(a, b, rtol=2e-5, atol=2e-7 * float(b.abs().max())), (i, float((a - b).abs().max()), float(b.abs().max()))
         else:
             assert torch.equal(a, b), i
+    R.check_pending_overflows(True)
+
+
+@pytest.mark.parametrize("P,H,W,V,use_mask", [(20000, 256, 256, 1, True), (6000, 128, 144, 2, False), (3000, 100, 90, 1, True)])
+def test_fused_single_view_step_equals_unfused_chain(P, H, W, V, use_mask):
+    """The fused single-view step (SgrL1Epilogue.fuse_backward) against the unfused chain through the SAME C++ node (sgr_set_fused_step 0):
+    flavour 1 (loss shares + dL/dcolor inside the segment-parallel compositing kernel, the bucket backward queued behind it by the forward
+    call, the caller's backward only gathers): images, radii and gradients bit for bit with dL/dloss = 1, the loss to the order of its
+    additions; flavour 2 (the bucket backward inside the compositing kernel too: one wave per bucket instead of the split pair, i.e. another
+    order of the pixel sums): gradients to the last bits.  A second backward on the same forward (gather only, twice) repeats the first; a
+    backward with a gradient into the colour as well falls back to the unfused backward and is bit-identical to the unfused chain's."""
+    from sigman_release_amd import _cabi, rasterizer as R
+    if _cabi.torch_node() is None:
+        pytest.skip("sgr_torch_node.so not built / SIGMAN_PY_NODE=1")
+    dev = _dev()
+    base, mk, target = _batched_l1_inputs(dev, 1, V, P=P, H=H, W=W, seed=11)
+    mask = (torch.rand(V, 1, H, W, device=dev, generator=torch.Generator(device=dev).manual_seed(3)) > 0.3).float() if use_mask else None
+    st = mk(600000)
+    L = _cabi.lib()
+    res = {}
+    try:
+        for fused in (0, 1, 2):
+            L.sgr_set_fused_step(fused)
+            for flavour in ("loss", "loss+color"):
+                d = {k: v.clone().requires_grad_(True) for k, v in base.items()}
+                loss, per_view, color, radii, depth, alpha = R.rasterize_l1_loss_batched(d["means3D"], None, None, d["rgb"], d["opacity"], None, None, d["cov3D"], st,
+                                                                                         target, mask, 0.37)
+                total = loss if flavour == "loss" else loss + (color * color).sum() * 0.01
+                total.backward(retain_graph=(flavour == "loss"))
+                g1 = [d[k].grad.clone() for k in ("means3D", "rgb", "opacity", "cov3D")]
+                if flavour == "loss":
+                    for k in d:
+                        d[k].grad = None
+                    total.backward()
+                    g2 = [d[k].grad.clone() for k in ("means3D", "rgb", "opacity", "cov3D")]
+                    for a, b in zip(g1, g2):
+                        assert torch.equal(a, b), "a second backward on the same forward must repeat the first"
+                torch.cuda.synchronize()
+                res[(fused, flavour)] = [x.detach().clone() for x in (loss, per_view, color, radii, depth, alpha)] + g1
+    finally:
+        L.sgr_set_fused_step(1)
+    for fused in (1, 2):
+        for flavour in ("loss", "loss+color"):
+            for i, (a, b) in enumerate(zip(res[(0, flavour)], res[(fused, flavour)])):
+                if i < 2:
+                    assert torch.allclose(a, b, rtol=1e-5, atol=0.0), (fused, flavour, i, a, b)
+                elif fused == 2 and flavour == "loss" and i >= 6:
+                    assert torch.allclose(a, b, rtol=2e-5, atol=2e-6 * float(a.abs().max())), (fused, flavour, i, float((a - b).abs().max()), float(a.abs().max()))
+                else:
+                    assert torch.equal(a, b), (fused, flavour, i, float((a.float() - b.float()).abs().max()))
+        assert float(res[(fused, "loss")][6].abs().max()) > 0.0
     R.check_pending_overflows(True)
 
 

@@ -21,9 +21,17 @@ L = _cabi.lib()
 L.sgr_debug_seg_trace.restype = C.c_int; L.sgr_debug_seg_trace.argtypes = [C.c_void_p]
 NS, NE = 8, 512
 TILES = (H // 16) ** 2
-buf = torch.zeros(NS * 4 * NE + TILES * 16, dtype=torch.int64, device=dev)
+buf = torch.zeros(NS * 4 * NE + TILES * 32, dtype=torch.int64, device=dev)
 leaves = [subj[k].clone().requires_grad_(True) for k in ("means3D", "rgb", "opacity", "cov3D")]
+FUSED = os.environ.get("FUSED", "0") == "1"       # the fused single-view step through the C++ node (the traced library must be the one the node links: lib/libsigman_gsplat.so)
+if FUSED:
+    st = R.BatchedRasterizationSettings(H, H, cameras.TAN_HALF_FOV, cameras.TAN_HALF_FOV, torch.ones(3, device=dev), 0.5, t(cv), t(cvp), 0, t(cp), 1, False, 400000 if name != "c5" else 4000000)
+    gt = torch.rand(1, 3, H, H, device=dev)
 def fwd():
+    if FUSED:
+        out = R.rasterize_l1_loss_batched(leaves[0], None, None, leaves[1], leaves[2][..., None] if leaves[2].dim() == 2 else leaves[2], None, None, leaves[3], st, gt, None, 1e-3)
+        out[0].backward()
+        return out
     return R.rasterize_gaussians_batched(leaves[0], None, None, leaves[1], leaves[2][..., None] if leaves[2].dim() == 2 else leaves[2], None, None, leaves[3], st)
 for _ in range(5): fwd()
 torch.cuda.synchronize()
@@ -32,8 +40,8 @@ ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=
 fwd(); torch.cuda.synchronize()
 raw = buf.cpu().numpy().astype(np.uint64)
 b = raw[:NS * 4 * NE].reshape(NS, 4, NE)
-sch = raw[NS * 4 * NE:].reshape(TILES, 4, 4)
-names = {1: "start", 2: "loop", 3: "fill", 4: "phase1", 5: "prefix", 6: "phase2", 7: "book", 8: "done", 9: "written"}
+sch = raw[NS * 4 * NE:].reshape(TILES, 4, 8)
+names = {1: "start", 2: "loop", 3: "fill", 4: "phase1", 5: "prefix", 6: "phase2", 7: "book", 8: "done", 9: "written", 10: "bwd-barrier", 11: "bwd-bucket", 12: "bwd-end"}
 t00 = None
 for s in range(NS):
     for q in range(4):
@@ -55,11 +63,11 @@ for s in range(NS):
 rows = []
 for sl in range(TILES):
     for q in range(4):
-        w0, w1, hw, info = (int(x) for x in sch[sl, q])
+        w0, w1, hw, info, wb, nbk = (int(x) for x in sch[sl, q][:6])
         if w0 == 0: continue
         xcc = (hw >> 32) & 0xF; hwid = hw & 0xFFFFFFFF
         cu = (hwid >> 8) & 0xF; sh = (hwid >> 12) & 1; se = (hwid >> 13) & 7
-        rows.append((w0, w1, sl, q, info >> 32, xcc, se, sh, cu))
+        rows.append((w0, w1, sl, q, info >> 32, xcc, se, sh, cu, wb, nbk))
 t0 = min(r[0] for r in rows)
 work = [r for r in rows if r[4] > 0]
 tend = max(r[1] for r in work)
@@ -78,3 +86,14 @@ starts = sorted((r[0] - t0) / 100.0 for r in work)
 print("start times of working workgroups (us), every 53rd:", [round(x, 1) for x in starts[::53]])
 durs = sorted(((r[1] - r[0]) / 100.0, r[4]) for r in work)
 print("durations (us, n): shortest", durs[:3], "median", durs[len(durs) // 2], "longest", durs[-3:])
+
+if FUSED:
+    fw = sorted(((r[9] - r[0]) / 100.0, (r[1] - r[9]) / 100.0, r[4], r[10]) for r in work if r[9])
+    print("fused: (forward us, backward us, n, buckets) shortest fwd", fw[:3], "median", fw[len(fw) // 2], "longest", fw[-3:])
+    bw = sorted(((r[1] - r[9]) / 100.0, r[10], r[4]) for r in work if r[9])
+    print("fused: backward phase (us, buckets, n): shortest", bw[:3], "median", bw[len(bw) // 2], "longest", bw[-5:])
+    import collections as _c
+    by_nb = _c.defaultdict(list)
+    for d, nb, n in bw: by_nb[min(nb, 17)].append(d)
+    print("fused: mean backward-phase us by bucket count:", {k: (len(v), round(sum(v) / len(v), 1)) for k, v in sorted(by_nb.items())})
+    print("fused: backward-phase start times (us), every 53rd:", [round((r[9] - t0) / 100.0, 1) for r in sorted(work, key=lambda r: r[9])[::53]])
