@@ -576,6 +576,11 @@ def main(args):
     dom_ms, dom_n = dom.get(dominant, (0.0, 0))
     dom_avg_ms = dom_ms / max(dom_n, 1)
     abytes = algorithmic_bytes(dominant, P * n_local, Rn, H * W * n_local, tiles * n_local, gt_mask is not None)
+    # the fused single-view step (one or two views through the C++ node, SIGMAN_FUSED_STEP != 0): no loss launch -- the compositing kernel also
+    # reads the target (12 B per pixel, + 4 B of mask) and writes dL/dcolor (12 B); the colour it would have re-read (12 B) never leaves the chip
+    fused_step = bool(bwd and breakdown and "clamped_l1" not in breakdown and "render_bwd" in breakdown)
+    if fused_step and dominant == 5:
+        abytes += (28 if gt_mask is not None else 24) * H * W * n_local
     achieved = abytes / (dom_avg_ms * 1e-3) / 1e9 if dom_avg_ms > 0 else 0.0
     step_bytes = ((212 if bwd else 104) * P * n_local + (176 if bwd else 88) * Rn + (52 if bwd else 24) * H * W * n_local + 8 * tiles * n_local)
 
@@ -603,7 +608,7 @@ def main(args):
                                + ((", clamp + masked L1 loss (mask = ground-truth alpha > 0.5)" if gt_mask is not None else ", clamp+L1 loss") if bwd else "") + (", dL/ddepth and dL/dalpha non-zero" if da else ""),
                    "name": args.config, "views_per_step_total": n_total_views, "view_slots_this_gpu": n_local,
                    "parallelism": (f"view-parallel x{world} ({backend}), exchange={'none (forward only)' if not bwd else args.exchange}" if dist_on else "single GPU"),
-                   "ranks_seen": world, "num_rendered_per_gpu": Rn, "gaussian_pixel_visits_per_gpu": S_visits,
+                   "fused_step": fused_step, "ranks_seen": world, "num_rendered_per_gpu": Rn, "gaussian_pixel_visits_per_gpu": S_visits,
                    "binning_buffers": "exact (D2H read of num_rendered per step)" if args.exact_sync else (f"pre-sized, max_rendered={st.max_rendered} (sync-free)" if st else "-"),
                    "count_check": "exact read" if args.exact_sync else ("every step, by the backward of the step after next at the latest (set_count_wait lazy)" if lazy_counts else "every step, by its own backward")},
         "gaussian_pixel_ops_per_s_per_gpu": round(S_visits / (ms_per_step * 1e-3), 1),

@@ -112,9 +112,8 @@ typedef struct SgrForwardState {
     uint64_t off_ranges, off_final_T, off_n_contrib, off_compact, off_ckpt_tc, off_ckpt_da, off_desc, off_order, off_flags;   /* in image */
     /* ABI v8: the single-view fused step (sgr_rasterize_forward_l1 with SgrL1Epilogue.fuse_backward) */
     uint64_t off_part, off_loss_part;   /* in image: the backward's partial records [4*R_alloc*10] f32, the per-(tile, quadrant) loss shares */
-    int32_t fused_bwd;           /* != 0: the forward call also produced the loss, dL/dcolor and the partial records of the loss's own backward
-                                    (1: bucket backward queued behind the compositing kernel, 2: inside it): sgr_rasterize_backward may be called
-                                    with grad_color = NULL */
+    int32_t fused_bwd;           /* 1: the forward call also produced the loss, dL/dcolor and the partial records of the loss's own backward:
+                                    sgr_rasterize_backward may be called with grad_color = NULL */
     int32_t reserved1;
 } SgrForwardState;
 
@@ -148,12 +147,13 @@ int sgr_rasterize_forward(const SgrProblem *pb, uint64_t capacity, int32_t with_
  *
  * fuse_backward != 0 (ABI v8) allows the FUSED single-view step: when the launch composites with the segment-parallel kernel (<= 2048
  * tiles: one or two 512^2 views) and records auxiliary outputs (with_aux = 3: no depth/alpha checkpoints), the clamp + masked L1 and its
- * gradient are evaluated by the compositing workgroups themselves (the loss is pixel-local) -- no loss launch -- and the bucket backward
- * of dL/dloss = 1 is queued right behind by the same call (or, sgr_set_fused_step(2), run inside the compositing kernel): the forward call
- * leaves the partial records behind (state->fused_bwd != 0, state->off_part).  sgr_rasterize_backward with grad_color = NULL then only
- * gathers them, multiplied by *grad_color_scale.  grad_color (dL/dcolor) is still written, so a backward that is handed another upstream
- * gradient (grad_color != NULL) works as after any forward.  Results: dL/dcolor and (default flavour) the partial records are bit-identical
- * to the unfused path's; the loss sums are added in a fixed order (no atomics) and so differ from the unfused path's in the last bits only.
+ * gradient are evaluated by the compositing workgroups themselves (the loss is pixel-local; the background's share is pre-filled by an
+ * early launch) -- no loss launch -- and the bucket backward of dL/dloss = 1 is queued right behind by the same call, its spare workgroup
+ * adding up the loss shares: the forward call leaves the partial records behind (state->fused_bwd = 1, state->off_part).
+ * sgr_rasterize_backward with grad_color = NULL then only gathers them, multiplied by *grad_color_scale.  grad_color (dL/dcolor) is still
+ * written, so a backward that is handed another upstream gradient (grad_color != NULL) works as after any forward.  Results: dL/dcolor and
+ * the partial records are bit-identical to the unfused path's; the loss sums are added in a fixed order (no atomics: reproducible) and so
+ * differ from the unfused path's in the last bits only.
  */
 typedef struct SgrL1Epilogue {
     const float *target;          /* [n_views,3,H,W] */
@@ -254,11 +254,8 @@ int sgr_set_forward_mode(int mode);
 int sgr_set_backward_gather(int mode);
 
 /* the fused single-view step of sgr_rasterize_forward_l1 when the epilogue allows it and the launch qualifies (environment SIGMAN_FUSED_STEP):
- * 1 (default) = loss shares + dL/dcolor inside the compositing kernel, the bucket backward queued right behind it by the forward call (one
- * launch fewer: no loss kernel; its spare workgroup sums the loss shares); 2 = the bucket backward inside the compositing kernel as well (two
- * launches fewer; measured slower at C1 / C2: a switch for measurements); 0 = never (A/B, parity tests against the unfused chain).
- * Thread-local; returns the previous value. */
-int sgr_set_fused_step(int mode);
+ * 1 (default) = taken; 0 = never (A/B measurements, parity tests against the unfused chain).  Thread-local; returns the previous value. */
+int sgr_set_fused_step(int on);
 
 /* sgr_rasterize_forward*: 0 (default) = when the binning ends in the register per-tile sort, only the point list is stored -- the sorted keys
  * have no reader behind that sort (the tile ranges come from the tile pass); 1 = keep the sorted keys in the binning blob as well

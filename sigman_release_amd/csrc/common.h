@@ -66,7 +66,6 @@ struct SgrFusedL1Args {
     const uint32_t *rect;
     float *part;
     uint32_t *flags;
-    int backward_inside;        // 1: the compositing kernel also runs its workgroups' own bucket backward (AUX == 4); 0: loss shares + dL/dcolor only
 };
 
 // The EMPTY tiles of a one- or two-view launch (812 of the 1024 tiles of a 512^2 humanoid view) only receive the background -- and, in the

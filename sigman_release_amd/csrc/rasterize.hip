@@ -17,10 +17,9 @@ inline uint64_t align_up(uint64_t v, uint64_t a = 256) { return (v + a - 1) / a 
 
 // 0 (default): a fused forward whose binning ends in the register per-tile sort stores only the point list -- the sorted keys have no
 // reader behind that sort (the tile ranges come from the tile pass); 1: keep them (forward_debug / the parity tests look at them)
-// the single-view fused step (SgrL1Epilogue.fuse_backward) when the launch qualifies: 0 = never (A/B, tests), 1 (default) = loss + dL/dcolor inside the
-// compositing kernel and the bucket backward queued behind it by the forward call, 2 = that backward inside the compositing kernel too: SIGMAN_FUSED_STEP
-static thread_local int g_fused_step = sgr_env_knob("SIGMAN_FUSED_STEP", 0, 2, 1);
-extern "C" int sgr_set_fused_step(int mode) { const int old = g_fused_step; g_fused_step = (mode >= 0 && mode <= 2) ? mode : 1; return old; }
+// the single-view fused step (SgrL1Epilogue.fuse_backward) when the launch qualifies: 1 (default) = taken, 0 = never (A/B, tests): SIGMAN_FUSED_STEP
+static thread_local int g_fused_step = sgr_env_knob("SIGMAN_FUSED_STEP", 0, 1, 1);
+extern "C" int sgr_set_fused_step(int on) { const int old = g_fused_step; g_fused_step = on ? 1 : 0; return old; }
 static int sgr_fused_step_enabled() { return g_fused_step; }
 static thread_local int g_keep_sorted_keys = 0;     // thread-local like sgr_set_debug: forward_debug() toggles it around ONE call
 extern "C" int sgr_set_keep_sorted_keys(int keep) { const int old = g_keep_sorted_keys; g_keep_sorted_keys = keep ? 1 : 0; return old; }
@@ -110,15 +109,14 @@ static int forward_launches(const SgrProblem *pb, uint64_t capacity, uint64_t R,
         fa.target = l1->target; fa.mask = l1->mask; fa.weight = l1->weight; fa.gimg = l1->grad_color;
         fa.loss_part = (float *)(image + st->off_loss_part); fa.loss_per_view = l1->loss_per_view; fa.loss_total = l1->loss_total;
         fa.rect = rect; fa.part = (float *)(image + st->off_part); fa.flags = (uint32_t *)(image + st->off_flags);
-        fa.backward_inside = st->fused_bwd == 2 ? 1 : 0;
     }
     const int rc = sgr_render_forward_ex(pb, (const uint32_t *)(image + st->off_ranges), point_list, rec, out_color, out_depth, out_alpha,
                               (float *)(image + st->off_final_T), (uint32_t *)(image + st->off_n_contrib), R,
                               aux_on ? image + st->off_compact : nullptr, aux_on ? image + st->off_ckpt_tc : nullptr,
                               (aux_on && !st->aux_no_da) ? image + st->off_ckpt_da : nullptr, aux_on ? image + st->off_desc : nullptr,
                               (uint32_t *)(image + st->off_order), prep_done != 0, st->fwd_kind, st->fused_bwd ? &fa : nullptr, bg_done != 0, stream);
-    if (rc || st->fused_bwd != 1) return rc;
-    // fused step, flavour 1: the compositing kernel left the loss shares and dL/dcolor; the bucket backward of dL/dloss = 1 follows at once
+    if (rc || !st->fused_bwd) return rc;
+    // fused step: the compositing kernel left the loss shares and dL/dcolor; the bucket backward of dL/dloss = 1 follows at once
     // (its spare workgroup sums the loss shares), so that the caller's backward only gathers
     SgrProblem pbb = *pb;
     pbb.clamp_grad = 0;                    // (the loss has its own clamp; dL/dcolor is w.r.t. the unclamped colour)
@@ -217,7 +215,7 @@ static int rasterize_forward_impl(const SgrProblem *pb, uint64_t capacity, int32
         st->off_ckpt_da = o; o = align_up(o + (st->aux_no_da ? 0 : 4 * NS * rows * 64 * 8));
         st->off_desc = o; o = align_up(o + 4 * NS * 8);
         if (l1 && l1->fuse_backward && st->aux_no_da && sgr_render_forward_kind(pb) == 2 && sgr_fused_step_enabled()) {
-            st->fused_bwd = sgr_fused_step_enabled();     // 1: loss inside the compositing kernel, bucket backward queued behind; 2: that backward inside as well
+            st->fused_bwd = 1;
             st->off_part = o; o = align_up(o + R * 4 * SGR_PART_FLOATS * 4);        // the backward's partial records are written by the forward's launch
             st->off_loss_part = o; o = align_up(o + tiles_total * 4 * 4);
         }

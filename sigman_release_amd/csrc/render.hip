@@ -66,17 +66,14 @@ struct FwdAux {
 // The single-view FUSED step (sgr_rasterize_forward_l1 with SgrL1Epilogue.fuse_backward; AUX >= 3 of the segment-parallel kernel): the clamp +
 // masked L1 of gs.py:107 / whole_loss.py:126-131 is pixel-local, so the workgroup that composited a (tile, quadrant) knows the loss share and
 // dL/dcolor of its 64 pixels the moment its forward is over: no loss launch (AUX == 3; the bucket backward is queued right behind by the same
-// host call and sums the loss shares on the side).  AUX == 4 also runs the backward of the workgroup's OWN buckets on the spot (no backward
-// launch either; measured slower at C1 / C2, DESIGN.md: kept as a switch).
+// host call and sums the loss shares on the side).  (Running the backward of the workgroup's OWN buckets on the spot as well -- no backward
+// launch either -- was built and measured: slower at C1 and C2, DESIGN.md dead ends (aj).)
 struct FusedL1 {
     const float *target;      // [n_views,3,H,W]
     const float *mask;        // [n_views,1,H,W] or NULL
     float weight;
     float *gimg;              // [n_views,3,H,W]  dL/dcolor (written like clamped_l1_kernel does: a backward that is handed another upstream gradient starts from it)
-    float *loss_part;         // [n_views*tiles*4]  weight * sum |clamp(colour) - target| * mask per (tile, quadrant), summed in a fixed order by l1_reduce_kernel
-    const uint4 *rect;        // the backward's inputs / outputs (render_bwd_bucket_kernel's)
-    float4 *part;
-    uint8_t *flags;
+    float *loss_part;         // [n_views*tiles*4]  weight * sum |clamp(colour) - target| * mask per (tile, quadrant), summed in a fixed order (l1_reduce_block)
 };
 
 // Sums of products are written with their fused multiply-adds spelled out.  `a*b + c*d` may be contracted with either product inside
@@ -256,144 +253,6 @@ __global__ __launch_bounds__(64, AUX ? SGR_WAVE_AUX_WAVES : 8) void render_fwd_w
     }
 }
 
-// shift one lane up inside each 16-lane row; lane 0 of every row takes `feed` (DPP row_shr:1 keeps `old` where there is no source)
-__device__ __forceinline__ float row_shift_in(float v, float feed) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, feed), __builtin_bit_cast(int, v),
-                                                                 SGR_DPP_ROW_SHR(1), 0xF, 0xF, false));
-}
-
-
-// The step of the bucket backward's pixel pipeline (render_bwd_bucket_kernel below explains it; the fused single-view kernel runs the same
-// steps).  Names taken from the expansion site: gx gy kxx kyy kxy op pstar gidx cr cg cb gdep (my Gaussian), rl (lane & 15), n_alive,
-// pa pb pd (this wave's LDS feeds), the ten sums S1 .. a9, HAS_DA.
-#define SGR_BWD_LOAD(S, FA, FB, FD) { FA = pa[(S)]; FB = pb[(S)]; FD = pd[min((S), n_alive - 1)]; asm volatile("" ::: "memory"); }
-#define SGR_BWD_STEP(IN, OUT, S, fa, fb, fd, NFA, NFB, NFD)                                                             \
-    {                                                                                                                   \
-        const bool has = (uint32_t)((S) - rl) < (uint32_t)n_alive;      /* a stream entry sits in this lane */           \
-        /* the shift is the first use of this step's reads (one wait, nothing else in flight: the compiler's wait counts do not   \
-           survive the loop's back edge, a wait with the next reads already issued would be a wait for them too); THEN the next   \
-           step's reads go out and travel while this step computes */                                                             \
-        OUT.T = row_shift_in(IN.T, fd.x); OUT.Rem = row_shift_in(IN.Rem, fd.y);                                         \
-        SGR_BWD_LOAD((S) + 1, NFA, NFB, NFD)                                                                            \
-        const float dx = gx - fa.x, dy = gy - fa.y;                                                                     \
-        const float p2 = sgr_power2(kxx, kyy, kxy, dx, dy);                                                             \
-        const float G = __builtin_amdgcn_exp2f(p2);                                                                     \
-        const float alpha = fminf(0.99f, op * G);                                                                       \
-        const bool valid = has && gidx < __float_as_uint(fa.z) && p2 <= 0.f && p2 >= pstar;                              \
-        if (valid) {                                                                                                    \
-            const float w = alpha * OUT.T;                                                                              \
-            float qj = sgr_dot3(cr, fa.w, cg, fb.x, cb, fb.y);                                                          \
-            if (HAS_DA) qj += fmaf(gdep, fb.z, fb.w);                                                                   \
-            const float oma = 1.f - alpha;                                                                              \
-            OUT.Rem = fmaf(-w, qj, OUT.Rem);                                                                            \
-            const float dL_dalpha = fmaf(OUT.T, qj, -(OUT.Rem * __builtin_amdgcn_rcpf(oma)));                           \
-            OUT.T *= oma;                                                                                               \
-            const float v = G * dL_dalpha; /* upstream differentiates through op*G even when alpha is capped */         \
-            const float vx = v * dx, vy = v * dy;                                                                       \
-            S1 += v; Sx += vx; Sy += vy;                                                                                \
-            Sxx = fmaf(vx, dx, Sxx); Sxy = fmaf(vx, dy, Sxy); Syy = fmaf(vy, dy, Syy);                                  \
-            if (HAS_DA) aD = fmaf(w, fb.z, aD);                                                                         \
-            a7 = fmaf(w, fa.w, a7); a8 = fmaf(w, fb.x, a8); a9 = fmaf(w, fb.y, a9);                                     \
-        }                                                                                                               \
-    }
-
-// One bucket of the backward inside the FUSED single-view kernel: what one wave of render_bwd_bucket_kernel<false, false> does, with the
-// quadrant's pixel data (position, n_contrib, dL/dcolor, O) taken from the LDS arrays the compositing epilogue just filled instead of from
-// the images -- the same terms in the same order, so the partial records are the ones the separate launch writes, bit for bit.
-__device__ __forceinline__ void fused_bwd_bucket(const uint32_t desc_x, const uint32_t desc_y, const size_t slot, const uint32_t q, const uint32_t tx,
-                                                 const uint32_t ty, const uint32_t rx, const int W, const int H, const float4 *__restrict__ rec,
-                                                 const FwdAux &aux, const FusedL1 &fz, const float4 *sFA, const float4 *sFB,
-                                                 float4 *wA, float4 *wB, float2 (*wDyn)[64], const int lane) {
-    constexpr bool HAS_DA = false;
-    const uint32_t rps = (desc_x >> 30) + 1u;
-    const uint32_t count = desc_y & 127u;
-    const uint32_t start = desc_y >> 7;
-    const int row = lane >> 4;
-    const bool has_g = (uint32_t)lane < count;
-    uint2 e = make_uint2(0u, 0xFFFFFFFFu);
-    if (has_g) e = aux.compact[(size_t)q * aux.R + rx + start + (uint32_t)lane];
-    const uint32_t gidx = e.y;
-    float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra, rc = ra;
-    uint4 rd = make_uint4(0u, 0u, 0u, 0u);
-    if (has_g) { ra = rec[(size_t)e.x * 4 + 0]; rb = rec[(size_t)e.x * 4 + 1]; rc = rec[(size_t)e.x * 4 + 2]; rd = fz.rect[e.x]; }
-    const float pstar = has_g ? rc.w : kNever;
-    const float gx = ra.x, gy = ra.y, cxx = ra.z, cxy = ra.w, cyy = rb.x, op = rb.y, gdep = rb.z, cr = rb.w, cg = rc.x, cb = rc.y;
-    const float kL2e = 1.4426950408889634f;
-    const float kxx = -0.5f * kL2e * cxx, kyy = -0.5f * kL2e * cyy, kxy = -kL2e * cxy;
-    (void)gdep;
-    const uint32_t gidx0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)gidx);
-    // pixel p = lane of the quadrant (an outside pixel carries n_contrib 0: never alive)
-    const float4 fpa = sFA[lane], fpb = sFB[lane];
-    const bool alive = __float_as_uint(fpa.z) > gidx0;
-    const uint64_t alive_mask = __ballot(alive);
-    const int n_alive = (int)__popcll(alive_mask);
-    const int pos = (int)__popcll(alive_mask & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))));
-    if (alive) {
-        const float g0 = fpa.w, g1 = fpb.x, g2 = fpb.y, O = fpb.z;
-        wA[16 + pos] = fpa;
-        wB[16 + pos] = make_float4(g1, g2, 0.f, 0.f);
-        float T0 = 1.f, Pre0 = 0.f;
-        if (start) {
-            const float4 tc = aux.ckpt_tc[slot * 256 + lane];
-            T0 = tc.x;
-            Pre0 = sgr_dot3(tc.y, g0, tc.z, g1, tc.w, g2);
-        }
-        wDyn[0][pos] = make_float2(T0, O - Pre0);
-        float PreSeg = Pre0;
-#pragma unroll
-        for (int r = 1; r < 4; r++) {
-            float Tr = 1.f, Prer = Pre0;
-            if ((uint32_t)(16 * r) < count) {
-                const float4 tc = aux.ckpt_tc[(slot * 4 + r) * 64 + lane];
-                Tr = tc.x;
-                const float dotv = sgr_dot3(tc.y, g0, tc.z, g1, tc.w, g2);
-                if (((uint32_t)r & (rps - 1u)) == 0u) PreSeg = dotv;
-                Prer = (((uint32_t)r & (rps - 1u)) == 0u) ? dotv : PreSeg + dotv;
-            }
-            wDyn[r][pos] = make_float2(Tr, O - Prer);
-        }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    struct PixState { float T, Rem; };
-    PixState A = {1.f, 0.f}, B = A;
-    float S1 = 0.f, Sx = 0.f, Sy = 0.f, Sxx = 0.f, Sxy = 0.f, Syy = 0.f, aD = 0.f, a7 = 0.f, a8 = 0.f, a9 = 0.f;
-    const int nsteps = n_alive ? n_alive + (int)min(count, 16u) - 1 : 0;
-    const int rl = lane & 15;
-    const float4 *pa = &wA[16 - rl], *pb = &wB[16 - rl];
-    const float2 *pd = &wDyn[row][0];
-    int s = 0;
-    float4 fa0, fb0, fa1, fb1;
-    float2 fd0, fd1;
-    SGR_BWD_LOAD(0, fa0, fb0, fd0)
-    for (; s + 1 < nsteps; s += 2) {
-        SGR_BWD_STEP(A, B, s, fa0, fb0, fd0, fa1, fb1, fd1)
-        SGR_BWD_STEP(B, A, s + 1, fa1, fb1, fd1, fa0, fb0, fd0)
-    }
-    if (s < nsteps) SGR_BWD_STEP(A, B, s, fa0, fb0, fd0, fa1, fb1, fd1)
-    const bool nonzero = (S1 != 0.f) | (Sx != 0.f) | (Sy != 0.f) | (Sxx != 0.f) | (Sxy != 0.f) | (Syy != 0.f) | (aD != 0.f) | (a7 != 0.f) |
-                         (a8 != 0.f) | (a9 != 0.f);
-    if (has_g) {
-        const uint32_t off = rd.w, rmin = rd.x, rmax = rd.y;
-        const uint32_t inst = off + (ty - (rmin >> 16)) * ((rmax & 0xFFFFu) - (rmin & 0xFFFFu)) + (tx - (rmin & 0xFFFFu));
-        fz.flags[(size_t)inst * 4 + q] = nonzero ? 1 : 0;
-        if (nonzero) {
-            const float a0 = -0.5f * (float)W * op * fmaf(cxy, Sy, cxx * Sx);
-            const float a1 = -0.5f * (float)H * op * fmaf(cxy, Sx, cyy * Sy);
-            struct __attribute__((packed, aligned(8))) Rec40 { float2 v[5]; };
-            Rec40 rr;
-            rr.v[0] = make_float2(a0, a1);
-            rr.v[1] = make_float2(-0.5f * op * Sxx, -0.5f * op * Sxy);
-            rr.v[2] = make_float2(-0.5f * op * Syy, S1);
-            rr.v[3] = make_float2(aD, a7);
-            rr.v[4] = make_float2(a8, a9);
-            *(reinterpret_cast<Rec40 *>(fz.part) + ((size_t)inst * 4 + q)) = rr;
-        }
-    }
-    // (the next bucket of this wave refills wA / wB / wDyn: LDS operations of one wave complete in order)
-}
-
 // -------------------------------------------------------------------------------------------------
 // F6, segment-parallel variant for launches that cannot fill the chip (one 512^2 humanoid view has ~200 occupied
 // tiles for 256 CUs, and the serial walk of the longest tile list -- ~2900 entries at C2 -- is the whole critical path).
@@ -450,7 +309,6 @@ __global__ __launch_bounds__(kSegThreads, 4) void render_fwd_seg_kernel(int W, i
     __shared__ uint32_t sLast[kSegWaves][64];
     __shared__ uint32_t sWaveCnt[kSegWaves];
     __shared__ uint32_t sContrib[kSegWaves];
-    __shared__ float4 sFA[AUX == 4 ? 64 : 1], sFB[AUX == 4 ? 64 : 1];        // FUSED backward: (x, y, n_contrib bits, g0) and (g1, g2, O, -) of the quadrant's pixels
     __shared__ float sTgt[AUX >= 3 ? 4 : 1][64];                             // FUSED loss: the pixels' target colour and mask, fetched straight into LDS at the start
     // work order: longest lists first (fwd_prepare_kernel); the tail of the grid are the empty tiles, which only write the background
     // XCD placement: consecutive workgroup ids go round-robin over the 8 XCDs (each with its own L2), so the four quadrant workgroups
@@ -526,10 +384,11 @@ __global__ __launch_bounds__(kSegThreads, 4) void render_fwd_seg_kernel(int W, i
         }
         return;
     }
+    constexpr int kLossWave = 1;
     if constexpr (AUX >= 3) {
         // the loss needs the pixel's target colour and mask when the last survivor is composited, i.e. at the end of the workgroup's critical
         // path: the wave that will need them requests them NOW, straight into LDS (global_load_lds: no registers held, nobody waits until the epilogue)
-        if (wave == (AUX == 3 ? 1 : 0) && inside) {              // (the loss wave of the epilogue: the wave that waits for them)
+        if (wave == kLossWave && inside) {                       // (the loss wave of the epilogue: the wave that waits for them)
             const size_t hw = (size_t)H * W, pix = (size_t)py * W + px, vb = (size_t)view * hw;
 #pragma unroll
             for (int c = 0; c < 3; c++) __builtin_amdgcn_global_load_lds(fz.target + vb * 3 + (size_t)c * hw + pix, &sTgt[c][0], 4, 0, 0);
@@ -544,7 +403,6 @@ __global__ __launch_bounds__(kSegThreads, 4) void render_fwd_seg_kernel(int W, i
     uint32_t kbase = 0;                                         // survivors composited in earlier rounds
     uint32_t qhead = 0, qcount = 0;                             // LDS ring of survivors waiting to be composited
     size_t slot_next = (size_t)q * aux.NS + (range.x >> 6) + (size_t)bid;
-    const size_t slot_first = slot_next;
     if (t < 64) sTstop[t] = -1.f;
     bool pix_done = !inside;
     // ---- software pipeline of the list: records of sub-chunk `commit` and ids of sub-chunk `commit + 1` live in registers
@@ -747,11 +605,9 @@ __global__ __launch_bounds__(kSegThreads, 4) void render_fwd_seg_kernel(int W, i
     sAcc[wave][0][lane] = C0; sAcc[wave][1][lane] = C1; sAcc[wave][2][lane] = C2; sAcc[wave][3][lane] = D; sAcc[wave][4][lane] = A;
     sLast[wave][lane] = last;
     __syncthreads();
-    // wave 0 writes the pixels' outputs; the fused step's loss share and dL/dcolor are wave kLossWave's (AUX == 3: wave 1, side by side with wave
-    // 0's stores -- the epilogue is on every workgroup's critical path; AUX == 4: wave 0 itself, which also feeds the backward's pixel arrays)
-    constexpr int kLossWave = AUX == 3 ? 1 : 0;
+    // wave 0 writes the pixels' outputs; the fused step's loss share and dL/dcolor are wave 1's, side by side with wave 0's stores (the epilogue
+    // is on every workgroup's critical path)
     if ((wave == 0 || (AUX >= 3 && wave == kLossWave)) && !(AUX && !aux.ckpt_tc)) {
-        float4 fa = make_float4(pxf, pyf, __uint_as_float(0u), 0.f), fb = make_float4(0.f, 0.f, 0.f, 0.f);     // FUSED: an outside pixel is never alive
         float lsum = 0.f;
         if (inside) {
             float r0 = 0.f, r1 = 0.f, r2 = 0.f, rD = 0.f, rA = 0.f;
@@ -802,43 +658,12 @@ __global__ __launch_bounds__(kSegThreads, 4) void render_fwd_seg_kernel(int W, i
                     g[c] = (oc[c] >= 0.f && oc[c] <= 1.f) ? fz.weight * m * sg : 0.f;
                     fz.gimg[vb * 3 + (size_t)c * hw + pix] = g[c];
                 }
-                fa.z = __uint_as_float(lmax); fa.w = g[0];
-                fb = make_float4(g[1], g[2], sgr_dot3(o0, g[0], o1, g[1], o2, g[2]), 0.f);      // O = out . g (render_bwd_bucket_kernel's)
             }
         }
         if (AUX >= 3 && wave == kLossWave) {
-            if constexpr (AUX == 4) { sFA[lane] = fa; sFB[lane] = fb; }
             lsum = sgr_wave_sum(lsum);
             if (lane == 0) fz.loss_part[(size_t)bid * 4 + q] = fz.weight * lsum;
         }
-    }
-    if constexpr (AUX == 4) {
-        // ---- FUSED backward: this quadrant's buckets, one per wave and round (the bucket layout is the forward's: segments of 64 survivors).
-        // The ring and the partial sums are dead now: wave w's pipeline feeds (two 96-entry pixel arrays + four rows of start states,
-        // 5 KB) live in ring array w (waves 0..5) or in one half of sAcc (waves 6, 7).
-        static_assert(kSegWaves == 8 && sizeof(pA) >= 320 * sizeof(float4) && sizeof(sAcc) >= 2 * 320 * sizeof(float4), "LDS carve-up of the fused backward");
-        __syncthreads();                                         // sFA / sFB written; wave 0 is done reading sAcc / sLast / sTstop
-#ifdef SGR_SEG_TRACE
-        SGR_TR(10);
-        if (sch) { sch[4] = wall_clock64(); sch[5] = (kbase + 63u) >> 6; }
-#endif
-        float4 *wbase = wave == 0 ? pA : wave == 1 ? pB : wave == 2 ? pC : wave == 3 ? pD : wave == 4 ? pE : wave == 5 ? pQ
-                        : reinterpret_cast<float4 *>(&sAcc[0][0][0]) + (wave - 6) * 320;
-        float4 *wA = wbase, *wB = wbase + 96;
-        float2 (*wDyn)[64] = reinterpret_cast<float2 (*)[64]>(wbase + 192);
-        const uint32_t nbk = (kbase + 63u) >> 6;                  // buckets the forward composited (identical in all waves)
-        for (uint32_t b = (uint32_t)wave; b < nbk; b += (uint32_t)kSegWaves) {
-            const size_t bslot = slot_first + b;
-            const uint2 dv = aux.desc[bslot];                    // written by this workgroup in front of a barrier; (0, 0): no pixel composited anything of the bucket
-            const uint32_t desc_y = (uint32_t)__builtin_amdgcn_readfirstlane((int)dv.y), desc_x = (uint32_t)__builtin_amdgcn_readfirstlane((int)dv.x);
-            if ((desc_y & 127u) == 0u) continue;
-            fused_bwd_bucket(desc_x, desc_y, bslot, q, tx, ty, range.x, W, H, rec, aux, fz, sFA, sFB, wA, wB, wDyn, lane);
-            SGR_TR(11);
-        }
-#ifdef SGR_SEG_TRACE
-        __syncthreads();
-        SGR_TR(12);
-#endif
     }
 #ifdef SGR_SEG_TRACE
     SGR_TR(9);
@@ -884,7 +709,6 @@ __device__ __forceinline__ void l1_reduce_block(const LossReduce &r) {
     }
     if (threadIdx.x == 0 && r.loss_total) *r.loss_total = total;
 }
-__global__ __launch_bounds__(1024) void l1_reduce_kernel(LossReduce r) { l1_reduce_block<16>(r); }
 
 // -------------------------------------------------------------------------------------------------
 // B1: bucket-parallel "systolic" backward.  One wave = one bucket of <= 64 consecutive surviving Gaussians of one (tile, quadrant)
@@ -900,6 +724,46 @@ __global__ __launch_bounds__(1024) void l1_reduce_kernel(LossReduce r) { l1_redu
 //   dL/dalpha_j = T_j q_j - (O - Pre_j - w_j q_j) / (1 - alpha_j),   O = out . g (includes the T_final*bg term),
 //   Pre_j = sum_{k<j} w_k q_k  (running), T_{j+1} = T_j (1 - alpha_j)  (bit-identical to the forward's T sequence).
 // -------------------------------------------------------------------------------------------------
+// shift one lane up inside each 16-lane row; lane 0 of every row takes `feed` (DPP row_shr:1 keeps `old` where there is no source)
+__device__ __forceinline__ float row_shift_in(float v, float feed) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, feed), __builtin_bit_cast(int, v),
+                                                                 SGR_DPP_ROW_SHR(1), 0xF, 0xF, false));
+}
+
+
+// The step of the bucket backward's pixel pipeline (render_bwd_bucket_kernel below explains it).  Names taken from the expansion site: gx gy kxx
+// kyy kxy op pstar gidx cr cg cb gdep (my Gaussian), rl (lane & 15), n_alive, pa pb pd (this wave's LDS feeds), the ten sums S1 .. a9, HAS_DA.
+#define SGR_BWD_LOAD(S, FA, FB, FD) { FA = pa[(S)]; FB = pb[(S)]; FD = pd[min((S), n_alive - 1)]; asm volatile("" ::: "memory"); }
+#define SGR_BWD_STEP(IN, OUT, S, fa, fb, fd, NFA, NFB, NFD)                                                             \
+    {                                                                                                                   \
+        const bool has = (uint32_t)((S) - rl) < (uint32_t)n_alive;      /* a stream entry sits in this lane */           \
+        /* the shift is the first use of this step's reads (one wait, nothing else in flight: the compiler's wait counts do not   \
+           survive the loop's back edge, a wait with the next reads already issued would be a wait for them too); THEN the next   \
+           step's reads go out and travel while this step computes */                                                             \
+        OUT.T = row_shift_in(IN.T, fd.x); OUT.Rem = row_shift_in(IN.Rem, fd.y);                                         \
+        SGR_BWD_LOAD((S) + 1, NFA, NFB, NFD)                                                                            \
+        const float dx = gx - fa.x, dy = gy - fa.y;                                                                     \
+        const float p2 = sgr_power2(kxx, kyy, kxy, dx, dy);                                                             \
+        const float G = __builtin_amdgcn_exp2f(p2);                                                                     \
+        const float alpha = fminf(0.99f, op * G);                                                                       \
+        const bool valid = has && gidx < __float_as_uint(fa.z) && p2 <= 0.f && p2 >= pstar;                              \
+        if (valid) {                                                                                                    \
+            const float w = alpha * OUT.T;                                                                              \
+            float qj = sgr_dot3(cr, fa.w, cg, fb.x, cb, fb.y);                                                          \
+            if (HAS_DA) qj += fmaf(gdep, fb.z, fb.w);                                                                   \
+            const float oma = 1.f - alpha;                                                                              \
+            OUT.Rem = fmaf(-w, qj, OUT.Rem);                                                                            \
+            const float dL_dalpha = fmaf(OUT.T, qj, -(OUT.Rem * __builtin_amdgcn_rcpf(oma)));                           \
+            OUT.T *= oma;                                                                                               \
+            const float v = G * dL_dalpha; /* upstream differentiates through op*G even when alpha is capped */         \
+            const float vx = v * dx, vy = v * dy;                                                                       \
+            S1 += v; Sx += vx; Sy += vy;                                                                                \
+            Sxx = fmaf(vx, dx, Sxx); Sxy = fmaf(vx, dy, Sxy); Syy = fmaf(vy, dy, Syy);                                  \
+            if (HAS_DA) aD = fmaf(w, fb.z, aD);                                                                         \
+            a7 = fmaf(w, fa.w, a7); a8 = fmaf(w, fb.x, a8); a9 = fmaf(w, fb.y, a9);                                     \
+        }                                                                                                               \
+    }
+
 // One wave = one bucket of <= 64 consecutive surviving Gaussians of a (tile, quadrant), run as FOUR independent 16-lane
 // pipelines: row r owns survivors 16r..16r+15 and starts from the forward's checkpoint for that row.  The stream of the quadrant's
 // pixels that can still receive something from the bucket enters lane 0 of every row, one pixel per step, and moves one lane up per
@@ -1155,7 +1019,7 @@ int sgr_render_forward_ex(const SgrProblem *pb, const uint32_t *ranges, const ui
                           uint64_t R, void *aux_compact, void *aux_ckpt_tc, void *aux_ckpt_da, void *aux_desc,
                           uint32_t *aux_order, bool prepared, int kind /* 0: choose (sgr_render_forward_kind); else the compositing kernel to
                           use: the depth/alpha checkpoint pass must repeat its forward's */, const SgrFusedL1Args *fused /* NULL, or: the
-                          single-view fused step -- loss, dL/dcolor and the bucket backward inside the segment-parallel kernel */,
+                          single-view fused step -- loss shares and dL/dcolor written by the segment-parallel kernel */,
                           bool bg_done /* the empty tiles' outputs (and loss shares) are already written: SgrBgJob */, void *stream_) {
     if (sgr_validate_problem(pb)) return 1;
     if (kind == 0) kind = sgr_render_forward_kind(pb);
@@ -1173,7 +1037,7 @@ int sgr_render_forward_ex(const SgrProblem *pb, const uint32_t *ranges, const ui
     const size_t n_desc = use_aux ? (size_t)4 * aux.NS : 0;
     const bool prep = seg && (aux_order || (use_aux && n_desc <= (1u << 17)));     // one workgroup orders the tiles and clears the descriptors
     if (da_pass && !prepared) { sgr_set_error("sgr_render_forward: the depth/alpha checkpoint pass must run on a prepared forward"); return 1; }
-    if (fused && !(seg && use_aux && aux_ckpt_tc && !aux_ckpt_da && (kSegWaves == 8 || !fused->backward_inside))) { sgr_set_error("sgr_render_forward: the fused step needs the segment-parallel kernel with row checkpoints and no depth/alpha checkpoints"); return 1; }
+    if (fused && !(seg && use_aux && aux_ckpt_tc && !aux_ckpt_da)) { sgr_set_error("sgr_render_forward: the fused step needs the segment-parallel kernel with row checkpoints and no depth/alpha checkpoints"); return 1; }
     if (use_aux && !(prep && n_desc <= (1u << 17)) && !prepared) SGR_CHECK_HIP(hipMemsetAsync(aux_desc, 0, n_desc * sizeof(uint2), stream));
     SgrProfScope _p(SGR_K_RENDER_FWD, stream);
     if (prep && !prepared) {                                    // (prepared: the tile-sort launch's spare workgroup already did it)
@@ -1191,21 +1055,11 @@ int sgr_render_forward_ex(const SgrProblem *pb, const uint32_t *ranges, const ui
         memset(&fz, 0, sizeof(fz));
         if (fused) {
             fz.target = fused->target; fz.mask = fused->mask; fz.weight = fused->weight; fz.gimg = fused->gimg; fz.loss_part = fused->loss_part;
-            if (fused->backward_inside) { fz.rect = (const uint4 *)fused->rect; fz.part = (float4 *)fused->part; fz.flags = (uint8_t *)fused->flags; }
         }
-        if (!use_aux) SGR_LAUNCH_SEG(0); else if (!fused) SGR_LAUNCH_SEG(2); else if (!fused->backward_inside) SGR_LAUNCH_SEG(3); else {
-#if SGR_SEG_WAVES == 8
-            SGR_LAUNCH_SEG(4);
-#endif
-        }
+        if (!use_aux) SGR_LAUNCH_SEG(0); else if (!fused) SGR_LAUNCH_SEG(2); else SGR_LAUNCH_SEG(3);
 #undef SGR_LAUNCH_SEG
         SGR_CHECK_LAUNCH("render_fwd_seg_kernel");
-        if (fused && fused->backward_inside) {      // (else: the bucket backward queued behind this launch sums the loss shares on the side)
-            LossReduce lr = {fused->loss_part, fused->loss_per_view, fused->loss_total, tiles * 4u, pb->n_views, 0u};
-            hipLaunchKernelGGL(l1_reduce_kernel, dim3(1), dim3(1024), 0, stream, lr);
-            SGR_CHECK_LAUNCH("l1_reduce_kernel");
-        }
-        return 0;
+        return 0;                      // (fused: the bucket backward queued behind this launch sums the loss shares on the side)
     }
     const uint32_t wgrid = (uint32_t)((tiles_total + 7) / 8) * 32u;          // 8 tiles x 4 quadrants per group of 32 ids
 #define SGR_LAUNCH_WAVE(A)                                                                                                  \

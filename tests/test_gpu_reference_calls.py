@@ -518,9 +518,9 @@ def test_cpp_batched_l1_node_equals_python_node(S, V, mode):
     """rasterize_l1_loss_batched routes the reference's input flavour in the explicit sync-free mode to the C++ node (csrc/torch_node.cpp):
     same loss, per-view losses, images and gradients as the Python node, bit for bit.  The Python node always runs the UNFUSED chain
     (compositing, loss kernel, compositing backward, gather); at these sizes (<= 2048 tiles) the C++ node takes the FUSED single-view step
-    (loss + dL/dcolor + the compositing backward inside the compositing kernel, csrc/render.hip FusedL1): its partial records are for
-    dL/dloss = 1 and the gather multiplies the upstream scalar in, so gradients are bit-identical for an upstream gradient of 1 and equal
-    to the last bits otherwise; with a second gradient into the colour (or depth / alpha) the node falls back to the unfused backward."""
+    (loss shares + dL/dcolor from the compositing kernel, the compositing backward of dL/dloss = 1 queued by the forward call, csrc/render.hip
+    FusedL1): the gather multiplies the upstream scalar in, so gradients are bit-identical for an upstream gradient of 1 and equal to the
+    last bits otherwise; with a second gradient into the colour (or depth / alpha) the node falls back to the unfused backward."""
     from sigman_release_amd import _cabi, rasterizer as R
     if _cabi.torch_node() is None:
         pytest.skip("sgr_torch_node.so not built / SIGMAN_PY_NODE=1")
@@ -554,14 +554,17 @@ def test_cpp_batched_l1_node_equals_python_node(S, V, mode):
     R.check_pending_overflows(True)
 
 
-@pytest.mark.parametrize("P,H,W,V,use_mask", [(20000, 256, 256, 1, True), (6000, 128, 144, 2, False), (3000, 100, 90, 1, True)])
-def test_fused_single_view_step_equals_unfused_chain(P, H, W, V, use_mask):
-    """The fused single-view step (SgrL1Epilogue.fuse_backward) against the unfused chain through the SAME C++ node (sgr_set_fused_step 0):
-    flavour 1 (loss shares + dL/dcolor inside the segment-parallel compositing kernel, the bucket backward queued behind it by the forward
-    call, the caller's backward only gathers): images, radii and gradients bit for bit with dL/dloss = 1, the loss to the order of its
-    additions; flavour 2 (the bucket backward inside the compositing kernel too: one wave per bucket instead of the split pair, i.e. another
-    order of the pixel sums): gradients to the last bits.  A second backward on the same forward (gather only, twice) repeats the first; a
-    backward with a gradient into the colour as well falls back to the unfused backward and is bit-identical to the unfused chain's."""
+@pytest.mark.parametrize("P,H,W,V,use_mask,sort_mode", [(20000, 256, 256, 1, True, 3), (6000, 128, 144, 2, False, 3), (3000, 100, 90, 1, True, 3),
+                                                        (6000, 128, 144, 2, True, 4)])
+def test_fused_single_view_step_equals_unfused_chain(P, H, W, V, use_mask, sort_mode):
+    """The fused single-view step (SgrL1Epilogue.fuse_backward: loss shares + dL/dcolor inside the segment-parallel compositing kernel, the
+    background's share pre-filled by the wide row scan's spare workgroups, the bucket backward queued behind the compositing kernel by the
+    forward call with the loss reduction in its spare workgroup, the caller's backward only gathers) against the unfused chain through the
+    SAME C++ node (sgr_set_fused_step 0): images, radii and gradients bit for bit with dL/dloss = 1, the loss to the order of its additions.
+    A second backward on the same forward (gather only, twice) repeats the first; a backward with a gradient into the colour as well falls
+    back to the unfused backward and is bit-identical to the unfused chain's; the fused loss is bitwise reproducible from run to run.
+    sort_mode 4: a binning flavour without the wide row scan, i.e. without the background pre-fill -- the compositing kernel's own empty-tile
+    workgroups then write the background's loss shares and dL/dcolor."""
     from sigman_release_amd import _cabi, rasterizer as R
     if _cabi.torch_node() is None:
         pytest.skip("sgr_torch_node.so not built / SIGMAN_PY_NODE=1")
@@ -572,7 +575,8 @@ def test_fused_single_view_step_equals_unfused_chain(P, H, W, V, use_mask):
     L = _cabi.lib()
     res = {}
     try:
-        for fused in (0, 1, 2):
+        assert L.sgr_set_sort_mode(sort_mode) == 0
+        for fused in (0, 1, 1):
             L.sgr_set_fused_step(fused)
             for flavour in ("loss", "loss+color"):
                 d = {k: v.clone().requires_grad_(True) for k, v in base.items()}
@@ -589,19 +593,20 @@ def test_fused_single_view_step_equals_unfused_chain(P, H, W, V, use_mask):
                     for a, b in zip(g1, g2):
                         assert torch.equal(a, b), "a second backward on the same forward must repeat the first"
                 torch.cuda.synchronize()
+                if (fused, flavour) in res:         # the second fused run: everything repeats bit for bit, the loss included (no atomics)
+                    for a, b in zip(res[(fused, flavour)], [x.detach() for x in (loss, per_view, color, radii, depth, alpha)] + g1):
+                        assert torch.equal(a, b)
                 res[(fused, flavour)] = [x.detach().clone() for x in (loss, per_view, color, radii, depth, alpha)] + g1
     finally:
         L.sgr_set_fused_step(1)
-    for fused in (1, 2):
-        for flavour in ("loss", "loss+color"):
-            for i, (a, b) in enumerate(zip(res[(0, flavour)], res[(fused, flavour)])):
-                if i < 2:
-                    assert torch.allclose(a, b, rtol=1e-5, atol=0.0), (fused, flavour, i, a, b)
-                elif fused == 2 and flavour == "loss" and i >= 6:
-                    assert torch.allclose(a, b, rtol=2e-5, atol=2e-6 * float(a.abs().max())), (fused, flavour, i, float((a - b).abs().max()), float(a.abs().max()))
-                else:
-                    assert torch.equal(a, b), (fused, flavour, i, float((a.float() - b.float()).abs().max()))
-        assert float(res[(fused, "loss")][6].abs().max()) > 0.0
+        L.sgr_set_sort_mode(3)
+    for flavour in ("loss", "loss+color"):
+        for i, (a, b) in enumerate(zip(res[(0, flavour)], res[(1, flavour)])):
+            if i < 2:
+                assert torch.allclose(a, b, rtol=1e-5, atol=0.0), (flavour, i, a, b)
+            else:
+                assert torch.equal(a, b), (flavour, i, float((a.float() - b.float()).abs().max()))
+    assert float(res[(1, "loss")][6].abs().max()) > 0.0
     R.check_pending_overflows(True)
 
 

@@ -41,7 +41,7 @@ fwd(); torch.cuda.synchronize()
 raw = buf.cpu().numpy().astype(np.uint64)
 b = raw[:NS * 4 * NE].reshape(NS, 4, NE)
 sch = raw[NS * 4 * NE:].reshape(TILES, 4, 8)
-names = {1: "start", 2: "loop", 3: "fill", 4: "phase1", 5: "prefix", 6: "phase2", 7: "book", 8: "done", 9: "written", 10: "bwd-barrier", 11: "bwd-bucket", 12: "bwd-end"}
+names = {1: "start", 2: "loop", 3: "fill", 4: "phase1", 5: "prefix", 6: "phase2", 7: "book", 8: "done", 9: "written"}
 t00 = None
 for s in range(NS):
     for q in range(4):
@@ -87,13 +87,3 @@ print("start times of working workgroups (us), every 53rd:", [round(x, 1) for x 
 durs = sorted(((r[1] - r[0]) / 100.0, r[4]) for r in work)
 print("durations (us, n): shortest", durs[:3], "median", durs[len(durs) // 2], "longest", durs[-3:])
 
-if FUSED:
-    fw = sorted(((r[9] - r[0]) / 100.0, (r[1] - r[9]) / 100.0, r[4], r[10]) for r in work if r[9])
-    print("fused: (forward us, backward us, n, buckets) shortest fwd", fw[:3], "median", fw[len(fw) // 2], "longest", fw[-3:])
-    bw = sorted(((r[1] - r[9]) / 100.0, r[10], r[4]) for r in work if r[9])
-    print("fused: backward phase (us, buckets, n): shortest", bw[:3], "median", bw[len(bw) // 2], "longest", bw[-5:])
-    import collections as _c
-    by_nb = _c.defaultdict(list)
-    for d, nb, n in bw: by_nb[min(nb, 17)].append(d)
-    print("fused: mean backward-phase us by bucket count:", {k: (len(v), round(sum(v) / len(v), 1)) for k, v in sorted(by_nb.items())})
-    print("fused: backward-phase start times (us), every 53rd:", [round((r[9] - t0) / 100.0, 1) for r in sorted(work, key=lambda r: r[9])[::53]])
