@@ -307,10 +307,7 @@ constexpr int kWideBits = 11, kWide = 1 << kWideBits;
 // digit total.  Every wave first sums its blocks, the 16 partial sums per digit meet in LDS, then it rewrites its blocks with the
 // running prefix -- blocks interleave, so wave w's block b needs the sums of ALL waves over blocks < b: done in two phases over
 // contiguous block ranges instead (wave w owns blocks [w * per, (w + 1) * per)).
-__global__ __launch_bounds__(1024) void wide_rowscan_kernel(uint32_t *__restrict__ hist, uint32_t nblocks, uint32_t *__restrict__ totals, SgrBgJob bg) {
-    // (workgroups behind the kWide / 64 that scan: the background pre-fill of the fused step -- common.h SgrBgJob; this launch keeps 32 CUs busy
-    // for its 5 us and the fill needs nothing it produces)
-    if (blockIdx.x >= kWide / 64) { if (bg.enabled) sgr_bg_fill(bg, (blockIdx.x - kWide / 64) * 4u + (threadIdx.x >> 8), (gridDim.x - kWide / 64) * 4u); return; }
+__global__ __launch_bounds__(1024) void wide_rowscan_kernel(uint32_t *__restrict__ hist, uint32_t nblocks, uint32_t *__restrict__ totals) {
     __shared__ uint32_t part[16][64];
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, d = blockIdx.x * 64 + lane;
     const uint32_t per = (nblocks + 15u) / 16u, b0 = min(nblocks, wave * per), b1 = min(nblocks, b0 + per);
@@ -1545,9 +1542,7 @@ int sgr_bin_ex(const SgrProblem *pb, const int32_t *radii, uint32_t *rect,
                uint64_t *keys_b, uint32_t *vals_a, uint32_t *vals_b, void *workspace, size_t workspace_bytes,
                uint32_t *ranges, int32_t *result_in_b_host, bool self_scan, uint64_t *nr_host, void *prep_desc, size_t prep_n_desc,
                uint32_t *prep_order, int *prep_done, uint32_t *const *clear_ptr /*[2] or NULL*/, const uint64_t *clear_words /*[2]*/,
-               int *clear_done /*[2]*/, bool first_index, bool sorted_keys, const SgrBgJob *bg_job /* optional: background pre-fill of every tile ... */,
-               int *bg_done /* ... set to 1 if a launch of this call took it on (the single wide tile pass has room for it) */, void *stream_) {
-    if (bg_done) *bg_done = 0;
+               int *clear_done /*[2]*/, bool first_index, bool sorted_keys, void *stream_) {
     if (sgr_validate_problem(pb)) return 1;
     hipStream_t stream = (hipStream_t)stream_;
     const int Tx = (pb->W + SGR_TILE - 1) / SGR_TILE, Ty = (pb->H + SGR_TILE - 1) / SGR_TILE;
@@ -1684,11 +1679,7 @@ int sgr_bin_ex(const SgrProblem *pb, const int32_t *radii, uint32_t *rect,
     if (mode == 5) {
         uint32_t *wl = (uint32_t *)((char *)workspace + sgr_bin_workspace_bytes(R, 0));     // [16 counters][6][tiles_total]
         { SgrProfScope _ps(SGR_K_SORT, stream);
-        SgrBgJob bgj;
-        memset(&bgj, 0, sizeof(bgj));
-        if (bg_job && bg_job->enabled) { bgj = *bg_job; if (bg_done) *bg_done = 1; }
-        hipLaunchKernelGGL(wide_rowscan_kernel, dim3(kWide / 64 + (bgj.enabled ? (bgj.tiles_total + 3u) / 4u : 0u)), dim3(1024), 0, stream, hist, nblk_e,
-                           hist + (size_t)nblk_e * kWide, bgj);
+        hipLaunchKernelGGL(wide_rowscan_kernel, dim3(kWide / 64), dim3(1024), 0, stream, hist, nblk_e, hist + (size_t)nblk_e * kWide);
         hipLaunchKernelGGL(wide_downsweep_runs_kernel<kItemsSmall>, dim3(nblk_e), dim3(kThreads), 0, stream, kin, vin, kout, blk_runs, hist,
                            hist + (size_t)nblk_e * kWide, (uint2 *)ranges, (uint32_t)tiles_total, wl, g_deep_max_windows);
         SGR_CHECK_LAUNCH("wide tile-bit pass (emitted rows)");
@@ -1737,6 +1728,5 @@ extern "C" int sgr_bin(const SgrProblem *pb, const int32_t *radii, uint32_t *rec
                        uint64_t *keys_b, uint32_t *vals_a, uint32_t *vals_b, void *workspace, size_t workspace_bytes,
                        uint32_t *ranges, int32_t *result_in_b_host, void *stream_) {
     return sgr_bin_ex(pb, radii, rect, block_offsets, R, num_rendered_dev, keys_a, keys_b, vals_a, vals_b, workspace,
-                      workspace_bytes, ranges, result_in_b_host, false, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, /*first_index=*/true, /*sorted_keys=*/true,
-                      nullptr, nullptr, stream_);
+                      workspace_bytes, ranges, result_in_b_host, false, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, /*first_index=*/true, /*sorted_keys=*/true, stream_);
 }

@@ -69,12 +69,13 @@ struct SgrFusedL1Args {
 };
 
 // The EMPTY tiles of a one- or two-view launch (812 of the 1024 tiles of a 512^2 humanoid view) only receive the background -- and, in the
-// fused step, contribute the background's loss share and dL/dcolor.  None of that depends on the Gaussians, so in the fused step EVERY tile
-// is pre-filled with it by extra workgroups of an early launch that leaves the chip idle (the row scan of the single wide tile pass: 32
-// workgroups, 5 us); the compositing kernel overwrites the occupied tiles and its empty-tile workgroups leave at once -- instead of 812 of
-// them trickling through its tail, each living through a load round trip (C2: 3.8 us).  Measured alternatives: idle workgroups of the
-// per-tile sort launch (knows the ranges, fills only the empty tiles): that launch 10.3 -> 13.7 us; extra workgroups of the preprocess
-// launch: 7.4 -> 8.5 us (the fill's 14 MB compete with its streams); without the loss the compositing kernel's own empty-tile path costs 0.2 us.
+// fused step, contribute the background's loss share and dL/dcolor.  None of that depends on the Gaussians, so in the fused step (sync-free
+// mode: the image blob exists before anything is launched) EVERY tile is pre-filled with it by extra workgroups of the preprocess launch, the
+// first kernel of the chain (7.4 -> 8.6 us at C2); the compositing kernel overwrites the occupied tiles and its empty-tile workgroups leave
+// at once -- instead of 812 of them trickling through its tail, each living through a load round trip (C2: 3.8 us).  Measured alternatives:
+// idle workgroups of the per-tile sort launch (knows the ranges, fills only the empty tiles): that launch 10.3 -> 13.7 us; extra workgroups
+// of the wide row scan (32 working workgroups, 5 us): 5.1 -> 6.9 us -- the fill is the loss kernel's traffic (14 MB) and hides nowhere
+// completely; without the loss the compositing kernel's own empty-tile path costs 0.2 us, so the pre-fill is only used by the fused step.
 struct SgrBgJob {
     int enabled, W, H, Tx;
     uint32_t tiles_per_view, tiles_total;

@@ -223,7 +223,9 @@ __global__ __launch_bounds__(kPreThreads) void preprocess_fwd_kernel(SgrProblem 
                                                                      int32_t *__restrict__ radii,
                                                                      uint4 *__restrict__ rect,
                                                                      uint8_t *__restrict__ clamped,
-                                                                     uint32_t *__restrict__ block_sums) {
+                                                                     uint32_t *__restrict__ block_sums, int nbx, SgrBgJob bg) {
+    // (workgroups behind the nbx that own Gaussians: the background pre-fill of the fused single-view step, common.h SgrBgJob)
+    if ((int)blockIdx.x >= nbx) { if (blockIdx.y == 0 && bg.enabled) sgr_bg_fill(bg, blockIdx.x - (uint32_t)nbx, gridDim.x - (uint32_t)nbx); return; }
     // One thread per Gaussian, looping over `views_per_wg` consecutive views: the per-Gaussian inputs (52 B: mean, covariance, opacity,
     // colour) stay in registers across the views of a subject.  With one view per workgroup a 90-view launch re-read them from HBM
     // 90 times (PMC at C4: 0.94 GB of reads beside 1.5 GB of writes).
@@ -362,7 +364,7 @@ __global__ __launch_bounds__(kPreThreads) void preprocess_fwd_kernel(SgrProblem 
         __builtin_amdgcn_wave_barrier();
     }
     const uint32_t tot = block_sum_u32(tiles, red[(view - v0) & 1]);   // alternating slots: one barrier per view is enough
-    if (threadIdx.x == 0) block_sums[(size_t)view * gridDim.x + blockIdx.x] = tot;
+    if (threadIdx.x == 0) block_sums[(size_t)view * nbx + blockIdx.x] = tot;
     }
 }
 
@@ -776,7 +778,8 @@ extern "C" int32_t sgr_preprocess_blocks_per_view(int32_t P) { return P <= 0 ? 1
 
 // skip_scan: leave the per-workgroup counts un-scanned behind block_offsets; sgr_bin_ex(self_scan = true) folds F2 into F3
 int sgr_preprocess_forward_ex(const SgrProblem *pb, float *rec, int32_t *radii, uint32_t *rect, uint8_t *clamped,
-                              uint32_t *block_offsets, uint64_t *num_rendered, uint64_t capacity, bool skip_scan, void *stream_) {
+                              uint32_t *block_offsets, uint64_t *num_rendered, uint64_t capacity, bool skip_scan,
+                              const SgrBgJob *bg /* optional: background pre-fill by extra workgroups of this launch (fused single-view step) */, void *stream_) {
     if (validate_problem(pb)) return 1;
     if (capacity == 0) capacity = ~0ull;
     hipStream_t stream = (hipStream_t)stream_;
@@ -790,10 +793,13 @@ int sgr_preprocess_forward_ex(const SgrProblem *pb, float *rec, int32_t *radii, 
     int vpw = 1;
     while (vpw < 8 && vpw * 2 <= pb->views_per_subject && (size_t)nbx * ((pb->n_views + vpw * 2 - 1) / (vpw * 2)) >= 4096) vpw *= 2;
     if (g_view_group > 0) vpw = g_view_group < pb->n_views ? g_view_group : pb->n_views;
-    dim3 grid(nbx, (pb->n_views + vpw - 1) / vpw);
+    SgrBgJob bgj;
+    memset(&bgj, 0, sizeof(bgj));
+    if (bg && bg->enabled) bgj = *bg;
+    dim3 grid(nbx + (bgj.enabled ? (int)bgj.tiles_total : 0), (pb->n_views + vpw - 1) / vpw);
     { SgrProfScope _p(SGR_K_PREPROCESS_FWD, stream);
     hipLaunchKernelGGL(preprocess_fwd_kernel, grid, dim3(kPreThreads), 0, stream, *pb, vpw, (float4 *)rec, radii, (uint4 *)rect,
-                       clamped, sums);
+                       clamped, sums, nbx, bgj);
     SGR_CHECK_LAUNCH("preprocess_fwd_kernel");
     }
     if (skip_scan) return 0;
@@ -807,7 +813,7 @@ int sgr_preprocess_forward_ex(const SgrProblem *pb, float *rec, int32_t *radii, 
 
 extern "C" int sgr_preprocess_forward(const SgrProblem *pb, float *rec, int32_t *radii, uint32_t *rect, uint8_t *clamped,
                                       uint32_t *block_offsets, uint64_t *num_rendered, uint64_t capacity, void *stream_) {
-    return sgr_preprocess_forward_ex(pb, rec, radii, rect, clamped, block_offsets, num_rendered, capacity, false, stream_);
+    return sgr_preprocess_forward_ex(pb, rec, radii, rect, clamped, block_offsets, num_rendered, capacity, false, nullptr, stream_);
 }
 
 // 0 = automatic (lanes over views on the colors_precomp path when views_per_subject is a power of two in 2..256), 1 = always the

@@ -24,12 +24,12 @@ static int sgr_fused_step_enabled() { return g_fused_step; }
 static thread_local int g_keep_sorted_keys = 0;     // thread-local like sgr_set_debug: forward_debug() toggles it around ONE call
 extern "C" int sgr_set_keep_sorted_keys(int keep) { const int old = g_keep_sorted_keys; g_keep_sorted_keys = keep ? 1 : 0; return old; }
 int sgr_preprocess_forward_ex(const SgrProblem *pb, float *rec, int32_t *radii, uint32_t *rect, uint8_t *clamped, uint32_t *block_offsets,
-                              uint64_t *num_rendered, uint64_t capacity, bool skip_scan, void *stream_);
+                              uint64_t *num_rendered, uint64_t capacity, bool skip_scan, const SgrBgJob *bg, void *stream_);
 int sgr_bin_ex(const SgrProblem *pb, const int32_t *radii, uint32_t *rect, const uint32_t *block_offsets, uint64_t R,
                const uint64_t *num_rendered_dev, uint64_t *keys_a, uint64_t *keys_b, uint32_t *vals_a, uint32_t *vals_b, void *workspace,
                size_t workspace_bytes, uint32_t *ranges, int32_t *result_in_b_host, bool self_scan, uint64_t *nr_host, void *prep_desc,
                size_t prep_n_desc, uint32_t *prep_order, int *prep_done, uint32_t *const *clear_ptr, const uint64_t *clear_words,
-               int *clear_done, bool first_index, bool sorted_keys, const SgrBgJob *bg_job, int *bg_done, void *stream_);
+               int *clear_done, bool first_index, bool sorted_keys, void *stream_);
 int sgr_render_backward_ex(const SgrProblem *pb, const uint32_t *ranges, const float *rec, const uint32_t *rect,
                            const uint32_t *n_contrib, const float *out_color, const float *out_depth, const float *out_alpha,
                            const float *grad_color, const float *grad_depth, const float *grad_alpha, const float *grad_color_scale,
@@ -61,12 +61,12 @@ static int forward_launches(const SgrProblem *pb, uint64_t capacity, uint64_t R,
     // caller's pinned slot are folded into the duplicate kernel (three launches fewer)
     const uint64_t nblk = (uint64_t)sgr_preprocess_blocks_per_view(pb->P) * pb->n_views;
     const bool self_scan = !preprocess_done && capacity > 0 && nblk <= 2048;
-    // the fused step: every tile is pre-filled with the background, its loss shares and dL/dcolor by extra workgroups of an early launch of the
-    // binning (bg_done says whether the flavour had room for it; common.h SgrBgJob); the compositing kernel's empty tiles then have nothing to do
+    // the fused step, sync-free mode (preprocess has not run yet): every tile is pre-filled with the background, its loss shares and dL/dcolor by
+    // extra workgroups of the preprocess launch (common.h SgrBgJob); the compositing kernel's empty tiles then have nothing to do (bg_done)
     SgrBgJob bgj;
     memset(&bgj, 0, sizeof(bgj));
     int bg_done = 0;
-    if (st->fused_bwd) {
+    if (st->fused_bwd && !preprocess_done) {
         bgj.enabled = 1; bgj.W = pb->W; bgj.H = pb->H; bgj.Tx = (pb->W + SGR_TILE - 1) / SGR_TILE;
         bgj.tiles_per_view = (uint32_t)bgj.Tx * (uint32_t)((pb->H + SGR_TILE - 1) / SGR_TILE);
         bgj.tiles_total = bgj.tiles_per_view * (uint32_t)pb->n_views;
@@ -74,9 +74,10 @@ static int forward_launches(const SgrProblem *pb, uint64_t capacity, uint64_t R,
         bgj.final_T = (float *)(image + st->off_final_T); bgj.n_contrib = (uint32_t *)(image + st->off_n_contrib); bgj.clamped = pb->color_clamped;
         if (st->fused_bwd) { bgj.target = l1->target; bgj.mask = l1->mask; bgj.weight = l1->weight; bgj.gimg = l1->grad_color;
                              bgj.loss_part = (float *)(image + st->off_loss_part); }
+        bg_done = 1;
     }
     if (!preprocess_done) {
-        if (sgr_preprocess_forward_ex(pb, rec, out_radii, rect, clamped, block_offsets, num_rendered, capacity, self_scan, stream)) return 1;
+        if (sgr_preprocess_forward_ex(pb, rec, out_radii, rect, clamped, block_offsets, num_rendered, capacity, self_scan, bg_done ? &bgj : nullptr, stream)) return 1;
         if (nr_pinned_host && !self_scan) SGR_CHECK_HIP(hipMemcpyAsync(nr_pinned_host, num_rendered + 2, 8, hipMemcpyDeviceToHost, stream));   // count | overflow << 63
         st->nr_by_copy = self_scan ? 0 : 1;
     }
@@ -96,7 +97,7 @@ static int forward_launches(const SgrProblem *pb, uint64_t capacity, uint64_t R,
                    binning + st->off_sort_ws, (size_t)sgr_bin_workspace_bytes(R, (uint64_t)((pb->W + SGR_TILE - 1) / SGR_TILE) * ((pb->H + SGR_TILE - 1) / SGR_TILE) * pb->n_views),
                    (uint32_t *)(image + st->off_ranges), &in_b, self_scan, self_scan ? nr_pinned_host : nullptr,
                    want_prep && aux_on ? image + st->off_desc : nullptr, n_desc, want_prep ? (uint32_t *)(image + st->off_order) : nullptr,
-                   &prep_done, clear_ptr, clear_words, clear_done, /*first_index=*/aux_on, /*sorted_keys=*/g_keep_sorted_keys != 0, bgj.enabled ? &bgj : nullptr, &bg_done, stream)) return 1;
+                   &prep_done, clear_ptr, clear_words, clear_done, /*first_index=*/aux_on, /*sorted_keys=*/g_keep_sorted_keys != 0, stream)) return 1;
     st->flags_cleared = clear_done[0];
     if (caller_clear && caller_clear_bytes && !clear_done[1]) SGR_CHECK_HIP(hipMemsetAsync(caller_clear, 0, (size_t)caller_clear_bytes, stream));
     st->result_in_b = in_b;

@@ -403,6 +403,13 @@ def _forward_impl(means3D, opacities, colors_precomp, shs, cov3D_precomp, scales
     return color, radii, depth, alpha, ctx
 
 
+_GATHER_ONLY = object()       # grad_color marker for _backward_impl: sgr_rasterize_backward with grad_color = NULL (include/sigman_gsplat.h)
+# The Python node of the fused rasterizer + L1 loss runs the UNFUSED chain (compositing, loss kernel, compositing backward, gather): it is the
+# reference the C++ node's fused single-view step is compared with, bit for bit.  True (tests): it asks for the fused step as well, which
+# brings the flavours the C++ node does not take (SH, scales + rotations, exact mode) through SgrL1Epilogue.fuse_backward.
+FUSE_STEP_IN_PYTHON_NODE = False
+
+
 def _backward_impl(ctx: _Ctx, means3D, opacities, colors_precomp, shs, cov3D_precomp, scales, rotations,
                    st: BatchedRasterizationSettings, grad_color, grad_depth, grad_alpha, img, grad_color_scale=None, want_means2D=True):
     L = _cabi.lib()
@@ -412,9 +419,12 @@ def _backward_impl(ctx: _Ctx, means3D, opacities, colors_precomp, shs, cov3D_pre
     pb = ctx.pb
     if pb.means3D != _ptr(means3D):      # (cannot happen through autograd; guards direct callers that pass other tensors)
         pb = _make_problem(means3D, opacities, colors_precomp, shs, cov3D_precomp, scales, rotations, st)
-    if grad_color is None:
-        grad_color = torch.zeros(nv, 3, H, W, dtype=f32, device=dev)
-    gC = _f32c(grad_color)
+    if grad_color is _GATHER_ONLY:      # a fused forward (state.fused_bwd) already ran the compositing backward of its own loss: gather, scaled
+        gC = None
+    else:
+        if grad_color is None:
+            grad_color = torch.zeros(nv, 3, H, W, dtype=f32, device=dev)
+        gC = _f32c(grad_color)
     gD = None if grad_depth is None else _f32c(grad_depth)
     gA = None if grad_alpha is None else _f32c(grad_alpha)
     d_means3D = torch.empty(S, P, 3, dtype=f32, device=dev)
@@ -533,7 +543,8 @@ class _RasterizeL1Batched(torch.autograd.Function):
             keep[:] = [gimg, tgt, msk]
             p = sums.data_ptr()
             return _cabi.SgrL1Epilogue(target=_ptr(tgt), mask=_ptr(msk), grad_color=gimg.data_ptr(), loss_per_view=p, loss_total=p + 4 * nv,
-                                       weight=float(weight), sums_already_zero=1)
+                                       weight=float(weight), sums_already_zero=1,
+                                       fuse_backward=1 if (FUSE_STEP_IN_PYTHON_NODE and not getattr(st, "depth_alpha_grads", None)) else 0)
 
         color, radii, depth, alpha = _fwd_common(ctx, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, st,
                                                  lambda _color: (keep[0],), clear=sums, l1=l1)
@@ -545,6 +556,8 @@ class _RasterizeL1Batched(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_loss, g_per_view, g_color, g_radii, g_depth, g_alpha):
         gimg = ctx.saved_tensors[10]
+        if ctx.sgr.state.fused_bwd and g_loss is not None and g_color is None and g_depth is None and g_alpha is None:
+            return _bwd_common(ctx, _GATHER_ONLY, None, None, g_loss.reshape(1).to(torch.float32)) + (None, None, None, None)
         if g_loss is None and g_color is None:
             g_color, scale = torch.zeros_like(gimg), None
         elif g_color is None:

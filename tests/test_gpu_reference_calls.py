@@ -610,6 +610,51 @@ def test_fused_single_view_step_equals_unfused_chain(P, H, W, V, use_mask, sort_
     R.check_pending_overflows(True)
 
 
+@pytest.mark.parametrize("flavour,cap", [("sh+scales", 300000), ("colors+cov", 0), ("sh+scales", 0)])
+def test_fused_single_view_step_other_input_flavours_and_exact_mode(flavour, cap):
+    """The fused single-view step is decided below the C ABI (sgr_rasterize_forward_l1 with SgrL1Epilogue.fuse_backward), for every input
+    flavour and capacity mode; the C++ node only takes colours + covariances in the sync-free mode.  Through the Python node with
+    rasterizer.FUSE_STEP_IN_PYTHON_NODE: spherical harmonics + scales / rotations, and the exact mode (max_rendered = 0: preprocess runs before
+    the image blob exists, so the background is not pre-filled and the compositing kernel's own empty-tile workgroups write its loss shares
+    and dL/dcolor) -- loss, images and gradients against the same node unfused, bit for bit at dL/dloss = 1."""
+    from sigman_release_amd import rasterizer as R
+    import cases
+    dev = _dev()
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    if flavour == "sh+scales":
+        inp, st = cases.cloud_sh(P=2000, H=96, W=112, seed=6, views=(30, 53))
+    else:
+        inp, st = cases.humanoid(P=5000, H=128, W=144, seed=4, views=(30, 65))
+    nv = np.asarray(st["viewmatrix"]).reshape(-1, 16).shape[0]
+    bst = R.BatchedRasterizationSettings(st["image_height"], st["image_width"], st["tanfovx"], st["tanfovy"], t(st["bg"]), float(st["scale_modifier"]),
+                                         t(np.asarray(st["viewmatrix"]).reshape(nv, 16)), t(np.asarray(st["projmatrix"]).reshape(nv, 16)), int(st["sh_degree"]),
+                                         t(np.asarray(st["campos"]).reshape(nv, 3)), nv, False, cap)
+    H, W = st["image_height"], st["image_width"]
+    g = torch.Generator(device=dev).manual_seed(9)
+    target = torch.rand(nv, 3, H, W, device=dev, generator=g)
+    mask = (torch.rand(nv, 1, H, W, device=dev, generator=g) > 0.25).float()
+    res = []
+    try:
+        for fuse in (False, True):
+            R.FUSE_STEP_IN_PYTHON_NODE = fuse
+            d = {k: t(v)[None].requires_grad_(True) for k, v in inp.items()}
+            op = d["opacities"][..., None] if d["opacities"].dim() == 2 else d["opacities"]
+            out = R._RasterizeL1Batched.apply(d["means3D"], None, d.get("shs"), d.get("colors_precomp"), op, d.get("scales"), d.get("rotations"),
+                                              d.get("cov3D_precomp"), bst, target, mask, 0.5)
+            out[0].backward()
+            torch.cuda.synchronize()
+            res.append([x.detach().clone() for x in out] + [d[k].grad.clone() for k in sorted(d)])
+    finally:
+        R.FUSE_STEP_IN_PYTHON_NODE = False
+    assert len(res[0]) > 8 and float(res[1][0]) > 0.0
+    for i, (a, b) in enumerate(zip(*res)):
+        if i < 2:
+            assert torch.allclose(a, b, rtol=1e-5, atol=0.0), (i, a, b)
+        else:
+            assert torch.equal(a, b), (i, float((a.float() - b.float()).abs().max()))
+    R.check_pending_overflows(True)
+
+
 def test_cpp_batched_l1_node_overflow_and_no_grad():
     """A forward that does not fit its explicit capacity raises from its own backward; without a backward, from check_pending_overflows();
     under torch.no_grad() from the forward itself -- the Python node's behaviour."""
