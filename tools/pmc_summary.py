@@ -49,6 +49,9 @@ def main():
     alg = {"preprocess_fwd+scan": 84 * nq, "duplicate_keys": 20 * nq + 12 * Rn, "radix_sort(all passes)": 24 * Rn,
            "tile_ranges": 8 * Rn + 8 * tiles, "render_fwd": 44 * Rn + 24 * HW, "render_bwd": 88 * Rn + 28 * HW, "preprocess_bwd": 108 * nq,
            "clamped_l1": (40 if "masked" in c["workload"] else 36) * HW}
+    if c.get("fused_step"):
+        # the fused single-view step: no loss launch -- the compositing kernel also reads the target (+ mask) and writes dL/dcolor (bench.py)
+        alg["render_fwd"] += (28 if "masked" in c["workload"] else 24) * HW
     # launches per step: total calls / steps is unreliable under warm-up; use median KB per launch x launches of one step (= kernels that share a group)
     out = {"config": cfg, "P": P, "size": size, "view_slots": slots, "num_rendered": Rn,
            "command": f"rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- python bench.py --config {cfg} "
