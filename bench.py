@@ -34,7 +34,7 @@ timed instead and the line says so (`steps` = what was timed, `steps_requested` 
 events on the launch stream (first kernel to last kernel: it excludes the host's final synchronise, not the gaps the host may leave between
 steps); `windows` repeats the K steps `--windows` more times and reports min / median / max per step of wall and event time, so that a slow
 phase of the box or of its clocks shows up as spread instead of being folded into one number; `sclk_mhz` = the GPU's shader clock sampled
-from sysfs by a side process during the timed region.  The loss of the timed step is the reference's MASKED L1 (whole_loss.py:126-131:
+from sysfs by a side process while those windows run (not during the timed region: each read is a message to the SMU and cost it ~0.5 us per step).  The loss of the timed step is the reference's MASKED L1 (whole_loss.py:126-131:
 gt_masks multiplies prediction and target; mask = ground-truth alpha > 0.5) unless `--no-mask`.
 `roofline` is for the dominant kernel, timed with HIP events recorded by the library on the launch stream inside the
 timed region; `roofline.traffic` comes from the committed rocprofv3 PMC summary of this same command
@@ -71,6 +71,7 @@ def parse_args(argv=None):
     ap.add_argument("--pipeline-chunks", type=int, default=0, help="full-pipelined: pipeline stages per step (default: one per subject)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-mask", action="store_true", help="plain L1 instead of the reference's masked L1 (whole_loss.py:126-131: gt_masks = ground-truth alpha > 0.5)")
+    ap.add_argument("--no-sclk", action="store_true", help="do not sample the shader clock (a side process reads an amdgpu sysfs node every 10 ms while the repeat windows run)")
     ap.add_argument("--windows", type=int, default=8, help="untimed-for-the-headline repeat windows of the same K steps behind the timed region (spread report)")
     ap.add_argument("--no-variants", action="store_true", help="skip the unpinned / exact-sync / per-view-loop re-runs (N=1, c2/c3)")
     ap.add_argument("--exact-sync", action="store_true", help="read num_rendered back every step (upstream behaviour) instead of the sync-free capacity mode")
@@ -517,7 +518,10 @@ def main(args):
     import gc
     gc.collect()
     gc.disable()
-    sclk = _SclkSampler(local_rank) if rank == 0 else None       # a side PROCESS on another core (no GIL, no HIP): reads one sysfs file every 10 ms
+    # (the collection above hands cached blocks back to torch's allocator and the host-core trial may have moved the threads: a few untimed
+    # steps in the final state -- without them the first region read ~1 us per step above every repeat window behind it, on every box)
+    for _ in range(max(3, min(warmup, 50))):
+        step()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)   # (the library launches on torch's current stream)
     sync_all()
     t0 = time.perf_counter()
@@ -532,8 +536,11 @@ def main(args):
     sync_all()
     elapsed = time.perf_counter() - t0
     gpu_elapsed = ev0.elapsed_time(ev1) * 1e-3
-    sclk_report = sclk.stop() if sclk is not None else None
     # ---- the same K steps `--windows` more times: spread of wall and event time per step (not the headline: that is the region above)
+    # The shader clock is sampled HERE, over the repeat windows, not over the headline region: the side process (another core, no GIL, no HIP)
+    # reads an amdgpu sysfs node every 10 ms, each read is a message to the SMU, and with it running the region read 0.4-0.9 us per step above
+    # the windows behind it (four alternating runs on one box; ~0.3 without).
+    sclk = _SclkSampler(local_rank) if (rank == 0 and not args.no_sclk and args.windows > 0) else None
     win_wall, win_gpu = [], []
     for _w in range(max(args.windows, 0)):
         sync_all()
@@ -545,6 +552,9 @@ def main(args):
         sync_all()
         win_wall.append((time.perf_counter() - tw) / steps * 1e3)
         win_gpu.append(ev0.elapsed_time(ev1) / steps)
+    sclk_report = sclk.stop() if sclk is not None else None
+    if sclk_report is not None and "min" in sclk_report:
+        sclk_report["sampled_over"] = "the repeat windows behind the timed region"
     gc.enable()
     R.check_pending_overflows(True)                      # every step's instance count has been looked at (raises if one did not fit)
     if _DEBUG_BLOCKS:
