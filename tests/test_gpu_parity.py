@@ -663,6 +663,53 @@ def test_full_size_c2_100k_512(oracle):
     assert ref.R > 150_000
 
 
+def test_full_size_c2_headline_step_against_the_oracle(oracle):
+    """bench.py's headline step at full size (BASELINE configs[1]: 100 000-Gaussian humanoid, one view 512x512): rasterizer + clamp + masked L1 as ONE
+    node -- the fused single-view step through the C++ node (loss shares and dL/dcolor out of the compositing kernel, background pre-filled by the
+    preprocess launch, compositing backward queued by the forward call, gather-only backward) -- against the CPU oracle: the loss from the oracle's
+    image, the gradients from the oracle's backward of that loss's dL/dcolor; and against the same node with the fused step switched off, bit for bit."""
+    from sigman_release_amd import _cabi, rasterizer as R
+    dev = _dev()
+    H = W = 512
+    inp, st = cases.humanoid(P=100_000, H=H, W=W, seed=1)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    gen = torch.Generator(device=dev).manual_seed(21)
+    target = torch.rand(1, 3, H, W, device=dev, generator=gen)
+    mask = (torch.rand(1, 1, H, W, device=dev, generator=gen) > 0.4).float()
+    weight = 1.0 / (3 * H * W)
+    bst = _batched_settings(st, dev, 1)._replace(max_rendered=300_000)
+    res = []
+    L = _cabi.lib()
+    try:
+        for fused in (1, 0):
+            L.sgr_set_fused_step(fused)
+            d = {k: t(v)[None].requires_grad_(True) for k, v in inp.items()}
+            out = R.rasterize_l1_loss_batched(d["means3D"], None, None, d["colors_precomp"], d["opacities"][..., None], None, None, d["cov3D_precomp"], bst,
+                                              target, mask, weight)
+            out[0].backward()
+            torch.cuda.synchronize()
+            res.append([out[0].detach().clone(), out[2].detach().clone()] + [d[k].grad.clone() for k in ("means3D", "colors_precomp", "opacities", "cov3D_precomp")])
+    finally:
+        L.sgr_set_fused_step(1)
+    R.check_pending_overflows(True)
+    assert torch.allclose(res[0][0], res[1][0], rtol=1e-5, atol=0.0)
+    for a, b in zip(res[0][1:], res[1][1:]):
+        assert torch.equal(a, b)
+    ref = oracle.forward(**inp, **cases.single_view(st))
+    tg, mk = target[0].cpu().numpy(), mask[0].cpu().numpy()
+    dd = (np.clip(ref.color, 0.0, 1.0) - tg) * mk
+    want = weight * float(np.abs(dd).astype(np.float64).sum())
+    assert abs(float(res[0][0]) - want) <= 1e-5 * want, (float(res[0][0]), want)
+    assert np.abs(res[0][1][0].cpu().numpy() - ref.color).max() <= IMG_TOL
+    gC = (weight * mk * np.sign(dd) * ((ref.color >= 0.0) & (ref.color <= 1.0))).astype(np.float32)
+    g = oracle.backward(ref, gC, None, None)
+    for got, want_g, nm in ((res[0][2][0], g["means3D"], "means3D"), (res[0][3][0], g["colors_precomp"], "colors"), (res[0][4][0], g["opacities"][:, 0], "opacities"),
+                            (res[0][5][0], g["cov3D_precomp"], "cov3D")):
+        e = np.abs(got.cpu().numpy() - want_g) / max(np.abs(want_g).max(), 1e-20)
+        # (a pixel whose clamped colour lies within rounding of its target would flip the sign of its L1 gradient on one side: a random target leaves none)
+        assert e.max() <= GRAD_TOL, f"{nm}: {e.max():.3e}, {(e > GRAD_TOL).sum()} entries"
+
+
 def test_full_size_c5_1m_stress(oracle):
     """BASELINE.json configs[4]: 1M Gaussians (10 jittered layers), 512x512, depth + alpha gradients on."""
     from sigman_release_amd import synthetic
