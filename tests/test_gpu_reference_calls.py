@@ -655,6 +655,41 @@ def test_fused_single_view_step_other_input_flavours_and_exact_mode(flavour, cap
     R.check_pending_overflows(True)
 
 
+@pytest.mark.parametrize("fused", [1, 0])
+def test_fused_single_view_step_with_nothing_visible(fused):
+    """Every Gaussian culled (behind the camera): the step returns the background's loss, the background image and zero gradients -- in the
+    sync-free mode the fused step still runs (the buffers are sized by the capacity, the true count is zero): pre-filled background, a
+    compositing launch and a bucket backward with nothing to do, the loss from the pre-filled shares alone."""
+    from sigman_release_amd import _cabi, rasterizer as R
+    if _cabi.torch_node() is None:
+        pytest.skip("sgr_torch_node.so not built / SIGMAN_PY_NODE=1")
+    dev = _dev()
+    base, mk, target = _batched_l1_inputs(dev, 1, 2, P=500, H=70, W=100, seed=2)
+    base["means3D"] = base["means3D"] + torch.tensor([0.0, 0.0, 50.0], device=dev)       # (camera rig looks at the origin from ~2.5 m: all behind / beyond it)
+    st = mk(50000)
+    L = _cabi.lib()
+    try:
+        L.sgr_set_fused_step(fused)
+        d = {k: v.clone().requires_grad_(True) for k, v in base.items()}
+        mask = (torch.rand(2, 1, 70, 100, device=dev) > 0.5).float()
+        loss, per_view, color, radii, depth, alpha = R.rasterize_l1_loss_batched(d["means3D"], None, None, d["rgb"], d["opacity"], None, None, d["cov3D"], st,
+                                                                                 target, mask, 0.25)
+        loss.backward()
+        torch.cuda.synchronize()
+    finally:
+        L.sgr_set_fused_step(1)
+    if int(radii.sum()) != 0:
+        pytest.skip("the shifted subject is still visible from this rig")
+    bg = st.bg[None, :, None, None].expand(2, 3, 70, 100)
+    assert torch.equal(color.detach(), bg) and float(alpha.detach().abs().max()) == 0.0 and float(depth.detach().abs().max()) == 0.0
+    want = 0.25 * ((bg.clamp(0, 1) - target) * mask).abs().double().sum()
+    assert abs(float(loss.detach()) - float(want)) <= 1e-5 * float(want)
+    assert torch.allclose(per_view.double().sum(), loss.detach().double(), rtol=1e-6)
+    for k in d:
+        assert d[k].grad is not None and float(d[k].grad.abs().sum()) == 0.0, k
+    R.check_pending_overflows(True)
+
+
 def test_cpp_batched_l1_node_overflow_and_no_grad():
     """A forward that does not fit its explicit capacity raises from its own backward; without a backward, from check_pending_overflows();
     under torch.no_grad() from the forward itself -- the Python node's behaviour."""
