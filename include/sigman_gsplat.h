@@ -275,8 +275,8 @@ int sgr_set_preprocess_view_group(int n);
  *                one record before each 16-survivor row -- T absolute; sums absolute on rows that start a forward segment, else relative
  *                to that row
  *   aux_desc     u32 [4*NS][2]   bucket descriptors (tile | (rows per segment - 1) << 30, (start << 7) | count); zeroed by this call
- * aux_order (optional, u32 [1 + n_views*tiles]) receives the work order of the segment-parallel kernel (longest tile lists
- * first, empty tiles last); NULL = tiles in index order.
+ * aux_order (optional, u32 [4 * n_views*tiles]) receives the work order of the segment-parallel kernel: (tile, first, end of its list, 0) per
+ * slot, longest tile lists first, empty tiles last; NULL = tiles in index order.
  */
 int sgr_render_forward(const SgrProblem *pb, const uint32_t *ranges, const uint32_t *point_list, const float *rec,
                        float *out_color, float *out_depth, float *out_alpha, float *final_T, uint32_t *n_contrib,

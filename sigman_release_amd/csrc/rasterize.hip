@@ -207,7 +207,7 @@ static int rasterize_forward_impl(const SgrProblem *pb, uint64_t capacity, int32
     st->off_ranges = o; o = align_up(o + tiles_total * 8);
     st->off_final_T = o; o = align_up(o + hw * 4);
     st->off_n_contrib = o; o = align_up(o + hw * 4);
-    st->off_order = o; o = align_up(o + (tiles_total + 1) * 4);
+    st->off_order = o; o = align_up(o + tiles_total * 16);
     if (aux_on) {
         st->off_flags = o; o = align_up(o + R * 4);                // one byte per (tile instance, quadrant): partial record written by the backward
         st->off_compact = o; o = align_up(o + 4 * R * 8);

@@ -317,10 +317,11 @@ __global__ __launch_bounds__(kSegThreads, 4) void render_fwd_seg_kernel(int W, i
     const uint32_t q = (blockIdx.x >> 3) & 3u;
     if (slot >= n_slots) return;                                 // (grid padded to a multiple of 32)
     uint32_t bid = slot;
-    if (order) bid = order[1 + bid];
+    uint2 range;
+    if (order) { const uint4 od = reinterpret_cast<const uint4 *>(order)[slot]; bid = od.x; range = make_uint2(od.y, od.z); }   // (tile, its range): one load
+    else range = ranges[bid];
     const uint32_t view = bid / tiles_per_view, tile = bid - view * tiles_per_view;
     const uint32_t tx = tile % Tx, ty = tile / Tx;
-    const uint2 range = ranges[bid];
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
 #ifdef SGR_SEG_TRACE
     unsigned long long *tr_buf = (g_seg_trace && slot < (uint32_t)kSegTraceSlots && t == 0) ? g_seg_trace + ((size_t)slot * 4 + q) * kSegTraceEvents : nullptr;
@@ -677,7 +678,7 @@ __global__ __launch_bounds__(kSegThreads, 4) void render_fwd_seg_kernel(int W, i
 // critical path start at t = 0 and the tail of the launch is made of short ones (the unordered launch started the heaviest
 // C2 tiles 35 us late behind 3000 empty workgroups).  32 length classes (n >> 7), order inside a class is arbitrary -- it only
 // affects scheduling, never results.  Also clears the bucket descriptors (replaces a memset launch).
-// order[0] = number of tiles, order[1..] = tile ids, longest list first, empty tiles last.
+// order = uint4 per slot: (tile id, first, end of its list, 0), longest list first, empty tiles last.
 // -------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void fwd_prepare_kernel(const uint2 *__restrict__ ranges, uint32_t tiles_total, uint2 *__restrict__ desc,
                                                            size_t n_desc, uint32_t *__restrict__ order) {

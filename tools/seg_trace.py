@@ -87,3 +87,14 @@ print("start times of working workgroups (us), every 53rd:", [round(x, 1) for x 
 durs = sorted(((r[1] - r[0]) / 100.0, r[4]) for r in work)
 print("durations (us, n): shortest", durs[:3], "median", durs[len(durs) // 2], "longest", durs[-3:])
 
+
+# ---- where the slot time goes: sum of workgroup lifetimes by list length (the kernel's length is the work per slot: DESIGN dead ends (ak))
+cls = [(0, 256), (256, 512), (512, 768), (768, 1024), (1024, 1536), (1536, 2048), (2048, 1 << 30)]
+tot = sum(r[1] - r[0] for r in work) / 100.0
+print("workgroup-time by list length [n0, n1): workgroups, sum of lifetimes us (share), mean lifetime us, mean start us")
+for a, b in cls:
+    w = [r for r in work if a <= r[4] < b]
+    if w:
+        s = sum(r[1] - r[0] for r in w) / 100.0
+        print(f"  [{a:5d},{b if b < 1 << 30 else 99999:5d}): {len(w):4d} wgs  {s:8.1f} us ({100 * s / tot:4.1f} %)  mean {s / len(w):5.1f} us  mean start {sum(r[0] - t0 for r in w) / 100.0 / len(w):5.1f} us")
+print(f"  all: {len(work)} wgs {tot:.1f} us = {tot / 512:.1f} us per slot of 512")
