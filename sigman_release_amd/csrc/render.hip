@@ -334,6 +334,7 @@ __global__ __launch_bounds__(kSegThreads, 4) void render_fwd_seg_kernel(int W, i
         sch[2] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 20) << 32) | (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);
         sch[3] = ((unsigned long long)(uint32_t)(range.y - range.x) << 32) | bid;
         sch[1] = sch[0];
+        sch[4] = 0ull; sch[5] = 0ull;
     }
 #endif
     const int px = (int)tx * 16 + (int)(q & 1u) * 8 + (lane & 7);
@@ -593,6 +594,9 @@ __global__ __launch_bounds__(kSegThreads, 4) void render_fwd_seg_kernel(int W, i
             slot_next += (m + 63u) >> 6;
         }
         SGR_TR(7);
+#ifdef SGR_SEG_TRACE
+        if (sch) { sch[4] += 1ull; sch[5] = kbase + m; }          // rounds, survivors composited
+#endif
         kbase += m;
         qhead = (qhead + m) & (kSegRing - 1);
         qcount -= m;

@@ -98,3 +98,13 @@ for a, b in cls:
         s = sum(r[1] - r[0] for r in w) / 100.0
         print(f"  [{a:5d},{b if b < 1 << 30 else 99999:5d}): {len(w):4d} wgs  {s:8.1f} us ({100 * s / tot:4.1f} %)  mean {s / len(w):5.1f} us  mean start {sum(r[0] - t0 for r in w) / 100.0 / len(w):5.1f} us")
 print(f"  all: {len(work)} wgs {tot:.1f} us = {tot / 512:.1f} us per slot of 512")
+
+# ---- rounds per workgroup (a round composites up to 512 survivors; the last one of a list is usually small and pays the full set of barriers)
+by_r = collections.defaultdict(list)
+for r in work: by_r[min(r[9], 4)].append(r)
+print("workgroups by number of rounds: rounds, workgroups, mean lifetime us, mean n, mean survivors, survivors of the LAST round (mean)")
+for k in sorted(by_r):
+    v = by_r[k]
+    print(f"  {k}: {len(v):4d} wgs  mean {sum(x[1] - x[0] for x in v) / 100.0 / len(v):5.1f} us  n {sum(x[4] for x in v) / len(v):6.0f}  survivors {sum(x[10] for x in v) / len(v):6.0f}  last round {sum((x[10] - 512 * (k - 1)) if k >= 1 else 0 for x in v) / len(v):5.0f}")
+two = [x for x in work if x[9] == 2 and x[10] <= 1020]
+print(f"two-round workgroups whose survivors would fit ONE round of 16 segments: {len(two)}, sum of lifetimes {sum(x[1] - x[0] for x in two) / 100.0:.0f} us")
