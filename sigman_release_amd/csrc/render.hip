@@ -504,8 +504,14 @@ __global__ __launch_bounds__(kSegThreads, 4) void render_fwd_seg_kernel(int W, i
         float Tin = Tcarry, Tall = Tcarry;
 #pragma unroll
         for (int w = 0; w < kSegWaves; w++) { const float tw = sT[w][lane]; if (w < wave) Tin *= tw; Tall *= tw; }
-        // ---- phase 2: composite my segment from T_in with the published sequential rule
-        float T = Tin;
+        // ---- phase 2: composite my segment from T_in with the published sequential rule.
+        // The transmittance in front of survivor k is evaluated as T_in * P_k with P_k the running product of the segment's (1 - alpha) from 1.0 -- the
+        // very sequence phase 1 multiplied -- not as a product chained on from T_in: then the T_in of every later segment, T_in * P_last of this one, is
+        // (rounding is monotone, P never grows) at most the value this segment tested at its stop, so "a pixel that stopped in an earlier segment has
+        // T_in < 1e-4" holds in floating point, not just on paper.  With the chained product the two could disagree when T crossed 1e-4 within
+        // rounding: a later segment then composited on and stopped the pixel a second time, and final_T -- two waves writing one LDS word --
+        // differed from run to run (found by tools/fuzz_fused_step.py: one pixel in ~100 random scenes).
+        float T = Tin, P = 1.f;
         bool done = !inside | (Tin < 0.0001f);
         const bool done_at_start = done;
         v2f d01 = {0.f, 0.f}, d2D = {0.f, 0.f};
@@ -546,7 +552,8 @@ __global__ __launch_bounds__(kSegThreads, 4) void render_fwd_seg_kernel(int W, i
             }
 #pragma unroll
             for (int u = 0; u < 4; u++) {
-                const float test_T = T * (1.f - al[u]);
+                P *= 1.f - al[u];
+                const float test_T = Tin * P;
                 done = done | (test_T < 0.0001f);                 // the crossing Gaussian is NOT composited
                 const bool contrib = (al[u] > 0.f) & !done;
                 const float w = contrib ? al[u] * T : 0.f;
@@ -727,7 +734,8 @@ __device__ __forceinline__ void l1_reduce_block(const LossReduce &r) {
 // Math (front-to-back form of the published reverse walk), per pixel with g = upstream gradient vector over
 // (r,g,b,depth,alpha), f_j = (r_j,g_j,b_j,depth_j,1), q_j = f_j . g, w_j = alpha_j T_j:
 //   dL/dalpha_j = T_j q_j - (O - Pre_j - w_j q_j) / (1 - alpha_j),   O = out . g (includes the T_final*bg term),
-//   Pre_j = sum_{k<j} w_k q_k  (running), T_{j+1} = T_j (1 - alpha_j)  (bit-identical to the forward's T sequence).
+//   Pre_j = sum_{k<j} w_k q_k  (running), T_{j+1} = T_j (1 - alpha_j)  (the wave forward's T sequence bit for bit; the segment-parallel forward
+//   evaluates T_in * P_k, equal to a last bit or two: its phase 2).
 // -------------------------------------------------------------------------------------------------
 // shift one lane up inside each 16-lane row; lane 0 of every row takes `feed` (DPP row_shr:1 keeps `old` where there is no source)
 __device__ __forceinline__ float row_shift_in(float v, float feed) {

@@ -690,6 +690,26 @@ def test_fused_single_view_step_with_nothing_visible(fused):
     R.check_pending_overflows(True)
 
 
+def test_randomised_fused_step_slice():
+    """A slice of tools/fuzz_fused_step.py under the driver: ~1 200 random small scenes (one to four views, odd sizes, with / without mask, backgrounds
+    beyond [0, 1], random capacity head-room) through the rasterizer + masked L1 node with the fused step on, off, on: images, radii, gradients bit
+    for bit, the fused loss identical run to run.  (This sweep found the one nondeterminism the forward ever had: a transmittance that crossed 1e-4
+    within rounding could be stopped by two segments of the segment-parallel forward -- csrc/render.hip, phase 2.)"""
+    import importlib.util
+    import os
+    from sigman_release_amd import _cabi
+    if _cabi.torch_node() is None:
+        pytest.skip("sgr_torch_node.so not built / SIGMAN_PY_NODE=1")
+    spec = importlib.util.spec_from_file_location("fuzz_fused_step", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_fused_step.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    # (seed, scenes): with the forward of before the fix scene 120 of seed 14, 414 of seed 2 and 594 of seed 19 differed between two runs in one pixel
+    # (13 of 14 attempts on the old build; 29 000 scenes and these three sequences are clean on the fixed one)
+    for seed, scenes in ((14, 160), (2, 450), (19, 620)):
+        n, n_empty = mod.run(seconds=60.0, seed=seed, max_scenes=scenes)
+        assert n == scenes, (seed, n)
+
+
 def test_cpp_batched_l1_node_overflow_and_no_grad():
     """A forward that does not fit its explicit capacity raises from its own backward; without a backward, from check_pending_overflows();
     under torch.no_grad() from the forward itself -- the Python node's behaviour."""

@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Randomised cross-check of the fused single-view step on the GPU box (dev): random small scenes (humanoids and random clouds, one to four views
+of up to 2 048 tiles in total, odd image sizes, with and without the loss mask, random background, random capacity head-room), the rasterizer +
+masked L1 step through the C++ node with the fused step on, off and on again: images, radii and gradients identical bit for bit (dL/dloss = 1),
+the fused loss identical run to run, fused and unfused losses equal to the order of their additions.     usage: python tools/fuzz_fused_step.py [seconds]"""
+import os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from sigman_release_amd import _cabi, cameras, synthetic
+from sigman_release_amd import rasterizer as R
+
+def run(seconds=60.0, seed=2025, max_scenes=None):
+    """-> (scenes, scenes with nothing visible); raises AssertionError with the configuration on the first difference."""
+    assert _cabi.torch_node() is not None, "needs sgr_torch_node.so"
+    dev = torch.device("cuda", 0)
+    L = _cabi.lib()
+    rng = np.random.default_rng(seed)
+    t_end = time.time() + float(seconds)
+    n = n_empty = 0
+    try:
+        while time.time() < t_end and (max_scenes is None or n < max_scenes):
+            V = int(rng.choice([1, 1, 1, 2, 3, 4]))
+            H = int(rng.integers(8, 260)); W = int(rng.integers(8, 260))
+            if ((H + 15) // 16) * ((W + 15) // 16) * V > 2048:
+                continue
+            P = int(rng.choice([1, 7, 300, 2000, 9000, 30000]))
+            g = synthetic.humanoid(P, int(rng.integers(1, 1 << 30))) if rng.random() < 0.6 else synthetic.random_cloud(P, int(rng.integers(1, 1 << 30)))
+            t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+            cov = synthetic.covariance_from_gaussians(g)
+            if rng.random() < 0.3:
+                cov = (cov * rng.uniform(1.0, 30.0)).astype(np.float32)        # larger splats: more tiles per Gaussian, deeper lists
+            base = [t(g["position"])[None], t(g["rgb"])[None], t(g["opacity"].reshape(P, 1))[None], t(cov)[None]]
+            views = [int(v) for v in rng.choice(90, V, replace=False)]
+            cv, cvp, cp = cameras.make_cameras(views)
+            bg = torch.tensor(rng.uniform(-0.2, 1.2, 3).astype(np.float32), device=dev)            # (beyond [0, 1] as well: the clamp's mask on the background)
+            st = R.BatchedRasterizationSettings(H, W, cameras.TAN_HALF_FOV, cameras.TAN_HALF_FOV, bg, 1.0, t(cv), t(cvp), 0, t(cp), V, False, 1)
+            # capacity: the exact count of a probe render times a random head-room
+            with torch.no_grad():
+                cnt = int(R.forward_debug(base[0], base[2], colors_precomp=base[1], cov3D_precomp=base[3], settings=st._replace(max_rendered=0))["num_rendered"])
+            st = st._replace(max_rendered=int(cnt * rng.uniform(1.0, 2.0)) + int(rng.integers(1, 5000)))
+            gen = torch.Generator(device=dev).manual_seed(int(rng.integers(1 << 30)))
+            target = torch.rand(V, 3, H, W, device=dev, generator=gen)
+            mask = (torch.rand(V, 1, H, W, device=dev, generator=gen) > 0.3).float() if rng.random() < 0.6 else None
+            weight = float(rng.uniform(0.1, 2.0)) / (3 * H * W)
+            res = []
+            for fused in (1, 0, 1):
+                L.sgr_set_fused_step(fused)
+                leaves = [x.clone().requires_grad_(True) for x in base]
+                out = R.rasterize_l1_loss_batched(leaves[0], None, None, leaves[1], leaves[2], None, None, leaves[3], st, target, mask, weight)
+                out[0].backward()
+                torch.cuda.synchronize()
+                res.append([np.atleast_1d(o.detach().cpu().numpy()).copy() for o in out] + [x.grad.detach().cpu().numpy().copy() for x in leaves])
+            R.check_pending_overflows(True)
+            cfg = (P, H, W, V, mask is not None, cnt)
+            names = ("loss", "per_view", "color", "radii", "depth", "alpha", "d_means3D", "d_rgb", "d_opacity", "d_cov3D")
+            for nm, a, b in zip(names, res[0], res[2]):                       # fused, run to run: everything, the loss included
+                if not np.array_equal(a.view(np.uint8), b.view(np.uint8)):
+                    bad = np.argwhere(a != b)
+                    raise AssertionError(("run to run", "scene %d of seed %d" % (n, seed), nm, cfg, len(bad), bad[:5].tolist(), a[tuple(bad[0])], b[tuple(bad[0])]))
+            for i, (a, b) in enumerate(zip(res[0], res[1])):                  # fused against unfused
+                if i < 2:
+                    assert np.allclose(a, b, rtol=2e-5, atol=1e-9), ("loss", cfg, a, b)
+                elif not np.array_equal(a.view(np.uint8), b.view(np.uint8)):
+                    bad = np.argwhere(a != b)
+                    raise AssertionError(("fused vs unfused", "scene %d of seed %d" % (n, seed), names[i], cfg, len(bad), bad[:5].tolist(), a[tuple(bad[0])], b[tuple(bad[0])]))
+            n += 1
+            n_empty += cnt == 0
+    finally:
+        L.sgr_set_fused_step(1)
+    return n, n_empty
+
+
+if __name__ == "__main__":
+    n, n_empty = run(float(sys.argv[1]) if len(sys.argv) > 1 else 60.0)
+    print("fuzz ok:", n, "scenes,", n_empty, "of them with nothing visible")
