@@ -329,6 +329,7 @@ void ref_preprocess(const RefCam *cam, const float *means3D, const float *opacit
         int maxx = (int)((px + (float)rad + (float)(TILE - 1)) / (float)TILE); maxx = maxx < 0 ? 0 : (maxx > Tx ? Tx : maxx);
         int maxy = (int)((py + (float)rad + (float)(TILE - 1)) / (float)TILE); maxy = maxy < 0 ? 0 : (maxy > Ty ? Ty : maxy);
         if ((maxx - minx) * (maxy - miny) == 0) continue;
+        if (!(rad > 0)) continue;   /* a NaN radius ((int)NaN is not even defined in C): never emitted (radii > 0 below), so it must not count tiles either -- the HIP path's rule */
         if (colors_precomp) {
             for (int k = 0; k < 3; k++) rgb[3 * i + k] = colors_precomp[3 * i + k]; /* untouched, no clamp */
         } else {

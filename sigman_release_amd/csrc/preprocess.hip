@@ -287,7 +287,11 @@ __global__ __launch_bounds__(kPreThreads) void preprocess_fwd_kernel(SgrProblem 
                 int maxx = (int)((px + (float)rad + (float)(SGR_TILE - 1)) / (float)SGR_TILE); maxx = min(Tx, max(0, maxx));
                 int maxy = (int)((py + (float)rad + (float)(SGR_TILE - 1)) / (float)SGR_TILE); maxy = min(Ty, max(0, maxy));
                 const int area = (maxx - minx) * (maxy - miny);
-                if (area != 0) {
+                // rad > 0: a non-finite covariance (a diverged decoder; a lone point's infinite 3-NN distance) gives a NaN radius, which converts to 0:
+                // the emission kernel skips radius-0 splats (`radii > 0`, as upstream's duplicateWithKeys does), so such a splat must not count
+                // tiles either -- upstream's preprocess does count them, and the key slots nobody writes then reach its sort uninitialised; here
+                // they sent a garbage tile id into the binning and, every few runs, a memory fault (found by tools/fuzz_determinism.py)
+                if (area != 0 && rad > 0) {
                     float rgb[3];
                     if (pb.colors_precomp) {
 #pragma unroll

@@ -12,6 +12,7 @@ import pytest
 import torch
 
 import cases
+from sigman_release_amd import cameras
 
 pytestmark = pytest.mark.gpu
 
@@ -145,6 +146,50 @@ def test_empty_and_degenerate():
         assert radii.shape == (P,) and int(radii.sum()) == 0
         color.sum().backward()
         assert m.grad is not None and float(m.grad.abs().sum()) == 0.0
+
+
+def test_non_finite_inputs_never_fault():
+    """Non-finite covariances (a diverged decoder; the 3-NN distance of a lone point is infinite: gs.py:70-73), means and opacities: the splat is
+    culled (NaN radius, behind-the-camera test) or composites NaN like upstream's would -- never a memory fault, and the finite splats around it
+    render as if it were not there.  (A NaN radius used to count tiles while the emission skipped it: uninitialised key slots reached the sort --
+    found by tools/fuzz_determinism.py.)  Both compositing kernels, single view and batch, forward + backward, repeated."""
+    from sigman_release_amd import rasterizer as R
+    dev = _dev()
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    for views, H, W in (((30,), 96, 80), ((3, 17, 30, 44, 51, 65, 72, 88) * 3, 292, 93)):
+        S = 3 if len(views) > 8 else 1
+        V = len(views) // S
+        inp, st = cases.humanoid(P=400, H=H, W=W, seed=5, views=views[:V])
+        cv, cvp, cp = cameras.make_cameras(list(views))
+        bst = R.BatchedRasterizationSettings(H, W, st["tanfovx"], st["tanfovy"], t(st["bg"]), 1.0, t(cv), t(cvp), 0, t(cp), V)
+        base = {k: np.stack([v] * S) for k, v in inp.items()}
+        ref = None
+        for bad in ("none", "cov_nan", "cov_inf", "cov_mixed", "mean_nan", "mean_inf", "opacity_nan", "lone"):
+            b = {k: v.copy() for k, v in base.items()}
+            sel = slice(0, 7)
+            if bad == "cov_nan": b["cov3D_precomp"][:, sel] = np.nan
+            if bad == "cov_inf": b["cov3D_precomp"][:, sel] = np.inf
+            if bad == "cov_mixed": b["cov3D_precomp"][:, sel] = np.array([np.inf, np.nan, np.nan, np.inf, np.nan, np.inf], np.float32)
+            if bad == "mean_nan": b["means3D"][:, sel] = np.nan
+            if bad == "mean_inf": b["means3D"][:, sel, 2] = np.inf
+            if bad == "opacity_nan": b["opacities"][:, sel] = np.nan
+            if bad == "lone":          # what the fuzzer met: ONE splat per subject, with the covariance its infinite 3-NN distance gives
+                b = {k: v[:, :1].copy() for k, v in b.items()}
+                b["cov3D_precomp"][:] = np.array([np.inf, np.nan, np.nan, np.inf, np.nan, np.inf], np.float32)
+            for rep in range(3):
+                d = {k: t(v).requires_grad_(True) for k, v in b.items()}
+                color, radii, depth, alpha = R.rasterize_gaussians_batched(d["means3D"], None, None, d["colors_precomp"], d["opacities"][..., None], None, None,
+                                                                           d["cov3D_precomp"], bst)
+                torch.nan_to_num(color).sum().backward()
+                torch.cuda.synchronize()
+            if bad == "none":
+                ref = color.detach().clone()
+            elif bad in ("cov_nan", "cov_mixed", "mean_nan"):
+                assert int(radii[:, :7].abs().sum()) == 0, bad                 # culled in every view
+                assert bool(torch.isfinite(color).all()), bad
+            elif bad == "lone":
+                assert int(radii.abs().sum()) == 0 and torch.equal(color, t(st["bg"])[None, :, None, None].expand_as(color))
+    R.check_pending_overflows(True)
 
 
 def test_argument_errors():
