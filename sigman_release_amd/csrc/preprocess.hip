@@ -624,7 +624,15 @@ __device__ __forceinline__ void bwd_finish(const SgrProblem &pb, size_t sp, cons
 #pragma unroll
         for (int k = 0; k < 3; k++) dL_dcolors[sp * 3 + k] = gcol[k];
     }
-    if (pb.scales) {
+    if (pb.scales && !((gcov[0] != 0.f) | (gcov[1] != 0.f) | (gcov[2] != 0.f) | (gcov[3] != 0.f) | (gcov[4] != 0.f) | (gcov[5] != 0.f))) {
+        // no gradient reached the covariance (culled in every view, or fully occluded): zeros, whatever the scales and the quaternion hold -- the
+        // chain below would turn a non-finite scale of a splat nobody saw into NaN gradients (0 * NaN), where upstream's backward returns early
+        // for a culled splat and leaves its zero-initialised outputs alone
+#pragma unroll
+        for (int k = 0; k < 3; k++) dL_dscales[sp * 3 + k] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; k++) dL_drot[sp * 4 + k] = 0.f;
+    } else if (pb.scales) {
         float s[3], qv[4], Rm[3][3];
 #pragma unroll
         for (int k = 0; k < 3; k++) s[k] = pb.scales[sp * 3 + k];

@@ -190,6 +190,21 @@ def test_non_finite_inputs_never_fault():
             elif bad == "lone":
                 assert int(radii.abs().sum()) == 0 and torch.equal(color, t(st["bg"])[None, :, None, None].expand_as(color))
     R.check_pending_overflows(True)
+    # scales + rotations: a splat culled in every view gets ZERO gradients for them even when its scale is not finite (the covariance -> scale chain
+    # would make 0 * NaN of it; upstream's backward returns early for a culled splat) -- in the exact mode (nothing rendered: gradients are cleared)
+    # and in the sync-free mode (the backward kernels run) alike; tools/fuzz_determinism.py met the two disagreeing
+    inp, st = cases.cloud_sh(P=1, H=64, W=80, seed=0, views=(30, 53))
+    inp["scales"][:] = np.nan
+    cv, cvp, cp = cameras.make_cameras([30, 53])
+    for cap in (0, 5000):
+        bst = R.BatchedRasterizationSettings(64, 80, st["tanfovx"], st["tanfovy"], t(st["bg"]), 1.0, t(cv), t(cvp), 3, t(cp), 2, False, cap)
+        d = {k: t(v)[None].requires_grad_(True) for k, v in inp.items()}
+        color = R.rasterize_gaussians_batched(d["means3D"], None, d["shs"], None, d["opacities"][..., None], d["scales"], d["rotations"], None, bst)[0]
+        color.sum().backward()
+        torch.cuda.synchronize()
+        for k in ("scales", "rotations", "means3D", "shs", "opacities"):
+            assert float(d[k].grad.abs().sum()) == 0.0, (cap, k, d[k].grad)
+    R.check_pending_overflows(True)
 
 
 def test_argument_errors():

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Randomised run-to-run check on the GPU box (dev): random batches (1-3 subjects x 1-8 views, odd image sizes, humanoids / random clouds with
+"""Randomised run-to-run check on the GPU box (dev): random batches (a fifth of them with NaN / Inf / huge entries sprinkled over the inputs) (1-3 subjects x 1-8 views, odd image sizes, humanoids / random clouds with
 random covariance scale, colours + covariances or spherical harmonics + scales / rotations, with and without gradients into depth and alpha,
 every capacity mode) rendered forward + backward TWICE: images, radii, depth, alpha and all gradients identical bit for bit.  The library has no
 float atomics and no order-dependent reductions on these paths, so any difference is a race.     usage: python tools/fuzz_determinism.py [seconds] [seed]"""
@@ -38,6 +38,12 @@ def run(seconds=60.0, seed=1, max_scenes=None):
             deg = 0
             cov = torch.stack([t((synthetic.covariance_from_gaussians(g) * scale).astype(np.float32)) for g in subs])
             base = dict(means3D=means, opacities=op, colors_precomp=torch.stack([t(g["rgb"]) for g in subs]), cov3Ds_precomp=cov)
+        if rng.random() < 0.2:                        # non-finite entries (a diverged decoder): nothing may fault, and two runs still agree bit for bit
+            for k in [k for k in base if k != "rotations"]:
+                if rng.random() < 0.5:
+                    flat = base[k].reshape(-1)
+                    idx = torch.from_numpy(rng.integers(0, flat.numel(), size=min(flat.numel(), int(rng.integers(1, 20))))).to(dev)
+                    flat[idx] = float(rng.choice([np.nan, np.inf, -np.inf, 1e30, -1e30]))
         views = [int(v) for v in rng.choice(90, V, replace=False)]
         cv, cvp, cp = cameras.make_cameras(views * S)
         da = bool(rng.random() < 0.3)
