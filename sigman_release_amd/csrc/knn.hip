@@ -69,7 +69,13 @@ __global__ __launch_bounds__(kT) void knn_prep_kernel(KnnBatch kb, int box_block
     float mn[3] = {3.0e38f, 3.0e38f, 3.0e38f}, mx[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
     for (int i = blockIdx.x * kT + threadIdx.x; i < P; i += box_blocks * kT)
 #pragma unroll
-        for (int k = 0; k < 3; k++) { const float v = pts[3 * (size_t)i + k]; mn[k] = fminf(mn[k], v); mx[k] = fmaxf(mx[k], v); }
+        for (int k = 0; k < 3; k++) {
+            // (only coordinates of a sane magnitude shape the grid: one Inf / 1e30 from a diverged decoder would otherwise stretch it until every
+            // other point shares ONE cell and the search is all pairs; such points -- and NaN ones -- are binned into the border cells by cell_of's
+            // clamps, which keeps the stop test of the search valid: clamping only ever moves a point's cell towards the rest)
+            const float v = pts[3 * (size_t)i + k];
+            if (fabsf(v) <= 1.0e15f) { mn[k] = fminf(mn[k], v); mx[k] = fmaxf(mx[k], v); }
+        }
 #pragma unroll
     for (int k = 0; k < 3; k++) {
 #pragma unroll
@@ -265,7 +271,7 @@ __global__ __launch_bounds__(kT) void knn3_kernel(KnnBatch kb) {
                     const float4 o = sorted[k];
                     const float dx = o.x - me.x, dy = o.y - me.y, dz = o.z - me.z;
                     const float d = dx * dx + dy * dy + dz * dz;
-                    offer3((int)k == s ? 3.0e38f : d, b0, b1, b2);
+                    offer3((int)k == s ? 3.0e38f : fminf(d, 3.0e38f), b0, b1, b2);     // (fminf: a NaN / Inf distance is "no neighbour" -- offer3's min / max would duplicate b0 for a NaN, order-dependently)
                 }
             } else {
 #pragma unroll
@@ -276,7 +282,7 @@ __global__ __launch_bounds__(kT) void knn3_kernel(KnnBatch kb) {
                     for (uint32_t k = lo; k < hi; k++) {
                         const float4 o = sorted[k];
                         const float dx = o.x - me.x, dy = o.y - me.y, dz = o.z - me.z;
-                        offer3(dx * dx + dy * dy + dz * dz, b0, b1, b2);
+                        offer3(fminf(dx * dx + dy * dy + dz * dz, 3.0e38f), b0, b1, b2);
                     }
                 }
             }

@@ -45,6 +45,29 @@ def test_dist_cuda2_exact_knn(kind, P):
     np.testing.assert_allclose(got, want, rtol=2e-5, atol=1e-12)
 
 
+def test_dist_cuda2_with_non_finite_points():
+    """A few NaN / Inf / 1e30 coordinates among 20 000 points (a diverged decoder): the finite points get exactly the 3-NN distances of the finite
+    subset (a non-finite point is nobody's neighbour), bit for bit from run to run, and the grid is not stretched by the outliers (one Inf in the
+    bounding box used to put every other point into ONE cell: an all-pairs search).  Found by tools/fuzz_render.py."""
+    import time
+    from scipy.spatial import cKDTree
+    from sigman_release_amd.renderer import dist_cuda2
+    rng = np.random.default_rng(8)
+    pts = (rng.normal(size=(20000, 3)) * 0.4).astype(np.float32)
+    bad = np.array([3, 500, 4099, 12345, 19999])
+    pts[bad[0], 1] = np.nan; pts[bad[1]] = np.inf; pts[bad[2], 0] = -np.inf; pts[bad[3], 2] = 1e30; pts[bad[4]] = np.nan
+    x = torch.from_numpy(pts).to(_dev())
+    a = dist_cuda2(x).cpu().numpy()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    b = dist_cuda2(x).cpu().numpy()
+    assert time.perf_counter() - t0 < 0.05, "the search must not degenerate into all pairs"
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    good = np.setdiff1d(np.arange(len(pts)), bad)
+    p64 = pts[good].astype(np.float64)
+    d, _ = cKDTree(p64).query(p64, k=4)
+    np.testing.assert_allclose(a[good], (d[:, 1:4] ** 2).mean(1), rtol=2e-5, atol=1e-12)
+
+
 def test_dist_cuda2_batched_equals_per_set():
     """[B,P,3] in one launch sequence == B single-set calls, bit for bit (sets with very different extents)."""
     from sigman_release_amd.renderer import dist_cuda2
