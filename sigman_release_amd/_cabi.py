@@ -135,7 +135,7 @@ def torch_node():
     return _node
 
 
-def check(status: int, what: str):
+def check(status: int, what: str, why: str = None):
     if status != 0:
         msg = lib().sgr_last_error().decode("utf-8", "replace")
-        raise RuntimeError(f"{what} failed: {msg}")
+        raise RuntimeError(f"{what} failed: {msg}" + (f" ({why})" if why else ""))

@@ -93,9 +93,17 @@ std::map<std::tuple<int, int64_t, int64_t, int64_t>, KeyState> g_keys;          
 std::map<std::tuple<int, int64_t, int64_t, int64_t, uint64_t, int, int>, std::array<uint64_t, 3>> g_blob_sizes;
 
 struct AllocCtx { c10::Device dev{c10::kCUDA, 0}; Tensor blob[4]; };
+thread_local std::string g_alloc_error;        // why the last allocator callback of this thread returned NULL
 char *alloc_cb(void *user, int32_t which, size_t bytes) {
+    // no exception may cross the C ABI: an out-of-memory error of the caching allocator becomes a NULL blob, on which the library returns an error
+    // before it launches anything (the nodes then release their count slot and raise with this message)
     AllocCtx *a = (AllocCtx *)user;
-    a->blob[which] = at::empty({(int64_t)(bytes < 256 ? 256 : bytes)}, at::TensorOptions().dtype(at::kByte).device(a->dev));
+    try {
+        a->blob[which] = at::empty({(int64_t)(bytes < 256 ? 256 : bytes)}, at::TensorOptions().dtype(at::kByte).device(a->dev));
+    } catch (const std::exception &e) {
+        g_alloc_error = std::string("allocating ") + std::to_string((double)bytes / (double)(1ull << 30)) + " GiB for blob " + std::to_string(which) + ": " + e.what();
+        return nullptr;
+    }
     return (char *)a->blob[which].data_ptr();
 }
 
@@ -208,7 +216,10 @@ void poll_pending(bool raise_now) {
     if (bad) raise_deferred(*bad);
 }
 
-void check_status(int status, const char *what) { TORCH_CHECK(status == 0, what, " failed: ", sgr_last_error()); }
+void check_status(int status, const char *what) {
+    if (status != 0 && !g_alloc_error.empty()) { const std::string why = g_alloc_error; g_alloc_error.clear(); TORCH_CHECK(false, what, " failed: ", sgr_last_error(), " (", why, ")"); }
+    TORCH_CHECK(status == 0, what, " failed: ", sgr_last_error());
+}
 
 SgrProblem make_problem(int64_t P, int64_t H, int64_t W, int64_t sh_degree, int64_t M, double tfx, double tfy, double smod, const Tensor &means3D,
                         const Tensor &opac, const Tensor &colors, const Tensor &sh, const Tensor &cov, const Tensor &scales, const Tensor &rot,

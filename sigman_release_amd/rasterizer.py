@@ -224,7 +224,14 @@ _pending = _threading.local()          # .slots: this thread's forwards whose in
 
 
 def _alloc_cb(_user, which, nbytes):
-    t = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=_alloc_target.dev)
+    # An exception must not leave this function: ctypes would print it and hand the C side an UNINITIALISED return value (a garbage device pointer:
+    # kernels launched on it -- found by tools/fuzz_determinism.py with a scene whose image blob did not fit the GPU).  NULL makes the library
+    # return an error before it launches anything on that blob; the message travels in _alloc_target.error.
+    try:
+        t = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=_alloc_target.dev)
+    except Exception as e:      # noqa: BLE001  (torch.OutOfMemoryError above all)
+        _alloc_target.error = f"allocating {int(nbytes) / 2 ** 30:.2f} GiB for blob {int(which)}: {e}"
+        return 0
     _alloc_target.blobs[which] = t
     return t.data_ptr()
 
@@ -349,13 +356,13 @@ def _forward_impl(means3D, opacities, colors_precomp, shs, cov3D_precomp, scales
             state.geom_bytes, state.binning_bytes, state.image_bytes = sizes
             status = forward_fn(*args, _NO_ALLOC, None, *outs)
         if status == 2:                    # first call with these shapes (or sizes changed): the library asks for memory through the callback
-            _alloc_target.dev, _alloc_target.blobs = dev, blobs
+            _alloc_target.dev, _alloc_target.blobs, _alloc_target.error = dev, blobs, None
             status = forward_fn(*args, _ALLOC, None, *outs)
             if status == 0 and size_key is not None:
                 _blob_sizes[size_key] = (max(int(state.geom_bytes), 256), max(int(state.binning_bytes), 256), max(int(state.image_bytes), 256))
     if status != 0:
         _pool(dev).release(slot)
-    _cabi.check(status, "sgr_rasterize_forward")
+    _cabi.check(status, "sgr_rasterize_forward", getattr(_alloc_target, "error", None))
     slot.by_copy = bool(state.nr_by_copy)
     pending = capacity > 0 and P > 0           # sync-free: the count is still on its way to the pinned slot
     if pending and (auto_key is not None or not use_aux):
@@ -436,12 +443,12 @@ def _backward_impl(ctx: _Ctx, means3D, opacities, colors_precomp, shs, cov3D_pre
     d_sc = torch.empty(S, P, 3, dtype=f32, device=dev) if scales is not None else None
     d_rot = torch.empty(S, P, 4, dtype=f32, device=dev) if scales is not None else None
     blobs = ctx.blobs
-    _alloc_target.dev, _alloc_target.blobs = dev, blobs
+    _alloc_target.dev, _alloc_target.blobs, _alloc_target.error = dev, blobs, None
     with _debug_scope(getattr(st, "debug", False)):
         _cabi.check(L.sgr_rasterize_backward(C.byref(pb), C.byref(ctx.state), _ptr(ctx.radii), _ptr(img[0]), _ptr(img[1]), _ptr(img[2]),
                                              _ptr(gC), _ptr(gD), _ptr(gA), _ptr(grad_color_scale), _ALLOC, None, _ptr(d_means3D), _ptr(d_means2D), _ptr(d_op),
                                              _ptr(d_col), _ptr(d_sh), _ptr(d_cov), _ptr(d_sc), _ptr(d_rot), _stream(dev)),
-                    "sgr_rasterize_backward")
+                    "sgr_rasterize_backward", getattr(_alloc_target, "error", None))
     grec = blobs[3]
     ctx.check_overflow()        # after the backward is queued: the host never idles the GPU while it waits for the forward's counter
     return d_means3D, d_means2D, d_sh, d_col, d_op, d_sc, d_rot, d_cov, grec

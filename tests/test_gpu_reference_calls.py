@@ -710,6 +710,33 @@ def test_randomised_fused_step_slice():
         assert n == scenes, (seed, n)
 
 
+@pytest.mark.parametrize("impl", ["cpp", "python"])
+def test_allocation_failure_is_an_error_not_a_fault(impl, monkeypatch):
+    """A forward whose buffers do not fit the GPU (a capacity of 3e9 tile instances: > 1 TB of checkpoints) raises a RuntimeError that names the
+    allocation -- before anything is launched on the blob that could not be had -- and the next ordinary call works.  The allocator callbacks used to
+    let the out-of-memory exception escape: ctypes then handed the library an uninitialised pointer (kernels launched on it: a memory fault; found by
+    tools/fuzz_determinism.py with a scene of 300 000 splats at ten times their size), the C++ node unwound through the C ABI with its count slot."""
+    from sigman_release_amd import _cabi, rasterizer as R
+    if impl == "cpp" and _cabi.torch_node() is None:
+        pytest.skip("sgr_torch_node.so not built")
+    if impl == "python":
+        monkeypatch.setattr(_cabi, "_node", None)
+    dev = _dev()
+    base, mk, target = _batched_l1_inputs(dev, 1, 2, P=800, H=64, W=80, seed=3)
+    def call(cap):
+        d = {k: v.clone().requires_grad_(True) for k, v in base.items()}
+        out = R.rasterize_l1_loss_batched(d["means3D"], None, None, d["rgb"], d["opacity"], None, None, d["cov3D"], mk(cap), target, None, 1.0)
+        out[0].backward()
+        torch.cuda.synchronize()
+        return out[0].detach().clone(), d["means3D"].grad.clone()
+    good = call(200000)
+    with pytest.raises(RuntimeError, match="(?i)allocat"):
+        call(3_000_000_000)
+    again = call(200000)
+    assert torch.allclose(good[0], again[0], rtol=1e-6) and torch.equal(good[1], again[1])
+    R.check_pending_overflows(True)
+
+
 def test_cpp_batched_l1_node_overflow_and_no_grad():
     """A forward that does not fit its explicit capacity raises from its own backward; without a backward, from check_pending_overflows();
     under torch.no_grad() from the forward itself -- the Python node's behaviour."""

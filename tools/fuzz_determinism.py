@@ -78,15 +78,27 @@ def run(seconds=60.0, seed=1, max_scenes=None):
         res = []
         for _rep in range(2):
             d = {k: v.clone().requires_grad_(True) for k, v in base.items()}
-            color, radii, depth, alpha = R.rasterize_gaussians_batched(d["means3D"], None, d.get("sh"), d.get("colors_precomp"), d["opacities"], d.get("scales"),
-                                                                       d.get("rotations"), d.get("cov3Ds_precomp"), st)
-            loss = (color * gC).sum()
-            if da:
-                loss = loss + (depth * gD).sum() + (alpha * gA).sum()
-            loss.backward()
-            torch.cuda.synchronize()
+            try:
+                color, radii, depth, alpha = R.rasterize_gaussians_batched(d["means3D"], None, d.get("sh"), d.get("colors_precomp"), d["opacities"], d.get("scales"),
+                                                                           d.get("rotations"), d.get("cov3Ds_precomp"), st)
+                loss = (color * gC).sum()
+                if da:
+                    loss = loss + (depth * gD).sum() + (alpha * gA).sum()
+                loss.backward()
+                torch.cuda.synchronize()
+            except RuntimeError as ex:                  # a scene whose buffers do not fit the GPU must be refused with an error (forward or backward), never fault
+                if "allocat" not in str(ex).lower() and "out of memory" not in str(ex).lower():
+                    raise
+                kinds["refused (memory)"] = kinds.get("refused (memory)", 0) + 1
+                res = None
+                del d
+                torch.cuda.empty_cache()
+                break
             res.append([x.detach().cpu().numpy().copy() for x in (color, radii, depth, alpha)] + [d[k].grad.detach().cpu().numpy().copy() for k in sorted(d)])
         R.check_pending_overflows(True)
+        if res is None:
+            n += 1
+            continue
         names = ["color", "radii", "depth", "alpha"] + ["d_" + k for k in sorted(base)]
         cfg = dict(S=S, V=V, H=H, W=W, P=P, sh=sh, da=da, cap=st.max_rendered, scale=round(scale, 2), scene=n, seed=seed)
         for nm, a, b in zip(names, *res):
