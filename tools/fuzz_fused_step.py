@@ -2,14 +2,14 @@
 """Randomised cross-check of the fused single-view step on the GPU box (dev): random small scenes (humanoids and random clouds, one to four views
 of up to 2 048 tiles in total, odd image sizes, with and without the loss mask, random background, random capacity head-room), the rasterizer +
 masked L1 step through the C++ node with the fused step on, off and on again: images, radii and gradients identical bit for bit (dL/dloss = 1),
-the fused loss identical run to run, fused and unfused losses equal to the order of their additions.     usage: python tools/fuzz_fused_step.py [seconds]"""
+the fused loss identical run to run, fused and unfused losses equal to the order of their additions.     usage: [FUZZ_SH=0.25] python tools/fuzz_fused_step.py [seconds] [seed]"""
 import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from sigman_release_amd import _cabi, cameras, synthetic
 from sigman_release_amd import rasterizer as R
 
-def run(seconds=60.0, seed=2025, max_scenes=None):
+def run(seconds=60.0, seed=2025, max_scenes=None, sh_share=0.0):
     """-> (scenes, scenes with nothing visible); raises AssertionError with the configuration on the first difference."""
     assert _cabi.torch_node() is not None, "needs sgr_torch_node.so"
     dev = torch.device("cuda", 0)
@@ -30,14 +30,24 @@ def run(seconds=60.0, seed=2025, max_scenes=None):
             if rng.random() < 0.3:
                 cov = (cov * rng.uniform(1.0, 30.0)).astype(np.float32)        # larger splats: more tiles per Gaussian, deeper lists
             base = [t(g["position"])[None], t(g["rgb"])[None], t(g["opacity"].reshape(P, 1))[None], t(cov)[None]]
+            # a quarter of the scenes through the PYTHON node with spherical harmonics + scales / rotations (the flavour the C++ node does not take;
+            # rasterizer.FUSE_STEP_IN_PYTHON_NODE switches its fused step), in a random capacity mode incl. the exact one
+            sh = sh_share > 0.0 and rng.random() < sh_share            # (sh_share = 0: no draw -- the sequences of the regression test stay what they were)
+            if sh:
+                deg = int(rng.integers(0, 4)); M = (deg + 1) ** 2
+                q = rng.normal(size=(P, 4)).astype(np.float32); q /= np.linalg.norm(q, axis=1, keepdims=True)
+                base = [base[0], t((rng.normal(size=(1, P, M, 3)) * 0.3).astype(np.float32)), base[2], t(rng.uniform(0.005, 0.08, (1, P, 3)).astype(np.float32)), t(q)[None]]
             views = [int(v) for v in rng.choice(90, V, replace=False)]
             cv, cvp, cp = cameras.make_cameras(views)
             bg = torch.tensor(rng.uniform(-0.2, 1.2, 3).astype(np.float32), device=dev)            # (beyond [0, 1] as well: the clamp's mask on the background)
-            st = R.BatchedRasterizationSettings(H, W, cameras.TAN_HALF_FOV, cameras.TAN_HALF_FOV, bg, 1.0, t(cv), t(cvp), 0, t(cp), V, False, 1)
+            st = R.BatchedRasterizationSettings(H, W, cameras.TAN_HALF_FOV, cameras.TAN_HALF_FOV, bg, 1.0, t(cv), t(cvp), deg if sh else 0, t(cp), V, False, 1)
             # capacity: the exact count of a probe render times a random head-room
             with torch.no_grad():
-                cnt = int(R.forward_debug(base[0], base[2], colors_precomp=base[1], cov3D_precomp=base[3], settings=st._replace(max_rendered=0))["num_rendered"])
+                kw = dict(shs=base[1], scales=base[3], rotations=base[4]) if sh else dict(colors_precomp=base[1], cov3D_precomp=base[3])
+                cnt = int(R.forward_debug(base[0], base[2], settings=st._replace(max_rendered=0), **kw)["num_rendered"])
             st = st._replace(max_rendered=int(cnt * rng.uniform(1.0, 2.0)) + int(rng.integers(1, 5000)))
+            if sh and rng.random() < 0.3:
+                st = st._replace(max_rendered=0)
             gen = torch.Generator(device=dev).manual_seed(int(rng.integers(1 << 30)))
             target = torch.rand(V, 3, H, W, device=dev, generator=gen)
             mask = (torch.rand(V, 1, H, W, device=dev, generator=gen) > 0.3).float() if rng.random() < 0.6 else None
@@ -46,13 +56,17 @@ def run(seconds=60.0, seed=2025, max_scenes=None):
             for fused in (1, 0, 1):
                 L.sgr_set_fused_step(fused)
                 leaves = [x.clone().requires_grad_(True) for x in base]
-                out = R.rasterize_l1_loss_batched(leaves[0], None, None, leaves[1], leaves[2], None, None, leaves[3], st, target, mask, weight)
+                if sh:
+                    R.FUSE_STEP_IN_PYTHON_NODE = bool(fused)
+                    out = R._RasterizeL1Batched.apply(leaves[0], None, leaves[1], None, leaves[2], leaves[3], leaves[4], None, st, target, mask, weight)
+                else:
+                    out = R.rasterize_l1_loss_batched(leaves[0], None, None, leaves[1], leaves[2], None, None, leaves[3], st, target, mask, weight)
                 out[0].backward()
                 torch.cuda.synchronize()
                 res.append([np.atleast_1d(o.detach().cpu().numpy()).copy() for o in out] + [x.grad.detach().cpu().numpy().copy() for x in leaves])
             R.check_pending_overflows(True)
             cfg = (P, H, W, V, mask is not None, cnt)
-            names = ("loss", "per_view", "color", "radii", "depth", "alpha", "d_means3D", "d_rgb", "d_opacity", "d_cov3D")
+            names = ("loss", "per_view", "color", "radii", "depth", "alpha", "d_means3D", "d_rgb|sh", "d_opacity", "d_cov3D|scales", "d_rotations")
             for nm, a, b in zip(names, res[0], res[2]):                       # fused, run to run: everything, the loss included
                 if not np.array_equal(a.view(np.uint8), b.view(np.uint8)):
                     bad = np.argwhere(a != b)
@@ -67,9 +81,10 @@ def run(seconds=60.0, seed=2025, max_scenes=None):
             n_empty += cnt == 0
     finally:
         L.sgr_set_fused_step(1)
+        R.FUSE_STEP_IN_PYTHON_NODE = False
     return n, n_empty
 
 
 if __name__ == "__main__":
-    n, n_empty = run(float(sys.argv[1]) if len(sys.argv) > 1 else 60.0)
+    n, n_empty = run(float(sys.argv[1]) if len(sys.argv) > 1 else 60.0, int(sys.argv[2]) if len(sys.argv) > 2 else 2025, sh_share=float(os.environ.get("FUZZ_SH", "0.25")))
     print("fuzz ok:", n, "scenes,", n_empty, "of them with nothing visible")
