@@ -20,6 +20,9 @@ def run(seconds=60.0, seed=1, max_scenes=None):
         S = int(rng.choice([1, 1, 2, 3])); V = int(rng.choice([1, 1, 2, 4, 8]))
         H = int(rng.integers(8, 300)); W = int(rng.integers(8, 300))
         P = int(rng.choice([1, 50, 1000, 6000, 20000]))
+        if os.environ.get("FUZZ_THIN"):               # extreme aspect ratios: a few pixels by a few thousand
+            a, b = int(rng.integers(1, 20)), int(rng.integers(300, 5000))
+            H, W = (a, b) if rng.random() < 0.5 else (b, a)
         if os.environ.get("FUZZ_BIG"):                # full-size scenes: several rounds per tile list, deep tiles, every sort flavour's large path
             S, V = 1, int(rng.choice([1, 2, 8])); H = W = int(rng.choice([512, 496, 1024])); P = int(rng.choice([100000, 300000]))
         sh = rng.random() < 0.3
