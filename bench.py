@@ -29,8 +29,9 @@ One "step" = one pass of the hot path over one batch (all view slots of this ran
 of the whole job with inputs resident in HBM.  The timed step is the rasterizer (+ fused loss): distCUDA2 + get_covariance
 (gs.py:70-73) run once per subject outside it; their cost is reported as `frontend_ms_per_subject`, and `variants.renderer_render_ms_per_step`
 times what the reference's render() really pays: GaussianRenderer.render (3-NN + covariance + rasterizer + clamp) forward and backward.
-A timed region shorter than 100 ms is not a measurement: when `--steps K` would give one, as many steps as 100 ms hold (at least 100) are
-timed instead and the line says so (`steps` = what was timed, `steps_requested` = K).  `gpu_ms_per_step` is the same region between two HIP
+A timed region shorter than 300 ms is not a measurement on this pool (its boxes have slow phases of 10-50 ms: a 100-ms region that met one read
+0.1474 ms per step with every repeat window behind it at 0.131): when `--steps K` would give a shorter one, as many steps as 300 ms hold (at least
+100) are timed instead and the line says so (`steps` = what was timed, `steps_requested` = K).  `gpu_ms_per_step` is the same region between two HIP
 events on the launch stream (first kernel to last kernel: it excludes the host's final synchronise, not the gaps the host may leave between
 steps); `windows` repeats the K steps `--windows` more times and reports min / median / max per step of wall and event time, so that a slow
 phase of the box or of its clocks shows up as spread instead of being folded into one number; `sclk_mhz` = the GPU's shader clock sampled
@@ -484,12 +485,13 @@ def main(args):
         t3 = float(tr.item())
     for _ in range(min(2000, int(0.05 / max(t3 / 3.0, 1e-5)))):
         step()
-    # a timed region under 100 ms is noise, not a measurement (20 steps of C2 are 3 ms; 20-ms windows of one box within a minute: 0.131 .. 0.159 ms per step,
-    # the slow phases last a few ms each and are neither the host's garbage collector nor its run-ahead): time as many steps as 100 ms hold then, and say so
+    # a timed region under 300 ms is noise, not a measurement (20 steps of C2 are 3 ms; 20-ms windows of one box within a minute: 0.131 .. 0.159 ms per step;
+    # 100-ms regions: 0.1307 .. 0.1474 with the repeat windows behind them at 0.131 -- the slow phases last 10-50 ms and are neither the host's garbage
+    # collector nor its run-ahead): time as many steps as 300 ms hold then, and say so
     steps_requested = steps
     t_step = max(t3 / 3.0, 1e-6)
-    if steps * t_step < 0.100:
-        steps = max(steps, int(np.ceil(0.100 / t_step)), 100)
+    if steps * t_step < 0.300:
+        steps = max(steps, int(np.ceil(0.300 / t_step)), 100)
         if dist_on:                                   # the same count on every rank
             ts = torch.tensor([steps], device=dev, dtype=torch.int64)
             dist.all_reduce(ts, op=dist.ReduceOp.MAX)
