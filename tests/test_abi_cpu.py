@@ -171,3 +171,15 @@ def test_torch_node_module_loads_and_exports_both_ops():
     assert node.abi_version() == _cabi.lib().sgr_abi_version()
     for name in ("rasterize_gaussians", "rasterize_l1_batched", "check_pending", "check_pending_batched", "set_count_check", "slot_stats"):
         assert callable(getattr(node, name)), name
+
+
+def test_allocator_callback_never_raises():
+    """The ctypes allocator callback of the Python nodes must turn a failed allocation into NULL (an escaping exception would leave ctypes an
+    uninitialised return value, i.e. hand the library a garbage device pointer): here the allocation fails because this box has no GPU."""
+    import torch
+    from sigman_release_amd import rasterizer as R
+    if torch.cuda.is_available():
+        pytest.skip("needs a box without a GPU (the allocation has to fail)")
+    R._alloc_target.dev, R._alloc_target.blobs, R._alloc_target.error = torch.device("cuda", 0), [None] * 4, None
+    assert R._alloc_cb(None, 2, 1 << 20) == 0
+    assert R._alloc_target.blobs[2] is None and "blob 2" in R._alloc_target.error
