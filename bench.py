@@ -35,7 +35,9 @@ A timed region shorter than 300 ms is not a measurement on this pool (its boxes 
 events on the launch stream (first kernel to last kernel: it excludes the host's final synchronise, not the gaps the host may leave between
 steps); `windows` repeats the K steps `--windows` more times and reports min / median / max per step of wall and event time, so that a slow
 phase of the box or of its clocks shows up as spread instead of being folded into one number; `sclk_mhz` = the GPU's shader clock sampled
-from sysfs by a side process while those windows run (not during the timed region: each read is a message to the SMU and cost it ~0.5 us per step).  The loss of the timed step is the reference's MASKED L1 (whole_loss.py:126-131:
+from sysfs by a side process while those windows run (not during the timed region: each read is a message to the SMU and cost it ~0.5 us per step);
+`sclk_mhz_probe` = the clock a wave really ran at right before and right behind the timed region, from the chip's own counters (the sysfs node has
+shown 95-157 MHz under full load on boxes of this pool; some boxes sit at a level where the same build reads 0.147 instead of 0.131 ms per step).  The loss of the timed step is the reference's MASKED L1 (whole_loss.py:126-131:
 gt_masks multiplies prediction and target; mask = ground-truth alpha > 0.5) unless `--no-mask`.
 `roofline` is for the dominant kernel, timed with HIP events recorded by the library on the launch stream inside the
 timed region; `roofline.traffic` comes from the committed rocprofv3 PMC summary of this same command
@@ -525,6 +527,15 @@ def main(args):
     for _ in range(max(3, min(warmup, 50))):
         step()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)   # (the library launches on torch's current stream)
+
+    def clock_probe():
+        # the shader clock a wave really runs at, from the chip's own counters (sgr_clock_probe: ~0.5 ms, outside the timed region)
+        import ctypes as _C
+        mhz = _C.c_double(0.0)
+        rc = L.sgr_clock_probe(_C.byref(mhz), _C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        return round(mhz.value, 1) if rc == 0 else None
+    sync_all()
+    clk_before = clock_probe()
     sync_all()
     t0 = time.perf_counter()
     ev0.record()
@@ -538,6 +549,7 @@ def main(args):
     sync_all()
     elapsed = time.perf_counter() - t0
     gpu_elapsed = ev0.elapsed_time(ev1) * 1e-3
+    clk_after = clock_probe()
     # ---- the same K steps `--windows` more times: spread of wall and event time per step (not the headline: that is the region above)
     # The shader clock is sampled HERE, over the repeat windows, not over the headline region: the side process (another core, no GIL, no HIP)
     # reads an amdgpu sysfs node every 10 ms, each read is a message to the SMU, and with it running the region read 0.4-0.9 us per step above
@@ -653,6 +665,8 @@ def main(args):
                           "note": "repeats of the timed region behind it (this rank); the headline is the first region, not their minimum"}
     if sclk_report is not None:
         out["sclk_mhz"] = sclk_report
+    out["sclk_mhz_probe"] = {"before_timed_region": clk_before, "behind_timed_region": clk_after,
+                             "how": "sgr_clock_probe: one wave's cycle counter against the chip's constant 100-MHz counter over ~0.5 ms"}
     if rank == 0 and world == 1:
         out["frontend_ms_per_subject"] = frontend_ms(g_host, dev)
         if not args.no_variants and args.config in ("c2", "c3"):

@@ -358,6 +358,10 @@ int sgr_prof_configure(uint32_t kernel_mask);
 /* after a device/stream synchronise: per-kernel-id summed milliseconds and launch counts; clears the log */
 int sgr_prof_collect(double *total_ms /*[SGR_K_COUNT]*/, uint32_t *counts /*[SGR_K_COUNT]*/);
 
+/* the shader clock (MHz) one wave ran at during a ~0.5-ms probe kernel on `stream`: ratio of the chip's own cycle counter to its constant 100-MHz
+ * counter (bench.py reports it around the timed region: the box pool has a slow level the amdgpu sysfs node does not show).  Synchronises the stream. */
+int sgr_clock_probe(double *mhz_host, void *stream);
+
 /* upstream `mark_visible`: present[i] = (view-space z > 0.2) */
 int sgr_mark_visible(int32_t P, const float *means3D, const float *viewmatrix, uint8_t *present, void *stream);
 

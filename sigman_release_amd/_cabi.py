@@ -85,6 +85,7 @@ _SIGNATURES = {
     "sgr_cov3d_backward": (C.c_int, [C.c_int32] + [C.c_void_p] * 7),
     "sgr_clamped_l1_loss": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p,
                                       C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
+    "sgr_clock_probe": (C.c_int, [C.POINTER(C.c_double), C.c_void_p]),
     "sgr_prof_configure": (C.c_int, [C.c_uint32]),
     "sgr_prof_collect": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_uint32)]),
 }

@@ -72,3 +72,34 @@ extern "C" int sgr_prof_collect(double *total_ms /*[SGR_K_COUNT]*/, uint32_t *co
     g_used = 0;
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------
+// shader-clock probe (bench.py): one wave spins on a dependent FMA chain for ~0.5 ms and reads both of the chip's counters around it -- the
+// cycle counter of its own clock domain (s_memtime) and the constant 100-MHz one (s_memrealtime); their ratio is the shader clock the wave
+// actually ran at.  (The amdgpu sysfs node bench.py used to trust reported 157 MHz and 95 MHz under full load on some boxes of this pool.)
+// ---------------------------------------------------------------------------------------------
+namespace {
+__global__ void clock_probe_kernel(unsigned long long *out, int iters) {
+    float x = (float)threadIdx.x * 1e-3f;
+    const unsigned long long w0 = wall_clock64(), c0 = __builtin_readcyclecounter();
+    for (int i = 0; i < iters; i++) x = fmaf(x, 0.999f, 1e-3f);
+    const unsigned long long c1 = __builtin_readcyclecounter(), w1 = wall_clock64();
+    if (threadIdx.x == 0) { out[0] = c1 - c0; out[1] = w1 - w0; }
+    if (x == 123.456f) out[2] = 1ull;                        // (keeps the chain alive)
+}
+}  // namespace
+
+extern "C" int sgr_clock_probe(double *mhz_host, void *stream_) {
+    if (!mhz_host) { sgr_set_error("sgr_clock_probe: NULL argument"); return 1; }
+    hipStream_t stream = (hipStream_t)stream_;
+    unsigned long long *dev = nullptr, host[3] = {0, 0, 0};
+    SGR_CHECK_HIP(hipMalloc((void **)&dev, sizeof(host)));
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, stream, dev, 250000);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(host, dev, sizeof(host), hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    (void)hipFree(dev);
+    if (e != hipSuccess) { sgr_set_error("sgr_clock_probe: %s", hipGetErrorString(e)); return 1; }
+    *mhz_host = host[1] ? 100.0 * (double)host[0] / (double)host[1] : 0.0;
+    return 0;
+}
