@@ -100,6 +100,9 @@ if __name__ == "__main__":
         sys.exit(_self_launch(_ARGS))          # (before any thread pinning: children inherit the affinity mask)
 
 
+_COUNT_WAIT_DEFAULT = "lazy:4"      # (the library default stays "own"; SIGMAN_COUNT_WAIT=own times that)
+
+
 def _pin_host_threads():
     """One process per GPU, pinned to 4 neighbouring cores (before torch creates its threads): the C2 step is ~0.2 ms of
     GPU work driven by two host threads (Python + autograd engine); left to the scheduler of a 2-socket / 256-thread host they
@@ -512,9 +515,10 @@ def main(args):
     # more behind the timed region (check_pending_overflows below).  SIGMAN_COUNT_WAIT=own keeps the default.
     lazy_counts = False
     _node = _cabi.torch_node()
-    if _node is not None and not args.exact_sync and os.environ.get("SIGMAN_COUNT_WAIT", "own") == "lazy":     # (opt-in: measured, no clear gain -- see DESIGN 7e)
-        _node.set_count_wait("lazy")
-        lazy_counts = True
+    _cw = os.environ.get("SIGMAN_COUNT_WAIT", _COUNT_WAIT_DEFAULT)
+    if _node is not None and not args.exact_sync and _cw != "own":
+        _node.set_count_wait(_cw)
+        lazy_counts = _cw
         for _ in range(3):
             step()
     # no cyclic garbage collection inside the timed region: every step creates a few hundred Python objects, and a generation-2 pass that
@@ -546,8 +550,10 @@ def main(args):
         if _DEBUG_BLOCKS and (k_ + 1) % max(steps // 8, 1) == 0:
             dbg_marks.append(time.perf_counter() - t0)           # (host time stamps only: no synchronisation inside the timed region)
     ev1.record()
+    t_issued = time.perf_counter() - t0                          # the host has handed over the last step; what the GPU still holds drains below
     sync_all()
     elapsed = time.perf_counter() - t0
+    elapsed_local = elapsed
     gpu_elapsed = ev0.elapsed_time(ev1) * 1e-3
     clk_after = clock_probe()
     # ---- the same K steps `--windows` more times: spread of wall and event time per step (not the headline: that is the region above)
@@ -555,7 +561,7 @@ def main(args):
     # reads an amdgpu sysfs node every 10 ms, each read is a message to the SMU, and with it running the region read 0.4-0.9 us per step above
     # the windows behind it (four alternating runs on one box; ~0.3 without).
     sclk = _SclkSampler(local_rank) if (rank == 0 and not args.no_sclk and args.windows > 0) else None
-    win_wall, win_gpu = [], []
+    win_wall, win_gpu, win_drain = [], [], []
     for _w in range(max(args.windows, 0)):
         sync_all()
         tw = time.perf_counter()
@@ -563,7 +569,9 @@ def main(args):
         for _ in range(steps):
             step()
         ev1.record()
+        tq = time.perf_counter()
         sync_all()
+        win_drain.append((time.perf_counter() - tq) * 1e3)
         win_wall.append((time.perf_counter() - tw) / steps * 1e3)
         win_gpu.append(ev0.elapsed_time(ev1) / steps)
     sclk_report = sclk.stop() if sclk is not None else None
@@ -634,7 +642,7 @@ def main(args):
                    "parallelism": (f"view-parallel x{world} ({backend}), exchange={'none (forward only)' if not bwd else args.exchange}" if dist_on else "single GPU"),
                    "fused_step": fused_step, "ranks_seen": world, "num_rendered_per_gpu": Rn, "gaussian_pixel_visits_per_gpu": S_visits,
                    "binning_buffers": "exact (D2H read of num_rendered per step)" if args.exact_sync else (f"pre-sized, max_rendered={st.max_rendered} (sync-free)" if st else "-"),
-                   "count_check": "exact read" if args.exact_sync else ("every step, by the backward of the step after next at the latest (set_count_wait lazy)" if lazy_counts else "every step, by its own backward")},
+                   "count_check": "exact read" if args.exact_sync else (f"every step, by a later forward of the thread at the latest (set_count_wait {lazy_counts}: the host may run ahead of the GPU by that many steps + 1; once more behind the timed region)" if lazy_counts else "every step, by its own backward")},
         "gaussian_pixel_ops_per_s_per_gpu": round(S_visits / (ms_per_step * 1e-3), 1),
         "tile_instances_per_s_per_gpu": round(Rn / (ms_per_step * 1e-3), 1),
         "step_hbm": {"algorithmic_bytes_per_step_per_gpu": step_bytes, "achieved_GBps": round(step_bytes / (ms_per_step * 1e-3) / 1e9, 1),
@@ -659,9 +667,15 @@ def main(args):
     except Exception:      # noqa: BLE001
         pass
     out["config"]["host_threads"] = pin_report
+    # Who limited the timed region: when the host has issued its last step, the work the GPU still holds takes `queue_drain_steps` steps' worth of
+    # time to finish.  Many steps = the host ran ahead and the GPU set the pace; ~1 or less = the GPU was waiting for the host (a host-bound
+    # region: the 0.14-0.15-ms readings of some runs on this pool's shared hosts are of that kind -- DESIGN.md 7).
+    out["host_queue"] = {"issue_ms_per_step": round(t_issued / steps * 1e3, 4), "queue_drain_steps": round((elapsed_local - t_issued) / (elapsed_local / steps), 2),
+                         "note": "queue_drain_steps ~<= 1: the region was host-bound (the GPU idled between steps); >> 1: GPU-bound"}
     if win_wall:
         q = lambda v: [round(float(x), 4) for x in (np.min(v), np.median(v), np.max(v))]
         out["windows"] = {"n": len(win_wall), "steps_each": steps, "wall_ms_per_step_min_median_max": q(win_wall), "gpu_ms_per_step_min_median_max": q(win_gpu),
+                          "queue_drain_steps_min_median_max": q([d / w for d, w in zip(win_drain, win_wall)]),
                           "note": "repeats of the timed region behind it (this rank); the headline is the first region, not their minimum"}
     if sclk_report is not None:
         out["sclk_mhz"] = sclk_report

@@ -460,18 +460,30 @@ bool b_resolve(BPending &p, bool block) {
 // host hiccup longer than the slack becomes a bubble on the GPU.  1 = "lazy" (set_count_wait("lazy") / SIGMAN_COUNT_WAIT=lazy; bench.py opts in):
 // the backward only looks (no wait); a count that has not arrived stays pending and is waited for by the thread's forward after next -- the host
 // may run two steps ahead.  An overflow is then reported one step later ("EARLIER forward"), still before anything else of that thread runs.
-std::atomic<int> g_count_wait{-1};
-bool count_wait_lazy() {
-    int v = g_count_wait.load();
-    if (v < 0) { const char *e = getenv("SIGMAN_COUNT_WAIT"); v = (e && std::string(e) == "lazy") ? 1 : 0; g_count_wait.store(v); }
-    return v == 1;
+// "lazy:N" (N = 1..16): the newest N forwards may stay unlooked-at (the host may run N + 1 steps ahead, an overflow is reported at most N steps
+// later) -- the slack that rides out a host thread that is preempted for a few hundred microseconds on a shared machine.
+std::atomic<int> g_count_wait{-1};               // -1 = not read yet; 0 = own; N >= 1 = lazy, depth N
+int parse_count_wait(const std::string &m) {     // -1 = not a mode
+    if (m == "own") return 0;
+    if (m == "lazy") return 1;
+    if (m.rfind("lazy:", 0) == 0 && m.size() > 5 && m.size() <= 7 && m.find_first_not_of("0123456789", 5) == std::string::npos) {
+        const int n = atoi(m.c_str() + 5);
+        if (n >= 1 && n <= 16) return n;
+    }
+    return -1;
 }
+int count_wait_depth() {
+    int v = g_count_wait.load();
+    if (v < 0) { const char *e = getenv("SIGMAN_COUNT_WAIT"); v = e ? parse_count_wait(e) : 0; if (v < 0) v = 0; g_count_wait.store(v); }
+    return v;
+}
+bool count_wait_lazy() { return count_wait_depth() >= 1; }
 
 void b_poll(bool block) {            // forwards of this thread whose backward never ran (or, lazy: ran before the count had arrived)
     auto &v = b_pending();
     std::shared_ptr<BPending> bad;
     size_t keep = 0;
-    const size_t in_flight = count_wait_lazy() ? 1 : 128;          // newest entries that may stay unresolved
+    const size_t in_flight = count_wait_lazy() ? (size_t)count_wait_depth() : 128;          // newest entries that may stay unresolved
     for (size_t i = 0; i < v.size(); i++) {
         BPending &p = *v[i];
         const bool done = p.checked || b_resolve(p, block || v.size() - i > in_flight);
@@ -886,10 +898,12 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
           }, "'inline' (default): the instance count is checked inside every call, a forward that does not fit is re-rendered exactly before it "
              "returns; 'deferred': the check moves behind the call once a shape's capacity has been stable (== SIGMAN_COUNT_CHECK=deferred)");
     m.def("set_count_wait", [](const std::string &mode) {
-              TORCH_CHECK(mode == "own" || mode == "lazy", "set_count_wait: 'own' or 'lazy'");
-              g_count_wait.store(mode == "lazy" ? 1 : 0);
+              const int d = parse_count_wait(mode);
+              TORCH_CHECK(d >= 0, "set_count_wait: 'own', 'lazy' or 'lazy:N' (N = 1..16)");
+              g_count_wait.store(d);
           }, "explicit-capacity batched nodes: 'own' (default): a backward waits for its forward's instance count; 'lazy': it only looks, a count that "
-             "has not arrived is waited for by the thread's forward after next (the host may run two steps ahead; an overflow is reported one step later)");
+             "has not arrived is waited for by the thread's forward after next (the host may run two steps ahead; an overflow is reported one step later); "
+             "'lazy:N': the newest N forwards may stay unlooked-at (N + 1 steps ahead, reported at most N steps later)");
     m.def("slot_stats", []() { std::lock_guard<std::mutex> l(g_slot_mu); return std::make_tuple((uint64_t)g_slots_created, (uint64_t)g_free_slots.size()); },
           "(pinned count slots ever created, idle slots in the pool)");
     m.def("key_state", [](int dev, int64_t P, int64_t H, int64_t W) { std::lock_guard<std::mutex> l(g_mu); const KeyState &k = g_keys[std::make_tuple(dev, P, H, W)];

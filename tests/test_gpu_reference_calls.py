@@ -954,9 +954,10 @@ def test_cpp_render_node_equals_python_render(monkeypatch):
 
 
 def test_cpp_batched_l1_node_lazy_count_wait():
-    """set_count_wait("lazy") (what bench.py opts into): a backward only LOOKS at its forward's instance count; one that has not arrived is waited
-    for by the thread's forward after next.  Same results as the default; an overflow is reported by the forward's own backward if the count
-    was there, else by one of the next two forwards ("EARLIER forward") or by check_pending_overflows() -- never lost."""
+    """set_count_wait("lazy" / "lazy:N") (what bench.py opts into): a backward only LOOKS at its forward's instance count; one that has not arrived
+    is waited for by the thread's forward after next (N = 1) / by the forward N + 1 later at the latest.  Same results as the default; an overflow is
+    reported by the forward's own backward if the count was there, else by one of the next N + 1 forwards ("EARLIER forward") or by
+    check_pending_overflows() -- never lost."""
     from sigman_release_amd import _cabi, rasterizer as R
     node = _cabi.torch_node()
     if node is None:
@@ -967,7 +968,10 @@ def test_cpp_batched_l1_node_lazy_count_wait():
     ok, small = mk(400000), mk(1000)
     res = {}
     try:
-        for mode in ("own", "lazy"):
+        for bad in ("", "eager", "lazy:", "lazy:0", "lazy:17", "lazy:x", "lazy:4 "):
+            with pytest.raises(RuntimeError, match="set_count_wait"):
+                node.set_count_wait(bad)
+        for mode in ("own", "lazy", "lazy:4"):
             node.set_count_wait(mode)
             for _ in range(40):                                              # many steps deep: pending entries are recycled
                 d = {k: v.clone().requires_grad_(True) for k, v in base.items()}
@@ -976,26 +980,27 @@ def test_cpp_batched_l1_node_lazy_count_wait():
             torch.cuda.synchronize()
             res[mode] = [out[2].detach().clone()] + [d[k].grad.clone() for k in ("means3D", "rgb", "opacity", "cov3D")]
             R.check_pending_overflows(True)
-        for a, b in zip(res["own"], res["lazy"]):
-            assert torch.equal(a, b)
-        node.set_count_wait("lazy")
-        seen = []
-        d = {k: v.clone().requires_grad_(True) for k, v in base.items()}
-        loss = call(d, small)[0]                                             # does not fit
-        try:
-            loss.backward()
-        except RuntimeError as e:
-            seen.append(str(e))
-        for _ in range(3):                                                   # the report comes from one of the next forwards at the latest
-            if seen:
-                break
+        for a, b, c in zip(res["own"], res["lazy"], res["lazy:4"]):
+            assert torch.equal(a, b) and torch.equal(a, c)
+        for depth, lazy_mode in ((1, "lazy"), (4, "lazy:4")):
+            node.set_count_wait(lazy_mode)
+            seen = []
+            d = {k: v.clone().requires_grad_(True) for k, v in base.items()}
+            loss = call(d, small)[0]                                             # does not fit
             try:
-                d = {k: v.clone().requires_grad_(True) for k, v in base.items()}
-                call(d, ok)[0].backward()
+                loss.backward()
             except RuntimeError as e:
                 seen.append(str(e))
-        assert len(seen) == 1 and "exceeds max_rendered 1000" in seen[0], seen
-        torch.cuda.synchronize()
-        R.check_pending_overflows(True)                                      # nothing left behind
+            for _ in range(depth + 2):                                           # the report comes from one of the next forwards at the latest
+                if seen:
+                    break
+                try:
+                    d = {k: v.clone().requires_grad_(True) for k, v in base.items()}
+                    call(d, ok)[0].backward()
+                except RuntimeError as e:
+                    seen.append(str(e))
+            assert len(seen) == 1 and "exceeds max_rendered 1000" in seen[0], seen
+            torch.cuda.synchronize()
+            R.check_pending_overflows(True)                                      # nothing left behind
     finally:
         node.set_count_wait("own")
