@@ -37,7 +37,11 @@ steps); `windows` repeats the K steps `--windows` more times and reports min / m
 phase of the box or of its clocks shows up as spread instead of being folded into one number; `sclk_mhz` = the GPU's shader clock sampled
 from sysfs by a side process while those windows run (not during the timed region: each read is a message to the SMU and cost it ~0.5 us per step);
 `sclk_mhz_probe` = the clock a wave really ran at right before and right behind the timed region, from the chip's own counters (the sysfs node has
-shown 95-157 MHz under full load on boxes of this pool; some boxes sit at a level where the same build reads 0.147 instead of 0.131 ms per step).  The loss of the timed step is the reference's MASKED L1 (whole_loss.py:126-131:
+shown 95-157 MHz under full load on boxes of this pool); `host_queue` says who set the pace of the timed region: `queue_drain_steps` = how many
+steps' worth of work the GPU still held when the host had issued its last step (<< 1: the GPU was waiting for the host -- every 0.14-0.157-ms
+reading of this build was of that kind, with the library's default count wait on a busy shared host; profiles/r05_count_wait_ab.txt -- which is
+why the timed step runs with set_count_wait("lazy:4"): the host may be five steps ahead, every step's instance count is still checked, at most
+four steps later and once more behind the region; SIGMAN_COUNT_WAIT=own times the library default).  The loss of the timed step is the reference's MASKED L1 (whole_loss.py:126-131:
 gt_masks multiplies prediction and target; mask = ground-truth alpha > 0.5) unless `--no-mask`.
 `roofline` is for the dominant kernel, timed with HIP events recorded by the library on the launch stream inside the
 timed region; `roofline.traffic` comes from the committed rocprofv3 PMC summary of this same command
@@ -510,9 +514,10 @@ def main(args):
     # ---- timed region (no per-kernel events here)
     # The fused node's backward normally WAITS for its own forward's instance count (it arrives ~15 us into that forward's kernels): the host can
     # then never be more than one step ahead, and a host hiccup longer than the ~30 us of slack a 133-us step leaves becomes a bubble on the GPU
-    # (timed regions of 0.131 .. 0.144 ms on one box within a minute).  "lazy": the backward only looks; a count that has not arrived yet is waited
-    # for two forwards later (csrc/torch_node.cpp, set_count_wait) -- the overflow check still happens for every step, one step later, and once
-    # more behind the timed region (check_pending_overflows below).  SIGMAN_COUNT_WAIT=own keeps the default.
+    # (timed regions of 0.131 .. 0.157 ms on one box within a minute, the slow ones with the GPU idle between steps: profiles/r05_count_wait_ab.txt).
+    # "lazy:N": the backward only looks; a count that has not arrived yet is waited for N + 1 forwards later (csrc/torch_node.cpp,
+    # set_count_wait) -- the overflow check still happens for every step, at most N steps later, and once more behind the timed region
+    # (check_pending_overflows below).  SIGMAN_COUNT_WAIT=own times the library default.
     lazy_counts = False
     _node = _cabi.torch_node()
     _cw = os.environ.get("SIGMAN_COUNT_WAIT", _COUNT_WAIT_DEFAULT)
