@@ -30,11 +30,15 @@ out.append("| `r05_bench_{c1,c2,c3,c4,c5}.json` | full bench lines (variants, wi
            + ", ".join(f"{c.upper()} {b[c]['ms_per_step']:.4g}" for c in b) + " ms per step |")
 out.append("| `r05_{c2,c3,c4,c5}_bench.json`, `r05_*_bench_under_rocprof.json` | the bench line of the profiled command without / under rocprofv3 |")
 out.append("| `r05_bench_*_n2gloo.json` | `SIGMAN_BENCH_BACKEND=gloo python bench.py --gpus 2 --config <c> [--exchange ...]`: the 2-rank path on ONE GPU, host-staged collectives -- plumbing, not measurements |")
+out.append("| `r05_fused_step_ab.txt` | the fused single-view step against the unfused chain on one box (`SIGMAN_FUSED_STEP=0/1`, three alternating runs) |")
+out.append("| `r05_count_wait_ab.txt`, `r05_bench_c2_lazy4_boxC.json` | who limits a slow C2 reading: `host_queue` of the bench line under the library's count-wait modes (own / lazy / lazy:4), on quiet hosts and with one busy loop per host core; a full line taken in a GPU-side slow phase |")
+out.append("| `r05_fuzz_parity.txt` | the round's randomised bit-for-bit sweeps (fused step, determinism, per-view pattern, host threads, 3-NN) |")
 out.append("| `r05_rocprofv3_counters_avail.txt` | `rocprofv3 --list-avail` of the box: there is no MALL / Infinity-Cache hit counter on gfx950 in this ROCm; the DRAM-side TCC_EA0 counters below are what exists |")
 out.append("")
 w = b["c2"].get("windows") or {}
 out.append(f"C2 headline line: {b['c2']['value']:.0f} views/s, {b['c2']['ms_per_step']:.4f} ms per step wall, gpu_ms_per_step {b['c2'].get('gpu_ms_per_step')}, "
-           f"windows {json.dumps(w)}, sclk {b['c2'].get('sclk_mhz')}.")
+           f"windows {json.dumps(w)}, sclk {b['c2'].get('sclk_mhz')}, sclk_mhz_probe {json.dumps({k: v for k, v in (b['c2'].get('sclk_mhz_probe') or {}).items() if k != 'how'})}, "
+           f"host_queue {json.dumps({k: v for k, v in (b['c2'].get('host_queue') or {}).items() if k != 'note'})}, count_check: {b['c2']['config'].get('count_check')}.")
 out.append("")
 out.append("DRAM-side check (`ea_dram_bytes` in `r05_pmc_*.json` = TCC_EA0_RDREQ_DRAM_32B x 32 B + write requests x 64 / 32 B): it equals 2 x FETCH_SIZE + WRITE_SIZE\n"
            "to within 1 % on every kernel group of C2-C5, i.e. the L2 counters already count only what leaves L2 towards the fabric; whether a request is then served\n"
