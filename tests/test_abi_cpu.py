@@ -169,8 +169,17 @@ def test_torch_node_module_loads_and_exports_both_ops():
     node = _cabi.torch_node()
     assert node is not None, "sgr_torch_node.so is not built (make -C sigman_release_amd/csrc)"
     assert node.abi_version() == _cabi.lib().sgr_abi_version()
-    for name in ("rasterize_gaussians", "rasterize_l1_batched", "check_pending", "check_pending_batched", "set_count_check", "slot_stats"):
+    for name in ("rasterize_gaussians", "rasterize_l1_batched", "check_pending", "check_pending_batched", "set_count_check", "set_count_wait", "slot_stats"):
         assert callable(getattr(node, name)), name
+    # the count-wait modes of the explicit-capacity batched nodes (host-only state): "own" | "lazy" | "lazy:N", N = 1..16; anything else is an error
+    try:
+        for good in ("lazy", "lazy:1", "lazy:4", "lazy:16", "own"):
+            node.set_count_wait(good)
+        for bad in ("", "eager", "lazy:", "lazy:0", "lazy:17", "lazy:x", "lazy:4 ", "lazy:-1", "LAZY"):
+            with pytest.raises(RuntimeError, match="set_count_wait"):
+                node.set_count_wait(bad)
+    finally:
+        node.set_count_wait("own")
 
 
 def test_allocator_callback_never_raises():
