@@ -522,7 +522,7 @@ def main(args):
     _node = _cabi.torch_node()
     _cw = os.environ.get("SIGMAN_COUNT_WAIT", _COUNT_WAIT_DEFAULT)
     if _node is not None and not args.exact_sync and _cw != "own":
-        _node.set_count_wait(_cw)
+        R.set_count_wait(_cw)
         lazy_counts = _cw
         for _ in range(3):
             step()

@@ -214,6 +214,19 @@ def check_pending_overflows(block: bool = True):
         raise err
 
 
+def set_count_wait(mode: str = "own"):
+    """Sync-free mode (max_rendered > 0) through the C++ batched nodes: WHEN a backward looks at its forward's instance count.
+    "own" (default): it waits for it -- an overflow raises before the optimizer step, and the host is at most one step ahead of the GPU.
+    "lazy" / "lazy:N" (N = 1..16): it only looks; a count that has not arrived is waited for by the thread's forward N + 1 later at the latest,
+    so the host may run N + 1 steps ahead (what keeps the GPU fed on a busy shared host: profiles/r05_count_wait_ab.txt) and an overflow is reported
+    at most N steps late -- never lost: call check_pending_overflows(True) behind the loop.  Process-wide; == SIGMAN_COUNT_WAIT."""
+    node = _cabi.torch_node()
+    if node is None:
+        raise RuntimeError("set_count_wait: the C++ autograd nodes (lib/sgr_torch_node.so) are not loaded (not built, or SIGMAN_PY_NODE=1); "
+                           "the Python nodes always wait for their own forward's count")
+    node.set_count_wait(mode)
+
+
 # one persistent allocator callback for the C ABI (creating a ctypes callback per call costs ~10 us); it serves the call
 # that is currently in flight on this thread: PyTorch allocates, the library only receives the pointer.
 # (thread-local: ctypes releases the GIL during the C call, and the forward (caller's thread) and a backward (autograd engine

@@ -173,8 +173,10 @@ def test_torch_node_module_loads_and_exports_both_ops():
         assert callable(getattr(node, name)), name
     # the count-wait modes of the explicit-capacity batched nodes (host-only state): "own" | "lazy" | "lazy:N", N = 1..16; anything else is an error
     try:
+        from sigman_release_amd import rasterizer as R
         for good in ("lazy", "lazy:1", "lazy:4", "lazy:16", "own"):
             node.set_count_wait(good)
+            R.set_count_wait(good)                              # (the public wrapper)
         for bad in ("", "eager", "lazy:", "lazy:0", "lazy:17", "lazy:x", "lazy:4 ", "lazy:-1", "LAZY"):
             with pytest.raises(RuntimeError, match="set_count_wait"):
                 node.set_count_wait(bad)
