@@ -449,11 +449,12 @@ bool b_resolve(BPending &p, bool block) {
     else while (g_b_by_id.size() > 4096) g_b_by_id.erase(g_b_by_id.begin());
     return true;
 }
-[[noreturn]] void b_raise(BPending &p, bool earlier) {
+[[noreturn]] void b_raise(BPending &p, bool earlier, size_t more = 0) {
     p.reported = true;
     TORCH_CHECK(false, "num_rendered ", p.count, " exceeds max_rendered ", p.capacity, ": results of ",
                 earlier ? "an EARLIER forward of this thread (reported now: nobody had looked at its count yet) are" : "this forward are",
-                " truncated; raise BatchedRasterizationSettings.max_rendered (or use 0 = exact mode)");
+                " truncated", more ? " (and those of " + std::to_string(more) + " more earlier forward(s) that did not fit either)" : std::string(),
+                "; raise BatchedRasterizationSettings.max_rendered (or use 0 = exact mode)");
 }
 // Explicit capacity: WHEN the backward looks at its forward's count.  0 = "own" (default): it waits for it -- the count arrives ~15 us into the
 // forward's own kernels, so the host can never be more than one step ahead of the GPU, and with ~100 us of host work per 133-us step (C2) every
@@ -482,16 +483,19 @@ bool count_wait_lazy() { return count_wait_depth() >= 1; }
 void b_poll(bool block) {            // forwards of this thread whose backward never ran (or, lazy: ran before the count had arrived)
     auto &v = b_pending();
     std::shared_ptr<BPending> bad;
-    size_t keep = 0;
+    size_t keep = 0, more = 0;
     const size_t in_flight = count_wait_lazy() ? (size_t)count_wait_depth() : 128;          // newest entries that may stay unresolved
     for (size_t i = 0; i < v.size(); i++) {
         BPending &p = *v[i];
         const bool done = p.checked || b_resolve(p, block || v.size() - i > in_flight);
-        if (done && p.overflow && !p.reported && !bad) bad = v[i];
+        if (done && p.overflow && !p.reported) {               // one error per call: it names the oldest and counts the others (none is dropped unsaid)
+            if (!bad) bad = v[i];
+            else { p.reported = true; more++; }
+        }
         if (!done) v[keep++] = v[i];
     }
     v.resize(keep);
-    if (bad) b_raise(*bad, true);
+    if (bad) b_raise(*bad, true, more);
 }
 
 struct RasterizeL1BatchedNode : public torch::autograd::Function<RasterizeL1BatchedNode> {

@@ -1,0 +1,108 @@
+"""Dev tool (GPU): the overflow bookkeeping of the explicit-capacity C++ L1 node under every count-wait mode (own / lazy / lazy:N).
+Random sequences of steps -- capacity fits or not, with a backward, under no_grad, or with the output dropped -- and the ledger must balance:
+every forward that ran with too small a capacity is covered by exactly one error (its own, or an "EARLIER forward ... (and those of K more ...)"
+one raised by a later call or by check_pending_overflows), no error without an overflow, fitting steps give the reference loss and gradients bit
+for bit whatever the mode, and every pinned count slot is back in the pool at the end of a round.
+usage: python tools/fuzz_count_wait.py [seconds] [seed]"""
+import os, re, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from sigman_release_amd import _cabi, cameras, synthetic, rasterizer as R
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+rng = np.random.default_rng(seed)
+dev = torch.device("cuda:0")
+node = _cabi.torch_node()
+assert node is not None
+t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+MORE = re.compile(r"and those of (\d+) more earlier")
+
+
+def scene(P, H, W, V, s):
+    g = synthetic.humanoid(P, s)
+    base = {"means3D": t(g["position"])[None], "rgb": t(g["rgb"])[None], "opacity": t(g["opacity"].reshape(P, 1))[None],
+            "cov3D": t(synthetic.covariance_from_gaussians(g))[None]}
+    cv, cvp, cp = cameras.make_cameras([int(v) for v in np.random.default_rng(s).choice(90, V, replace=False)])
+    mk = lambda cap: R.BatchedRasterizationSettings(H, W, cameras.TAN_HALF_FOV, cameras.TAN_HALF_FOV, torch.ones(3, device=dev), 1.0, t(cv), t(cvp), 0, t(cp), V, False, int(cap))
+    target = torch.rand(V, 3, H, W, device=dev)
+    return base, mk, target
+
+
+def call(base, st, target, grad=True):
+    d = {k: v.clone().requires_grad_(grad) for k, v in base.items()}
+    return d, R.rasterize_l1_loss_batched(d["means3D"], None, None, d["rgb"], d["opacity"], None, None, d["cov3D"], st, target, None, 1.0)
+
+
+t_end = time.time() + budget
+rounds = steps_total = overflows_total = errors_total = 0
+while time.time() < t_end:
+    P, H, W, V = int(rng.integers(200, 6000)), int(rng.choice([32, 64, 128])), int(rng.choice([48, 64, 144])), int(rng.integers(1, 4))
+    base, mk, target = scene(P, H, W, V, int(rng.integers(1, 1000)))
+    node.set_count_wait("own")
+    with torch.no_grad():
+        try:
+            call(base, mk(1), target, False)
+            count = 0                                    # nothing visible (or a single instance): every capacity fits
+        except RuntimeError as e:
+            count = int(re.search(r"num_rendered (\d+) exceeds", str(e)).group(1))
+    d, out = call(base, mk(max(count, 1)), target)
+    out[0].backward()
+    ref = [out[0].detach().clone()] + [d[k].grad.clone() for k in ("means3D", "rgb", "opacity", "cov3D")]
+    R.check_pending_overflows(True)
+    mode = str(rng.choice(["own", "lazy", "lazy:2", "lazy:4", "lazy:16"]))
+    node.set_count_wait(mode)
+    ran_over = covered = 0
+
+    def account(e, own_overflowed):
+        global covered
+        msg = str(e)
+        assert "exceeds max_rendered" in msg, msg
+        m = MORE.search(msg)
+        covered += 1 + (int(m.group(1)) if m else 0)
+
+    for _ in range(int(rng.integers(3, 40))):
+        fits = count <= 1 or rng.random() > 0.3
+        cap = int(rng.integers(max(count, 1), 4 * max(count, 1) + 2)) if fits else int(rng.integers(1, count))
+        kind = str(rng.choice(["bwd", "bwd", "bwd", "nograd", "dropped"]))
+        steps_total += 1
+        try:
+            if kind == "nograd":
+                with torch.no_grad():
+                    d, out = call(base, mk(cap), target, False)
+            else:
+                d, out = call(base, mk(cap), target)
+        except RuntimeError as e:
+            account(e, False)
+            if "this forward are" in str(e):                 # (no_grad: looked at once, the forward did run)
+                assert kind == "nograd" and not fits, (kind, fits, str(e))
+                ran_over += 1
+            continue                                         # an EARLIER forward's report: this call never launched
+        if not fits:
+            ran_over += 1
+        if kind == "bwd":
+            try:
+                out[0].backward()
+            except RuntimeError as e:
+                assert not fits, str(e)
+                account(e, True)
+                continue
+            if fits:
+                got = [out[0].detach()] + [d[k].grad for k in ("means3D", "rgb", "opacity", "cov3D")]
+                for a, b in zip(ref, got):
+                    assert torch.equal(a, b), (mode, cap, count)
+        del d, out
+    for _ in range(64):                                      # behind the loop: one error per call until the ledger is empty
+        try:
+            R.check_pending_overflows(True)
+            break
+        except RuntimeError as e:
+            account(e, False)
+    assert covered == ran_over, (mode, covered, ran_over)
+    torch.cuda.synchronize()
+    created, idle = node.slot_stats()
+    assert created == idle, (created, idle)
+    rounds += 1; overflows_total += ran_over; errors_total += covered
+node.set_count_wait("own")
+print(f"fuzz_count_wait seed {seed}: {rounds} rounds, {steps_total} steps, {overflows_total} forwards that did not fit -- each covered by exactly one error report; "
+      f"fitting steps bit-identical to the reference in every mode; all count slots returned")
