@@ -28,6 +28,8 @@ out.append("| `r05_sq_{c2,c3,c4}.json` | SQ counters of the compositing kernels 
 b = {c: j(f"r05_bench_{c}.json") for c in ("c1", "c2", "c3", "c4", "c5")}
 out.append("| `r05_bench_{c1,c2,c3,c4,c5}.json` | full bench lines (variants, windows, cpu_baseline, masked L1 headline): "
            + ", ".join(f"{c.upper()} {b[c]['ms_per_step']:.4g}" for c in b) + " ms per step |")
+out.append("| `r05_bench_c2_driver_cmd.json` | `python bench.py --gpus 1 --steps 20 --warmup 5`, the driver's command, on the round's last commit right behind the full GPU suite (214 passed) and `smoke()`: "
+           + f"{j('r05_bench_c2_driver_cmd.json')['ms_per_step']:.4f} ms per step, {j('r05_bench_c2_driver_cmd.json')['value']:.0f} views/s |")
 out.append("| `r05_{c2,c3,c4,c5}_bench.json`, `r05_*_bench_under_rocprof.json` | the bench line of the profiled command without / under rocprofv3 |")
 out.append("| `r05_bench_*_n2gloo.json` | `SIGMAN_BENCH_BACKEND=gloo python bench.py --gpus 2 --config <c> [--exchange ...]`: the 2-rank path on ONE GPU, host-staged collectives -- plumbing, not measurements |")
 out.append("| `r05_fused_step_ab.txt` | the fused single-view step against the unfused chain on one box (`SIGMAN_FUSED_STEP=0/1`, three alternating runs) |")
