@@ -147,6 +147,14 @@ def test_bench_rccl_path_with_one_rank():
         assert out["config"]["parallelism"] == f"view-parallel x1 (nccl), exchange={want}", out["config"]["parallelism"]
         assert out["config"]["name"] == config
         assert out["value"] > 0 and out["roofline"]["frac"] > 0
+        # the line's contract (bench.py docstring): every key the driver reads, the roofline object, who set the pace of the timed region
+        for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+            assert key in out, key
+        assert out["unit"] == "views/s" and out["higher_is_better"] is True and out["scaling"] == ("weak" if config == "c2" else out["scaling"]) and out["scaling"] in ("weak", "strong") and out["dtype"] == "f32" and out["vs_baseline"] is None
+        assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(out["roofline"]) and out["roofline"]["peak"] == 8000.0
+        assert out["host_queue"]["issue_ms_per_step"] > 0 and "queue_drain_steps" in out["host_queue"]
+        if config != "c4":
+            assert "lazy:4" in out["config"]["count_check"], out["config"]["count_check"]      # (the timed step's count wait: bench.py _COUNT_WAIT_DEFAULT)
 
 
 # ---- several subjects per step: the pipelined "full" exchange with the real HIP node
