@@ -1,6 +1,7 @@
 """Dev tool (GPU): the overflow bookkeeping of the explicit-capacity C++ L1 node under every count-wait mode (own / lazy / lazy:N).
 Random sequences of steps -- capacity fits or not, with a backward, under no_grad, or with the output dropped -- and the ledger must balance:
-every forward that ran with too small a capacity is covered by exactly one error (its own, or an "EARLIER forward ... (and those of K more ...)"
+every forward that ran with too small a capacity is covered by exactly one error (the batched rasterizer node, which raises from a truncated
+forward's own backward even after a later call reported it: once or twice) (its own, or an "EARLIER forward ... (and those of K more ...)"
 one raised by a later call or by check_pending_overflows), no error without an overflow, fitting steps give the reference loss and gradients bit
 for bit whatever the mode, and every pinned count slot is back in the pool at the end of a round.
 usage: python tools/fuzz_count_wait.py [seconds] [seed]"""
@@ -29,14 +30,22 @@ def scene(P, H, W, V, s):
     return base, mk, target
 
 
+NODE = "l1"
+
+
 def call(base, st, target, grad=True):
     d = {k: v.clone().requires_grad_(grad) for k, v in base.items()}
-    return d, R.rasterize_l1_loss_batched(d["means3D"], None, None, d["rgb"], d["opacity"], None, None, d["cov3D"], st, target, None, 1.0)
+    if NODE == "l1":                                         # rasterizer + L1 loss in one node (RasterizeL1BatchedNode)
+        return d, R.rasterize_l1_loss_batched(d["means3D"], None, None, d["rgb"], d["opacity"], None, None, d["cov3D"], st, target, None, 1.0)
+    out = R.rasterize_gaussians_batched(d["means3D"], None, None, d["rgb"], d["opacity"], None, None, d["cov3D"], st)      # RenderBatchedNode, the caller's loss
+    return d, ((out[0] * target).sum(),) + tuple(out)
 
 
 t_end = time.time() + budget
 rounds = steps_total = overflows_total = errors_total = 0
+by_node = {}
 while time.time() < t_end:
+    NODE = str(rng.choice(["l1", "batched"]))
     P, H, W, V = int(rng.integers(200, 6000)), int(rng.choice([32, 64, 128])), int(rng.choice([48, 64, 144])), int(rng.integers(1, 4))
     base, mk, target = scene(P, H, W, V, int(rng.integers(1, 1000)))
     node.set_count_wait("own")
@@ -98,11 +107,13 @@ while time.time() < t_end:
             break
         except RuntimeError as e:
             account(e, False)
-    assert covered == ran_over, (mode, covered, ran_over)
+    # (the batched rasterizer's own backward raises for a truncated forward even if a later call has reported it already: once or twice there)
+    assert covered == ran_over if NODE == "l1" else ran_over <= covered <= 2 * ran_over, (NODE, mode, covered, ran_over)
+    by_node[NODE] = by_node.get(NODE, 0) + 1
     torch.cuda.synchronize()
     created, idle = node.slot_stats()
     assert created == idle, (created, idle)
     rounds += 1; overflows_total += ran_over; errors_total += covered
 node.set_count_wait("own")
-print(f"fuzz_count_wait seed {seed}: {rounds} rounds, {steps_total} steps, {overflows_total} forwards that did not fit -- each covered by exactly one error report; "
+print(f"fuzz_count_wait seed {seed}: {rounds} rounds {by_node}, {steps_total} steps, {overflows_total} forwards that did not fit, {errors_total} covered by error reports (L1 node: exactly one each); "
       f"fitting steps bit-identical to the reference in every mode; all count slots returned")
