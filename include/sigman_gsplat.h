@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SGR_ABI_VERSION 8
+#define SGR_ABI_VERSION 9
 #define SGR_TILE 16                 /* 16x16 pixel tiles, as the published algorithm */
 #define SGR_PART_FLOATS 10          /* floats of a partial gradient record (bucket-parallel backward): 40 B, 8-byte aligned */
 #define SGR_REC_STRIDE 16           /* floats of the packed per-(view,Gaussian) record `rec` (64 B, one cache line) */
@@ -77,10 +77,12 @@ typedef struct SgrProblem {
  * kernels (4 x float4 = 64 B = one cache line per tile instance):
  *   rec[0..3]   = pixel x, pixel y, conic.xx, conic.xy
  *   rec[4..7]   = conic.yy, opacity, view depth, r
- *   rec[8..11]  = g, b, hx, hy      (hx,hy: half extents of the exact alpha >= 1/255 bound; <0 = never visible)
- *   rec[12..15] = p*, 0, 0, 0       (ABI v7) p*: the published alpha test `min(0.99, opacity * exp(power)) >= 1/255` as a threshold on the
- *                 exponent in the exp2 domain -- the smallest float power2 <= 0 that passes, computed with a correctly rounded exp2 exactly
- *                 like the CPU oracle (+inf: never passes); the compositing kernels test p* <= power2 <= 0 (csrc/render.hip, header)
+ *   rec[8..11]  = g, b, bf16(hx) | bf16(hy) << 16, p*
+ *                 hx, hy: half extents of the exact alpha >= 1/255 bound, as the two bf16 halves of ONE word, rounded up (0xBF80 = -1: never
+ *                 visible); p* (ABI v7): the published alpha test `min(0.99, opacity * exp(power)) >= 1/255` as a threshold on the exponent in the
+ *                 exp2 domain -- the smallest float power2 <= 0 that passes, computed with a correctly rounded exp2 exactly like the CPU oracle
+ *                 (+inf: never passes); the compositing kernels test p* <= power2 <= 0 (csrc/render.hip, header)
+ *   rec[12..15] = 0 (padding: the record is one 64-byte line)
  */
 
 int sgr_abi_version(void);
@@ -114,7 +116,9 @@ typedef struct SgrForwardState {
     uint64_t off_part, off_loss_part;   /* in image: the backward's partial records [4*R_alloc*10] f32, the per-(tile, quadrant) loss shares */
     int32_t fused_bwd;           /* 1: the forward call also produced the loss, dL/dcolor and the partial records of the loss's own backward:
                                     sgr_rasterize_backward may be called with grad_color = NULL */
-    int32_t reserved1;
+    int32_t order_kind;          /* ABI v9: form of the segment-parallel forward's work order at off_order: 0 = one uint4 per slot (render.hip's own
+                                    prepare step), 1 = class-major, written by the single-view path's per-tile sort (empty tiles not listed) */
+    uint64_t off_flags_fused;    /* ABI v9, in image: the record flags of the fused step's OWN backward (off_flags: of an ordinary backward's scratch records) */
 } SgrForwardState;
 
 /*

@@ -12,7 +12,6 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SIGMAN_GSPLAT_LIB") or os.path.join(_HERE, "lib", "libsigman_gsplat.so")   # env override: dev A/B builds only
 _lib = None
 
-SGR_REC_FLOATS = 12
 SGR_TILE = 16
 
 
@@ -37,7 +36,7 @@ class SgrForwardState(C.Structure):
                                           "off_keys_b", "off_vals_a", "off_vals_b", "off_sort_ws", "off_ranges", "off_final_T",
                                           "off_n_contrib", "off_compact", "off_ckpt_tc", "off_ckpt_da", "off_desc", "off_order", "off_flags",
                                           "off_part", "off_loss_part")] + \
-               [("fused_bwd", C.c_int32), ("reserved1", C.c_int32)]
+               [("fused_bwd", C.c_int32), ("order_kind", C.c_int32), ("off_flags_fused", C.c_uint64)]
 
 
 class SgrL1Epilogue(C.Structure):
@@ -45,7 +44,7 @@ class SgrL1Epilogue(C.Structure):
                 ("loss_total", C.c_void_p), ("weight", C.c_float), ("sums_already_zero", C.c_int32), ("fuse_backward", C.c_int32), ("reserved0", C.c_int32)]
 
 
-ABI_VERSION = 8          # include/sigman_gsplat.h: SGR_ABI_VERSION
+ABI_VERSION = 9          # include/sigman_gsplat.h: SGR_ABI_VERSION
 ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_int32, C.c_size_t)
 
 _SIGNATURES = {

@@ -31,15 +31,18 @@ constexpr int kItemsSmall = 4, kItemsLarge = 16;
 // workgroup of the big (15 360-composite) / small (4 096-composite) instantiation; worklist entry = tile id | window << 26
 constexpr uint32_t kDeepBinMax = 128, kDeepBigCap = 15360, kDeepSmallCap = 4096, kDeepTileMask = 0x03FFFFFFu;
 constexpr uint32_t kDeepMaxWindows = 64;           // 6-bit window field
-// FB instantiation of deep_tile_kernel (behind the single wide tile pass: <= 2048 tiles, so bits 11..25 of an entry are free):
-//   kDeepWhole     set by the tile pass in the ONE entry of a tile with more windows than the window field can number (> 64 x 3968 entries;
-//                  sgr_set_sort_deep can lower the cap for tests): that workgroup sorts the whole tile on the spot with the stable radix
-//                  passes, alone (windows 64, 128.. of such a tile used to wrap to window 0: several workgroups re-sorting one segment in place)
-//   kDeepDeclined  set in a tile's window-0 entry by that window's workgroup when it declines the tile (massive depth ties), BEFORE it starts
-//                  to re-sort the tile's segment in place; the other windows' workgroups look at it once their own histogram reads of the
-//                  segment are over
-constexpr uint32_t kDeepWhole = 1u << 24, kDeepDeclined = 1u << 25, kDeepFbTileMask = kDeepWhole - 1u;
-constexpr int kTileBins = 2048;                    // tiles of a launch whose emission kernel writes the tile pass's histogram rows (== kWide)
+constexpr int kRunThreads = 1024;                  // threads of an emission workgroup on the single-view path (duplicate_keys_kernel<true, ..>)
+constexpr int kTileBins = 2048;                    // most tiles of a launch that takes the single-view path (one or two 512^2 views)
+// The single-view path (<= kTileBins tiles, <= 512 emission workgroups, <= 2^19 instances): the emission workgroup b writes its key run ORDERED BY
+// TILE (composites, depth bits << 32 | value) and one row of the run matrix: rows[b][T] = position of the first composite of tile T in its run,
+// rows[b][T + 1] = the end of that piece; run_base[b] = where the run starts.  The per-tile sort then needs no tile pass at all: the workgroup
+// of tile T reads column T (and T + 1) of the matrix -- one strided round trip --, which gives it the pieces of its list in every run AND,
+// summed, the number of instances in all tiles before T (sum_b rows[b][T] - run_base[b]), i.e. the tile's range in the sorted list.
+// The emission workgroups also mark the tiles they touch in occ[kTileBins] (plain stores of 1 into words the preprocess launch zeroed): the
+// workgroup of an EMPTY tile leaves the sort launch after one load.
+constexpr uint32_t kRunRow = kTileBins + 32;       // row stride in words: a multiple of four (16-byte stores) and NOT a multiple of the L2 channel
+                                                   // interleave -- a column read walks 8 320-byte strides (8 KiB + one line): with 8 208 every row of a
+                                                   // tile's column met in the same channel
 struct DupExtra {
     const uint32_t *self_sums;          // un-scanned per-workgroup tile counts (NULL: block_offsets already holds the scan)
     uint64_t *num_rendered;             // [2] device counter + overflow flag (self-scan mode)
@@ -48,8 +51,9 @@ struct DupExtra {
     uint32_t *zero_ptr[3];              // optional buffers to clear on the side: tile ranges, backward flags, a caller buffer
     uint32_t zero_words[3];
     uint32_t *zero_small; uint32_t zero_small_n;      // optional few words (<= 256) to clear: the tile-sort worklist counter(s)
-    uint32_t *hist_rows;                // optional [workgroups][kTileBins]: this workgroup's keys per tile, the block-major histogram row of the
-    uint2 *blk_runs;                    // small-launch tile pass (which then needs no histogram kernel), and its key run (first key, keys written)
+    uint32_t *run_rows;                 // RUNS: [workgroups][kRunRow] the run matrix (above)
+    uint32_t *run_base;                 // RUNS: [workgroups] first position of the workgroup's run
+    uint32_t *occ;                      // RUNS: [kTileBins] tile-occupancy flags (zeroed before this launch)
     uint32_t write_first;               // store every Gaussian's first tile-instance index into rect[q].w (only the bucket backward's gathers read it;
                                         // a forward-only launch skips the 4-byte stores that dirty every line of the rect array: 0.29 GB of
                                         // write-back for the 90 views of C4)
@@ -59,25 +63,40 @@ struct DupExtra {
 // Same grid as preprocess (blockIdx.y = view).  The block re-scans its 256 tile counts in LDS and adds
 // the block offset from F2, so the per-Gaussian offsets array of the published algorithm is never
 // materialised in HBM.
-__global__ __launch_bounds__(kThreads) void duplicate_keys_kernel(int P, int Tx, int tiles_per_view,
-                                                                  const int32_t *__restrict__ radii,
-                                                                  uint4 *__restrict__ rect,
-                                                                  const uint32_t *__restrict__ block_offsets, uint32_t cap,
-                                                                  uint64_t *__restrict__ keys, uint32_t *__restrict__ vals,
-                                                                  DupExtra ex) {
-    __shared__ uint32_t wave_tot[4];
-    __shared__ unsigned long long red64[4];
-    __shared__ __attribute__((aligned(16))) uint32_t s_th[kTileBins];      // this workgroup's keys per tile (only with ex.hist_rows)
-    if (ex.hist_rows) for (int d = threadIdx.x; d < kTileBins / 4; d += kThreads) reinterpret_cast<uint4 *>(s_th)[d] = make_uint4(0u, 0u, 0u, 0u);
+// RUNS (the single-view path): the run is written ordered by tile, as composites, and its row of the run matrix with it (kRunRow above); one
+// workgroup of NT = 1024 threads covers four of preprocess's 256-Gaussian blocks (a quarter of the rows for the per-tile sort to read, four
+// times longer pieces to gather; the work per thread is the same).
+template <bool RUNS, int NT>
+__global__ __launch_bounds__(NT) void duplicate_keys_kernel(int P, int Tx, int tiles_per_view, int nbx /* preprocess blocks per view */,
+                                                            const int32_t *__restrict__ radii,
+                                                            uint4 *__restrict__ rect,
+                                                            const uint32_t *__restrict__ block_offsets, uint32_t cap,
+                                                            uint64_t *__restrict__ keys, uint32_t *__restrict__ vals,
+                                                            DupExtra ex) {
+    constexpr int NWV = NT / 64, BPW = NT / kThreads;                  // waves; preprocess blocks per workgroup
+    static_assert(NT % kThreads == 0 && (NT & (NT - 1)) == 0, "whole preprocess blocks");
+    __shared__ uint32_t wave_tot[NWV];
+    __shared__ unsigned long long red64[NWV];
+    __shared__ __attribute__((aligned(16))) uint32_t s_th[RUNS ? kTileBins : 4];      // RUNS: this workgroup's keys per tile, then the tiles' cursors
+    if (RUNS) for (int d = threadIdx.x; d < kTileBins / 4; d += NT) reinterpret_cast<uint4 *>(s_th)[d] = make_uint4(0u, 0u, 0u, 0u);
     const int view = blockIdx.y;
-    // piggy-backed clear of a small buffer the later kernels expect zeroed (the tile ranges): replaces a memset launch
+    // piggy-backed clear of small buffers the later kernels expect zeroed: replaces memset launches
 #pragma unroll
     for (int c = 0; c < 3; c++)
-        for (uint32_t z = (blockIdx.y * gridDim.x + blockIdx.x) * kThreads + threadIdx.x; z < ex.zero_words[c]; z += gridDim.x * gridDim.y * kThreads)
+        for (uint32_t z = (blockIdx.y * gridDim.x + blockIdx.x) * NT + threadIdx.x; z < ex.zero_words[c]; z += gridDim.x * gridDim.y * NT)
             ex.zero_ptr[c][z] = 0u;
     if (ex.zero_small && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < ex.zero_small_n) ex.zero_small[threadIdx.x] = 0u;
-    const int i = blockIdx.x * kThreads + threadIdx.x;
+    const int i = blockIdx.x * NT + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t pb0 = (uint32_t)view * (uint32_t)nbx + blockIdx.x * (uint32_t)BPW;      // my first preprocess block
+    // F2 folded in (small launches, sync-free mode): every workgroup sums the un-scanned counts of the preprocess blocks before its own (at most a
+    // few thousand values) instead of waiting for a separate one-workgroup scan kernel.  Requested first: the loads travel with the rect loads
+    unsigned long long acc = 0;
+    if (ex.self_sums) {
+        const uint32_t nb = (uint32_t)nbx * gridDim.y;
+        const uint32_t upto = pb0 == 0 ? nb : pb0;
+        for (uint32_t k = threadIdx.x; k < upto; k += NT) acc += ex.self_sums[k];
+    }
     uint32_t cnt = 0, depth_bits = 0;
     int minx = 0, miny = 0, maxx = 0, maxy = 0;
     size_t q = 0;
@@ -101,72 +120,141 @@ __global__ __launch_bounds__(kThreads) void duplicate_keys_kernel(int P, int Tx,
     __syncthreads();
     uint32_t base;
     if (ex.self_sums) {
-        // F2 folded in (small launches, sync-free mode): every workgroup sums the un-scanned counts of the workgroups before it
-        // (at most a few thousand values) instead of waiting for a separate one-workgroup scan kernel; workgroup 0 also
-        // publishes the total (device counter, overflow flag and -- if given -- the caller's pinned host slot)
-        const uint32_t b = blockIdx.y * gridDim.x + blockIdx.x, nb = gridDim.x * gridDim.y;
-        const uint32_t upto = b == 0 ? nb : b;
-        unsigned long long acc = 0;
-        for (uint32_t k = threadIdx.x; k < upto; k += kThreads) acc += ex.self_sums[k];
+        // workgroup 0 also publishes the total (device counter, overflow flag and -- if given -- the caller's pinned host slot)
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
         if (lane == 0) red64[wave] = acc;
         __syncthreads();
-        const unsigned long long tot = (red64[0] + red64[1]) + (red64[2] + red64[3]);
-        base = b == 0 ? 0u : (uint32_t)tot;
-        if (b == 0 && threadIdx.x == 0) {
+        unsigned long long tot = 0;
+#pragma unroll
+        for (int w = 0; w < NWV; w++) tot += red64[w];
+        base = pb0 == 0 ? 0u : (uint32_t)tot;
+        if (pb0 == 0 && threadIdx.x == 0) {
             const unsigned long long ovf = (tot > 0xFFFFFFF0ull || tot > ex.capacity) ? 1ull : 0ull;
             ex.num_rendered[0] = tot; ex.num_rendered[1] = ovf; ex.num_rendered[2] = tot | (ovf << 63);
             // ONE 8-byte store: the host can never observe the count without its overflow flag
             if (ex.nr_host) { __hip_atomic_store(ex.nr_host, tot | (ovf << 63), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); __threadfence_system(); }
         }
     } else {
-        base = block_offsets[(size_t)view * gridDim.x + blockIdx.x];
+        base = block_offsets[pb0];
     }
     const uint32_t block_base = base;
     for (int w = 0; w < wave; w++) base += wave_tot[w];
     const uint32_t off = base + inc - cnt;
     // ---- cooperative emission: the workgroup's keys form one contiguous run [block_base, block_base + total); output slot j is
-    // written by thread j % 256 (perfectly coalesced 8-byte / 4-byte stores, no divergence between small and huge splats), which
-    // finds the owning Gaussian by binary search over the 256 offsets in LDS.  (One thread per Gaussian looping over its own rect
+    // written by thread j % NT (perfectly coalesced 8-byte / 4-byte stores, no divergence between small and huge splats), which
+    // finds the owning Gaussian by binary search over the NT offsets in LDS.  (One thread per Gaussian looping over its own rect
     // wrote runs of 2-4 keys per lane: 0.7 TB/s at 64 views.)
-    __shared__ uint32_t s_off[kThreads + 1], s_geo[kThreads], s_w[kThreads], s_dep[kThreads];
+    __shared__ uint32_t s_off[NT + 1], s_geo[NT], s_w[NT], s_dep[NT];
     s_off[threadIdx.x] = off - block_base;
     s_geo[threadIdx.x] = (uint32_t)minx | ((uint32_t)miny << 16);
     s_w[threadIdx.x] = (uint32_t)(maxx - minx);
-    if (threadIdx.x == kThreads - 1) s_off[kThreads] = off - block_base + cnt;
+    if (threadIdx.x == NT - 1) s_off[NT] = off - block_base + cnt;
     if (cnt) {
         s_dep[threadIdx.x] = depth_bits;
         if (ex.write_first) rect[q].w = off;               // first tile-instance index of this Gaussian (backward gathers); the 16-byte record was just read
     }
     __syncthreads();
-    const uint32_t total = s_off[kThreads];
+    const uint32_t total = s_off[NT];
     const uint32_t tbase = (uint32_t)view * (uint32_t)tiles_per_view;
-    const uint32_t q0 = (uint32_t)view * (uint32_t)P + blockIdx.x * kThreads;
-    for (uint32_t j = threadIdx.x; j < total; j += kThreads) {
-        uint32_t lo = 0;                                       // largest o with s_off[o] <= j (runs of equal offsets end in the owner)
+    const uint32_t q0 = (uint32_t)view * (uint32_t)P + blockIdx.x * NT;
+    // slot j of the run -> (owning Gaussian, tile id)
+    auto slot_of = [&](uint32_t j, uint32_t &lo, uint32_t &tile_id) {
+        lo = 0;                                                // largest o with s_off[o] <= j (runs of equal offsets end in the owner)
 #pragma unroll
-        for (uint32_t step = kThreads / 2; step > 0; step >>= 1)
+        for (uint32_t step = NT / 2; step > 0; step >>= 1)
             if (s_off[lo + step] <= j) lo += step;
         const uint32_t local = j - s_off[lo], w = s_w[lo], g = s_geo[lo];
         uint32_t y = (uint32_t)((float)local / (float)w);
         if (y * w > local) y--;
         if ((y + 1u) * w <= local) y++;
         const uint32_t x = local - y * w;
-        const uint32_t dst = block_base + j;
-        if (dst < cap) {                                       // capacity mode: never write past the caller's buffers
-            const uint32_t tile_id = tbase + ((g >> 16) + y) * (uint32_t)Tx + (g & 0xFFFFu) + x;
-            keys[dst] = ((uint64_t)tile_id << 32) | s_dep[lo];
-            vals[dst] = q0 + lo;
-            if (ex.hist_rows) atomicAdd(&s_th[tile_id], 1u);
+        tile_id = tbase + ((g >> 16) + y) * (uint32_t)Tx + (g & 0xFFFFu) + x;
+    };
+    if constexpr (!RUNS) {
+        for (uint32_t j = threadIdx.x; j < total; j += NT) {
+            uint32_t lo, tile_id;
+            slot_of(j, lo, tile_id);
+            const uint32_t dst = block_base + j;
+            if (dst < cap) {                                       // capacity mode: never write past the caller's buffers
+                keys[dst] = ((uint64_t)tile_id << 32) | s_dep[lo];
+                vals[dst] = q0 + lo;
+            }
         }
-    }
-    if (ex.hist_rows) {                                        // (workgroup-uniform) the tile pass's histogram row of this key run
+    } else {
+        // (capacity mode: only the keys whose EMISSION index fits the caller's buffers exist -- the backward addresses its per-instance records
+        // by that index, whatever place the key takes inside the run)
+        const uint32_t total_all = total;
+        const uint32_t total = block_base < cap ? min(total_all, cap - block_base) : 0u;
+        // pass 1: keys per tile (the first four slots of a thread -- a run of <= 4 NT keys: all of them -- stay in registers for pass 2)
+        constexpr int KEEP = 4;
+        uint32_t k_lo[KEEP], k_tile[KEEP];
+#pragma unroll
+        for (int it = 0; it < KEEP; it++) {
+            const uint32_t j = threadIdx.x + (uint32_t)it * NT;
+            k_lo[it] = 0u; k_tile[it] = 0u;
+            if (j < total) { slot_of(j, k_lo[it], k_tile[it]); atomicAdd(&s_th[k_tile[it]], 1u); }
+        }
+        for (uint32_t j = threadIdx.x + KEEP * NT; j < total; j += NT) {
+            uint32_t lo, tile_id;
+            slot_of(j, lo, tile_id);
+            atomicAdd(&s_th[tile_id], 1u);
+        }
         __syncthreads();
-        const uint32_t b = blockIdx.y * gridDim.x + blockIdx.x;
-        uint4 *row = reinterpret_cast<uint4 *>(ex.hist_rows + (size_t)b * kTileBins);
-        for (int d = threadIdx.x; d < kTileBins / 4; d += kThreads) row[d] = reinterpret_cast<const uint4 *>(s_th)[d];
-        if (threadIdx.x == 0) ex.blk_runs[b] = make_uint2(block_base, block_base < cap ? min(total, cap - block_base) : 0u);
+        // exclusive scan over the tiles (PER consecutive per thread): the row of the run matrix, and the cursors of pass 2.  Positions are
+        // clamped to the capacity (sync-free mode): what the row promises is what pass 2 writes.  Tiles with keys are marked occupied.
+        {
+            constexpr int PER = kTileBins / NT;
+            static_assert(PER == 2, "one uint2 per thread");
+            const uint2 hv = reinterpret_cast<const uint2 *>(s_th)[threadIdx.x];
+            const uint32_t sum = hv.x + hv.y;
+            uint32_t sc = sum;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t n = __shfl_up(sc, o, 64);
+                if (lane >= o) sc += n;
+            }
+            __syncthreads();                                   // (wave_tot is reused; everybody has read s_th)
+            if (lane == 63) wave_tot[wave] = sc;
+            __syncthreads();
+            uint32_t run = sc - sum;
+            for (int w = 0; w < wave; w++) run += wave_tot[w];
+            const uint32_t e0 = run, e1 = run + hv.x;
+            reinterpret_cast<uint2 *>(s_th)[threadIdx.x] = make_uint2(e0, e1);
+            if (hv.x) ex.occ[threadIdx.x * 2] = 1u;
+            if (hv.y) ex.occ[threadIdx.x * 2 + 1] = 1u;
+            const uint32_t b = blockIdx.y * gridDim.x + blockIdx.x;
+            uint32_t *row = ex.run_rows + (size_t)b * kRunRow;
+            // (block_base + x <= 2^32 - 16: the count is checked against that)
+            // total == 0 beyond the capacity: every position of the row is base_c = min(block_base, cap).  (The optimiser folded that minimum to
+            // block_base -- ROCm 7.2 clang, as if block_base < cap were known here -- and the sort launch then read row positions beyond the
+            // buffers: the capacity is hidden from it for this one comparison.)
+            uint32_t cap_opaque = cap;
+            asm volatile("" : "+s"(cap_opaque));
+            const uint32_t base_c = block_base < cap_opaque ? block_base : cap_opaque;
+            reinterpret_cast<uint2 *>(row)[threadIdx.x] = make_uint2(base_c + e0, base_c + e1);
+            if (threadIdx.x == 0) {
+                reinterpret_cast<uint2 *>(row)[kTileBins / 2] = make_uint2(base_c + total, base_c + total);
+                ex.run_base[b] = base_c;
+            }
+        }
+        __syncthreads();
+        // pass 2: every key takes the next free slot of its tile's piece (one returning LDS atomic; the order inside a piece is arbitrary --
+        // the per-tile sort orders (depth, value) composites, a total order)
+#pragma unroll
+        for (int it = 0; it < KEEP; it++) {
+            const uint32_t j = threadIdx.x + (uint32_t)it * NT;
+            if (j < total) {
+                const uint32_t dst = block_base + atomicAdd(&s_th[k_tile[it]], 1u);
+                if (dst < cap) keys[dst] = ((uint64_t)s_dep[k_lo[it]] << 32) | (q0 + k_lo[it]);
+            }
+        }
+        for (uint32_t j = threadIdx.x + KEEP * NT; j < total; j += NT) {
+            uint32_t lo, tile_id;
+            slot_of(j, lo, tile_id);
+            const uint32_t dst = block_base + atomicAdd(&s_th[tile_id], 1u);
+            if (dst < cap) keys[dst] = ((uint64_t)s_dep[lo] << 32) | (q0 + lo);
+        }
     }
 }
 
@@ -296,116 +384,6 @@ __global__ __launch_bounds__(kThreads) void radix_downsweep_kernel(const uint64_
     }
 }
 
-// ---- F4, wide-digit variant for the tile bits of small launches ---------------------------------------
-// With <= 2048 tiles (one 512^2 view = 1024) the whole tile id fits ONE 11-bit digit: a single stable pass (three
-// kernels) instead of two 8-bit passes (six).  Same structure as above; the per-round bookkeeping only touches the
-// digits that occur in the round (leaders of each wave's match-any groups), never the whole 2048-entry tables.
-constexpr int kWideBits = 11, kWide = 1 << kWideBits;
-
-// hist is block-major [nblocks][2048].  One workgroup of 1024 threads per group of 64 consecutive digits: lane = digit (a row's 64
-// counts are one 256-byte run), wave w walks the blocks w, w + 16, ..: per digit an exclusive prefix over the blocks in place + the
-// digit total.  Every wave first sums its blocks, the 16 partial sums per digit meet in LDS, then it rewrites its blocks with the
-// running prefix -- blocks interleave, so wave w's block b needs the sums of ALL waves over blocks < b: done in two phases over
-// contiguous block ranges instead (wave w owns blocks [w * per, (w + 1) * per)).
-__global__ __launch_bounds__(1024) void wide_rowscan_kernel(uint32_t *__restrict__ hist, uint32_t nblocks, uint32_t *__restrict__ totals) {
-    __shared__ uint32_t part[16][64];
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, d = blockIdx.x * 64 + lane;
-    const uint32_t per = (nblocks + 15u) / 16u, b0 = min(nblocks, wave * per), b1 = min(nblocks, b0 + per);
-    uint32_t *col = hist + d;
-    constexpr int kMaxPer = 32;                                  // nblocks <= 512 on this path (<= 2^19 keys, 1024 per block)
-    uint32_t v[kMaxPer], sum = 0;
-#pragma unroll
-    for (int i = 0; i < kMaxPer; i++) { const uint32_t b = b0 + (uint32_t)i; v[i] = b < b1 ? col[(size_t)b * kWide] : 0u; sum += v[i]; }
-    part[wave][lane] = sum;
-    __syncthreads();
-    uint32_t run = 0, all = 0;
-#pragma unroll
-    for (uint32_t w = 0; w < 16; w++) { const uint32_t x = part[w][lane]; if (w < wave) run += x; all += x; }
-#pragma unroll
-    for (int i = 0; i < kMaxPer; i++) { const uint32_t b = b0 + (uint32_t)i; if (b < b1) col[(size_t)b * kWide] = run; run += v[i]; }
-    if (wave == 0) totals[d] = all;
-}
-
-// The order-free scatter of the tile pass for key RUNS: workgroup b places the keys the emission workgroup b wrote (blk_runs[b]: first
-// key, count), whose histogram row that workgroup also wrote -- so the small-launch tile pass needs no histogram kernel of its own.
-// Same slots as wide_downsweep_kernel<ITEMS, false>: one returning LDS atomic per key, (depth bits << 32 | value) composites;
-// workgroup 0 writes the tile ranges (F5) and the class worklists.
-template <int ITEMS>
-__global__ __launch_bounds__(kThreads) void wide_downsweep_runs_kernel(const uint64_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
-                                                                       uint64_t *__restrict__ keys_out, const uint2 *__restrict__ blk_runs,
-                                                                       const uint32_t *__restrict__ hist, const uint32_t *__restrict__ totals,
-                                                                       uint2 *__restrict__ ranges, uint32_t tiles_total, uint32_t *__restrict__ worklist, uint32_t deep_all) {
-    __shared__ uint32_t digit_base[kWide];
-    __shared__ uint32_t wtot[4];
-    __shared__ uint32_t s_wl[8];
-    const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    if (t < 8) s_wl[t] = 0u;
-    constexpr int PER = kWide / kThreads;
-    static_assert(PER == 8, "two uint4 per thread");
-    const uint2 my = blk_runs[blockIdx.x];
-    {
-        uint32_t v[PER], hb[PER], sum = 0;
-        {
-            const uint4 t0 = reinterpret_cast<const uint4 *>(totals)[t * 2], t1 = reinterpret_cast<const uint4 *>(totals)[t * 2 + 1];
-            const uint4 *hr = reinterpret_cast<const uint4 *>(hist + (size_t)blockIdx.x * kWide);
-            const uint4 h0 = hr[t * 2], h1 = hr[t * 2 + 1];
-            v[0] = t0.x; v[1] = t0.y; v[2] = t0.z; v[3] = t0.w; v[4] = t1.x; v[5] = t1.y; v[6] = t1.z; v[7] = t1.w;
-            hb[0] = h0.x; hb[1] = h0.y; hb[2] = h0.z; hb[3] = h0.w; hb[4] = h1.x; hb[5] = h1.y; hb[6] = h1.z; hb[7] = h1.w;
-        }
-#pragma unroll
-        for (int j = 0; j < PER; j++) sum += v[j];
-        uint32_t inc = sum;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t nb = __shfl_up(inc, off, 64);
-            if (lane >= (uint32_t)off) inc += nb;
-        }
-        if (lane == 63) wtot[wave] = inc;
-        __syncthreads();
-        uint32_t run = inc - sum;
-        for (uint32_t w = 0; w < wave; w++) run += wtot[w];
-#pragma unroll
-        for (int j = 0; j < PER; j++) {
-            const uint32_t d = t * PER + j;
-            digit_base[d] = run + hb[j];
-            if (blockIdx.x == 0 && d < tiles_total) {
-                ranges[d] = v[j] ? make_uint2(run, run + v[j]) : make_uint2(0u, 0u);
-                if (v[j] && deep_all) {
-                    // (deep_all = the most windows a tile may have, <= 64: the window field of an entry has 6 bits.  A longer tile is listed
-                    // once, marked kDeepWhole)
-                    uint32_t nw = (v[j] + (kDeepSmallCap - kDeepBinMax) - 1u) / (kDeepSmallCap - kDeepBinMax);
-                    const uint32_t whole = nw > deep_all ? kDeepWhole : 0u;
-                    if (whole) nw = 1u;
-                    const uint32_t at = atomicAdd(&s_wl[0], nw);
-                    for (uint32_t w = 0; w < nw; w++) worklist[16u + at + w] = d | whole | (w << 26);
-                } else if (v[j]) {
-                    const uint32_t m = v[j] <= 1024u ? 0u : (v[j] <= 2048u ? 1u : (v[j] <= 4096u ? 2u : (v[j] <= 8192u ? 3u : (v[j] <= 16384u ? 4u : 5u))));
-                    worklist[16u + m * tiles_total + atomicAdd(&s_wl[m], 1u)] = d;
-                }
-            }
-            run += v[j];
-        }
-    }
-    __syncthreads();
-    if (blockIdx.x == 0 && t < 6u) worklist[t] = s_wl[t];
-    for (uint32_t c0 = 0; c0 < my.y; c0 += kThreads * ITEMS) {
-        uint64_t keys_r[ITEMS];
-        uint32_t vals_r[ITEMS];
-        const uint32_t lastk = my.y - 1u;
-#pragma unroll
-        for (int it = 0; it < ITEMS; it++) {                     // (indices past the run re-read its last key: no guarded loads)
-            const uint32_t k = my.x + min(c0 + (uint32_t)it * kThreads + t, lastk);
-            keys_r[it] = keys_in[k]; vals_r[it] = vals_in[k];
-        }
-#pragma unroll
-        for (int it = 0; it < ITEMS; it++)
-            if (c0 + (uint32_t)it * kThreads + t < my.y) {
-                const uint32_t d = (uint32_t)(keys_r[it] >> 32) & (kWide - 1);
-                keys_out[atomicAdd(&digit_base[d], 1u)] = (keys_r[it] << 32) | vals_r[it];
-            }
-    }
-}
-
 // ---- stable LSD radix passes over ONE tile's segment, through the global ping-pong pair ------------------------------
 // The generic path of the per-tile sorts below: tiles beyond the register network's 16 384 entries, and tiles the LDS distribution
 // sort declines (massive exact depth ties).  Digits on which a whole segment agrees are skipped -- the exponent byte of the depths
@@ -524,9 +502,19 @@ __device__ __forceinline__ void seg_sort_passes(uint32_t n, uint64_t *gka, uint3
     }
 }
 
-struct SortPrep {               // optional piggy-back job of the per-tile sort launch's spare last workgroup (sgr_fwd_prepare)
-    uint2 *desc; size_t n_desc; uint32_t *order; uint32_t tiles_total; int enabled;
-};
+// The single-view path's front end of deep_tile_kernel<.., FB = true> (one workgroup per TILE, no worklist; kRunRow above)
+struct GatherFront {
+    const uint32_t *rows, *base;        // the run matrix [nblk][kRunRow] and the runs' first positions [nblk]
+    const uint32_t *occ;                // [kTileBins] != 0: some run holds a key of the tile
+    uint32_t nblk, tiles_total, tx, ty /* tiles per image row / column */, search_top /* largest power of two < max(nblk, 2) */;
+    uint2 *ranges;                      // [tiles_total], written here (F5): every tile's workgroup computes its own range from its columns
+    uint4 *order;                       // optional work order of the segment-parallel forward, class-major: order[cls * tiles_total + k] = (tile, first,
+    uint32_t *cls_count;                //   end, 0) of the k-th OCCUPIED tile with 31 - min(31, n >> 7) == cls; cls_count[32] (zeroed by the emission kernel)
+    uint64_t *scratch_k;                // [R] composites of the tiles that go through global memory (several windows / massive depth ties)
+    uint32_t cap_dbg;                   // (capacity of the buffers: -DSGR_DEBUG_BOUNDS checks)
+    uint32_t max_windows;               // a tile of more windows is sorted whole by the stable radix passes (<= 64; tests lower it)
+    SgrBgJob bg;                        // bg.enabled: the workgroup of an EMPTY tile writes the tile's background (the compositing kernel then never
+};                                      //   looks at empty tiles)
 
 // sorts ONE tile's segment of (depth bits << 32 | value) composites by that composite (stable passes over the value bits first, then over
 // the depth bits), src -> dst as (tile | depth) keys and values; all NT threads of the workgroup take part.
@@ -549,6 +537,15 @@ __device__ __forceinline__ void sort_one_tile(const uint2 range, uint64_t *__res
     __syncthreads();
     if (!in_b)
         for (uint32_t k = t; k < n; k += NT) { gdst_k[k] = gsrc_k[k]; gdst_v[k] = gsrc_v[k]; }
+}
+
+// (out of line: inlined into the single-view path's per-tile sort, the rare fallback's registers spill the main path)
+template <int NT>
+__device__ __attribute__((noinline)) void sort_one_tile_ool(const uint2 range, uint64_t *src_keys, uint32_t *src_vals, uint64_t *dst_keys, uint32_t *dst_vals,
+                                                            uint32_t *lds, uint32_t tile) {
+    uint32_t *hist = lds, *digit_base = lds + kRadix, *wtot = lds + 2 * kRadix;
+    uint32_t (*wave_cnt)[kRadix] = (uint32_t (*)[kRadix])(lds + 2 * kRadix + 64);
+    sort_one_tile<NT>(range, src_keys, src_vals, dst_keys, dst_vals, hist, digit_base, wave_cnt, wtot, tile);
 }
 
 struct TileWork { const uint32_t *list; uint32_t *ticket; const uint32_t *count; };
@@ -786,18 +783,13 @@ struct TileWork4 { TileWork w[6]; };        // [m], m = 0..4: tiles with <= 1024
 template <int NW>
 __global__ __launch_bounds__(64 * NW) void tile_sort_regs_kernel(const uint2 *__restrict__ ranges, uint64_t *__restrict__ src_comp,
                                                                  uint32_t *__restrict__ src_scratch, uint64_t *__restrict__ dst_keys,
-                                                                 uint32_t *__restrict__ dst_vals, TileWork4 tw, int m_hi, int m_lo, SortPrep prep,
-                                                                 int keep_keys) {
+                                                                 uint32_t *__restrict__ dst_vals, TileWork4 tw, int m_hi, int m_lo, int keep_keys) {
     // keep_keys == 0: only the point list is stored (the sorted keys have no reader behind the per-tile sort: the ranges come from the
     // tile pass); the global-memory fallback for oversize tiles writes both regardless
     __shared__ uint64_t xbuf[NW * 64 * 17];                                      // per wave 64 x (16 + 1) composites: exchange + final re-deal
     __shared__ uint32_t s_item, s_next;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    uint32_t nsort = gridDim.x;                                                  // workgroups that sort
-    if (prep.enabled) {                                                          // the spare last workgroup orders the tiles for the forward
-        nsort = gridDim.x - 1;
-        if (blockIdx.x == nsort) { sgr_fwd_prepare(ranges, prep.tiles_total, prep.desc, prep.n_desc, prep.order, (uint32_t *)xbuf); return; }
-    }
+    const uint32_t nsort = gridDim.x;                                            // workgroups that sort
     // all class sizes up front (independent loads: one memory latency instead of one per class on the single-view critical path)
     uint32_t cnt[6];
 #pragma unroll
@@ -1252,58 +1244,151 @@ __global__ __launch_bounds__(1024) void vseg_colscan_par_kernel(uint32_t *__rest
 #ifdef SGR_DEEP_TIMING          /* tools/micro/bench_tile_sort.hip: phase stamps of the first tile of every workgroup (100 MHz clock) */
 __device__ unsigned long long sgr_deep_dbg[1024 * 16];
 #define SGR_STAMP(P) if (t == 0 && i == blockIdx.x && blockIdx.x < 1024u) sgr_deep_dbg[blockIdx.x * 16 + (P)] = __builtin_amdgcn_s_memrealtime();
+extern "C" int sgr_debug_deep_stamps(unsigned long long *host) { return hipMemcpyFromSymbol(host, HIP_SYMBOL(sgr_deep_dbg), sizeof(sgr_deep_dbg)) == hipSuccess ? 0 : 1; }
 #else
 #define SGR_STAMP(P)
 #endif
-// worklist entry of the deep kernels: tile id | window << 26 (one workgroup per WINDOW of a tile: a tile of more than CAP - 128 entries
-// is shared by several workgroups, each of which builds the tile's histogram for itself and then places / ranks its own window)
-// FB = false: a tile the distribution sort declines goes to the register sort's worklists (lists / plan).
-// FB = true (the single wide tile pass of one or two views: every occupied tile is on the list and this launch sorts everything): a declined
-// tile is sorted on the spot by stable radix passes through the global ping-pong pair (comp / scratch <-> dst), and the spare last
-// workgroup does the compositing kernel's prepare step (tile order + descriptor clear).
+// worklist entry of the deep kernels (FB = false): tile id | window << 26 (one workgroup per WINDOW of a tile: a tile of more than CAP - 128
+// entries is shared by several workgroups, each of which builds the tile's histogram for itself and then places / ranks its own window); a tile
+// the distribution sort declines goes to the register sort's worklists (lists / plan).
+// FB = true (the single-view path: one or two views, <= 2048 tiles): ONE WORKGROUP PER TILE and no tile pass in front of it.  The workgroup
+// reads its tile's columns of the run matrix the emission kernel left (GatherFront, kRunRow): the pieces of its list in the emission
+// workgroups' tile-ordered runs and -- summed -- its range in the sorted list; it writes that range (F5), enters the tile into the compositing
+// kernel's work order (a class-major list: one returning atomic per OCCUPIED tile on one of 32 counters), gathers its composites straight into
+// registers and sorts them.  An empty tile's workgroup writes the tile's background on the spot (gf.bg), so the compositing kernel never looks at
+// empty tiles.  A tile beyond one window (> CAP - 128 entries) is first copied to a contiguous scratch segment and its windows are then
+// walked one after the other by this workgroup; a tile the distribution sort declines (massive depth ties) or with more windows than
+// gf.max_windows is sorted by the stable radix passes through global memory.
 template <int NT, int CAP, int NBF, bool FB = false>
-__global__ __launch_bounds__(NT) void deep_tile_kernel(uint64_t *comp, uint32_t *scratch, uint64_t *__restrict__ dst_keys, uint32_t *__restrict__ dst_vals,
+__global__ __launch_bounds__(NT, (FB && NT == 512) ? 4 : 1) void deep_tile_kernel(uint64_t *comp, uint32_t *scratch, uint64_t *__restrict__ dst_keys, uint32_t *__restrict__ dst_vals,
                                                        const uint32_t *__restrict__ count_ptr, uint32_t *deep_list,
                                                        const uint2 *__restrict__ ranges, int keep_keys, VsegPlan *__restrict__ plan,
-                                                       uint32_t *__restrict__ lists, uint32_t list_stride, SortPrep prep) {
+                                                       uint32_t *__restrict__ lists, uint32_t list_stride, GatherFront gf) {
     constexpr uint32_t RI = (CAP + NT - 1) / NT <= 4 ? 4 : ((CAP + NT - 1) / NT <= 8 ? 8 : 16), REG = NT * RI;   // the first REG composites of a tile live in registers (RI per thread) for all passes
     constexpr uint32_t ITEMS = 8, ROUND = NT * ITEMS;     // the rest (tiles beyond REG entries) is re-read from the segment in every pass
     constexpr uint32_t NW = NT / 64, NBC = 256, WIN = CAP - kDeepBinMax, PER = NBF / NT;
     static_assert(NBF % NT == 0 && NT >= (int)NBC && NT % 64 == 0 && (NBF & (NBF - 1)) == 0, "layout");
+    static_assert(!FB || (NBF >= 513 && NT >= 512 && WIN <= REG), "FB: the piece tables of <= 512 runs live in s_pre / s_cur; a one-window tile fits the registers");
     __shared__ uint64_t s_comp[CAP];
     __shared__ uint32_t s_pre[NBF], s_cur[NBF];
     __shared__ uint32_t s_ccnt[NBC], s_fstart[NBC], s_fcnt[NBC];
     __shared__ uint32_t s_wave[NW], s_wave2[NW], s_lo, s_hi, s_bad;
     const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
-    uint32_t nsort = gridDim.x;
-    if (FB && prep.enabled) {                                                     // the spare last workgroup orders the tiles for the forward
-        nsort = gridDim.x - 1;
-        if (blockIdx.x == nsort) { sgr_fwd_prepare(ranges, prep.tiles_total, prep.desc, prep.n_desc, prep.order, s_pre); return; }
-    }
-    const uint32_t ndeep = *count_ptr;
+    const uint32_t nsort = gridDim.x;
+    const uint32_t ndeep = FB ? gf.tiles_total : *count_ptr;
 #define SGR_UNIFORM(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
     for (uint32_t i = blockIdx.x; i < ndeep; i += nsort) {
         __syncthreads();                                                        // (LDS reuse between tiles)
         SGR_STAMP(0)
-        const uint32_t entry = SGR_UNIFORM(deep_list[i]);
-        const uint32_t tile = entry & (FB ? kDeepFbTileMask : kDeepTileMask), w0 = (entry >> 26) * WIN;  // this workgroup's window: sorted positions of bins starting in [w0, w0 + WIN)
-        const uint2 range_v = ranges[tile];
-        const uint2 range = make_uint2(SGR_UNIFORM(range_v.x), SGR_UNIFORM(range_v.y));
-        const uint32_t n = range.y - range.x, last = n - 1u;
-        // FB: stable LSD passes over the value bits, then the depth bits, through global memory (comp / scratch <-> dst): the whole tile, by
-        // this workgroup alone
-        auto sort_here = [&]() {
-            uint32_t *l32 = (uint32_t *)s_comp;
-            uint32_t *hist = l32, *digit_base = l32 + kRadix, *wtot = l32 + 2 * kRadix;
-            uint32_t (*wave_cnt)[kRadix] = (uint32_t (*)[kRadix])(l32 + 2 * kRadix + 64);
-            __syncthreads();
-            sort_one_tile<NT>(range, comp, scratch, dst_keys, dst_vals, hist, digit_base, wave_cnt, wtot, tile);
-        };
-        if constexpr (FB) { if (entry & kDeepWhole) { sort_here(); continue; } }
-        const uint64_t *seg = comp + range.x;
+        uint32_t tile, w0;
+        uint2 range;
         uint64_t c[RI];
+        const uint64_t *seg;                                                    // the tile's composites in one piece (FB: only for tiles beyond one window)
+        if constexpr (FB) {
+            // ---- my columns of the run matrix: piece of run b = [rows[b][tile], rows[b][tile + 1]); sum_b (rows[b][tile] - base[b]) instances
+            // sit in tiles before mine
+            // workgroup i <-> tile i.  An empty tile's workgroup (three of four at a humanoid view) leaves after one load: its range, its background
+            w0 = 0u;
+            // Workgroup ids go round the XCDs and, inside an XCD, round its shader engines: with 32 tiles per image row, id mod 32 -- one image
+            // COLUMN -- would meet in one engine, and a humanoid's centre columns hold more occupied tiles (24) than an engine has slots for these
+            // workgroups (16): the last ones started when the first had finished, 14 us late.  Ids walk down the image columns instead, every
+            // column rotated by 5 rows more than the one before, so an engine's tiles lie on a diagonal.
+            // And the columns are visited from the image centre outwards (the workgroups that do not fit the chip at once -- the second half of
+            // the ids -- are the image's outer columns: a centred subject's tiles all start at t = 0).
+            {
+                const uint32_t tpv = gf.tx * gf.ty, vw = i / tpv, r = i - vw * tpv;
+                const uint32_t ci = r / gf.ty, ri = r - ci * gf.ty, mid = gf.tx >> 1;
+                const uint32_t tcol = (ci & 1u) ? mid - 1u - (ci >> 1) : mid + (ci >> 1);
+                tile = vw * tpv + ((ri + 5u * ci) % gf.ty) * gf.tx + tcol;
+            }
+            if (SGR_UNIFORM(gf.occ[tile]) == 0u) {
+                if (t == 0) gf.ranges[tile] = make_uint2(0u, 0u);
+                if (gf.bg.enabled && t < 256u) sgr_bg_fill_tile(gf.bg, tile);
+                continue;
+            }
+            SGR_STAMP(8)
+            uint32_t a = 0u, e = 0u, bs = 0u;
+            if (t < gf.nblk) { const uint32_t *r = gf.rows + (size_t)t * kRunRow + tile; a = r[0]; e = r[1]; bs = gf.base[t]; }
+#ifdef SGR_DEBUG_BOUNDS
+            if (t < gf.nblk && (a < bs || e < a || e > gf.cap_dbg)) printf("bad piece tile %u run %u a %u e %u bs %u cap %u from %p\n", tile, t, a, e, bs, gf.cap_dbg, (const void *)(gf.base + t));
+#endif
+            const uint32_t cnt = e - a;
+            uint32_t inc = cnt, before = a - bs;
 #pragma unroll
-        for (uint32_t it = 0; it < RI; it++) c[it] = seg[min(it * NT + t, last)];
+            for (int off = 1; off < 64; off <<= 1) { const uint32_t nbv = __shfl_up(inc, off, 64); if (lane >= (uint32_t)off) inc += nbv; }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) before += __shfl_xor(before, off, 64);
+            if (lane == 63u) s_wave[wave] = inc;
+            if (lane == 0u) s_wave2[wave] = before;
+            __syncthreads();
+            uint32_t pre = 0u, n_all = 0u, first = 0u;
+#pragma unroll
+            for (uint32_t w = 0; w < NW; w++) { const uint32_t x = s_wave[w]; if (w < wave) pre += x; n_all += x; first += s_wave2[w]; }
+            if (t < 512u) { s_pre[t] = pre + inc - cnt; s_cur[t] = a; }          // piece prefix / piece start (runs beyond nblk: prefix = n, never chosen)
+            static_assert(NT >= 512, "one run per thread");
+            const uint32_t n_t = SGR_UNIFORM(n_all), first_t = SGR_UNIFORM(first);
+            range = make_uint2(first_t, first_t + n_t);
+            if (t == 0) {
+                gf.ranges[tile] = n_t ? range : make_uint2(0u, 0u);
+                if (gf.order && n_t) {
+                    const uint32_t cls = 31u - min(31u, n_t >> 7);
+                    gf.order[(size_t)cls * gf.tiles_total + atomicAdd(&gf.cls_count[cls], 1u)] = make_uint4(tile, range.x, range.y, 0u);
+                }
+            }
+            if (n_t == 0u) continue;                                            // (cannot happen: the tile is marked occupied)
+            __syncthreads();
+            SGR_STAMP(9)
+#ifdef SGR_DEEP_TIMING
+            if (t == 0 && blockIdx.x < 1024u) sgr_deep_dbg[blockIdx.x * 16 + 15] = n_t;
+#endif
+            // composite j of the tile: in the piece of the last run whose prefix is <= j
+            auto gather = [&](uint32_t j) -> uint64_t {
+                uint32_t lo = 0u;
+                for (uint32_t step = gf.search_top; step > 0u; step >>= 1) if (s_pre[lo + step] <= j) lo += step;
+#ifdef SGR_DEBUG_BOUNDS
+                if (s_cur[lo] + (j - s_pre[lo]) >= gf.cap_dbg) { printf("gather oob tile %u j %u lo %u pre %u cur %u n %u nblk %u\n", tile, j, lo, s_pre[lo], s_cur[lo], n_t, gf.nblk); return 0; }
+#endif
+                return comp[s_cur[lo] + (j - s_pre[lo])];
+            };
+            const uint32_t last_j = n_t - 1u;
+            if (n_t <= WIN) {
+#pragma unroll
+                for (uint32_t it = 0; it < RI; it++) c[it] = gather(min(it * NT + t, last_j));
+                seg = nullptr;                                                   // (n <= WIN <= REG: nothing below reads it)
+            } else {
+                uint64_t *sk = gf.scratch_k + range.x;
+                for (uint32_t j = t; j < n_t; j += NT) sk[j] = gather(j);
+                __threadfence_block();
+                __syncthreads();
+                seg = sk;
+#pragma unroll
+                for (uint32_t it = 0; it < RI; it++) c[it] = seg[min(it * NT + t, last_j)];
+            }
+            __syncthreads();                                                    // (s_pre / s_cur change roles below)
+            SGR_STAMP(10)
+        } else {
+            const uint32_t entry = SGR_UNIFORM(deep_list[i]);
+            tile = entry & kDeepTileMask; w0 = (entry >> 26) * WIN;              // this workgroup's window: sorted positions of bins starting in [w0, w0 + WIN)
+            const uint2 range_v = ranges[tile];
+            range = make_uint2(SGR_UNIFORM(range_v.x), SGR_UNIFORM(range_v.y));
+            seg = comp + range.x;
+            const uint32_t last_j = range.y - range.x - 1u;
+#pragma unroll
+            for (uint32_t it = 0; it < RI; it++) c[it] = seg[min(it * NT + t, last_j)];
+        }
+        const uint32_t n = range.y - range.x, last = n - 1u;
+        // FB: stable LSD passes over the value bits, then the depth bits, through global memory (scratch_k / scratch <-> dst): the whole tile, by
+        // this workgroup alone.  The composites must sit in scratch_k: a one-window tile's are still in registers only
+        auto sort_here = [&]() {
+            if (!seg) {
+#pragma unroll
+                for (uint32_t it = 0; it < RI; it++) if (it * NT + t < n) gf.scratch_k[range.x + it * NT + t] = c[it];
+                __threadfence_block();
+            }
+            __syncthreads();
+            sort_one_tile_ool<NT>(range, gf.scratch_k, scratch, dst_keys, dst_vals, (uint32_t *)s_comp, tile);
+        };
+        if constexpr (FB) { if ((n + WIN - 1u) / WIN > gf.max_windows) { sort_here(); continue; } }
         // f(composite) for the composites beyond the registers
         auto for_each_rest = [&](auto f) {
             for (uint32_t r0 = REG; r0 < n; r0 += ROUND) {
@@ -1401,20 +1486,12 @@ __global__ __launch_bounds__(NT) void deep_tile_kernel(uint64_t *comp, uint32_t 
             for (uint32_t w = 0; w < wave; w++) p += s_wave[w];
 #pragma unroll
             for (uint32_t j = 0; j < PER; j++) { s_pre[t * PER + j] = p; s_cur[t * PER + j] = p; p += h[j]; }
-            // FB, a later window of a shared tile: has window 0 declined the tile?  Then it is re-sorting the segment in place, and whatever this
-            // workgroup's own histogram said (its reads may have met half-rewritten data) it must stay away.  Flag clear: window 0 had not
-            // started when every read above was already over -- this histogram is the tile's, and window 0 will decide the same.
-            if (FB && w0 != 0u && t == 0 &&
-                (__hip_atomic_load(&deep_list[i - (entry >> 26)], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) & kDeepDeclined)) s_bad = 1u;
         }
         __syncthreads();
         SGR_STAMP(5)
         if (s_bad) {
             if constexpr (FB) {
-                if (w0 == 0u) {             // once per tile
-                    if (t == 0) { __hip_atomic_fetch_or(&deep_list[i], kDeepDeclined, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); __threadfence(); }
-                    sort_here();
-                }
+                sort_here();                // massive depth ties: the stable radix passes
             } else if (t == 0 && w0 == 0u) {       // -> the generic per-tile sort (register classes up to 16 384 entries, global-memory passes beyond); once per tile
                 const uint32_t cls = n <= 1024u ? 0u : (n <= 2048u ? 1u : (n <= 4096u ? 2u : (n <= 8192u ? 3u : (n <= 16384u ? 4u : 5u))));
                 lists[(size_t)cls * list_stride + atomicAdd(&plan->count[cls], 1u)] = tile;
@@ -1422,12 +1499,13 @@ __global__ __launch_bounds__(NT) void deep_tile_kernel(uint64_t *comp, uint32_t 
             continue;
         }
         // ---- 4. my window: the bins that start in [w0, w0 + WIN) cover the sorted positions [wbeg, wend) (s_pre is monotone: first bin at
-        // or beyond a position by binary search, the same for every thread)
+        // or beyond a position by binary search, the same for every thread).  FB: the tile's windows one after the other
         auto first_at = [&](uint32_t x) -> uint32_t {
             uint32_t b = 0;
             for (uint32_t step = NBF / 2; step > 0; step >>= 1) if (s_pre[b + step - 1u] < x) b += step;       // b = number of bins with s_pre < x (<= NBF - 1 probed)
             return (b == (uint32_t)NBF - 1u && s_pre[b] < x) ? n : s_pre[b];
         };
+        for (;;) {
         const uint32_t wbeg = SGR_UNIFORM(first_at(w0)), wend = SGR_UNIFORM(first_at(w0 + WIN));
         {   // placement in LDS, bin-ordered (rank inside the bin = one returning LDS atomic; the order inside a bin is settled below)
             uint32_t pp[RI];
@@ -1440,9 +1518,9 @@ __global__ __launch_bounds__(NT) void deep_tile_kernel(uint64_t *comp, uint32_t 
         }
         __syncthreads();
         SGR_STAMP(6)
-        // every composite counts the smaller ones of its own bin: its final place
-        for (uint32_t q = wbeg + t; q < wend; q += NT) {
-            const uint64_t v = s_comp[q - w0];
+        // every composite counts the smaller ones of its own bin: its final place (two composites per trip: the chains of dependent LDS reads overlap)
+        auto place_of = [&](uint32_t q, uint64_t &v, uint32_t &fb_out) -> uint32_t {
+            v = s_comp[q - w0];
             const uint32_t fb = fine_bin(v);
             const uint32_t st = s_pre[fb] - w0, en = s_cur[fb] - w0, el = en - 1u;
             uint32_t rank = 0;
@@ -1450,11 +1528,24 @@ __global__ __launch_bounds__(NT) void deep_tile_kernel(uint64_t *comp, uint32_t 
                 const uint64_t x0 = s_comp[k], x1 = s_comp[min(k + 1u, el)], x2 = s_comp[min(k + 2u, el)], x3 = s_comp[min(k + 3u, el)];
                 rank += (x0 < v ? 1u : 0u) + ((k + 1u < en && x1 < v) ? 1u : 0u) + ((k + 2u < en && x2 < v) ? 1u : 0u) + ((k + 3u < en && x3 < v) ? 1u : 0u);
             }
-            const uint32_t g = range.x + s_pre[fb] + rank;
-            if (keep_keys) dst_keys[g] = ((uint64_t)tile << 32) | (v >> 32);
-            dst_vals[g] = (uint32_t)v;
+            fb_out = fb;
+            return range.x + s_pre[fb] + rank;
+        };
+        for (uint32_t q = wbeg + t; q < wend; q += 2u * NT) {
+            uint64_t v0, v1 = 0;
+            uint32_t f0, f1;
+            const bool two = q + NT < wend;
+            const uint32_t g0 = place_of(q, v0, f0);
+            const uint32_t g1 = two ? place_of(q + NT, v1, f1) : 0u;
+            if (keep_keys) { dst_keys[g0] = ((uint64_t)tile << 32) | (v0 >> 32); if (two) dst_keys[g1] = ((uint64_t)tile << 32) | (v1 >> 32); }
+            dst_vals[g0] = (uint32_t)v0;
+            if (two) dst_vals[g1] = (uint32_t)v1;
         }
         SGR_STAMP(7)
+        if (!FB || wend >= n) break;
+        w0 += WIN;
+        __syncthreads();                                                        // (s_comp is refilled by the next window)
+        }
     }
 #undef SGR_UNIFORM
 }
@@ -1526,23 +1617,43 @@ extern "C" int sgr_set_sort_deep(int mode) {
     return 0;
 }
 
+// the single-view path's share of the workspace: the run matrix, the runs' bases, the scratch composites of tiles that go through global memory
+struct RunsLayout { size_t occ, rows, base, scratch_k, end; };
+inline RunsLayout runs_layout(uint64_t R, uint32_t nblk) {
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    RunsLayout L;
+    L.occ = 0;                                   // (at the head of the workspace: rasterize.hip has the preprocess launch zero it)
+    L.rows = al((size_t)kTileBins * sizeof(uint32_t));
+    L.base = al(L.rows + (size_t)nblk * kRunRow * sizeof(uint32_t));
+    L.scratch_k = al(L.base + (size_t)nblk * sizeof(uint32_t));
+    L.end = al(L.scratch_k + (size_t)R * sizeof(uint64_t));
+    return L;
+}
+
 extern "C" size_t sgr_bin_workspace_bytes(uint64_t R, uint64_t tiles_total) {
     const uint64_t nblocks = (R + kThreads * kItemsSmall - 1) / (kThreads * kItemsSmall);
     // whole-key passes: [hist blocks x 256][totals 256]; the view-segmented flavour lays its plan / chunk map / histograms / worklists
-    // over the whole area from the start (<= 2 R + R / 256 + 100 B per tile + 64 KB: see vseg_layout)
-    // (+ 4 MB: room for one 8-KB histogram row per emission workgroup of a small launch, see sgr_bin_ex; the size formula is round 1's)
-    return (size_t)((8 * (nblocks > 0 ? nblocks : 1) + 8 + 2) * kRadix * sizeof(uint32_t) + 1024 + ((size_t)4 << 20) +
-                    (tiles_total ? (tiles_total + 64) * sizeof(uint32_t) + tiles_total * 128 + 65536 : 0));
+    // over the whole area from the start (<= 2 R + R / 256 + 100 B per tile + 64 KB: see vseg_layout); the single-view path its run matrix
+    // (<= 512 rows of 8 KB) and 8 B per instance of scratch (runs_layout)
+    const size_t a = (size_t)((8 * (nblocks > 0 ? nblocks : 1) + 8 + 2) * kRadix * sizeof(uint32_t) + 1024 + ((size_t)4 << 20) +
+                              (tiles_total ? (tiles_total + 64) * sizeof(uint32_t) + tiles_total * 128 + 65536 : 0));
+    const size_t b = (tiles_total && tiles_total <= (uint64_t)kTileBins && R <= (1u << 19)) ? runs_layout(R, 512u).end : 0;
+    return std::max(a, b);
 }
 
 // self_scan: the caller skipped the F2 scan kernel (sgr_preprocess_forward_ex) and block_offsets + n + 1 holds the un-scanned
 // counts; num_rendered_dev is then WRITTEN by the duplicate kernel (capacity mode only).  nr_host: optional pinned host slot.
+// fwd_order (optional, the segment-parallel forward's work order, SGR_ORDER_HDR_WORDS + 33 * tiles_total * 4 words): filled by the single-view
+// path in its class-major form (*order_kind_out = 1; the workgroups of empty tiles then also write those tiles' background, `bg`); every other
+// flavour leaves it alone (*order_kind_out = 0).  clear_ptr / clear_words / clear_done [3]: buffers to zero on the side of the emission kernel
+// ([2] only by the single-view path).
 int sgr_bin_ex(const SgrProblem *pb, const int32_t *radii, uint32_t *rect,
                const uint32_t *block_offsets, uint64_t R, const uint64_t *num_rendered_dev, uint64_t *keys_a,
                uint64_t *keys_b, uint32_t *vals_a, uint32_t *vals_b, void *workspace, size_t workspace_bytes,
-               uint32_t *ranges, int32_t *result_in_b_host, bool self_scan, uint64_t *nr_host, void *prep_desc, size_t prep_n_desc,
-               uint32_t *prep_order, int *prep_done, uint32_t *const *clear_ptr /*[2] or NULL*/, const uint64_t *clear_words /*[2]*/,
-               int *clear_done /*[2]*/, bool first_index, bool sorted_keys, void *stream_) {
+               uint32_t *ranges, int32_t *result_in_b_host, bool self_scan, uint64_t *nr_host, uint32_t *fwd_order, int *order_kind_out,
+               const SgrBgJob *bg, bool occ_zeroed /* the first SGR_BIN_OCC_WORDS words of the workspace are zero (else: a memset launch on the
+               single-view path) */, uint32_t *const *clear_ptr /*[3] or NULL*/, const uint64_t *clear_words /*[3]*/,
+               int *clear_done /*[3]*/, bool first_index, bool sorted_keys, void *stream_) {
     if (sgr_validate_problem(pb)) return 1;
     hipStream_t stream = (hipStream_t)stream_;
     const int Tx = (pb->W + SGR_TILE - 1) / SGR_TILE, Ty = (pb->H + SGR_TILE - 1) / SGR_TILE;
@@ -1550,15 +1661,12 @@ int sgr_bin_ex(const SgrProblem *pb, const int32_t *radii, uint32_t *rect,
     if (tiles_total >= (1ull << 32)) { sgr_set_error("too many tiles (%llu)", (unsigned long long)tiles_total); return 1; }
     if (R > 0xFFFFFFF0ull) { sgr_set_error("num_rendered %llu exceeds the 32-bit instance index", (unsigned long long)R); return 1; }
     if (result_in_b_host) *result_in_b_host = 0;
-    if (prep_done) *prep_done = 0;
-    if (clear_done) clear_done[0] = clear_done[1] = 0;
-    const bool fold_clear = R > 0 && pb->P > 0 && tiles_total * 2 <= (1u << 20);     // small: cleared by the duplicate kernel
-    if (!fold_clear) SGR_CHECK_HIP(hipMemsetAsync(ranges, 0, tiles_total * 2 * sizeof(uint32_t), stream));
-    if (R == 0 || pb->P == 0) return 0;
+    if (order_kind_out) *order_kind_out = 0;
+    if (clear_done) clear_done[0] = clear_done[1] = clear_done[2] = 0;
+    if (R == 0 || pb->P == 0) { SGR_CHECK_HIP(hipMemsetAsync(ranges, 0, tiles_total * 2 * sizeof(uint32_t), stream)); return 0; }
     if (workspace_bytes < sgr_bin_workspace_bytes(R, tiles_total)) { sgr_set_error("sgr_bin: workspace too small"); return 1; }
     const uint32_t n = (uint32_t)R;
     const int nbx = sgr_preprocess_blocks_per_view(pb->P);
-    const bool all_large = tiles_total <= 2048;                  // the wide tile pass's worklist area sits behind the radix scratch: cleared by the emission kernel
     const bool small = n <= (1u << 19);
     const uint32_t tile_keys = kThreads * (small ? kItemsSmall : kItemsLarge);
     const uint32_t nblocks = (n + tile_keys - 1) / tile_keys;
@@ -1568,9 +1676,9 @@ int sgr_bin_ex(const SgrProblem *pb, const int32_t *radii, uint32_t *rect,
     const int passes = (total_bits + kRadixBits - 1) / kRadixBits;
     uint64_t *kin = keys_a, *kout = keys_b;
     uint32_t *vin = vals_a, *vout = vals_b;
-    // automatic: one or two 512^2 views (<= 2048 tiles, <= 2^19 instances, <= 512 emission workgroups): ONE order-free 11-bit pass over
-    // the tile id whose histogram rows the emission kernel writes itself, then the LDS distribution sort per tile; everything else with
-    // <= 4096 tiles per view: view-segmented; beyond that the whole-key passes
+    // automatic: one or two 512^2 views (<= 2048 tiles, <= 2^19 instances, <= 512 emission workgroups): the single-view path -- tile-ordered
+    // emission runs + one workgroup per tile that gathers and sorts (no tile pass); everything else with <= 4096 tiles per view:
+    // view-segmented; beyond that the whole-key passes
     const uint32_t tpv = (uint32_t)Tx * (uint32_t)Ty;
     // launches whose tile lists are deep on average (C5: 1M Gaussians on 1024 tiles): the view-segmented flavour hands its long tiles to the
     // LDS distribution sort (deep_tile_kernel) instead of the register network; without room for its worklists they keep the whole-key passes
@@ -1580,20 +1688,23 @@ int sgr_bin_ex(const SgrProblem *pb, const int32_t *radii, uint32_t *rect,
     bool split = want_deep;
     if (split && VL.end > workspace_bytes) { split = false; VL = vseg_layout(R, tiles_total, (uint32_t)pb->n_views, tpv, false); }
     const bool vseg_ok = tpv <= (uint32_t)kVsegMaxBins && pb->n_views <= kVsegMaxViews && VL.end <= workspace_bytes;
-    // the wide pass: the emission kernel writes the tile pass's block-major histogram rows for its own key runs (one 8-KB row per
-    // workgroup at the head of the workspace, then the 2048 digit totals, then the runs) -- no histogram kernel
-    const uint32_t nblk_e = (uint32_t)nbx * (uint32_t)pb->n_views;
-    const bool wide_ok = all_large && small && nblk_e <= 512u &&
-                         ((size_t)(nblk_e + 1u) * kWide + 2u * (size_t)nblk_e) * sizeof(uint32_t) <= sgr_bin_workspace_bytes(R, 0);
+    const uint32_t nbx_e = (uint32_t)(nbx + kRunThreads / kThreads - 1) / (uint32_t)(kRunThreads / kThreads);     // emission workgroups per view
+    const uint32_t nblk_e = nbx_e * (uint32_t)pb->n_views;
+    const RunsLayout RL = runs_layout(R, nblk_e);
+    const bool runs_ok = tiles_total <= (uint64_t)kTileBins && small && nblk_e <= 512u && RL.end <= workspace_bytes;
     int mode = sgr_sort_mode;
-    if (mode == 3 || mode == 5) mode = wide_ok ? 5 : 4;
+    if (mode == 3 || mode == 5) mode = runs_ok ? 5 : 4;
     if (mode == 4 && !(vseg_ok && (!deep || split || sgr_sort_mode == 4))) mode = 1;
     if (mode == 4 && !vseg_ok) mode = 1;
-    const bool emit_hist = mode == 5;
-    uint2 *blk_runs = (uint2 *)(hist + (size_t)(nblk_e + 1u) * kWide);
+    const bool runs = mode == 5;
+    // (every tile's range is written by its own workgroup on the single-view path; the other flavours write the occupied tiles' only)
+    const bool fold_clear = !runs && tiles_total * 2 <= (1u << 20);     // small: cleared by the duplicate kernel
+    if (!runs && !fold_clear) SGR_CHECK_HIP(hipMemsetAsync(ranges, 0, tiles_total * 2 * sizeof(uint32_t), stream));
     { SgrProfScope _p(SGR_K_DUPLICATE, stream);
     DupExtra ex;
-    ex.hist_rows = emit_hist ? hist : nullptr; ex.blk_runs = emit_hist ? blk_runs : nullptr;
+    ex.run_rows = runs ? (uint32_t *)((char *)workspace + RL.rows) : nullptr; ex.run_base = runs ? (uint32_t *)((char *)workspace + RL.base) : nullptr;
+    ex.occ = runs ? (uint32_t *)((char *)workspace + RL.occ) : nullptr;
+    if (runs && !occ_zeroed) SGR_CHECK_HIP(hipMemsetAsync(ex.occ, 0, (size_t)kTileBins * sizeof(uint32_t), stream));
     ex.write_first = first_index ? 1u : 0u;
     const uint32_t nblk = (uint32_t)nbx * (uint32_t)pb->n_views;
     ex.self_sums = self_scan ? block_offsets + (nblk + 1) : nullptr;
@@ -1604,12 +1715,20 @@ int sgr_bin_ex(const SgrProblem *pb, const int32_t *radii, uint32_t *rect,
         ex.zero_ptr[1 + c] = ok ? clear_ptr[c] : nullptr; ex.zero_words[1 + c] = ok ? (uint32_t)clear_words[c] : 0u;
         if (clear_done) clear_done[c] = ok ? 1 : 0;
     }
-    ex.zero_small = all_large ? (uint32_t *)((char *)workspace + sgr_bin_workspace_bytes(R, 0)) : nullptr; ex.zero_small_n = 16u;   // [0] worklist counter / class counts + tickets
+    if (runs && clear_ptr && clear_ptr[2] && clear_words[2] <= (1ull << 26)) {       // (slot 0 is free on this path)
+        ex.zero_ptr[0] = clear_ptr[2]; ex.zero_words[0] = (uint32_t)clear_words[2];
+        if (clear_done) clear_done[2] = 1;
+    }
+    ex.zero_small = (runs && fwd_order) ? fwd_order : nullptr; ex.zero_small_n = 48u;       // the work order's class counters
     if (self_scan && !num_rendered_dev) { sgr_set_error("sgr_bin: self-scan needs the device counter"); return 1; }
-    hipLaunchKernelGGL(duplicate_keys_kernel, dim3(nbx, pb->n_views), dim3(kThreads), 0, stream, pb->P, Tx, Tx * Ty,
-                       radii, (uint4 *)rect, block_offsets, n, keys_a, vals_a, ex);
+    if (runs) hipLaunchKernelGGL((duplicate_keys_kernel<true, kRunThreads>), dim3(nbx_e, pb->n_views), dim3(kRunThreads), 0, stream, pb->P, Tx, Tx * Ty, nbx,
+                                 radii, (uint4 *)rect, block_offsets, n, kout, (uint32_t *)nullptr, ex);
+    else hipLaunchKernelGGL((duplicate_keys_kernel<false, kThreads>), dim3(nbx, pb->n_views), dim3(kThreads), 0, stream, pb->P, Tx, Tx * Ty, nbx,
+                            radii, (uint4 *)rect, block_offsets, n, keys_a, vals_a, ex);
     SGR_CHECK_LAUNCH("duplicate_keys_kernel");
     }
+    GatherFront no_gf;
+    memset(&no_gf, 0, sizeof(no_gf));
     if (mode == 4) {
         char *ws = (char *)workspace;
         VsegPlan *plan = (VsegPlan *)(ws + VL.plan);
@@ -1645,7 +1764,6 @@ int sgr_bin_ex(const SgrProblem *pb, const int32_t *radii, uint32_t *rect,
             hipLaunchKernelGGL((vseg_scatter_staged_kernel<4096, 8>), dim3(VL.max_chunks + 8), dim3(1024), 0, stream, kin, vin, kout, plan, chunk_map, tpv, vhist,
                                (const uint2 *)ranges);
         SGR_CHECK_LAUNCH("view-segmented tile pass");
-        SortPrep none; none.desc = nullptr; none.n_desc = 0; none.order = nullptr; none.tiles_total = 0; none.enabled = 0;
         if (split) {
             // one workgroup per (window of a) deep tile sorts it by distribution in LDS; the final list goes straight to (kin, vin)
             // (grids of resident workgroups that stride over their lists: the counts are only known on the device, and a 1024-thread workgroup
@@ -1653,9 +1771,9 @@ int sgr_bin_ex(const SgrProblem *pb, const int32_t *radii, uint32_t *rect,
             const uint32_t gbig = std::max(1u, (uint32_t)std::min<uint64_t>(R / (kDeepSmallCap - kDeepBinMax) + 1, 256u));
             const uint32_t gsmall = std::max(1u, (uint32_t)std::min<uint64_t>(std::min<uint64_t>(tiles_total, R / 64 + 1), 768u));
             hipLaunchKernelGGL((deep_tile_kernel<1024, kDeepBigCap, 4096>), dim3(gbig), dim3(1024), 0, stream, kout, vout, kin, vin, &plan->count[6],
-                               lists + (size_t)6 * VL.list_stride, (const uint2 *)ranges, sorted_keys ? 1 : 0, plan, lists, VL.list_stride, none);
+                               lists + (size_t)6 * VL.list_stride, (const uint2 *)ranges, sorted_keys ? 1 : 0, plan, lists, VL.list_stride, no_gf);
             hipLaunchKernelGGL((deep_tile_kernel<512, kDeepSmallCap, 1024>), dim3(gsmall), dim3(512), 0, stream, kout, vout, kin, vin, &plan->count[7],
-                               lists + (size_t)7 * VL.list_stride, (const uint2 *)ranges, sorted_keys ? 1 : 0, plan, lists, VL.list_stride, none);
+                               lists + (size_t)7 * VL.list_stride, (const uint2 *)ranges, sorted_keys ? 1 : 0, plan, lists, VL.list_stride, no_gf);
             SGR_CHECK_LAUNCH("deep_tile_kernel");
         }
         {
@@ -1669,7 +1787,7 @@ int sgr_bin_ex(const SgrProblem *pb, const int32_t *radii, uint32_t *rect,
         // (deep mode with every tile on the deep lists: only the tiles those kernels declined -- massive depth ties -- are left: a small grid,
         // it usually just exits)
         hipLaunchKernelGGL(tile_sort_regs_kernel<16>, dim3(deep_min == 0u ? std::min(grid(1), 64u) : grid(1)), dim3(1024), 0, stream, rg, kout, vout, kin, vin, tw4, 4, 0,
-                           none, sorted_keys ? 1 : 0);
+                           sorted_keys ? 1 : 0);
         SGR_CHECK_LAUNCH("tile_sort_regs_kernel");
         }
         }
@@ -1677,24 +1795,24 @@ int sgr_bin_ex(const SgrProblem *pb, const int32_t *radii, uint32_t *rect,
         return 0;
     }
     if (mode == 5) {
-        uint32_t *wl = (uint32_t *)((char *)workspace + sgr_bin_workspace_bytes(R, 0));     // [16 counters][6][tiles_total]
+        // the tile-ordered runs sit in kout as composites; the sorted list goes into (kin, vin).  One launch, one 512-thread workgroup per tile, two
+        // per CU: the occupied tiles (212 of 1 024 at a humanoid view) all start at once and the empty tiles' workgroups -- one load and gone -- pass
+        // through the slots beside them.  (1024-thread workgroups sort a tile ~1 us faster, but only ONE fits a CU (123 VGPRs): 812 empty-tile
+        // workgroups then queued for the 44 CUs the working ones left free and the launch lasted 24 us instead of 14.)
         { SgrProfScope _ps(SGR_K_SORT, stream);
-        hipLaunchKernelGGL(wide_rowscan_kernel, dim3(kWide / 64), dim3(1024), 0, stream, hist, nblk_e, hist + (size_t)nblk_e * kWide);
-        hipLaunchKernelGGL(wide_downsweep_runs_kernel<kItemsSmall>, dim3(nblk_e), dim3(kThreads), 0, stream, kin, vin, kout, blk_runs, hist,
-                           hist + (size_t)nblk_e * kWide, (uint2 *)ranges, (uint32_t)tiles_total, wl, g_deep_max_windows);
-        SGR_CHECK_LAUNCH("wide tile-bit pass (emitted rows)");
-        // composites sit tile-bucketed in kout (vout is scratch); the sorted list goes back into (kin, vin).  Per-tile step: the LDS
-        // distribution sort (O(n), one workgroup per window of 3968 entries, ONE launch for everything; its spare last workgroup runs the
-        // forward's prepare step).  Resident workgroups stride over the window list.  1024 threads per tile: a single view has fewer
-        // tiles than the chip has CUs, so a tile's workgroup has its CU to itself and the phases are latency chains -- 256 threads: 15.5 us
-        // at C2, 512: 11.5, 1024: 10.5
-        SortPrep sp;
-        sp.desc = (uint2 *)prep_desc; sp.n_desc = prep_n_desc; sp.order = prep_order; sp.tiles_total = (uint32_t)tiles_total;
-        sp.enabled = (prep_order || prep_desc) ? 1 : 0;
-        hipLaunchKernelGGL((deep_tile_kernel<1024, kDeepSmallCap, 1024, true>), dim3((uint32_t)std::min<uint64_t>(tiles_total + R / (kDeepSmallCap - kDeepBinMax) + 1, 768u) + (sp.enabled ? 1u : 0u)),
-                           dim3(1024), 0, stream, kout, vout, kin, vin, wl, wl + 16, (const uint2 *)ranges, sorted_keys ? 1 : 0, (VsegPlan *)nullptr, (uint32_t *)nullptr, 0u, sp);
-        if (sp.enabled && prep_done) *prep_done = 1;
-        SGR_CHECK_LAUNCH("deep_tile_kernel");
+        GatherFront gf = no_gf;
+        gf.rows = (const uint32_t *)((char *)workspace + RL.rows); gf.base = (const uint32_t *)((char *)workspace + RL.base);
+        gf.occ = (const uint32_t *)((char *)workspace + RL.occ);
+        gf.nblk = nblk_e; gf.tiles_total = (uint32_t)tiles_total; gf.tx = (uint32_t)Tx; gf.ty = (uint32_t)Ty; gf.ranges = (uint2 *)ranges;
+        gf.search_top = 1u; while (gf.search_top * 2u < nblk_e) gf.search_top *= 2u;
+        gf.order = fwd_order ? (uint4 *)(fwd_order + SGR_ORDER_HDR_WORDS) : nullptr; gf.cls_count = fwd_order;
+        gf.scratch_k = (uint64_t *)((char *)workspace + RL.scratch_k);
+        gf.max_windows = g_deep_max_windows; gf.cap_dbg = n;
+        if (bg && fwd_order) gf.bg = *bg;
+        hipLaunchKernelGGL((deep_tile_kernel<512, kDeepSmallCap, 1024, true>), dim3((uint32_t)tiles_total), dim3(512), 0, stream, kout, vout, kin, vin,
+                           (const uint32_t *)nullptr, (uint32_t *)nullptr, (const uint2 *)nullptr, sorted_keys ? 1 : 0, (VsegPlan *)nullptr, (uint32_t *)nullptr, 0u, gf);
+        SGR_CHECK_LAUNCH("deep_tile_kernel (single-view path)");
+        if (order_kind_out && fwd_order) *order_kind_out = 1;
         }
         if (result_in_b_host) *result_in_b_host = (kin == keys_b) ? 1 : 0;
         return 0;
@@ -1728,5 +1846,5 @@ extern "C" int sgr_bin(const SgrProblem *pb, const int32_t *radii, uint32_t *rec
                        uint64_t *keys_b, uint32_t *vals_a, uint32_t *vals_b, void *workspace, size_t workspace_bytes,
                        uint32_t *ranges, int32_t *result_in_b_host, void *stream_) {
     return sgr_bin_ex(pb, radii, rect, block_offsets, R, num_rendered_dev, keys_a, keys_b, vals_a, vals_b, workspace,
-                      workspace_bytes, ranges, result_in_b_host, false, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, /*first_index=*/true, /*sorted_keys=*/true, stream_);
+                      workspace_bytes, ranges, result_in_b_host, false, nullptr, nullptr, nullptr, nullptr, false, nullptr, nullptr, nullptr, /*first_index=*/true, /*sorted_keys=*/true, stream_);
 }

@@ -3,11 +3,17 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "../../include/sigman_gsplat.h"
 
 #define SGR_WAVE 64
+// The segment-parallel forward's work order, CLASS-MAJOR form (written by the single-view path's per-tile sort, binning.hip GatherFront): words
+// [0, 32) = number of occupied tiles per length class (class c: 31 - min(31, n >> 7) == c, i.e. longest lists first), then from word
+// SGR_ORDER_HDR_WORDS on uint4 entries (tile, first, end, 0), class c's at [c * tiles_total, c * tiles_total + count[c]).  Empty tiles are not listed.
+#define SGR_ORDER_HDR_WORDS 64
+#define SGR_BIN_OCC_WORDS 2048     // binning.hip: the single-view path's tile-occupancy flags, the first words of the sort workspace
 
 // ---------------------------------------------------------------------------------------------
 // error plumbing (host)
@@ -30,6 +36,7 @@ int sgr_debug_enabled();        // api.hip: upstream's debug=True (thread-local)
             return 1;                                                                            \
         }                                                                                        \
         if (sgr_debug_enabled()) {                                                               \
+            if (getenv("SIGMAN_TRACE_LAUNCH")) { fprintf(stderr, "[sgr] %s\n", name); fflush(stderr); }  \
             _e = hipDeviceSynchronize();                                                         \
             if (_e != hipSuccess) {                                                              \
                 sgr_set_error("debug: %s failed on the device: %s", name, hipGetErrorString(_e)); \
@@ -86,6 +93,10 @@ struct SgrBgJob {
     const float *target, *mask;     // target == NULL: no loss
     float weight;
     float *gimg, *loss_part;
+    // independent of `enabled`: a few words the FIRST kernel of the chain (preprocess) zeroes on the side for a later one -- the single-view
+    // path's tile-occupancy flags (binning.hip), which the emission kernel sets with plain stores
+    uint32_t *zero_ptr;
+    uint32_t zero_words;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -169,41 +180,43 @@ __device__ __forceinline__ void sgr_fwd_prepare(const uint2 *__restrict__ ranges
     }
 }
 
-// Background (and, fused step, loss share + dL/dcolor) of the tiles bid = group, group + n_groups, ...; called by whole groups of 256
-// threads (4 waves; a tile's 256 pixels; wave w's loss sum goes to the loss slot of quadrant w -- render.hip's own empty-tile path writes the same).
-__device__ __forceinline__ void sgr_bg_fill(const SgrBgJob &j, uint32_t group, uint32_t n_groups) {
+// Background (and, fused step, loss share + dL/dcolor) of tile `bid`; called by whole groups of 256 threads (4 waves; a tile's 256 pixels;
+// wave w's loss sum goes to the loss slot of quadrant w -- render.hip's own empty-tile path writes the same).
+__device__ __forceinline__ void sgr_bg_fill_tile(const SgrBgJob &j, uint32_t bid) {
     const uint32_t t = threadIdx.x & 255u, wv = t >> 6;
     const size_t hw = (size_t)j.H * j.W;
-    for (uint32_t bid = group; bid < j.tiles_total; bid += n_groups) {
-        const uint32_t view = bid / j.tiles_per_view, tile = bid - view * j.tiles_per_view;
-        const int bx = (int)(tile % (uint32_t)j.Tx) * 16 + (int)(t & 15u), by = (int)(tile / (uint32_t)j.Tx) * 16 + (int)(t >> 4);
-        const bool in = bx < j.W && by < j.H;
-        const size_t pix = (size_t)by * j.W + bx, vb = (size_t)view * hw;
-        float lsum = 0.f;
-        if (in) {
-            const float b[3] = {j.bg[0], j.bg[1], j.bg[2]};
-            j.final_T[vb + pix] = 1.f;
-            j.n_contrib[vb + pix] = 0u;
-            j.out_depth[vb + pix] = 0.f;
-            j.out_alpha[vb + pix] = 0.f;
-            const float m = (j.target && j.mask) ? j.mask[vb + pix] : 1.f;
+    const uint32_t view = bid / j.tiles_per_view, tile = bid - view * j.tiles_per_view;
+    const int bx = (int)(tile % (uint32_t)j.Tx) * 16 + (int)(t & 15u), by = (int)(tile / (uint32_t)j.Tx) * 16 + (int)(t >> 4);
+    const bool in = bx < j.W && by < j.H;
+    const size_t pix = (size_t)by * j.W + bx, vb = (size_t)view * hw;
+    float lsum = 0.f;
+    if (in) {
+        const float b[3] = {j.bg[0], j.bg[1], j.bg[2]};
+        j.final_T[vb + pix] = 1.f;
+        j.n_contrib[vb + pix] = 0u;
+        j.out_depth[vb + pix] = 0.f;
+        j.out_alpha[vb + pix] = 0.f;
+        const float m = (j.target && j.mask) ? j.mask[vb + pix] : 1.f;
 #pragma unroll
-            for (int c = 0; c < 3; c++) {
-                j.out_color[vb * 3 + (size_t)c * hw + pix] = b[c];
-                if (j.clamped) j.clamped[vb * 3 + (size_t)c * hw + pix] = fminf(fmaxf(b[c], 0.f), 1.f);
-                if (j.target) {
-                    const float d = (fminf(fmaxf(b[c], 0.f), 1.f) - j.target[vb * 3 + (size_t)c * hw + pix]) * m;
-                    lsum += fabsf(d);
-                    const float sg = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
-                    j.gimg[vb * 3 + (size_t)c * hw + pix] = (b[c] >= 0.f && b[c] <= 1.f) ? j.weight * m * sg : 0.f;
-                }
+        for (int c = 0; c < 3; c++) {
+            j.out_color[vb * 3 + (size_t)c * hw + pix] = b[c];
+            if (j.clamped) j.clamped[vb * 3 + (size_t)c * hw + pix] = fminf(fmaxf(b[c], 0.f), 1.f);
+            if (j.target) {
+                const float d = (fminf(fmaxf(b[c], 0.f), 1.f) - j.target[vb * 3 + (size_t)c * hw + pix]) * m;
+                lsum += fabsf(d);
+                const float sg = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+                j.gimg[vb * 3 + (size_t)c * hw + pix] = (b[c] >= 0.f && b[c] <= 1.f) ? j.weight * m * sg : 0.f;
             }
         }
-        if (j.target) {
-            lsum = sgr_wave_sum(lsum);
-            if ((t & 63u) == 0u) j.loss_part[(size_t)bid * 4 + wv] = j.weight * lsum;
-        }
     }
+    if (j.target) {
+        lsum = sgr_wave_sum(lsum);
+        if ((t & 63u) == 0u) j.loss_part[(size_t)bid * 4 + wv] = j.weight * lsum;
+    }
+}
+// the tiles bid = group, group + n_groups, ...
+__device__ __forceinline__ void sgr_bg_fill(const SgrBgJob &j, uint32_t group, uint32_t n_groups) {
+    for (uint32_t bid = group; bid < j.tiles_total; bid += n_groups) sgr_bg_fill_tile(j, bid);
 }
 
 #endif  // __HIPCC__

@@ -224,6 +224,8 @@ __global__ __launch_bounds__(kPreThreads) void preprocess_fwd_kernel(SgrProblem 
                                                                      uint4 *__restrict__ rect,
                                                                      uint8_t *__restrict__ clamped,
                                                                      uint32_t *__restrict__ block_sums, int nbx, SgrBgJob bg) {
+    if (bg.zero_words && blockIdx.y == 0)
+        for (uint32_t z = blockIdx.x * kPreThreads + threadIdx.x; z < bg.zero_words; z += gridDim.x * kPreThreads) bg.zero_ptr[z] = 0u;
     // (workgroups behind the nbx that own Gaussians: the background pre-fill of the fused single-view step, common.h SgrBgJob)
     if ((int)blockIdx.x >= nbx) { if (blockIdx.y == 0 && bg.enabled) sgr_bg_fill(bg, blockIdx.x - (uint32_t)nbx, gridDim.x - (uint32_t)nbx); return; }
     // One thread per Gaussian, looping over `views_per_wg` consecutive views: the per-Gaussian inputs (52 B: mean, covariance, opacity,
@@ -791,7 +793,7 @@ extern "C" int32_t sgr_preprocess_blocks_per_view(int32_t P) { return P <= 0 ? 1
 // skip_scan: leave the per-workgroup counts un-scanned behind block_offsets; sgr_bin_ex(self_scan = true) folds F2 into F3
 int sgr_preprocess_forward_ex(const SgrProblem *pb, float *rec, int32_t *radii, uint32_t *rect, uint8_t *clamped,
                               uint32_t *block_offsets, uint64_t *num_rendered, uint64_t capacity, bool skip_scan,
-                              const SgrBgJob *bg /* optional: background pre-fill by extra workgroups of this launch (fused single-view step) */, void *stream_) {
+                              const SgrBgJob *bg /* optional: background pre-fill by extra workgroups of this launch (fused single-view step) and / or a few words to zero */, void *stream_) {
     if (validate_problem(pb)) return 1;
     if (capacity == 0) capacity = ~0ull;
     hipStream_t stream = (hipStream_t)stream_;
@@ -807,7 +809,7 @@ int sgr_preprocess_forward_ex(const SgrProblem *pb, float *rec, int32_t *radii, 
     if (g_view_group > 0) vpw = g_view_group < pb->n_views ? g_view_group : pb->n_views;
     SgrBgJob bgj;
     memset(&bgj, 0, sizeof(bgj));
-    if (bg && bg->enabled) bgj = *bg;
+    if (bg) bgj = *bg;
     dim3 grid(nbx + (bgj.enabled ? (int)bgj.tiles_total : 0), (pb->n_views + vpw - 1) / vpw);
     { SgrProfScope _p(SGR_K_PREPROCESS_FWD, stream);
     hipLaunchKernelGGL(preprocess_fwd_kernel, grid, dim3(kPreThreads), 0, stream, *pb, vpw, (float4 *)rec, radii, (uint4 *)rect,

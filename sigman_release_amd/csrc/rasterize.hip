@@ -27,8 +27,8 @@ int sgr_preprocess_forward_ex(const SgrProblem *pb, float *rec, int32_t *radii, 
                               uint64_t *num_rendered, uint64_t capacity, bool skip_scan, const SgrBgJob *bg, void *stream_);
 int sgr_bin_ex(const SgrProblem *pb, const int32_t *radii, uint32_t *rect, const uint32_t *block_offsets, uint64_t R,
                const uint64_t *num_rendered_dev, uint64_t *keys_a, uint64_t *keys_b, uint32_t *vals_a, uint32_t *vals_b, void *workspace,
-               size_t workspace_bytes, uint32_t *ranges, int32_t *result_in_b_host, bool self_scan, uint64_t *nr_host, void *prep_desc,
-               size_t prep_n_desc, uint32_t *prep_order, int *prep_done, uint32_t *const *clear_ptr, const uint64_t *clear_words,
+               size_t workspace_bytes, uint32_t *ranges, int32_t *result_in_b_host, bool self_scan, uint64_t *nr_host, uint32_t *fwd_order,
+               int *order_kind_out, const SgrBgJob *bg, bool occ_zeroed, uint32_t *const *clear_ptr, const uint64_t *clear_words,
                int *clear_done, bool first_index, bool sorted_keys, void *stream_);
 int sgr_render_backward_ex(const SgrProblem *pb, const uint32_t *ranges, const float *rec, const uint32_t *rect,
                            const uint32_t *n_contrib, const float *out_color, const float *out_depth, const float *out_alpha,
@@ -42,7 +42,7 @@ int sgr_preprocess_backward_ex(const SgrProblem *pb, const int32_t *radii, const
 int sgr_render_forward_wants_prepare(const SgrProblem *pb, uint64_t R, bool use_aux, size_t *n_desc_out);
 int sgr_render_forward_ex(const SgrProblem *pb, const uint32_t *ranges, const uint32_t *point_list, const float *rec, float *out_color,
                           float *out_depth, float *out_alpha, float *final_T, uint32_t *n_contrib, uint64_t R, void *aux_compact,
-                          void *aux_ckpt_tc, void *aux_ckpt_da, void *aux_desc, uint32_t *aux_order, bool prepared, int kind,
+                          void *aux_ckpt_tc, void *aux_ckpt_da, void *aux_desc, uint32_t *aux_order, int prepared, int kind,
                           const SgrFusedL1Args *fused, bool bg_done, void *stream_);
 int sgr_render_forward_kind(const SgrProblem *pb);
 int sgr_get_forward_mode();
@@ -76,46 +76,70 @@ static int forward_launches(const SgrProblem *pb, uint64_t capacity, uint64_t R,
                              bgj.loss_part = (float *)(image + st->off_loss_part); }
         bg_done = 1;
     }
+    bool occ_zeroed = false;
     if (!preprocess_done) {
-        if (sgr_preprocess_forward_ex(pb, rec, out_radii, rect, clamped, block_offsets, num_rendered, capacity, self_scan, bg_done ? &bgj : nullptr, stream)) return 1;
+        // (the single-view path's tile-occupancy flags sit at the head of the sort workspace and must be zero when the emission kernel starts)
+        bgj.zero_ptr = (uint32_t *)(binning + st->off_sort_ws); bgj.zero_words = SGR_BIN_OCC_WORDS;
+        occ_zeroed = true;
+        if (sgr_preprocess_forward_ex(pb, rec, out_radii, rect, clamped, block_offsets, num_rendered, capacity, self_scan, &bgj, stream)) return 1;
         if (nr_pinned_host && !self_scan) SGR_CHECK_HIP(hipMemcpyAsync(nr_pinned_host, num_rendered + 2, 8, hipMemcpyDeviceToHost, stream));   // count | overflow << 63
         st->nr_by_copy = self_scan ? 0 : 1;
     }
     int32_t in_b = 0;
     const bool aux_on = st->with_aux != 0;
-    // the forward's one-workgroup prepare step (tile order + descriptor clear) rides in the tile-sort launch when there is one
+    // the segment-parallel forward wants a work order (longest tile lists first) and cleared bucket descriptors: on the single-view path the
+    // per-tile sort launch writes the order (class-major form) and the emission kernel clears the descriptors; else render.hip's own prepare kernel
     size_t n_desc = 0;
     const bool want_prep = sgr_render_forward_wants_prepare(pb, R, aux_on, &n_desc) != 0;
-    int prep_done = 0;
-    // buffers the later stages expect zeroed are cleared on the side by the duplicate kernel: the backward's flags and an optional
-    // caller buffer (the fused loss node's accumulators)
-    uint32_t *clear_ptr[2] = {aux_on ? (uint32_t *)(image + st->off_flags) : nullptr, (uint32_t *)caller_clear};
-    const uint64_t clear_words[2] = {aux_on ? (R + 0) : 0, (caller_clear_bytes + 3) / 4};
-    int clear_done[2] = {0, 0};
+    int order_kind = 0;
+    // buffers the later stages expect zeroed are cleared on the side by the duplicate kernel: the backward's flags (a fused step's own backward
+    // has its own: off_flags_fused), an optional caller buffer (the fused loss node's accumulators), the bucket descriptors
+    uint32_t *const own_flags = !aux_on ? nullptr : (uint32_t *)(image + (st->fused_bwd ? st->off_flags_fused : st->off_flags));
+    uint32_t *clear_ptr[3] = {own_flags, (uint32_t *)caller_clear, (want_prep && aux_on) ? (uint32_t *)(image + st->off_desc) : nullptr};
+    const uint64_t clear_words[3] = {aux_on ? (R + 0) : 0, (caller_clear_bytes + 3) / 4, (uint64_t)n_desc * 2};
+    int clear_done[3] = {0, 0, 0};
+    // the empty tiles' outputs, unless the preprocess launch pre-filled every tile (fused step): written by the empty tiles' own workgroups of
+    // the single-view path's sort launch
+    SgrBgJob bgs;
+    memset(&bgs, 0, sizeof(bgs));
+    if (!bg_done) {
+        bgs.enabled = 1; bgs.W = pb->W; bgs.H = pb->H; bgs.Tx = (pb->W + SGR_TILE - 1) / SGR_TILE;
+        bgs.tiles_per_view = (uint32_t)bgs.Tx * (uint32_t)((pb->H + SGR_TILE - 1) / SGR_TILE);
+        bgs.tiles_total = bgs.tiles_per_view * (uint32_t)pb->n_views;
+        bgs.bg = pb->bg; bgs.out_color = out_color; bgs.out_depth = out_depth; bgs.out_alpha = out_alpha;
+        bgs.final_T = (float *)(image + st->off_final_T); bgs.n_contrib = (uint32_t *)(image + st->off_n_contrib); bgs.clamped = pb->color_clamped;
+        if (st->fused_bwd) { bgs.target = l1->target; bgs.mask = l1->mask; bgs.weight = l1->weight; bgs.gimg = l1->grad_color;       // (exact mode)
+                             bgs.loss_part = (float *)(image + st->off_loss_part); }
+    }
     if (sgr_bin_ex(pb, out_radii, rect, block_offsets, R, capacity > 0 ? num_rendered : nullptr, (uint64_t *)(binning + st->off_keys_a),
                    (uint64_t *)(binning + st->off_keys_b), (uint32_t *)(binning + st->off_vals_a), (uint32_t *)(binning + st->off_vals_b),
                    binning + st->off_sort_ws, (size_t)sgr_bin_workspace_bytes(R, (uint64_t)((pb->W + SGR_TILE - 1) / SGR_TILE) * ((pb->H + SGR_TILE - 1) / SGR_TILE) * pb->n_views),
                    (uint32_t *)(image + st->off_ranges), &in_b, self_scan, self_scan ? nr_pinned_host : nullptr,
-                   want_prep && aux_on ? image + st->off_desc : nullptr, n_desc, want_prep ? (uint32_t *)(image + st->off_order) : nullptr,
-                   &prep_done, clear_ptr, clear_words, clear_done, /*first_index=*/aux_on, /*sorted_keys=*/g_keep_sorted_keys != 0, stream)) return 1;
-    st->flags_cleared = clear_done[0];
+                   want_prep ? (uint32_t *)(image + st->off_order) : nullptr, &order_kind, bg_done ? nullptr : &bgs, occ_zeroed,
+                   clear_ptr, clear_words, clear_done, /*first_index=*/aux_on, /*sorted_keys=*/g_keep_sorted_keys != 0, stream)) return 1;
+    // (the single-view path cleared the descriptors with its order; without the clear the order is not used either: render.hip prepares itself)
+    st->order_kind = (order_kind == 1 && (clear_done[2] || !(want_prep && aux_on))) ? 1 : 0;
+    st->flags_cleared = st->fused_bwd ? 0 : clear_done[0];          // (of off_flags: what an ordinary backward writes)
+    int fused_flags_cleared = st->fused_bwd ? clear_done[0] : 0;
     if (caller_clear && caller_clear_bytes && !clear_done[1]) SGR_CHECK_HIP(hipMemsetAsync(caller_clear, 0, (size_t)caller_clear_bytes, stream));
     st->result_in_b = in_b;
     const uint32_t *point_list = (const uint32_t *)(binning + (in_b ? st->off_vals_b : st->off_vals_a));
     st->fwd_kind = sgr_render_forward_kind(pb);
     SgrFusedL1Args fa;
     if (st->fused_bwd) {
-        // the fused kernel's backward writes the flags of the survivors it looks at: the rest must be clear before it starts
-        if (!st->flags_cleared) { SGR_CHECK_HIP(hipMemsetAsync(image + st->off_flags, 0, (size_t)R * 4, stream)); st->flags_cleared = 1; }
+        // the fused kernel's backward writes the flags of the survivors it looks at: the rest must be clear before it starts.  These flags are
+        // the fused records' OWN (off_flags_fused): an ordinary backward on the same forward state (retain_graph, a second upstream gradient)
+        // rewrites off_flags for ITS scratch records and must not touch what a later gather-only backward reads
+        if (!fused_flags_cleared) { SGR_CHECK_HIP(hipMemsetAsync(image + st->off_flags_fused, 0, (size_t)R * 4, stream)); fused_flags_cleared = 1; }
         fa.target = l1->target; fa.mask = l1->mask; fa.weight = l1->weight; fa.gimg = l1->grad_color;
         fa.loss_part = (float *)(image + st->off_loss_part); fa.loss_per_view = l1->loss_per_view; fa.loss_total = l1->loss_total;
-        fa.rect = rect; fa.part = (float *)(image + st->off_part); fa.flags = (uint32_t *)(image + st->off_flags);
+        fa.rect = rect; fa.part = (float *)(image + st->off_part); fa.flags = (uint32_t *)(image + st->off_flags_fused);
     }
     const int rc = sgr_render_forward_ex(pb, (const uint32_t *)(image + st->off_ranges), point_list, rec, out_color, out_depth, out_alpha,
                               (float *)(image + st->off_final_T), (uint32_t *)(image + st->off_n_contrib), R,
                               aux_on ? image + st->off_compact : nullptr, aux_on ? image + st->off_ckpt_tc : nullptr,
                               (aux_on && !st->aux_no_da) ? image + st->off_ckpt_da : nullptr, aux_on ? image + st->off_desc : nullptr,
-                              (uint32_t *)(image + st->off_order), prep_done != 0, st->fwd_kind, st->fused_bwd ? &fa : nullptr, bg_done != 0, stream);
+                              (uint32_t *)(image + st->off_order), st->order_kind ? 2 : 0, st->fwd_kind, st->fused_bwd ? &fa : nullptr, bg_done != 0, stream);
     if (rc || !st->fused_bwd) return rc;
     // fused step: the compositing kernel left the loss shares and dL/dcolor; the bucket backward of dL/dloss = 1 follows at once
     // (its spare workgroup sums the loss shares), so that the caller's backward only gathers
@@ -207,7 +231,8 @@ static int rasterize_forward_impl(const SgrProblem *pb, uint64_t capacity, int32
     st->off_ranges = o; o = align_up(o + tiles_total * 8);
     st->off_final_T = o; o = align_up(o + hw * 4);
     st->off_n_contrib = o; o = align_up(o + hw * 4);
-    st->off_order = o; o = align_up(o + tiles_total * 16);
+    // (the segment-parallel forward's work order; class-major form on the single-view path: header + 33 class regions, common.h)
+    st->off_order = o; o = align_up(o + (tiles_total <= 2048 ? SGR_ORDER_HDR_WORDS * 4 + 33 * tiles_total * 16 : tiles_total * 16));
     if (aux_on) {
         st->off_flags = o; o = align_up(o + R * 4);                // one byte per (tile instance, quadrant): partial record written by the backward
         st->off_compact = o; o = align_up(o + 4 * R * 8);
@@ -219,6 +244,7 @@ static int rasterize_forward_impl(const SgrProblem *pb, uint64_t capacity, int32
             st->fused_bwd = 1;
             st->off_part = o; o = align_up(o + R * 4 * SGR_PART_FLOATS * 4);        // the backward's partial records are written by the forward's launch
             st->off_loss_part = o; o = align_up(o + tiles_total * 4 * 4);
+            st->off_flags_fused = o; o = align_up(o + R * 4);          // the flags of THOSE records (off_flags: of an ordinary backward's scratch records)
         }
     }
     st->image_bytes = o;
@@ -293,7 +319,7 @@ extern "C" int sgr_rasterize_backward(const SgrProblem *pb, const SgrForwardStat
         if (!st->fused_bwd) { sgr_set_error("sgr_rasterize_backward: grad_color is NULL but the forward was not a fused rasterize + L1 step"); return 1; }
         if (grad_depth || grad_alpha) { sgr_set_error("sgr_rasterize_backward: the fused step's own backward has no dL/ddepth / dL/dalpha: pass grad_color"); return 1; }
         return sgr_preprocess_backward_ex(pb, radii, pb->shs ? (const uint8_t *)(geom + st->off_clamped) : nullptr, rect, (const float *)(image + st->off_part),
-                                          (const uint32_t *)(image + st->off_flags), st->R_alloc, dL_dmeans3D, dL_dmeans2D, dL_dopacity, dL_dcolors, dL_dsh,
+                                          (const uint32_t *)(image + st->off_flags_fused), st->R_alloc, dL_dmeans3D, dL_dmeans2D, dL_dopacity, dL_dcolors, dL_dsh,
                                           dL_dcov3D, dL_dscales, dL_drotations, grad_color_scale, stream_);
     }
     // scratch: partial records [4*R][10] f32 (the flags [R] u32 live in the forward's image blob)
@@ -313,7 +339,7 @@ extern "C" int sgr_rasterize_backward(const SgrProblem *pb, const SgrForwardStat
         const uint32_t *point_list = (const uint32_t *)(binning + (st->result_in_b ? st->off_vals_b : st->off_vals_a));
         if (sgr_render_forward_ex(pb, (const uint32_t *)(image + st->off_ranges), point_list, rec, (float *)out_color, (float *)out_depth, (float *)out_alpha,
                                   (float *)(im + st->off_final_T), (uint32_t *)(im + st->off_n_contrib), st->R_alloc, im + st->off_compact, nullptr, da,
-                                  im + st->off_desc, (uint32_t *)(im + st->off_order), /*prepared=*/true, st->fwd_kind, nullptr, false, stream_)) return 1;
+                                  im + st->off_desc, (uint32_t *)(im + st->off_order), /*prepared=*/st->order_kind ? 2 : 1, st->fwd_kind, nullptr, false, stream_)) return 1;
         ckpt_da = da;
     }
     if (sgr_render_backward_ex(pb, (const uint32_t *)(image + st->off_ranges), rec, rect, (const uint32_t *)(image + st->off_n_contrib),

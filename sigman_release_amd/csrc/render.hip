@@ -297,7 +297,7 @@ __global__ __launch_bounds__(kSegThreads, 4) void render_fwd_seg_kernel(int W, i
                                                                      float *__restrict__ out_color, float *__restrict__ out_depth,
                                                                      float *__restrict__ out_alpha, float *__restrict__ final_T,
                                                                      uint32_t *__restrict__ n_contrib, FwdAux aux,
-                                                                     const uint32_t *__restrict__ order, uint32_t n_slots, FusedL1 fz, int bg_done) {
+                                                                     const uint32_t *__restrict__ order, uint32_t n_slots, FusedL1 fz, int bg_done, int order_kind) {
     // survivor ring, stored as PAIRS of consecutive survivors with the two survivors' values of each field adjacent, so that the
     // per-pixel arithmetic of both runs as packed fp32 (v_pk_*: two survivors per instruction) straight out of ds_read_b128:
     __shared__ float4 pA[kSegRing / 2], pB[kSegRing / 2], pC[kSegRing / 2];   // (x0,x1,y0,y1) (kxx0,kxx1,kxy0,kxy1) (kyy0,kyy1,op0,op1)
@@ -318,7 +318,20 @@ __global__ __launch_bounds__(kSegThreads, 4) void render_fwd_seg_kernel(int W, i
     if (slot >= n_slots) return;                                 // (grid padded to a multiple of 32)
     uint32_t bid = slot;
     uint2 range;
-    if (order) { const uint4 od = reinterpret_cast<const uint4 *>(order)[slot]; bid = od.x; range = make_uint2(od.y, od.z); }   // (tile, its range): one load
+    if (order_kind == 1) {
+        // class-major order (common.h SGR_ORDER_HDR_WORDS): slot k is the k-th occupied tile counting through the classes, longest lists first;
+        // slots beyond the occupied tiles have nothing to do (the empty tiles' background was written by the per-tile sort launch)
+        uint32_t k = slot, cls = 0u;
+        bool found = false;
+#pragma unroll
+        for (uint32_t c = 0; c < 32u; c++) {
+            const uint32_t cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)order[c]);
+            if (!found) { if (k < cnt) { found = true; cls = c; } else k -= cnt; }
+        }
+        if (!found) return;
+        const uint4 od = reinterpret_cast<const uint4 *>(order + SGR_ORDER_HDR_WORDS)[(size_t)cls * n_slots + k];
+        bid = od.x; range = make_uint2(od.y, od.z);
+    } else if (order) { const uint4 od = reinterpret_cast<const uint4 *>(order)[slot]; bid = od.x; range = make_uint2(od.y, od.z); }   // (tile, its range): one load
     else range = ranges[bid];
     const uint32_t view = bid / tiles_per_view, tile = bid - view * tiles_per_view;
     const uint32_t tx = tile % Tx, ty = tile / Tx;
@@ -1030,7 +1043,8 @@ int sgr_render_forward_wants_prepare(const SgrProblem *pb, uint64_t R, bool use_
 int sgr_render_forward_ex(const SgrProblem *pb, const uint32_t *ranges, const uint32_t *point_list, const float *rec,
                           float *out_color, float *out_depth, float *out_alpha, float *final_T, uint32_t *n_contrib,
                           uint64_t R, void *aux_compact, void *aux_ckpt_tc, void *aux_ckpt_da, void *aux_desc,
-                          uint32_t *aux_order, bool prepared, int kind /* 0: choose (sgr_render_forward_kind); else the compositing kernel to
+                          uint32_t *aux_order, int prepared /* 0: no; 1: the order (old form) and the descriptor clear are done; 2: the same with the
+                          class-major order of the single-view path (the empty tiles' outputs are written, too) */, int kind /* 0: choose (sgr_render_forward_kind); else the compositing kernel to
                           use: the depth/alpha checkpoint pass must repeat its forward's */, const SgrFusedL1Args *fused /* NULL, or: the
                           single-view fused step -- loss shares and dL/dcolor written by the segment-parallel kernel */,
                           bool bg_done /* the empty tiles' outputs (and loss shares) are already written: SgrBgJob */, void *stream_) {
@@ -1063,7 +1077,7 @@ int sgr_render_forward_ex(const SgrProblem *pb, const uint32_t *ranges, const ui
 #define SGR_LAUNCH_SEG(A)                                                                                                   \
         hipLaunchKernelGGL(render_fwd_seg_kernel<A>, dim3(seg_grid), dim3(kSegThreads), 0, stream, pb->W, pb->H, Tx, tiles,        \
                            (const uint2 *)ranges, point_list, (const float4 *)rec, pb->bg, out_color, out_depth, out_alpha, final_T,  \
-                           n_contrib, aux, (const uint32_t *)aux_order, (uint32_t)tiles_total, fz, bg_done ? 1 : 0)
+                           n_contrib, aux, (const uint32_t *)aux_order, (uint32_t)tiles_total, fz, (bg_done || prepared == 2) ? 1 : 0, prepared == 2 ? 1 : 0)
         FusedL1 fz;
         memset(&fz, 0, sizeof(fz));
         if (fused) {

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 10
     for n in names:
         assert hasattr(L, n), f"{n} declared in include/sigman_gsplat.h but not exported"
-    assert _cabi.lib().sgr_abi_version() == _cabi.ABI_VERSION == 8
+    assert _cabi.lib().sgr_abi_version() == _cabi.ABI_VERSION == 9
     assert _cabi.lib().sgr_preprocess_blocks_per_view(1000) == 4
     assert _cabi.lib().sgr_bin_workspace_bytes(10_000, 1024) >= 3 * 256 * 4
 
@@ -141,7 +141,7 @@ int main(void) {
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(root, "include"), str(c_file), "-o", str(exe),
                            "-L", libdir, "-lsigman_gsplat", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
     out = subprocess.check_output([str(exe)], text=True).split()
-    assert int(out[0]) == 8 and int(out[1]) == (1000 >> 6) + 16 + 1 and int(out[2]) > 0
+    assert int(out[0]) == 9 and int(out[1]) == (1000 >> 6) + 16 + 1 and int(out[2]) > 0
 
 
 def test_full_size_record_matches_kernel_sources():

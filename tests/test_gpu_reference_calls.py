@@ -610,6 +610,49 @@ def test_fused_single_view_step_equals_unfused_chain(P, H, W, V, use_mask, sort_
     R.check_pending_overflows(True)
 
 
+def test_fused_step_ordinary_backward_then_gather_only_backward():
+    """One fused forward, then (1) an ORDINARY backward through the colour output (another upstream gradient: the compositing backward runs
+    again, into scratch records with their own flags) and (2) the gather-only backward of the step's own loss.  The second must read the
+    fused records through the flags the FUSED pass wrote (SgrForwardState.off_flags_fused): with one shared flags array the ordinary
+    backward's flags decided which fused records the gather saw (records dropped, or uninitialised slots read).  Both orders must give the
+    gradients of a fresh forward, bit for bit (the reference's calculate_adaptive_weight calls autograd.grad twice on one graph)."""
+    from sigman_release_amd import _cabi, rasterizer as R
+    if _cabi.torch_node() is None:
+        pytest.skip("sgr_torch_node.so not built / SIGMAN_PY_NODE=1")
+    dev = _dev()
+    base, mk, target = _batched_l1_inputs(dev, 1, 1, P=8000, H=128, W=128, seed=5)
+    # a mask that switches the loss off on half of the image: there the L1 gradient is zero (no fused record, flag 0) while the colour
+    # gradient below is not (the ordinary backward writes a record and sets its flag)
+    mask = torch.zeros(1, 1, 128, 128, device=dev)
+    mask[..., :, :64] = 1.0
+    st = mk(300000)
+    names = ("means3D", "rgb", "opacity", "cov3D")
+
+    def run(order):
+        d = {k: v.clone().requires_grad_(True) for k, v in base.items()}
+        loss, per_view, color, radii, depth, alpha = R.rasterize_l1_loss_batched(d["means3D"], None, None, d["rgb"], d["opacity"], None, None, d["cov3D"], st,
+                                                                                 target, mask, 0.37)
+        other = (color * color).sum() * 0.01
+        out = {}
+        for which in order:
+            for k in d:
+                d[k].grad = None
+            (loss if which == "loss" else other).backward(retain_graph=True)
+            out[which] = [d[k].grad.clone() for k in names]
+        torch.cuda.synchronize()
+        return out
+
+    a = run(("loss", "color"))
+    b = run(("color", "loss"))
+    c = run(("color", "loss", "color", "loss"))
+    assert float(a["loss"][0].abs().max()) > 0.0 and float(a["color"][0].abs().max()) > 0.0
+    for which in ("loss", "color"):
+        for x, y, z in zip(a[which], b[which], c[which]):
+            assert torch.equal(x, y), (which, float((x - y).abs().max()))
+            assert torch.equal(x, z), (which, float((x - z).abs().max()))
+    R.check_pending_overflows(True)
+
+
 @pytest.mark.parametrize("flavour,cap", [("sh+scales", 300000), ("colors+cov", 0), ("sh+scales", 0)])
 def test_fused_single_view_step_other_input_flavours_and_exact_mode(flavour, cap):
     """The fused single-view step is decided below the C ABI (sgr_rasterize_forward_l1 with SgrL1Epilogue.fuse_backward), for every input
