@@ -48,8 +48,8 @@ struct DupExtra {
     uint64_t *num_rendered;             // [2] device counter + overflow flag (self-scan mode)
     uint64_t *nr_host;                  // optional pinned host copy of the same
     unsigned long long capacity;
-    uint32_t *zero_ptr[3];              // optional buffers to clear on the side: tile ranges, backward flags, a caller buffer
-    uint32_t zero_words[3];
+    uint32_t *zero_ptr[4];              // optional buffers to clear on the side: tile ranges, backward flags, a caller buffer, bucket descriptors
+    uint32_t zero_words[4];
     uint32_t *zero_small; uint32_t zero_small_n;      // optional few words (<= 256) to clear: the tile-sort worklist counter(s)
     uint32_t *run_rows;                 // RUNS: [workgroups][kRunRow] the run matrix (above)
     uint32_t *run_base;                 // RUNS: [workgroups] first position of the workgroup's run
@@ -82,7 +82,7 @@ __global__ __launch_bounds__(NT) void duplicate_keys_kernel(int P, int Tx, int t
     const int view = blockIdx.y;
     // piggy-backed clear of small buffers the later kernels expect zeroed: replaces memset launches
 #pragma unroll
-    for (int c = 0; c < 3; c++)
+    for (int c = 0; c < 4; c++)
         for (uint32_t z = (blockIdx.y * gridDim.x + blockIdx.x) * NT + threadIdx.x; z < ex.zero_words[c]; z += gridDim.x * gridDim.y * NT)
             ex.zero_ptr[c][z] = 0u;
     if (ex.zero_small && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < ex.zero_small_n) ex.zero_small[threadIdx.x] = 0u;
@@ -783,13 +783,18 @@ struct TileWork4 { TileWork w[6]; };        // [m], m = 0..4: tiles with <= 1024
 template <int NW>
 __global__ __launch_bounds__(64 * NW) void tile_sort_regs_kernel(const uint2 *__restrict__ ranges, uint64_t *__restrict__ src_comp,
                                                                  uint32_t *__restrict__ src_scratch, uint64_t *__restrict__ dst_keys,
-                                                                 uint32_t *__restrict__ dst_vals, TileWork4 tw, int m_hi, int m_lo, int keep_keys) {
+                                                                 uint32_t *__restrict__ dst_vals, TileWork4 tw, int m_hi, int m_lo, int keep_keys,
+                                                                 uint32_t *__restrict__ prep_order, uint32_t prep_tiles) {
     // keep_keys == 0: only the point list is stored (the sorted keys have no reader behind the per-tile sort: the ranges come from the
     // tile pass); the global-memory fallback for oversize tiles writes both regardless
     __shared__ uint64_t xbuf[NW * 64 * 17];                                      // per wave 64 x (16 + 1) composites: exchange + final re-deal
     __shared__ uint32_t s_item, s_next;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint32_t nsort = gridDim.x;                                            // workgroups that sort
+    uint32_t nsort = gridDim.x;                                                  // workgroups that sort
+    if (prep_order) {                                                            // the spare last workgroup orders the tiles for the segment-parallel forward
+        nsort = gridDim.x - 1;
+        if (blockIdx.x == nsort) { sgr_fwd_prepare(ranges, prep_tiles, nullptr, 0, prep_order, (uint32_t *)xbuf); return; }
+    }
     // all class sizes up front (independent loads: one memory latency instead of one per class on the single-view critical path)
     uint32_t cnt[6];
 #pragma unroll
@@ -1645,8 +1650,9 @@ extern "C" size_t sgr_bin_workspace_bytes(uint64_t R, uint64_t tiles_total) {
 // counts; num_rendered_dev is then WRITTEN by the duplicate kernel (capacity mode only).  nr_host: optional pinned host slot.
 // fwd_order (optional, the segment-parallel forward's work order, SGR_ORDER_HDR_WORDS + 33 * tiles_total * 4 words): filled by the single-view
 // path in its class-major form (*order_kind_out = 1; the workgroups of empty tiles then also write those tiles' background, `bg`); every other
-// flavour leaves it alone (*order_kind_out = 0).  clear_ptr / clear_words / clear_done [3]: buffers to zero on the side of the emission kernel
-// ([2] only by the single-view path).
+// flavour with a per-tile register sort launch (view-segmented) fills it in the plain form -- one uint4 per slot, longest lists first, empty tiles
+// last -- by that launch's spare workgroup (*order_kind_out = 2); else *order_kind_out = 0.  clear_ptr / clear_words / clear_done [3]: buffers
+// to zero on the side of the emission kernel.
 int sgr_bin_ex(const SgrProblem *pb, const int32_t *radii, uint32_t *rect,
                const uint32_t *block_offsets, uint64_t R, const uint64_t *num_rendered_dev, uint64_t *keys_a,
                uint64_t *keys_b, uint32_t *vals_a, uint32_t *vals_b, void *workspace, size_t workspace_bytes,
@@ -1710,14 +1716,10 @@ int sgr_bin_ex(const SgrProblem *pb, const int32_t *radii, uint32_t *rect,
     ex.self_sums = self_scan ? block_offsets + (nblk + 1) : nullptr;
     ex.num_rendered = const_cast<uint64_t *>(num_rendered_dev); ex.nr_host = self_scan ? nr_host : nullptr; ex.capacity = R;
     ex.zero_ptr[0] = fold_clear ? ranges : nullptr; ex.zero_words[0] = fold_clear ? (uint32_t)(tiles_total * 2) : 0u;
-    for (int c = 0; c < 2; c++) {
+    for (int c = 0; c < 3; c++) {
         const bool ok = clear_ptr && clear_ptr[c] && clear_words && clear_words[c] <= (1ull << 26);
         ex.zero_ptr[1 + c] = ok ? clear_ptr[c] : nullptr; ex.zero_words[1 + c] = ok ? (uint32_t)clear_words[c] : 0u;
         if (clear_done) clear_done[c] = ok ? 1 : 0;
-    }
-    if (runs && clear_ptr && clear_ptr[2] && clear_words[2] <= (1ull << 26)) {       // (slot 0 is free on this path)
-        ex.zero_ptr[0] = clear_ptr[2]; ex.zero_words[0] = (uint32_t)clear_words[2];
-        if (clear_done) clear_done[2] = 1;
     }
     ex.zero_small = (runs && fwd_order) ? fwd_order : nullptr; ex.zero_small_n = 48u;       // the work order's class counters
     if (self_scan && !num_rendered_dev) { sgr_set_error("sgr_bin: self-scan needs the device counter"); return 1; }
@@ -1786,9 +1788,10 @@ int sgr_bin_ex(const SgrProblem *pb, const int32_t *radii, uint32_t *rect,
         for (int c = 0; c < 6; c++) tw4.w[c] = work(c);
         // (deep mode with every tile on the deep lists: only the tiles those kernels declined -- massive depth ties -- are left: a small grid,
         // it usually just exits)
-        hipLaunchKernelGGL(tile_sort_regs_kernel<16>, dim3(deep_min == 0u ? std::min(grid(1), 64u) : grid(1)), dim3(1024), 0, stream, rg, kout, vout, kin, vin, tw4, 4, 0,
-                           sorted_keys ? 1 : 0);
+        hipLaunchKernelGGL(tile_sort_regs_kernel<16>, dim3((deep_min == 0u ? std::min(grid(1), 64u) : grid(1)) + (fwd_order ? 1u : 0u)), dim3(1024), 0, stream, rg, kout, vout,
+                           kin, vin, tw4, 4, 0, sorted_keys ? 1 : 0, fwd_order, (uint32_t)tiles_total);
         SGR_CHECK_LAUNCH("tile_sort_regs_kernel");
+        if (fwd_order && order_kind_out) *order_kind_out = 2;
         }
         }
         if (result_in_b_host) *result_in_b_host = (kin == keys_b) ? 1 : 0;

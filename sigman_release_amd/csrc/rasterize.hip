@@ -60,7 +60,7 @@ static int forward_launches(const SgrProblem *pb, uint64_t capacity, uint64_t R,
     // small sync-free launches: the block-sum scan (F2), the clear of the tile ranges and the copy of the instance count to the
     // caller's pinned slot are folded into the duplicate kernel (three launches fewer)
     const uint64_t nblk = (uint64_t)sgr_preprocess_blocks_per_view(pb->P) * pb->n_views;
-    const bool self_scan = !preprocess_done && capacity > 0 && nblk <= 2048;
+    const bool self_scan = !preprocess_done && capacity > 0 && nblk <= 4096;
     // the fused step, sync-free mode (preprocess has not run yet): every tile is pre-filled with the background, its loss shares and dL/dcolor by
     // extra workgroups of the preprocess launch (common.h SgrBgJob); the compositing kernel's empty tiles then have nothing to do (bg_done)
     SgrBgJob bgj;
@@ -95,7 +95,7 @@ static int forward_launches(const SgrProblem *pb, uint64_t capacity, uint64_t R,
     // buffers the later stages expect zeroed are cleared on the side by the duplicate kernel: the backward's flags (a fused step's own backward
     // has its own: off_flags_fused), an optional caller buffer (the fused loss node's accumulators), the bucket descriptors
     uint32_t *const own_flags = !aux_on ? nullptr : (uint32_t *)(image + (st->fused_bwd ? st->off_flags_fused : st->off_flags));
-    uint32_t *clear_ptr[3] = {own_flags, (uint32_t *)caller_clear, (want_prep && aux_on) ? (uint32_t *)(image + st->off_desc) : nullptr};
+    uint32_t *clear_ptr[3] = {own_flags, (uint32_t *)caller_clear, aux_on ? (uint32_t *)(image + st->off_desc) : nullptr};
     const uint64_t clear_words[3] = {aux_on ? (R + 0) : 0, (caller_clear_bytes + 3) / 4, (uint64_t)n_desc * 2};
     int clear_done[3] = {0, 0, 0};
     // the empty tiles' outputs, unless the preprocess launch pre-filled every tile (fused step): written by the empty tiles' own workgroups of
@@ -117,8 +117,8 @@ static int forward_launches(const SgrProblem *pb, uint64_t capacity, uint64_t R,
                    (uint32_t *)(image + st->off_ranges), &in_b, self_scan, self_scan ? nr_pinned_host : nullptr,
                    want_prep ? (uint32_t *)(image + st->off_order) : nullptr, &order_kind, bg_done ? nullptr : &bgs, occ_zeroed,
                    clear_ptr, clear_words, clear_done, /*first_index=*/aux_on, /*sorted_keys=*/g_keep_sorted_keys != 0, stream)) return 1;
-    // (the single-view path cleared the descriptors with its order; without the clear the order is not used either: render.hip prepares itself)
-    st->order_kind = (order_kind == 1 && (clear_done[2] || !(want_prep && aux_on))) ? 1 : 0;
+    st->order_kind = order_kind == 1 ? 1 : 0;                        // (the form of the order: what a later depth/alpha checkpoint pass must know)
+    const int prepared = (order_kind == 1 ? 2 : (order_kind == 2 ? 1 : 0)) | (clear_done[2] ? 4 : 0);
     st->flags_cleared = st->fused_bwd ? 0 : clear_done[0];          // (of off_flags: what an ordinary backward writes)
     int fused_flags_cleared = st->fused_bwd ? clear_done[0] : 0;
     if (caller_clear && caller_clear_bytes && !clear_done[1]) SGR_CHECK_HIP(hipMemsetAsync(caller_clear, 0, (size_t)caller_clear_bytes, stream));
@@ -139,7 +139,7 @@ static int forward_launches(const SgrProblem *pb, uint64_t capacity, uint64_t R,
                               (float *)(image + st->off_final_T), (uint32_t *)(image + st->off_n_contrib), R,
                               aux_on ? image + st->off_compact : nullptr, aux_on ? image + st->off_ckpt_tc : nullptr,
                               (aux_on && !st->aux_no_da) ? image + st->off_ckpt_da : nullptr, aux_on ? image + st->off_desc : nullptr,
-                              (uint32_t *)(image + st->off_order), st->order_kind ? 2 : 0, st->fwd_kind, st->fused_bwd ? &fa : nullptr, bg_done != 0, stream);
+                              (uint32_t *)(image + st->off_order), prepared, st->fwd_kind, st->fused_bwd ? &fa : nullptr, bg_done != 0, stream);
     if (rc || !st->fused_bwd) return rc;
     // fused step: the compositing kernel left the loss shares and dL/dcolor; the bucket backward of dL/dloss = 1 follows at once
     // (its spare workgroup sums the loss shares), so that the caller's backward only gathers
@@ -339,7 +339,7 @@ extern "C" int sgr_rasterize_backward(const SgrProblem *pb, const SgrForwardStat
         const uint32_t *point_list = (const uint32_t *)(binning + (st->result_in_b ? st->off_vals_b : st->off_vals_a));
         if (sgr_render_forward_ex(pb, (const uint32_t *)(image + st->off_ranges), point_list, rec, (float *)out_color, (float *)out_depth, (float *)out_alpha,
                                   (float *)(im + st->off_final_T), (uint32_t *)(im + st->off_n_contrib), st->R_alloc, im + st->off_compact, nullptr, da,
-                                  im + st->off_desc, (uint32_t *)(im + st->off_order), /*prepared=*/st->order_kind ? 2 : 1, st->fwd_kind, nullptr, false, stream_)) return 1;
+                                  im + st->off_desc, (uint32_t *)(im + st->off_order), /*prepared=*/(st->order_kind ? 2 : 1) | 4, st->fwd_kind, nullptr, false, stream_)) return 1;
         ckpt_da = da;
     }
     if (sgr_render_backward_ex(pb, (const uint32_t *)(image + st->off_ranges), rec, rect, (const uint32_t *)(image + st->off_n_contrib),

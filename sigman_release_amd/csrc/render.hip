@@ -1037,14 +1037,14 @@ int sgr_render_forward_wants_prepare(const SgrProblem *pb, uint64_t R, bool use_
     const uint64_t tiles_total = (uint64_t)((pb->W + SGR_TILE - 1) / SGR_TILE) * ((pb->H + SGR_TILE - 1) / SGR_TILE) * pb->n_views;
     const size_t n_desc = use_aux ? (size_t)4 * sgr_bucket_slots(R, tiles_total) : 0;
     if (n_desc_out) *n_desc_out = n_desc;
-    return fwd_is_seg(tiles_total) && n_desc <= (1u << 17) ? 1 : 0;
+    return fwd_is_seg(tiles_total) ? 1 : 0;
 }
 
 int sgr_render_forward_ex(const SgrProblem *pb, const uint32_t *ranges, const uint32_t *point_list, const float *rec,
                           float *out_color, float *out_depth, float *out_alpha, float *final_T, uint32_t *n_contrib,
                           uint64_t R, void *aux_compact, void *aux_ckpt_tc, void *aux_ckpt_da, void *aux_desc,
-                          uint32_t *aux_order, int prepared /* 0: no; 1: the order (old form) and the descriptor clear are done; 2: the same with the
-                          class-major order of the single-view path (the empty tiles' outputs are written, too) */, int kind /* 0: choose (sgr_render_forward_kind); else the compositing kernel to
+                          uint32_t *aux_order, int prepared /* bits: 1 the work order is there (plain form), 2 it is there in the single-view path's
+                          class-major form (the empty tiles' outputs are written, too), 4 the bucket descriptors are cleared */, int kind /* 0: choose (sgr_render_forward_kind); else the compositing kernel to
                           use: the depth/alpha checkpoint pass must repeat its forward's */, const SgrFusedL1Args *fused /* NULL, or: the
                           single-view fused step -- loss shares and dL/dcolor written by the segment-parallel kernel */,
                           bool bg_done /* the empty tiles' outputs (and loss shares) are already written: SgrBgJob */, void *stream_) {
@@ -1062,14 +1062,18 @@ int sgr_render_forward_ex(const SgrProblem *pb, const uint32_t *ranges, const ui
     // few workgroups (one or two 512^2 views): trade 1.5x arithmetic for an 8x shorter dependency chain
     const bool seg = kind == 2;
     const size_t n_desc = use_aux ? (size_t)4 * aux.NS : 0;
-    const bool prep = seg && (aux_order || (use_aux && n_desc <= (1u << 17)));     // one workgroup orders the tiles and clears the descriptors
+    // prepared: bit 0 = the work order is there in the plain form, bit 1 = in the class-major form (the empty tiles' outputs are written, too),
+    // bit 2 = the bucket descriptors are cleared
+    const bool order_done = (prepared & 3) != 0, desc_done = (prepared & 4) != 0;
+    const bool prep = seg && !order_done && (aux_order || (use_aux && !desc_done && n_desc <= (1u << 17)));     // one workgroup orders the tiles (and clears the descriptors)
+    const bool prep_desc = prep && use_aux && !desc_done && n_desc <= (1u << 17);
     if (da_pass && !prepared) { sgr_set_error("sgr_render_forward: the depth/alpha checkpoint pass must run on a prepared forward"); return 1; }
     if (fused && !(seg && use_aux && aux_ckpt_tc && !aux_ckpt_da)) { sgr_set_error("sgr_render_forward: the fused step needs the segment-parallel kernel with row checkpoints and no depth/alpha checkpoints"); return 1; }
-    if (use_aux && !(prep && n_desc <= (1u << 17)) && !prepared) SGR_CHECK_HIP(hipMemsetAsync(aux_desc, 0, n_desc * sizeof(uint2), stream));
+    if (use_aux && !desc_done && !prep_desc && !da_pass) SGR_CHECK_HIP(hipMemsetAsync(aux_desc, 0, n_desc * sizeof(uint2), stream));
     SgrProfScope _p(SGR_K_RENDER_FWD, stream);
-    if (prep && !prepared) {                                    // (prepared: the tile-sort launch's spare workgroup already did it)
+    if (prep) {
         hipLaunchKernelGGL(fwd_prepare_kernel, dim3(1), dim3(1024), 0, stream, (const uint2 *)ranges, (uint32_t)tiles_total,
-                           (use_aux && n_desc <= (1u << 17)) ? (uint2 *)aux_desc : (uint2 *)nullptr, n_desc, aux_order);
+                           prep_desc ? (uint2 *)aux_desc : (uint2 *)nullptr, n_desc, aux_order);
         SGR_CHECK_LAUNCH("fwd_prepare_kernel");
     }
     if (seg) {
@@ -1077,7 +1081,7 @@ int sgr_render_forward_ex(const SgrProblem *pb, const uint32_t *ranges, const ui
 #define SGR_LAUNCH_SEG(A)                                                                                                   \
         hipLaunchKernelGGL(render_fwd_seg_kernel<A>, dim3(seg_grid), dim3(kSegThreads), 0, stream, pb->W, pb->H, Tx, tiles,        \
                            (const uint2 *)ranges, point_list, (const float4 *)rec, pb->bg, out_color, out_depth, out_alpha, final_T,  \
-                           n_contrib, aux, (const uint32_t *)aux_order, (uint32_t)tiles_total, fz, (bg_done || prepared == 2) ? 1 : 0, prepared == 2 ? 1 : 0)
+                           n_contrib, aux, (const uint32_t *)aux_order, (uint32_t)tiles_total, fz, (bg_done || (prepared & 2)) ? 1 : 0, (prepared & 2) ? 1 : 0)
         FusedL1 fz;
         memset(&fz, 0, sizeof(fz));
         if (fused) {

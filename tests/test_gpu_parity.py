@@ -637,8 +637,8 @@ def _check_against_observed(name, stats):
     ulp, so out of ~1e7..1e9 pixel-Gaussian visits a handful land on the other side of the published `alpha < 1/255 -> skip` /
     `T < 1e-4 -> stop` decisions; such a flip moves a pixel by at most alpha*T <= 1/255 and the gradient of the Gaussians involved.
     The number and size of these excursions is DETERMINISTIC for a given build, so it is recorded (tests/golden/full_size_observed.json,
-    written from a GPU run by tools/record_full_size_observed.py) and a run may exceed the record by at most 2x (count: max(2n, 4);
-    size: 2x) -- a regression that doubles the decision flips fails.  `stats`: {key: (n_beyond_tolerance, max_error)}."""
+    written from a GPU run by tools/record_full_size_observed.py) and a run may not exceed the recorded COUNT at all (the record against the
+    reproducible-form oracle is zero everywhere since round 5) nor twice the recorded size (floor 1e-5).  `stats`: {key: (n_beyond_tolerance, max_error)}."""
     import json
     print("FULL_SIZE_OBSERVED " + json.dumps({name: {k: [int(v[0]), float(v[1])] for k, v in stats.items()}}))
     out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
@@ -663,8 +663,8 @@ def _check_against_observed(name, stats):
                  "SIGMAN_RECORD_OBSERVED=1, then tools/record_full_size_observed.py)")
     for k, (n, mx) in stats.items():
         n0, mx0 = rec[k]
-        assert n <= max(2 * n0, 4), f"{name}/{k}: {n} values beyond tolerance, recorded {n0}"
-        assert mx <= max(2.0 * mx0, 1.2e-4), f"{name}/{k}: max error {mx:.3e}, recorded {mx0:.3e}"
+        assert n <= n0, f"{name}/{k}: {n} values beyond tolerance, recorded {n0}"
+        assert mx <= max(2.0 * mx0, 1e-5), f"{name}/{k}: max error {mx:.3e}, recorded {mx0:.3e}"
 
 
 def _parity_stats(color, depth, alpha, grads, ref, gref):
@@ -679,7 +679,7 @@ def _parity_stats(color, depth, alpha, grads, ref, gref):
     return st
 
 
-def _full_size_check(oracle, inp, st, with_depth_alpha_grads, name):
+def _full_size_check(oracle, inp, st, with_depth_alpha_grads, name, published=False):
     from sigman_release_amd import rasterizer as R
     dev = _dev()
     H, W = st["image_height"], st["image_width"]
@@ -709,10 +709,37 @@ def _full_size_check(oracle, inp, st, with_depth_alpha_grads, name):
                           {"means3D": (d["means3D"].grad[0].cpu().numpy(), g["means3D"]), "opacities": (d["opacities"].grad[0].cpu().numpy(), g["opacities"][:, 0]),
                            "colors": (d["colors_precomp"].grad[0].cpu().numpy(), g["colors_precomp"]),
                            "cov3D": (d["cov3D_precomp"].grad[0].cpu().numpy(), g["cov3D_precomp"])}, ref, g)
-    # hard ceilings (what ONE decision flip can do), then the recorded counts
-    assert stats["color"][1] <= 1.0 / 255.0 + IMG_TOL and stats["depth"][1] <= 4.0 / 255.0 + IMG_TOL and stats["alpha"][1] <= 1.0 / 255.0 + IMG_TOL, stats
-    assert all(v[1] <= 2e-2 for k, v in stats.items() if k.startswith("grad_")), stats
+    # hard ceilings (they hold in a recording run as well), then the recorded counts
+    assert stats["color"][1] <= 3e-4 and stats["depth"][1] <= 3e-4 and stats["alpha"][1] <= 3e-4, stats
+    assert all(v[1] <= 1e-3 for k, v in stats.items() if k.startswith("grad_")), stats
     _check_against_observed(name, stats)
+    if published:
+        # ---- an arithmetic-INDEPENDENT comparison: the oracle's published form (alpha mode 1: the exponent as the published expression, left to
+        # right, libm expf -- no shared FMA chain, no shared exp2 polynomial, the alpha test evaluated directly).  Integer artefacts identical;
+        # what may differ is a threshold decision (an alpha within a few ulp of 1/255, a T within rounding of 1e-4): each flip is counted --
+        # `n_contrib` changes for the pixel -- and moves the pixel by less than one alpha step.  The counts are recorded like the others.
+        try:
+            oracle.set_alpha_mode(1)
+            ref1 = oracle.forward(**inp, **cases.single_view(st))
+            g1 = oracle.backward(ref1, gC, gD if with_depth_alpha_grads else None, gA if with_depth_alpha_grads else None)
+        finally:
+            oracle.set_alpha_mode(0)
+        np.testing.assert_array_equal(radii[0].cpu().numpy(), ref1.radii)
+        np.testing.assert_array_equal(ref.keys, ref1.keys)
+        np.testing.assert_array_equal(ref.ranges, ref1.ranges)
+        flips = int((ref.n_contrib != ref1.n_contrib).sum())       # (the HIP path's n_contrib == the reproducible form's: asserted in the forward-artefact tests)
+        st1 = _parity_stats(c, depth[0].detach().cpu().numpy(), alpha[0].detach().cpu().numpy(),
+                            {"means3D": (d["means3D"].grad[0].cpu().numpy(), g1["means3D"]), "opacities": (d["opacities"].grad[0].cpu().numpy(), g1["opacities"][:, 0]),
+                             "colors": (d["colors_precomp"].grad[0].cpu().numpy(), g1["colors_precomp"]),
+                             "cov3D": (d["cov3D_precomp"].grad[0].cpu().numpy(), g1["cov3D_precomp"])}, ref1, g1)
+        n_px = int(((np.abs(c - ref1.color) > IMG_TOL).any(0) | (np.abs(depth[0, 0].detach().cpu().numpy() - ref1.depth.reshape(H, W)) > IMG_TOL)
+                    | (np.abs(alpha[0, 0].detach().cpu().numpy() - ref1.alpha.reshape(H, W)) > IMG_TOL)).sum())
+        assert n_px <= flips and flips <= 8, (n_px, flips)                 # every pixel off is a counted decision flip; a handful per million pixels
+        assert max(st1[k][1] for k in ("color", "alpha")) < 1.0 / 255.0 + IMG_TOL and st1["depth"][1] < 4.0 / 255.0 + IMG_TOL, st1
+        if flips == 0:
+            assert all(v[0] == 0 for v in st1.values()), st1
+        st1["decision_flips"] = (flips, float(n_px))
+        _check_against_observed(name + "_published", st1)
     return ref
 
 
@@ -721,6 +748,22 @@ def test_full_size_c2_100k_512(oracle):
     inp, st = cases.humanoid(P=100_000, H=512, W=512, seed=1)
     ref = _full_size_check(oracle, inp, st, with_depth_alpha_grads=False, name="c2")
     assert ref.R > 150_000
+
+
+@pytest.mark.parametrize("cfg", ["c2", "c5"])
+def test_full_size_against_published_order_oracle(cfg, oracle):
+    """BASELINE configs[1] and [4] at full size against the oracle's PUBLISHED arithmetic (alpha mode 1: the published expression + libm expf,
+    sharing no arithmetic with the kernels' FMA chain / exp2 polynomial / threshold p*): integer artefacts identical, every pixel beyond
+    1e-4 is a counted threshold-decision flip (expected: a handful per million pixels, each below one alpha step), gradients follow.  The
+    counts are recorded in tests/golden/full_size_observed.json (`c2_published`, `c5_published`)."""
+    if cfg == "c2":
+        inp, st = cases.humanoid(P=100_000, H=512, W=512, seed=1)
+    else:
+        from sigman_release_amd import synthetic
+        g = synthetic.humanoid_layers(1_000_000, 4, layers=10)
+        inp = dict(means3D=g["position"], opacities=g["opacity"].reshape(-1), colors_precomp=g["rgb"], cov3D_precomp=synthetic.covariance_from_gaussians(g))
+        _, st = cases.humanoid(P=10, H=512, W=512, seed=1)
+    _full_size_check(oracle, inp, st, with_depth_alpha_grads=(cfg == "c5"), name=cfg, published=True)
 
 
 def test_full_size_c2_headline_step_against_the_oracle(oracle):
@@ -885,7 +928,7 @@ def test_full_size_c3_batch_8x8_views_512(oracle):
         e = np.abs(color[i].detach().cpu().numpy() - r.color)
         n_bad += int((e > IMG_TOL).sum())
         e_max = max(e_max, float(e.max()))
-        assert np.abs(alpha[i].detach().cpu().numpy() - r.alpha).max() <= 1.0 / 255.0 + IMG_TOL
+        assert np.abs(alpha[i].detach().cpu().numpy() - r.alpha).max() <= 3e-4
         if s_ == 2:
             gr = oracle.backward(r, gC[i].cpu().numpy())
             acc = gr if acc is None else {k: acc[k] + gr[k] for k in acc}
@@ -894,7 +937,7 @@ def test_full_size_c3_batch_8x8_views_512(oracle):
                           ("cov3D", cov.grad[2], acc["cov3D_precomp"])):
         e = np.abs(got.cpu().numpy().reshape(want.shape) - want) / max(np.abs(want).max(), 1e-20)
         stats["grad_" + nm] = (int((e > GRAD_TOL).sum()), float(e.max()))
-    assert stats["color"][1] <= 1.0 / 255.0 + IMG_TOL and all(v[1] <= 2e-2 for k, v in stats.items() if k.startswith("grad_")), stats
+    assert stats["color"][1] <= 3e-4 and all(v[1] <= 1e-3 for k, v in stats.items() if k.startswith("grad_")), stats
     _check_against_observed("c3", stats)
     # ---- batch == single-view renders, linearity
     for s_, v in ((0, 0), (3, 5), (7, 7)):
@@ -978,7 +1021,7 @@ def test_full_size_c4_200k_90_views_1024_forward(oracle):
                 n_bad[k] += int((e > IMG_TOL).sum()); e_max[k] = max(e_max[k], float(e.max()))
             assert float((d["n_contrib"][i].cpu().numpy().astype(np.uint32) != ref.n_contrib).mean()) <= 1e-3
         for k in n_bad:
-            assert e_max[k] <= 5e-3, f"c4 {k}: max abs error {e_max[k]:.3e}"             # hard ceiling: a decision flip moves a pixel by <= 1/255
+            assert e_max[k] <= 3e-4, f"c4 {k}: max abs error {e_max[k]:.3e}"             # hard ceiling (the record: 0 values beyond 1e-4)
         _check_against_observed("c4", {k: (n_bad[k], e_max[k]) for k in n_bad})
 
 
