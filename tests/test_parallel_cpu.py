@@ -201,3 +201,92 @@ def test_pipelined_subject_exchange_matches_blocking_and_single_process():
     np.testing.assert_array_equal(res[0][1], res[1][1])
     for c in range(S):
         np.testing.assert_array_equal(res[0][2][c], res[1][2][c])              # all-reduced: identical on both ranks
+
+
+# ---- the world size north_star names: 8 ranks (gloo, this box's CPU cores), a cheap analytic "renderer" with the renderer's interface
+_V8 = [30, 37, 45, 53, 65, 85, 0, 8]            # C3: the rig's 8 training views, one per rank
+
+
+def _toy8(views_all, chunk=0):
+    def render_loss(m, c, o, r, my_views):
+        total = m.sum() * 0.0
+        for v in my_views:
+            w = 1.0 + 0.01 * v + 0.1 * chunk
+            total = total + (torch.sin(m * w).sum() + (c * c).sum() * w + (o * r.sum(1, keepdim=True)).sum() * (w - 0.5)) / (len(views_all) * m.shape[0])
+        return total
+    return render_loss
+
+
+def _world8_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    P = 40
+    gen = torch.Generator().manual_seed(23)
+    packed_true = torch.randn(13 * P, generator=gen)
+    # (1) C3's shape: 8 views <-> 8 ranks, one view each.  "loss": replicated attributes, the loss all-reduce only, partial gradients;
+    #     "full": broadcast from the producer, packed-gradient all-reduce
+    assert parallel.shard_views(len(_V8), rank, world) == [rank]
+    loss_l, grad_l = parallel.view_parallel_step(packed_true.clone(), _V8, _toy8(_V8), exchange="loss")
+    gsum = grad_l.clone()
+    dist.all_reduce(gsum)
+    packed = packed_true.clone() if rank == 3 else torch.zeros_like(packed_true)          # (producer: rank 3)
+    loss_f, grad_f = parallel.view_parallel_step(packed, _V8, _toy8(_V8), src=3)
+    assert torch.equal(packed, packed_true)
+    # (2) C4's shape: 90 views -> 11-12 per rank, forward only, one padded all-gather in view order
+    mine = parallel.shard_views(90, rank, world)
+    assert len(mine) == (12 if rank < 2 else 11) and mine[0] == rank
+    local = torch.stack([torch.full((3, 2, 3), float(v)) + torch.arange(3.0).reshape(3, 1, 1) for v in mine])
+    allv = parallel.all_gather_images(local, 90)
+    assert allv.shape == (90, 3, 2, 3)
+    assert all(torch.equal(allv[v], torch.full((3, 2, 3), float(v)) + torch.arange(3.0).reshape(3, 1, 1)) for v in range(90))
+    # (3) 8 subjects as 8 pipelined chunks with alternating producers: pipelined == blocking, bit for bit
+    S = 8
+    truth = [torch.randn(13 * P, generator=gen) for _ in range(S)]
+    srcs = [c % world for c in range(S)]
+    fns = [_toy8(_V8, c) for c in range(S)]
+    out = {}
+    for pipeline in (False, True):
+        chunks = [t.clone() if rank == srcs[c] else torch.zeros_like(t) for c, t in enumerate(truth)]
+        losses, grads = parallel.view_parallel_subjects(chunks, _V8, fns, srcs=srcs, pipeline=pipeline)
+        out[pipeline] = (losses.clone(), [g.clone() for g in grads])
+        assert all(torch.equal(a, t) for a, t in zip(chunks, truth))
+    assert torch.equal(out[True][0], out[False][0]) and all(torch.equal(a, b) for a, b in zip(out[True][1], out[False][1]))
+    q.put((rank, float(loss_l), gsum.numpy(), float(grad_l.abs().sum()), float(loss_f), grad_f.numpy(), out[True][0].numpy(), [g.numpy() for g in out[True][1]]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_eight_ranks_c3_c4_shapes_and_pipelined_chunks():
+    """World size 8 (the node north_star names), gloo on the CPU: C3's 8 views sharded one per rank -- loss all-reduce with partial gradients
+    that add up to the single-process gradient ("loss"), attribute broadcast from a non-zero producer rank + packed-gradient all-reduce
+    ("full") --; C4's 90 views -> 12, 12, 11, ... per rank through the padded `all_gather_images` (uneven shards) in view order;
+    `view_parallel_subjects` with 8 chunks from 8 different producers, pipelined == blocking bit for bit, == single process."""
+    world, P = 8, 40
+    gen = torch.Generator().manual_seed(23)
+    packed_true = torch.randn(13 * P, generator=gen)
+    loss1, grad1 = parallel.view_parallel_step(packed_true.clone(), _V8, _toy8(_V8))
+    truth = [torch.randn(13 * P, generator=gen) for _ in range(8)]
+    want = parallel.view_parallel_subjects([t.clone() for t in truth], _V8, [_toy8(_V8, c) for c in range(8)])
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_world8_worker, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in procs]
+    res = [q.get(timeout=300) for _ in range(world)]
+    [p.join(timeout=60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    g1 = grad1.numpy()
+    norms = []
+    for rank, loss_l, gsum, pnorm, loss_f, grad_f, sub_losses, sub_grads in sorted(res, key=lambda x: x[0]):
+        assert abs(loss_l - float(loss1)) <= 1e-5 * max(1.0, abs(float(loss1))) and abs(loss_f - float(loss1)) <= 1e-5 * max(1.0, abs(float(loss1)))
+        np.testing.assert_allclose(gsum, g1, atol=2e-6 * np.abs(g1).max())              # the 8 partial gradients add up to the global one
+        np.testing.assert_allclose(grad_f, g1, atol=2e-6 * np.abs(g1).max())
+        np.testing.assert_allclose(sub_losses, want[0].numpy(), rtol=1e-5)
+        for c in range(8):
+            np.testing.assert_allclose(sub_grads[c], want[1][c].numpy(), atol=2e-6 * np.abs(want[1][c].numpy()).max())
+        norms.append(pnorm)
+    assert all(n > 0 for n in norms) and len(set(round(n, 6) for n in norms)) == 8       # eight different, really partial gradients
+    for r in res[1:]:
+        np.testing.assert_array_equal(r[5], res[0][5])                                 # all-reduced gradients: identical on every rank
