@@ -81,6 +81,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-sclk", action="store_true", help="do not sample the shader clock (a side process reads an amdgpu sysfs node every 10 ms while the repeat windows run)")
     ap.add_argument("--windows", type=int, default=8, help="untimed-for-the-headline repeat windows of the same K steps behind the timed region (spread report)")
     ap.add_argument("--no-variants", action="store_true", help="skip the unpinned / exact-sync / per-view-loop re-runs (N=1, c2/c3)")
+    ap.add_argument("--order", choices=("random", "template"), default="random",
+                    help="order of a subject's Gaussians in memory: 'random' (headline: a random permutation, the pessimistic case for every gather) or "
+                         "'template' (spatially coherent, as the faces of the reference's template mesh: a VARIANT, never the headline)")
     ap.add_argument("--exact-sync", action="store_true", help="read num_rendered back every step (upstream behaviour) instead of the sync-free capacity mode")
     return ap.parse_args(argv)
 
@@ -215,11 +218,11 @@ def algorithmic_bytes(kid: int, P: int, Rn: int, HW: int, tiles: int, masked: bo
                   6: 88 * Rn + 28 * HW, 7: 108 * P, 10: (40 if masked else 36) * HW}[kid])
 
 
-def build_subject(cfg_name: str, P: int, seed: int, dev):
+def build_subject(cfg_name: str, P: int, seed: int, dev, order: str = "random"):
     if cfg_name == "c1":
         g = synthetic.random_cloud(P, seed)             # world_scale: isotropic, log-uniform in [5e-3, 5e-2]
     else:
-        g = synthetic.humanoid_layers(P, seed, layers=10) if cfg_name == "c5" else synthetic.humanoid(P, seed)
+        g = synthetic.humanoid_layers(P, seed, layers=10) if cfg_name == "c5" else synthetic.humanoid(P, seed, order=order)
     if cfg_name == "c4":
         g["position"] = np.clip(g["position"], -1.0, 1.0)      # decode-path positions are clamped to [-1,1]^3
     cov = synthetic.covariance_from_gaussians(g)       # host stand-in for distCUDA2 + get_covariance (gs.py:70-73), untimed
@@ -330,7 +333,7 @@ def main(args):
     n_total_views = S * len(all_views)
     n_local = S * len(mine)
     seeds = {"c1": [0], "c2": [1], "c3": [100 + b for b in range(S)], "c4": [3], "c5": [4]}[args.config]
-    subs = [build_subject(args.config, P, s, dev) for s in seeds]
+    subs = [build_subject(args.config, P, s, dev, args.order) for s in seeds]
     subj = {k: torch.stack([x[0][k] for x in subs]) for k in ("means3D", "cov3D", "opacity", "rgb")}      # [S,P,...]
     g_host, cov_host = subs[0][1], subs[0][2]
     bg = torch.ones(3, device=dev)
@@ -643,7 +646,9 @@ def main(args):
         "config": {"workload": f"{cfg['label']}, {P} Gaussians/subject, {S} subject(s) x {len(mine)} view(s) on this GPU per step, "
                                f"{H}x{W}, {'fwd+bwd' if bwd else 'forward only'}, colors_precomp+cov3D_precomp"
                                + ((", clamp + masked L1 loss (mask = ground-truth alpha > 0.5)" if gt_mask is not None else ", clamp+L1 loss") if bwd else "") + (", dL/ddepth and dL/dalpha non-zero" if da else ""),
-                   "name": args.config, "views_per_step_total": n_total_views, "view_slots_this_gpu": n_local,
+                   "name": args.config, "gaussian_order": args.order,
+                   "count_wait": (lazy_counts if lazy_counts else "own") + (" (the library default is \"own\": variants.count_wait_own_ms_per_step is the same step timed with it)" if lazy_counts else " (the library default)"),
+                   "views_per_step_total": n_total_views, "view_slots_this_gpu": n_local,
                    "parallelism": (f"view-parallel x{world} ({backend}), exchange={'none (forward only)' if not bwd else args.exchange}" if dist_on else "single GPU"),
                    "fused_step": fused_step, "ranks_seen": world, "num_rendered_per_gpu": Rn, "gaussian_pixel_visits_per_gpu": S_visits,
                    "binning_buffers": "exact (D2H read of num_rendered per step)" if args.exact_sync else (f"pre-sized, max_rendered={st.max_rendered} (sync-free)" if st else "-"),
@@ -803,13 +808,19 @@ def variants(args, subj, st, gt, norm, S, P, H, W, mine, dev, subs):
     out["per_view_loop_ms_per_step"] = round(dt * 1e3, 4)
     out["per_view_loop_views_per_s"] = round(S * V / dt, 1)
     base = [sys.executable, os.path.abspath(__file__), "--config", args.config, "--no-cpu-baseline", "--no-variants"]
-    for key, env, extra in (("unpinned", {"SIGMAN_NO_PIN": "1"}, []), ("exact_sync", {}, ["--exact-sync"])):
+    # count_wait_own: the same step with the LIBRARY DEFAULT count wait ("own": every backward waits for its own forward's instance count, the host
+    # is never more than one step ahead) instead of the headline's set_count_wait("lazy:4"); order_template: the subjects' Gaussians in a
+    # spatially coherent order (--order template) instead of a random permutation
+    for key, env, extra in (("unpinned", {"SIGMAN_NO_PIN": "1"}, []), ("exact_sync", {}, ["--exact-sync"]), ("count_wait_own", {"SIGMAN_COUNT_WAIT": "own"}, []),
+                            ("order_template", {}, ["--order", "template"])):
         try:
             if _ORIG_AFFINITY is not None:
                 os.sched_setaffinity(0, _ORIG_AFFINITY)
             r = subprocess.run(base + extra, capture_output=True, text=True, timeout=600, env={**os.environ, **env})
             line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
             out[f"{key}_ms_per_step"] = json.loads(line)["ms_per_step"]
+            if key == "order_template":
+                out["order_template_kernel_ms_per_step"] = json.loads(line).get("kernel_ms_per_step")
         except Exception as e:      # noqa: BLE001  (a variant that cannot run is reported, not fatal)
             out[f"{key}_ms_per_step"] = f"failed: {e}"
     return out

@@ -1424,18 +1424,18 @@ __global__ __launch_bounds__(NT, (FB && NT == 512) ? 4 : 1) void deep_tile_kerne
         lo = SGR_UNIFORM(s_lo);
         // coarse position of depth bits z: (z - lo) * 256 / (range + 1) in fp32 -- monotone in z; its integer part is the coarse bin
         const float scc = __builtin_bit_cast(float, SGR_UNIFORM(__builtin_bit_cast(uint32_t, (float)NBC / ((float)(SGR_UNIFORM(s_hi) - lo) + 1.0f))));
-        // a density estimate is all the coarse histogram is: a quarter of the composites (every 4th register / every 4th of the rest)
+        // a density estimate is all the coarse histogram is: every 4th composite of the LIST (register composite j = it * NT + t with j % 4 == t % 4:
+        // the threads with t % 4 == 0 enter all of theirs).  Not "every 4th register": the list arrives run by run, and with Gaussians in a
+        // spatially coherent order its first NT entries are one patch of one surface -- the bins were dealt by that patch's depths, other
+        // depths overflowed their bins and every long tile was declined (C2 in template order: per-tile sort 20 -> 73 us)
         uint32_t n_samples = 0;
+        if ((t & 3u) == 0u) {
 #pragma unroll
-        for (uint32_t it = 0; it < RI; it += 4)
-            if (it * NT + t < n) atomicAdd(&s_ccnt[min(NBC - 1u, (uint32_t)((float)((uint32_t)(c[it] >> 32) - lo) * scc))], 1u);
-        for (uint32_t k = REG + t * 4u; k < n; k += NT * 4u) atomicAdd(&s_ccnt[min(NBC - 1u, (uint32_t)((float)((uint32_t)(seg[k] >> 32) - lo) * scc))], 1u);
-        {   // number of samples (uniform arithmetic): registers it = 0, 4, 8, 12 with it * NT + t < n, plus every 4th of the rest
-            const uint32_t nr = min(n, REG);
-#pragma unroll
-            for (uint32_t it = 0; it < RI; it += 4) n_samples += nr > it * NT ? min((uint32_t)NT, nr - it * NT) : 0u;
-            if (n > REG) n_samples += (n - REG + 3u) / 4u;
+            for (uint32_t it = 0; it < RI; it++)
+                if (it * NT + t < n) atomicAdd(&s_ccnt[min(NBC - 1u, (uint32_t)((float)((uint32_t)(c[it] >> 32) - lo) * scc))], 1u);
         }
+        for (uint32_t k = REG + t * 4u; k < n; k += NT * 4u) atomicAdd(&s_ccnt[min(NBC - 1u, (uint32_t)((float)((uint32_t)(seg[k] >> 32) - lo) * scc))], 1u);
+        n_samples = (min(n, REG) + 3u) / 4u + (n > REG ? (n - REG + 3u) / 4u : 0u);      // (uniform arithmetic; REG % 4 == 0)
         __syncthreads();
         SGR_STAMP(2)
         // ---- 2. fine bins per coarse bin: one for every occupied coarse bin + the rest in proportion to the samples
@@ -1572,7 +1572,8 @@ __global__ __launch_bounds__(kThreads) void tile_ranges_kernel(const uint64_t *_
 
 // 3 = automatic (default), 5 = single wide tile pass + LDS distribution sort per tile (one or two 512^2 views; else like 3),
 // 4 = view-segmented (per-view tile pass + per-tile depth sort), 1 = three kernels per 8-bit digit over the whole key (the fallback)
-thread_local int sgr_sort_mode = sgr_env_knob("SIGMAN_SORT_MODE", 1, 5, 3);        // (per thread; every thread starts from the environment)
+static int sgr_sort_mode_from_env() { const int v = sgr_env_knob("SIGMAN_SORT_MODE", 1, 5, 3); return v == 2 ? 3 : v; }     // (2 was removed in round 5: as refused as by the setter)
+thread_local int sgr_sort_mode = sgr_sort_mode_from_env();        // (per thread; every thread starts from the environment)
 
 struct VsegLayout {
     size_t plan, totals, key_start, chunk_start, chunk_map, hist, tile_total, lists, end; uint32_t chunk_keys, max_chunks;

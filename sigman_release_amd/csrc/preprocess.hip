@@ -470,56 +470,101 @@ __global__ __launch_bounds__(1024) void scan_block_sums_kernel(const uint32_t *_
 //                                in the same order as the loop, so both kernels give bit-identical gradients
 // -------------------------------------------------------------------------------------------------
 struct ViewGrad { float mean[3], cov[6], op, col[3]; };
+// bwd_view<SH, CH>: CH items per round of the wave-wide gather (128: two per lane and round trip; 64 for the kernel whose occupancy LDS bounds); LDS per wave
+constexpr uint32_t gather_lds_floats(uint32_t ch) { return ch * 10 + 128; }
 
 // SH=false (the reference's colors_precomp path) compiles without the spherical-harmonics tables: no scratch, half the VGPRs
-template <bool SH>
+template <bool SH, uint32_t kGatherChunk>
 __device__ __forceinline__ void bwd_view(const SgrProblem &pb, int view, int i, size_t sp, const float (&p)[3], const float (&c6)[6], float fx, float fy,
                                          const int32_t *__restrict__ radii, const uint8_t *__restrict__ clamped,
                                          const uint4 *__restrict__ rect, const float4 *__restrict__ part, const uint32_t *__restrict__ flags,
                                          uint32_t n_inst, const float *__restrict__ part_scale, float *__restrict__ dL_dmeans2D, float *__restrict__ dL_dsh,
-                                         ViewGrad &out) {
+                                         ViewGrad &out, bool live /* false: a lane without a Gaussian -- EVERY lane of a wave must make this call (the
+                                         gather is done by the whole wave) */, float *gather_lds /* this WAVE's gather_lds_floats(kGatherChunk) floats of LDS */) {
 #pragma unroll
     for (int k = 0; k < 3; k++) { out.mean[k] = 0.f; out.col[k] = 0.f; }
 #pragma unroll
     for (int k = 0; k < 6; k++) out.cov[k] = 0.f;
     out.op = 0.f;
-    const size_t q = (size_t)view * pb.P + i;
-    float *g2out = dL_dmeans2D ? dL_dmeans2D + q * 3 : nullptr;      // (NULL: nobody wants dL/dNDC)
-    const uint4 r3 = rect[q];                                        // requested beside the radius, not behind it (one round trip less)
-    if (!(radii[q] > 0)) { if (g2out) { g2out[0] = g2out[1] = g2out[2] = 0.f; } return; }
+    const size_t q = live ? (size_t)view * pb.P + i : 0;
+    float *g2out = (dL_dmeans2D && live) ? dL_dmeans2D + q * 3 : nullptr;      // (NULL: nobody wants dL/dNDC)
+    uint4 r3 = make_uint4(0u, 0u, 0u, 0u);
+    bool vis = false;
+    if (live) { r3 = rect[q]; vis = radii[q] > 0; }                 // (the rect is requested beside the radius, not behind it: one round trip less)
     float4 g0, g1, g2;
     {
         // deterministic gather of the bucket-parallel backward's partial records: one per (tile instance, quadrant),
         // summed in tile order then quadrant order -- no atomics anywhere in the backward
         const uint32_t off = r3.w, rmin = r3.x, rmax = r3.y;
-        const uint32_t ntile = ((rmax & 0xFFFFu) - (rmin & 0xFFFFu)) * ((rmax >> 16) - (rmin >> 16));
+        const uint32_t ntile_all = vis ? ((rmax & 0xFFFFu) - (rmin & 0xFFFFu)) * ((rmax >> 16) - (rmin >> 16)) : 0u;
+        // ---- the gather, by the whole WAVE.  One thread walking its own n tile instances is a chain of n dependent round trips, as long as the
+        // largest splat among 64 lanes (C1, 10 000 Gaussians of up to 7 x 7 tiles: 23 us, twice C2's time for a tenth of the Gaussians).  The
+        // instances of the wave's 64 splats are numbered through (prefix over the lanes) and dealt to the lanes kGatherChunk at a time: lane l
+        // fetches the flag word and the present quadrant records of items l, l + 64 of the chunk -- no dummy loads, two round trips per chunk --,
+        // adds the quadrants in quadrant order and leaves the ten sums in LDS; the owner then adds its items in instance order.  The same
+        // additions in the same order whatever the kernel, the lane or the run: bitwise reproducible, and one order for both gather kernels.
         g0 = make_float4(0.f, 0.f, 0.f, 0.f); g1 = g0; g2 = g0;
-        // The loop is a chain of dependent memory round trips on a kernel that lives on latency: the flag word of the next instance is
-        // fetched while this one is summed, and the (up to four) quadrant records of an instance are requested TOGETHER -- a quadrant
-        // without a record re-reads the instance's first existing one (same cache line, value discarded) instead of branching around
-        // its loads.  (A branch per quadrant serialised four round trips per instance: some lane of the wave always takes each.)
-        // Adding the +0.0f of a discarded record changes nothing: the sums start at +0.0f and can never become -0.0f.
         struct __attribute__((packed, aligned(8))) Rec40 { float2 v[5]; };   // 40 bytes, 8-byte aligned: 16 + 16 + 8-byte loads
-        uint32_t f = (ntile && off < n_inst) ? flags[off] : 0u;
-        for (uint32_t k = 0; k < ntile; k++) {
-            if (off + k >= n_inst) break;                   // sync-free mode after an overflow: instances beyond the buffers do not exist
-            const uint32_t fn = (k + 1u < ntile && off + k + 1u < n_inst) ? flags[off + k + 1u] : 0u;
-            if (f) {
-                const Rec40 *base = reinterpret_cast<const Rec40 *>(part) + (size_t)(off + k) * 4;
-                const uint32_t dq = (uint32_t)(__ffs((int)f) - 1) >> 3;
-                Rec40 rr[4];
-                bool on[4];
+        {
+            const uint32_t lane = sgr_lane_id();
+            float *s_item = gather_lds;                                      // [kGatherChunk][10] sums of one item
+            uint32_t *s_end = reinterpret_cast<uint32_t *>(gather_lds + kGatherChunk * 10), *s_off = s_end + 64;
+            uint32_t inc = ntile_all;
 #pragma unroll
-                for (uint32_t qd = 0; qd < 4; qd++) { on[qd] = ((f >> (8 * qd)) & 0xFFu) != 0u; rr[qd] = base[on[qd] ? qd : dq]; }
+            for (int o = 1; o < 64; o <<= 1) { const uint32_t nb = __shfl_up(inc, o, 64); if (lane >= (uint32_t)o) inc += nb; }
+            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63), my_begin = inc - ntile_all;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();        // (the previous view's reads of the tables are over)
+            s_end[lane] = inc; s_off[lane] = off;
+            float acc[10];
 #pragma unroll
-                for (uint32_t qd = 0; qd < 4; qd++) {
-                    const float2 p0 = rr[qd].v[0], p1 = rr[qd].v[1], p2 = rr[qd].v[2], p3 = rr[qd].v[3], p4 = rr[qd].v[4];
-                    g0.x += on[qd] ? p0.x : 0.f; g0.y += on[qd] ? p0.y : 0.f; g0.z += on[qd] ? p1.x : 0.f; g0.w += on[qd] ? p1.y : 0.f;
-                    g1.x += on[qd] ? p2.x : 0.f; g1.y += on[qd] ? p2.y : 0.f; g1.z += on[qd] ? p3.x : 0.f; g1.w += on[qd] ? p3.y : 0.f;
-                    g2.x += on[qd] ? p4.x : 0.f; g2.y += on[qd] ? p4.y : 0.f;
+            for (int j = 0; j < 10; j++) acc[j] = 0.f;
+            for (uint32_t base = 0; base < total; base += kGatherChunk) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                uint32_t inst[kGatherChunk / 64], fw[kGatherChunk / 64];
+#pragma unroll
+                for (uint32_t r = 0; r < kGatherChunk / 64; r++) {
+                    const uint32_t j = base + r * 64u + lane;
+                    inst[r] = 0xFFFFFFFFu; fw[r] = 0u;
+                    if (j < total) {
+                        uint32_t lo = 0;                                     // the owner: the number of lanes whose items end at or before j
+#pragma unroll
+                        for (uint32_t step = 32; step > 0; step >>= 1) if (s_end[lo + step - 1u] <= j) lo += step;
+                        const uint32_t i2 = s_off[lo] + (j - (lo ? s_end[lo - 1u] : 0u));
+                        if (i2 < n_inst) { inst[r] = i2; fw[r] = flags[i2]; }        // (instances beyond the buffers do not exist: sync-free mode after an overflow)
+                    }
+                }
+#pragma unroll
+                for (uint32_t r = 0; r < kGatherChunk / 64; r++) {
+                    float it[10];
+#pragma unroll
+                    for (int j = 0; j < 10; j++) it[j] = 0.f;
+                    if (fw[r]) {
+                        const Rec40 *rb = reinterpret_cast<const Rec40 *>(part) + (size_t)inst[r] * 4;
+                        Rec40 rr[4];
+#pragma unroll
+                        for (uint32_t qd = 0; qd < 4; qd++) {
+#pragma unroll
+                            for (int j = 0; j < 5; j++) rr[qd].v[j] = make_float2(0.f, 0.f);
+                            if ((fw[r] >> (8 * qd)) & 0xFFu) rr[qd] = rb[qd];
+                        }
+#pragma unroll
+                        for (uint32_t qd = 0; qd < 4; qd++)
+#pragma unroll
+                            for (int j = 0; j < 5; j++) { it[2 * j] += rr[qd].v[j].x; it[2 * j + 1] += rr[qd].v[j].y; }
+                    }
+                    float *dst = s_item + (r * 64u + lane) * 10u;
+#pragma unroll
+                    for (int j = 0; j < 10; j += 2) *reinterpret_cast<float2 *>(dst + j) = make_float2(it[j], it[j + 1]);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const uint32_t j0 = max(my_begin, base), j1 = min(inc, base + kGatherChunk);
+                for (uint32_t j = j0; j < j1; j++) {
+                    const float *src = s_item + (j - base) * 10u;
+#pragma unroll
+                    for (int k = 0; k < 10; k += 2) { const float2 v2 = *reinterpret_cast<const float2 *>(src + k); acc[k] += v2.x; acc[k + 1] += v2.y; }
                 }
             }
-            f = fn;
+            g0 = make_float4(acc[0], acc[1], acc[2], acc[3]); g1 = make_float4(acc[4], acc[5], acc[6], acc[7]); g2.x = acc[8]; g2.y = acc[9];
         }
         if (part_scale) {
             // the partial records of a fused rasterize + loss step are for dL/dloss = 1: everything below is linear in the ten sums
@@ -527,6 +572,7 @@ __device__ __forceinline__ void bwd_view(const SgrProblem &pb, int view, int i, 
             g0.x *= sc; g0.y *= sc; g0.z *= sc; g0.w *= sc; g1.x *= sc; g1.y *= sc; g1.z *= sc; g1.w *= sc; g2.x *= sc; g2.y *= sc;
         }
     }
+    if (!vis) { if (g2out) { g2out[0] = g2out[1] = g2out[2] = 0.f; } return; }
     const float *V = pb.viewmatrix + 16 * (size_t)view;
     const float *M = pb.projmatrix + 16 * (size_t)view;
     float pv[3];
@@ -682,29 +728,32 @@ __device__ __forceinline__ void bwd_finish(const SgrProblem &pb, size_t sp, cons
 
 template <bool SH>
 __global__ __launch_bounds__(kPreThreads) void preprocess_bwd_kernel(SGR_BWD_ARGS) {
+    __shared__ __attribute__((aligned(16))) float gather_lds[kPreThreads / 64][gather_lds_floats(128)];
     const int subj = blockIdx.y;
-    const int i = blockIdx.x * kPreThreads + threadIdx.x;
-    if (i >= pb.P) return;
+    const int i_raw = blockIdx.x * kPreThreads + threadIdx.x;
+    const bool live = i_raw < pb.P;                                  // (no early exit: the gather of a large splat needs every lane of its wave)
+    const int i = live ? i_raw : pb.P - 1;
     const size_t sp = (size_t)subj * pb.P + i;
     const float fx = (float)pb.W / (2.0f * pb.tanfovx), fy = (float)pb.H / (2.0f * pb.tanfovy);
     const float p[3] = {pb.means3D[sp * 3 + 0], pb.means3D[sp * 3 + 1], pb.means3D[sp * 3 + 2]};
     float c6[6];
     load_cov3d(pb, sp, c6);
     float gmean[3] = {0.f, 0.f, 0.f}, gcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, gop = 0.f, gcol[3] = {0.f, 0.f, 0.f};
-    if (SH) {
+    if (SH && live) {
         float *gsh = dL_dsh + sp * (size_t)pb.M * 3;
         for (int k = 0; k < pb.M * 3; k++) gsh[k] = 0.f;
     }
     const int v0 = subj * pb.views_per_subject;
     for (int vv = 0; vv < pb.views_per_subject; vv++) {
         ViewGrad g;
-        bwd_view<SH>(pb, v0 + vv, i, sp, p, c6, fx, fy, radii, clamped, rect, part, flags, n_inst, part_scale, dL_dmeans2D, dL_dsh, g);
+        bwd_view<SH, 128>(pb, v0 + vv, i, sp, p, c6, fx, fy, radii, clamped, rect, part, flags, n_inst, part_scale, dL_dmeans2D, dL_dsh, g, live, gather_lds[threadIdx.x >> 6]);
 #pragma unroll
         for (int k = 0; k < 6; k++) gcov[k] += g.cov[k];
         if (!SH) { gcol[0] += g.col[0]; gcol[1] += g.col[1]; gcol[2] += g.col[2]; }
         gop += g.op;
         gmean[0] += g.mean[0]; gmean[1] += g.mean[1]; gmean[2] += g.mean[2];
     }
+    if (!live) return;
     bwd_finish<SH>(pb, sp, gmean, gcov, gop, gcol, dL_dmeans3D, dL_dopacity, dL_dcolors, dL_dcov3D, dL_dscales, dL_drot);
 }
 
@@ -713,17 +762,22 @@ __global__ __launch_bounds__(kPreThreads) void preprocess_bwd_kernel(SGR_BWD_ARG
 // (five waves per SIMD: the gather lives on memory latency, 96 VGPRs instead of 98 buy a fifth wave -- 0.368 -> 0.348 ms at C3; six spill: 0.45)
 __global__ __launch_bounds__(kPreThreads) __attribute__((amdgpu_waves_per_eu(5))) void preprocess_bwd_lanes_kernel(SGR_BWD_ARGS) {
     __shared__ float acc[13][kPreThreads];
+    __shared__ __attribute__((aligned(16))) float gather_lds[kPreThreads / 64][gather_lds_floats(64)];
     const int subj = blockIdx.y, vps = pb.views_per_subject, gpb = kPreThreads / vps;
     const int t = threadIdx.x, vv = t / gpb, gl = t - vv * gpb;
     const int i = blockIdx.x * gpb + gl;
     const float fx = (float)pb.W / (2.0f * pb.tanfovx), fy = (float)pb.H / (2.0f * pb.tanfovy);
     ViewGrad g;
-    if (i < pb.P) {
-        const size_t sp = (size_t)subj * pb.P + i;
+    {
+        const bool live = i < pb.P;                                   // (every lane makes the call: the gather of a large splat is done by the whole wave)
+        const int ic = live ? i : pb.P - 1;
+        const size_t sp = (size_t)subj * pb.P + ic;
         const float p[3] = {pb.means3D[sp * 3 + 0], pb.means3D[sp * 3 + 1], pb.means3D[sp * 3 + 2]};
         float c6[6];
         load_cov3d(pb, sp, c6);
-        bwd_view<false>(pb, subj * vps + vv, i, sp, p, c6, fx, fy, radii, clamped, rect, part, flags, n_inst, part_scale, dL_dmeans2D, dL_dsh, g);
+        bwd_view<false, 64>(pb, subj * vps + vv, ic, sp, p, c6, fx, fy, radii, clamped, rect, part, flags, n_inst, part_scale, dL_dmeans2D, dL_dsh, g, live, gather_lds[t >> 6]);
+    }
+    if (i < pb.P) {
 #pragma unroll
         for (int k = 0; k < 3; k++) { acc[k][t] = g.mean[k]; acc[10 + k][t] = g.col[k]; }
 #pragma unroll

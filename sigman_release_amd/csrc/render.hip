@@ -362,7 +362,7 @@ __global__ __launch_bounds__(kSegThreads, 4) void render_fwd_seg_kernel(int W, i
         // 256 pixels, the other three leave at once: these workgroups are dispatched behind the working ones and each holds a full
         // workgroup's registers and LDS while it lives -- four of them per empty tile, each walking through the whole kernel with 64 of its
         // 512 threads writing, were 5 of the kernel's 53 us at C2.  (Workgroup-uniform exit in front of the first barrier.)
-        // (bg_done: the idle workgroups of the per-tile sort launch already did all of it -- SgrBgJob, common.h)
+        // (bg_done: extra workgroups of the preprocess launch already did all of it -- SgrBgJob, common.h)
         if (bg_done || q != 0u || (AUX && !aux.ckpt_tc) || t >= 256) return;
         const int bx = (int)tx * 16 + (t & 15), by = (int)ty * 16 + (t >> 4);
         if (bx < W && by < H) {
@@ -1004,7 +1004,8 @@ int sgr_render_forward_kind(const SgrProblem *pb);
 
 // 0 = automatic (segment-parallel for <= 2048 tiles, else one wave per quadrant), 2 = segment-parallel kernel, 3 = one wave per
 // (tile, quadrant) (dev/test override: sgr_set_forward_mode).  (1 was round 1's serial per-tile kernel: removed in round 5.)
-static thread_local int sgr_fwd_mode = sgr_env_knob("SIGMAN_FWD_MODE", 0, 3, 0);          // (dev/test switch, thread-local like sgr_set_debug: the forward runs on the caller's thread; every thread starts from the environment)
+static int sgr_fwd_mode_from_env() { const int v = sgr_env_knob("SIGMAN_FWD_MODE", 0, 3, 0); return v == 1 ? 0 : v; }       // (1 was removed in round 5: as refused as by the setter)
+static thread_local int sgr_fwd_mode = sgr_fwd_mode_from_env();          // (dev/test switch, thread-local like sgr_set_debug: the forward runs on the caller's thread; every thread starts from the environment)
 extern "C" int sgr_set_forward_mode(int mode) {
     if (mode != 0 && mode != 2 && mode != 3) { sgr_set_error("sgr_set_forward_mode: %d is not a forward kernel (0 automatic, 2 segment-parallel, 3 one wave per quadrant)", mode); return 1; }
     sgr_fwd_mode = mode;

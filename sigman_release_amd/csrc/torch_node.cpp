@@ -543,7 +543,11 @@ struct RasterizeL1BatchedNode : public torch::autograd::Function<RasterizeL1Batc
         ac.dev = dev;
         CountSlot slot = acquire_slot(didx);
         slot.host[0] = ~0ull; slot.host[1] = 0;
-        const auto size_key = std::make_tuple(didx, P, nv, H, W, capacity, with_aux);
+        // (the fused single-view step keeps its partial records in the image blob: the calling thread's switch is part of the key, so toggling it
+        // -- sgr_set_fused_step, parallel.py -- neither makes the pre-allocated attempt fail nor leaves unfused calls with the larger blob)
+        const int fused_on = sgr_set_fused_step(1);
+        sgr_set_fused_step(fused_on);
+        const auto size_key = std::make_tuple(didx, P, nv, H, W, capacity, with_aux | (fused_on ? 256 : 0));
         std::array<uint64_t, 3> sizes{0, 0, 0};
         bool have = false;
         { std::lock_guard<std::mutex> l(g_mu); auto it = g_b_blob_sizes.find(size_key); if (it != g_b_blob_sizes.end()) { sizes = it->second; have = true; } }

@@ -357,7 +357,11 @@ def _forward_impl(means3D, opacities, colors_precomp, shs, cov3D_precomp, scales
         forward_fn = L.sgr_rasterize_forward_l1
     # sync-free mode: blob sizes only depend on the shapes, so from the second call on the blobs are allocated here and handed over
     # directly (no allocator callbacks through ctypes)
-    size_key = (didx, P, nv, H, W, capacity, use_aux, shs is not None) if capacity > 0 else None
+    fused_key = 0
+    if l1 is not None and ep.fuse_backward:      # (the fused step keeps its partial records in the image blob: the thread's switch is part of the key)
+        fused_key = L.sgr_set_fused_step(1)
+        L.sgr_set_fused_step(fused_key)
+    size_key = (didx, P, nv, H, W, capacity, use_aux, shs is not None, fused_key) if capacity > 0 else None
     sizes = _blob_sizes.get(size_key) if size_key is not None else None
     status = 2
     with _debug_scope(getattr(st, "debug", False)):

@@ -84,8 +84,24 @@ def _finish(rng, pos, R0, P):
                 cov3d=rot.astype(f), rgb=rgb.astype(f))
 
 
-def humanoid(P: int, seed: int) -> dict:
-    """Config C2/C3/C4 subject: P Gaussians on the procedural humanoid surface."""
+def _morton_order(pos: np.ndarray) -> np.ndarray:
+    """Indices that sort points along a 30-bit Morton curve over their bounding box (a spatially coherent order)."""
+    lo, hi = pos.min(0), pos.max(0)
+    q = np.minimum(((pos - lo) / np.maximum(hi - lo, 1e-12) * 1024.0).astype(np.uint64), 1023)
+
+    def spread(v):
+        v = (v | (v << 16)) & 0x030000FF
+        v = (v | (v << 8)) & 0x0300F00F
+        v = (v | (v << 4)) & 0x030C30C3
+        return (v | (v << 2)) & 0x09249249
+    return np.argsort(spread(q[:, 0]) | (spread(q[:, 1]) << 1) | (spread(q[:, 2]) << 2), kind="stable")
+
+
+def humanoid(P: int, seed: int, order: str = "random") -> dict:
+    """Config C2/C3/C4 subject: P Gaussians on the procedural humanoid surface.
+    order = "random" (default: the Gaussians of the whole subject in a random permutation -- the pessimistic case for every gather) or
+    "template": part by part, each part along a Morton curve -- neighbours in memory are neighbours in space, as the faces of the reference's
+    subdivided template mesh are (/root/reference/core/modules/deformers/utils_smplx.py:145-162: one Gaussian per face, in face order)."""
     rng = np.random.default_rng(seed)
     areas = []
     for a, b, r in _CAPSULES:
@@ -96,9 +112,15 @@ def humanoid(P: int, seed: int) -> dict:
     for (a, b, r), n in zip(_CAPSULES, counts):
         p, nn, _ = _sample_capsule_surface(rng, int(n), a, b, r)
         pos.append(p); nrm.append(nn)
-    pos, nrm = np.concatenate(pos), np.concatenate(nrm)
-    perm = rng.permutation(P)         # the template's face order is not spatially sorted per part either
-    pos, nrm = pos[perm], nrm[perm]
+    if order == "template":
+        for k in range(len(pos)):
+            o = _morton_order(pos[k])
+            pos[k], nrm[k] = pos[k][o], nrm[k][o]
+        pos, nrm = np.concatenate(pos), np.concatenate(nrm)
+    else:
+        pos, nrm = np.concatenate(pos), np.concatenate(nrm)
+        perm = rng.permutation(P)
+        pos, nrm = pos[perm], nrm[perm]
     return _finish(rng, pos, _tangent_frames(nrm), P)
 
 

@@ -558,13 +558,13 @@ def test_cpp_batched_l1_node_equals_python_node(S, V, mode):
                                                         (6000, 128, 144, 2, True, 4)])
 def test_fused_single_view_step_equals_unfused_chain(P, H, W, V, use_mask, sort_mode):
     """The fused single-view step (SgrL1Epilogue.fuse_backward: loss shares + dL/dcolor inside the segment-parallel compositing kernel, the
-    background's share pre-filled by the wide row scan's spare workgroups, the bucket backward queued behind the compositing kernel by the
+    background's share pre-filled by extra workgroups of the preprocess launch, the bucket backward queued behind the compositing kernel by the
     forward call with the loss reduction in its spare workgroup, the caller's backward only gathers) against the unfused chain through the
     SAME C++ node (sgr_set_fused_step 0): images, radii and gradients bit for bit with dL/dloss = 1, the loss to the order of its additions.
     A second backward on the same forward (gather only, twice) repeats the first; a backward with a gradient into the colour as well falls
     back to the unfused backward and is bit-identical to the unfused chain's; the fused loss is bitwise reproducible from run to run.
-    sort_mode 4: a binning flavour without the wide row scan, i.e. without the background pre-fill -- the compositing kernel's own empty-tile
-    workgroups then write the background's loss shares and dL/dcolor."""
+    sort_mode 4: the view-segmented binning flavour (plain work order written by its register-sort launch's spare workgroup) instead of the
+    single-view path (class-major work order, empty tiles never visited by the compositing kernel)."""
     from sigman_release_amd import _cabi, rasterizer as R
     if _cabi.torch_node() is None:
         pytest.skip("sgr_torch_node.so not built / SIGMAN_PY_NODE=1")

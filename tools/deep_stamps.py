@@ -11,7 +11,7 @@ cfg = sys.argv[1] if len(sys.argv) > 1 else "c2"
 dev = torch.device("cuda:0")
 c = bench.CONFIGS[cfg]
 P, H = c["P"], c["size"]
-sub, _, _ = bench.build_subject(cfg, P, {"c1": 0, "c2": 1}[cfg], dev)
+sub, _, _ = bench.build_subject(cfg, P, {"c1": 0, "c2": 1}[cfg], dev, os.environ.get("ORDER", "random"))
 cv, cvp, cp = cameras.make_cameras([bench.VIEWS[0]])
 t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 st = R.BatchedRasterizationSettings(H, H, cameras.TAN_HALF_FOV, cameras.TAN_HALF_FOV, torch.ones(3, device=dev), 0.5, t(cv), t(cvp), 0, t(cp), 1)
