@@ -1555,6 +1555,75 @@ __global__ __launch_bounds__(NT, (FB && NT == 512) ? 4 : 1) void deep_tile_kerne
 #undef SGR_UNIFORM
 }
 
+// ---- deep launches of one or two views (C5: a million Gaussians on 1 024 tiles): the tile pass as ONE launch --------------------------------
+// The emission kernel writes tile-ordered runs and the run matrix as on the single-view path (duplicate_keys_kernel<true, ..>, kRunRow); one
+// workgroup per tile then reads its columns of the matrix -- the pieces of its list in the runs and, summed, its range --, copies the pieces
+// into the tile's contiguous segment, writes the range (F5) and enters the tile into the per-tile sorts' worklists (exactly what
+// vseg_scan_kernel enters: register-sort classes 0..5, the deep kernels' lists 6 / 7, one entry per window of a big tile).  Replaces the
+// view-segmented flavour's plan / upsweep / column scan / tile scan / staged scatter launches (five dependent launches, 39 us of C5's 360).
+template <int NT>
+__global__ __launch_bounds__(NT) void tile_collect_kernel(const uint64_t *__restrict__ runs, uint64_t *__restrict__ dst, GatherFront gf, VsegPlan *__restrict__ plan,
+                                                          uint32_t *__restrict__ lists, uint32_t list_stride, uint32_t deep_min, uint32_t small_max) {
+    constexpr uint32_t NW = NT / 64;
+    __shared__ uint32_t s_pre[NT], s_cur[NT], s_wave[NW], s_wave2[NW];
+    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6, i = blockIdx.x;
+    uint32_t tile;
+    {   // (the dispatch order of deep_tile_kernel<.., FB>: image columns from the centre outwards, rotated rows -- see there)
+        const uint32_t tpv = gf.tx * gf.ty, vw = i / tpv, r = i - vw * tpv;
+        const uint32_t ci = r / gf.ty, ri = r - ci * gf.ty, mid = gf.tx >> 1;
+        const uint32_t tcol = (ci & 1u) ? mid - 1u - (ci >> 1) : mid + (ci >> 1);
+        tile = vw * tpv + ((ri + 5u * ci) % gf.ty) * gf.tx + tcol;
+    }
+    if ((uint32_t)__builtin_amdgcn_readfirstlane((int)gf.occ[tile]) == 0u) { if (t == 0) gf.ranges[tile] = make_uint2(0u, 0u); return; }
+    uint32_t a = 0u, e = 0u, bs = 0u;
+    if (t < gf.nblk) { const uint32_t *r = gf.rows + (size_t)t * kRunRow + tile; a = r[0]; e = r[1]; bs = gf.base[t]; }
+    const uint32_t cnt = e - a;
+    uint32_t inc = cnt, before = a - bs;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const uint32_t nbv = __shfl_up(inc, off, 64); if (lane >= (uint32_t)off) inc += nbv; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) before += __shfl_xor(before, off, 64);
+    if (lane == 63u) s_wave[wave] = inc;
+    if (lane == 0u) s_wave2[wave] = before;
+    __syncthreads();
+    uint32_t pre = 0u, n_all = 0u, first = 0u;
+#pragma unroll
+    for (uint32_t w = 0; w < NW; w++) { const uint32_t x = s_wave[w]; if (w < wave) pre += x; n_all += x; first += s_wave2[w]; }
+    s_pre[t] = pre + inc - cnt; s_cur[t] = a;                                    // piece prefix / piece start (runs beyond nblk: prefix = n)
+    const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)n_all), x0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)first);
+    if (t == 0) {
+        gf.ranges[tile] = n ? make_uint2(x0, x0 + n) : make_uint2(0u, 0u);
+        if (n) {                                                                 // (single-key tiles too: the sort kernels move them to the destination buffer)
+            uint32_t cls = n <= 1024u ? 0u : (n <= 2048u ? 1u : (n <= 4096u ? 2u : (n <= 8192u ? 3u : (n <= 16384u ? 4u : 5u))));
+            uint32_t take = 1u;
+            if (n > deep_min && n <= kDeepMaxN) {
+                if (n <= small_max) cls = 7u;
+                else { cls = 6u; take = (n + (kDeepBigCap - kDeepBinMax) - 1u) / (kDeepBigCap - kDeepBinMax); }
+            }
+            uint32_t *d = lists + (size_t)cls * list_stride + atomicAdd(&plan->count[cls], take);
+            d[0] = tile;
+            for (uint32_t w = 1; w < take; w++) d[w] = tile | (w << 26);
+        }
+    }
+    __syncthreads();
+    // the copy: one thread per composite, which finds its piece by binary search over the piece prefixes (four composites per trip: their
+    // searches and loads overlap).  (Piece by piece -- a wave per piece, contiguous loads and stores, no search -- was SLOWER: 42 against 31 us
+    // at C5; a piece holds ~30 composites, half a wave's lanes idle and twice the load instructions.)
+    uint64_t *out = dst + x0;
+    for (uint32_t j0 = t; j0 < n; j0 += 4u * NT) {
+        uint64_t v[4];
+#pragma unroll
+        for (uint32_t u = 0; u < 4; u++) {
+            const uint32_t j = min(j0 + u * NT, n - 1u);
+            uint32_t lo = 0u;
+            for (uint32_t step = gf.search_top; step > 0u; step >>= 1) if (s_pre[lo + step] <= j) lo += step;
+            v[u] = runs[s_cur[lo] + (j - s_pre[lo])];
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < 4; u++) if (j0 + u * NT < n) out[j0 + u * NT] = v[u];
+    }
+}
+
 // ---- F5 -------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kThreads) void tile_ranges_kernel(const uint64_t *__restrict__ keys, uint32_t n_host,
                                                                const uint64_t *__restrict__ n_dev, uint2 *__restrict__ ranges) {
@@ -1616,6 +1685,7 @@ static thread_local int g_deep_mode = sgr_env_knob("SIGMAN_SORT_DEEP", 0, 2, 0);
 // bits 8..15 of `mode` (tests): the most windows a tile may have behind the single wide tile pass before it is listed once and sorted whole
 // (0 = the window field's 64)
 static thread_local uint32_t g_deep_max_windows = kDeepMaxWindows;
+static thread_local int g_collect_mode = sgr_env_knob("SIGMAN_SORT_COLLECT", 0, 1, 1);      // A/B: 0 = deep launches of one or two views keep the five-launch tile pass
 extern "C" int sgr_set_sort_deep(int mode) {
     const int m = mode & 0xFF, cap = (mode >> 8) & 0xFF;
     g_deep_mode = (m >= 0 && m <= 2) ? m : 0;
@@ -1644,7 +1714,9 @@ extern "C" size_t sgr_bin_workspace_bytes(uint64_t R, uint64_t tiles_total) {
     const size_t a = (size_t)((8 * (nblocks > 0 ? nblocks : 1) + 8 + 2) * kRadix * sizeof(uint32_t) + 1024 + ((size_t)4 << 20) +
                               (tiles_total ? (tiles_total + 64) * sizeof(uint32_t) + tiles_total * 128 + 65536 : 0));
     const size_t b = (tiles_total && tiles_total <= (uint64_t)kTileBins && R <= (1u << 19)) ? runs_layout(R, 512u).end : 0;
-    return std::max(a, b);
+    // (deep launches of one or two views: the run matrix of <= 1024 emission workgroups in front of the view-segmented flavour's own layout)
+    const size_t c = (tiles_total && tiles_total <= (uint64_t)kTileBins) ? runs_layout(0, 1024u).end : 0;
+    return std::max(a + c, b);
 }
 
 // self_scan: the caller skipped the F2 scan kernel (sgr_preprocess_forward_ex) and block_offsets + n + 1 holds the un-scanned
@@ -1703,14 +1775,18 @@ int sgr_bin_ex(const SgrProblem *pb, const int32_t *radii, uint32_t *rect,
     if (mode == 3 || mode == 5) mode = runs_ok ? 5 : 4;
     if (mode == 4 && !(vseg_ok && (!deep || split || sgr_sort_mode == 4))) mode = 1;
     if (mode == 4 && !vseg_ok) mode = 1;
-    const bool runs = mode == 5;
+    // deep launches of one or two views (C5) in the view-segmented flavour: the collect form of the tile pass (tile_collect_kernel)
+    const RunsLayout RC = runs_layout(0, nblk_e);
+    const bool collect = mode == 4 && split && tiles_total <= (uint64_t)kTileBins && nblk_e <= 1024u && RC.end + VL.end <= workspace_bytes && g_collect_mode != 0;
+    const bool runs = mode == 5 || collect;
     // (every tile's range is written by its own workgroup on the single-view path; the other flavours write the occupied tiles' only)
     const bool fold_clear = !runs && tiles_total * 2 <= (1u << 20);     // small: cleared by the duplicate kernel
     if (!runs && !fold_clear) SGR_CHECK_HIP(hipMemsetAsync(ranges, 0, tiles_total * 2 * sizeof(uint32_t), stream));
     { SgrProfScope _p(SGR_K_DUPLICATE, stream);
     DupExtra ex;
-    ex.run_rows = runs ? (uint32_t *)((char *)workspace + RL.rows) : nullptr; ex.run_base = runs ? (uint32_t *)((char *)workspace + RL.base) : nullptr;
-    ex.occ = runs ? (uint32_t *)((char *)workspace + RL.occ) : nullptr;
+    const RunsLayout &RU = collect ? RC : RL;
+    ex.run_rows = runs ? (uint32_t *)((char *)workspace + RU.rows) : nullptr; ex.run_base = runs ? (uint32_t *)((char *)workspace + RU.base) : nullptr;
+    ex.occ = runs ? (uint32_t *)((char *)workspace + RU.occ) : nullptr;
     if (runs && !occ_zeroed) SGR_CHECK_HIP(hipMemsetAsync(ex.occ, 0, (size_t)kTileBins * sizeof(uint32_t), stream));
     ex.write_first = first_index ? 1u : 0u;
     const uint32_t nblk = (uint32_t)nbx * (uint32_t)pb->n_views;
@@ -1722,16 +1798,50 @@ int sgr_bin_ex(const SgrProblem *pb, const int32_t *radii, uint32_t *rect,
         ex.zero_ptr[1 + c] = ok ? clear_ptr[c] : nullptr; ex.zero_words[1 + c] = ok ? (uint32_t)clear_words[c] : 0u;
         if (clear_done) clear_done[c] = ok ? 1 : 0;
     }
-    ex.zero_small = (runs && fwd_order) ? fwd_order : nullptr; ex.zero_small_n = 48u;       // the work order's class counters
+    ex.zero_small = (mode == 5 && fwd_order) ? fwd_order : nullptr; ex.zero_small_n = 48u;       // the work order's class counters
+    if (collect) { ex.zero_small = (uint32_t *)((char *)workspace + RC.end + VL.plan); ex.zero_small_n = (uint32_t)(sizeof(VsegPlan) / 4); }   // the worklist counters and tickets
     if (self_scan && !num_rendered_dev) { sgr_set_error("sgr_bin: self-scan needs the device counter"); return 1; }
     if (runs) hipLaunchKernelGGL((duplicate_keys_kernel<true, kRunThreads>), dim3(nbx_e, pb->n_views), dim3(kRunThreads), 0, stream, pb->P, Tx, Tx * Ty, nbx,
-                                 radii, (uint4 *)rect, block_offsets, n, kout, (uint32_t *)nullptr, ex);
+                                 radii, (uint4 *)rect, block_offsets, n, collect ? kin : kout, (uint32_t *)nullptr, ex);
     else hipLaunchKernelGGL((duplicate_keys_kernel<false, kThreads>), dim3(nbx, pb->n_views), dim3(kThreads), 0, stream, pb->P, Tx, Tx * Ty, nbx,
                             radii, (uint4 *)rect, block_offsets, n, keys_a, vals_a, ex);
     SGR_CHECK_LAUNCH("duplicate_keys_kernel");
     }
     GatherFront no_gf;
     memset(&no_gf, 0, sizeof(no_gf));
+    if (mode == 4 && collect) {
+        // deep launch of one or two views: tile-ordered emission runs (in kin, as composites) -> one collect launch (ranges, worklists, the tiles'
+        // contiguous segments in kout) -> the per-tile sorts as below
+        char *ws = (char *)workspace + RC.end;
+        VsegPlan *plan = (VsegPlan *)(ws + VL.plan);
+        uint32_t *lists = (uint32_t *)(ws + VL.lists);
+        { SgrProfScope _ps(SGR_K_SORT, stream);
+        GatherFront gf = no_gf;
+        gf.rows = (const uint32_t *)((char *)workspace + RC.rows); gf.base = (const uint32_t *)((char *)workspace + RC.base);
+        gf.occ = (const uint32_t *)((char *)workspace + RC.occ);
+        gf.nblk = nblk_e; gf.tiles_total = (uint32_t)tiles_total; gf.tx = (uint32_t)Tx; gf.ty = (uint32_t)Ty; gf.ranges = (uint2 *)ranges;
+        gf.search_top = 1u; while (gf.search_top * 2u < nblk_e) gf.search_top *= 2u;
+        hipLaunchKernelGGL(tile_collect_kernel<1024>, dim3((uint32_t)tiles_total), dim3(1024), 0, stream, (const uint64_t *)kin, kout, gf, plan, lists,
+                           VL.list_stride, 0u, kDeepSmallCap - kDeepBinMax);
+        SGR_CHECK_LAUNCH("tile_collect_kernel");
+        const uint32_t gbig = std::max(1u, (uint32_t)std::min<uint64_t>(R / (kDeepSmallCap - kDeepBinMax) + 1, 256u));
+        const uint32_t gsmall = std::max(1u, (uint32_t)std::min<uint64_t>(std::min<uint64_t>(tiles_total, R / 64 + 1), 768u));
+        hipLaunchKernelGGL((deep_tile_kernel<1024, kDeepBigCap, 4096>), dim3(gbig), dim3(1024), 0, stream, kout, vout, kin, vin, &plan->count[6],
+                           lists + (size_t)6 * VL.list_stride, (const uint2 *)ranges, sorted_keys ? 1 : 0, plan, lists, VL.list_stride, no_gf);
+        hipLaunchKernelGGL((deep_tile_kernel<512, kDeepSmallCap, 1024>), dim3(gsmall), dim3(512), 0, stream, kout, vout, kin, vin, &plan->count[7],
+                           lists + (size_t)7 * VL.list_stride, (const uint2 *)ranges, sorted_keys ? 1 : 0, plan, lists, VL.list_stride, no_gf);
+        SGR_CHECK_LAUNCH("deep_tile_kernel");
+        auto work = [&](int cls) { TileWork w = {lists + (size_t)cls * VL.list_stride, &plan->ticket[cls], &plan->count[cls]}; return w; };
+        TileWork4 tw4;
+        for (int c = 0; c < 6; c++) tw4.w[c] = work(c);
+        hipLaunchKernelGGL(tile_sort_regs_kernel<16>, dim3(std::min<uint32_t>((uint32_t)tiles_total, 64u) + (fwd_order ? 1u : 0u)), dim3(1024), 0, stream, (const uint2 *)ranges, kout, vout,
+                           kin, vin, tw4, 4, 0, sorted_keys ? 1 : 0, fwd_order, (uint32_t)tiles_total);
+        SGR_CHECK_LAUNCH("tile_sort_regs_kernel");
+        if (fwd_order && order_kind_out) *order_kind_out = 2;
+        }
+        if (result_in_b_host) *result_in_b_host = (kin == keys_b) ? 1 : 0;
+        return 0;
+    }
     if (mode == 4) {
         char *ws = (char *)workspace;
         VsegPlan *plan = (VsegPlan *)(ws + VL.plan);

@@ -4,7 +4,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks_$c -o x -- pytho
 python3 - "$@" <<PY
 import csv, glob, sys
 f = glob.glob("/tmp/ks_$c/**/*kernel_stats.csv", recursive=True)[0]
-pats = sys.argv[1:] or ["preprocess", "duplicate", "deep_tile", "tile_sort", "render", "clamped", "scan", "vseg", "radix", "fill", "copy"]
+pats = sys.argv[1:] or ["preprocess", "duplicate", "collect", "deep_tile", "tile_sort", "render", "clamped", "scan", "vseg", "radix", "fill", "copy"]
 for r in sorted(csv.DictReader(open(f)), key=lambda r: -float(r["TotalDurationNs"])):
     if any(p in r["Name"] for p in pats): print("%-70s calls %5s avg %8.1f us" % (r["Name"][:70], r["Calls"], float(r["AverageNs"]) / 1e3))
 PY
