@@ -602,20 +602,28 @@ def main(args):
     L.sgr_prof_configure(0)
 
     # ---- workload counters (from the run's own buffers)
-    Rn = S_visits = 0
+    Rn = S_visits = R_visited = 0
     if n_local:
         with torch.no_grad():
             dbg = R.forward_debug(subj["means3D"], subj["opacity"], colors_precomp=subj["rgb"], cov3D_precomp=subj["cov3D"],
                                   settings=st._replace(max_rendered=0))
             Rn = int(dbg["num_rendered"])
             S_visits = int(dbg["n_contrib"].to(torch.int64).sum().item())
-            del dbg
+            # tile instances the BACKWARD can visit: per tile, the list entries up to the last contributor of any of its pixels (the walk of a
+            # tile ends there; at C5 -- deep lists behind an opaque front -- that is a third of num_rendered).  SURVEY 8d prices B1 at 88 B per
+            # tile instance: per VISITED instance, or a table prints counter traffic below the algorithmic bytes
+            nc = dbg["n_contrib"].reshape(-1, H, W).to(torch.int64)
+            Ty_, Tx_ = (H + 15) // 16, (W + 15) // 16
+            ncp = torch.zeros(nc.shape[0], Ty_ * 16, Tx_ * 16, dtype=torch.int64, device=nc.device)
+            ncp[:, :H, :W] = nc
+            R_visited = int(ncp.reshape(-1, Ty_, 16, Tx_, 16).amax(dim=(2, 4)).sum().item())
+            del dbg, nc, ncp
     ms_per_step = elapsed / steps * 1e3
     views_per_s = n_total_views / (ms_per_step * 1e-3)
     tiles = ((W + 15) // 16) * ((H + 15) // 16)
     dom_ms, dom_n = dom.get(dominant, (0.0, 0))
     dom_avg_ms = dom_ms / max(dom_n, 1)
-    abytes = algorithmic_bytes(dominant, P * n_local, Rn, H * W * n_local, tiles * n_local, gt_mask is not None)
+    abytes = algorithmic_bytes(dominant, P * n_local, R_visited if dominant == 6 else Rn, H * W * n_local, tiles * n_local, gt_mask is not None)     # (B1: per instance within the backward's reach)
     # the fused single-view step (one or two views through the C++ node, SIGMAN_FUSED_STEP != 0): no loss launch -- the compositing kernel also
     # reads the target (12 B per pixel, + 4 B of mask) and writes dL/dcolor (12 B); the colour it would have re-read (12 B) never leaves the chip
     fused_step = bool(bwd and breakdown and "clamped_l1" not in breakdown and "render_bwd" in breakdown)
@@ -627,7 +635,7 @@ def main(args):
     # HBM traffic of the dominant kernel from the committed rocprofv3 PMC summary of this same command (separate --pmc passes,
     # gfx950 FETCH_SIZE correction applied as MI355X_MICROARCH.md prescribes); null when no summary matches this workload
     traffic, traffic_src = None, None
-    for rnd in ("r05", "r04", "r03", "r02"):               # the newest committed summary for this config
+    for rnd in ("r06", "r05", "r04", "r03", "r02"):               # the newest committed summary for this config
         try:
             path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_{args.config}.json")
             pmc = json.load(open(path))
@@ -650,7 +658,7 @@ def main(args):
                    "count_wait": (lazy_counts if lazy_counts else "own") + (" (the library default is \"own\": variants.count_wait_own_ms_per_step is the same step timed with it)" if lazy_counts else " (the library default)"),
                    "views_per_step_total": n_total_views, "view_slots_this_gpu": n_local,
                    "parallelism": (f"view-parallel x{world} ({backend}), exchange={'none (forward only)' if not bwd else args.exchange}" if dist_on else "single GPU"),
-                   "fused_step": fused_step, "ranks_seen": world, "num_rendered_per_gpu": Rn, "gaussian_pixel_visits_per_gpu": S_visits,
+                   "fused_step": fused_step, "ranks_seen": world, "num_rendered_per_gpu": Rn, "tile_instances_within_reach_of_the_backward_per_gpu": R_visited, "gaussian_pixel_visits_per_gpu": S_visits,
                    "binning_buffers": "exact (D2H read of num_rendered per step)" if args.exact_sync else (f"pre-sized, max_rendered={st.max_rendered} (sync-free)" if st else "-"),
                    "count_check": "exact read" if args.exact_sync else (f"every step, by a later forward of the thread at the latest (set_count_wait {lazy_counts}: the host may run ahead of the GPU by that many steps + 1; once more behind the timed region)" if lazy_counts else "every step, by its own backward")},
         "gaussian_pixel_ops_per_s_per_gpu": round(S_visits / (ms_per_step * 1e-3), 1),

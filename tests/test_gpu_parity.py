@@ -528,7 +528,7 @@ def kernel_sources_sha16():
     import hashlib
     csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "sigman_release_amd", "csrc")
     h = hashlib.sha256()
-    for f in sorted(glob.glob(os.path.join(csrc, "*.hip")) + [os.path.join(csrc, "common.h")]):
+    for f in sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h"))):
         h.update(os.path.basename(f).encode() + b"\0" + open(f, "rb").read())
     return h.hexdigest()[:16]
 

@@ -5,7 +5,7 @@ set -e
 cd "$(dirname "$0")/../sigman_release_amd/csrc"
 src=$1; shift
 extra=""
-case $src in preprocess.hip) extra="-ffp-contract=off";; render.hip) extra="-fno-slp-vectorize";; binning.hip) extra="-fno-honor-nans";; esac
+case $src in preprocess.hip) extra="-ffp-contract=off";; render.hip) extra="-fno-slp-vectorize";; tile_sort.hip) extra="-fno-honor-nans";; esac
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics $extra "$@" -Rpass-analysis=kernel-resource-usage -c $src -o /dev/null 2>&1 |
   python3 -c "
 import sys,re

@@ -3,6 +3,7 @@
 //   tools/micro/bts [tools/micro/tile_hist_c3.txt ...]      (files: "<tile length> <count>" lines, e.g. from tools/tile_hist.py)
 #define SGR_DEEP_TIMING 1
 #include "../../sigman_release_amd/csrc/binning.hip"
+#include "../../sigman_release_amd/csrc/tile_sort.hip"
 #include "../../sigman_release_amd/csrc/api.hip"
 #include <string.h>
 #include <vector>

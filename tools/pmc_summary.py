@@ -11,7 +11,7 @@ GROUPS = [  # (bench kernel id name, regex over rocprof kernel names)
     # (F1 + F2 are ONE row since round 5: SURVEY 8d's 8 B per Gaussian of the scan are the tile counts, which never leave preprocess_fwd's workgroups --
     # scan_block_sums only scans one sum per workgroup, a row of its own priced it at more than the memory peak)
     ("preprocess_fwd+scan", r"(preprocess_fwd_kernel|scan_block_sums_kernel)"), ("duplicate_keys", r"duplicate_keys_kernel"),
-    ("radix_sort(all passes)", r"(wide_|radix_|vseg_|tile_sort|deep_tile)"), ("tile_ranges", r"tile_ranges_kernel"),
+    ("radix_sort(all passes)", r"(wide_|radix_|vseg_|tile_sort|deep_tile|tile_collect)"), ("tile_ranges", r"tile_ranges_kernel"),
     ("render_fwd", r"(render_fwd|fwd_prepare)"), ("render_bwd", r"render_bwd"), ("preprocess_bwd", r"preprocess_bwd(_lanes)?_kernel"),
     ("clamped_l1", r"clamped_l1_kernel"),
 ]
@@ -46,8 +46,11 @@ def main():
     bwd = "fwd+bwd" in c["workload"]
     HW, tiles = size * size * slots, ((size + 15) // 16) ** 2 * slots
     nq = P * slots
+    # B1's 88 B per tile instance are per instance the backward can VISIT (list entries up to the tile's last contributor: bench.py); the whole
+    # list only where the line does not carry the count (lines of rounds 1-5)
+    Rv = c.get("tile_instances_within_reach_of_the_backward_per_gpu", Rn)
     alg = {"preprocess_fwd+scan": 84 * nq, "duplicate_keys": 20 * nq + 12 * Rn, "radix_sort(all passes)": 24 * Rn,
-           "tile_ranges": 8 * Rn + 8 * tiles, "render_fwd": 44 * Rn + 24 * HW, "render_bwd": 88 * Rn + 28 * HW, "preprocess_bwd": 108 * nq,
+           "tile_ranges": 8 * Rn + 8 * tiles, "render_fwd": 44 * Rn + 24 * HW, "render_bwd": 88 * Rv + 28 * HW, "preprocess_bwd": 108 * nq,
            "clamped_l1": (40 if "masked" in c["workload"] else 36) * HW}
     if c.get("fused_step"):
         # the fused single-view step: no loss launch -- the compositing kernel also reads the target (+ mask) and writes dL/dcolor (bench.py)
@@ -68,7 +71,7 @@ def main():
     for k in sorted(set(fetch) | set(write)):
         f, w = statistics.median(fetch.get(k, [0.0])), statistics.median(write.get(k, [0.0]))
         us, n = stats.get(k, (0.0, 0))
-        fwd_chain = bool(re.search(r"(preprocess_fwd|scan_block|duplicate|wide_|radix_|vseg_|tile_sort|tile_ranges|fwd_prepare)", k))
+        fwd_chain = bool(re.search(r"(preprocess_fwd|scan_block|duplicate|wide_|radix_|vseg_|tile_sort|tile_collect|deep_tile|tile_ranges|fwd_prepare)", k))
         per_step = max(1, round(n / n_fwd)) if fwd_chain else 1                # launches of this kernel per forward (radix passes: several)
         out["per_kernel"][k] = {"fetch_size_kb": round(f, 1), "write_size_kb": round(w, 1), "hbm_bytes_corrected": int((2 * f + w) * 1024),
                                 "avg_us": round(us, 2), "launches_per_step": per_step}
