@@ -45,7 +45,7 @@ four steps later and once more behind the region; SIGMAN_COUNT_WAIT=own times th
 gt_masks multiplies prediction and target; mask = ground-truth alpha > 0.5) unless `--no-mask`.
 `roofline` is for the dominant kernel, timed with HIP events recorded by the library on the launch stream inside the
 timed region; `roofline.traffic` comes from the committed rocprofv3 PMC summary of this same command
-(profiles/r05_pmc_<config>.json, else the newest older one; null when there is none for the workload).  `cpu_baseline` is the CPU oracle
+(profiles/r06_pmc_<config>.json, else the newest older one; null when there is none for the workload).  `cpu_baseline` is the CPU oracle
 (oracle/gsplat_ref.c, OpenMP) on a bounded sample of the same inputs, rank 0 at N=1 only.
 """
 from __future__ import annotations
@@ -675,13 +675,14 @@ def main(args):
     # they really approach -- plain wave64 VALU instructions issued per second against the rate measured on this part with
     # tools/micro/valu_rate.hip (8.55e11/s) -- from the committed SQ-counter summary of this same command (tools/pmc_sq.sh), if there is one
     try:
-        sq = json.load(open(os.path.join(ROOT, "profiles", f"r05_sq_{args.config}.json")))
+        sq_path = next(q for q in (os.path.join(ROOT, "profiles", f"{r}_sq_{args.config}.json") for r in ("r06", "r05", "r04", "r03")) if os.path.exists(q))
+        sq = json.load(open(sq_path))
         kname = KERNELS.get(dominant, "")
         ent = next((v for k, v in sq["kernels"].items() if k.startswith(kname) and "SQ_INSTS_VALU" in v and v.get("avg_us")), None)
         if ent:
             rate = ent["SQ_INSTS_VALU"] / (ent["avg_us"] * 1e-6)
             out["roofline_valu_issue"] = {"bound": "valu_issue", "kernel": kname, "achieved": round(rate / 1e9, 1), "peak": 855.0, "unit": "G wave-instr/s",
-                                          "frac": round(rate / 8.55e11, 4), "source": f"profiles/r05_sq_{args.config}.json (SQ_INSTS_VALU / kernel duration of that run)"}
+                                          "frac": round(rate / 8.55e11, 4), "source": f"profiles/{os.path.basename(sq_path)} (SQ_INSTS_VALU / kernel duration of that run)"}
     except Exception:      # noqa: BLE001
         pass
     out["config"]["host_threads"] = pin_report

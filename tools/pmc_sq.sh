@@ -1,4 +1,4 @@
-# SQ counters of the compositing kernels inside a bench config (separate rocprofv3 --pmc passes next to --kernel-trace only) -> gpurun_out/sq_<config>/r05_sq_<config>.json
+# SQ counters of the compositing kernels inside a bench config (separate rocprofv3 --pmc passes next to --kernel-trace only) -> gpurun_out/sq_<config>/r06_sq_<config>.json
 #   usage: pmc_sq.sh <config> <kernel name substring> [more substrings...]
 export TMPDIR=/tmp
 c=$1; shift
@@ -33,6 +33,6 @@ for r in csv.DictReader(open(ks[0])):
         if pat in r["Name"] and "avg_us" not in out["kernels"].get(pat, {}): out["kernels"].setdefault(pat, {})["avg_us"] = float(r["AverageNs"]) / 1e3
 try: out["bench"] = {k: json.load(open(O + "/bench.json"))[k] for k in ("ms_per_step", "kernel_ms_per_step")}
 except Exception: pass
-json.dump(out, open(O + "/r05_sq_%s.json" % c, "w"), indent=1)
+json.dump(out, open(O + "/r06_sq_%s.json" % c, "w"), indent=1)
 print(json.dumps(out, indent=1))
 PY

@@ -67,12 +67,15 @@ def main():
     except Exception:
         pass
     calls = {k: v[1] for k, v in stats.items()}
-    n_fwd = max(calls.get("duplicate_keys_kernel", 1), 1)                      # forwards in the profiled run (timed steps + probe / gt renders)
+    # forwards in the profiled run (timed steps + probe / gt renders): launches of the emission kernel (all instantiations)
+    n_fwd = max(sum(v for k, v in calls.items() if k.startswith("duplicate_keys_kernel")), 1)
     for k in sorted(set(fetch) | set(write)):
         f, w = statistics.median(fetch.get(k, [0.0])), statistics.median(write.get(k, [0.0]))
         us, n = stats.get(k, (0.0, 0))
         fwd_chain = bool(re.search(r"(preprocess_fwd|scan_block|duplicate|wide_|radix_|vseg_|tile_sort|tile_collect|deep_tile|tile_ranges|fwd_prepare)", k))
         per_step = max(1, round(n / n_fwd)) if fwd_chain else 1                # launches of this kernel per forward (radix passes: several)
+        if k.startswith("duplicate_keys_kernel") or k.startswith("scan_block"):
+            per_step = 1 if n >= n_fwd / 2 else 0                              # (an instantiation only the untimed exact-mode probes use: not part of a step)
         out["per_kernel"][k] = {"fetch_size_kb": round(f, 1), "write_size_kb": round(w, 1), "hbm_bytes_corrected": int((2 * f + w) * 1024),
                                 "avg_us": round(us, 2), "launches_per_step": per_step}
         if dram:
@@ -94,6 +97,8 @@ def main():
             continue
         tot = sum(out["per_kernel"][k]["hbm_bytes_corrected"] * out["per_kernel"][k]["launches_per_step"] for k in ks)
         us = sum(out["per_kernel"][k]["avg_us"] * out["per_kernel"][k]["launches_per_step"] for k in ks)
+        if us <= 0:
+            continue
         out["kernels"][g] = {"members": ks, "hbm_bytes_corrected": tot, "us": round(us, 2), "algorithmic_bytes": alg.get(g)}
         if dram:
             out["kernels"][g]["ea_dram_bytes"] = sum(out["per_kernel"][k].get("ea_dram_bytes", 0) * out["per_kernel"][k]["launches_per_step"] for k in ks)
