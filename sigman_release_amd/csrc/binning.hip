@@ -700,12 +700,7 @@ __global__ __launch_bounds__(NT) void tile_collect_kernel(const uint64_t *__rest
     __shared__ uint32_t s_pre[NT], s_cur[NT], s_wave[NW], s_wave2[NW];
     const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6, i = blockIdx.x;
     uint32_t tile;
-    {   // (the dispatch order of deep_tile_kernel<.., FB>: image columns from the centre outwards, rotated rows -- see there)
-        const uint32_t tpv = gf.tx * gf.ty, vw = i / tpv, r = i - vw * tpv;
-        const uint32_t ci = r / gf.ty, ri = r - ci * gf.ty, mid = gf.tx >> 1;
-        const uint32_t tcol = (ci & 1u) ? mid - 1u - (ci >> 1) : mid + (ci >> 1);
-        tile = vw * tpv + ((ri + 5u * ci) % gf.ty) * gf.tx + tcol;
-    }
+    tile = sgr_tile_of_workgroup(i, gf.tx, gf.ty);
     if ((uint32_t)__builtin_amdgcn_readfirstlane((int)gf.occ[tile]) == 0u) { if (t == 0) gf.ranges[tile] = make_uint2(0u, 0u); return; }
     uint32_t a = 0u, e = 0u, bs = 0u;
     if (t < gf.nblk) { const uint32_t *r = gf.rows + (size_t)t * kRunRow + tile; a = r[0]; e = r[1]; bs = gf.base[t]; }
@@ -738,21 +733,25 @@ __global__ __launch_bounds__(NT) void tile_collect_kernel(const uint64_t *__rest
         }
     }
     __syncthreads();
-    // the copy: one thread per composite, which finds its piece by binary search over the piece prefixes (four composites per trip: their
-    // searches and loads overlap).  (Piece by piece -- a wave per piece, contiguous loads and stores, no search -- was SLOWER: 42 against 31 us
-    // at C5; a piece holds ~30 composites, half a wave's lanes idle and twice the load instructions.)
+    // the copy: one thread per composite, which finds its piece by binary search over the piece prefixes -- eight composites per trip, their
+    // searches in lock-step (eight independent LDS reads per level) and their loads in flight together.  (Piece by piece -- a wave per piece,
+    // contiguous loads and stores, no search -- was SLOWER: 42 against 31 us at C5; a piece holds ~30 composites, half a wave's lanes idle and
+    // twice the load instructions.)
     uint64_t *out = dst + x0;
-    for (uint32_t j0 = t; j0 < n; j0 += 4u * NT) {
-        uint64_t v[4];
+    constexpr uint32_t GK = 8;
+    for (uint32_t j0 = t; j0 < n; j0 += GK * NT) {
+        uint32_t j[GK], lo[GK];
+        uint64_t v[GK];
 #pragma unroll
-        for (uint32_t u = 0; u < 4; u++) {
-            const uint32_t j = min(j0 + u * NT, n - 1u);
-            uint32_t lo = 0u;
-            for (uint32_t step = gf.search_top; step > 0u; step >>= 1) if (s_pre[lo + step] <= j) lo += step;
-            v[u] = runs[s_cur[lo] + (j - s_pre[lo])];
+        for (uint32_t u = 0; u < GK; u++) { j[u] = min(j0 + u * NT, n - 1u); lo[u] = 0u; }
+        for (uint32_t step = gf.search_top; step > 0u; step >>= 1) {
+#pragma unroll
+            for (uint32_t u = 0; u < GK; u++) if (s_pre[lo[u] + step] <= j[u]) lo[u] += step;
         }
 #pragma unroll
-        for (uint32_t u = 0; u < 4; u++) if (j0 + u * NT < n) out[j0 + u * NT] = v[u];
+        for (uint32_t u = 0; u < GK; u++) v[u] = runs[s_cur[lo[u]] + (j[u] - s_pre[lo[u]])];
+#pragma unroll
+        for (uint32_t u = 0; u < GK; u++) if (j0 + u * NT < n) out[j0 + u * NT] = v[u];
     }
 }
 
@@ -822,6 +821,8 @@ extern "C" int sgr_set_sort_deep(int mode) {
     const int m = mode & 0xFF, cap = (mode >> 8) & 0xFF;
     g_deep_mode = (m >= 0 && m <= 2) ? m : 0;
     g_deep_max_windows = (cap >= 1 && cap <= (int)kDeepMaxWindows) ? (uint32_t)cap : kDeepMaxWindows;
+    const int col = (mode >> 16) & 0xF;                       // bits 16..19 (tests): SIGMAN_SORT_COLLECT's value + 1; 0 = the environment's
+    g_collect_mode = (col >= 1 && col <= 2) ? col - 1 : sgr_env_knob("SIGMAN_SORT_COLLECT", 0, 1, 1);
     return 0;
 }
 

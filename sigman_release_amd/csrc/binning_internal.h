@@ -13,6 +13,7 @@ constexpr int kItemsSmall = 4, kItemsLarge = 16;
 // the LDS distribution sort of long tile lists (deep_tile_kernel): a fine bin holds at most kDeepBinMax composites; LDS composites per
 // workgroup of the big (15 360-composite) / small (4 096-composite) instantiation; worklist entry = tile id | window << 26
 constexpr uint32_t kDeepBinMax = 128, kDeepBigCap = 15360, kDeepSmallCap = 4096, kDeepTileMask = 0x03FFFFFFu;
+constexpr uint32_t kDeepTiny = 256;               // single-view path: tiles of <= this many entries are ranked by all-pairs counting
 constexpr uint32_t kDeepMaxWindows = 64;           // 6-bit window field
 constexpr int kRunThreads = 1024;                  // threads of an emission workgroup on the single-view path (duplicate_keys_kernel<true, ..>)
 constexpr int kTileBins = 2048;                    // most tiles of a launch that takes the single-view path (one or two 512^2 views)
@@ -39,6 +40,29 @@ struct GatherFront {
     uint32_t max_windows;               // a tile of more windows is sorted whole by the stable radix passes (<= 64; tests lower it)
     SgrBgJob bg;                        // bg.enabled: the workgroup of an EMPTY tile writes the tile's background (the compositing kernel then never
 };                                      //   looks at empty tiles)
+
+// Workgroup id -> tile of the single-view path's per-tile launches (deep_tile_kernel<.., FB>, tile_collect_kernel).  Three things decide it:
+//  * workgroup ids go round the XCDs, and a tile's workgroup reads its columns of the run matrix -- 128-byte lines of 32 neighbouring tiles, one
+//    image row of a 512^2 view: with image row r handled by XCD r % 8 an XCD pulls only ITS eighth of the matrix over the fabric (C5's collect
+//    launch: 977 rows, 8.1 MB -- every XCD fetching all of it was 8-10 us at the head of every workgroup, 5 us now; C2: 2.2 -> 1.8 us);
+//  * inside an XCD ids go round the shader engines, which place workgroups IN ORDER: an engine whose next tile finds no free CU holds up
+//    everything behind it.  The XCD's image rows are therefore rotated from column to column (an engine's tiles lie on a diagonal) and
+//  * the columns are visited from the image centre outwards: the workgroups that do not fit the chip at once are a centred subject's empty margin.
+// (tiles per image column not a multiple of 8: the same without the XCD part -- columns centre-out, rows rotated by 5 per column.)
+__device__ __forceinline__ uint32_t sgr_tile_of_workgroup(uint32_t i, uint32_t tx, uint32_t ty) {
+    const uint32_t tpv = tx * ty, vw = i / tpv, r = i - vw * tpv, mid = tx >> 1;
+    uint32_t ci, row;
+    if ((ty & 7u) == 0u) {
+        const uint32_t k = r & 7u, l = r >> 3, nr = ty >> 3;       // XCD, index within the XCD, image rows per XCD
+        ci = l / nr;
+        row = k + 8u * ((l - ci * nr + ci) % nr);
+    } else {
+        ci = r / ty;
+        row = (r - ci * ty + 5u * ci) % ty;
+    }
+    const uint32_t col = (ci & 1u) ? mid - 1u - (ci >> 1) : mid + (ci >> 1);
+    return vw * tpv + row * tx + col;
+}
 
 struct TileWork { const uint32_t *list; uint32_t *ticket; const uint32_t *count; };
 struct TileWork4 { TileWork w[6]; };        // [m], m = 0..4: tiles with <= 1024 << m entries; [5]: longer ones (global-memory fallback)

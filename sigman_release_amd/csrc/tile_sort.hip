@@ -570,24 +570,14 @@ __global__ __launch_bounds__(NT, (FB && NT == 512) ? 4 : 1) void deep_tile_kerne
         uint32_t tile, w0;
         uint2 range;
         uint64_t c[RI];
+        uint32_t rest_lo = 0xFFFFFFFFu, rest_hi = 0u;                           // FB: depth range of the composites beyond the registers
         const uint64_t *seg;                                                    // the tile's composites in one piece (FB: only for tiles beyond one window)
         if constexpr (FB) {
             // ---- my columns of the run matrix: piece of run b = [rows[b][tile], rows[b][tile + 1]); sum_b (rows[b][tile] - base[b]) instances
             // sit in tiles before mine
             // workgroup i <-> tile i.  An empty tile's workgroup (three of four at a humanoid view) leaves after one load: its range, its background
             w0 = 0u;
-            // Workgroup ids go round the XCDs and, inside an XCD, round its shader engines: with 32 tiles per image row, id mod 32 -- one image
-            // COLUMN -- would meet in one engine, and a humanoid's centre columns hold more occupied tiles (24) than an engine has slots for these
-            // workgroups (16): the last ones started when the first had finished, 14 us late.  Ids walk down the image columns instead, every
-            // column rotated by 5 rows more than the one before, so an engine's tiles lie on a diagonal.
-            // And the columns are visited from the image centre outwards (the workgroups that do not fit the chip at once -- the second half of
-            // the ids -- are the image's outer columns: a centred subject's tiles all start at t = 0).
-            {
-                const uint32_t tpv = gf.tx * gf.ty, vw = i / tpv, r = i - vw * tpv;
-                const uint32_t ci = r / gf.ty, ri = r - ci * gf.ty, mid = gf.tx >> 1;
-                const uint32_t tcol = (ci & 1u) ? mid - 1u - (ci >> 1) : mid + (ci >> 1);
-                tile = vw * tpv + ((ri + 5u * ci) % gf.ty) * gf.tx + tcol;
-            }
+            tile = sgr_tile_of_workgroup(i, gf.tx, gf.ty);                        // (XCD-local columns, engines on diagonals, centre first: binning_internal.h)
             if (SGR_UNIFORM(gf.occ[tile]) == 0u) {
                 if (t == 0) gf.ranges[tile] = make_uint2(0u, 0u);
                 if (gf.bg.enabled && t < 256u) sgr_bg_fill_tile(gf.bg, tile);
@@ -611,8 +601,8 @@ __global__ __launch_bounds__(NT, (FB && NT == 512) ? 4 : 1) void deep_tile_kerne
             uint32_t pre = 0u, n_all = 0u, first = 0u;
 #pragma unroll
             for (uint32_t w = 0; w < NW; w++) { const uint32_t x = s_wave[w]; if (w < wave) pre += x; n_all += x; first += s_wave2[w]; }
-            if (t < 512u) { s_pre[t] = pre + inc - cnt; s_cur[t] = a; }          // piece prefix / piece start (runs beyond nblk: prefix = n, never chosen)
-            static_assert(NT >= 512, "one run per thread");
+            s_pre[t] = pre + inc - cnt; s_cur[t] = a;                            // piece prefix / piece start (runs beyond nblk: prefix = n, never chosen)
+            static_assert(NT >= 512 && NT <= NBF, "one run per thread (<= NT emission runs); the piece tables live in s_pre / s_cur");
             const uint32_t n_t = SGR_UNIFORM(n_all), first_t = SGR_UNIFORM(first);
             range = make_uint2(first_t, first_t + n_t);
             if (t == 0) {
@@ -628,28 +618,65 @@ __global__ __launch_bounds__(NT, (FB && NT == 512) ? 4 : 1) void deep_tile_kerne
 #ifdef SGR_DEEP_TIMING
             if (t == 0 && blockIdx.x < 1024u) sgr_deep_dbg[blockIdx.x * 16 + 15] = n_t;
 #endif
-            // composite j of the tile: in the piece of the last run whose prefix is <= j
-            auto gather = [&](uint32_t j) -> uint64_t {
-                uint32_t lo = 0u;
-                for (uint32_t step = gf.search_top; step > 0u; step >>= 1) if (s_pre[lo + step] <= j) lo += step;
+            // composite j of the tile: in the piece of the last run whose prefix is <= j.  K composites at a time, their binary searches in
+            // lock-step (GK independent LDS reads per level instead of GK x levels dependent LDS round trips)
+            constexpr int GK = 8;
+            static_assert(RI % GK == 0, "register composites are gathered GK at a time");
+            auto gather_k = [&](const uint32_t (&j)[GK], uint64_t (&out)[GK]) {
+                uint32_t lo[GK];
+#pragma unroll
+                for (int k = 0; k < GK; k++) lo[k] = 0u;
+                for (uint32_t step = gf.search_top; step > 0u; step >>= 1) {
+#pragma unroll
+                    for (int k = 0; k < GK; k++) if (s_pre[lo[k] + step] <= j[k]) lo[k] += step;
+                }
+#pragma unroll
+                for (int k = 0; k < GK; k++) {
 #ifdef SGR_DEBUG_BOUNDS
-                if (s_cur[lo] + (j - s_pre[lo]) >= gf.cap_dbg) { printf("gather oob tile %u j %u lo %u pre %u cur %u n %u nblk %u\n", tile, j, lo, s_pre[lo], s_cur[lo], n_t, gf.nblk); return 0; }
+                    if (s_cur[lo[k]] + (j[k] - s_pre[lo[k]]) >= gf.cap_dbg) { printf("gather oob tile %u j %u lo %u pre %u cur %u n %u nblk %u\n", tile, j[k], lo[k], s_pre[lo[k]], s_cur[lo[k]], n_t, gf.nblk); out[k] = 0; continue; }
 #endif
-                return comp[s_cur[lo] + (j - s_pre[lo])];
+                    out[k] = comp[s_cur[lo[k]] + (j[k] - s_pre[lo[k]])];
+                }
             };
             const uint32_t last_j = n_t - 1u;
-            if (n_t <= WIN) {
 #pragma unroll
-                for (uint32_t it = 0; it < RI; it++) c[it] = gather(min(it * NT + t, last_j));
+            for (uint32_t it0 = 0; it0 < RI; it0 += GK) {
+                if (it0 == 0u || it0 * NT < n_t) {                               // (uniform)
+                    uint32_t j[GK];
+                    uint64_t v[GK];
+#pragma unroll
+                    for (int k = 0; k < GK; k++) j[k] = min((it0 + k) * NT + t, last_j);
+                    gather_k(j, v);
+#pragma unroll
+                    for (int k = 0; k < GK; k++) c[it0 + k] = v[k];
+                } else {
+                    // registers wholly beyond the list: any entry of the list will do (they only meet the range's min / max; every other use
+                    // checks the index)
+#pragma unroll
+                    for (int k = 0; k < GK; k++) c[it0 + k] = c[0];
+                }
+            }
+            if (n_t <= WIN) {
                 seg = nullptr;                                                   // (n <= WIN <= REG: nothing below reads it)
             } else {
+                // a tile beyond one window: the composites beyond the registers are re-read by every pass -- they go to the tile's stretch of the
+                // scratch buffer (their depth range is taken on the way: one pass over them less; GK at a time: one at a time a long tile spent 1.7 us per trip here)
                 uint64_t *sk = gf.scratch_k + range.x;
-                for (uint32_t j = t; j < n_t; j += NT) sk[j] = gather(j);
-                __threadfence_block();
-                __syncthreads();
-                seg = sk;
+                for (uint32_t j0 = REG + t; j0 < n_t; j0 += (uint32_t)GK * NT) {
+                    uint32_t j[GK];
+                    uint64_t v[GK];
 #pragma unroll
-                for (uint32_t it = 0; it < RI; it++) c[it] = seg[min(it * NT + t, last_j)];
+                    for (int k = 0; k < GK; k++) j[k] = min(j0 + (uint32_t)k * NT, last_j);
+                    gather_k(j, v);
+#pragma unroll
+                    for (uint32_t u = 0; u < (uint32_t)GK; u++) {
+                        const uint32_t z = (uint32_t)(v[u] >> 32);
+                        rest_lo = min(rest_lo, z); rest_hi = max(rest_hi, z);       // (an index past the end repeats the last entry)
+                        if (j0 + u * NT < n_t) sk[j0 + u * NT] = v[u];
+                    }
+                }
+                __threadfence_block();
+                seg = sk;
             }
             __syncthreads();                                                    // (s_pre / s_cur change roles below)
             SGR_STAMP(10)
@@ -665,16 +692,34 @@ __global__ __launch_bounds__(NT, (FB && NT == 512) ? 4 : 1) void deep_tile_kerne
         }
         const uint32_t n = range.y - range.x, last = n - 1u;
         // FB: stable LSD passes over the value bits, then the depth bits, through global memory (scratch_k / scratch <-> dst): the whole tile, by
-        // this workgroup alone.  The composites must sit in scratch_k: a one-window tile's are still in registers only
+        // this workgroup alone.  The composites must sit in scratch_k: the first REG of them are in registers only
         auto sort_here = [&]() {
-            if (!seg) {
 #pragma unroll
-                for (uint32_t it = 0; it < RI; it++) if (it * NT + t < n) gf.scratch_k[range.x + it * NT + t] = c[it];
-                __threadfence_block();
-            }
+            for (uint32_t it = 0; it < RI; it++) if (it * NT + t < n) gf.scratch_k[range.x + it * NT + t] = c[it];
+            __threadfence_block();
             __syncthreads();
             sort_one_tile_ool<NT>(range, gf.scratch_k, scratch, dst_keys, dst_vals, (uint32_t *)s_comp, tile);
         };
+        if constexpr (FB) {
+            // tiny tiles (the rim of a subject's silhouette): every composite counts the smaller
+            // ones -- n broadcast reads of LDS -- instead of the distribution sort's passes over its bin tables (6 us whatever the tile holds)
+            if (n <= kDeepTiny) {
+                if (t < n) s_comp[t] = c[0];
+                __syncthreads();
+                if (t < n) {
+                    const uint64_t v = c[0];
+                    uint32_t rank = 0;
+                    for (uint32_t k = 0; k < n; k += 4u) {
+                        const uint64_t x0 = s_comp[k], x1 = s_comp[min(k + 1u, last)], x2 = s_comp[min(k + 2u, last)], x3 = s_comp[min(k + 3u, last)];
+                        rank += (x0 < v ? 1u : 0u) + ((k + 1u < n && x1 < v) ? 1u : 0u) + ((k + 2u < n && x2 < v) ? 1u : 0u) + ((k + 3u < n && x3 < v) ? 1u : 0u);
+                    }
+                    if (keep_keys) dst_keys[range.x + rank] = ((uint64_t)tile << 32) | (v >> 32);
+                    dst_vals[range.x + rank] = (uint32_t)v;
+                }
+                SGR_STAMP(7)
+                continue;
+            }
+        }
         if constexpr (FB) { if ((n + WIN - 1u) / WIN > gf.max_windows) { sort_here(); continue; } }
         // f(composite) for the composites beyond the registers
         auto for_each_rest = [&](auto f) {
@@ -690,7 +735,8 @@ __global__ __launch_bounds__(NT, (FB && NT == 512) ? 4 : 1) void deep_tile_kerne
         uint32_t lo = 0xFFFFFFFFu, hi = 0u;
 #pragma unroll
         for (uint32_t it = 0; it < RI; it++) { const uint32_t z = (uint32_t)(c[it] >> 32); lo = min(lo, z); hi = max(hi, z); }      // (indices past the end repeat the last entry)
-        for_each_rest([&](uint64_t v) { const uint32_t z = (uint32_t)(v >> 32); lo = min(lo, z); hi = max(hi, z); });
+        if constexpr (FB) { lo = min(lo, rest_lo); hi = max(hi, rest_hi); }
+        else for_each_rest([&](uint64_t v) { const uint32_t z = (uint32_t)(v >> 32); lo = min(lo, z); hi = max(hi, z); });
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) { lo = min(lo, (uint32_t)__shfl_xor((int)lo, off, 64)); hi = max(hi, (uint32_t)__shfl_xor((int)hi, off, 64)); }
         if (lane == 0) { s_wave[wave] = lo; s_wave2[wave] = hi; }

@@ -131,7 +131,8 @@ def test_sgr_bin_direct_all_flavours(n_views, P, size, depth_kind, big_rects):
         # mode): tiles of more than 3968 / 7936 entries are listed ONCE, marked "whole", and sorted on the spot by one workgroup -- the path a
         # tile of more than 64 windows (254 000 entries) takes in production, exercised here at sizes the other flavours are checked at
         # (flavours 0 = onesweep and 2 = LDS-segmented were removed in round 5: the automatic choice could hardly reach them)
-        for mode, deep in ((1, 0), (4, 2), (4, 1), (5, 0), (5, 1 << 8), (5, 2 << 8), (3, 0)):
+        # (4, 1 | 2 << 16): deep mode with the collect launch (the default for one or two views), (4, 1 | 1 << 16): with the five-launch tile pass
+        for mode, deep in ((1, 0), (4, 2), (4, 1), (4, 1 | (2 << 16)), (4, 1 | (1 << 16)), (5, 0), (5, 1 << 8), (5, 2 << 8), (3, 0)):
             radii, rect, boff = t(case["radii"]), t(case["rect"]), t(offs)
             ka, kb = (torch.zeros(R, dtype=torch.int64, device=dev) for _ in range(2))
             va, vb = (torch.zeros(R, dtype=torch.int32, device=dev) for _ in range(2))

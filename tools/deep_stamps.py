@@ -1,5 +1,5 @@
 """Dev tool: phase stamps of the single-view path's per-tile sort (deep_tile_kernel<.., FB>), one forward of C2 / C1.
-usage (GPU box): tools/build_ab.sh stamps binning.hip -DSGR_DEEP_TIMING && SIGMAN_GSPLAT_LIB=$PWD/tools/ab/stamps.so SIGMAN_PY_NODE=1 python tools/deep_stamps.py [c1|c2]"""
+usage (GPU box): tools/build_ab.sh stamps tile_sort.hip -DSGR_DEEP_TIMING && SIGMAN_GSPLAT_LIB=$PWD/tools/ab/stamps.so SIGMAN_PY_NODE=1 python tools/deep_stamps.py [c1|c2|c5]"""
 import ctypes, os, sys
 import numpy as np
 import torch
@@ -11,7 +11,7 @@ cfg = sys.argv[1] if len(sys.argv) > 1 else "c2"
 dev = torch.device("cuda:0")
 c = bench.CONFIGS[cfg]
 P, H = c["P"], c["size"]
-sub, _, _ = bench.build_subject(cfg, P, {"c1": 0, "c2": 1}[cfg], dev, os.environ.get("ORDER", "random"))
+sub, _, _ = bench.build_subject(cfg, P, {"c1": 0, "c2": 1, "c5": 4}[cfg], dev, os.environ.get("ORDER", "random"))
 cv, cvp, cp = cameras.make_cameras([bench.VIEWS[0]])
 t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 st = R.BatchedRasterizationSettings(H, H, cameras.TAN_HALF_FOV, cameras.TAN_HALF_FOV, torch.ones(3, device=dev), 0.5, t(cv), t(cvp), 0, t(cp), 1)
@@ -37,7 +37,7 @@ rows = [(int(s[i, 15]), i) for i in range(1024) if s[i, 9] > 0]
 rows.sort(reverse=True)
 names = {0: "start", 8: "select", 9: "columns", 10: "gather", 1: "range", 2: "coarse", 3: "alloc", 4: "fine", 5: "scan", 6: "place", 7: "rank/out"}
 print("num_rendered", probe["num_rendered"], "workgroups with work:", len(rows), "  units: us since the first start")
-for n, i in rows[:6] + rows[len(rows) // 2: len(rows) // 2 + 3] + rows[-3:]:
+for n, i in rows[:4] + [rows[len(rows) * k // 16] for k in (1, 2, 3, 4, 6, 8, 10, 12)] + rows[-3:]:
     print(f"wg {i:4d} n={n:5d}: " + "  ".join(f"{names[k]} {(s[i, k] - t0) / 100.0:6.2f}" for k in (0, 8, 9, 10, 1, 2, 3, 4, 5, 6, 7) if s[i, k] > 0))
 empt = [i for i in range(1024) if s[i, 0] > 0 and s[i, 9] == 0]
 if empt:
