@@ -182,9 +182,13 @@ __global__ __launch_bounds__(NT) void duplicate_keys_kernel(int P, int Tx, int t
         // clamped to the capacity (sync-free mode): what the row promises is what pass 2 writes.  Tiles with keys are marked occupied.
         {
             constexpr int PER = kTileBins / NT;
-            static_assert(PER == 2, "one uint2 per thread");
-            const uint2 hv = reinterpret_cast<const uint2 *>(s_th)[threadIdx.x];
-            const uint32_t sum = hv.x + hv.y;
+            static_assert(PER >= 2 && PER % 2 == 0, "whole uint2 per thread");
+            uint32_t hv[PER], sum = 0;
+#pragma unroll
+            for (int k = 0; k < PER; k += 2) {
+                const uint2 h2 = reinterpret_cast<const uint2 *>(s_th)[(threadIdx.x * PER + k) / 2];
+                hv[k] = h2.x; hv[k + 1] = h2.y; sum += h2.x + h2.y;
+            }
             uint32_t sc = sum;
 #pragma unroll
             for (int o = 1; o < 64; o <<= 1) {
@@ -196,10 +200,6 @@ __global__ __launch_bounds__(NT) void duplicate_keys_kernel(int P, int Tx, int t
             __syncthreads();
             uint32_t run = sc - sum;
             for (int w = 0; w < wave; w++) run += wave_tot[w];
-            const uint32_t e0 = run, e1 = run + hv.x;
-            reinterpret_cast<uint2 *>(s_th)[threadIdx.x] = make_uint2(e0, e1);
-            if (hv.x) ex.occ[threadIdx.x * 2] = 1u;
-            if (hv.y) ex.occ[threadIdx.x * 2 + 1] = 1u;
             const uint32_t b = blockIdx.y * gridDim.x + blockIdx.x;
             uint32_t *row = ex.run_rows + (size_t)b * kRunRow;
             // (block_base + x <= 2^32 - 16: the count is checked against that)
@@ -209,7 +209,15 @@ __global__ __launch_bounds__(NT) void duplicate_keys_kernel(int P, int Tx, int t
             uint32_t cap_opaque = cap;
             asm volatile("" : "+s"(cap_opaque));
             const uint32_t base_c = block_base < cap_opaque ? block_base : cap_opaque;
-            reinterpret_cast<uint2 *>(row)[threadIdx.x] = make_uint2(base_c + e0, base_c + e1);
+#pragma unroll
+            for (int k = 0; k < PER; k += 2) {
+                const uint32_t e0 = run, e1 = run + hv[k];
+                run = e1 + hv[k + 1];
+                reinterpret_cast<uint2 *>(s_th)[(threadIdx.x * PER + k) / 2] = make_uint2(e0, e1);
+                if (hv[k]) ex.occ[threadIdx.x * PER + k] = 1u;
+                if (hv[k + 1]) ex.occ[threadIdx.x * PER + k + 1] = 1u;
+                reinterpret_cast<uint2 *>(row)[(threadIdx.x * PER + k) / 2] = make_uint2(base_c + e0, base_c + e1);
+            }
             if (threadIdx.x == 0) {
                 reinterpret_cast<uint2 *>(row)[kTileBins / 2] = make_uint2(base_c + total, base_c + total);
                 ex.run_base[b] = base_c;
@@ -900,7 +908,10 @@ int sgr_bin_ex(const SgrProblem *pb, const int32_t *radii, uint32_t *rect,
     bool split = want_deep;
     if (split && VL.end > workspace_bytes) { split = false; VL = vseg_layout(R, tiles_total, (uint32_t)pb->n_views, tpv, false); }
     const bool vseg_ok = tpv <= (uint32_t)kVsegMaxBins && pb->n_views <= kVsegMaxViews && VL.end <= workspace_bytes;
-    const uint32_t nbx_e = (uint32_t)(nbx + kRunThreads / kThreads - 1) / (uint32_t)(kRunThreads / kThreads);     // emission workgroups per view
+    // (launches of few Gaussians -- C1: 10 000 large splats -- emit with 256-thread workgroups: ten 1024-thread ones leave 246 CUs idle while
+    // each walks 30 000 keys through one CU's LDS)
+    const int run_nt = ((int64_t)pb->P * pb->n_views <= 32768) ? kThreads : kRunThreads;
+    const uint32_t nbx_e = (uint32_t)(nbx + run_nt / kThreads - 1) / (uint32_t)(run_nt / kThreads);     // emission workgroups per view
     const uint32_t nblk_e = nbx_e * (uint32_t)pb->n_views;
     const RunsLayout RL = runs_layout(R, nblk_e);
     const bool runs_ok = tiles_total <= (uint64_t)kTileBins && small && nblk_e <= 512u && RL.end <= workspace_bytes;
@@ -934,7 +945,9 @@ int sgr_bin_ex(const SgrProblem *pb, const int32_t *radii, uint32_t *rect,
     ex.zero_small = (mode == 5 && fwd_order) ? fwd_order : nullptr; ex.zero_small_n = 48u;       // the work order's class counters
     if (collect) { ex.zero_small = (uint32_t *)((char *)workspace + RC.end + VL.plan); ex.zero_small_n = (uint32_t)(sizeof(VsegPlan) / 4); }   // the worklist counters and tickets
     if (self_scan && !num_rendered_dev) { sgr_set_error("sgr_bin: self-scan needs the device counter"); return 1; }
-    if (runs) hipLaunchKernelGGL((duplicate_keys_kernel<true, kRunThreads>), dim3(nbx_e, pb->n_views), dim3(kRunThreads), 0, stream, pb->P, Tx, Tx * Ty, nbx,
+    if (runs && run_nt == kRunThreads) hipLaunchKernelGGL((duplicate_keys_kernel<true, kRunThreads>), dim3(nbx_e, pb->n_views), dim3(kRunThreads), 0, stream, pb->P, Tx, Tx * Ty, nbx,
+                                 radii, (uint4 *)rect, block_offsets, n, collect ? kin : kout, (uint32_t *)nullptr, ex);
+    else if (runs) hipLaunchKernelGGL((duplicate_keys_kernel<true, kThreads>), dim3(nbx_e, pb->n_views), dim3(kThreads), 0, stream, pb->P, Tx, Tx * Ty, nbx,
                                  radii, (uint4 *)rect, block_offsets, n, collect ? kin : kout, (uint32_t *)nullptr, ex);
     else hipLaunchKernelGGL((duplicate_keys_kernel<false, kThreads>), dim3(nbx, pb->n_views), dim3(kThreads), 0, stream, pb->P, Tx, Tx * Ty, nbx,
                             radii, (uint4 *)rect, block_offsets, n, keys_a, vals_a, ex);

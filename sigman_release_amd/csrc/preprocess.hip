@@ -726,12 +726,16 @@ __device__ __forceinline__ void bwd_finish(const SgrProblem &pb, size_t sp, cons
     float *__restrict__ dL_dcolors, float *__restrict__ dL_dsh, float *__restrict__ dL_dcov3D, float *__restrict__ dL_dscales,      \
     float *__restrict__ dL_drot
 
-template <bool SH>
+// GPW = Gaussians per WAVE: 64, or 16 for launches of few Gaussians (C1: 10 000 splats of up to 7 x 7 tiles are 157 full waves on 1 024 SIMDs,
+// each walking ~15 rounds of the wave-wide gather one after the other; with 16 Gaussians on the first 16 lanes of a wave -- all 64 lanes
+// still gather -- it is 625 waves of ~4 rounds).  The additions per Gaussian are the same in the same order: bit-identical gradients.
+template <bool SH, int GPW = 64>
 __global__ __launch_bounds__(kPreThreads) void preprocess_bwd_kernel(SGR_BWD_ARGS) {
     __shared__ __attribute__((aligned(16))) float gather_lds[kPreThreads / 64][gather_lds_floats(128)];
     const int subj = blockIdx.y;
-    const int i_raw = blockIdx.x * kPreThreads + threadIdx.x;
-    const bool live = i_raw < pb.P;                                  // (no early exit: the gather of a large splat needs every lane of its wave)
+    const int i_raw = GPW == 64 ? blockIdx.x * kPreThreads + threadIdx.x
+                                : (blockIdx.x * (kPreThreads / 64) + (threadIdx.x >> 6)) * GPW + (threadIdx.x & 63);
+    const bool live = i_raw < pb.P && (GPW == 64 || (int)(threadIdx.x & 63) < GPW);     // (no early exit: the gather of a large splat needs every lane of its wave)
     const int i = live ? i_raw : pb.P - 1;
     const size_t sp = (size_t)subj * pb.P + i;
     const float fx = (float)pb.W / (2.0f * pb.tanfovx), fy = (float)pb.H / (2.0f * pb.tanfovy);
@@ -885,9 +889,10 @@ extern "C" int sgr_preprocess_forward(const SgrProblem *pb, float *rec, int32_t 
 }
 
 // 0 = automatic (lanes over views on the colors_precomp path when views_per_subject is a power of two in 2..256), 1 = always the
-// one-thread-per-Gaussian kernel (A/B, and the bit-identity test of the two kernels)
+// one-thread-per-Gaussian kernel (A/B, and the bit-identity test of the kernels)
+// (tests: 2 / 3 = the one-thread-per-Gaussian kernel with 64 / 16 Gaussians per wave whatever the launch holds)
 static std::atomic<int> g_bwd_view_loop{0};     // read by the backward, i.e. on the autograd thread: process-wide, but an atomic
-extern "C" int sgr_set_backward_gather(int mode) { g_bwd_view_loop.store(mode == 1 ? 1 : 0); return 0; }
+extern "C" int sgr_set_backward_gather(int mode) { g_bwd_view_loop.store((mode >= 1 && mode <= 3) ? mode : 0); return 0; }
 
 // n_inst: number of tile instances part / flags were sized for (the gather never reads beyond it)
 int sgr_preprocess_backward_ex(const SgrProblem *pb, const int32_t *radii, const uint8_t *clamped,
@@ -913,9 +918,17 @@ int sgr_preprocess_backward_ex(const SgrProblem *pb, const int32_t *radii, const
                            radii, clamped, (const uint4 *)rect, (const float4 *)part, flags,
                            (uint32_t)(n_inst > 0xFFFFFFFFull ? 0xFFFFFFFFull : n_inst), part_scale, dL_dmeans3D, dL_dmeans2D, dL_dopacity, dL_dcolors, dL_dsh, dL_dcov3D,
                            dL_dscales, dL_drotations);
-    } else
+    } else {
+        // few Gaussians: 16 per wave (four times the waves, a quarter of the gather rounds each)
+        const int loop_mode = g_bwd_view_loop.load();
+        const bool sparse = loop_mode == 3 || (loop_mode != 2 && (int64_t)pb->P * (pb->n_views / pb->views_per_subject) <= 32768);
+        if (sparse)
+            hipLaunchKernelGGL((preprocess_bwd_kernel<false, 16>), dim3((pb->P + 16 * (kPreThreads / 64) - 1) / (16 * (kPreThreads / 64)), grid.y), dim3(kPreThreads), 0, stream, *pb, radii, clamped,
+                               (const uint4 *)rect, (const float4 *)part, flags, (uint32_t)(n_inst > 0xFFFFFFFFull ? 0xFFFFFFFFull : n_inst), part_scale, dL_dmeans3D, dL_dmeans2D, dL_dopacity, dL_dcolors, dL_dsh, dL_dcov3D, dL_dscales, dL_drotations);
+        else
         hipLaunchKernelGGL(preprocess_bwd_kernel<false>, grid, dim3(kPreThreads), 0, stream, *pb, radii, clamped,
                            (const uint4 *)rect, (const float4 *)part, flags, (uint32_t)(n_inst > 0xFFFFFFFFull ? 0xFFFFFFFFull : n_inst), part_scale, dL_dmeans3D, dL_dmeans2D, dL_dopacity, dL_dcolors, dL_dsh, dL_dcov3D, dL_dscales, dL_drotations);
+    }
     SGR_CHECK_LAUNCH("preprocess_bwd_kernel");
     }
     return 0;
