@@ -128,8 +128,10 @@ def view_parallel_step(packed: torch.Tensor, view_ids: Sequence[int], render_los
         if mine:
             # The loss all-reduce below is meant to travel while the backward runs.  The fused single-view step (rasterize_l1_loss_batched on one or
             # two views: the forward call already queues the compositing backward, csrc/render.hip FusedL1) would leave it only the gather to hide
-            # behind (12 of 45 us at C2) for the 2.5 us the fused step saves: with live collectives this rank's forward runs unfused.
-            with _fused_step(not _collectives(world)):
+            # behind (12 of 45 us at C2) for the 2.5 us the fused step saves: with live collectives this rank's forward runs unfused -- unless the
+            # caller does not wait for the loss here (wait=False): the all-reduce then has the whole next step to hide behind, and the rank keeps
+            # the single-rank launch chain (a weak-scaling run compares exactly these two)
+            with _fused_step(not _collectives(world) or not wait):
                 loss, extra_out, extra_grad = _split(render_loss(*leaves, mine))
             loss_val = loss.detach().reshape(1).clone()
         else:
