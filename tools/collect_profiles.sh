@@ -1,7 +1,7 @@
 # copy the evidence of gpu_final.sh from gpurun_out/ into profiles/ (tracked)    usage: collect_profiles.sh <gpu_final tag> <round prefix e.g. r03> [bench prefix e.g. r03a]
 set -e
 T=$1; RND=$2; PFX=${3:-$2}; H=$(git rev-parse --short HEAD)
-for c in c2 c3 c4 c5; do P=gpurun_out/prof_$c; [ -f $P/pmc_$c.json ] || continue
+for c in c1 c2 c3 c4 c5; do P=gpurun_out/prof_$c; [ -f $P/pmc_$c.json ] || continue
 python3 - <<PY
 import json
 d=json.load(open("$P/pmc_$c.json")); d["commit"]="$H"; json.dump(d, open("profiles/${RND}_pmc_$c.json","w"), indent=1)
