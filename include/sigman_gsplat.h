@@ -212,9 +212,9 @@ int32_t sgr_preprocess_blocks_per_view(int32_t P);
 int sgr_preprocess_forward(const SgrProblem *pb, float *rec, int32_t *radii, uint32_t *rect, uint8_t *clamped,
                            uint32_t *block_offsets, uint64_t *num_rendered, uint64_t capacity, void *stream);
 
-/* sort flavour: 3 = automatic (default); 5 = one order-free 11-bit pass over the tile id (its histogram rows written by the emission
- * kernel) + an LDS distribution sort of (depth bits, value) composites per tile: one or two 512^2 views (<= 2048 tiles, <= 2^19 instances),
- * else like 3; 4 = view-segmented: the emission is view-major, so ONE order-free counting pass per view over the tile id (<= 4096 tiles per
+/* sort flavour: 3 = automatic (default); 5 = the single-view path (ABI 9): the emission kernel writes tile-ordered runs of (depth bits, value) composites
+ * and a run matrix, ONE launch then gathers and sorts every tile's list in LDS (no tile pass): one or two 512^2 views (<= 2048 tiles, <= 2^19
+ * instances), else like 3; 4 = view-segmented: the emission is view-major, so ONE order-free counting pass per view over the tile id (<= 4096 tiles per
  * view) + a register sort of the composites per tile; 1 = three kernels per 8-bit digit over the whole key (the fallback beyond 4096 tiles
  * per view).  All give bit-identical sorted keys, values and ranges (for finite depths).  Anything else is refused.  (ABI <= 6 also had
  * 0 = onesweep and 2 = LDS-segmented.) */
@@ -223,9 +223,10 @@ int sgr_set_sort_mode(int mode);
  * by one workgroup (per window of 15 232 entries): adaptive depth bins from the tile's own histogram, bin-ordered placement, rank inside
  * the (tiny) bin -- O(n).  mode 0 = automatic (launches with more than 1024 instances per tile on average, e.g. 1M Gaussians at 512^2:
  * they used to fall back to six whole-key radix passes), 1 = whenever flavour 4 runs, 2 = never (flavour 4 only: flavour 5 always uses it).  Same bits out; a tile with massive
- * exact depth ties (> 128 in one bin) takes the generic path.  Bits 8..15 of `mode` (tests; 0 = default 64): behind the single wide tile pass
- * (one or two 512^2 views) a tile with more windows of 3968 entries than this is listed once and sorted whole by one workgroup -- what a tile
- * beyond 64 windows (the window field of a list entry) gets in production. */
+ * exact depth ties (> 128 in one bin) takes the generic path.  Bits 8..15 of `mode` (tests; 0 = default 64): on the single-view path
+ * (flavour 5: one or two 512^2 views) a tile with more windows of 3968 entries than this is sorted whole by its workgroup's stable radix passes --
+ * what a tile beyond 64 windows gets in production.  Bits 16..19 (tests): 1 / 2 = deep launches of one or two views with the five-launch tile pass /
+ * the one collect launch (default), 0 = the environment's SIGMAN_SORT_COLLECT. */
 int sgr_set_sort_deep(int mode);
 
 /* bytes of scratch sgr_bin needs for R tile instances */
@@ -254,7 +255,8 @@ int sgr_set_forward_mode(int mode);
 
 /* B2 + B3 kernel choice: 0 = automatic (default: on the colors_precomp path with views_per_subject in {2, 4, .., 256} one thread per
  * (view, Gaussian), the per-view contributions added in view order by one thread per Gaussian; otherwise one thread per Gaussian that
- * loops over the views), 1 = always the loop.  Both give bit-identical gradients. */
+ * loops over the views), 1 = always the loop.  (Tests: 2 / 3 = the loop with 64 / 16 Gaussians per wave whatever the launch holds; launches of at
+ * most 32 768 Gaussians take the latter on their own.)  All give bit-identical gradients. */
 int sgr_set_backward_gather(int mode);
 
 /* the fused single-view step of sgr_rasterize_forward_l1 when the epilogue allows it and the launch qualifies (environment SIGMAN_FUSED_STEP):

@@ -778,7 +778,7 @@ __global__ __launch_bounds__(kThreads) void tile_ranges_kernel(const uint64_t *_
     if (r == n - 1) ranges[tile].y = n;
 }
 
-// 3 = automatic (default), 5 = single wide tile pass + LDS distribution sort per tile (one or two 512^2 views; else like 3),
+// 3 = automatic (default), 5 = the single-view path: tile-ordered emission runs + one workgroup per tile that gathers and sorts, no tile pass (one or two 512^2 views; else like 3),
 // 4 = view-segmented (per-view tile pass + per-tile depth sort), 1 = three kernels per 8-bit digit over the whole key (the fallback)
 static int sgr_sort_mode_from_env() { const int v = sgr_env_knob("SIGMAN_SORT_MODE", 1, 5, 3); return v == 2 ? 3 : v; }     // (2 was removed in round 5: as refused as by the setter)
 thread_local int sgr_sort_mode = sgr_sort_mode_from_env();        // (per thread; every thread starts from the environment)
@@ -814,14 +814,14 @@ inline int bits_for(uint64_t v) { int b = 0; while ((1ull << b) < v) b++; return
 int sgr_validate_problem(const SgrProblem *pb);
 
 extern "C" int sgr_set_sort_mode(int mode) {
-    if (mode != 1 && mode != 3 && mode != 4 && mode != 5) { sgr_set_error("sgr_set_sort_mode: %d is not a sort flavour (3 automatic, 5 wide pass, 4 view-segmented, 1 whole-key passes)", mode); return 1; }
+    if (mode != 1 && mode != 3 && mode != 4 && mode != 5) { sgr_set_error("sgr_set_sort_mode: %d is not a sort flavour (3 automatic, 5 single-view path, 4 view-segmented, 1 whole-key passes)", mode); return 1; }
     sgr_sort_mode = mode;
     return 0;
 }
 // deep tile lists in the view-segmented flavour (the LDS distribution sort, deep_tile_kernel): 0 = automatic (launches whose tile lists are
 // deep on average), 1 = whenever that flavour runs, 2 = never (deep launches then keep the whole-key passes)
 static thread_local int g_deep_mode = sgr_env_knob("SIGMAN_SORT_DEEP", 0, 2, 0);
-// bits 8..15 of `mode` (tests): the most windows a tile may have behind the single wide tile pass before it is listed once and sorted whole
+// bits 8..15 of `mode` (tests): the most windows a tile may have on the single-view path before it is sorted whole by the stable radix passes
 // (0 = the window field's 64)
 static thread_local uint32_t g_deep_max_windows = kDeepMaxWindows;
 static thread_local int g_collect_mode = sgr_env_knob("SIGMAN_SORT_COLLECT", 0, 1, 1);      // A/B: 0 = deep launches of one or two views keep the five-launch tile pass

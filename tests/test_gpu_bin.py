@@ -83,7 +83,7 @@ def _build(n_views, P, size, seed, depth_kind, big_rects):
 
 @pytest.mark.parametrize("n_views,P,size,depth_kind,big_rects", [
     (1, 3000, 256, "normal", False),
-    (1, 40000, 512, "extreme", True),          # one view, <= 2^19 instances: the wide tile pass + register sort, tiles of every length class
+    (1, 40000, 512, "extreme", True),          # one view, <= 2^19 instances: the single-view path (no tile pass), tiles of every length class
     (3, 5000, 512, "ties", True),
     (4, 60000, 512, "extreme", True),
     (2, 6000, 1024, "extreme", False),
@@ -127,7 +127,7 @@ def test_sgr_bin_direct_all_flavours(n_views, P, size, depth_kind, big_rects):
     try:
         # (flavour, deep mode): 4 with the deep mode forced on = the long tiles (all tiles, for one or two views) go through the LDS
         # distribution sort; tiles with massive exact depth ties must come back through the generic path
-        # (5, 1 << 8) / (5, 2 << 8): flavour 5 with the window cap of the wide pass's distribution sort lowered to 1 / 2 (bits 8..15 of the deep
+        # (5, 1 << 8) / (5, 2 << 8): flavour 5 with the window cap of the single-view path's distribution sort lowered to 1 / 2 (bits 8..15 of the deep
         # mode): tiles of more than 3968 / 7936 entries are listed ONCE, marked "whole", and sorted on the spot by one workgroup -- the path a
         # tile of more than 64 windows (254 000 entries) takes in production, exercised here at sizes the other flavours are checked at
         # (flavours 0 = onesweep and 2 = LDS-segmented were removed in round 5: the automatic choice could hardly reach them)
