@@ -404,24 +404,23 @@ __global__ __launch_bounds__(1024) void vseg_plan_kernel(const unsigned long lon
                                                          VsegPlan *__restrict__ plan, uint32_t *__restrict__ view_key_start,
                                                          uint32_t *__restrict__ view_chunk_start, uint4 *__restrict__ chunk_map,
                                                          const uint32_t *__restrict__ sums /* NULL, or the per-block emission counts [n_views][nbx] of
-                                                         a launch with <= 16 views: the view totals are then summed here (one launch fewer) */,
+                                                         a launch with <= kVsegFoldViews views and <= 65 536 counts: the view totals are then summed here (one launch fewer) */,
                                                          uint32_t nbx) {
     __shared__ uint32_t s_key[kVsegMaxViews + 1], s_chunk[kVsegMaxViews + 1];
-    __shared__ unsigned long long s_wave[16], s_vtot[16];
+    __shared__ unsigned long long s_wave[16], s_vtot[kVsegFoldViews];
     __shared__ uint32_t s_wave32[16];
     const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
     if (sums) {
-        for (uint32_t v = 0; v < n_views; v++) {
+        // one wave per view (views w, w + 16, ..): no workgroup barrier per view
+        for (uint32_t v = wave; v < n_views; v += 16u) {
             const uint32_t *row = sums + (size_t)v * nbx;
             unsigned long long acc = 0;
-            for (uint32_t k = t; k < nbx; k += 1024) acc += row[k];
+            for (uint32_t k = lane; k < nbx; k += 64u) acc += row[k];
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
-            if (lane == 0) s_wave[wave] = acc;
-            __syncthreads();
-            if (t == 0) { unsigned long long a = 0; for (int w = 0; w < 16; w++) a += s_wave[w]; s_vtot[v] = a; }
-            __syncthreads();
+            if (lane == 0) s_vtot[v] = acc;
         }
+        __syncthreads();
     }
     const unsigned long long n_true = n_dev ? min((unsigned long long)cap, (unsigned long long)*n_dev) : (unsigned long long)cap;
     // ---- exclusive scan of the view totals (4 consecutive views per thread), clamped to the keys that exist in the buffers
@@ -996,7 +995,7 @@ int sgr_bin_ex(const SgrProblem *pb, const int32_t *radii, uint32_t *rect,
         const uint32_t nblk = (uint32_t)nbx * (uint32_t)pb->n_views;
         const uint32_t *sums = block_offsets + (nblk + 1);                   // un-scanned per-block emission counts, [view][block]
         { SgrProfScope _ps(SGR_K_SORT, stream);
-        const bool fold_totals = pb->n_views <= 16;
+        const bool fold_totals = pb->n_views <= (int)kVsegFoldViews && (uint64_t)pb->n_views * (uint64_t)nbx <= 65536ull;      // (C3: 64 views x 391 counts)
         if (!fold_totals) hipLaunchKernelGGL(vseg_view_totals_kernel, dim3(pb->n_views), dim3(kThreads), 0, stream, sums, (uint32_t)nbx, totals);
         hipLaunchKernelGGL(vseg_plan_kernel, dim3(1), dim3(1024), 0, stream, totals, (uint32_t)pb->n_views, n, num_rendered_dev, VL.chunk_keys,
                            VL.max_chunks, plan, key_start, chunk_start, chunk_map, fold_totals ? sums : (const uint32_t *)nullptr, (uint32_t)nbx);

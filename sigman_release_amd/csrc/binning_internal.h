@@ -13,6 +13,7 @@ constexpr int kItemsSmall = 4, kItemsLarge = 16;
 // the LDS distribution sort of long tile lists (deep_tile_kernel): a fine bin holds at most kDeepBinMax composites; LDS composites per
 // workgroup of the big (15 360-composite) / small (4 096-composite) instantiation; worklist entry = tile id | window << 26
 constexpr uint32_t kDeepBinMax = 128, kDeepBigCap = 15360, kDeepSmallCap = 4096, kDeepTileMask = 0x03FFFFFFu;
+constexpr uint32_t kVsegFoldViews = 256;          // the plan kernel sums the view totals itself for launches of up to this many views
 constexpr uint32_t kDeepTiny = 256;               // single-view path: tiles of <= this many entries are ranked by all-pairs counting
 constexpr uint32_t kDeepMaxWindows = 64;           // 6-bit window field
 constexpr int kRunThreads = 1024;                  // threads of an emission workgroup on the single-view path (duplicate_keys_kernel<true, ..>)
